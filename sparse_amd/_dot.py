@@ -1,0 +1,344 @@
+"""tensordot / matmul / dot and the `_dot` dispatch table of the hip backend.
+
+Host logic only: axes normalisation, transpose+reshape to 2-D, dispatch on operand
+type/`compressed_axes`/`return_type`, reshape back — the structure of the reference's
+`sparse/numba_backend/_common.py:95-503`, with every jitted kernel replaced by a C-ABI call
+(`_kernels.py`).  Dense operands may be NumPy arrays (copied to HBM, result copied back) or
+torch tensors already on the device (zero-copy, result stays on the device).
+"""
+import builtins
+import warnings
+
+import numpy as np
+import torch
+
+from . import _device as dev
+from . import _kernels as K
+from . import _settings
+from ._sparse_array import SparseArray
+from ._utils import check_zero_fill_value, prod
+
+
+def _is_dense(x):
+    return isinstance(x, (np.ndarray, torch.Tensor))
+
+
+def _is_scipy_sparse(x):
+    return hasattr(x, "tocsr") and type(x).__module__.startswith("scipy.sparse")
+
+
+class _DenseIO:
+    """Remembers whether dense results go back to the host (NumPy in -> NumPy out)."""
+
+    def __init__(self, *operands):
+        self.numpy_out = builtins.any(isinstance(o, np.ndarray) for o in operands) or not builtins.any(
+            isinstance(o, torch.Tensor) for o in operands)
+        self.device = None
+        for o in operands:
+            d = getattr(o, "device", None)
+            if isinstance(d, torch.device) and d.type == "cuda":
+                self.device = d
+                break
+
+    def to_dev(self, x):
+        return dev.to_device(x, self.device)
+
+    def out(self, t):
+        if isinstance(t, torch.Tensor) and self.numpy_out:
+            return dev.to_numpy(t)
+        return t
+
+
+def tensordot_plan(a_shape, b_shape, axes=2):
+    """Pure shape logic of tensordot (reference _common.py:133-198; NumPy's own algorithm).
+
+    Returns (newaxes_a, newshape_a, newaxes_b, newshape_b, olda, oldb) or raises the same
+    ValueErrors as the reference.
+    """
+    try:
+        iter(axes)
+    except TypeError:
+        axes_a = list(range(-axes, 0))
+        axes_b = list(range(axes))
+    else:
+        axes_a, axes_b = axes
+    try:
+        na = len(axes_a)
+        axes_a = list(axes_a)
+    except TypeError:
+        axes_a = [axes_a]
+        na = 1
+    try:
+        nb = len(axes_b)
+        axes_b = list(axes_b)
+    except TypeError:
+        axes_b = [axes_b]
+        nb = 1
+    nda, ndb = len(a_shape), len(b_shape)
+    if nda == 0 or ndb == 0:
+        if axes_a == [] and axes_b == []:
+            return None
+        raise ValueError(f"Input {int(nda != 0)} operand does not have enough dimensions")
+    equal = na == nb
+    if equal:
+        for k in range(na):
+            if a_shape[axes_a[k]] != b_shape[axes_b[k]]:
+                equal = False
+                break
+            if axes_a[k] < 0:
+                axes_a[k] += nda
+            if axes_b[k] < 0:
+                axes_b[k] += ndb
+    if not equal:
+        raise ValueError("shape-mismatch for sum")
+    keep_a = [k for k in range(nda) if k not in axes_a]
+    keep_b = [k for k in range(ndb) if k not in axes_b]
+    n2a = prod(a_shape[ax] for ax in axes_a)
+    n2b = prod(b_shape[ax] for ax in axes_b)
+    return (keep_a + axes_a, (-1, n2a), axes_b + keep_b, (n2b, -1),
+            [a_shape[ax] for ax in keep_a], [b_shape[ax] for ax in keep_b])
+
+
+def _permute_reshape(x, axes, shape):
+    if isinstance(x, torch.Tensor):
+        return x.permute(*axes).reshape(*shape)
+    if isinstance(x, np.ndarray):
+        return x.transpose(axes).reshape(shape)
+    return x.transpose(axes).reshape(shape)
+
+
+def tensordot(a, b, axes=2, *, return_type=None):
+    """Equivalent of `numpy.tensordot` for sparse/dense operand pairs
+    (reference _common.py:95-215)."""
+    from ._coo import COO
+    from ._gcxs import GCXS
+
+    check_zero_fill_value(a, b)
+    if _is_scipy_sparse(a):
+        a = GCXS.from_scipy_sparse(a)
+    if _is_scipy_sparse(b):
+        b = GCXS.from_scipy_sparse(b)
+    plan = tensordot_plan(tuple(a.shape), tuple(b.shape), axes)
+    if plan is None:  # both 0-d contraction-free: scalar product
+        if a.ndim == 0 and isinstance(a, SparseArray):
+            a = a.todense()
+        if b.ndim == 0 and isinstance(b, SparseArray):
+            b = b.todense()
+        return a * b
+    newaxes_a, newshape_a, newaxes_b, newshape_b, olda, oldb = plan
+    if builtins.any(d == 0 for d in (*newshape_a, *newshape_b)):
+        dt = np.result_type(dev.np_dtype(a.dtype) if _is_dense(a) else a.dtype,
+                            dev.np_dtype(b.dtype) if _is_dense(b) else b.dtype)
+        if _is_dense(a) or _is_dense(b):
+            io = _DenseIO(a, b)
+            if io.numpy_out:
+                return np.zeros(tuple(olda + oldb), dtype=dt)
+            return torch.zeros(tuple(olda + oldb), dtype=dev.torch_dtype(dt), device=io.device)
+        sp = a if isinstance(a, SparseArray) else b
+        return COO(np.empty((len(olda) + len(oldb), 0), dtype=np.int64), data=np.empty(0, dtype=dt),
+                   shape=tuple(olda + oldb), device=sp.device)
+    at = _permute_reshape(a, newaxes_a, newshape_a)
+    bt = _permute_reshape(b, newaxes_b, newshape_b)
+    res = _dot(at, bt, return_type)
+    return res.reshape(tuple(olda + oldb))
+
+
+def check_class_nan(x):
+    """True if any stored value / dense element is NaN (reference _common.py:72-92, the full
+    pass `matmul` makes before multiplying, :245)."""
+    from ._coo import COO
+    from ._gcxs import GCXS
+
+    if isinstance(x, (COO, GCXS)):
+        data = x.data
+    elif isinstance(x, np.ndarray):
+        return bool(np.isnan(np.min(x))) if x.size and x.dtype.kind in "fc" else False
+    elif isinstance(x, torch.Tensor):
+        data = x
+    else:
+        raise ValueError(f"Unsupported type {type(x)}")
+    if data.numel() == 0 or not (data.is_floating_point() or data.is_complex()):
+        return False
+    return K.has_nan(data)
+
+
+def matmul(a, b):
+    """Equivalent of `numpy.matmul` (reference _common.py:218-293)."""
+    check_zero_fill_value(a, b)
+    if not hasattr(a, "ndim") or not hasattr(b, "ndim"):
+        raise TypeError(f"Cannot perform dot product on types {type(a)}, {type(b)}")
+    if _settings.NAN_CHECK and (check_class_nan(a) or check_class_nan(b)):
+        warnings.warn("Nan will not be propagated in matrix multiplication", RuntimeWarning, stacklevel=1)
+
+    if b.ndim <= 2:
+        return dot(a, b)
+    if a.ndim <= 2:
+        res = dot(a, b)
+        axes = list(range(res.ndim))
+        axes.insert(-1, axes.pop(0))
+        return res.permute(*axes) if isinstance(res, torch.Tensor) else res.transpose(axes)
+    if a.ndim <= b.ndim and prod(a.shape[:-1]) == 1:
+        res = dot(a.reshape(-1), b)
+        shape = list(res.shape)
+        shape.insert(-1, 1)
+        return res.reshape(shape)
+    if b.ndim <= a.ndim and prod(b.shape[:-2]) == 1:
+        return dot(a, b.reshape(tuple(b.shape[-2:])))
+    if a.ndim < b.ndim:
+        a = a[(None,) * (b.ndim - a.ndim)]
+    if a.ndim > b.ndim:
+        b = b[(None,) * (a.ndim - b.ndim)]
+    for i, j in zip(a.shape[:-2], b.shape[:-2]):
+        if i != 1 and j != 1 and i != j:
+            raise ValueError("shapes of a and b are not broadcastable")
+    from ._batched import matmul_batched
+
+    return matmul_batched(a, b)
+
+
+def dot(a, b):
+    """Equivalent of `numpy.dot` (reference _common.py:296-336)."""
+    check_zero_fill_value(a, b)
+    if not hasattr(a, "ndim") or not hasattr(b, "ndim"):
+        raise TypeError(f"Cannot perform dot product on types {type(a)}, {type(b)}")
+    if a.ndim == 1 and b.ndim == 1:
+        from ._coo import as_coo
+
+        if isinstance(a, SparseArray):
+            a = as_coo(a)
+        if isinstance(b, SparseArray):
+            b = as_coo(b)
+        return (a * b).sum()
+    a_axis, b_axis = -1, -2
+    if b.ndim == 1:
+        b_axis = -1
+    return tensordot(a, b, axes=(a_axis, b_axis))
+
+
+def _return_kind(return_type):
+    """Normalise `return_type` to one of None / "ndarray" / "coo" / "gcxs"."""
+    from ._coo import COO
+    from ._gcxs import GCXS
+
+    if return_type is None:
+        return None
+    if return_type is np.ndarray or return_type is torch.Tensor:
+        return "ndarray"
+    if return_type is COO:
+        return "coo"
+    if return_type is GCXS:
+        return "gcxs"
+    # the reference's own classes (drop-in callers may pass sparse.COO / sparse.GCXS)
+    name = getattr(return_type, "__name__", "")
+    if name in ("COO", "GCXS"):
+        return name.lower()
+    raise TypeError(f"unsupported return_type {return_type!r}")
+
+
+def _dot(a, b, return_type=None):
+    """2-D x 2-D product: the dispatch table of reference `_common.py:339-503` (Appendix B of
+    SURVEY.md), one C-ABI kernel per row of the table."""
+    from ._coo import COO
+    from ._gcxs import GCXS
+
+    rk = _return_kind(return_type)
+    out_shape = (int(a.shape[0]), int(b.shape[1]))
+    io = _DenseIO(a, b)
+
+    if isinstance(a, SparseArray) and isinstance(b, SparseArray) and (
+            isinstance(a, GCXS) or isinstance(b, GCXS)):
+        a = a.asformat("gcxs")
+        b = b.asformat("gcxs", compressed_axes=a.compressed_axes)
+
+    if isinstance(a, GCXS) and isinstance(b, GCXS):
+        if a.nbytes > b.nbytes:
+            b = b.change_compressed_axes(a.compressed_axes)
+        else:
+            a = a.change_compressed_axes(b.compressed_axes)
+        if a.compressed_axes == (0,):  # csr @ csr
+            ca = (0,)
+            data, indices, indptr = K.dot_csr_csr(out_shape, a.data, b.data, a.indices, b.indices,
+                                                  a.indptr, b.indptr)
+        else:  # csc @ csc:  a @ b = (b.T @ a.T).T, the transposes being free
+            ca = (1,)
+            data, indices, indptr = K.dot_csr_csr(out_shape[::-1], b.data, a.data, b.indices, a.indices,
+                                                  b.indptr, a.indptr)
+        out = GCXS((data, indices, indptr), shape=out_shape, compressed_axes=ca, prune=True)
+        if rk == "ndarray":
+            return io.out(out.todense_device())
+        if rk == "coo":
+            return out.tocoo()
+        return out
+
+    if isinstance(a, GCXS) and _is_dense(b):
+        bt = io.to_dev(b) if not (isinstance(b, torch.Tensor) and b.is_cuda) else b
+        bt = dev.to_device(bt, a.device)
+        if a.compressed_axes == (0,):  # csr @ dense
+            if rk in (None, "ndarray"):
+                return io.out(K.dot_csr_ndarray(out_shape, a.data, a.indices, a.indptr, bt,
+                                                exact=_settings.EXACT_MULADD))
+            data, indices, indptr = K.dot_csr_ndarray_sparse(out_shape, a.data, a.indices, a.indptr, bt)
+            out = GCXS((data, indices, indptr), shape=out_shape, compressed_axes=(0,), prune=True)
+            return out.tocoo() if rk == "coo" else out
+        # csc @ dense
+        if rk in (None, "ndarray"):
+            return io.out(K.dot_csc_ndarray(a.shape, tuple(bt.shape), a.data, a.indices, a.indptr, bt,
+                                            exact=_settings.EXACT_MULADD))
+        data, indices, indptr = K.dot_csc_ndarray_sparse(a.shape, tuple(bt.shape), a.data, a.indices,
+                                                         a.indptr, bt)
+        out = GCXS((data, indices, indptr), shape=out_shape, compressed_axes=(1,), prune=True)
+        return out.tocoo() if rk == "coo" else out
+
+    if _is_dense(a) and isinstance(b, GCXS):
+        # dense @ sparse == (sparse.T @ dense.T).T ; sparse.T is free for 2-D GCXS
+        at = dev.to_device(a, b.device).t()
+        bt = b.T
+        if rk in (None, "ndarray"):
+            if bt.compressed_axes == (0,):
+                res = K.dot_csr_ndarray(out_shape[::-1], bt.data, bt.indices, bt.indptr, at,
+                                        exact=_settings.EXACT_MULADD)
+            else:
+                res = K.dot_csc_ndarray(bt.shape, tuple(at.shape), bt.data, bt.indices, bt.indptr, at,
+                                        exact=_settings.EXACT_MULADD)
+            return io.out(res.t())
+        if bt.compressed_axes == (0,):
+            data, indices, indptr = K.dot_csr_ndarray_sparse(out_shape[::-1], bt.data, bt.indices,
+                                                             bt.indptr, at)
+        else:
+            data, indices, indptr = K.dot_csc_ndarray_sparse(bt.shape, tuple(at.shape), bt.data,
+                                                             bt.indices, bt.indptr, at)
+        # the product was formed transposed, so its compressed axis flips back
+        out = GCXS((data, indices, indptr), shape=out_shape, compressed_axes=b.compressed_axes, prune=True)
+        return out.tocoo() if rk == "coo" else out
+
+    if isinstance(a, COO) and isinstance(b, COO):
+        coords, data = K.dot_coo_coo(out_shape, a.coords, b.coords, a.data, b.data)
+        out = COO(coords, data, shape=out_shape, has_duplicates=False, sorted=True, prune=True)
+        if rk == "ndarray":
+            return io.out(out.todense_device())
+        if rk == "gcxs":
+            return out.asformat("gcxs")
+        return out
+
+    if isinstance(a, COO) and _is_dense(b):
+        bt = dev.to_device(b, a.device)
+        if rk in (None, "ndarray"):
+            return io.out(K.dot_coo_ndarray(a.coords, a.data, bt, out_shape, exact=_settings.EXACT_MULADD))
+        coords, data = K.dot_coo_ndarray_sparse(a.coords, a.data, bt, out_shape)
+        out = COO(coords, data, shape=out_shape, has_duplicates=False, sorted=True)
+        return out.asformat("gcxs") if rk == "gcxs" else out
+
+    if _is_dense(a) and isinstance(b, COO):
+        at = dev.to_device(a, b.device)
+        if rk in (None, "ndarray"):
+            return io.out(K.dot_ndarray_coo(at, b.coords, b.data, out_shape, exact=_settings.EXACT_MULADD))
+        coords, data = K.dot_ndarray_coo_sparse(at, b.coords, b.data, out_shape)
+        out = COO(coords, data, shape=out_shape, has_duplicates=False, sorted=True, prune=True)
+        return out.asformat("gcxs") if rk == "gcxs" else out
+
+    if _is_dense(a) and _is_dense(b):
+        if isinstance(a, np.ndarray) and isinstance(b, np.ndarray):
+            return np.dot(a, b)
+        return torch.matmul(dev.to_device(a, io.device), dev.to_device(b, io.device))
+
+    raise TypeError("Unsupported types.")

@@ -1,0 +1,75 @@
+"""ctypes binding of the C-ABI library ``libsparse_amd.so`` (declared in include/sparse_amd.h).
+
+The library is the product's only compute path.  If it is missing this module raises — there
+is no CPU / PyTorch fallback (a silent fallback would void every parity claim).
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libsparse_amd.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sparse_amd.h")
+
+# dtype codes (include/sparse_amd.h)
+F32, F64, I32, I64, BF16 = 0, 1, 2, 3, 4
+EXACT_MULADD = 1
+
+_lib = None
+
+
+class HipBackendError(RuntimeError):
+    """Raised when libsparse_amd.so is missing or a C-ABI entry point reports an error."""
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Fails loudly if the library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipBackendError(
+                f"{LIB_PATH} not found: build it with `python -m sparse_amd.csrc.build` "
+                "(there is deliberately no CPU fallback)")
+        try:
+            _lib = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise HipBackendError(f"cannot load {LIB_PATH}: {e}") from e
+        _declare(_lib)
+    return _lib
+
+
+_C = ctypes
+_i64, _int, _vp, _u32 = _C.c_int64, _C.c_int, _C.c_void_p, _C.c_uint
+
+# name -> (restype, argtypes).  Kept in lock-step with include/sparse_amd.h; the
+# `-m "not gpu"` test suite parses the header and checks both the table and the .so.
+SIGNATURES = {
+    "spamd_version": (_int, []),
+    "spamd_target_arch": (_C.c_char_p, []),
+    "spamd_spmm_csr": (_int, [_int, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _u32, _vp]),
+}
+
+
+def _declare(handle):
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(handle, name)  # AttributeError here == symbol missing: loud by design
+        fn.restype = res
+        fn.argtypes = args
+
+
+def header_symbols(path=HEADER_PATH):
+    """Names of every function declared in include/sparse_amd.h."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(spamd_[a-z0-9_]+)\s*\(", text)))
+
+
+def check(code, what):
+    if code != 0:
+        kind = {-1: "invalid argument", -2: "unsupported dtype", -3: "workspace too small"}.get(
+            code, f"hipError_t {code}" if code > 0 else f"error {code}")
+        raise HipBackendError(f"{what} failed: {kind}")
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args), name)

@@ -1,0 +1,326 @@
+"""`GCXS`: N-D compressed sparse array whose (data, indices, indptr) live in HBM.
+
+Same constructor, attributes and methods as the reference container
+(sparse/numba_backend/_compressed/compressed.py:80-187): the array is the CSR of the 2-D
+matrix (prod(compressed dims) x prod(other dims)) obtained after ordering the axes as
+`compressed_axes + remaining`.  The three arrays are torch tensors on the HIP device.
+"""
+import copy as _copy
+from collections.abc import Iterable
+
+import numpy as np
+import torch
+
+from . import _device as dev
+from ._sparse_array import NDArrayOperatorsMixin, SparseArray
+from ._utils import can_store, check_compressed_axes, normalize_axis, prod, zero_of_dtype
+
+
+def _is_scipy_sparse(x):
+    return hasattr(x, "tocsr") and hasattr(x, "format") and type(x).__module__.startswith("scipy.sparse")
+
+
+class GCXS(SparseArray, NDArrayOperatorsMixin):
+    """Generalised compressed row/column storage on the device.
+
+    Parameters follow the reference (`compressed.py:135-143`): `arg` is a
+    `(data, indices, indptr)` triple (ndarrays or device tensors), a `COO`, another `GCXS`, a
+    dense ndarray, or a SciPy sparse matrix.
+    """
+
+    __array_priority__ = 12
+
+    def __init__(self, arg, shape=None, compressed_axes=None, prune=False, fill_value=None,
+                 idx_dtype=None, device=None):
+        from ._coo import COO
+        from ._convert import coo_to_gcxs_arrays
+
+        if _is_scipy_sparse(arg):
+            arg = GCXS.from_scipy_sparse(arg, device=device)
+        if isinstance(arg, (np.ndarray, torch.Tensor)) and not isinstance(arg, tuple):
+            arg = COO.from_numpy(arg, fill_value=fill_value, device=device)
+            arg, shape, compressed_axes, fill_value = coo_to_gcxs_arrays(arg, compressed_axes)
+        elif isinstance(arg, COO):
+            arg, shape, compressed_axes, fill_value = coo_to_gcxs_arrays(arg, compressed_axes, idx_dtype)
+        elif isinstance(arg, GCXS):
+            if compressed_axes is not None and arg.compressed_axes != compressed_axes:
+                arg = arg.change_compressed_axes(compressed_axes)
+            arg, shape, compressed_axes, fill_value = (
+                (arg.data, arg.indices, arg.indptr), arg.shape, arg.compressed_axes, arg.fill_value)
+
+        if shape is None:
+            raise ValueError("missing `shape` argument")
+        shape = tuple(int(s) for s in (shape if isinstance(shape, Iterable) else (shape,)))
+        check_compressed_axes(len(shape), compressed_axes)
+        if len(shape) == 1:
+            compressed_axes = None
+
+        data, indices, indptr = arg
+        if device is None:
+            device = next((t.device for t in (data, indices, indptr) if isinstance(t, torch.Tensor)), None)
+        if device is None:
+            device = dev.default_device()
+        self.data = dev.to_device(data, device)
+        self.indices = dev.to_device(indices, device)
+        if isinstance(indptr, (list, tuple)) and len(indptr) == 0:
+            indptr = np.empty(0, dtype=dev.np_dtype(self.indices))
+        self.indptr = dev.to_device(indptr, device)
+        if self.indices.dtype not in (torch.int32, torch.int64):
+            self.indices = self.indices.to(torch.int64)
+        if self.indptr.dtype != self.indices.dtype:
+            self.indptr = self.indptr.to(self.indices.dtype)
+        if self.data.dim() != 1:
+            raise ValueError("data must be a scalar or 1-dimensional.")
+
+        self.shape = shape
+        if fill_value is None:
+            fill_value = zero_of_dtype(self.dtype)
+        self._compressed_axes = tuple(int(c) for c in compressed_axes) if isinstance(compressed_axes, Iterable) else None
+        self.fill_value = self.dtype.type(fill_value)
+        if prune:
+            self._prune()
+
+    # ---- construction ------------------------------------------------------------------
+    def copy(self, deep=True):
+        if not deep:
+            return _copy.copy(self)
+        return GCXS((self.data.clone(), self.indices.clone(), self.indptr.clone()), shape=self.shape,
+                    compressed_axes=self.compressed_axes, fill_value=self.fill_value)
+
+    @classmethod
+    def from_numpy(cls, x, compressed_axes=None, fill_value=None, idx_dtype=None, device=None):
+        from ._coo import COO
+
+        coo = COO.from_numpy(x, fill_value=fill_value, idx_dtype=idx_dtype, device=device)
+        return cls.from_coo(coo, compressed_axes, idx_dtype)
+
+    @classmethod
+    def from_coo(cls, x, compressed_axes=None, idx_dtype=None):
+        from ._convert import coo_to_gcxs_arrays
+
+        arg, shape, compressed_axes, fill_value = coo_to_gcxs_arrays(x, compressed_axes, idx_dtype)
+        return cls(arg, shape=shape, compressed_axes=compressed_axes, fill_value=fill_value)
+
+    @classmethod
+    def from_scipy_sparse(cls, x, /, *, fill_value=None, device=None):
+        """CSR/CSC SciPy matrix -> GCXS with compressed_axes (0,)/(1,) (reference compressed.py:210-219)."""
+        is_csc = x.format == "csc"
+        ca = (1,) if is_csc else (0,)
+        if not is_csc:
+            x = x.asformat("csr")
+        if not x.has_canonical_format:
+            x.eliminate_zeros()
+            x.sum_duplicates()
+        return cls((x.data, x.indices, x.indptr), shape=x.shape, compressed_axes=ca,
+                   fill_value=fill_value, device=device)
+
+    # ---- properties ----------------------------------------------------------------------
+    @property
+    def compressed_axes(self):
+        return self._compressed_axes
+
+    @property
+    def nnz(self):
+        return int(self.data.shape[0])
+
+    @property
+    def format(self):
+        return "gcxs"
+
+    @property
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in (self.data, self.indices, self.indptr))
+
+    @property
+    def _axis_order(self):
+        order = list(self.compressed_axes)
+        order.extend(a for a in range(self.ndim) if a not in self.compressed_axes)
+        return order
+
+    @property
+    def _axisptr(self):
+        return len(self.compressed_axes)
+
+    @property
+    def _reordered_shape(self):
+        return tuple(self.shape[i] for i in self._axis_order)
+
+    @property
+    def _compressed_shape(self):
+        rs = self._reordered_shape
+        return (prod(rs[: self._axisptr]), prod(rs[self._axisptr:]))
+
+    @property
+    def T(self):
+        return self.transpose()
+
+    @property
+    def mT(self):
+        if self.ndim < 2:
+            raise ValueError("Cannot compute matrix transpose if `ndim < 2`.")
+        axis = list(range(self.ndim))
+        axis[-1], axis[-2] = axis[-2], axis[-1]
+        return self.transpose(axis)
+
+    def __str__(self):
+        return (f"<GCXS: shape={self.shape}, dtype={self.dtype}, nnz={self.nnz}, fill_value={self.fill_value}, "
+                f"compressed_axes={self.compressed_axes}, device={self.device}>")
+
+    __repr__ = __str__
+
+    # ---- conversions (device kernels live in _convert.py) -----------------------------------
+    def change_compressed_axes(self, new_compressed_axes):
+        """Re-compress along other axes (reference compressed.py:388-423)."""
+        from ._convert import gcxs_relayout
+
+        if new_compressed_axes == self.compressed_axes:
+            return self
+        if self.ndim == 1:
+            raise NotImplementedError("no axes to compress for 1d array")
+        new_compressed_axes = tuple(normalize_axis(a, self.ndim) for a in new_compressed_axes)
+        if new_compressed_axes == self.compressed_axes:
+            return self
+        if len(new_compressed_axes) >= len(self.shape):
+            raise ValueError("cannot compress all axes")
+        if len(set(new_compressed_axes)) != len(new_compressed_axes):
+            raise ValueError("repeated axis in compressed_axes")
+        arg = gcxs_relayout(self, self.shape, tuple(range(self.ndim)), new_compressed_axes)
+        return GCXS(arg, shape=self.shape, compressed_axes=new_compressed_axes, fill_value=self.fill_value)
+
+    def tocoo(self):
+        from ._convert import gcxs_to_coo
+
+        return gcxs_to_coo(self)
+
+    def todense(self):
+        """Dense host ndarray (reference compressed.py:462-482 returns an ndarray)."""
+        from ._convert import gcxs_todense
+
+        return dev.to_numpy(gcxs_todense(self))
+
+    def todense_device(self):
+        """Dense tensor that stays in HBM."""
+        from ._convert import gcxs_todense
+
+        return gcxs_todense(self)
+
+    def asformat(self, format, **kwargs):
+        from ._utils import convert_format
+
+        format = convert_format(format)
+        ca = kwargs.pop("compressed_axes", None)
+        if format == "gcxs":
+            if ca is None or tuple(ca) == self.compressed_axes:
+                return self
+            return self.change_compressed_axes(tuple(ca))
+        if format == "coo":
+            if kwargs or ca is not None:
+                raise TypeError("unexpected keyword arguments for format 'coo'")
+            return self.tocoo()
+        raise NotImplementedError(f"format {format!r} is not available in the hip backend")
+
+    def maybe_densify(self, max_size=1000, min_density=0.25):
+        if self.size <= max_size or self.density >= min_density:
+            return self.todense()
+        raise ValueError("Operation would require converting large sparse array to dense")
+
+    def flatten(self, order="C"):
+        if order not in {"C", None}:
+            raise NotImplementedError("The `order` parameter is not supported.")
+        return self.reshape(-1)
+
+    def reshape(self, shape, order="C", compressed_axes=None):
+        """reference compressed.py:622-682"""
+        from ._convert import gcxs_relayout
+
+        shape = tuple(shape) if isinstance(shape, Iterable) else (shape,)
+        if order not in {"C", None}:
+            raise NotImplementedError("The 'order' parameter is not supported")
+        if any(d == -1 for d in shape):
+            extra = int(self.size / max(1, prod(d for d in shape if d != -1)))
+            shape = tuple(d if d != -1 else extra for d in shape)
+        shape = tuple(int(d) for d in shape)
+        if self.shape == shape:
+            return self
+        if self.size != prod(shape):
+            raise ValueError(f"cannot reshape array of size {self.size} into shape {shape}")
+        if len(shape) == 0:
+            return self.tocoo().reshape(shape).asformat("gcxs")
+        if compressed_axes is None:
+            compressed_axes = self.compressed_axes if len(shape) == self.ndim else (int(np.argmin(shape)),)
+        if self.ndim == 1:
+            return self.tocoo().reshape(shape).asformat("gcxs", compressed_axes=compressed_axes)
+        if len(shape) == 1:
+            return self.tocoo().reshape(shape).asformat("gcxs")
+        check_compressed_axes(len(shape), compressed_axes)
+        arg = gcxs_relayout(self, shape, tuple(range(self.ndim)), tuple(compressed_axes), reshape=True)
+        return GCXS(arg, shape=shape, compressed_axes=tuple(compressed_axes), fill_value=self.fill_value)
+
+    def transpose(self, axes=None, compressed_axes=None):
+        """reference compressed.py:688-741; the 2-D case is metadata-only (:743-768)."""
+        from ._convert import gcxs_relayout
+
+        if axes is None:
+            axes = list(reversed(range(self.ndim)))
+        axes = normalize_axis(tuple(axes), self.ndim)
+        if len(set(axes)) != len(axes):
+            raise ValueError("repeated axis in transpose")
+        if set(axes) != set(range(self.ndim)):
+            raise ValueError("axes don't match array")
+        axes = tuple(axes)
+        if axes == tuple(range(self.ndim)):
+            return self
+        if self.ndim == 2:
+            return self._2d_transpose()
+        shape = tuple(self.shape[ax] for ax in axes)
+        if compressed_axes is None:
+            compressed_axes = (int(np.argmin(shape)),)
+        check_compressed_axes(len(shape), compressed_axes)
+        arg = gcxs_relayout(self, shape, axes, tuple(compressed_axes), transpose=True)
+        return GCXS(arg, shape=shape, compressed_axes=tuple(compressed_axes), fill_value=self.fill_value)
+
+    def _2d_transpose(self):
+        ca = ((self.compressed_axes[0] + 1) % 2,)
+        return GCXS((self.data, self.indices, self.indptr), shape=self.shape[::-1], compressed_axes=ca,
+                    fill_value=self.fill_value)
+
+    def dot(self, other):
+        from ._dot import dot
+
+        return dot(self, other)
+
+    def __matmul__(self, other):
+        from ._dot import matmul
+
+        try:
+            return matmul(self, other)
+        except NotImplementedError:
+            return NotImplemented
+
+    def __rmatmul__(self, other):
+        from ._dot import matmul
+
+        try:
+            return matmul(other, self)
+        except NotImplementedError:
+            return NotImplemented
+
+    def _prune(self):
+        """Drop stored entries bit-equal to the fill value (reference compressed.py:816-848)."""
+        from ._convert import gcxs_prune
+
+        gcxs_prune(self)
+
+    def _make_shallow_copy_of(self, other):
+        self.data, self.indices, self.indptr = other.data, other.indices, other.indptr
+        self.shape = other.shape
+        self._compressed_axes = other.compressed_axes
+        self.fill_value = other.fill_value
+
+    def to_scipy_sparse(self, accept_fv=None):
+        import scipy.sparse
+
+        if self.ndim != 2:
+            raise ValueError("Can only convert a 2-dimensional array to a Scipy sparse matrix.")
+        cls = scipy.sparse.csr_matrix if self.compressed_axes == (0,) else scipy.sparse.csc_matrix
+        return cls((dev.to_numpy(self.data), dev.to_numpy(self.indices), dev.to_numpy(self.indptr)), shape=self.shape)

@@ -1,0 +1,9 @@
+"""Environment flags, read once at import — same names as the reference
+(sparse/numba_backend/_settings.py:5-6)."""
+import os
+
+AUTO_DENSIFY = bool(int(os.environ.get("SPARSE_AUTO_DENSIFY", "0")))
+WARN_ON_TOO_DENSE = bool(int(os.environ.get("SPARSE_WARN_ON_TOO_DENSE", "0")))
+# hip-backend extras
+NAN_CHECK = bool(int(os.environ.get("SPARSE_AMD_NAN_CHECK", "1")))  # matmul's NaN RuntimeWarning pass
+EXACT_MULADD = bool(int(os.environ.get("SPARSE_AMD_EXACT", "0")))  # bit-exact mul+add instead of FMA

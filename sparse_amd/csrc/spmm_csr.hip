@@ -1,0 +1,180 @@
+// A1: CSR x dense -> dense SpMM for gfx950 (replaces `_dot_csr_ndarray`,
+// reference sparse/numba_backend/_common.py:720-755).
+//
+// Mapping ("row-group" kernel): G lanes of a 64-lane wave own one compressed row; each
+// lane owns VEC contiguous output columns per column pass, so a wave-load of a B row is
+// G*VEC*sizeof(T) contiguous bytes (512 B for fp32 N=128 with G=64, VEC=2).  The row's
+// (index, value) pairs are fetched G at a time with one coalesced load and broadcast
+// lane-by-lane (v_readlane for G=64, ds_bpermute otherwise).  Every output element is
+// accumulated by exactly one lane in storage (k-ascending) order -> the summation order is
+// the reference's, and the result is deterministic.  `out` is written exactly once per
+// element (no zero-fill + read-modify-write as in the reference).
+#include "common.h"
+
+namespace spamd {
+
+template <typename T, typename I, int VEC, int G, bool EXACT, int UNROLL>
+__global__ void __launch_bounds__(256)
+spmm_csr_rowgroup_kernel(int64_t M, int64_t N, const T* __restrict__ a_data,
+                         const I* __restrict__ a_idx, const I* __restrict__ a_ptr,
+                         const T* __restrict__ b, int64_t ldb, T* __restrict__ out,
+                         int64_t ldo) {
+  constexpr int RPW = SPAMD_WAVE / G;  // rows per wave
+  using V = Vec<T, VEC>;
+  const int lane = threadIdx.x & (SPAMD_WAVE - 1);
+  const int gl = lane % G;             // lane within the row group
+  const int gbase = lane - gl;         // first lane of my group
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / SPAMD_WAVE) + (threadIdx.x / SPAMD_WAVE);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / SPAMD_WAVE);
+
+  for (int64_t row0 = wave * RPW; row0 < M; row0 += nwaves * RPW) {
+    const int64_t row = row0 + lane / G;
+    const bool row_ok = row < M;
+    const int64_t start = row_ok ? (int64_t)a_ptr[row] : 0;
+    const int64_t end = row_ok ? (int64_t)a_ptr[row + 1] : 0;
+
+    for (int64_t c0 = 0; c0 < N; c0 += (int64_t)G * VEC) {
+      const int64_t col = c0 + (int64_t)gl * VEC;
+      const bool col_ok = col < N;  // N % VEC == 0 is guaranteed by the dispatcher
+      T acc[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] = T(0);
+
+      for (int64_t p = start; p < end; p += G) {
+        const int64_t mine = p + gl;
+        I ci = 0;
+        T vi = T(0);
+        if (mine < end) {
+          ci = a_idx[mine];
+          vi = a_data[mine];
+        }
+        const int cnt = (int)((end - p) < (int64_t)G ? (end - p) : (int64_t)G);
+        int j = 0;
+        for (; j + UNROLL <= cnt; j += UNROLL) {
+          I cj[UNROLL];
+          T vj[UNROLL];
+          V bj[UNROLL];
+#pragma unroll
+          for (int u = 0; u < UNROLL; ++u) {
+            if constexpr (G == SPAMD_WAVE) {
+              cj[u] = wave_bcast(ci, j + u);
+              vj[u] = wave_bcast(vi, j + u);
+            } else {
+              cj[u] = lane_shfl(ci, gbase + j + u);
+              vj[u] = lane_shfl(vi, gbase + j + u);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < UNROLL; ++u) {
+            if (col_ok) bj[u] = *reinterpret_cast<const V*>(b + (int64_t)cj[u] * ldb + col);
+          }
+#pragma unroll
+          for (int u = 0; u < UNROLL; ++u) {
+            if (col_ok) {
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) acc[e] = mul_add<EXACT>(vj[u], bj[u].v[e], acc[e]);
+            }
+          }
+        }
+        for (; j < cnt; ++j) {
+          I cj;
+          T vj;
+          if constexpr (G == SPAMD_WAVE) {
+            cj = wave_bcast(ci, j);
+            vj = wave_bcast(vi, j);
+          } else {
+            cj = lane_shfl(ci, gbase + j);
+            vj = lane_shfl(vi, gbase + j);
+          }
+          if (col_ok) {
+            V bj = *reinterpret_cast<const V*>(b + (int64_t)cj * ldb + col);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] = mul_add<EXACT>(vj, bj.v[e], acc[e]);
+          }
+        }
+      }
+      if (row_ok && col_ok) {
+        V o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o.v[e] = acc[e];
+        *reinterpret_cast<V*>(out + row * ldo + col) = o;
+      }
+    }
+  }
+}
+
+template <typename T, typename I, int VEC, int G, bool EXACT>
+static int launch_rowgroup(int64_t M, int64_t N, const T* a_data, const I* a_idx, const I* a_ptr,
+                           const T* b, int64_t ldb, T* out, int64_t ldo, hipStream_t s) {
+  constexpr int RPW = SPAMD_WAVE / G;
+  constexpr int WPB = 4;  // waves per 256-thread block
+  int64_t blocks = ceil_div(M, (int64_t)RPW * WPB);
+  const int64_t cap = 256 * 8 * 4;  // grid-stride above this many blocks
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL((spmm_csr_rowgroup_kernel<T, I, VEC, G, EXACT, 4>), dim3((unsigned)blocks),
+                     dim3(256), 0, s, M, N, a_data, a_idx, a_ptr, b, ldb, out, ldo);
+  return launch_status();
+}
+
+template <typename T, typename I, bool EXACT>
+static int dispatch_shape(int64_t M, int64_t N, const T* a_data, const I* a_idx, const I* a_ptr,
+                          const T* b, int64_t ldb, T* out, int64_t ldo, hipStream_t s) {
+  // widest vector (<= 16 B) that the shapes/alignments allow
+  int vmax = 16 / (int)sizeof(T);
+  if (vmax > 4) vmax = 4;
+  auto ok = [&](int v) {
+    return N % v == 0 && ldb % v == 0 && ldo % v == 0 &&
+           ((uintptr_t)b % (v * sizeof(T))) == 0 && ((uintptr_t)out % (v * sizeof(T))) == 0;
+  };
+  while (vmax > 1 && !ok(vmax)) vmax >>= 1;
+  // N >= 64: one row per wave, widest vector that still fills all 64 lanes.
+  // N <  64: 16 lanes per row (4 rows per wave), narrowest vector that covers N in one pass.
+  int vec = 1, g = 64;
+  if (N >= 64) {
+    vec = vmax;
+    while (vec > 1 && N / vec < SPAMD_WAVE) vec >>= 1;
+  } else if (N <= 16 * vmax) {
+    g = 16;
+    while (vec < vmax && ceil_div(N, vec) > 16) vec <<= 1;
+  }
+#define SPAMD_CASE(V, GG)                                                                        \
+  if (vec == V && g == GG)                                                                       \
+    return launch_rowgroup<T, I, V, GG, EXACT>(M, N, a_data, a_idx, a_ptr, b, ldb, out, ldo, s);
+  SPAMD_CASE(1, 64)
+  SPAMD_CASE(2, 64)
+  if constexpr (sizeof(T) == 4) { SPAMD_CASE(4, 64) }
+  SPAMD_CASE(1, 16)
+  SPAMD_CASE(2, 16)
+  if constexpr (sizeof(T) == 4) { SPAMD_CASE(4, 16) }
+#undef SPAMD_CASE
+  return SPAMD_EINVAL;
+}
+
+}  // namespace spamd
+
+extern "C" int spamd_spmm_csr(int val_dtype, int idx_dtype, int64_t M, int64_t K, int64_t N,
+                              const void* a_data, const void* a_indices, const void* a_indptr,
+                              const void* b, int64_t ldb, void* out, int64_t ldo, unsigned flags,
+                              void* stream) {
+  using namespace spamd;
+  if (M < 0 || K < 0 || N < 0) return SPAMD_EINVAL;
+  if (M == 0 || N == 0) return 0;
+  if (!a_indptr || !out || ldo < N || (K > 0 && (!b || ldb < N))) return SPAMD_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const bool exact = (flags & SPAMD_EXACT_MULADD) != 0;
+  SPAMD_DISPATCH_VAL(val_dtype, T, {
+    SPAMD_DISPATCH_IDX(idx_dtype, I, {
+      const T* ad = (const T*)a_data;
+      const I* ai = (const I*)a_indices;
+      const I* ap = (const I*)a_indptr;
+      const T* bb = (const T*)b;
+      T* oo = (T*)out;
+      if constexpr (std::is_floating_point<T>::value) {
+        if (exact) return dispatch_shape<T, I, true>(M, N, ad, ai, ap, bb, ldb, oo, ldo, s);
+      }
+      return dispatch_shape<T, I, false>(M, N, ad, ai, ap, bb, ldb, oo, ldo, s);
+    })
+  })
+  return SPAMD_ETYPE;
+}
