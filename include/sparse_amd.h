@@ -66,6 +66,14 @@ int spamd_spmm_csr(int val_dtype, int idx_dtype, int64_t M, int64_t K, int64_t N
                    const void* b, int64_t ldb, void* out, int64_t ldo,
                    unsigned flags, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * A10  NaN scan                    replaces `nan_check` (_common.py:51-69), the pass `matmul`
+ *                                  runs over every operand before multiplying (:245-246).
+ *   *flag (device int32) is set to 1 if any of the n values is NaN, else 0.  `data` must be
+ *   16-byte aligned.  val_dtype: F32 | F64 (I32 | I64 accepted: flag = 0).
+ * ------------------------------------------------------------------------------------- */
+int spamd_has_nan(int val_dtype, int64_t n, const void* data, int* flag, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

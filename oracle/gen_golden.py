@@ -1,0 +1,293 @@
+"""Generate tests/golden/*.npz by RUNNING THE REAL REFERENCE (pydata/sparse numba_backend,
+imported in place from /root/reference under the no-op numba stub, see ref_loader.py).
+
+    python oracle/gen_golden.py            # rewrites every fixture (deterministic seeds)
+
+TEST INFRASTRUCTURE.  Runs only in the build container (the GPU box has no /root/reference);
+the fixtures it writes are committed, travel to the GPU box, and pin both the CPU oracle
+(tests/test_oracle_pin.py) and the HIP kernels (tests/test_*_gpu.py).  The reference ships no
+golden vectors of its own, so these are produced with fixed seeds
+(`sparse.random(..., random_state=<int>)`) plus the literal cases its tests do hold
+(`test_small_values`, tests/test_dot.py:289-300).
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import ref_loader  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def _save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"  {name}.npz  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def _rand_gcxs(sp, shape, density, seed, dtype, idt, ca):
+    x = sp.random(shape, density=density, format="gcxs", compressed_axes=ca, random_state=seed, idx_dtype=idt)
+    if np.dtype(dtype).kind == "f":
+        x = (x - 0.25 * (x != 0)).astype(dtype)  # mixed signs, keeps sparsity pattern
+        x = sp.GCXS(x, compressed_axes=ca, idx_dtype=idt) if not isinstance(x, sp.GCXS) else x
+    else:
+        x = (x * 100).astype(dtype)
+    return x
+
+
+def gen_dot(sp):
+    """A1/A2/A3/A4/A5: every `_dot` kernel, dense and sparse return types."""
+    rng = np.random.default_rng(7)
+    cases = {}
+    k = 0
+    # --- GCXS(csr|csc) @ ndarray, dense out -------------------------------------------------
+    for dtype, idt in ((np.float32, np.int32), (np.float32, np.int64), (np.float64, np.int64), (np.int64, np.int64),
+                       (np.int32, np.int32)):
+        for N in (1, 7, 64, 128, 130):
+            for ca in ((0,), (1,)):
+                M, K = 60, 45
+                a = _rand_gcxs(sp, (M, K), 0.15, 100 + k, dtype, idt, ca)
+                if np.dtype(dtype).kind == "f":
+                    b = (rng.random((K, N)) - 0.5).astype(dtype)
+                    b[:, 0] = 0  # an all-zero dense column
+                else:
+                    b = rng.integers(-9, 9, size=(K, N)).astype(dtype)
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    c = sp.tensordot(a, b, axes=1)
+                assert isinstance(c, np.ndarray)
+                pre = f"gd{k}_"
+                cases[pre + "data"], cases[pre + "indices"], cases[pre + "indptr"] = a.data, a.indices, a.indptr
+                cases[pre + "ca"] = np.array(ca)
+                cases[pre + "shape"] = np.array((M, K))
+                cases[pre + "b"] = b
+                cases[pre + "out"] = c
+                k += 1
+    cases["n_gcxs_dense"] = np.array(k)
+
+    # --- rows: empty rows + one dense row + NaN in A (matmul warns, NaN*0 skipped structurally) ---
+    a = sp.random((40, 300), density=0.02, format="gcxs", compressed_axes=(0,), random_state=5).astype(np.float32)
+    d = a.todense()
+    d[3, :] = 0
+    d[4, :] = 0
+    d[17, :] = np.linspace(-1, 1, 300, dtype=np.float32)
+    d[17, 0] = 1
+    d[20, 5] = np.nan
+    a = sp.GCXS.from_numpy(d, compressed_axes=(0,))
+    b = (rng.random((300, 128)) - 0.5).astype(np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        c = a @ b
+    cases.update(edge_data=a.data, edge_indices=a.indices, edge_indptr=a.indptr, edge_b=b, edge_out=c)
+
+    # --- COO @ ndarray / ndarray @ COO, dense + sparse returns --------------------------------
+    x = sp.random((50, 30), density=0.2, format="coo", random_state=11).astype(np.float64)
+    b = rng.random((30, 9))
+    a2 = rng.random((8, 50))
+    cases.update(coo_coords=x.coords, coo_data=x.data, coo_b=b, coo_out=sp.tensordot(x, b, axes=1),
+                 coo_a2=a2, coo_out2=sp.tensordot(a2, x, axes=1))
+    r = sp.tensordot(x, b, axes=1, return_type=sp.COO)
+    cases.update(coo_sp_coords=r.coords, coo_sp_data=r.data)
+    r = sp.tensordot(a2, x, axes=1, return_type=sp.COO)
+    cases.update(coo_sp2_coords=r.coords, coo_sp2_data=r.data)
+
+    # --- sparse-returning GCXS @ dense (A1s, A2) ---------------------------------------------
+    for tag, ca in (("csr", (0,)), ("csc", (1,))):
+        a = _rand_gcxs(sp, (30, 25), 0.2, 21, np.float64, np.int64, ca)
+        b = rng.random((25, 6))
+        b[:, 2] = 0
+        b[rng.random((25, 6)) < 0.5] = 0
+        r = sp.tensordot(a, b, axes=1, return_type=sp.GCXS)
+        cases.update({f"sp_{tag}_data": a.data, f"sp_{tag}_indices": a.indices, f"sp_{tag}_indptr": a.indptr,
+                      f"sp_{tag}_b": b, f"sp_{tag}_out_dense": r.todense(), f"sp_{tag}_out_nnz": np.array(r.nnz),
+                      f"sp_{tag}_out_ca": np.array(r.compressed_axes)})
+
+    # --- SpGEMM: GCXS @ GCXS (csr and csc), COO @ COO -----------------------------------------
+    for tag, ca in (("csr", (0,)), ("csc", (1,))):
+        a = _rand_gcxs(sp, (40, 35), 0.12, 31, np.float64, np.int64, ca)
+        b = _rand_gcxs(sp, (35, 45), 0.12, 32, np.float64, np.int64, ca)
+        r = a @ b
+        assert isinstance(r, sp.GCXS)
+        rc = r.tocoo()
+        cases.update({f"gg_{tag}_a_data": a.data, f"gg_{tag}_a_indices": a.indices, f"gg_{tag}_a_indptr": a.indptr,
+                      f"gg_{tag}_b_data": b.data, f"gg_{tag}_b_indices": b.indices, f"gg_{tag}_b_indptr": b.indptr,
+                      f"gg_{tag}_out_coords": rc.coords, f"gg_{tag}_out_data": rc.data,
+                      f"gg_{tag}_out_ca": np.array(r.compressed_axes),
+                      f"gg_{tag}_raw_indices": r.indices, f"gg_{tag}_raw_indptr": r.indptr, f"gg_{tag}_raw_data": r.data})
+    x = sp.random((30, 20), density=0.2, random_state=41)
+    y = sp.random((20, 25), density=0.2, random_state=42)
+    r = x @ y
+    cases.update(cc_x_coords=x.coords, cc_x_data=x.data, cc_y_coords=y.coords, cc_y_data=y.data,
+                 cc_out_coords=r.coords, cc_out_data=r.data)
+    # integer SpGEMM must be exact
+    xi = (sp.random((25, 25), density=0.3, random_state=43, format="gcxs", compressed_axes=(0,)) * 10).astype(np.int64)
+    r = (xi @ xi).tocoo()
+    cases.update(ci_data=xi.data, ci_indices=xi.indices, ci_indptr=xi.indptr, ci_out_coords=r.coords, ci_out_data=r.data)
+
+    # --- literal KAT of the reference: test_small_values (tests/test_dot.py:289-300) ----------
+    a = sp.COO.from_numpy(np.array([[3.6e-100, 0.0, 0.0], [0.0, 4.5e-225, 0.0]]))
+    bb = np.array([[1e-120, 0.0], [0.0, 2.0], [1.0, 1.0]])
+    cases.update(small_a=a.todense(), small_b=bb, small_out=sp.dot(a, bb))
+
+    # --- N-D tensordot: 3-D COO x dense, axes=1 (BASELINE config 3, reduced) and GCXS 3-D -----
+    c3 = sp.random((12, 10, 8), density=0.1, random_state=51)
+    dmat = rng.random((8, 6))
+    cases.update(t3_coords=c3.coords, t3_data=c3.data, t3_d=dmat, t3_out=sp.tensordot(c3, dmat, axes=1))
+    g3 = sp.GCXS(c3, compressed_axes=(1,))
+    cases.update(t3g_out=sp.tensordot(g3, dmat, axes=((2,), (0,))))
+    dd = rng.random((10, 12, 5))
+    cases.update(t3_dd=dd, t3_out2=sp.tensordot(c3, dd, axes=((0, 1), (1, 0))))
+    _save("dot", **cases)
+
+
+def gen_convert(sp):
+    """A6 / T1-T3: canonicalisation and format conversion (integer side, bit-exact)."""
+    rng = np.random.default_rng(3)
+    cases = {}
+    shape = (7, 5, 6, 4)
+    nnz = 150
+    coords = np.stack([rng.integers(0, s, nnz) for s in shape])
+    data = rng.integers(-3, 4, nnz).astype(np.float64)  # duplicates + explicit zeros + cancellation
+    x = sp.COO(coords, data, shape=shape)  # sort + sum duplicates (no prune)
+    xp = sp.COO(coords, data, shape=shape, prune=True)
+    cases.update(raw_coords=coords, raw_data=data, shape=np.array(shape), can_coords=x.coords, can_data=x.data,
+                 pruned_coords=xp.coords, pruned_data=xp.data)
+    for i, ca in enumerate([(0,), (1,), (3,), (0, 1), (1, 3), (0, 2, 3)]):
+        g = sp.GCXS(x, compressed_axes=ca)
+        cases.update({f"g{i}_ca": np.array(ca), f"g{i}_data": g.data, f"g{i}_indices": g.indices, f"g{i}_indptr": g.indptr})
+        back = g.tocoo()
+        assert np.array_equal(back.coords, x.coords)
+    g = sp.GCXS(x, compressed_axes=(0,))
+    h = g.change_compressed_axes((2, 3))
+    cases.update(cca_data=h.data, cca_indices=h.indices, cca_indptr=h.indptr)
+    t = g.transpose((2, 0, 3, 1))
+    cases.update(tr_ca=np.array(t.compressed_axes), tr_data=t.data, tr_indices=t.indices, tr_indptr=t.indptr,
+                 tr_shape=np.array(t.shape))
+    r = g.reshape((35, 24))
+    cases.update(rs_ca=np.array(r.compressed_axes), rs_data=r.data, rs_indices=r.indices, rs_indptr=r.indptr)
+    ct = x.transpose((3, 1, 0, 2))
+    cr = x.reshape((35, 24))
+    cases.update(ct_coords=ct.coords, ct_data=ct.data, cr_coords=cr.coords, cr_data=cr.data)
+    # -0.0 survives pruning (Appendix C.1)
+    z = sp.COO(np.array([[0, 1, 2]]), np.array([0.0, -0.0, 1.0]), shape=(4,), prune=True)
+    cases.update(negzero_coords=z.coords, negzero_data=z.data)
+    cases.update(dense=x.todense())
+    _save("convert", **cases)
+
+
+def gen_elemwise(sp):
+    """A7: binary/unary elementwise on same-shape zero-fill COO operands (+ one broadcast and one
+    non-zero-fill case for the general path)."""
+    cases = {}
+    shape = (9, 8, 7)
+    x = sp.random(shape, density=0.2, random_state=61)
+    y = sp.random(shape, density=0.2, random_state=62)
+    x = sp.COO(x.coords, x.data - 0.5, shape=shape)
+    y = sp.COO(y.coords, y.data - 0.5, shape=shape)
+    # force exact cancellation at a few coincident positions
+    both = sp.COO(x.coords[:, :5], -x.data[:5], shape=shape)
+    y = (y + both)
+    y = sp.COO(y.coords, y.data, shape=shape)
+    cases.update(shape=np.array(shape), x_coords=x.coords, x_data=x.data, y_coords=y.coords, y_data=y.data)
+    ops = {"add": np.add, "subtract": np.subtract, "multiply": np.multiply, "maximum": np.maximum,
+           "minimum": np.minimum, "greater": np.greater, "less": np.less, "not_equal": np.not_equal,
+           "greater_equal": np.greater_equal, "equal": np.equal, "divide": np.divide}
+    for name, f in ops.items():
+        with np.errstate(all="ignore"), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            r = f(x, y)
+        cases.update({f"{name}_coords": r.coords, f"{name}_data": r.data, f"{name}_fill": np.asarray(r.fill_value)})
+    for name, f in {"negative": np.negative, "abs": np.abs, "exp": np.exp, "sin": np.sin, "sqrt_abs": None,
+                    "astype_f32": None, "astype_bool": None, "mul_scalar": None, "add_scalar": None}.items():
+        with np.errstate(all="ignore"):
+            if name == "sqrt_abs":
+                r = np.sqrt(np.abs(x))
+            elif name == "astype_f32":
+                r = x.astype(np.float32)
+            elif name == "astype_bool":
+                r = sp.COO(x.coords, np.where(np.arange(x.nnz) % 3 == 0, 0.0, x.data), shape=shape).astype(bool)
+            elif name == "mul_scalar":
+                r = x * 3.0
+            elif name == "add_scalar":
+                r = x + 1.0
+            else:
+                r = f(x)
+        cases.update({f"u_{name}_coords": r.coords, f"u_{name}_data": r.data, f"u_{name}_fill": np.asarray(r.fill_value)})
+    # integer operands
+    xi = sp.COO(x.coords, (x.data * 20).astype(np.int64), shape=shape)
+    yi = sp.COO(y.coords, (y.data * 20).astype(np.int64), shape=shape)
+    for name, f in {"add": np.add, "multiply": np.multiply, "bitwise_and": np.bitwise_and}.items():
+        r = f(xi, yi)
+        cases.update({f"i_{name}_coords": r.coords, f"i_{name}_data": r.data})
+    cases.update(xi_data=xi.data, yi_data=yi.data, xi_coords=xi.coords, yi_coords=yi.coords)
+    # broadcasting (general path): (9,8,7) * (8,1)
+    z = sp.random((8, 1), density=0.6, random_state=63)
+    r = x * z
+    cases.update(bz_coords=z.coords, bz_data=z.data, bmul_coords=r.coords, bmul_data=r.data)
+    # GCXS in -> GCXS out with same compressed axes
+    gx, gy = sp.GCXS(x, compressed_axes=(1,)), sp.GCXS(y, compressed_axes=(1,))
+    r = gx + gy
+    cases.update(gadd_ca=np.array(r.compressed_axes), gadd_data=r.data, gadd_indices=r.indices, gadd_indptr=r.indptr)
+    # sparse (*) dense gather path (SDDMM formulation, A9): s * (a @ b)
+    s = sp.random((20, 30), density=0.1, random_state=64)
+    rng = np.random.default_rng(65)
+    a, b = rng.random((20, 6)), rng.random((6, 30))
+    r = s * (a @ b)
+    cases.update(sd_s_coords=s.coords, sd_s_data=s.data, sd_a=a, sd_b=b, sd_out_coords=r.coords, sd_out_data=r.data)
+    _save("elemwise", **cases)
+
+
+def gen_reduce(sp):
+    """A8: reductions over axis sets, with and without non-zero fill values."""
+    cases = {}
+    shape = (6, 7, 5)
+    x = sp.random(shape, density=0.3, random_state=71)
+    x = sp.COO(x.coords, x.data - 0.4, shape=shape)
+    cases.update(shape=np.array(shape), x_coords=x.coords, x_data=x.data)
+    k = 0
+    for name in ("sum", "prod", "max", "min", "mean", "var", "std", "any", "all"):
+        for axis in (None, 0, 1, 2, (0, 1), (1, 2), (0, 2), (0, 1, 2)):
+            for keepdims in (False, True):
+                with np.errstate(all="ignore"), warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    r = getattr(x, name)(axis=axis, keepdims=keepdims)
+                d = r.todense() if hasattr(r, "todense") else np.asarray(r)
+                cases[f"r{k}_name"] = np.array(name)
+                cases[f"r{k}_axis"] = np.array(-99 if axis is None else axis)
+                cases[f"r{k}_keepdims"] = np.array(keepdims)
+                cases[f"r{k}_dense"] = d
+                cases[f"r{k}_nnz"] = np.array(getattr(r, "nnz", -1))
+                cases[f"r{k}_fill"] = np.asarray(getattr(r, "fill_value", 0))
+                k += 1
+    cases["n_reduce"] = np.array(k)
+    # non-zero fill value: (x + 1).sum(axis=1) has fill_value = n_cols (Appendix D5)
+    r = (x + 1).sum(axis=1)
+    cases.update(fv_dense=r.todense(), fv_fill=np.asarray(r.fill_value), fv_nnz=np.array(r.nnz))
+    # GCXS reductions
+    g = sp.GCXS(x, compressed_axes=(1,))
+    for j, axis in enumerate((0, (0, 2), None)):
+        r = g.sum(axis=axis)
+        cases[f"g{j}_dense"] = r.todense()
+    # integer + narrow idx dtype (reference test_reduce_narrow_idx_dtype, tests/test_coo.py:783-799)
+    xi = sp.COO(x.coords.astype(np.uint8), (x.data * 50).astype(np.int32), shape=shape)
+    cases.update(isum=xi.sum(axis=(0, 2)).todense(), imax=xi.max(axis=1).todense())
+    _save("reduce", **cases)
+
+
+def main():
+    sp = ref_loader.load()
+    print("reference:", sp.__file__)
+    gen_dot(sp)
+    gen_convert(sp)
+    gen_elemwise(sp)
+    gen_reduce(sp)
+
+
+if __name__ == "__main__":
+    main()

@@ -53,7 +53,7 @@ def all_gather_rows(b_shard, n_rows, group=None):
     """All-gather a row-sharded dense operand into the full (n_rows x N) matrix on every rank.
 
     Uses one `all_gather_into_tensor` when the shards are equal-sized (the RCCL fast path),
-    otherwise one `all_gather` with per-rank buffers."""
+    otherwise one padded gather followed by a local compaction."""
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
@@ -64,11 +64,16 @@ def all_gather_rows(b_shard, n_rows, group=None):
     if n_rows % world == 0:
         dist.all_gather_into_tensor(out, b_shard.contiguous(), group=group)
         return out
-    parts = []
+    # ragged shards: pad every shard to the largest one (collectives need equal sizes), gather
+    # once, then compact the valid rows into `out`
+    maxrows = -(-n_rows // world)
+    padded = torch.zeros((maxrows, *cols), dtype=b_shard.dtype, device=b_shard.device)
+    padded[: b_shard.shape[0]] = b_shard
+    gathered = torch.empty((world * maxrows, *cols), dtype=b_shard.dtype, device=b_shard.device)
+    dist.all_gather_into_tensor(gathered, padded, group=group)
     for r in range(world):
         lo, hi = row_bounds(n_rows, r, world)
-        parts.append(out[lo:hi])
-    dist.all_gather(parts, b_shard.contiguous(), group=group)
+        out[lo:hi] = gathered[r * maxrows: r * maxrows + (hi - lo)]
     return out
 
 

@@ -46,6 +46,7 @@ _i64, _int, _vp, _u32 = _C.c_int64, _C.c_int, _C.c_void_p, _C.c_uint
 SIGNATURES = {
     "spamd_version": (_int, []),
     "spamd_target_arch": (_C.c_char_p, []),
+    "spamd_has_nan": (_int, [_int, _i64, _vp, _vp, _vp]),
     "spamd_spmm_csr": (_int, [_int, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _u32, _vp]),
 }
 

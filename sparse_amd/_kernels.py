@@ -54,5 +54,14 @@ def dot_csr_ndarray(out_shape, a_data, a_indices, a_indptr, b, *, exact=False, o
 
 
 def has_nan(data):
-    """Any NaN in a float tensor?  (reference `nan_check`, _common.py:51-69)."""
-    raise NotImplementedError
+    """Any NaN in a float tensor?  (reference `nan_check`, _common.py:51-69).  One streaming
+    pass on the device; the 4-byte flag is the only thing copied back."""
+    dev = require_hip(data)
+    if data.numel() == 0 or not data.is_floating_point():
+        return False
+    data = data.contiguous()
+    if data.data_ptr() % 16:
+        data = data.clone()
+    flag = torch.empty(1, dtype=torch.int32, device=dev)
+    _ffi.call("spamd_has_nan", code_of(data.dtype), data.numel(), ptr(data), ptr(flag), stream_ptr(dev))
+    return bool(flag.item())

@@ -28,6 +28,14 @@ __device__ __forceinline__ T wave_bcast(T x, int src) {
   }
 }
 
+// Tell the compiler a value is wave-uniform (moves it to SGPRs; enables scalar branches).
+__device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ int64_t uniform(int64_t x) {
+  int lo = __builtin_amdgcn_readfirstlane((int)(x & 0xffffffffll));
+  int hi = __builtin_amdgcn_readfirstlane((int)(x >> 32));
+  return ((int64_t)hi << 32) | (unsigned int)lo;
+}
+
 // Per-lane source (ds_bpermute): any lane may read any other lane.
 template <typename T>
 __device__ __forceinline__ T lane_shfl(T x, int src) {
@@ -56,6 +64,69 @@ template <typename T, int N>
 struct alignas(sizeof(T) * N) Vec {
   T v[N];
 };
+
+// Clang extended vectors: what the non-temporal builtins and 8/16-byte loads want.
+template <typename T, int N>
+struct ExtVec {
+  typedef T type __attribute__((ext_vector_type(N)));
+};
+template <typename T>
+struct ExtVec<T, 1> {
+  typedef T type;
+};
+
+// Non-temporal (streaming) vector store / load of N contiguous elements.
+template <typename T, int N>
+__device__ __forceinline__ void nt_store(T* p, const T (&v)[N]) {
+  if constexpr (N == 1) {
+    __builtin_nontemporal_store(v[0], p);
+  } else {
+    typename ExtVec<T, N>::type x;
+#pragma unroll
+    for (int e = 0; e < N; ++e) x[e] = v[e];
+    __builtin_nontemporal_store(x, reinterpret_cast<typename ExtVec<T, N>::type*>(p));
+  }
+}
+
+// Global store that the compiler's s_waitcnt insertion does NOT see (inline asm).
+// Why: on gfx9-family targets loads and stores share vmcnt and LLVM treats a pending store
+// next to pending loads as "may return out of order", turning every later load wait into
+// vmcnt(0) — which would drain a software-pipelined gather at every row end.  Hiding the
+// store is safe for the compiler's load waits: vmcnt(N) with N = number of LATER LOADS still
+// guarantees the awaited load has returned (loads return in order; an outstanding store can
+// only make the wait longer).  The asm reads its data VGPRs at issue; the trailing s_nop covers
+// the >8-byte store-data write-after-read hazard the compiler cannot see.
+template <typename T, int N>
+__device__ __forceinline__ void hidden_nt_store(T* p, const T (&v)[N]) {
+  constexpr int BYTES = sizeof(T) * N;
+  static_assert(BYTES == 4 || BYTES == 8 || BYTES == 16, "4/8/16-byte stores only");
+  if constexpr (BYTES == 4) {
+    unsigned x = __builtin_bit_cast(unsigned, v[0]);
+    asm volatile("global_store_dword %0, %1, off nt" : : "v"(p), "v"(x) : "memory");
+  } else if constexpr (BYTES == 8) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    u2 x;
+    if constexpr (N == 1) {
+      x = __builtin_bit_cast(u2, v[0]);
+    } else {
+      x[0] = __builtin_bit_cast(unsigned, v[0]);
+      x[1] = __builtin_bit_cast(unsigned, v[1]);
+    }
+    asm volatile("global_store_dwordx2 %0, %1, off nt" : : "v"(p), "v"(x) : "memory");
+  } else {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    u4 x;
+    if constexpr (N == 2) {
+      typedef unsigned long long ull;
+      ull a = __builtin_bit_cast(ull, v[0]), b = __builtin_bit_cast(ull, v[1]);
+      x[0] = (unsigned)a; x[1] = (unsigned)(a >> 32); x[2] = (unsigned)b; x[3] = (unsigned)(b >> 32);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = __builtin_bit_cast(unsigned, v[e]);
+    }
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(p), "v"(x) : "memory");
+  }
+}
 
 inline int launch_status() {
   hipError_t e = hipGetLastError();

@@ -1,0 +1,54 @@
+// A10: NaN scan over a value array (replaces `nan_check`, reference
+// sparse/numba_backend/_common.py:51-69, the full pass `matmul` makes before multiplying).
+// HBM-bound streaming read: 16 B per lane per iteration, one atomicOr per wave that saw a NaN.
+#include "common.h"
+
+namespace spamd {
+
+template <typename T>
+__global__ void __launch_bounds__(256) has_nan_kernel(const T* __restrict__ x, int64_t n, int* flag) {
+  constexpr int VEC = 16 / sizeof(T);
+  using V = Vec<T, VEC>;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t nvec = n / VEC;
+  bool bad = false;
+  const V* xv = reinterpret_cast<const V*>(x);
+  for (int64_t i = tid; i < nvec; i += stride) {
+    V v = xv[i];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) bad |= (v.v[e] != v.v[e]);
+  }
+  for (int64_t i = nvec * VEC + tid; i < n; i += stride) bad |= (x[i] != x[i]);
+  if (__any(bad) && (threadIdx.x & (SPAMD_WAVE - 1)) == 0) atomicOr(flag, 1);
+}
+
+}  // namespace spamd
+
+extern "C" int spamd_has_nan(int val_dtype, int64_t n, const void* data, int* flag, void* stream) {
+  using namespace spamd;
+  if (n < 0 || !flag) return SPAMD_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), s);
+  if (e != hipSuccess) return (int)e;
+  if (n == 0) return 0;
+  if (((uintptr_t)data % 16) != 0) return SPAMD_EINVAL;
+  int64_t blocks = ceil_div(n, 256 * 4);
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  switch (val_dtype) {
+    case SPAMD_F32:
+      hipLaunchKernelGGL(has_nan_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s,
+                         (const float*)data, n, flag);
+      break;
+    case SPAMD_F64:
+      hipLaunchKernelGGL(has_nan_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, s,
+                         (const double*)data, n, flag);
+      break;
+    case SPAMD_I32:
+    case SPAMD_I64:
+      return 0;  // integers cannot hold NaN
+    default:
+      return SPAMD_ETYPE;
+  }
+  return launch_status();
+}

@@ -9,7 +9,9 @@
 // accumulated by exactly one lane in storage (k-ascending) order -> the summation order is
 // the reference's, and the result is deterministic.  `out` is written exactly once per
 // element (no zero-fill + read-modify-write as in the reference).
-#include "common.h"
+#include "spmm_internal.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace spamd {
 
@@ -18,7 +20,12 @@ __global__ void __launch_bounds__(256)
 spmm_csr_rowgroup_kernel(int64_t M, int64_t N, const T* __restrict__ a_data,
                          const I* __restrict__ a_idx, const I* __restrict__ a_ptr,
                          const T* __restrict__ b, int64_t ldb, T* __restrict__ out,
-                         int64_t ldo) {
+                         int64_t ldo, int64_t panel) {
+  // blockIdx.y selects a column panel [c_lo, c_hi) of the output: with panel < N the
+  // gathered part of B per pass shrinks to K*panel*sizeof(T) so that it stays resident in the
+  // 4 MiB per-XCD L2 (A is then streamed once per panel).
+  const int64_t c_lo = (int64_t)blockIdx.y * panel;
+  const int64_t c_hi = (c_lo + panel < N) ? (c_lo + panel) : N;
   constexpr int RPW = SPAMD_WAVE / G;  // rows per wave
   using V = Vec<T, VEC>;
   const int lane = threadIdx.x & (SPAMD_WAVE - 1);
@@ -33,9 +40,9 @@ spmm_csr_rowgroup_kernel(int64_t M, int64_t N, const T* __restrict__ a_data,
     const int64_t start = row_ok ? (int64_t)a_ptr[row] : 0;
     const int64_t end = row_ok ? (int64_t)a_ptr[row + 1] : 0;
 
-    for (int64_t c0 = 0; c0 < N; c0 += (int64_t)G * VEC) {
+    for (int64_t c0 = c_lo; c0 < c_hi; c0 += (int64_t)G * VEC) {
       const int64_t col = c0 + (int64_t)gl * VEC;
-      const bool col_ok = col < N;  // N % VEC == 0 is guaranteed by the dispatcher
+      const bool col_ok = col < c_hi;  // N % VEC == 0 and panel % VEC == 0 (dispatcher)
       T acc[VEC];
 #pragma unroll
       for (int e = 0; e < VEC; ++e) acc[e] = T(0);
@@ -103,22 +110,49 @@ spmm_csr_rowgroup_kernel(int64_t M, int64_t N, const T* __restrict__ a_data,
   }
 }
 
-template <typename T, typename I, int VEC, int G, bool EXACT>
+struct SpmmVariant {
+  int g = 0, vec = 0, unroll = 0;
+  int64_t panel = 0;  // 0 = whole N in one pass
+  int lds = -1;       // 1: LDS-DMA ring kernel
+  int depth = 0, rb = 0;
+};
+
+// Tuning hook: SPAMD_SPMM_VARIANT="G=32,VEC=2,U=8,PANEL=64" overrides the heuristic.
+static SpmmVariant env_variant() {
+  SpmmVariant v;
+  const char* e = getenv("SPAMD_SPMM_VARIANT");
+  if (!e) return v;
+  const char* p;
+  if ((p = strstr(e, "G="))) v.g = atoi(p + 2);
+  if ((p = strstr(e, "VEC="))) v.vec = atoi(p + 4);
+  if ((p = strstr(e, "U="))) v.unroll = atoi(p + 2);
+  if ((p = strstr(e, "PANEL="))) v.panel = atoll(p + 6);
+  if ((p = strstr(e, "LDS="))) v.lds = atoi(p + 4);
+  if ((p = strstr(e, "D="))) v.depth = atoi(p + 2);
+  if ((p = strstr(e, "RB="))) v.rb = atoi(p + 3);
+  return v;
+}
+
+template <typename T, typename I, int VEC, int G, bool EXACT, int UNROLL>
 static int launch_rowgroup(int64_t M, int64_t N, const T* a_data, const I* a_idx, const I* a_ptr,
-                           const T* b, int64_t ldb, T* out, int64_t ldo, hipStream_t s) {
+                           const T* b, int64_t ldb, T* out, int64_t ldo, int64_t panel,
+                           hipStream_t s) {
   constexpr int RPW = SPAMD_WAVE / G;
   constexpr int WPB = 4;  // waves per 256-thread block
   int64_t blocks = ceil_div(M, (int64_t)RPW * WPB);
   const int64_t cap = 256 * 8 * 4;  // grid-stride above this many blocks
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((spmm_csr_rowgroup_kernel<T, I, VEC, G, EXACT, 4>), dim3((unsigned)blocks),
-                     dim3(256), 0, s, M, N, a_data, a_idx, a_ptr, b, ldb, out, ldo);
+  if (panel <= 0 || panel > N) panel = N;
+  const unsigned npanels = (unsigned)ceil_div(N, panel);
+  hipLaunchKernelGGL((spmm_csr_rowgroup_kernel<T, I, VEC, G, EXACT, UNROLL>),
+                     dim3((unsigned)blocks, npanels), dim3(256), 0, s, M, N, a_data, a_idx, a_ptr, b,
+                     ldb, out, ldo, panel);
   return launch_status();
 }
 
 template <typename T, typename I, bool EXACT>
-static int dispatch_shape(int64_t M, int64_t N, const T* a_data, const I* a_idx, const I* a_ptr,
+static int dispatch_shape(int64_t M, int64_t K, int64_t N, const T* a_data, const I* a_idx, const I* a_ptr,
                           const T* b, int64_t ldb, T* out, int64_t ldo, hipStream_t s) {
   // widest vector (<= 16 B) that the shapes/alignments allow
   int vmax = 16 / (int)sizeof(T);
@@ -128,25 +162,46 @@ static int dispatch_shape(int64_t M, int64_t N, const T* a_data, const I* a_idx,
            ((uintptr_t)b % (v * sizeof(T))) == 0 && ((uintptr_t)out % (v * sizeof(T))) == 0;
   };
   while (vmax > 1 && !ok(vmax)) vmax >>= 1;
-  // N >= 64: one row per wave, widest vector that still fills all 64 lanes.
-  // N <  64: 16 lanes per row (4 rows per wave), narrowest vector that covers N in one pass.
-  int vec = 1, g = 64;
-  if (N >= 64) {
-    vec = vmax;
-    while (vec > 1 && N / vec < SPAMD_WAVE) vec >>= 1;
-  } else if (N <= 16 * vmax) {
-    g = 16;
-    while (vec < vmax && ceil_div(N, vec) > 16) vec <<= 1;
+  // Measured on MI355X (tools/micro/gather_bw.hip, profiles/): the vector-memory front end
+  // moves 16 B per lane per instruction at ~25 TB/s chip-wide but 8 B per lane at only
+  // ~18.5 TB/s, so every lane always fetches the widest vector the alignment allows and a row
+  // takes just as many lanes as that needs — 32 lanes for 128 fp32 columns, i.e. two rows per
+  // wave.  The group size is the power of two (16/32/64) that covers N in one pass if possible.
+  int vec = vmax, g = 64, unroll = 8;
+  int64_t panel = N;
+  {
+    const int64_t lanes = ceil_div(N, vec);
+    g = lanes <= 16 ? 16 : (lanes <= 32 ? 32 : 64);
+  }
+  const SpmmVariant ev = env_variant();
+  if (ev.g) g = ev.g;
+  if (ev.vec && ev.vec <= vmax) vec = ev.vec;
+  if (ev.unroll) unroll = ev.unroll;
+  if (ev.panel > 0 && ev.panel % vec == 0) panel = ev.panel;
+  if (ev.lds == 1 && K * ldb * (int64_t)sizeof(T) < ((int64_t)1 << 46)) {
+    int rc = spmm_csr_ldsring_dispatch<T, I, EXACT>(M, N, a_data, a_idx, a_ptr, b, ldb, out, ldo,
+                                                    ev.depth ? ev.depth : 8, ev.rb ? ev.rb : 32, s);
+    if (rc != SPAMD_ETYPE) return rc;
   }
 #define SPAMD_CASE(V, GG)                                                                        \
-  if (vec == V && g == GG)                                                                       \
-    return launch_rowgroup<T, I, V, GG, EXACT>(M, N, a_data, a_idx, a_ptr, b, ldb, out, ldo, s);
+  if (vec == V && g == GG) {                                                                     \
+    if (unroll == 8)                                                                             \
+      return launch_rowgroup<T, I, V, GG, EXACT, 8>(M, N, a_data, a_idx, a_ptr, b, ldb, out, ldo, \
+                                                    panel, s);                                   \
+    return launch_rowgroup<T, I, V, GG, EXACT, 4>(M, N, a_data, a_idx, a_ptr, b, ldb, out, ldo,  \
+                                                  panel, s);                                     \
+  }
   SPAMD_CASE(1, 64)
   SPAMD_CASE(2, 64)
-  if constexpr (sizeof(T) == 4) { SPAMD_CASE(4, 64) }
+  SPAMD_CASE(1, 32)
+  SPAMD_CASE(2, 32)
   SPAMD_CASE(1, 16)
   SPAMD_CASE(2, 16)
-  if constexpr (sizeof(T) == 4) { SPAMD_CASE(4, 16) }
+  if constexpr (sizeof(T) == 4) {
+    SPAMD_CASE(4, 64)
+    SPAMD_CASE(4, 32)
+    SPAMD_CASE(4, 16)
+  }
 #undef SPAMD_CASE
   return SPAMD_EINVAL;
 }
@@ -171,9 +226,9 @@ extern "C" int spamd_spmm_csr(int val_dtype, int idx_dtype, int64_t M, int64_t K
       const T* bb = (const T*)b;
       T* oo = (T*)out;
       if constexpr (std::is_floating_point<T>::value) {
-        if (exact) return dispatch_shape<T, I, true>(M, N, ad, ai, ap, bb, ldb, oo, ldo, s);
+        if (exact) return dispatch_shape<T, I, true>(M, K, N, ad, ai, ap, bb, ldb, oo, ldo, s);
       }
-      return dispatch_shape<T, I, false>(M, N, ad, ai, ap, bb, ldb, oo, ldo, s);
+      return dispatch_shape<T, I, false>(M, K, N, ad, ai, ap, bb, ldb, oo, ldo, s);
     })
   })
   return SPAMD_ETYPE;

@@ -1,0 +1,13 @@
+// Internal cross-file declarations for the SpMM kernels.
+#pragma once
+#include "common.h"
+
+namespace spamd {
+
+// spmm_csr_ldsring.hip — LDS-DMA ring kernel; SPAMD_ETYPE when the shape does not fit it.
+template <typename T, typename I, bool EXACT>
+int spmm_csr_ldsring_dispatch(int64_t M, int64_t N, const T* a_data, const I* a_idx,
+                              const I* a_ptr, const T* b, int64_t ldb, T* out, int64_t ldo,
+                              int depth, int RB, hipStream_t s);
+
+}  // namespace spamd

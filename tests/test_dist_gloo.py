@@ -1,0 +1,63 @@
+"""world_size-2 `gloo` test of the multi-GPU path's host logic: nnz-balanced
+row-block sharding of A + one all-gather of the row-sharded dense operand B.  The local
+product of each rank is formed here by the ORACLE (test infrastructure) because this container
+has no GPU; what is under test is the sharding arithmetic and the collective plumbing that
+`sparse_amd._dist` / bench.py use unchanged with the "nccl" (RCCL) backend."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from util import random_csr, random_dense
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, K, N, ret):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle
+    from sparse_amd import _dist
+
+    M = 501
+    data, idx, ptr = random_csr(M, K, 0.05, 9, np.float64, np.int64, empty_rows=(0, 1, 2), long_row=77)
+    b = random_dense(K, N, 10, np.float64)
+    tptr = torch.from_numpy(ptr)
+    bounds = _dist.partition_rows_by_nnz(tptr, world)
+    d, i, p, r0, r1 = _dist.shard_csr(torch.from_numpy(data), torch.from_numpy(idx), tptr, rank, world, bounds)
+    b_shard = _dist.row_shard(torch.from_numpy(b), rank, world)
+    b_full = _dist.all_gather_rows(b_shard, K)
+    assert torch.equal(b_full, torch.from_numpy(b))
+    local = oracle.dot_csr_ndarray((r1 - r0, N), d.numpy(), i.numpy(), p.numpy(), b_full.numpy())
+    whole = oracle.dot_csr_ndarray((M, N), data, idx, ptr, b)
+    assert np.array_equal(local, whole[r0:r1])
+    # the output stays row-sharded: row counts add up and cover [0, M)
+    cnt = torch.tensor([r1 - r0])
+    dist.all_reduce(cnt)
+    assert int(cnt) == M
+    ret[rank] = (r0, r1)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("K,N", [(300, 8), (301, 5)])  # even and ragged shards of B
+def test_row_block_sharding_with_allgather_world2(K, N):
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, K, N, ret), nprocs=world, join=True)
+    spans = sorted(ret.values())
+    assert spans[0][0] == 0 and spans[0][1] == spans[1][0] and spans[1][1] == 501

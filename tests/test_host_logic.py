@@ -1,0 +1,136 @@
+"""CPU-side checks: the C ABI loads and exports what include/sparse_amd.h declares, and the
+host logic around the kernels (axes normalisation, argument contracts, sharding arithmetic)
+matches the reference's behaviour.  No compute calls: there is no GPU here."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+
+def test_library_exports_every_declared_symbol(hiplib):
+    from sparse_amd import _ffi
+
+    declared = _ffi.header_symbols()
+    assert declared, "no symbols parsed from include/sparse_amd.h"
+    assert set(declared) == set(_ffi.SIGNATURES), "ctypes table out of step with the header"
+    for name in declared:
+        assert hasattr(hiplib, name), name
+    assert hiplib.spamd_target_arch() == b"gfx950"
+    assert hiplib.spamd_version() >= 100
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from sparse_amd import _ffi
+
+    monkeypatch.setattr(_ffi, "_lib", None)
+    monkeypatch.setattr(_ffi, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_ffi.HipBackendError, match="no CPU fallback"):
+        _ffi.lib()
+
+
+def test_no_device_fails_loudly():
+    import torch
+
+    from sparse_amd import _device, _ffi, _kernels
+
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is visible")
+    with pytest.raises(_ffi.HipBackendError):
+        _device.default_device()
+    t = torch.zeros(3)
+    with pytest.raises(_ffi.HipBackendError, match="no CPU fallback"):
+        _kernels.dot_csr_ndarray((2, 1), t, torch.zeros(3, dtype=torch.int64), torch.zeros(3, dtype=torch.int64),
+                                 torch.zeros((1, 1)))
+
+
+def test_product_never_imports_the_oracle():
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sparse_amd")
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "liboracle" not in text, f
+
+
+@pytest.mark.parametrize("a_shape,b_shape,axes", [
+    ((3, 4), (4, 5), 1), ((3, 4, 5), (4, 5, 6), 2), ((3, 4, 5), (5, 4, 2), ((1, 2), (1, 0))),
+    ((3, 4, 5), (5, 7), ((-1,), (0,))), ((6,), (6, 2), ((0,), (0,))), ((2, 3), (4, 5), 0),
+])
+def test_tensordot_plan_matches_numpy(a_shape, b_shape, axes):
+    from sparse_amd._dot import tensordot_plan
+
+    rng = np.random.default_rng(0)
+    a, b = rng.random(a_shape), rng.random(b_shape)
+    na, sa, nb, sb, olda, oldb = tensordot_plan(a_shape, b_shape, axes)
+    got = (a.transpose(na).reshape(sa) @ b.transpose(nb).reshape(sb)).reshape(olda + oldb)
+    assert np.allclose(got, np.tensordot(a, b, axes))
+
+
+def test_tensordot_plan_errors():
+    from sparse_amd._dot import tensordot_plan
+
+    with pytest.raises(ValueError, match="shape-mismatch for sum"):
+        tensordot_plan((3, 4), (5, 6), 1)
+    with pytest.raises(ValueError, match="does not have enough dimensions"):
+        tensordot_plan((), (5, 6), 1)
+    assert tensordot_plan((), (), 0) is None
+
+
+def test_argument_contracts():
+    from sparse_amd import _utils as U
+
+    class Fake:
+        size, dtype = 4, np.dtype("f8")
+
+        def __init__(self, fv):
+            self.fill_value = np.float64(fv)
+
+    U.check_zero_fill_value(Fake(0.0), Fake(-0.0))
+    with pytest.raises(ValueError, match="argument 1 had a fill value of 0.5"):
+        U.check_zero_fill_value(Fake(0.0), Fake(0.5))
+    assert U.normalize_axis(-1, 3) == 2 and U.normalize_axis((0, -2), 3) == (0, 1)
+    with pytest.raises(ValueError, match="Invalid axis index 3 for ndim=3"):
+        U.normalize_axis(3, 3)
+    U.check_compressed_axes(3, (0, 2))
+    for bad, msg in (((0, 1, 2), "cannot compress all axes"), ((1, 0), "sorted without repeats"),
+                     ((0, 5), "axis out of range"), ((0.5,), "integers")):
+        with pytest.raises(ValueError, match=msg):
+            U.check_compressed_axes(3, bad)
+    assert bool(U.equivalent(np.float64(0.0), np.float64(-0.0), loose=True))
+    assert not bool(U.equivalent(np.float64(0.0), np.float64(-0.0)))
+    assert bool(U.equivalent(np.nan, np.nan, loose=True))
+    assert U.can_store(np.int8, 127) and not U.can_store(np.int8, 128)
+
+
+def test_dot_dtype_rule():
+    from sparse_amd._kernels import dot_dtype
+
+    assert dot_dtype(np.float32, np.float32) == np.float32
+    assert dot_dtype(np.float32, np.float64) == np.float64
+    assert dot_dtype(np.int32, np.int32) == np.int32
+    assert dot_dtype(np.int64, np.float32) == np.float64
+
+
+def test_nnz_balanced_row_partition():
+    import torch
+
+    from sparse_amd._dist import partition_rows_by_nnz, row_bounds, shard_csr
+
+    rng = np.random.default_rng(1)
+    counts = rng.integers(0, 200, 1000)
+    counts[100:300] = 0
+    counts[500] = 20000  # one very long row
+    indptr = torch.from_numpy(np.concatenate([[0], np.cumsum(counts)]))
+    for world in (1, 2, 4, 8):
+        b = partition_rows_by_nnz(indptr, world)
+        assert b[0] == 0 and b[-1] == 1000 and all(x <= y for x, y in zip(b, b[1:]))
+        data = torch.arange(int(indptr[-1]))
+        pieces = [shard_csr(data, data, indptr, r, world, b) for r in range(world)]
+        assert sum(int(p[0].numel()) for p in pieces) == int(indptr[-1])
+        for d, _, ip, r0, r1 in pieces:
+            assert int(ip[0]) == 0 and int(ip[-1]) == d.numel() and ip.numel() == r1 - r0 + 1
+        if world > 1:
+            sizes = [int(p[0].numel()) for p in pieces]
+            assert max(sizes) <= int(indptr[-1]) / world + 20000  # balanced up to one row
+    assert [row_bounds(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]

@@ -122,3 +122,25 @@ def test_full_size_linearity_property():
     want = torch.zeros((M, N), device="cuda")
     want[rows[sel], (idx[sel] - 100).long()] = data[sel]
     assert torch.equal(col, want)
+
+
+VARIANTS = ["LDS=1,D=8,RB=32", "LDS=1,D=4,RB=5", "LDS=1,D=16,RB=64", "LDS=1,D=8,RB=1", "G=32,VEC=2,U=8", "G=16,VEC=1,U=4,PANEL=32", "G=64,VEC=1,U=4"]
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("N", [2, 64, 128, 200, 512])
+@pytest.mark.parametrize("dtype,idt", [(np.float32, np.int32), (np.float64, np.int64), (np.int64, np.int32)])
+def test_kernel_variants_bit_identical(orc, monkeypatch, variant, N, dtype, idt):
+    """Every kernel form keeps the reference's summation order: exact mode == oracle."""
+    monkeypatch.setenv("SPAMD_SPMM_VARIANT", variant)
+    (data, idx, ptr, b), got = _run(777, 900, N, 0.03, dtype, idt, exact=True, seed=3,
+                                    empty_rows=(0, 1, 2, 400, 401, 776), long_row=300)
+    want = orc.dot_csr_ndarray((777, N), data, idx, ptr, b)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("variant", VARIANTS[:5])
+def test_kernel_variants_all_rows_empty(monkeypatch, variant):
+    monkeypatch.setenv("SPAMD_SPMM_VARIANT", variant)
+    (_, _, _, _), got = _run(300, 50, 128, 0.0, np.float32, np.int32, exact=False)
+    assert got.shape == (300, 128) and not got.any()
