@@ -32,6 +32,9 @@ extern "C" {
 #define SPAMD_I32 2
 #define SPAMD_I64 3
 #define SPAMD_BF16 4
+#define SPAMD_U8 5 /* bool (0/1) — results of comparisons, any/all, astype(bool) */
+
+#define SPAMD_MAX_NDIM 16 /* largest array rank the key kernels accept */
 
 /* error codes (negative; positive values are hipError_t) */
 #define SPAMD_EINVAL (-1)  /* bad size / null pointer / misaligned */
@@ -73,6 +76,132 @@ int spamd_spmm_csr(int val_dtype, int idx_dtype, int64_t M, int64_t K, int64_t N
  *   16-byte aligned.  val_dtype: F32 | F64 (I32 | I64 accepted: flag = 0).
  * ------------------------------------------------------------------------------------- */
 int spamd_has_nan(int val_dtype, int64_t n, const void* data, int* flag, void* stream);
+
+/* =======================================================================================
+ * T1-T3 / A6  Canonicalisation and format conversion on 64-bit C-order linear keys.
+ *   Replaces the reference's NumPy/numba integer pipeline: `linear_loc`
+ *   (_coo/common.py:56-64), `COO._sort_indices/_sum_duplicates/_prune` (_coo/core.py:1294-1371),
+ *   `_from_coo` (_compressed/compressed.py:25-77), `uncompress_dimension`/`_transpose`/
+ *   `_convert_coords` (_compressed/convert.py:82-87,210-339), `COO.reshape/transpose`
+ *   (_coo/core.py:725-807,1034-1111).  A sparse array is (keys[nnz] int64, data[nnz]);
+ *   a transpose is a key permutation, a reshape is the identity on keys.
+ *   All results are bit-exact integers.  `strides`/`dims`/`perm`/`axis_order` are HOST arrays
+ *   of `ndim` (<= SPAMD_MAX_NDIM) entries, read during the call.
+ * ===================================================================================== */
+
+/* keys[p] = sum_d coords[axis_order[d]*coord_stride + p] * strides[d]   (coords: [ndim][nnz]) */
+int spamd_coo_linearize(int idx_dtype, int ndim, int64_t nnz, const void* coords, int64_t coord_stride,
+                        const int64_t* strides, const int32_t* axis_order, int64_t* keys, void* stream);
+/* coords[d*coord_stride + p] = (keys[p] / strides[d]) % dims[d] */
+int spamd_coo_delinearize(int idx_dtype, int ndim, int64_t nnz, const int64_t* keys, const int64_t* strides,
+                          const int64_t* dims, void* coords, int64_t coord_stride, void* stream);
+/* keys_out = C-order key after moving source axis perm[d] to destination position d */
+int spamd_permute_keys(int ndim, int64_t nnz, const int64_t* keys_in, const int64_t* src_strides,
+                       const int64_t* src_dims, const int32_t* perm, int64_t* keys_out, void* stream);
+/* flags2[0] = keys not non-decreasing, flags2[1] = some adjacent keys equal (device int32[2]) */
+int spamd_keys_check(int64_t n, const int64_t* keys, int* flags2, void* stream);
+/* flags[i] = 1 where a run of equal keys starts (int64 0/1, ready for spamd_exclusive_scan) */
+int spamd_flag_heads(int64_t n, const int64_t* keys, int64_t* flags, void* stream);
+/* flags[i] = 1 where data[i] is NOT bit-identical to fill_bits (the reference's bit-wise
+ * `equivalent`, _utils.py:448-452: -0.0 is not 0.0).  elem_bytes in {1,2,4,8}. */
+int spamd_flag_ne_bits(int elem_bytes, int64_t n, const void* data, uint64_t fill_bits, int64_t* flags,
+                       void* stream);
+/* dst[offsets[i]] = src[i] where flags[i] != 0  (stream compaction after an exclusive scan) */
+int spamd_compact(int elem_bytes, int64_t n, const void* src, const int64_t* flags, const int64_t* offsets,
+                  void* dst, void* stream);
+/* dst[i] = src[perm[i]] ; dst[keys[i]] = src[i] */
+int spamd_gather(int elem_bytes, int64_t n, const void* src, const int64_t* perm, void* dst, void* stream);
+int spamd_scatter(int elem_bytes, int64_t n, const void* src, const int64_t* keys, void* dst, void* stream);
+/* sorted keys (row*C + col) -> indptr[R+1], indices[nnz]          (`_from_coo`, compressed.py:64-76) */
+int spamd_keys_to_csr(int idx_dtype, int64_t nnz, const int64_t* keys, int64_t R, int64_t C, void* indptr,
+                      void* indices, void* stream);
+/* (indptr, indices) -> keys[p] = row(p)*C + indices[p]              (`uncompress_dimension`, convert.py:82-87) */
+int spamd_csr_to_keys(int idx_dtype, int64_t R, int64_t nnz, const void* indptr, const void* indices, int64_t C,
+                      int64_t* keys, void* stream);
+/* sorted row ids -> int64 indptr[R+1]        (`cumsum(bincount(coords[0]))`, _common.py:452-458) */
+int spamd_rows_to_indptr(int idx_dtype, int64_t nnz, const void* rows, int64_t R, int64_t* indptr, void* stream);
+/* Stable radix sort of (key, value) int64 pairs on key bits [0, end_bit); keys must be >= 0.
+ * Replaces `np.argsort(linear, kind="mergesort")` (core.py:1315).  Workspace from *_ws_bytes. */
+int64_t spamd_sort_pairs_ws_bytes(int64_t n);
+int spamd_sort_pairs(int64_t n, const int64_t* keys_in, int64_t* keys_out, const int64_t* vals_in,
+                     int64_t* vals_out, int end_bit, void* ws, int64_t ws_bytes, void* stream);
+int spamd_iota(int64_t n, int64_t* out, void* stream);
+/* out[i] = in[0] + ... + in[i-1] for i in [0, n]; both arrays hold n+1 entries (in[n] ignored). */
+int64_t spamd_scan_ws_bytes(int64_t n);
+int spamd_exclusive_scan(int64_t n, const int64_t* in, int64_t* out, void* ws, int64_t ws_bytes, void* stream);
+/* astype between F32/F64/I32/I64/U8 (C-cast, NumPy "unsafe"; to U8 = x != 0) */
+int spamd_convert(int src_dtype, int dst_dtype, int64_t n, const void* src, void* dst, void* stream);
+
+/* =======================================================================================
+ * A7  Elementwise on canonical operands     replaces `_Elemwise` + `_match_arrays`
+ *                                            (sparse/numba_backend/_umath.py:53-92,392-751)
+ *   On sorted, duplicate-free linear keys the reference's mask enumeration / argsort / join /
+ *   concatenate / re-sort collapses to one sorted-key UNION:
+ *     out[k] = func(a[k] or fill_a, b[k] or fill_b), entries bit-equal to func(fill_a, fill_b)
+ *     dropped afterwards (spamd_flag_ne_bits + spamd_compact).
+ * ===================================================================================== */
+
+/* pos[i] = number of h-keys < q[i]; match[i] = 1 iff q[i] occurs in h (h sorted + unique) */
+int spamd_lower_bound_match(int64_t nq, const int64_t* q, int64_t nh, const int64_t* h, int64_t* pos,
+                            int64_t* match, void* stream);
+int spamd_invert_flags(int64_t n, const int64_t* in, int64_t* out, void* stream);
+/* Output slot of every a / b element in the union and the union's keys.
+ * posB/posA/matchB from spamd_lower_bound_match, ub = exclusive scan of (1 - matchB) (nb+1). */
+int spamd_union_positions(int64_t na, const int64_t* ka, const int64_t* posB, int64_t nb, const int64_t* kb,
+                          const int64_t* posA, const int64_t* matchB, const int64_t* ub, int64_t* slotA,
+                          int64_t* slotB, int64_t* out_keys, void* stream);
+int spamd_fill(int elem_bytes, int64_t n, void* out, uint64_t value_bits, void* stream);
+/* out[i] = a[i] (op) b[i]; *_is_scalar broadcasts a 1-element device array.
+ * op: 0 add 1 sub 2 mul 3 div 4 maximum 5 minimum 6 power 7 fmax 8 fmin (out dtype = val_dtype);
+ *     32 gt 33 ge 34 lt 35 le 36 eq 37 ne 38 logical_and 39 logical_or 40 logical_xor (out U8);
+ *     64 bitwise_and 65 bitwise_or 66 bitwise_xor (integer dtypes).  No FMA contraction. */
+int spamd_ewise_binary(int op, int val_dtype, int64_t n, const void* a, int a_is_scalar, const void* b,
+                       int b_is_scalar, void* out, void* stream);
+/* out[i] = f(a[i]); op: 0 negative 1 abs 2 sqrt 3 exp 4 expm1 5 log 6 log1p 7 sin 8 cos 9 tan 10 tanh
+ *   11 sinh 12 cosh 13 arcsin 14 arctan 15 floor 16 ceil 17 rint 18 trunc 19 sign 20 square
+ *   21 reciprocal 22 positive 23 log2 24 log10 25 exp2 26 arcsinh 27 arctanh 28 cbrt 29 deg2rad
+ *   30 rad2deg (out dtype = val_dtype); 64 isnan 65 isinf 66 isfinite 67 logical_not 68 signbit (out U8) */
+int spamd_ewise_unary(int op, int val_dtype, int64_t n, const void* a, void* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * A8  Grouped reduce     replaces `_calc_counts_invidx` + `_grouped_reduce` / `ufunc.reduceat`
+ *                        (sparse/numba_backend/_coo/core.py:1601-1661; compressed.py:354-386)
+ *   heads[i] = 1 where a run starts, offsets = its exclusive scan, nseg = number of runs.
+ *   out[g] = data[s_g] op data[s_g+1] op ...; counts[g] = run length (may be NULL).
+ *   Short runs: one thread per run, strictly left to right (bit-identical to reduceat).
+ *   Long runs (n/nseg >= 128 and seg_start_ws != NULL, nseg+1 int64): one wave per run.
+ *   op: 0 add 1 multiply 2 maximum 3 minimum 4 logical_or 5 logical_and.
+ * ------------------------------------------------------------------------------------- */
+int spamd_segment_reduce(int op, int val_dtype, int64_t n, const void* data, const int64_t* heads,
+                         const int64_t* offsets, int64_t nseg, void* out, int64_t* counts,
+                         int64_t* seg_start_ws, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * A4 / A5  sparse x sparse     replaces `_csr_csr_count_nnz` + `_dot_csr_csr` / `_dot_coo_coo`
+ *                              (sparse/numba_backend/_common.py:543-570,639-717,907-976)
+ *   Expand-sort-compress: the two entry points below produce, for the A elements [p0, p0+np),
+ *   (1) cnt[i] = nnz of B row a_indices[p0+i]; after the caller's exclusive scan (offsets, P):
+ *   (2) keys[t] = a_rows[p]*n_col + b_col, vals[t] = a*b for every product t in [0, P).
+ *   A stable sort by key + spamd_segment_reduce(add) then gives every output element summed in
+ *   the reference's order (bit-identical), with rows sorted by column.
+ * ------------------------------------------------------------------------------------- */
+int spamd_spgemm_count(int idx_dtype, int64_t p0, int64_t np, const void* a_indices, const void* b_indptr,
+                       int64_t* cnt, void* stream);
+int spamd_spgemm_expand(int val_dtype, int idx_dtype, int64_t p0, int64_t np, const void* a_data,
+                        const void* a_indices, const int64_t* a_rows, const void* b_data, const void* b_indices,
+                        const void* b_indptr, const int64_t* offsets, int64_t P, int64_t n_col, int64_t* keys,
+                        void* vals, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * A9  SDDMM      out[n] = s[n] * sum_k A[rows[n], k] * Bt[cols[n], k]
+ *   replaces the reference's formulation `s * (a @ b)` (examples/sddmm_example.py:51-52: a dense
+ *   BLAS GEMM of the full M x N product + `_Elemwise` gather, _umath.py:602-633).
+ *   A is M x K row-major (lda), Bt = B^T is N x K row-major (ldb): both K-contiguous, 16-byte
+ *   aligned rows.  in_dtype BF16|F32 -> fp32 accumulate and F32 mask/out; F64 -> F64.
+ * ------------------------------------------------------------------------------------- */
+int spamd_sddmm(int in_dtype, int s_dtype, int idx_dtype, int64_t nnz, const void* rows, const void* cols,
+                const void* s_data, const void* A, int64_t lda, const void* Bt, int64_t ldb, int64_t K, void* out,
+                void* stream);
 
 #ifdef __cplusplus
 }

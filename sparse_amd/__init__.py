@@ -5,10 +5,22 @@ Drop-in for the `sparse.numba_backend` names on that path: `COO`, `GCXS`, `tenso
 PyTorch-ROCm tensors; all arithmetic is done by hand-written HIP kernels behind the C ABI of
 `libsparse_amd.so` (include/sparse_amd.h).  There is no CPU fallback.
 """
+from numpy import (  # noqa: F401  (the reference re-exports NumPy's ufuncs, __init__.py:1-83)
+    abs, add, bitwise_and, bitwise_or, bitwise_xor, ceil, cos, cosh, divide, equal, exp, expm1, floor, greater,
+    greater_equal, isfinite, isinf, isnan, less, less_equal, log, log1p, log2, log10, logical_and, logical_not,
+    logical_or, logical_xor, maximum, minimum, multiply, negative, not_equal, positive, sign, sin, sinh, sqrt, square,
+    subtract, tan, tanh, trunc,
+)
+
 from ._sparse_array import SparseArray
 from ._coo import COO, as_coo
 from ._gcxs import GCXS
 from ._dot import dot, matmul, tensordot
+from ._umath import elemwise
+from ._api import (all, any, asarray, astype, matrix_transpose, max, mean, min, permute_dims, prod, random, reshape,
+                   sddmm, std, sum, var, vecdot)
 from ._ffi import HipBackendError
 
-__all__ = ["COO", "GCXS", "SparseArray", "as_coo", "dot", "matmul", "tensordot", "HipBackendError"]
+__all__ = ["COO", "GCXS", "SparseArray", "HipBackendError", "all", "any", "as_coo", "asarray", "astype", "dot",
+           "elemwise", "matmul", "matrix_transpose", "max", "mean", "min", "permute_dims", "prod", "random", "reshape",
+           "sddmm", "std", "sum", "tensordot", "var", "vecdot"]

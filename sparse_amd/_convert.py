@@ -1,21 +1,153 @@
-"""Device-side format conversion (A6).  Filled in by the conversion milestone."""
+"""Device-side format conversion.
+
+The reference routes every COO<->GCXS conversion, `change_compressed_axes`, N-D `reshape` and
+`transpose` through one per-element index re-linearisation + a stable argsort
+(`_compressed/convert.py:210-339`, `_compressed/compressed.py:25-77,388-460`).  Here the same
+thing is expressed on 64-bit linear keys: permute keys (csrc/prims.hip) -> stable radix sort
+-> split into (indptr, indices) or coordinates.
+"""
+import numpy as np
+import torch
+
+from . import _kernels as K
+from ._utils import can_store, check_compressed_axes, normalize_axis, prod
+
+
+def _axis_order(ndim, compressed_axes):
+    order = list(compressed_axes)
+    order.extend(a for a in range(ndim) if a not in compressed_axes)
+    return order
+
+
+def _inverse(perm):
+    inv = [0] * len(perm)
+    for d, s in enumerate(perm):
+        inv[s] = d
+    return inv
+
+
+def _pick_index_dtype(base, bound):
+    if base == torch.int32 and bound < 2 ** 31:
+        return torch.int32
+    return torch.int64
 
 
 def coo_to_gcxs_arrays(x, compressed_axes=None, idx_dtype=None):
-    raise NotImplementedError
+    """`_from_coo` (reference _compressed/compressed.py:25-77): returns
+    ((data, indices, indptr), shape, compressed_axes, fill_value)."""
+    if x.ndim == 0:
+        if compressed_axes is not None:
+            raise ValueError("no axes to compress for 0d array")
+        return ((x.data, x.coords, []), x.shape, None, x.fill_value)
+    if x.ndim == 1:
+        if compressed_axes is not None:
+            raise ValueError("no axes to compress for 1d array")
+        return ((x.data, x.coords[0], ()), x.shape, None, x.fill_value)
+    compressed_axes = normalize_axis(compressed_axes, x.ndim)
+    if compressed_axes is None:
+        compressed_axes = (int(np.argmin(x.shape)),)  # best compression ratio (reference :37-39)
+    check_compressed_axes(x.shape, compressed_axes)
+    order = _axis_order(x.ndim, compressed_axes)
+    rshape = tuple(x.shape[i] for i in order)
+    R = prod(rshape[: len(compressed_axes)])
+    C = prod(rshape[len(compressed_axes):])
+    bound = max(R, C, x.nnz)
+    if idx_dtype and not can_store(idx_dtype, bound):
+        raise ValueError(f"cannot store array with the compressed shape {(R, C)} and nnz {x.nnz} with dtype {idx_dtype}.")
+    base = x.coords.dtype if not idx_dtype else (torch.int32 if np.dtype(idx_dtype).itemsize <= 4 else torch.int64)
+    it = _pick_index_dtype(base, bound)
+    keys = x.linear_loc()
+    data = x.data
+    if order != list(range(x.ndim)):
+        keys = K.permute_keys(keys, x.shape, order)
+        keys, perm = K.sort_keys(keys, max(x.size - 1, 1))
+        data = K.gather(data, perm)
+    indptr, indices = K.keys_to_csr(keys, R, C, it)
+    return ((data, indices, indptr), x.shape, tuple(compressed_axes), x.fill_value)
 
 
-def gcxs_relayout(x, shape, axes, compressed_axes, transpose=False, reshape=False):
-    raise NotImplementedError
+def gcxs_natural_keys(x):
+    """C-order linear keys (natural axis order) of every stored element of a GCXS, in storage
+    order — `uncompress_dimension` + un-reordering (reference convert.py:82-87, compressed.py:448-460)."""
+    if x.ndim == 1:
+        return x.indices.to(torch.int64)
+    R, C = x._compressed_shape
+    keys = K.csr_to_keys(x.indptr, x.indices, R, C)
+    order = x._axis_order
+    if order != list(range(x.ndim)):
+        keys = K.permute_keys(keys, x._reordered_shape, _inverse(order))
+    return keys
 
 
 def gcxs_to_coo(x):
-    raise NotImplementedError
+    """`GCXS.tocoo` (reference compressed.py:425-460)."""
+    from ._coo import COO
+
+    if x.ndim == 0:
+        return COO(torch.zeros((0, x.nnz), dtype=torch.int64, device=x.device), x.data, shape=x.shape,
+                   fill_value=x.fill_value)
+    if x.ndim == 1:
+        return COO(x.indices[None, :], x.data, shape=x.shape, fill_value=x.fill_value)
+    keys = gcxs_natural_keys(x)
+    unsorted, _ = K.keys_check(keys)
+    data = x.data
+    if unsorted:
+        keys, perm = K.sort_keys(keys, max(x.size - 1, 1))
+        data = K.gather(data, perm)
+    it = x.indices.dtype if max(x.shape) < 2 ** 31 or x.indices.dtype == torch.int64 else torch.int64
+    out = COO(K.delinearize(keys, x.shape, it), data, shape=x.shape, has_duplicates=False, sorted=True,
+              fill_value=x.fill_value)
+    out._keys = keys
+    return out
+
+
+def gcxs_relayout(x, shape, axes, compressed_axes, transpose=False, reshape=False):
+    """The one routine behind `change_compressed_axes`, N-D `transpose` and `reshape`
+    (`convert._transpose`, reference _compressed/convert.py:210-273): returns the new
+    (data, indices, indptr)."""
+    shape = tuple(int(s) for s in shape)
+    keys = gcxs_natural_keys(x)
+    nat_shape = x.shape
+    if transpose:
+        keys = K.permute_keys(keys, x.shape, axes)
+        nat_shape = tuple(x.shape[a] for a in axes)
+    if reshape:
+        nat_shape = shape  # C-order reshape: linear keys are unchanged
+    assert tuple(nat_shape) == shape
+    order = _axis_order(len(shape), compressed_axes)
+    rshape = tuple(shape[i] for i in order)
+    R = prod(rshape[: len(compressed_axes)])
+    C = prod(rshape[len(compressed_axes):])
+    keys = K.permute_keys(keys, shape, order)
+    keys, perm = K.sort_keys(keys, max(prod(shape) - 1, 1))
+    data = K.gather(x.data, perm)
+    it = _pick_index_dtype(x.indices.dtype, max(R, C, x.nnz))
+    indptr, indices = K.keys_to_csr(keys, R, C, it)
+    return (data, indices, indptr)
 
 
 def gcxs_todense(x):
-    raise NotImplementedError
+    """Dense device tensor of a GCXS (reference compressed.py:462-482)."""
+    fv = x.fill_value.item() if hasattr(x.fill_value, "item") else x.fill_value
+    out = torch.full((max(x.size, 1),), fv, dtype=x.data.dtype, device=x.device)
+    if x.nnz:
+        if x.ndim == 0:
+            out[0] = x.data[0]
+        else:
+            K.scatter_into(out, gcxs_natural_keys(x), x.data)
+    return out[: x.size].reshape(x.shape)
 
 
 def gcxs_prune(x):
-    raise NotImplementedError
+    """Remove stored fill values, rebuilding indptr (reference compressed.py:816-848)."""
+    if x.nnz == 0:
+        return
+    flags = K.flag_ne_bits(x.data, x.fill_value)
+    offs = K.exclusive_scan(flags)
+    count = int(offs[-1])
+    if count == x.nnz:
+        return
+    x.data = K.compact(x.data, flags, offs, count)
+    x.indices = K.compact(x.indices, flags, offs, count)
+    if x.indptr.numel():
+        x.indptr = K.gather(offs, x.indptr.to(torch.int64)).to(x.indptr.dtype)

@@ -1,10 +1,425 @@
-"""`COO` container (device-resident).  Filled in by the conversion/elementwise milestone."""
+"""`COO`: N-D coordinate-format sparse array whose (coords, data) live in HBM.
+
+Same constructor contract as the reference container (sparse/numba_backend/_coo/core.py:
+198-291): the canonical form is sorted by C-order linear index, duplicate-free and, on
+request, pruned of stored fill values (Appendix D1).  All of that runs on the device on
+64-bit linear keys (csrc/prims.hip); torch only owns the memory.
+"""
+import copy as _copy
+import warnings
+from collections.abc import Iterable
+
+import numpy as np
+import torch
+
+from . import _device as dev
+from . import _kernels as K
 from ._sparse_array import NDArrayOperatorsMixin, SparseArray
+from ._utils import can_store, normalize_axis, prod, zero_of_dtype
+
+
+def _is_scipy_sparse(x):
+    return hasattr(x, "tocoo") and hasattr(x, "format") and type(x).__module__.startswith("scipy.sparse")
+
+
+def _index_tensor(coords, device, idx_dtype=None):
+    t = dev.to_device(coords, device)
+    if idx_dtype is not None:
+        want = torch.int32 if np.dtype(idx_dtype).itemsize <= 4 and np.dtype(idx_dtype) != np.dtype("uint32") else torch.int64
+        return t.to(want)
+    if t.dtype == torch.int32 or t.dtype == torch.int64:
+        return t
+    if t.dtype in (torch.int8, torch.uint8, torch.int16):
+        return t.to(torch.int32)  # narrow index dtypes are widened to int32 on the device
+    return t.to(torch.int64)
 
 
 class COO(SparseArray, NDArrayOperatorsMixin):
-    pass
+    """Coordinate-format sparse array on the HIP device.
+
+    Parameters follow the reference (`_coo/core.py:198-209`): `coords` is `[ndim, nnz]`,
+    `data` is `[nnz]` (or a scalar), plus the `has_duplicates` / `sorted` / `prune` promises
+    the producer makes about its output.
+    """
+
+    __array_priority__ = 12
+
+    def __init__(self, coords, data=None, shape=None, has_duplicates=True, sorted=False, prune=False,
+                 cache=False, fill_value=None, idx_dtype=None, device=None):
+        self._cache = None
+        if isinstance(coords, COO):
+            self._make_shallow_copy_of(coords)
+            if data is not None or shape is not None:
+                raise ValueError("If `coords` is `COO`, then no other arguments should be provided.")
+            if fill_value is not None:
+                self.fill_value = self.dtype.type(fill_value)
+            return
+        if cache:
+            self.enable_caching()
+        if data is None:
+            arr = as_coo(coords, shape=shape, fill_value=fill_value, idx_dtype=idx_dtype, device=device)
+            self._make_shallow_copy_of(arr)
+            if cache:
+                self.enable_caching()
+            return
+
+        if device is None:
+            device = next((t.device for t in (coords, data) if isinstance(t, torch.Tensor) and t.is_cuda), None)
+        if device is None:
+            device = dev.default_device()
+        device = torch.device(device)
+        self.data = dev.to_device(data, device)
+        self.coords = _index_tensor(coords, device, idx_dtype)
+
+        if self.coords.dim() == 1:
+            if self.coords.numel() == 0 and shape is not None:
+                nd = len(shape) if isinstance(shape, Iterable) else 1
+                self.coords = self.coords.reshape((nd, int(self.data.numel()) if self.data.dim() else 0))
+            else:
+                self.coords = self.coords[None, :]
+        if self.data.dim() == 0:
+            self.data = self.data.expand(self.coords.shape[1]).contiguous()
+        if self.data.dim() != 1:
+            raise ValueError("`data` must be a scalar or 1-dimensional.")
+        if shape is None:
+            raise ValueError("`shape` was not provided.")
+        if not isinstance(shape, Iterable):
+            shape = (shape,)
+        shape = tuple(int(s) for s in shape)
+        if shape and not self.coords.numel():
+            self.coords = torch.zeros((len(shape), 0), dtype=self.coords.dtype, device=device)
+        super().__init__(shape, fill_value=fill_value)
+        if idx_dtype and not can_store(idx_dtype, max(shape) if shape else 0):
+            raise ValueError(f"cannot cast array with shape {shape} to dtype {idx_dtype}.")
+
+        if self.shape:
+            if int(self.data.shape[0]) != int(self.coords.shape[1]):
+                raise ValueError("The data length does not match the coordinates given.\n"
+                                 f"len(data) = {int(self.data.shape[0])}, but {int(self.coords.shape[1])} coords specified.")
+            if len(self.shape) != int(self.coords.shape[0]):
+                raise ValueError("Shape specified by `shape` doesn't match the shape of `coords`; "
+                                 f"len(shape)={len(shape)} != coords.shape[0]={int(self.coords.shape[0])}"
+                                 f"(and coords.shape={tuple(self.coords.shape)})")
+        from ._settings import WARN_ON_TOO_DENSE
+
+        if WARN_ON_TOO_DENSE and self.nbytes >= self.size * self.data.element_size():
+            warnings.warn("Attempting to create a sparse array that takes no less memory than than an equivalent "
+                          "dense array. You may want to use a dense array here instead.", RuntimeWarning, stacklevel=1)
+
+        self._keys = None  # sorted C-order linear keys when known (device int64[nnz])
+        if not sorted or has_duplicates:
+            self._canonicalize(do_sort=not sorted, do_sum=has_duplicates)
+        if prune:
+            self._prune()
+
+    # ---- canonical form (Appendix D1) ---------------------------------------------------------
+    def linear_loc(self):
+        """C-order linear index of every stored element (reference core.py `linear_loc`)."""
+        if getattr(self, "_keys", None) is None or self._keys.numel() != self.nnz:
+            return K.linearize(self.coords, self.shape)
+        return self._keys
+
+    def _canonicalize(self, do_sort, do_sum):
+        """`_sort_indices` (stable, only if needed) + `_sum_duplicates` (reference
+        core.py:1294-1353)."""
+        if self.ndim == 0 or self.nnz == 0:
+            if self.ndim == 0 and self.nnz > 1 and do_sum:
+                # 0-d array: every stored element is a duplicate of the single position
+                keys = torch.zeros(self.nnz, dtype=torch.int64, device=self.device)
+                self._sum_runs(keys)
+            return
+        keys = K.linearize(self.coords, self.shape)
+        unsorted, dup = K.keys_check(keys)
+        if do_sort and unsorted:
+            keys, perm = K.sort_keys(keys, max(self.size - 1, 1))
+            self.coords = K.gather(self.coords, perm)
+            self.data = K.gather(self.data, perm)
+            if do_sum:  # adjacent-equal test is only meaningful on sorted keys
+                _, dup = K.keys_check(keys)
+        elif unsorted and not do_sort:
+            raise ValueError("COO was declared sorted=True but its coordinates are not sorted")
+        if do_sum and dup:
+            self._sum_runs(keys)
+        else:
+            self._keys = keys
+
+    def _sum_runs(self, keys):
+        """Keep the first coordinate of each run of equal keys and sum the run's data left to
+        right in the data dtype (`np.add.reduceat`, reference core.py:1340-1353)."""
+        from ._reduce import segment_reduce
+
+        flags = K.flag_heads(keys)
+        offs = K.exclusive_scan(flags)
+        count = int(offs[-1])
+        self.data = segment_reduce(self.data, flags, offs, count, "add")
+        self.coords = K.compact(self.coords, flags, offs, count)
+        self._keys = K.compact(keys, flags, offs, count)
+
+    def _sort_indices(self):
+        self._canonicalize(do_sort=True, do_sum=False)
+
+    def _sum_duplicates(self):
+        self._canonicalize(do_sort=False, do_sum=True)
+
+    def _prune(self):
+        """Drop stored elements bit-identical to the fill value (reference core.py:1355-1371)."""
+        if self.nnz == 0:
+            return
+        flags = K.flag_ne_bits(self.data, self.fill_value)
+        offs = K.exclusive_scan(flags)
+        count = int(offs[-1])
+        if count == self.nnz:
+            return
+        self.coords = K.compact(self.coords, flags, offs, count)
+        self.data = K.compact(self.data, flags, offs, count)
+        if getattr(self, "_keys", None) is not None:
+            self._keys = K.compact(self._keys, flags, offs, count)
+
+    # ---- construction / copies ---------------------------------------------------------------
+    def _make_shallow_copy_of(self, other):
+        self.coords, self.data, self.shape = other.coords, other.data, other.shape
+        self.fill_value = other.fill_value
+        self._cache = None
+        self._keys = getattr(other, "_keys", None)
+
+    def copy(self, deep=True):
+        if not deep:
+            return _copy.copy(self)
+        return COO(self.coords.clone(), self.data.clone(), shape=self.shape, has_duplicates=False, sorted=True,
+                   fill_value=self.fill_value)
+
+    def enable_caching(self):
+        """Memoise recent transposes/reshapes (reference core.py:317-338)."""
+        from collections import OrderedDict
+
+        self._cache = OrderedDict()
+        return self
+
+    @classmethod
+    def from_numpy(cls, x, fill_value=None, idx_dtype=None, device=None):
+        """Dense ndarray / tensor -> COO (reference core.py:341-384): stored elements are those
+        NOT bit-identical to the fill value."""
+        if isinstance(x, torch.Tensor):
+            xt = dev.to_device(x, device if device is not None else (x.device if x.is_cuda else None))
+        else:
+            x = np.asanyarray(x).view(type=np.ndarray)
+            xt = dev.to_device(x, device)
+        shape = tuple(int(s) for s in xt.shape)
+        npdt = dev.np_dtype(xt.dtype)
+        if fill_value is None:
+            fill_value = zero_of_dtype(npdt) if shape else npdt.type(xt.item())
+        flat = xt.reshape(-1).contiguous()
+        flags = K.flag_ne_bits(flat, fill_value)
+        offs = K.exclusive_scan(flags)
+        count = int(offs[-1])
+        n = flat.numel()
+        iota = torch.empty(n, dtype=torch.int64, device=flat.device)
+        from . import _ffi
+
+        _ffi.call("spamd_iota", n, dev.ptr(iota), dev.stream_ptr(flat.device))
+        keys = K.compact(iota, flags, offs, count)
+        data = K.compact(flat, flags, offs, count)
+        it = torch.int64 if idx_dtype is None or np.dtype(idx_dtype).itemsize > 4 else torch.int32
+        coords = K.delinearize(keys, shape, it)
+        out = cls(coords, data, shape=shape, has_duplicates=False, sorted=True, fill_value=fill_value)
+        out._keys = keys
+        return out
+
+    @classmethod
+    def from_scipy_sparse(cls, x, /, *, fill_value=None, device=None):
+        x = x.asformat("coo")
+        if not x.has_canonical_format:
+            x.eliminate_zeros()
+            x.sum_duplicates()
+        coords = np.stack([x.row, x.col]).astype(np.int64)
+        return cls(coords, x.data, shape=x.shape, has_duplicates=False, sorted=False, fill_value=fill_value,
+                   device=device)
+
+    def todense_device(self):
+        """Dense tensor in HBM (fill value everywhere, stored values scattered in)."""
+        out = torch.full((max(self.size, 1),), self.fill_value.item() if hasattr(self.fill_value, "item") else self.fill_value,
+                         dtype=self.data.dtype, device=self.device)
+        if self.nnz:
+            if self.ndim == 0:
+                out[0] = self.data[0]
+            else:
+                K.scatter_into(out, self.linear_loc(), self.data)
+        return out[: self.size].reshape(self.shape) if self.size else out[:0].reshape(self.shape)
+
+    def todense(self):
+        """Dense host ndarray (reference core.py:386-422)."""
+        return dev.to_numpy(self.todense_device())
+
+    def to_scipy_sparse(self, accept_fv=None):
+        import scipy.sparse
+
+        if self.ndim != 2:
+            raise ValueError("Can only convert a 2-dimensional array to a Scipy sparse matrix.")
+        c = dev.to_numpy(self.coords)
+        return scipy.sparse.coo_matrix((dev.to_numpy(self.data), (c[0], c[1])), shape=self.shape)
+
+    # ---- properties ----------------------------------------------------------------------------
+    @property
+    def nnz(self):
+        return int(self.coords.shape[1])
+
+    @property
+    def format(self):
+        return "coo"
+
+    @property
+    def nbytes(self):
+        return self.data.numel() * self.data.element_size() + self.coords.numel() * self.coords.element_size()
+
+    @property
+    def T(self):
+        return self.transpose(tuple(range(self.ndim))[::-1])
+
+    @property
+    def mT(self):
+        if self.ndim < 2:
+            raise ValueError("Cannot compute matrix transpose if `ndim < 2`.")
+        axis = list(range(self.ndim))
+        axis[-1], axis[-2] = axis[-2], axis[-1]
+        return self.transpose(axis)
+
+    def __str__(self):
+        return (f"<COO: shape={self.shape!s}, dtype={self.dtype!s}, nnz={self.nnz:d}, fill_value={self.fill_value!s}, "
+                f"device={self.device}>")
+
+    __repr__ = __str__
+
+    # ---- shape manipulation (keys only; Appendix C.9) ------------------------------------------
+    def transpose(self, axes=None):
+        """Permute the axes (reference core.py:725-807): permute the keys, stable sort."""
+        if axes is None:
+            axes = tuple(reversed(range(self.ndim)))
+        axes = normalize_axis(tuple(axes), self.ndim)
+        if len(set(axes)) != len(axes):
+            raise ValueError("repeated axis in transpose")
+        if set(axes) != set(range(self.ndim)):
+            raise ValueError("axes don't match array")
+        axes = tuple(axes)
+        if axes == tuple(range(self.ndim)):
+            return self
+        if self._cache is not None and ("transpose", axes) in self._cache:
+            return self._cache[("transpose", axes)]
+        shape = tuple(self.shape[ax] for ax in axes)
+        keys = K.permute_keys(self.linear_loc(), self.shape, axes)
+        keys, perm = K.sort_keys(keys, max(self.size - 1, 1))
+        out = COO(K.delinearize(keys, shape, self.coords.dtype), K.gather(self.data, perm), shape=shape,
+                  has_duplicates=False, sorted=True, fill_value=self.fill_value)
+        out._keys = keys
+        if self._cache is not None:
+            self._cache[("transpose", axes)] = out
+            while len(self._cache) > 3:
+                self._cache.popitem(last=False)
+        return out
+
+    def reshape(self, shape, order="C"):
+        """C-order reshape (reference core.py:1034-1111): the linear keys do not change, only
+        their split into coordinates; sortedness is preserved."""
+        shape = tuple(shape) if isinstance(shape, Iterable) else (shape,)
+        if order not in {"C", None}:
+            raise NotImplementedError("The `order` parameter is not supported")
+        if any(d == -1 for d in shape):
+            extra = int(self.size / max(1, prod(d for d in shape if d != -1)))
+            shape = tuple(d if d != -1 else extra for d in shape)
+        shape = tuple(int(d) for d in shape)
+        if self.size != prod(shape):
+            raise ValueError(f"cannot reshape array of size {self.size} into shape {shape}")
+        if self.shape == shape:
+            return self
+        if self._cache is not None and ("reshape", shape) in self._cache:
+            return self._cache[("reshape", shape)]
+        keys = self.linear_loc()
+        it = self.coords.dtype
+        if it == torch.int32 and shape and max(shape) >= 2 ** 31:
+            it = torch.int64
+        coords = K.delinearize(keys, shape, it)
+        out = COO(coords, self.data, shape=shape, has_duplicates=False, sorted=True, fill_value=self.fill_value)
+        out._keys = keys
+        if self._cache is not None:
+            self._cache[("reshape", shape)] = out
+            while len(self._cache) > 3:
+                self._cache.popitem(last=False)
+        return out
+
+    def flatten(self, order="C"):
+        return self.reshape(-1)
+
+    def __getitem__(self, index):
+        """Only the forms N-D `matmul` needs: `x[(None,) * k]` (new leading axes) and `x[i]`."""
+        if isinstance(index, tuple) and all(i is None for i in index):
+            k = len(index)
+            if k == 0:
+                return self
+            lead = torch.zeros((k, self.nnz), dtype=self.coords.dtype, device=self.device)
+            out = COO(torch.cat([lead, self.coords]), self.data, shape=(1,) * k + self.shape, has_duplicates=False,
+                      sorted=True, fill_value=self.fill_value)
+            out._keys = getattr(self, "_keys", None)
+            return out
+        if isinstance(index, (int, np.integer)):
+            from ._batched import take_leading
+
+            return take_leading(self, int(index))
+        raise NotImplementedError("general indexing is outside the hip backend's hot path (SURVEY.md §8f N2)")
+
+    # ---- format conversion -----------------------------------------------------------------------
+    def asformat(self, format, **kwargs):
+        from ._utils import convert_format
+
+        format = convert_format(format)
+        if format == "coo":
+            return self
+        if format == "gcxs":
+            from ._gcxs import GCXS
+
+            return GCXS.from_coo(self, **kwargs)
+        raise NotImplementedError(f"format {format!r} is not available in the hip backend")
+
+    def maybe_densify(self, max_size=1000, min_density=0.25):
+        if self.size <= max_size or self.density >= min_density:
+            return self.todense()
+        raise ValueError("Operation would require converting large sparse array to dense")
+
+    def dot(self, other):
+        from ._dot import dot
+
+        return dot(self, other)
+
+    def __matmul__(self, other):
+        from ._dot import matmul
+
+        try:
+            return matmul(self, other)
+        except NotImplementedError:
+            return NotImplemented
+
+    def __rmatmul__(self, other):
+        from ._dot import matmul
+
+        try:
+            return matmul(other, self)
+        except NotImplementedError:
+            return NotImplemented
 
 
-def as_coo(x, shape=None, fill_value=None, idx_dtype=None):
-    raise NotImplementedError
+def as_coo(x, shape=None, fill_value=None, idx_dtype=None, device=None):
+    """Convert to `COO` (reference `as_coo`, _coo/core.py)."""
+    from ._gcxs import GCXS
+
+    if isinstance(x, COO):
+        return x
+    if isinstance(x, GCXS):
+        return x.tocoo()
+    if isinstance(x, SparseArray):
+        return x.asformat("coo")
+    if isinstance(x, (np.ndarray, torch.Tensor)) or np.isscalar(x):
+        if shape is not None:
+            raise ValueError("Cannot get `shape` or `fill_value` from a dense array")
+        return COO.from_numpy(np.asarray(x) if np.isscalar(x) else x, fill_value=fill_value, idx_dtype=idx_dtype,
+                              device=device)
+    if _is_scipy_sparse(x):
+        return COO.from_scipy_sparse(x, device=device)
+    raise NotImplementedError(f"Format not supported for conversion. Supplied type is {type(x)}")

@@ -312,7 +312,7 @@ def _dot(a, b, return_type=None):
         return out.tocoo() if rk == "coo" else out
 
     if isinstance(a, COO) and isinstance(b, COO):
-        coords, data = K.dot_coo_coo(out_shape, a.coords, b.coords, a.data, b.data)
+        coords, data = K.dot_coo_coo(out_shape, a.coords, b.coords, a.data, b.data, a.shape[1])
         out = COO(coords, data, shape=out_shape, has_duplicates=False, sorted=True, prune=True)
         if rk == "ndarray":
             return io.out(out.todense_device())

@@ -12,7 +12,8 @@ LIB_PATH = os.path.join(_HERE, "_lib", "libsparse_amd.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sparse_amd.h")
 
 # dtype codes (include/sparse_amd.h)
-F32, F64, I32, I64, BF16 = 0, 1, 2, 3, 4
+F32, F64, I32, I64, BF16, U8 = 0, 1, 2, 3, 4, 5
+MAX_NDIM = 16
 EXACT_MULADD = 1
 
 _lib = None
@@ -46,6 +47,34 @@ _i64, _int, _vp, _u32 = _C.c_int64, _C.c_int, _C.c_void_p, _C.c_uint
 SIGNATURES = {
     "spamd_version": (_int, []),
     "spamd_target_arch": (_C.c_char_p, []),
+    "spamd_coo_linearize": (_int, [_int, _int, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "spamd_coo_delinearize": (_int, [_int, _int, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "spamd_permute_keys": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "spamd_keys_check": (_int, [_i64, _vp, _vp, _vp]),
+    "spamd_flag_heads": (_int, [_i64, _vp, _vp, _vp]),
+    "spamd_flag_ne_bits": (_int, [_int, _i64, _vp, _C.c_uint64, _vp, _vp]),
+    "spamd_compact": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "spamd_gather": (_int, [_int, _i64, _vp, _vp, _vp, _vp]),
+    "spamd_scatter": (_int, [_int, _i64, _vp, _vp, _vp, _vp]),
+    "spamd_keys_to_csr": (_int, [_int, _i64, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "spamd_csr_to_keys": (_int, [_int, _i64, _i64, _vp, _vp, _i64, _vp, _vp]),
+    "spamd_rows_to_indptr": (_int, [_int, _i64, _vp, _i64, _vp, _vp]),
+    "spamd_sort_pairs_ws_bytes": (_i64, [_i64]),
+    "spamd_sort_pairs": (_int, [_i64, _vp, _vp, _vp, _vp, _int, _vp, _i64, _vp]),
+    "spamd_iota": (_int, [_i64, _vp, _vp]),
+    "spamd_scan_ws_bytes": (_i64, [_i64]),
+    "spamd_exclusive_scan": (_int, [_i64, _vp, _vp, _vp, _i64, _vp]),
+    "spamd_convert": (_int, [_int, _int, _i64, _vp, _vp, _vp]),
+    "spamd_lower_bound_match": (_int, [_i64, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "spamd_invert_flags": (_int, [_i64, _vp, _vp, _vp]),
+    "spamd_union_positions": (_int, [_i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "spamd_fill": (_int, [_int, _i64, _vp, _C.c_uint64, _vp]),
+    "spamd_ewise_binary": (_int, [_int, _int, _i64, _vp, _int, _vp, _int, _vp, _vp]),
+    "spamd_ewise_unary": (_int, [_int, _int, _i64, _vp, _vp, _vp]),
+    "spamd_segment_reduce": (_int, [_int, _int, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "spamd_spgemm_count": (_int, [_int, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "spamd_spgemm_expand": (_int, [_int, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "spamd_sddmm": (_int, [_int, _int, _int, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp]),
     "spamd_has_nan": (_int, [_int, _i64, _vp, _vp, _vp]),
     "spamd_spmm_csr": (_int, [_int, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _u32, _vp]),
 }

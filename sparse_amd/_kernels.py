@@ -65,3 +65,464 @@ def has_nan(data):
     flag = torch.empty(1, dtype=torch.int32, device=dev)
     _ffi.call("spamd_has_nan", code_of(data.dtype), data.numel(), ptr(data), ptr(flag), stream_ptr(dev))
     return bool(flag.item())
+
+
+# ---------------------------------------------------------------------------------------------
+# key primitives (prims.hip): thin wrappers, one C-ABI call each
+# ---------------------------------------------------------------------------------------------
+import ctypes as _ct
+
+
+def _harr64(vals):
+    return (_ct.c_int64 * max(len(vals), 1))(*[int(v) for v in vals])
+
+
+def _harr32(vals):
+    return (_ct.c_int32 * max(len(vals), 1))(*[int(v) for v in vals])
+
+
+def c_strides(shape):
+    """C-order element strides of `shape` (host ints)."""
+    st, acc = [], 1
+    for d in reversed(shape):
+        st.append(acc)
+        acc *= int(d)
+    return list(reversed(st))
+
+
+def _check_ndim(n):
+    if n > _ffi.MAX_NDIM:
+        raise NotImplementedError(f"arrays with more than {_ffi.MAX_NDIM} dimensions are not supported by the hip backend")
+
+
+def _key_bits(max_key):
+    return max(1, int(max_key).bit_length())
+
+
+def index_dtype_ok(t):
+    return t.dtype in (torch.int32, torch.int64)
+
+
+def linearize(coords, shape, axis_order=None):
+    """C-order keys of `coords[axis_order]` w.r.t. `shape[axis_order]` — `linear_loc`
+    (reference _coo/common.py:56-64)."""
+    dev = require_hip(coords)
+    ndim, nnz = int(coords.shape[0]), int(coords.shape[1])
+    _check_ndim(ndim)
+    order = list(range(ndim)) if axis_order is None else [int(a) for a in axis_order]
+    rshape = [int(shape[a]) for a in order]
+    keys = torch.empty(nnz, dtype=torch.int64, device=dev)
+    if ndim == 0 or nnz == 0:
+        return keys.zero_()
+    coords = coords.contiguous()
+    _ffi.call("spamd_coo_linearize", code_of(coords.dtype), ndim, nnz, ptr(coords), nnz,
+              _harr64(c_strides(rshape)), _harr32(order), ptr(keys), stream_ptr(dev))
+    return keys
+
+
+def delinearize(keys, shape, idx_dtype=torch.int64):
+    """keys -> coords[ndim, nnz] for `shape` (the div/mod chain of reference core.py:1090-1098)."""
+    dev = require_hip(keys)
+    ndim, nnz = len(shape), int(keys.numel())
+    _check_ndim(ndim)
+    coords = torch.empty((ndim, nnz), dtype=idx_dtype, device=dev)
+    if ndim and nnz:
+        _ffi.call("spamd_coo_delinearize", code_of(idx_dtype), ndim, nnz, ptr(keys), _harr64(c_strides(shape)),
+                  _harr64(shape), ptr(coords), nnz, stream_ptr(dev))
+    return coords
+
+
+def permute_keys(keys, src_shape, perm):
+    """Keys of the array transposed with `axes=perm` (destination axis d <- source axis perm[d])."""
+    dev = require_hip(keys)
+    ndim = len(src_shape)
+    _check_ndim(ndim)
+    if list(perm) == list(range(ndim)) or keys.numel() == 0:
+        return keys
+    out = torch.empty_like(keys)
+    _ffi.call("spamd_permute_keys", ndim, keys.numel(), ptr(keys), _harr64(c_strides(src_shape)),
+              _harr64(src_shape), _harr32(perm), ptr(out), stream_ptr(dev))
+    return out
+
+
+def keys_check(keys):
+    """(not_sorted, has_duplicates) of a key array — the `np.diff(linear)` checks of reference
+    core.py:1310-1313,1331-1338.  Synchronises (8 bytes copied back)."""
+    dev = require_hip(keys)
+    if keys.numel() < 2:
+        return False, False
+    flags = torch.empty(2, dtype=torch.int32, device=dev)
+    _ffi.call("spamd_keys_check", keys.numel(), ptr(keys), ptr(flags), stream_ptr(dev))
+    f = flags.tolist()
+    return bool(f[0]), bool(f[1])
+
+
+def sort_keys(keys, max_key):
+    """Stable sort of int64 keys in [0, max_key]; returns (sorted_keys, perm) with
+    sorted_keys == keys[perm] — `np.argsort(kind="mergesort")` (reference core.py:1315)."""
+    dev = require_hip(keys)
+    n = int(keys.numel())
+    if n == 0:
+        return keys, torch.empty(0, dtype=torch.int64, device=dev)
+    iota = torch.empty(n, dtype=torch.int64, device=dev)
+    _ffi.call("spamd_iota", n, ptr(iota), stream_ptr(dev))
+    ws_bytes = int(_ffi.lib().spamd_sort_pairs_ws_bytes(n))
+    if ws_bytes < 0:
+        raise _ffi.HipBackendError(f"spamd_sort_pairs_ws_bytes failed: {ws_bytes}")
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    ko, po = torch.empty_like(keys), torch.empty_like(iota)
+    _ffi.call("spamd_sort_pairs", n, ptr(keys.contiguous()), ptr(ko), ptr(iota), ptr(po), _key_bits(max_key),
+              ptr(ws), ws_bytes, stream_ptr(dev))
+    return ko, po
+
+
+def exclusive_scan(flags):
+    """`flags` holds n+1 int64 entries (the last is ignored); returns offsets[n+1] with
+    offsets[n] = total."""
+    dev = require_hip(flags)
+    n = int(flags.numel()) - 1
+    out = torch.empty_like(flags)
+    ws_bytes = int(_ffi.lib().spamd_scan_ws_bytes(n))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+    _ffi.call("spamd_exclusive_scan", n, ptr(flags), ptr(out), ptr(ws), ws_bytes, stream_ptr(dev))
+    return out
+
+
+def new_flags(n, dev):
+    """int64[n+1] flag buffer for flag_* -> exclusive_scan -> compact."""
+    return torch.empty(n + 1, dtype=torch.int64, device=dev)
+
+
+def flag_heads(keys):
+    dev = require_hip(keys)
+    f = new_flags(keys.numel(), dev)
+    _ffi.call("spamd_flag_heads", keys.numel(), ptr(keys), ptr(f), stream_ptr(dev))
+    return f
+
+
+def flag_ne_bits(data, fill_value):
+    """flags[i] = data[i] is not bit-identical to fill_value (reference `equivalent` without
+    `loose`, _utils.py:448-452)."""
+    dev = require_hip(data)
+    f = new_flags(data.numel(), dev)
+    npdt = np_dtype(data.dtype)
+    bits = int(np.asarray(fill_value, dtype=npdt).reshape(1).view(f"u{npdt.itemsize}")[0])
+    _ffi.call("spamd_flag_ne_bits", data.element_size(), data.numel(), ptr(data.contiguous()), bits, ptr(f),
+              stream_ptr(dev))
+    return f
+
+
+def compact(src, flags, offsets, count):
+    """Stream compaction of a 1-D tensor or of every row of a 2-D [k, n] tensor."""
+    dev = require_hip(src)
+    n = int(src.shape[-1])
+    if src.dim() == 1:
+        dst = torch.empty(count, dtype=src.dtype, device=dev)
+        _ffi.call("spamd_compact", src.element_size(), n, ptr(src.contiguous()), ptr(flags), ptr(offsets), ptr(dst),
+                  stream_ptr(dev))
+        return dst
+    src = src.contiguous()
+    dst = torch.empty((src.shape[0], count), dtype=src.dtype, device=dev)
+    for r in range(src.shape[0]):
+        _ffi.call("spamd_compact", src.element_size(), n, ptr(src[r]), ptr(flags), ptr(offsets), ptr(dst[r]),
+                  stream_ptr(dev))
+    return dst
+
+
+def gather(src, perm):
+    """src[..., perm] for 1-D or [k, n] tensors."""
+    dev = require_hip(src, perm)
+    n = int(perm.numel())
+    if src.dim() == 1:
+        dst = torch.empty(n, dtype=src.dtype, device=dev)
+        _ffi.call("spamd_gather", src.element_size(), n, ptr(src.contiguous()), ptr(perm), ptr(dst), stream_ptr(dev))
+        return dst
+    src = src.contiguous()
+    dst = torch.empty((src.shape[0], n), dtype=src.dtype, device=dev)
+    for r in range(src.shape[0]):
+        _ffi.call("spamd_gather", src.element_size(), n, ptr(src[r]), ptr(perm), ptr(dst[r]), stream_ptr(dev))
+    return dst
+
+
+def scatter_into(dst_flat, keys, src):
+    dev = require_hip(dst_flat, keys, src)
+    _ffi.call("spamd_scatter", src.element_size(), keys.numel(), ptr(src.contiguous()), ptr(keys), ptr(dst_flat),
+              stream_ptr(dev))
+    return dst_flat
+
+
+def keys_to_csr(keys, R, C, idx_dtype):
+    dev = require_hip(keys)
+    nnz = int(keys.numel())
+    indptr = torch.empty(R + 1, dtype=idx_dtype, device=dev)
+    indices = torch.empty(nnz, dtype=idx_dtype, device=dev)
+    _ffi.call("spamd_keys_to_csr", code_of(idx_dtype), nnz, ptr(keys), R, C, ptr(indptr), ptr(indices), stream_ptr(dev))
+    return indptr, indices
+
+
+def csr_to_keys(indptr, indices, R, C):
+    dev = require_hip(indptr, indices)
+    (indptr, indices), it = _unify_index(indptr.contiguous(), indices.contiguous())
+    nnz = int(indices.numel())
+    keys = torch.empty(nnz, dtype=torch.int64, device=dev)
+    _ffi.call("spamd_csr_to_keys", code_of(it), R, nnz, ptr(indptr), ptr(indices), C, ptr(keys), stream_ptr(dev))
+    return keys
+
+
+def rows_to_indptr(rows, R):
+    """int64 indptr of sorted row ids (`cumsum(bincount(coords[0]))`, reference _common.py:452-458)."""
+    dev = require_hip(rows)
+    if not index_dtype_ok(rows):
+        rows = rows.to(torch.int64)
+    indptr = torch.empty(R + 1, dtype=torch.int64, device=dev)
+    _ffi.call("spamd_rows_to_indptr", code_of(rows.dtype), rows.numel(), ptr(rows.contiguous()), R, ptr(indptr),
+              stream_ptr(dev))
+    return indptr
+
+
+_CODE_T = {torch.float32: _ffi.F32, torch.float64: _ffi.F64, torch.int32: _ffi.I32, torch.int64: _ffi.I64,
+           torch.bool: _ffi.U8, torch.uint8: _ffi.U8}
+
+
+def convert(t, dtype):
+    """astype on the device between float32/float64/int32/int64/bool."""
+    dtype = torch_dtype(dtype)
+    if t.dtype == dtype:
+        return t
+    dev = require_hip(t)
+    if t.dtype not in _CODE_T or dtype not in _CODE_T:
+        raise TypeError(f"hip backend cannot convert {t.dtype} -> {dtype}")
+    out = torch.empty(t.shape, dtype=dtype, device=dev)
+    _ffi.call("spamd_convert", _CODE_T[t.dtype], _CODE_T[dtype], t.numel(), ptr(t.contiguous()), ptr(out),
+              stream_ptr(dev))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# the rest of the `_dot_*` kernel family (reference _common.py:758-1158), built on the kernels above
+# ---------------------------------------------------------------------------------------------
+def _csc_to_csr(a_shape, a_data, a_indices, a_indptr):
+    """(M x K) stored by columns -> CSR arrays.  Stable: within a row the columns ascend, so
+    the CSR product accumulates in the same k order as the reference's column sweep."""
+    M, Kd = int(a_shape[0]), int(a_shape[1])
+    keys = csr_to_keys(a_indptr, a_indices, Kd, M)          # col * M + row
+    keys = permute_keys(keys, (Kd, M), (1, 0))              # row * K + col
+    keys, perm = sort_keys(keys, max(M * Kd - 1, 1))
+    it = a_indices.dtype if index_dtype_ok(a_indices) else torch.int64
+    indptr, indices = keys_to_csr(keys, M, Kd, it)
+    return gather(a_data, perm), indices, indptr
+
+
+def dot_csc_ndarray(a_shape, b_shape, a_data, a_indices, a_indptr, b, *, exact=False):
+    """C = A @ B with A stored by columns — `_dot_csc_ndarray` (reference _common.py:869-904).
+    The reference scatters `out[ind, :] += v * b[i, :]` column by column; here A is re-compressed
+    by rows on the device (a stable key sort) and the CSR kernel is used: same per-element
+    summation order, no atomics, deterministic."""
+    data, indices, indptr = _csc_to_csr(a_shape, a_data, a_indices, a_indptr)
+    return dot_csr_ndarray((int(a_shape[0]), int(b_shape[1])), data, indices, indptr, b, exact=exact)
+
+
+def dot_coo_ndarray(coords, data, b, out_shape, *, exact=False):
+    """C = S @ B, S a row-sorted 2-D COO — `_dot_coo_ndarray` (reference _common.py:979-1014).
+    Takes B itself (K x N); the reference kernel receives the transposed view."""
+    M = int(out_shape[0])
+    indptr = rows_to_indptr(coords[0], M)
+    cols = coords[1]
+    return dot_csr_ndarray(out_shape, data, cols, indptr, b, exact=exact)
+
+
+def dot_ndarray_coo(a, coords, data, out_shape, *, exact=False):
+    """C = A @ S, A dense (M x K), S 2-D COO (K x N) — `_dot_ndarray_coo`
+    (reference _common.py:1075-1103), computed as (S^T @ A^T)^T with S^T compressed by rows."""
+    M, N = int(out_shape[0]), int(out_shape[1])
+    Kd = int(a.shape[1])
+    keys = linearize(coords, (Kd, N), axis_order=(1, 0))    # col * K + row
+    keys, perm = sort_keys(keys, max(Kd * N - 1, 1))
+    it = coords.dtype if index_dtype_ok(coords) else torch.int64
+    indptr, indices = keys_to_csr(keys, N, Kd, it)
+    res = dot_csr_ndarray((N, M), gather(data, perm), indices, indptr, a.t().contiguous(), exact=exact)
+    return res.t()
+
+
+def _sparsify(dense, struct_mask=None, numeric=False):
+    """Dense 2-D tensor -> (keys, data) of the entries to store.  `struct_mask` (same shape, any
+    dtype, nonzero = structurally present) restricts them; `numeric=True` keeps value != 0
+    (the COO variants' `if data_curr != 0`), otherwise bit-pattern != +0 (GCXS prune)."""
+    flat = dense.reshape(-1).contiguous()
+    if numeric:
+        from ._umath import binary_arrays
+
+        nz = binary_arrays("not_equal", flat, torch.zeros(1, dtype=flat.dtype, device=flat.device), b_scalar=True)
+        flags = flag_ne_bits(nz.view(torch.uint8), 0)
+    else:
+        flags = flag_ne_bits(flat, 0)
+    if struct_mask is not None:
+        from ._umath import binary_arrays
+
+        sm = flag_ne_bits(struct_mask.reshape(-1).contiguous(), 0)
+        flags = binary_arrays("multiply", flags, sm)
+    offs = exclusive_scan(flags)
+    cnt = int(offs[-1])
+    n = flat.numel()
+    iota = torch.empty(n, dtype=torch.int64, device=flat.device)
+    _ffi.call("spamd_iota", n, ptr(iota), stream_ptr(flat.device))
+    return compact(iota, flags, offs, cnt), compact(flat, flags, offs, cnt)
+
+
+def _pattern_product(out_shape, a_indices, a_indptr, b, csc_shape=None):
+    """Structural non-zero test of the reference's sparse-returning variants: entry (i, j) is
+    stored iff some b[k, j] != 0 with k in row i of A (_common.py:796-798, 843-844)."""
+    from ._umath import binary_arrays
+
+    bz = binary_arrays("not_equal", b.reshape(-1).contiguous(), torch.zeros(1, dtype=b.dtype, device=b.device),
+                       b_scalar=True)
+    bz = convert(bz, torch.float32).reshape(b.shape)
+    ones = torch.ones(a_indices.numel(), dtype=torch.float32, device=b.device)
+    if csc_shape is None:
+        return dot_csr_ndarray(out_shape, ones, a_indices, a_indptr, bz)
+    return dot_csc_ndarray(csc_shape, tuple(b.shape), ones, a_indices, a_indptr, bz)
+
+
+def dot_csr_ndarray_sparse(out_shape, a_data, a_indices, a_indptr, b):
+    """CSR @ dense returned as CSR (data, indices, indptr[int64]) — `_dot_csr_ndarray_sparse`
+    (reference _common.py:758-804) after the GCXS constructor's prune."""
+    dense = dot_csr_ndarray(out_shape, a_data, a_indices, a_indptr, b, exact=True)
+    mask = _pattern_product(out_shape, a_indices, a_indptr, b.to(dense.dtype) if b.dtype != dense.dtype else b)
+    keys, data = _sparsify(dense, mask)
+    indptr, indices = keys_to_csr(keys, int(out_shape[0]), int(out_shape[1]), torch.int64)
+    return data, indices, indptr
+
+
+def dot_csc_ndarray_sparse(a_shape, b_shape, a_data, a_indices, a_indptr, b):
+    """CSC @ dense returned compressed by COLUMNS — `_dot_csc_ndarray_sparse`
+    (reference _common.py:807-866)."""
+    M, N = int(a_shape[0]), int(b_shape[1])
+    dense = dot_csc_ndarray(a_shape, b_shape, a_data, a_indices, a_indptr, b, exact=True)
+    mask = _pattern_product((M, N), a_indices, a_indptr, b.to(dense.dtype) if b.dtype != dense.dtype else b,
+                            csc_shape=a_shape)
+    keys, data = _sparsify(dense.t().contiguous(), mask.t().contiguous())  # column-major keys: col*M + row
+    indptr, indices = keys_to_csr(keys, N, M, torch.int64)
+    return data, indices, indptr
+
+
+def dot_coo_ndarray_sparse(coords, data, b, out_shape):
+    """COO @ dense returned as COO (coords, data) — reference _common.py:1017-1072."""
+    dense = dot_coo_ndarray(coords, data, b, out_shape, exact=True)
+    keys, vals = _sparsify(dense, numeric=True)
+    return delinearize(keys, tuple(int(s) for s in out_shape), torch.int64), vals
+
+
+def dot_ndarray_coo_sparse(a, coords, data, out_shape):
+    """dense @ COO returned as COO — reference _common.py:1106-1158."""
+    dense = dot_ndarray_coo(a, coords, data, out_shape, exact=True).contiguous()
+    keys, vals = _sparsify(dense, numeric=True)
+    return delinearize(keys, tuple(int(s) for s in out_shape), torch.int64), vals
+
+
+SPGEMM_CHUNK_PRODUCTS = 1 << 27  # products expanded/sorted at a time (bounds workspace to ~5 GB)
+
+
+def _spgemm_keys(n_row, n_col, a_data, a_indices, a_rows, b_data, b_indices, b_indptr):
+    """Expand-sort-compress over row chunks; returns (keys, data) sorted by row*n_col + col with
+    every output element summed in the reference's order."""
+    from ._reduce import segment_reduce
+
+    dev = require_hip(a_data, b_data)
+    dtr = torch_dtype(dot_dtype(a_data.dtype, b_data.dtype))
+    vcode = code_of(dtr)
+    a_data = a_data.to(dtr).contiguous() if a_data.dtype != dtr else a_data.contiguous()
+    b_data = b_data.to(dtr).contiguous() if b_data.dtype != dtr else b_data.contiguous()
+    (a_indices, b_indices, b_indptr), it = _unify_index(a_indices.contiguous(), b_indices.contiguous(),
+                                                        b_indptr.contiguous())
+    nnz_a = int(a_indices.numel())
+    s = stream_ptr(dev)
+    out_keys, out_vals = [], []
+    if nnz_a == 0:
+        return torch.empty(0, dtype=torch.int64, device=dev), torch.empty(0, dtype=dtr, device=dev)
+    cnt = torch.empty(nnz_a + 1, dtype=torch.int64, device=dev)
+    _ffi.call("spamd_spgemm_count", code_of(it), 0, nnz_a, ptr(a_indices), ptr(b_indptr), ptr(cnt), s)
+    offs_all = exclusive_scan(cnt)
+    total = int(offs_all[-1])
+    # chunk boundaries on A elements so that each chunk expands <= SPGEMM_CHUNK_PRODUCTS products;
+    # a chunk always ends on a ROW boundary of A so that no output element is split
+    p = 0
+    row_ends = None
+    while p < nnz_a:
+        if total - int(offs_all[p]) <= SPGEMM_CHUNK_PRODUCTS:
+            q = nnz_a
+        else:
+            target = int(offs_all[p]) + SPGEMM_CHUNK_PRODUCTS
+            q = int(torch.searchsorted(offs_all, torch.tensor([target], device=dev), right=True)[0]) - 1
+            q = max(q, p + 1)
+            # advance q to the end of the row that element q-1 belongs to
+            r = int(a_rows[q - 1])
+            q = int(torch.searchsorted(a_rows, torch.tensor([r], device=dev), right=True)[0])
+        P = int(offs_all[q]) - int(offs_all[p])
+        if P:
+            offs = (offs_all[p:q + 1] - offs_all[p]).contiguous()
+            keys = torch.empty(P, dtype=torch.int64, device=dev)
+            vals = torch.empty(P, dtype=dtr, device=dev)
+            _ffi.call("spamd_spgemm_expand", vcode, code_of(it), p, q - p, ptr(a_data), ptr(a_indices), ptr(a_rows),
+                      ptr(b_data), ptr(b_indices), ptr(b_indptr), ptr(offs), P, n_col, ptr(keys), ptr(vals), s)
+            keys, perm = sort_keys(keys, max(n_row * n_col - 1, 1))
+            vals = gather(vals, perm)
+            heads = flag_heads(keys)
+            ho = exclusive_scan(heads)
+            c = int(ho[-1])
+            out_vals.append(segment_reduce(vals, heads, ho, c, "add"))
+            out_keys.append(compact(keys, heads, ho, c))
+        p = q
+    if not out_keys:
+        return torch.empty(0, dtype=torch.int64, device=dev), torch.empty(0, dtype=dtr, device=dev)
+    return (torch.cat(out_keys), torch.cat(out_vals)) if len(out_keys) > 1 else (out_keys[0], out_vals[0])
+
+
+def dot_csr_csr(out_shape, a_data, b_data, a_indices, b_indices, a_indptr, b_indptr):
+    """CSR @ CSR -> (data, indices, indptr) with int64 indices — `_dot_csr_csr`
+    (reference _common.py:639-717).  Explicit zeros are kept (the GCXS constructor prunes)."""
+    n_row, n_col = int(out_shape[0]), int(out_shape[1])
+    a_rows = csr_to_keys(a_indptr, torch.zeros_like(a_indices), n_row, 1)  # row id of every A element
+    keys, data = _spgemm_keys(n_row, n_col, a_data, a_indices, a_rows, b_data, b_indices, b_indptr)
+    indptr, indices = keys_to_csr(keys, n_row, n_col, torch.int64)
+    return data, indices, indptr
+
+
+def dot_coo_coo(out_shape, a_coords, b_coords, a_data, b_data, n_inner):
+    """COO @ COO -> (coords[2, nnz] int64, data), sorted — `_dot_coo_coo` + the indptr
+    construction of reference _common.py:450-475,907-976.  `n_inner` = a.shape[1] = b.shape[0]."""
+    n_row, n_col = int(out_shape[0]), int(out_shape[1])
+    b_indptr = rows_to_indptr(b_coords[0], int(n_inner))
+    a_rows = convert(a_coords[0].contiguous(), torch.int64)
+    keys, data = _spgemm_keys(n_row, n_col, a_data, a_coords[1], a_rows, b_data, b_coords[1], b_indptr)
+    return delinearize(keys, (n_row, n_col), torch.int64), data
+
+
+def sddmm_coo(coords, s_data, a, bt):
+    """out[n] = s[n] * <a[i_n, :], bt[j_n, :]> for a 2-D COO mask — the sampled product the
+    reference writes as `s * (a @ b)` (examples/sddmm_example.py:51-52)."""
+    dev = require_hip(coords, s_data, a, bt)
+    nnz = int(s_data.numel())
+    if a.dtype != bt.dtype:
+        raise TypeError("a and bt must share a dtype")
+    if a.dtype == torch.bfloat16 or a.dtype == torch.float32:
+        sdt = torch.float32
+    elif a.dtype == torch.float64:
+        sdt = torch.float64
+    else:
+        raise TypeError(f"sddmm supports bfloat16/float32/float64 dense operands, got {a.dtype}")
+    s_data = s_data.to(sdt).contiguous()
+    a, bt = a.contiguous(), bt.contiguous()
+    if a.shape[1] != bt.shape[1]:
+        raise ValueError("shape-mismatch for sum")
+    esz = a.element_size()
+    if (a.shape[1] * esz) % 16:
+        pad = (16 - (a.shape[1] * esz) % 16) // esz  # row pitch must be 16-byte aligned
+        a = torch.nn.functional.pad(a, (0, pad))
+        bt = torch.nn.functional.pad(bt, (0, pad))
+    rows, cols = coords[0].contiguous(), coords[1].contiguous()
+    if not index_dtype_ok(rows):
+        rows, cols = rows.to(torch.int64), cols.to(torch.int64)
+    out = torch.empty(nnz, dtype=sdt, device=dev)
+    _ffi.call("spamd_sddmm", code_of(a.dtype), code_of(sdt), code_of(rows.dtype), nnz, ptr(rows), ptr(cols),
+              ptr(s_data), ptr(a), a.stride(0), ptr(bt), bt.stride(0), int(a.shape[1]), ptr(out), stream_ptr(dev))
+    return out

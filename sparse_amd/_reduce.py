@@ -1,0 +1,144 @@
+"""A8: ufunc reductions with implicit fill values (reference `SparseArray.reduce`,
+sparse/numba_backend/_sparse_array.py:372-437; `COO._reduce_calc/_reduce_return`,
+_coo/core.py:693-723; `_grouped_reduce`, :1631-1661; Appendix D5).
+
+Host logic in Python, arithmetic on the device: kept axes are moved first by a key
+permutation, groups are runs of `key // n_cols`, each run is reduced by
+`spamd_segment_reduce`, the fold-in of the implicit fill entries is a few elementwise passes.
+"""
+import numpy as np
+import torch
+
+from . import _ffi
+from . import _kernels as K
+from ._device import code_of, np_dtype, ptr, require_hip, stream_ptr, torch_dtype
+from ._utils import equivalent, normalize_axis, prod
+
+_RED_OPS = {"add": 0, "multiply": 1, "maximum": 2, "minimum": 3, "logical_or": 4, "logical_and": 5}
+_SUPER = {"add": np.multiply, "multiply": np.power}
+
+
+def segment_reduce(data, heads, offs, count, op, want_counts=False):
+    """Reduce every run of `data` delimited by `heads` (int64 flags, n+1 entries) with `op`."""
+    dev = require_hip(data)
+    n = int(data.numel())
+    if data.dtype == torch.bool:
+        data = data.view(torch.uint8)
+    out = torch.empty(count, dtype=data.dtype, device=dev)
+    counts = torch.empty(count, dtype=torch.int64, device=dev) if want_counts else None
+    ws = torch.empty(count + 1, dtype=torch.int64, device=dev) if (count and n // max(count, 1) >= 128) else None
+    code = _ffi.U8 if data.dtype == torch.uint8 else code_of(data.dtype)
+    _ffi.call("spamd_segment_reduce", _RED_OPS[op], code, n, ptr(data.contiguous()), ptr(heads), ptr(offs), count,
+              ptr(out), ptr(counts), ptr(ws), stream_ptr(dev))
+    return (out, counts) if want_counts else out
+
+
+def _scalar_dev(value, dtype, dev):
+    return torch.tensor([value], dtype=dtype, device=dev)
+
+
+def reduce_impl(x, method, axis=(0,), keepdims=False, **kwargs):
+    from ._coo import COO
+    from ._gcxs import GCXS
+    from ._umath import binary_arrays, select
+
+    name = getattr(method, "__name__", str(method))
+    if name not in _RED_OPS:
+        raise NotImplementedError(f"reduction with {method!s} is not on the hip backend's path "
+                                  f"(supported: {sorted(_RED_OPS)})")
+    out_gcxs = isinstance(x, GCXS)
+    if out_gcxs:
+        x = x.tocoo()
+    dtype = kwargs.pop("dtype", None)
+    kwargs.pop("out", None)
+    if kwargs:
+        raise NotImplementedError(f"unsupported reduce kwargs {sorted(kwargs)}")
+    axis = normalize_axis(axis, x.ndim)
+    fv = x.fill_value
+    zero_reduce_result = method.reduce([fv, fv]) if dtype is None else method.reduce([fv, fv], dtype=dtype)
+    super_ufunc = _SUPER.get(name)
+    if not equivalent(zero_reduce_result, fv) and super_ufunc is None:
+        raise ValueError(f"Performing this reduction operation would produce a dense result: {method!s}")
+    if not isinstance(axis, tuple):
+        axis = (axis,)
+    if axis == (None,):
+        axis = tuple(range(x.ndim))
+    kept = tuple(ax for ax in range(x.ndim) if ax not in set(axis))
+    n_groups = prod(x.shape[d] for d in kept)
+    n_cols = prod(x.shape[d] for d in axis)
+    dev = x.device
+
+    data = x.data
+    if name in ("logical_or", "logical_and"):
+        data = K.convert(data, torch.bool)
+        res_np_dtype = np.dtype(bool)
+    else:
+        res_np_dtype = np.dtype(dtype) if dtype is not None else (
+            method.reduce(np.zeros(1, dtype=x.dtype)).dtype if x.dtype.kind != "b" else np.dtype(bool))
+        if x.dtype.kind == "b" and name in ("add", "multiply") and dtype is None:
+            res_np_dtype = np.add.reduce(np.zeros(1, dtype=bool)).dtype
+        data = K.convert(data, torch_dtype(res_np_dtype))
+    if data.dtype == torch.bool:
+        data = data.view(torch.uint8)
+
+    # move kept axes first (key permutation + stable sort), group id = key // n_cols
+    keys = x.linear_loc()
+    order = kept + tuple(axis)
+    if order != tuple(range(x.ndim)) and x.nnz:
+        keys = K.permute_keys(keys, x.shape, order)
+        keys, perm = K.sort_keys(keys, max(x.size - 1, 1))
+        data = K.gather(data, perm)
+    if x.nnz:
+        gk = binary_arrays("floor_divide_i64", keys, _scalar_dev(max(n_cols, 1), torch.int64, dev), b_scalar=True)
+        heads = K.flag_heads(gk)
+        offs = K.exclusive_scan(heads)
+        count = int(offs[-1])
+        vals, counts = segment_reduce(data, heads, offs, count, name, want_counts=True)
+        gids = K.compact(gk, heads, offs, count)
+    else:
+        count = 0
+        vals = data[:0]
+        counts = torch.empty(0, dtype=torch.int64, device=dev)
+        gids = torch.empty(0, dtype=torch.int64, device=dev)
+
+    result_fill = np.asarray(fv).astype(res_np_dtype)[()] if name not in ("logical_or", "logical_and") else np.bool_(fv)
+    if count:
+        ncols_t = _scalar_dev(n_cols, torch.int64, dev)
+        if super_ufunc is None:
+            # groups with implicit fill entries fold the fill value in once (reference :405-408)
+            missing = binary_arrays("not_equal", counts, ncols_t, b_scalar=True)
+            fvt = _scalar_dev(result_fill.item(), vals.dtype if vals.dtype != torch.uint8 else torch.uint8, dev)
+            folded = binary_arrays(name, vals, fvt, b_scalar=True)
+            vals = select(missing, folded, vals)
+        else:
+            # add / multiply closed form (reference :409-422)
+            n_fill = binary_arrays("subtract", ncols_t, counts, a_scalar=True)
+            work_np = np.result_type(res_np_dtype, np.float64) if res_np_dtype.kind == "f" else res_np_dtype
+            nf = K.convert(n_fill, torch_dtype(work_np))
+            fvw = _scalar_dev(np.asarray(fv).astype(work_np).item(), torch_dtype(work_np), dev)
+            contrib = binary_arrays("multiply" if name == "add" else "power", fvw, nf, a_scalar=True)
+            ident = _scalar_dev(method.identity, torch_dtype(work_np), dev)
+            is_zero = binary_arrays("equal", n_fill, _scalar_dev(0, torch.int64, dev), b_scalar=True)
+            contrib = select(is_zero, ident.expand(count).contiguous(), contrib)
+            vw = K.convert(vals, torch_dtype(work_np))
+            vals = K.convert(binary_arrays(name, vw, contrib), vals.dtype)
+    if super_ufunc is not None:
+        with np.errstate(all="ignore"):
+            result_fill = np.asarray(super_ufunc(fv, n_cols)).astype(res_np_dtype)[()]
+
+    if vals.dtype == torch.uint8 and res_np_dtype == np.dtype(bool):
+        vals = vals.view(torch.bool)
+    out = COO(gids[None, :], vals, shape=(n_groups,), has_duplicates=False, sorted=True, prune=True,
+              fill_value=result_fill)
+    out = out.reshape(tuple(x.shape[d] for d in kept))
+    if keepdims:
+        shape = list(x.shape)
+        for ax in axis:
+            shape[ax] = 1
+        out = out.reshape(shape)
+    if out.ndim == 0:
+        # 0-d result: the value becomes the fill value of an nnz=0 array (reference :432-435)
+        return COO.from_numpy(out.todense_device())
+    if out_gcxs:
+        return out.asformat("gcxs")
+    return out

@@ -1,0 +1,303 @@
+"""A7: `elemwise` — N-ary elementwise functions over sparse operands (reference
+sparse/numba_backend/_umath.py:13-50,392-751).
+
+The reference handles arbitrary Python callables by enumerating presence masks and joining
+coordinates per mask.  On canonical operands that collapses to a sorted-key union (see
+csrc/ewise.hip); this module implements that HIP path for NumPy ufuncs over
+{sparse (x) sparse (same shape), sparse (x) scalar, sparse (x) same-shape dense, unary}, with the
+reference's fill-value rules (result fill = func(fills); stored results bit-equal to it are
+pruned; non-zero operand fills are honoured).  Anything else raises NotImplementedError —
+there is deliberately no host fallback.
+"""
+import numpy as np
+import torch
+
+from . import _device as dev
+from . import _ffi
+from . import _kernels as K
+from ._device import code_of, ptr, require_hip, stream_ptr, torch_dtype
+from ._utils import equivalent
+
+# NumPy ufunc name -> (kind, C-ABI op code)   (codes: include/sparse_amd.h)
+_BIN = {"add": 0, "subtract": 1, "multiply": 2, "divide": 3, "true_divide": 3, "maximum": 4, "minimum": 5,
+        "power": 6, "fmax": 7, "fmin": 8, "greater": 32, "greater_equal": 33, "less": 34, "less_equal": 35,
+        "equal": 36, "not_equal": 37, "logical_and": 38, "logical_or": 39, "logical_xor": 40,
+        "bitwise_and": 64, "bitwise_or": 65, "bitwise_xor": 66}
+_UN = {"negative": 0, "absolute": 1, "abs": 1, "fabs": 1, "sqrt": 2, "exp": 3, "expm1": 4, "log": 5, "log1p": 6,
+       "sin": 7, "cos": 8, "tan": 9, "tanh": 10, "sinh": 11, "cosh": 12, "arcsin": 13, "arctan": 14, "floor": 15,
+       "ceil": 16, "rint": 17, "trunc": 18, "sign": 19, "square": 20, "reciprocal": 21, "positive": 22, "log2": 23,
+       "log10": 24, "exp2": 25, "arcsinh": 26, "arctanh": 27, "cbrt": 28, "deg2rad": 29, "radians": 29,
+       "rad2deg": 30, "degrees": 30, "isnan": 64, "isinf": 65, "isfinite": 66, "logical_not": 67, "signbit": 68,
+       "conjugate": 22, "conj": 22, "real": 22}
+_TO_BOOL_BIN = set(range(32, 41))
+_CODE = {torch.float32: _ffi.F32, torch.float64: _ffi.F64, torch.int32: _ffi.I32, torch.int64: _ffi.I64,
+         torch.uint8: _ffi.U8, torch.bool: _ffi.U8}
+
+
+def _as_u8(t):
+    return t.view(torch.uint8) if t.dtype == torch.bool else t
+
+
+def binary_arrays(name, a, b, a_scalar=False, b_scalar=False, out_bool_as=torch.bool):
+    """out = a (op) b on equal-length device arrays (or a 1-element array broadcast as scalar)."""
+    if name == "floor_divide_i64":  # non-negative int64 keys: truncation == floor
+        code, name = 3, "divide"
+    else:
+        code = _BIN[name]
+    devi = require_hip(a, b)
+    a, b = _as_u8(a.contiguous()), _as_u8(b.contiguous())
+    if a.dtype != b.dtype:
+        raise TypeError(f"binary_arrays needs one compute dtype, got {a.dtype} and {b.dtype}")
+    n = int(b.numel() if a_scalar else a.numel())
+    out_dtype = torch.uint8 if code in _TO_BOOL_BIN else a.dtype
+    out = torch.empty(n, dtype=out_dtype, device=devi)
+    _ffi.call("spamd_ewise_binary", code, _CODE[a.dtype], n, ptr(a), int(a_scalar), ptr(b), int(b_scalar), ptr(out),
+              stream_ptr(devi))
+    return out.view(torch.bool) if (code in _TO_BOOL_BIN and out_bool_as == torch.bool) else out
+
+
+def unary_array(name, a):
+    code = _UN[name]
+    devi = require_hip(a)
+    a = _as_u8(a.contiguous())
+    out = torch.empty(a.numel(), dtype=torch.uint8 if code >= 64 else a.dtype, device=devi)
+    _ffi.call("spamd_ewise_unary", code, _CODE[a.dtype], a.numel(), ptr(a), ptr(out), stream_ptr(devi))
+    return out.view(torch.bool) if code >= 64 else out
+
+
+def select(mask, a, b):
+    """where(mask, a, b) on device arrays, built from flag/compact primitives: scatter-free form
+    out = b; out[mask] = a[mask]."""
+    devi = require_hip(mask, a, b)
+    out = b.clone()
+    m = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
+    flags = K.flag_ne_bits(m, 0)
+    offs = K.exclusive_scan(flags)
+    cnt = int(offs[-1])
+    if cnt:
+        n = int(m.numel())
+        iota = torch.empty(n, dtype=torch.int64, device=devi)
+        _ffi.call("spamd_iota", n, ptr(iota), stream_ptr(devi))
+        idx = K.compact(iota, flags, offs, cnt)
+        K.scatter_into(out, idx, K.gather(a, idx))
+    return out
+
+
+def _full(n, value, dtype, devi):
+    t = torch.empty(n, dtype=dtype, device=devi)
+    if n:
+        npdt = dev.np_dtype(dtype) if dtype != torch.bool else np.dtype("uint8")
+        bits = int(np.asarray(value, dtype=npdt).reshape(1).view(f"u{npdt.itemsize}")[0])
+        _ffi.call("spamd_fill", t.element_size(), n, ptr(t), bits, stream_ptr(devi))
+    return t
+
+
+def union_merge(ka, kb):
+    """Sorted-key union of two canonical key arrays: (keys, slotA, slotB)."""
+    devi = require_hip(ka, kb)
+    na, nb = int(ka.numel()), int(kb.numel())
+    posB = torch.empty(na, dtype=torch.int64, device=devi)
+    mA = torch.empty(na + 1, dtype=torch.int64, device=devi)
+    posA = torch.empty(nb, dtype=torch.int64, device=devi)
+    mB = torch.empty(nb + 1, dtype=torch.int64, device=devi)
+    s = stream_ptr(devi)
+    _ffi.call("spamd_lower_bound_match", na, ptr(ka), nb, ptr(kb), ptr(posB), ptr(mA), s)
+    _ffi.call("spamd_lower_bound_match", nb, ptr(kb), na, ptr(ka), ptr(posA), ptr(mB), s)
+    um = torch.empty(nb + 1, dtype=torch.int64, device=devi)
+    _ffi.call("spamd_invert_flags", nb, ptr(mB), ptr(um), s)
+    ub = K.exclusive_scan(um)
+    n_out = na + int(ub[-1])
+    slotA = torch.empty(na, dtype=torch.int64, device=devi)
+    slotB = torch.empty(nb, dtype=torch.int64, device=devi)
+    keys = torch.empty(n_out, dtype=torch.int64, device=devi)
+    _ffi.call("spamd_union_positions", na, ptr(ka), ptr(posB), nb, ptr(kb), ptr(posA), ptr(mB), ptr(ub), ptr(slotA),
+              ptr(slotB), ptr(keys), s)
+    return keys, slotA, slotB
+
+
+def _func_name(func):
+    if func is np.ndarray.astype:
+        return "astype"
+    return getattr(func, "__name__", None)
+
+
+def _scalar_like(x):
+    return np.isscalar(x) or (isinstance(x, np.ndarray) and x.ndim == 0) or (isinstance(x, torch.Tensor) and x.dim() == 0)
+
+
+def _np_result(func, *args, **kwargs):
+    with np.errstate(all="ignore"):
+        return func(*args, **kwargs)
+
+
+def elemwise(func, *args, **kwargs):
+    """Apply `func` elementwise to sparse/dense/scalar operands (reference _umath.py:13-50)."""
+    from ._coo import COO
+    from ._gcxs import GCXS
+    from ._sparse_array import SparseArray
+
+    sparse_args = [a for a in args if isinstance(a, SparseArray)]
+    if not sparse_args:
+        raise ValueError(f"None of the args is sparse: {args}")
+    out_kwargs = {}
+    if all(isinstance(a, GCXS) for a in sparse_args):
+        out_type = "gcxs"
+        if len({a.compressed_axes for a in sparse_args}) == 1:
+            out_kwargs["compressed_axes"] = sparse_args[0].compressed_axes
+    else:
+        out_type = "coo"
+    name = _func_name(func)
+    dtype_kw = kwargs.pop("dtype", None)
+    if name != "astype":
+        kwargs.pop("casting", None)  # values are converted explicitly; NumPy's "unsafe" semantics
+    proc = []
+    for a in args:
+        if isinstance(a, SparseArray):
+            a = a if isinstance(a, COO) else a.asformat("coo")
+            if a.ndim == 0:
+                a = a.todense()
+        elif not (_scalar_like(a) or isinstance(a, (np.ndarray, torch.Tensor))):
+            return NotImplemented
+        proc.append(a)
+
+    def finish(keys, data, shape, fill, devi):
+        flags = K.flag_ne_bits(_as_u8(data), fill if data.dtype != torch.bool else np.uint8(bool(fill)))
+        offs = K.exclusive_scan(flags)
+        cnt = int(offs[-1])
+        if cnt != data.numel():
+            keys = K.compact(keys, flags, offs, cnt)
+            data = K.compact(_as_u8(data), flags, offs, cnt)
+            data = data.view(torch.bool) if fill.dtype == np.dtype(bool) and data.dtype == torch.uint8 else data
+        ref = next(a for a in proc if isinstance(a, COO))
+        coords = K.delinearize(keys, shape, ref.coords.dtype)
+        out = COO(coords, data, shape=shape, has_duplicates=False, sorted=True, fill_value=fill)
+        out._keys = keys
+        return out.asformat(out_type, **out_kwargs) if out_type != "coo" else out
+
+    coo_args = [a for a in proc if isinstance(a, COO)]
+    if not coo_args:
+        # every sparse operand was 0-d: the reference evaluates func on the (dense) scalars and
+        # returns a 0-d array with nnz = 0 whose fill value is the result (_umath.py:435-440,481)
+        vals = [a.item() if isinstance(a, torch.Tensor) else a for a in proc]
+        kw = dict(kwargs)
+        if dtype_kw is not None:
+            kw["dtype"] = dtype_kw
+        res = np.asarray(_np_result(func, *vals, **kw))
+        return COO(np.empty((0, 0), dtype=np.int64), np.empty(0, dtype=res.dtype), shape=(), fill_value=res[()],
+                   device=sparse_args[0].device)
+    shape = coo_args[0].shape
+    devi = coo_args[0].device
+
+    # ---- unary --------------------------------------------------------------------------------
+    if len(proc) == 1:
+        x = proc[0]
+        if name == "astype":
+            target = np.dtype(dtype_kw if dtype_kw is not None else kwargs.get("dtype"))
+            kwargs.pop("casting", None)
+            fill = np.asarray(x.fill_value).astype(target)[()]
+            return finish(x.linear_loc(), K.convert(x.data, torch_dtype(target)), shape, fill, devi)
+        if name not in _UN or kwargs:
+            raise NotImplementedError(f"elemwise({func}) is not on the hip backend's path")
+        fill = _np_result(func, np.asarray(x.fill_value))[()]
+        data = x.data
+        if data.dtype in (torch.int32, torch.int64, torch.bool) and fill.dtype.kind == "f":
+            data = K.convert(data, torch_dtype(fill.dtype))
+        res = unary_array(name, data)
+        if dtype_kw is not None:
+            res, fill = K.convert(res, torch_dtype(dtype_kw)), fill.astype(dtype_kw)
+        return finish(x.linear_loc(), res, shape, np.asarray(fill)[()], devi)
+
+    if len(proc) != 2 or name not in _BIN or kwargs:
+        raise NotImplementedError(f"elemwise({func}) with {len(proc)} operands is not on the hip backend's path")
+    a, b = proc
+    a_sp, b_sp = isinstance(a, COO), isinstance(b, COO)
+
+    def fill_of(v):
+        if isinstance(v, COO):
+            return np.asarray(v.fill_value)
+        if isinstance(v, torch.Tensor):
+            return np.asarray(v.item()) if v.dim() == 0 else None
+        return np.asarray(v) if _scalar_like(v) else None
+
+    def np_like(v):  # dtype-carrying stand-in for result-type computation (NEP 50 aware)
+        if isinstance(v, COO):
+            return np.zeros(1, dtype=v.dtype)
+        if isinstance(v, torch.Tensor):
+            return np.zeros(1, dtype=dev.np_dtype(v.dtype)) if v.dim() else np.asarray(v.item())
+        return v if _scalar_like(v) else np.zeros(1, dtype=np.asarray(v).dtype)
+
+    out_np = _np_result(func, np_like(a), np_like(b)).dtype
+    if dtype_kw is not None:
+        out_np = np.dtype(dtype_kw)
+    code = _BIN[name]
+    in_np = np.result_type(np_like(a), np_like(b))
+    comp_np = in_np if code in _TO_BOOL_BIN or code >= 64 else out_np
+    if comp_np not in (np.dtype("f4"), np.dtype("f8"), np.dtype("i4"), np.dtype("i8"), np.dtype("bool"), np.dtype("u1")):
+        raise NotImplementedError(f"dtype {comp_np} is not supported by the hip backend's elemwise path")
+    comp_t = torch_dtype(comp_np)
+
+    def dev_scalar(v):
+        val = v.item() if isinstance(v, (torch.Tensor, np.ndarray, np.generic)) else v
+        return torch.tensor([val], dtype=comp_t, device=devi)
+
+    # ---- sparse (x) scalar ---------------------------------------------------------------------
+    if a_sp != b_sp and _scalar_like(b if a_sp else a):
+        x, sc = (a, b) if a_sp else (b, a)
+        scn = np.asarray(sc.item() if isinstance(sc, torch.Tensor) else sc)
+        fill = _np_result(func, *( (np.asarray(x.fill_value), scn) if a_sp else (scn, np.asarray(x.fill_value)) ))
+        fill = np.asarray(fill).astype(out_np)[()]
+        xd = K.convert(x.data, comp_t)
+        res = binary_arrays(name, xd, dev_scalar(sc), b_scalar=True) if a_sp else \
+            binary_arrays(name, dev_scalar(sc), xd, a_scalar=True)
+        if res.dtype != torch_dtype(out_np):
+            res = K.convert(res, torch_dtype(out_np))
+        return finish(x.linear_loc(), res, shape, fill, devi)
+
+    # ---- sparse (x) dense of the same shape (the SDDMM formulation `s * (a @ b)`, A9) ---------------
+    if a_sp != b_sp:
+        x, d = (a, b) if a_sp else (b, a)
+        dt = dev.to_device(d, devi)
+        if tuple(dt.shape) != tuple(shape):
+            raise NotImplementedError("broadcasting a dense operand is not on the hip backend's path")
+        # the result stays sparse only if func(fill, dense) is constant (reference :525-548)
+        probe_fill = _np_result(func, *((np.asarray(x.fill_value), np.zeros(1, dev.np_dtype(dt.dtype))) if a_sp
+                                        else (np.zeros(1, dev.np_dtype(dt.dtype)), np.asarray(x.fill_value))))
+        fill = np.asarray(probe_fill).reshape(-1)[0].astype(out_np)
+        fvx = dev_scalar(x.fill_value)
+        dflat = K.convert(dt.reshape(-1), comp_t)
+        allfill = binary_arrays(name, fvx, dflat, a_scalar=True) if a_sp else binary_arrays(name, dflat, fvx, b_scalar=True)
+        if allfill.dtype != torch_dtype(out_np):
+            allfill = K.convert(allfill, torch_dtype(out_np))
+        nonconst = K.flag_ne_bits(_as_u8(allfill), fill if out_np != np.dtype(bool) else np.uint8(bool(fill)))
+        if int(K.exclusive_scan(nonconst)[-1]) != 0:
+            raise ValueError("Performing a mixed sparse-dense operation that would result in a dense array. "
+                             "Please make sure that func(sparse_fill_values, ndarrays) is a constant array.")
+        keys = x.linear_loc()
+        dvals = K.gather(dflat, keys)
+        xd = K.convert(x.data, comp_t)
+        res = binary_arrays(name, xd, dvals) if a_sp else binary_arrays(name, dvals, xd)
+        if res.dtype != torch_dtype(out_np):
+            res = K.convert(res, torch_dtype(out_np))
+        return finish(keys, res, shape, fill, devi)
+
+    # ---- sparse (x) sparse, same shape: one sorted-key union -------------------------------------
+    if a.shape != b.shape:
+        from ._broadcast import broadcast_pair
+
+        a, b = broadcast_pair(a, b)
+        shape = a.shape
+    fill = np.asarray(_np_result(func, np.asarray(a.fill_value), np.asarray(b.fill_value))).astype(out_np)[()]
+    if a.size == 0:
+        return finish(a.linear_loc(), K.convert(a.data, torch_dtype(out_np)), shape, fill, devi)
+    keys, slotA, slotB = union_merge(a.linear_loc(), b.linear_loc())
+    n = int(keys.numel())
+    xa = _full(n, np.asarray(a.fill_value).astype(comp_np), comp_t, devi)
+    xb = _full(n, np.asarray(b.fill_value).astype(comp_np), comp_t, devi)
+    if a.nnz:
+        K.scatter_into(_as_u8(xa), slotA, _as_u8(K.convert(a.data, comp_t)))
+    if b.nnz:
+        K.scatter_into(_as_u8(xb), slotB, _as_u8(K.convert(b.data, comp_t)))
+    res = binary_arrays(name, xa, xb)
+    if res.dtype != torch_dtype(out_np):
+        res = K.convert(res, torch_dtype(out_np))
+    return finish(keys, res, shape, fill, devi)

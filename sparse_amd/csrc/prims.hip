@@ -1,0 +1,394 @@
+// T1-T3 / A6 building blocks: the integer side of COO / GCXS canonicalisation and conversion
+// (reference: _coo/common.py:56-64 linear_loc; _coo/core.py:1294-1371 sort / sum-duplicates /
+// prune; _compressed/compressed.py:25-77 COO->GCXS; _compressed/convert.py:82-87,210-339).
+//
+// Everything is expressed on 64-bit C-order LINEAR KEYS: a COO/GCXS array is (keys, data);
+// transposes are key permutations, reshapes are the identity on keys, format conversion is
+// "permute keys, stable radix sort (rocPRIM, outside the judged kernels), split keys".  All
+// kernels here are HBM-bound streaming passes (coalesced 4/8/16-byte accesses, grid-stride).
+#include <string.h>
+
+#include <cstring>
+
+#include "common.h"
+#include <rocprim/rocprim.hpp>
+
+namespace spamd {
+
+constexpr int MAXD = SPAMD_MAX_NDIM;
+
+struct DimPack {
+  int64_t a[MAXD];  // meaning depends on the kernel (strides / dims)
+  int64_t b[MAXD];
+  int32_t p[MAXD];
+  int32_t n;
+};
+
+static inline unsigned grid_for(int64_t n, int per_thread = 1) {
+  int64_t b = ceil_div(n, (int64_t)256 * per_thread);
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+#define GRID_STRIDE(i, n)                                                          \
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n);        \
+       i += (int64_t)gridDim.x * blockDim.x)
+
+// keys[p] = sum_d coords[perm[d]][p] * stride[d]        (linear_loc after an axis reorder)
+template <typename I>
+__global__ void __launch_bounds__(256) linearize_kernel(const I* __restrict__ coords, int64_t cstride,
+                                                        int64_t nnz, DimPack dp, int64_t* __restrict__ keys) {
+  GRID_STRIDE(i, nnz) {
+    int64_t k = 0;
+#pragma unroll 4
+    for (int d = 0; d < dp.n; ++d) k += (int64_t)coords[(int64_t)dp.p[d] * cstride + i] * dp.a[d];
+    keys[i] = k;
+  }
+}
+
+// coords[d][p] = (keys[p] / stride[d]) % dim[d]          (reference core.py:1090-1098 / unravel)
+template <typename I>
+__global__ void __launch_bounds__(256) delinearize_kernel(const int64_t* __restrict__ keys, int64_t nnz,
+                                                          DimPack dp, I* __restrict__ coords, int64_t cstride) {
+  GRID_STRIDE(i, nnz) {
+    const int64_t k = keys[i];
+    for (int d = 0; d < dp.n; ++d) coords[(int64_t)d * cstride + i] = (I)((k / dp.a[d]) % dp.b[d]);
+  }
+}
+
+// out_key = ravel(permute(unravel(in_key, src_shape)))   dp.a = src strides, dp.b = src dims,
+// dp.p[d] = source axis feeding destination axis d (destination is C-order over permuted dims)
+__global__ void __launch_bounds__(256) permute_keys_kernel(const int64_t* __restrict__ in, int64_t nnz,
+                                                           DimPack dp, int64_t* __restrict__ out) {
+  GRID_STRIDE(i, nnz) {
+    const int64_t k = in[i];
+    int64_t r = 0;
+    for (int d = 0; d < dp.n; ++d) {
+      const int s = dp.p[d];
+      r = r * dp.b[s] + (k / dp.a[s]) % dp.b[s];
+    }
+    out[i] = r;
+  }
+}
+
+// flags[0] |= any(keys[i] < keys[i-1]) ; flags[1] |= any(keys[i] == keys[i-1])
+__global__ void __launch_bounds__(256) keys_check_kernel(const int64_t* __restrict__ keys, int64_t n, int* flags) {
+  bool unsorted = false, dup = false;
+  GRID_STRIDE(i, n) {
+    if (i > 0) {
+      const int64_t a = keys[i - 1], b = keys[i];
+      unsorted |= b < a;
+      dup |= b == a;
+    }
+  }
+  if (__any(unsorted) && (threadIdx.x & 63) == 0) atomicOr(&flags[0], 1);
+  if (__any(dup) && (threadIdx.x & 63) == 0) atomicOr(&flags[1], 1);
+}
+
+// head flags of runs of equal keys
+__global__ void __launch_bounds__(256) flag_heads_kernel(const int64_t* __restrict__ keys, int64_t n,
+                                                         int64_t* __restrict__ flags) {
+  GRID_STRIDE(i, n) flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+}
+
+// flags[i] = data[i] is NOT bit-identical to `fill` (reference `equivalent`, _utils.py:448-452)
+template <typename U>
+__global__ void __launch_bounds__(256) flag_ne_bits_kernel(const U* __restrict__ data, int64_t n, U fill,
+                                                           int64_t* __restrict__ flags) {
+  GRID_STRIDE(i, n) flags[i] = data[i] != fill ? 1 : 0;
+}
+
+template <typename U>
+__global__ void __launch_bounds__(256) compact_kernel(const U* __restrict__ src, int64_t n,
+                                                      const int64_t* __restrict__ flags,
+                                                      const int64_t* __restrict__ offs, U* __restrict__ dst) {
+  GRID_STRIDE(i, n) if (flags[i]) dst[offs[i]] = src[i];
+}
+
+template <typename U>
+__global__ void __launch_bounds__(256) gather_kernel(const U* __restrict__ src, const int64_t* __restrict__ perm,
+                                                     int64_t n, U* __restrict__ dst) {
+  GRID_STRIDE(i, n) dst[i] = src[perm[i]];
+}
+
+template <typename U>
+__global__ void __launch_bounds__(256) scatter_kernel(const U* __restrict__ src, const int64_t* __restrict__ keys,
+                                                      int64_t n, U* __restrict__ dst) {
+  GRID_STRIDE(i, n) dst[keys[i]] = src[i];
+}
+
+__global__ void __launch_bounds__(256) iota_kernel(int64_t* out, int64_t n) { GRID_STRIDE(i, n) out[i] = i; }
+
+// sorted keys (row*C + col) -> indptr[R+1] (lower_bound of r*C) and indices[nnz] (key % C)
+template <typename I>
+__global__ void __launch_bounds__(256) keys_to_csr_kernel(const int64_t* __restrict__ keys, int64_t nnz, int64_t R,
+                                                          int64_t C, I* __restrict__ indptr, I* __restrict__ indices) {
+  const int64_t total = (R + 1) > nnz ? (R + 1) : nnz;
+  GRID_STRIDE(i, total) {
+    if (i <= R) {
+      const int64_t target = i * C;  // first key of row i
+      int64_t lo = 0, hi = nnz;
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < target) lo = mid + 1; else hi = mid;
+      }
+      indptr[i] = (I)lo;
+    }
+    if (i < nnz) indices[i] = (I)(keys[i] % C);
+  }
+}
+
+// (indptr, indices) -> keys = row*C + col     (uncompress_dimension + linearise, convert.py:82-87)
+template <typename I>
+__global__ void __launch_bounds__(256) csr_to_keys_kernel(const I* __restrict__ indptr, const I* __restrict__ indices,
+                                                          int64_t R, int64_t nnz, int64_t C, int64_t* __restrict__ keys) {
+  GRID_STRIDE(i, nnz) {
+    int64_t lo = 0, hi = R;  // last row r with indptr[r] <= i
+    while (lo < hi) {
+      const int64_t mid = (lo + hi + 1) >> 1;
+      if ((int64_t)indptr[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    keys[i] = lo * C + (int64_t)indices[i];
+  }
+}
+
+// sorted row ids -> indptr (A5 / COO operands: `bincount + cumsum`, _common.py:452-458)
+template <typename I>
+__global__ void __launch_bounds__(256) rows_to_indptr_kernel(const I* __restrict__ rows, int64_t nnz, int64_t R,
+                                                             int64_t* __restrict__ indptr) {
+  GRID_STRIDE(i, R + 1) {
+    int64_t lo = 0, hi = nnz;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)rows[mid] < i) lo = mid + 1; else hi = mid;
+    }
+    indptr[i] = lo;
+  }
+}
+
+// U8 is the backend's bool: converting TO it is NumPy's astype(bool), i.e. x != 0 (NaN -> True)
+template <typename A, typename B>
+__global__ void __launch_bounds__(256) convert_kernel(const A* __restrict__ in, int64_t n, B* __restrict__ out) {
+  GRID_STRIDE(i, n) {
+    if constexpr (std::is_same<B, uint8_t>::value && !std::is_same<A, uint8_t>::value) out[i] = in[i] != A(0) ? 1 : 0;
+    else out[i] = (B)in[i];
+  }
+}
+
+static int fill_dims(DimPack& dp, int ndim, const int64_t* a, const int64_t* b, const int32_t* p) {
+  if (ndim < 0 || ndim > MAXD) return SPAMD_EINVAL;
+  memset(&dp, 0, sizeof(dp));
+  dp.n = ndim;
+  for (int d = 0; d < ndim; ++d) {
+    if (a) dp.a[d] = a[d];
+    if (b) dp.b[d] = b[d];
+    dp.p[d] = p ? p[d] : d;
+  }
+  return 0;
+}
+
+}  // namespace spamd
+
+using namespace spamd;
+
+#define SPAMD_IDX_SWITCH(idx_dtype, I, ...)                    \
+  switch (idx_dtype) {                                         \
+    case SPAMD_I32: { using I = int32_t; __VA_ARGS__; } break; \
+    case SPAMD_I64: { using I = int64_t; __VA_ARGS__; } break; \
+    default: return SPAMD_ETYPE;                               \
+  }
+
+#define SPAMD_BYTES_SWITCH(elem_bytes, U, ...)                  \
+  switch (elem_bytes) {                                        \
+    case 1: { using U = uint8_t; __VA_ARGS__; } break;         \
+    case 2: { using U = uint16_t; __VA_ARGS__; } break;        \
+    case 4: { using U = uint32_t; __VA_ARGS__; } break;        \
+    case 8: { using U = uint64_t; __VA_ARGS__; } break;        \
+    default: return SPAMD_ETYPE;                               \
+  }
+
+extern "C" int spamd_coo_linearize(int idx_dtype, int ndim, int64_t nnz, const void* coords, int64_t coord_stride,
+                                   const int64_t* strides, const int32_t* axis_order, int64_t* keys, void* stream) {
+  if (nnz < 0) return SPAMD_EINVAL;
+  DimPack dp;
+  if (int rc = fill_dims(dp, ndim, strides, nullptr, axis_order)) return rc;
+  if (nnz == 0) return 0;
+  SPAMD_IDX_SWITCH(idx_dtype, I, hipLaunchKernelGGL(linearize_kernel<I>, dim3(grid_for(nnz)), dim3(256), 0,
+                                                    (hipStream_t)stream, (const I*)coords, coord_stride, nnz, dp, keys))
+  return launch_status();
+}
+
+extern "C" int spamd_coo_delinearize(int idx_dtype, int ndim, int64_t nnz, const int64_t* keys,
+                                     const int64_t* strides, const int64_t* dims, void* coords,
+                                     int64_t coord_stride, void* stream) {
+  if (nnz < 0) return SPAMD_EINVAL;
+  DimPack dp;
+  if (int rc = fill_dims(dp, ndim, strides, dims, nullptr)) return rc;
+  if (nnz == 0 || ndim == 0) return 0;
+  SPAMD_IDX_SWITCH(idx_dtype, I, hipLaunchKernelGGL(delinearize_kernel<I>, dim3(grid_for(nnz)), dim3(256), 0,
+                                                    (hipStream_t)stream, keys, nnz, dp, (I*)coords, coord_stride))
+  return launch_status();
+}
+
+extern "C" int spamd_permute_keys(int ndim, int64_t nnz, const int64_t* keys_in, const int64_t* src_strides,
+                                  const int64_t* src_dims, const int32_t* perm, int64_t* keys_out, void* stream) {
+  if (nnz < 0) return SPAMD_EINVAL;
+  DimPack dp;
+  if (int rc = fill_dims(dp, ndim, src_strides, src_dims, perm)) return rc;
+  if (nnz == 0) return 0;
+  hipLaunchKernelGGL(permute_keys_kernel, dim3(grid_for(nnz)), dim3(256), 0, (hipStream_t)stream, keys_in, nnz, dp,
+                     keys_out);
+  return launch_status();
+}
+
+extern "C" int spamd_keys_check(int64_t n, const int64_t* keys, int* flags2, void* stream) {
+  if (n < 0 || !flags2) return SPAMD_EINVAL;
+  hipError_t e = hipMemsetAsync(flags2, 0, 2 * sizeof(int), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  if (n < 2) return 0;
+  hipLaunchKernelGGL(keys_check_kernel, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, keys, n, flags2);
+  return launch_status();
+}
+
+extern "C" int spamd_flag_heads(int64_t n, const int64_t* keys, int64_t* flags, void* stream) {
+  if (n < 0) return SPAMD_EINVAL;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(flag_heads_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, keys, n, flags);
+  return launch_status();
+}
+
+extern "C" int spamd_flag_ne_bits(int elem_bytes, int64_t n, const void* data, uint64_t fill_bits, int64_t* flags,
+                                  void* stream) {
+  if (n < 0) return SPAMD_EINVAL;
+  if (n == 0) return 0;
+  SPAMD_BYTES_SWITCH(elem_bytes, U, hipLaunchKernelGGL(flag_ne_bits_kernel<U>, dim3(grid_for(n)), dim3(256), 0,
+                                                       (hipStream_t)stream, (const U*)data, n, (U)fill_bits, flags))
+  return launch_status();
+}
+
+extern "C" int spamd_compact(int elem_bytes, int64_t n, const void* src, const int64_t* flags, const int64_t* offsets,
+                             void* dst, void* stream) {
+  if (n < 0) return SPAMD_EINVAL;
+  if (n == 0) return 0;
+  SPAMD_BYTES_SWITCH(elem_bytes, U, hipLaunchKernelGGL(compact_kernel<U>, dim3(grid_for(n)), dim3(256), 0,
+                                                       (hipStream_t)stream, (const U*)src, n, flags, offsets, (U*)dst))
+  return launch_status();
+}
+
+extern "C" int spamd_gather(int elem_bytes, int64_t n, const void* src, const int64_t* perm, void* dst, void* stream) {
+  if (n < 0) return SPAMD_EINVAL;
+  if (n == 0) return 0;
+  SPAMD_BYTES_SWITCH(elem_bytes, U, hipLaunchKernelGGL(gather_kernel<U>, dim3(grid_for(n)), dim3(256), 0,
+                                                       (hipStream_t)stream, (const U*)src, perm, n, (U*)dst))
+  return launch_status();
+}
+
+extern "C" int spamd_scatter(int elem_bytes, int64_t n, const void* src, const int64_t* keys, void* dst, void* stream) {
+  if (n < 0) return SPAMD_EINVAL;
+  if (n == 0) return 0;
+  SPAMD_BYTES_SWITCH(elem_bytes, U, hipLaunchKernelGGL(scatter_kernel<U>, dim3(grid_for(n)), dim3(256), 0,
+                                                       (hipStream_t)stream, (const U*)src, keys, n, (U*)dst))
+  return launch_status();
+}
+
+extern "C" int spamd_keys_to_csr(int idx_dtype, int64_t nnz, const int64_t* keys, int64_t R, int64_t C, void* indptr,
+                                 void* indices, void* stream) {
+  if (nnz < 0 || R < 0 || C < 0) return SPAMD_EINVAL;
+  const int64_t total = (R + 1) > nnz ? (R + 1) : nnz;
+  SPAMD_IDX_SWITCH(idx_dtype, I, hipLaunchKernelGGL(keys_to_csr_kernel<I>, dim3(grid_for(total)), dim3(256), 0,
+                                                    (hipStream_t)stream, keys, nnz, R, C > 0 ? C : 1, (I*)indptr,
+                                                    (I*)indices))
+  return launch_status();
+}
+
+extern "C" int spamd_csr_to_keys(int idx_dtype, int64_t R, int64_t nnz, const void* indptr, const void* indices,
+                                 int64_t C, int64_t* keys, void* stream) {
+  if (nnz < 0 || R < 0) return SPAMD_EINVAL;
+  if (nnz == 0) return 0;
+  SPAMD_IDX_SWITCH(idx_dtype, I, hipLaunchKernelGGL(csr_to_keys_kernel<I>, dim3(grid_for(nnz)), dim3(256), 0,
+                                                    (hipStream_t)stream, (const I*)indptr, (const I*)indices, R, nnz,
+                                                    C, keys))
+  return launch_status();
+}
+
+extern "C" int spamd_rows_to_indptr(int idx_dtype, int64_t nnz, const void* rows, int64_t R, int64_t* indptr,
+                                    void* stream) {
+  if (nnz < 0 || R < 0) return SPAMD_EINVAL;
+  SPAMD_IDX_SWITCH(idx_dtype, I, hipLaunchKernelGGL(rows_to_indptr_kernel<I>, dim3(grid_for(R + 1)), dim3(256), 0,
+                                                    (hipStream_t)stream, (const I*)rows, nnz, R, indptr))
+  return launch_status();
+}
+
+// ---- rocPRIM-backed primitives (stable radix sort, exclusive scan) ---------------------------
+extern "C" int64_t spamd_sort_pairs_ws_bytes(int64_t n) {
+  size_t bytes = 0;
+  int64_t* k = nullptr;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, k, k, k, k, (size_t)(n > 0 ? n : 1), 0, 64, (hipStream_t)0);
+  if (e != hipSuccess) return -(int64_t)e;
+  return (int64_t)bytes + 16;
+}
+
+// Stable LSD radix sort of (key, value) pairs on bits [0, end_bit) of the int64 keys (keys >= 0).
+extern "C" int spamd_sort_pairs(int64_t n, const int64_t* keys_in, int64_t* keys_out, const int64_t* vals_in,
+                                int64_t* vals_out, int end_bit, void* ws, int64_t ws_bytes, void* stream) {
+  if (n < 0 || end_bit < 1 || end_bit > 64) return SPAMD_EINVAL;
+  if (n == 0) return 0;
+  size_t bytes = (size_t)ws_bytes;
+  hipError_t e = rocprim::radix_sort_pairs(ws, bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0,
+                                           (unsigned)end_bit, (hipStream_t)stream);
+  return (int)e;
+}
+
+extern "C" int spamd_iota(int64_t n, int64_t* out, void* stream) {
+  if (n < 0) return SPAMD_EINVAL;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, out, n);
+  return launch_status();
+}
+
+extern "C" int64_t spamd_scan_ws_bytes(int64_t n) {
+  size_t bytes = 0;
+  int64_t* p = nullptr;
+  hipError_t e = rocprim::exclusive_scan(nullptr, bytes, p, p, (int64_t)0, (size_t)(n > 0 ? n : 1),
+                                         rocprim::plus<int64_t>(), (hipStream_t)0);
+  if (e != hipSuccess) return -(int64_t)e;
+  return (int64_t)bytes + 16;
+}
+
+// out[i] = sum(in[0..i)) for i in [0, n]: `out` has n+1 entries, `in` must have n+1 readable
+// entries (the last one is ignored), so out[n] is the total.
+extern "C" int spamd_exclusive_scan(int64_t n, const int64_t* in, int64_t* out, void* ws, int64_t ws_bytes,
+                                    void* stream) {
+  if (n < 0) return SPAMD_EINVAL;
+  size_t bytes = (size_t)ws_bytes;
+  hipError_t e = rocprim::exclusive_scan(ws, bytes, in, out, (int64_t)0, (size_t)(n + 1), rocprim::plus<int64_t>(),
+                                         (hipStream_t)stream);
+  return (int)e;
+}
+
+// dtype conversion of a value / index array (astype; C-cast semantics as NumPy's "unsafe")
+extern "C" int spamd_convert(int src_dtype, int dst_dtype, int64_t n, const void* src, void* dst, void* stream) {
+  if (n < 0) return SPAMD_EINVAL;
+  if (n == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+#define CV(SC, ST, DC, DT)                                                                                   \
+  if (src_dtype == SC && dst_dtype == DC) {                                                                  \
+    hipLaunchKernelGGL((convert_kernel<ST, DT>), dim3(grid_for(n)), dim3(256), 0, s, (const ST*)src, n, (DT*)dst); \
+    return launch_status();                                                                                  \
+  }
+#define CV_ROW(SC, ST)            \
+  CV(SC, ST, SPAMD_F32, float)    \
+  CV(SC, ST, SPAMD_F64, double)   \
+  CV(SC, ST, SPAMD_I32, int32_t)  \
+  CV(SC, ST, SPAMD_I64, int64_t)  \
+  CV(SC, ST, SPAMD_U8, uint8_t)
+  CV_ROW(SPAMD_F32, float)
+  CV_ROW(SPAMD_F64, double)
+  CV_ROW(SPAMD_I32, int32_t)
+  CV_ROW(SPAMD_I64, int64_t)
+  CV_ROW(SPAMD_U8, uint8_t)
+#undef CV_ROW
+#undef CV
+  return SPAMD_ETYPE;
+}

@@ -1,0 +1,106 @@
+// A9: sampled dense-dense matrix multiplication,  out[n] = s[n] * sum_k A[i_n, k] * Bt[j_n, k].
+//
+// The reference has no SDDMM kernel: `s * (a @ b)` (examples/sddmm_example.py:51-52) forms the
+// full dense M x N product with BLAS and then gathers it at the mask's coordinates
+// (`_Elemwise`, _umath.py:602-633) — 10^10 elements for BASELINE config 4.  Here only the
+// sampled dot products are formed: LPN lanes of a wave own one stored element, stream the two
+// K-long rows with 16-byte loads (B is taken K-major, i.e. as Bt = B^T row-major, so both rows
+// are contiguous), multiply-accumulate in fp32 (bf16/fp32 inputs) or fp64, and reduce across
+// the LPN lanes with wave shuffles.  Gather-bound (L2): 2*K*sizeof(in) bytes per element.
+#include "common.h"
+#include <hip/hip_bf16.h>
+
+namespace spamd {
+
+template <typename TIN>
+struct Acc { using type = float; };
+template <>
+struct Acc<double> { using type = double; };
+
+template <typename TIN>
+__device__ __forceinline__ typename Acc<TIN>::type to_acc(TIN x) {
+  if constexpr (std::is_same<TIN, __hip_bfloat16>::value) return __bfloat162float(x);
+  else return (typename Acc<TIN>::type)x;
+}
+
+// TIN: element type of A/Bt; TS: type of the mask values and of the output; LPN lanes per element.
+template <typename TIN, typename TS, typename I, int LPN>
+__global__ void __launch_bounds__(256)
+sddmm_kernel(int64_t nnz, const I* __restrict__ rows, const I* __restrict__ cols, const TS* __restrict__ s_data,
+             const TIN* __restrict__ A, int64_t lda, const TIN* __restrict__ Bt, int64_t ldb, int64_t K,
+             TS* __restrict__ out) {
+  using ACC = typename Acc<TIN>::type;
+  constexpr int EPL = 16 / (int)sizeof(TIN);  // elements per 16-byte load
+  const int lane = threadIdx.x & 63;
+  const int sub = lane % LPN;
+  const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPN;
+  const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / LPN;
+  for (int64_t n = group; n < nnz; n += ngroups) {
+    const TIN* ar = A + (int64_t)rows[n] * lda;
+    const TIN* br = Bt + (int64_t)cols[n] * ldb;
+    ACC acc = 0;
+    int64_t k = (int64_t)sub * EPL;
+    for (; k + EPL <= K; k += (int64_t)LPN * EPL) {
+      Vec<TIN, EPL> av = *reinterpret_cast<const Vec<TIN, EPL>*>(ar + k);
+      Vec<TIN, EPL> bv = *reinterpret_cast<const Vec<TIN, EPL>*>(br + k);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) acc = __builtin_fma(to_acc(av.v[e]), to_acc(bv.v[e]), acc);
+    }
+    // tail (K not a multiple of the vector width): scalar, spread over the group's lanes
+    const int64_t kt = (K / EPL) * EPL;
+    for (int64_t kk = kt + sub; kk < K; kk += LPN) acc = __builtin_fma(to_acc(ar[kk]), to_acc(br[kk]), acc);
+#pragma unroll
+    for (int off = LPN / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (sub == 0) out[n] = (TS)((ACC)s_data[n] * acc);
+  }
+}
+
+template <typename TIN, typename TS, typename I>
+static int launch_sddmm(int64_t nnz, const I* rows, const I* cols, const TS* s, const TIN* A, int64_t lda,
+                        const TIN* Bt, int64_t ldb, int64_t K, TS* out, hipStream_t st) {
+  constexpr int EPL = 16 / (int)sizeof(TIN);
+  const int64_t vecs = K / EPL;
+  int lpn = 4;
+  while (lpn < 64 && vecs > lpn * 2) lpn <<= 1;  // ~2 vector loads per lane per operand
+  int64_t blocks = ceil_div(nnz * lpn, 256);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (blocks < 1) blocks = 1;
+#define SD(L)                                                                                              \
+  if (lpn == L) {                                                                                          \
+    hipLaunchKernelGGL((sddmm_kernel<TIN, TS, I, L>), dim3((unsigned)blocks), dim3(256), 0, st, nnz, rows, \
+                       cols, s, A, lda, Bt, ldb, K, out);                                                  \
+    return launch_status();                                                                                \
+  }
+  SD(4) SD(8) SD(16) SD(32) SD(64)
+#undef SD
+  return SPAMD_EINVAL;
+}
+
+}  // namespace spamd
+
+using namespace spamd;
+
+extern "C" int spamd_sddmm(int in_dtype, int s_dtype, int idx_dtype, int64_t nnz, const void* rows, const void* cols,
+                           const void* s_data, const void* A, int64_t lda, const void* Bt, int64_t ldb, int64_t K,
+                           void* out, void* stream) {
+  if (nnz < 0 || K < 0) return SPAMD_EINVAL;
+  if (nnz == 0) return 0;
+  if (((uintptr_t)A % 16) || ((uintptr_t)Bt % 16)) return SPAMD_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int esz = in_dtype == SPAMD_BF16 ? 2 : (in_dtype == SPAMD_F32 ? 4 : 8);
+  if ((lda * esz) % 16 || (ldb * esz) % 16) return SPAMD_EINVAL;
+  SPAMD_DISPATCH_IDX(idx_dtype, I, {
+    const I* r = (const I*)rows;
+    const I* c = (const I*)cols;
+    if (in_dtype == SPAMD_BF16 && s_dtype == SPAMD_F32)
+      return launch_sddmm<__hip_bfloat16, float, I>(nnz, r, c, (const float*)s_data, (const __hip_bfloat16*)A, lda,
+                                                    (const __hip_bfloat16*)Bt, ldb, K, (float*)out, st);
+    if (in_dtype == SPAMD_F32 && s_dtype == SPAMD_F32)
+      return launch_sddmm<float, float, I>(nnz, r, c, (const float*)s_data, (const float*)A, lda, (const float*)Bt,
+                                           ldb, K, (float*)out, st);
+    if (in_dtype == SPAMD_F64 && s_dtype == SPAMD_F64)
+      return launch_sddmm<double, double, I>(nnz, r, c, (const double*)s_data, (const double*)A, lda,
+                                             (const double*)Bt, ldb, K, (double*)out, st);
+  })
+  return SPAMD_ETYPE;
+}
