@@ -1,6 +1,8 @@
 """Function surface of the hip backend on the hot path (reference
 sparse/numba_backend/__init__.py:179-350, the subset SURVEY.md §8b names): thin wrappers that
 delegate to the containers, like the reference's own (`_common.py:2077-2633`)."""
+import builtins
+
 import numpy as np
 import torch
 
@@ -82,7 +84,7 @@ def random(shape, density=None, nnz=None, random_state=None, format="coo", fill_
         keys = torch.empty(0, dtype=torch.int64, device=d)
         while keys.numel() < nnz:
             need = nnz - keys.numel()
-            draw = torch.randint(0, max(size, 1), (int(need * 1.05) + 1024,), generator=g, device=d)
+            draw = torch.randint(0, builtins.max(size, 1), (int(need * 1.05) + 1024,), generator=g, device=d)
             keys = torch.unique(torch.cat([keys, draw]))
         if keys.numel() > nnz:
             keep = torch.ones(keys.numel(), dtype=torch.bool, device=d)
