@@ -23,35 +23,55 @@ __device__ __forceinline__ typename Acc<TIN>::type to_acc(TIN x) {
   else return (typename Acc<TIN>::type)x;
 }
 
-// TIN: element type of A/Bt; TS: type of the mask values and of the output; LPN lanes per element.
-template <typename TIN, typename TS, typename I, int LPN>
+// TIN: element type of A/Bt; TS: type of the mask values and of the output; LPN lanes per element;
+// UNR stored elements per lane group in flight (all their row loads are issued before any FMA).
+template <typename TIN, typename TS, typename I, int LPN, int UNR>
 __global__ void __launch_bounds__(256)
 sddmm_kernel(int64_t nnz, const I* __restrict__ rows, const I* __restrict__ cols, const TS* __restrict__ s_data,
              const TIN* __restrict__ A, int64_t lda, const TIN* __restrict__ Bt, int64_t ldb, int64_t K,
              TS* __restrict__ out) {
   using ACC = typename Acc<TIN>::type;
   constexpr int EPL = 16 / (int)sizeof(TIN);  // elements per 16-byte load
+  using VT = Vec<TIN, EPL>;
   const int lane = threadIdx.x & 63;
   const int sub = lane % LPN;
   const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPN;
   const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / LPN;
-  for (int64_t n = group; n < nnz; n += ngroups) {
-    const TIN* ar = A + (int64_t)rows[n] * lda;
-    const TIN* br = Bt + (int64_t)cols[n] * ldb;
-    ACC acc = 0;
-    int64_t k = (int64_t)sub * EPL;
-    for (; k + EPL <= K; k += (int64_t)LPN * EPL) {
-      Vec<TIN, EPL> av = *reinterpret_cast<const Vec<TIN, EPL>*>(ar + k);
-      Vec<TIN, EPL> bv = *reinterpret_cast<const Vec<TIN, EPL>*>(br + k);
+  const int64_t kvec = (K / EPL) * EPL;
+  for (int64_t n0 = group * UNR; n0 < nnz; n0 += ngroups * UNR) {
+    const TIN* ar[UNR];
+    const TIN* br[UNR];
+    ACC acc[UNR];
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) acc = __builtin_fma(to_acc(av.v[e]), to_acc(bv.v[e]), acc);
+    for (int u = 0; u < UNR; ++u) {
+      const int64_t n = (n0 + u < nnz) ? (n0 + u) : (nnz - 1);  // clamp: duplicates are not stored
+      ar[u] = A + (int64_t)rows[n] * lda;
+      br[u] = Bt + (int64_t)cols[n] * ldb;
+      acc[u] = 0;
+    }
+    for (int64_t k = (int64_t)sub * EPL; k + EPL <= K; k += (int64_t)LPN * EPL) {
+      VT av[UNR], bv[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        av[u] = *reinterpret_cast<const VT*>(ar[u] + k);
+        bv[u] = *reinterpret_cast<const VT*>(br[u] + k);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[u] = __builtin_fma(to_acc(av[u].v[e]), to_acc(bv[u].v[e]), acc[u]);
+      }
     }
     // tail (K not a multiple of the vector width): scalar, spread over the group's lanes
-    const int64_t kt = (K / EPL) * EPL;
-    for (int64_t kk = kt + sub; kk < K; kk += LPN) acc = __builtin_fma(to_acc(ar[kk]), to_acc(br[kk]), acc);
 #pragma unroll
-    for (int off = LPN / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if (sub == 0) out[n] = (TS)((ACC)s_data[n] * acc);
+    for (int u = 0; u < UNR; ++u)
+      for (int64_t kk = kvec + sub; kk < K; kk += LPN) acc[u] = __builtin_fma(to_acc(ar[u][kk]), to_acc(br[u][kk]), acc[u]);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+      for (int off = LPN / 2; off > 0; off >>= 1) acc[u] += __shfl_xor(acc[u], off, 64);
+      if (sub == 0 && n0 + u < nnz) out[n0 + u] = (TS)((ACC)s_data[n0 + u] * acc[u]);
+    }
   }
 }
 
@@ -62,12 +82,15 @@ static int launch_sddmm(int64_t nnz, const I* rows, const I* cols, const TS* s, 
   const int64_t vecs = K / EPL;
   int lpn = 4;
   while (lpn < 64 && vecs > lpn * 2) lpn <<= 1;  // ~2 vector loads per lane per operand
-  int64_t blocks = ceil_div(nnz * lpn, 256);
+  // measured on MI355X (config 4): bf16 rows (512 B) are fastest with one element per lane group
+  // in flight (0.86 ms), fp32/fp64 rows with four (1.44 ms vs 1.54 ms)
+  constexpr int UNR = sizeof(TIN) >= 4 ? 4 : 1;
+  int64_t blocks = ceil_div(ceil_div(nnz, UNR) * lpn, 256);
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (blocks < 1) blocks = 1;
 #define SD(L)                                                                                              \
   if (lpn == L) {                                                                                          \
-    hipLaunchKernelGGL((sddmm_kernel<TIN, TS, I, L>), dim3((unsigned)blocks), dim3(256), 0, st, nnz, rows, \
+    hipLaunchKernelGGL((sddmm_kernel<TIN, TS, I, L, UNR>), dim3((unsigned)blocks), dim3(256), 0, st, nnz, rows, \
                        cols, s, A, lda, Bt, ldb, K, out);                                                  \
     return launch_status();                                                                                \
   }

@@ -15,15 +15,16 @@
 
 namespace spamd {
 
-template <typename T, typename I, int VEC, int G, bool EXACT, int UNROLL>
+template <typename T, typename I, int VEC, int G, bool EXACT, int UNROLL, int CH>
 __global__ void __launch_bounds__(256)
 spmm_csr_rowgroup_kernel(int64_t M, int64_t N, const T* __restrict__ a_data,
                          const I* __restrict__ a_idx, const I* __restrict__ a_ptr,
                          const T* __restrict__ b, int64_t ldb, T* __restrict__ out,
                          int64_t ldo, int64_t panel) {
-  // blockIdx.y selects a column panel [c_lo, c_hi) of the output: with panel < N the
-  // gathered part of B per pass shrinks to K*panel*sizeof(T) so that it stays resident in the
-  // 4 MiB per-XCD L2 (A is then streamed once per panel).
+  // blockIdx.y selects a column panel [c_lo, c_hi) of the output.  Inside a panel a lane owns
+  // CH groups of VEC contiguous columns, G*VEC columns apart, so one pass over the row's stored
+  // elements covers G*VEC*CH columns (wide outputs such as the 512-column tensordot config do
+  // not re-read A per 128 columns).
   const int64_t c_lo = (int64_t)blockIdx.y * panel;
   const int64_t c_hi = (c_lo + panel < N) ? (c_lo + panel) : N;
   constexpr int RPW = SPAMD_WAVE / G;  // rows per wave
@@ -40,12 +41,17 @@ spmm_csr_rowgroup_kernel(int64_t M, int64_t N, const T* __restrict__ a_data,
     const int64_t start = row_ok ? (int64_t)a_ptr[row] : 0;
     const int64_t end = row_ok ? (int64_t)a_ptr[row + 1] : 0;
 
-    for (int64_t c0 = c_lo; c0 < c_hi; c0 += (int64_t)G * VEC) {
-      const int64_t col = c0 + (int64_t)gl * VEC;
-      const bool col_ok = col < c_hi;  // N % VEC == 0 and panel % VEC == 0 (dispatcher)
-      T acc[VEC];
+    for (int64_t c0 = c_lo; c0 < c_hi; c0 += (int64_t)G * VEC * CH) {
+      int64_t col[CH];
+      bool col_ok[CH];  // N % VEC == 0 and panel % VEC == 0 (dispatcher)
+      T acc[CH][VEC];
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) acc[e] = T(0);
+      for (int h = 0; h < CH; ++h) {
+        col[h] = c0 + (int64_t)h * G * VEC + (int64_t)gl * VEC;
+        col_ok[h] = col[h] < c_hi;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[h][e] = T(0);
+      }
 
       for (int64_t p = start; p < end; p += G) {
         const int64_t mine = p + gl;
@@ -56,13 +62,14 @@ spmm_csr_rowgroup_kernel(int64_t M, int64_t N, const T* __restrict__ a_data,
           vi = a_data[mine];
         }
         const int cnt = (int)((end - p) < (int64_t)G ? (end - p) : (int64_t)G);
+        constexpr int U = (UNROLL / CH) < 1 ? 1 : (UNROLL / CH);  // keep ~UNROLL gathers in flight
         int j = 0;
-        for (; j + UNROLL <= cnt; j += UNROLL) {
-          I cj[UNROLL];
-          T vj[UNROLL];
-          V bj[UNROLL];
+        for (; j + U <= cnt; j += U) {
+          I cj[U];
+          T vj[U];
+          V bj[U][CH];
 #pragma unroll
-          for (int u = 0; u < UNROLL; ++u) {
+          for (int u = 0; u < U; ++u) {
             if constexpr (G == SPAMD_WAVE) {
               cj[u] = wave_bcast(ci, j + u);
               vj[u] = wave_bcast(vi, j + u);
@@ -72,14 +79,19 @@ spmm_csr_rowgroup_kernel(int64_t M, int64_t N, const T* __restrict__ a_data,
             }
           }
 #pragma unroll
-          for (int u = 0; u < UNROLL; ++u) {
-            if (col_ok) bj[u] = *reinterpret_cast<const V*>(b + (int64_t)cj[u] * ldb + col);
+          for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int h = 0; h < CH; ++h)
+              if (col_ok[h]) bj[u][h] = *reinterpret_cast<const V*>(b + (int64_t)cj[u] * ldb + col[h]);
           }
 #pragma unroll
-          for (int u = 0; u < UNROLL; ++u) {
-            if (col_ok) {
+          for (int u = 0; u < U; ++u) {
 #pragma unroll
-              for (int e = 0; e < VEC; ++e) acc[e] = mul_add<EXACT>(vj[u], bj[u].v[e], acc[e]);
+            for (int h = 0; h < CH; ++h) {
+              if (col_ok[h]) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[h][e] = mul_add<EXACT>(vj[u], bj[u][h].v[e], acc[h][e]);
+              }
             }
           }
         }
@@ -93,19 +105,19 @@ spmm_csr_rowgroup_kernel(int64_t M, int64_t N, const T* __restrict__ a_data,
             cj = lane_shfl(ci, gbase + j);
             vj = lane_shfl(vi, gbase + j);
           }
-          if (col_ok) {
-            V bj = *reinterpret_cast<const V*>(b + (int64_t)cj * ldb + col);
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) acc[e] = mul_add<EXACT>(vj, bj.v[e], acc[e]);
+          for (int h = 0; h < CH; ++h) {
+            if (col_ok[h]) {
+              V bj = *reinterpret_cast<const V*>(b + (int64_t)cj * ldb + col[h]);
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) acc[h][e] = mul_add<EXACT>(vj, bj.v[e], acc[h][e]);
+            }
           }
         }
       }
-      if (row_ok && col_ok) {
-        V o;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) o.v[e] = acc[e];
-        *reinterpret_cast<V*>(out + row * ldo + col) = o;
-      }
+      for (int h = 0; h < CH; ++h)
+        if (row_ok && col_ok[h]) nt_store<T, VEC>(out + row * ldo + col[h], acc[h]);
     }
   }
 }
@@ -114,7 +126,7 @@ struct SpmmVariant {
   int g = 0, vec = 0, unroll = 0;
   int64_t panel = 0;  // 0 = whole N in one pass
   int lds = -1;       // 1: LDS-DMA ring kernel
-  int depth = 0, rb = 0;
+  int depth = 0, rb = 0, ch = 0;
 };
 
 // Tuning hook: SPAMD_SPMM_VARIANT="G=32,VEC=2,U=8,PANEL=64" overrides the heuristic.
@@ -130,10 +142,11 @@ static SpmmVariant env_variant() {
   if ((p = strstr(e, "LDS="))) v.lds = atoi(p + 4);
   if ((p = strstr(e, "D="))) v.depth = atoi(p + 2);
   if ((p = strstr(e, "RB="))) v.rb = atoi(p + 3);
+  if ((p = strstr(e, "CH="))) v.ch = atoi(p + 3);
   return v;
 }
 
-template <typename T, typename I, int VEC, int G, bool EXACT, int UNROLL>
+template <typename T, typename I, int VEC, int G, bool EXACT, int UNROLL, int CH>
 static int launch_rowgroup(int64_t M, int64_t N, const T* a_data, const I* a_idx, const I* a_ptr,
                            const T* b, int64_t ldb, T* out, int64_t ldo, int64_t panel,
                            hipStream_t s) {
@@ -145,7 +158,7 @@ static int launch_rowgroup(int64_t M, int64_t N, const T* a_data, const I* a_idx
   if (blocks < 1) blocks = 1;
   if (panel <= 0 || panel > N) panel = N;
   const unsigned npanels = (unsigned)ceil_div(N, panel);
-  hipLaunchKernelGGL((spmm_csr_rowgroup_kernel<T, I, VEC, G, EXACT, UNROLL>),
+  hipLaunchKernelGGL((spmm_csr_rowgroup_kernel<T, I, VEC, G, EXACT, UNROLL, CH>),
                      dim3((unsigned)blocks, npanels), dim3(256), 0, s, M, N, a_data, a_idx, a_ptr, b,
                      ldb, out, ldo, panel);
   return launch_status();
@@ -183,13 +196,26 @@ static int dispatch_shape(int64_t M, int64_t K, int64_t N, const T* a_data, cons
                                                     ev.depth ? ev.depth : 8, ev.rb ? ev.rb : 32, s);
     if (rc != SPAMD_ETYPE) return rc;
   }
+  // column groups per lane: cover the panel in one pass over A when it is at most 4 groups wide
+  int ch = 1;
+  {
+    const int64_t groups = ceil_div(panel, (int64_t)g * vec);
+    ch = groups >= 4 ? 4 : (groups >= 2 ? 2 : 1);
+  }
+  if (ev.ch) ch = ev.ch;
 #define SPAMD_CASE(V, GG)                                                                        \
   if (vec == V && g == GG) {                                                                     \
-    if (unroll == 8)                                                                             \
-      return launch_rowgroup<T, I, V, GG, EXACT, 8>(M, N, a_data, a_idx, a_ptr, b, ldb, out, ldo, \
-                                                    panel, s);                                   \
-    return launch_rowgroup<T, I, V, GG, EXACT, 4>(M, N, a_data, a_idx, a_ptr, b, ldb, out, ldo,  \
-                                                  panel, s);                                     \
+    if (ch == 4)                                                                                 \
+      return launch_rowgroup<T, I, V, GG, EXACT, 8, 4>(M, N, a_data, a_idx, a_ptr, b, ldb, out,  \
+                                                       ldo, panel, s);                           \
+    if (ch == 2)                                                                                 \
+      return launch_rowgroup<T, I, V, GG, EXACT, 8, 2>(M, N, a_data, a_idx, a_ptr, b, ldb, out,  \
+                                                       ldo, panel, s);                           \
+    if (unroll == 4)                                                                             \
+      return launch_rowgroup<T, I, V, GG, EXACT, 4, 1>(M, N, a_data, a_idx, a_ptr, b, ldb, out,  \
+                                                       ldo, panel, s);                           \
+    return launch_rowgroup<T, I, V, GG, EXACT, 8, 1>(M, N, a_data, a_idx, a_ptr, b, ldb, out,    \
+                                                     ldo, panel, s);                             \
   }
   SPAMD_CASE(1, 64)
   SPAMD_CASE(2, 64)
