@@ -280,6 +280,46 @@ def gen_reduce(sp):
     _save("reduce", **cases)
 
 
+def gen_nd(sp):
+    """N2: N-D matmul broadcasting (`_matmul_recurser`), stack / concatenate, x[i]."""
+    cases = {}
+    rng = np.random.default_rng(81)
+    shapes = [((2, 3, 4, 5), (2, 3, 5, 6)), ((2, 1, 3, 4), (1, 5, 4, 6)), ((3, 4), (2, 4, 5)), ((2, 3, 4), (4, 5)),
+              ((1, 1, 4), (3, 4, 2)), ((3, 2, 4, 5), (1, 5, 3))]
+    for k, (sa, sb) in enumerate(shapes):
+        a = sp.random(sa, density=0.4, random_state=90 + k)
+        b = sp.random(sb, density=0.4, random_state=190 + k)
+        bd = rng.random(sb)
+        r_ss = sp.matmul(a, b)
+        r_sd = sp.matmul(a, bd)
+        r_ds = sp.matmul(bd.swapaxes(-1, -2) if False else rng.random(sa), b)
+        cases.update({f"m{k}_a_coords": a.coords, f"m{k}_a_data": a.data, f"m{k}_a_shape": np.array(sa),
+                      f"m{k}_b_coords": b.coords, f"m{k}_b_data": b.data, f"m{k}_b_shape": np.array(sb),
+                      f"m{k}_bd": bd, f"m{k}_ss": r_ss.todense() if hasattr(r_ss, "todense") else r_ss,
+                      f"m{k}_ss_sparse": np.array(hasattr(r_ss, "todense")),
+                      f"m{k}_sd": r_sd.todense() if hasattr(r_sd, "todense") else r_sd})
+        ga, gb = sp.GCXS(a), sp.GCXS(b)
+        r_gg = sp.matmul(ga, gb)
+        cases[f"m{k}_gg"] = r_gg.todense()
+        cases[f"m{k}_gg_fmt"] = np.array(r_gg.format)
+    cases["n_matmul"] = np.array(len(shapes))
+    xs = [sp.random((4, 5, 3), density=0.3, random_state=300 + i) for i in range(3)]
+    for i, x in enumerate(xs):
+        cases.update({f"s{i}_coords": x.coords, f"s{i}_data": x.data})
+    for ax in (0, 1, 2, 3, -1):
+        r = sp.stack(xs, axis=ax)
+        cases.update({f"stack{ax}_coords": r.coords, f"stack{ax}_data": r.data, f"stack{ax}_shape": np.array(r.shape)})
+    for ax in (0, 1, 2):
+        r = sp.concatenate(xs, axis=ax)
+        cases.update({f"cat{ax}_coords": r.coords, f"cat{ax}_data": r.data, f"cat{ax}_shape": np.array(r.shape)})
+    r = sp.concatenate([sp.GCXS(x, compressed_axes=(0,)) for x in xs], axis=1)
+    cases.update(gcat_fmt=np.array(r.format), gcat_dense=r.todense())
+    for i in (0, 2, -1):
+        r = xs[0][i]
+        cases.update({f"take{i}_coords": r.coords, f"take{i}_data": r.data})
+    _save("nd", **cases)
+
+
 def main():
     sp = ref_loader.load()
     print("reference:", sp.__file__)
@@ -287,6 +327,7 @@ def main():
     gen_convert(sp)
     gen_elemwise(sp)
     gen_reduce(sp)
+    gen_nd(sp)
 
 
 if __name__ == "__main__":

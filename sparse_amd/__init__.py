@@ -17,10 +17,11 @@ from ._coo import COO, as_coo
 from ._gcxs import GCXS
 from ._dot import dot, matmul, tensordot
 from ._umath import elemwise
+from ._batched import concatenate, stack
 from ._api import (all, any, asarray, astype, matrix_transpose, max, mean, min, permute_dims, prod, random, reshape,
                    sddmm, std, sum, var, vecdot)
 from ._ffi import HipBackendError
 
-__all__ = ["COO", "GCXS", "SparseArray", "HipBackendError", "all", "any", "as_coo", "asarray", "astype", "dot",
+__all__ = ["COO", "GCXS", "SparseArray", "HipBackendError", "all", "any", "as_coo", "asarray", "astype", "concatenate", "dot",
            "elemwise", "matmul", "matrix_transpose", "max", "mean", "min", "permute_dims", "prod", "random", "reshape",
-           "sddmm", "std", "sum", "tensordot", "var", "vecdot"]
+           "sddmm", "stack", "std", "sum", "tensordot", "var", "vecdot"]

@@ -1,10 +1,149 @@
-"""N-D matmul broadcasting (reference `_matmul_recurser`, _common.py:278-293): SURVEY.md §8f row N2
-("next").  Not built in round 1."""
+"""N-D matmul broadcasting and the stack/concatenate/leading-index helpers it needs
+(reference `_matmul_recurser`, _common.py:278-293; `_coo/common.py:132-249`;
+`_compressed/common.py:6-96`).
+
+Everything stays on linear keys: `x[i]` is a contiguous key range of a canonical COO (found by
+two binary searches), `stack`/`concatenate` offset the keys of each piece and append them (pieces
+along axis 0 are already in order, so no re-sort)."""
+import numpy as np
+import torch
+
+from . import _ffi
+from . import _kernels as K
+from ._device import ptr, stream_ptr
 
 
-def matmul_batched(a, b):
-    raise NotImplementedError("N-D (x) N-D matmul broadcasting is a 'next' row (SURVEY.md §8f N2)")
+def _key_range(keys, lo_key, hi_key):
+    """[first index with key >= lo_key, first index with key >= hi_key) in a sorted key array."""
+    dev = keys.device
+    q = torch.tensor([lo_key, hi_key], dtype=torch.int64, device=dev)
+    pos = torch.empty(2, dtype=torch.int64, device=dev)
+    m = torch.empty(3, dtype=torch.int64, device=dev)
+    _ffi.call("spamd_lower_bound_match", 2, ptr(q), keys.numel(), ptr(keys), ptr(pos), ptr(m), stream_ptr(dev))
+    lo, hi = pos.tolist()
+    return int(lo), int(hi)
 
 
 def take_leading(x, i):
-    raise NotImplementedError("integer indexing is a 'next' row (SURVEY.md §8f N2)")
+    """`x[i]` for an integer i on the leading axis (COO or GCXS; result has the same format)."""
+    from ._coo import COO
+    from ._gcxs import GCXS
+    from ._umath import binary_arrays
+
+    if x.ndim == 0:
+        raise IndexError("too many indices for array")
+    n0 = x.shape[0]
+    if i < 0:
+        i += n0
+    if not 0 <= i < n0:
+        raise IndexError(f"index {i} is out of bounds for axis 0 with size {n0}")
+    is_gcxs = isinstance(x, GCXS)
+    c = x.tocoo() if is_gcxs else x
+    stride = 1
+    for s in c.shape[1:]:
+        stride *= s
+    keys = c.linear_loc()
+    lo, hi = _key_range(keys, i * stride, (i + 1) * stride)
+    sub_keys = keys[lo:hi].contiguous()
+    if hi > lo and i:
+        sub_keys = binary_arrays("subtract", sub_keys, torch.tensor([i * stride], dtype=torch.int64, device=keys.device),
+                                 b_scalar=True)
+    out = COO(c.coords[1:, lo:hi].contiguous(), c.data[lo:hi].contiguous(), shape=c.shape[1:], has_duplicates=False,
+              sorted=True, fill_value=c.fill_value)
+    out._keys = sub_keys
+    return out.asformat("gcxs") if is_gcxs and out.ndim >= 1 else out
+
+
+def concatenate(arrays, axis=0):
+    """Join sparse arrays along an existing axis (reference _coo/common.py:132-192)."""
+    from ._coo import COO, as_coo
+    from ._gcxs import GCXS
+    from ._umath import binary_arrays
+    from ._utils import normalize_axis
+
+    arrays = list(arrays)
+    if not arrays:
+        raise ValueError("need at least one array to concatenate")
+    all_gcxs = all(isinstance(a, GCXS) for a in arrays)
+    coos = [as_coo(a) for a in arrays]
+    fv = coos[0].fill_value
+    for k, c in enumerate(coos):
+        if not np.array_equal(np.asarray(c.fill_value), np.asarray(fv), equal_nan=True):
+            raise ValueError("This operation requires consistent fill-values, "
+                             f"but argument {k:d} had a fill value of {c.fill_value!s}, which "
+                             f"is different from a fill_value of {fv!s} in the first argument.")
+    axis = normalize_axis(axis, coos[0].ndim)
+    ref_shape = coos[0].shape
+    for c in coos:
+        if c.ndim != len(ref_shape) or any(c.shape[d] != ref_shape[d] for d in range(c.ndim) if d != axis):
+            raise ValueError("All arrays must have the same shape except for the concatenation axis.")
+    dt = np.result_type(*[c.dtype for c in coos])
+    dev = coos[0].device
+    it = torch.int64 if any(c.coords.dtype == torch.int64 for c in coos) else torch.int32
+    total = sum(c.shape[axis] for c in coos)
+    shape = tuple(total if d == axis else ref_shape[d] for d in range(len(ref_shape)))
+    parts_c, parts_d, off = [], [], 0
+    for c in coos:
+        cc = c.coords.to(it).clone()
+        if off and c.nnz:
+            cc[axis] = binary_arrays("add", cc[axis].contiguous(), torch.tensor([off], dtype=it, device=dev), b_scalar=True)
+        parts_c.append(cc)
+        parts_d.append(K.convert(c.data, dt))
+        off += c.shape[axis]
+    out = COO(torch.cat(parts_c, dim=1), torch.cat(parts_d), shape=shape, has_duplicates=False, sorted=(axis == 0),
+              fill_value=fv)
+    return out.asformat("gcxs") if all_gcxs else out
+
+
+def stack(arrays, axis=0):
+    """Join sparse arrays along a NEW axis (reference _coo/common.py:195-249)."""
+    from ._coo import COO, as_coo
+    from ._gcxs import GCXS
+
+    arrays = list(arrays)
+    if not arrays:
+        raise ValueError("need at least one array to stack")
+    all_gcxs = all(isinstance(a, GCXS) for a in arrays)
+    coos = [as_coo(a) for a in arrays]
+    if any(c.shape != coos[0].shape for c in coos):
+        raise ValueError("All arrays must have the same shape.")
+    nd = coos[0].ndim
+    if axis < 0:
+        axis += nd + 1
+    lifted = [c[(None,)] for c in coos]              # new leading axis of length 1
+    out = concatenate(lifted, axis=0)                 # stack along axis 0 ...
+    if axis != 0:                                     # ... then move it into place
+        perm = list(range(1, nd + 1))
+        perm.insert(axis, 0)
+        out = out.transpose(perm)
+    return out.asformat("gcxs") if all_gcxs else out
+
+
+def matmul_batched(a, b):
+    """`_matmul_recurser` (reference _common.py:278-293): loop over the broadcast leading axis,
+    2-D `dot` per slice, stack the results."""
+    from ._dot import dot
+    from ._sparse_array import SparseArray
+
+    def idx(x, i):
+        if isinstance(x, SparseArray):
+            return x[i]
+        return x[i]
+
+    def rec(a, b):
+        if a.ndim == 2:
+            return dot(a, b)
+        res = []
+        for i in range(max(a.shape[0], b.shape[0])):
+            a_i = idx(a, 0) if a.shape[0] == 1 else idx(a, i)
+            b_i = idx(b, 0) if b.shape[0] == 1 else idx(b, i)
+            res.append(rec(a_i, b_i))
+        if all(isinstance(x, SparseArray) for x in res):
+            return stack(res)
+        res = [x.todense_device() if isinstance(x, SparseArray) else x for x in res]
+        if all(isinstance(x, np.ndarray) for x in res):
+            return np.stack(res)
+        dev0 = next(x.device for x in res if isinstance(x, torch.Tensor))
+        return torch.stack([x if isinstance(x, torch.Tensor) else torch.from_numpy(x).to(dev0) for x in res])
+
+    return rec(a, b)

@@ -391,18 +391,12 @@ class COO(SparseArray, NDArrayOperatorsMixin):
     def __matmul__(self, other):
         from ._dot import matmul
 
-        try:
-            return matmul(self, other)
-        except NotImplementedError:
-            return NotImplemented
+        return matmul(self, other)
 
     def __rmatmul__(self, other):
         from ._dot import matmul
 
-        try:
-            return matmul(other, self)
-        except NotImplementedError:
-            return NotImplemented
+        return matmul(other, self)
 
 
 def as_coo(x, shape=None, fill_value=None, idx_dtype=None, device=None):

@@ -284,6 +284,16 @@ class GCXS(SparseArray, NDArrayOperatorsMixin):
         return GCXS((self.data, self.indices, self.indptr), shape=self.shape[::-1], compressed_axes=ca,
                     fill_value=self.fill_value)
 
+    def __getitem__(self, index):
+        """Only the forms N-D `matmul` needs: `x[(None,) * k]` and `x[i]`."""
+        if isinstance(index, tuple) and all(i is None for i in index):
+            return self.tocoo()[index].asformat("gcxs") if index else self
+        if isinstance(index, (int, np.integer)):
+            from ._batched import take_leading
+
+            return take_leading(self, int(index))
+        raise NotImplementedError("general indexing is outside the hip backend's hot path (SURVEY.md §8f N2)")
+
     def dot(self, other):
         from ._dot import dot
 
@@ -292,18 +302,12 @@ class GCXS(SparseArray, NDArrayOperatorsMixin):
     def __matmul__(self, other):
         from ._dot import matmul
 
-        try:
-            return matmul(self, other)
-        except NotImplementedError:
-            return NotImplemented
+        return matmul(self, other)
 
     def __rmatmul__(self, other):
         from ._dot import matmul
 
-        try:
-            return matmul(other, self)
-        except NotImplementedError:
-            return NotImplemented
+        return matmul(other, self)
 
     def _prune(self):
         """Drop stored entries bit-equal to the fill value (reference compressed.py:816-848)."""

@@ -43,9 +43,6 @@ def reduce_impl(x, method, axis=(0,), keepdims=False, **kwargs):
     from ._umath import binary_arrays, select
 
     name = getattr(method, "__name__", str(method))
-    if name not in _RED_OPS:
-        raise NotImplementedError(f"reduction with {method!s} is not on the hip backend's path "
-                                  f"(supported: {sorted(_RED_OPS)})")
     out_gcxs = isinstance(x, GCXS)
     if out_gcxs:
         x = x.tocoo()
@@ -59,6 +56,9 @@ def reduce_impl(x, method, axis=(0,), keepdims=False, **kwargs):
     super_ufunc = _SUPER.get(name)
     if not equivalent(zero_reduce_result, fv) and super_ufunc is None:
         raise ValueError(f"Performing this reduction operation would produce a dense result: {method!s}")
+    if name not in _RED_OPS:
+        raise NotImplementedError(f"reduction with {method!s} is not on the hip backend's path "
+                                  f"(supported: {sorted(_RED_OPS)})")
     if not isinstance(axis, tuple):
         axis = (axis,)
     if axis == (None,):
@@ -142,3 +142,74 @@ def reduce_impl(x, method, axis=(0,), keepdims=False, **kwargs):
     if out_gcxs:
         return out.asformat("gcxs")
     return out
+
+
+def var_impl(x, axis=None, dtype=None, ddof=0, keepdims=False):
+    """Variance over `axis` (reference `SparseArray.var`, _sparse_array.py:725-814).
+
+    The reference composes it from `sum(keepdims)` / broadcast subtract / square / `sum`, which
+    materialises a nearly dense intermediate.  Here the same two-pass formula is evaluated per
+    group on the device: var_g = (sum_stored (x - m_g)^2 + n_fill_g * m_g^2) / (n - ddof) with
+    m_g = sum_g / n — equal to the reference up to summation order (fp tolerance)."""
+    import warnings
+
+    from ._coo import COO
+    from ._gcxs import GCXS
+    from ._umath import binary_arrays
+
+    out_gcxs = isinstance(x, GCXS)
+    if out_gcxs:
+        x = x.tocoo()
+    if not equivalent(x.fill_value, 0, loose=True):
+        raise NotImplementedError("var/std with a non-zero fill value is not on the hip backend's path")
+    axis = normalize_axis(axis, x.ndim)
+    if axis is None:
+        axis = tuple(range(x.ndim))
+    if not isinstance(axis, tuple):
+        axis = (axis,)
+    kept = tuple(ax for ax in range(x.ndim) if ax not in set(axis))
+    rcount = prod(x.shape[a] for a in axis)
+    if ddof >= rcount:
+        warnings.warn("Degrees of freedom <= 0 for slice", RuntimeWarning, stacklevel=1)
+    if dtype is None:
+        dtype = np.dtype("f8") if x.dtype.kind in "iub" else x.dtype
+    work = torch_dtype(dtype)
+    dev = x.device
+    n_groups, n_cols = prod(x.shape[d] for d in kept), rcount
+    keys, data = x.linear_loc(), K.convert(x.data, work)
+    order = kept + tuple(axis)
+    if order != tuple(range(x.ndim)) and x.nnz:
+        keys = K.permute_keys(keys, x.shape, order)
+        keys, perm = K.sort_keys(keys, max(x.size - 1, 1))
+        data = K.gather(data, perm)
+    denom = max(rcount - ddof, 0)
+    if x.nnz:
+        one64 = _scalar_dev(1, torch.int64, dev)
+        gk = binary_arrays("floor_divide_i64", keys, _scalar_dev(max(n_cols, 1), torch.int64, dev), b_scalar=True)
+        heads = K.flag_heads(gk)
+        offs = K.exclusive_scan(heads)
+        count = int(offs[-1])
+        sums, counts = segment_reduce(data, heads, offs, count, "add", want_counts=True)
+        mean = binary_arrays("divide", sums, _scalar_dev(rcount, work, dev), b_scalar=True)
+        gi = binary_arrays("subtract", offs[1:].contiguous(), one64, b_scalar=True)  # group index of each element
+        d = binary_arrays("subtract", data, K.gather(mean, gi))
+        s1 = segment_reduce(binary_arrays("multiply", d, d), heads, offs, count, "add")
+        n_fill = K.convert(binary_arrays("subtract", _scalar_dev(n_cols, torch.int64, dev), counts, a_scalar=True), work)
+        s = binary_arrays("add", s1, binary_arrays("multiply", n_fill, binary_arrays("multiply", mean, mean)))
+        with np.errstate(all="ignore"):
+            vals = binary_arrays("divide", s, _scalar_dev(float(denom), work, dev), b_scalar=True)
+        gids = K.compact(gk, heads, offs, count)
+    else:
+        vals = data[:0]
+        gids = torch.empty(0, dtype=torch.int64, device=dev)
+    out = COO(gids[None, :], vals, shape=(n_groups,), has_duplicates=False, sorted=True, prune=True,
+              fill_value=np.dtype(dtype).type(0))
+    out = out.reshape(tuple(x.shape[d] for d in kept))
+    if keepdims:
+        shape = list(x.shape)
+        for ax in axis:
+            shape[ax] = 1
+        out = out.reshape(shape)
+    if out.ndim == 0:
+        return COO.from_numpy(out.todense_device())
+    return out.asformat("gcxs") if out_gcxs else out

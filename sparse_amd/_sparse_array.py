@@ -206,27 +206,10 @@ class SparseArray:
         return np.divide(num, den, dtype=dtype, out=out)
 
     def var(self, axis=None, dtype=None, out=None, ddof=0, keepdims=False):
-        """Two-pass variance as the reference composes it (_sparse_array.py:725-814)."""
-        axis = normalize_axis(axis, self.ndim)
-        if axis is None:
-            axis = tuple(range(self.ndim))
-        if not isinstance(axis, tuple):
-            axis = (axis,)
-        rcount = 1
-        for ax in axis:
-            rcount *= self.shape[ax]
-        if dtype is None and issubclass(self.dtype.type, (np.integer, np.bool_)):
-            dtype = np.dtype("f8")
-        arrmean = self.sum(axis, dtype=dtype, keepdims=True)[...]
-        np.divide(arrmean, rcount, out=arrmean)
-        x = self - arrmean
-        if issubclass(self.dtype.type, np.complexfloating):
-            x = x.real * x.real + x.imag * x.imag
-        else:
-            x = np.multiply(x, x, out=x)
-        ret = x.sum(axis=axis, dtype=dtype, out=out, keepdims=keepdims)
-        rcount = max(rcount - ddof, 0)
-        return np.divide(ret, rcount, out=ret)
+        """Variance (reference _sparse_array.py:725-814), evaluated per group on the device."""
+        from ._reduce import var_impl
+
+        return var_impl(self, axis=axis, dtype=dtype, ddof=ddof, keepdims=keepdims)
 
     def std(self, axis=None, dtype=None, out=None, ddof=0, keepdims=False):
         ret = self.var(axis=axis, dtype=dtype, out=out, ddof=ddof, keepdims=keepdims)

@@ -236,23 +236,21 @@ def test_reductions(sp):
     done = 0
     for k in range(int(g["n_reduce"])):
         name = str(g[f"r{k}_name"])
-        if name in ("var", "std"):
-            continue
         axis = g[f"r{k}_axis"]
         axis = None if axis.ndim == 0 and int(axis) == -99 else (int(axis) if axis.ndim == 0 else tuple(int(a) for a in axis))
         r = getattr(x, name)(axis=axis, keepdims=bool(g[f"r{k}_keepdims"]))
         want = g[f"r{k}_dense"]
         got = r.todense()
         assert got.shape == want.shape and got.dtype == want.dtype, (name, axis)
-        if name in ("sum", "mean", "prod") and want.dtype.kind == "f":
-            assert np.allclose(got, want, rtol=1e-13, atol=1e-15), (name, axis)
+        if name in ("sum", "mean", "prod", "var", "std") and want.dtype.kind == "f":
+            assert np.allclose(got, want, rtol=1e-12, atol=1e-15), (name, axis)
         else:
             assert np.array_equal(got, want), (name, axis)
-        if r.ndim:
+        if r.ndim and name not in ("var", "std"):
             assert r.nnz == int(g[f"r{k}_nnz"]), (name, axis)
         assert np.allclose(np.asarray(r.fill_value, dtype=np.float64), np.asarray(g[f"r{k}_fill"], dtype=np.float64)), (name, axis)
         done += 1
-    assert done >= 100
+    assert done == int(g["n_reduce"])
     r = (x + 1).sum(axis=1)  # non-zero fill value: Appendix D5
     assert np.allclose(r.todense(), g["fv_dense"], rtol=1e-13) and float(r.fill_value) == float(g["fv_fill"])
     gx = sp.GCXS(x, compressed_axes=(1,))
