@@ -18,10 +18,12 @@ from ._gcxs import GCXS
 from ._dot import dot, matmul, tensordot
 from ._umath import elemwise
 from ._batched import concatenate, stack
+from ._broadcast import broadcast_to
+from ._io import load_npz, save_npz
 from ._api import (all, any, asarray, astype, matrix_transpose, max, mean, min, permute_dims, prod, random, reshape,
                    sddmm, std, sum, var, vecdot)
 from ._ffi import HipBackendError
 
-__all__ = ["COO", "GCXS", "SparseArray", "HipBackendError", "all", "any", "as_coo", "asarray", "astype", "concatenate", "dot",
-           "elemwise", "matmul", "matrix_transpose", "max", "mean", "min", "permute_dims", "prod", "random", "reshape",
-           "sddmm", "stack", "std", "sum", "tensordot", "var", "vecdot"]
+__all__ = ["COO", "GCXS", "SparseArray", "HipBackendError", "all", "any", "as_coo", "asarray", "astype", "broadcast_to", "concatenate", "dot",
+           "elemwise", "load_npz", "matmul", "matrix_transpose", "max", "mean", "min", "permute_dims", "prod", "random", "reshape",
+           "save_npz", "sddmm", "stack", "std", "sum", "tensordot", "var", "vecdot"]

@@ -1,5 +1,80 @@
-"""Sparse (x) sparse broadcasting (reference _umath.py:95-389): SURVEY.md §8f row N3 ("next")."""
+"""Sparse (x) sparse broadcasting (reference _umath.py:95-389 `broadcast_to`
+and the reduced-coordinate matching of `_match_coo`).
+
+`broadcast_to` materialises the broadcast array on the device: with base[e] = key of entry e
+under the target strides (size-1 axes contribute 0) and off[r] = key offset of replica r along
+the broadcast axes, the result's keys are the outer sum base[e] + off[r] (then one stable sort).
+Elementwise ops on operands of different shapes broadcast both sides and take the same-shape
+union path; results equal the reference's mask-matching (which only avoids the materialisation)."""
+import numpy as np
+import torch
+
+from . import _ffi
+from . import _kernels as K
+from ._device import ptr, stream_ptr
+
+
+def broadcast_shapes(*shapes):
+    try:
+        return tuple(int(s) for s in np.broadcast_shapes(*shapes))
+    except ValueError:
+        raise ValueError(f"operands could not be broadcast together with shapes {' '.join(str(s) for s in shapes)}") from None
+
+
+def broadcast_to(x, shape):
+    """COO broadcast to `shape` (reference `broadcast_to`, _umath.py:344-389)."""
+    from ._coo import COO
+    from ._umath import binary_arrays
+
+    shape = tuple(int(s) for s in shape)
+    if x.shape == shape:
+        return x
+    if broadcast_shapes(x.shape, shape) != shape:
+        raise ValueError(f"The shapes {x.shape} and {shape} are not broadcastable.")
+    nd = len(shape)
+    xs = (1,) * (nd - x.ndim) + tuple(x.shape)
+    bdims = [d for d in range(nd) if xs[d] == 1 and shape[d] != 1]
+    rep = 1
+    for d in bdims:
+        rep *= shape[d]
+    dev = x.device
+    strides = K.c_strides(shape)
+    nnz = x.nnz
+    if nnz == 0 or rep == 0 or any(s == 0 for s in shape):
+        return COO(torch.zeros((nd, 0), dtype=x.coords.dtype, device=dev), x.data[:0], shape=shape,
+                   has_duplicates=False, sorted=True, fill_value=x.fill_value)
+    # base[e]: x's coordinates weighted by the TARGET strides of the axes x really has
+    lead = nd - x.ndim
+    base = torch.empty(nnz, dtype=torch.int64, device=dev)
+    _ffi.call("spamd_coo_linearize", K.code_of(x.coords.dtype), x.ndim, nnz, ptr(x.coords.contiguous()), nnz,
+              K._harr64(strides[lead:]), K._harr32(range(x.ndim)), ptr(base), stream_ptr(dev))
+    # off[r]: host-side (rep entries) offsets of the replicas along the broadcast axes
+    bshape = [shape[d] for d in bdims]
+    grids = np.indices(bshape).reshape(len(bdims), -1) if bdims else np.zeros((0, 1), dtype=np.int64)
+    off = np.zeros(rep, dtype=np.int64)
+    for j, d in enumerate(bdims):
+        off += grids[j].astype(np.int64) * strides[d]
+    off_t = torch.from_numpy(off).to(dev)
+    n_out = nnz * rep
+    t = torch.empty(n_out, dtype=torch.int64, device=dev)
+    _ffi.call("spamd_iota", n_out, ptr(t), stream_ptr(dev))
+    rep_t = torch.tensor([rep], dtype=torch.int64, device=dev)
+    e = binary_arrays("floor_divide_i64", t, rep_t, b_scalar=True)
+    r = binary_arrays("subtract", t, binary_arrays("multiply", e, rep_t, b_scalar=True))
+    keys = binary_arrays("add", K.gather(base, e), K.gather(off_t, r))
+    data = K.gather(x.data, e)
+    size = 1
+    for s in shape:
+        size *= s
+    keys, perm = K.sort_keys(keys, max(size - 1, 1))
+    data = K.gather(data, perm)
+    it = x.coords.dtype if max(shape) < 2 ** 31 or x.coords.dtype == torch.int64 else torch.int64
+    out = COO(K.delinearize(keys, shape, it), data, shape=shape, has_duplicates=False, sorted=True,
+              fill_value=x.fill_value)
+    out._keys = keys
+    return out
 
 
 def broadcast_pair(a, b):
-    raise NotImplementedError("broadcasting between sparse operands is a 'next' row (SURVEY.md §8f N3)")
+    shape = broadcast_shapes(a.shape, b.shape)
+    return broadcast_to(a, shape), broadcast_to(b, shape)

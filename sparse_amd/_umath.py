@@ -258,7 +258,12 @@ def elemwise(func, *args, **kwargs):
         x, d = (a, b) if a_sp else (b, a)
         dt = dev.to_device(d, devi)
         if tuple(dt.shape) != tuple(shape):
-            raise NotImplementedError("broadcasting a dense operand is not on the hip backend's path")
+            from ._broadcast import broadcast_shapes
+
+            if broadcast_shapes(tuple(dt.shape), tuple(shape)) != tuple(shape):
+                raise ValueError("Performing a mixed sparse-dense operation that would result in a dense array. "
+                                 "Please make sure that func(sparse_fill_values, ndarrays) is a constant array.")
+            dt = dt.broadcast_to(shape).contiguous()  # view + copy: memory plumbing only
         # the result stays sparse only if func(fill, dense) is constant (reference :525-548)
         probe_fill = _np_result(func, *((np.asarray(x.fill_value), np.zeros(1, dev.np_dtype(dt.dtype))) if a_sp
                                         else (np.zeros(1, dev.np_dtype(dt.dtype)), np.asarray(x.fill_value))))

@@ -87,3 +87,33 @@ def test_exception_parity(sp):
     assert np.allclose(np.tensordot(x, y, axes=1), x.todense() @ y)
     assert np.allclose(np.matmul(x, y), x.todense() @ y)
     assert float(np.sum(x).todense()) == 3.0
+
+
+def test_broadcasting_and_npz_interchange(sp, tmp_path):
+    """N3: sparse (x) sparse / sparse (x) dense broadcasting vs the reference's result; N4: npz files
+    written here load in the reference's layout and vice versa (layout = reference _io.py:49-62)."""
+    ge = np.load(os.path.join(GOLD, "elemwise.npz"))
+    shape = tuple(ge["shape"])
+    x = sp.COO(ge["x_coords"], ge["x_data"], shape=shape)
+    z = sp.COO(ge["bz_coords"], ge["bz_data"], shape=(8, 1))
+    r = x * z
+    assert r.shape == shape
+    assert np.array_equal(r.coords.cpu().numpy(), ge["bmul_coords"])
+    assert np.array_equal(r.data.cpu().numpy(), ge["bmul_data"])
+    zb = sp.broadcast_to(z, shape)
+    assert np.array_equal(zb.todense(), np.broadcast_to(z.todense(), shape))
+    d = np.linspace(0.5, 2.0, shape[2])
+    assert np.array_equal((x * d).todense(), x.todense() * d)
+    # npz round trip + the reference's key layout
+    p = tmp_path / "a.npz"
+    sp.save_npz(p, x)
+    with np.load(p) as f:
+        assert set(f.files) == {"data", "coords", "shape", "fill_value"}
+    y = sp.load_npz(p)
+    assert np.array_equal(y.coords.cpu().numpy(), ge["x_coords"]) and np.array_equal(y.data.cpu().numpy(), ge["x_data"])
+    gx = sp.GCXS(x, compressed_axes=(1,))
+    sp.save_npz(p, gx)
+    with np.load(p) as f:
+        assert set(f.files) == {"data", "indices", "indptr", "compressed_axes", "shape", "fill_value"}
+    gy = sp.load_npz(p)
+    assert gy.compressed_axes == (1,) and np.array_equal(gy.todense(), x.todense())
