@@ -1,0 +1,108 @@
+"""Size-independent properties at BASELINE.json's full sizes (where the oracle would take too
+long): the checks the domain offers — set algebra of the index merge, identities, linearity."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sp():
+    import sparse_amd
+
+    return sparse_amd
+
+
+def test_config1_elementwise_add_mul_full_size(sp):
+    """config 1: two COO (1000,1000,1000) with 1e6 nnz each, f64/int64."""
+    shape = (1000, 1000, 1000)
+    x = sp.random(shape, nnz=1_000_000, random_state=0)
+    y = sp.random(shape, nnz=1_000_000, random_state=1)
+    z = x + y
+    kx, ky, kz = x.linear_loc(), y.linear_loc(), z.linear_loc()
+    both = torch.isin(kx, ky).sum().item()
+    assert z.nnz == 2_000_000 - both                      # |union| (values are in (0,1): no cancellation)
+    assert torch.equal(kz, torch.unique(torch.cat([kx, ky])))  # sorted, duplicate-free, exact index set
+    assert bool((kz[1:] > kz[:-1]).all())
+    m = x * y
+    assert m.nnz == both and torch.equal(m.linear_loc(), kx[torch.isin(kx, ky)])
+    # (x + y) - y == x on x's pattern, exactly 0 elsewhere up to fp rounding of one add/sub
+    w = z - y
+    dx = w.todense_device().reshape(-1)[kx]
+    assert torch.allclose(dx, x.data, rtol=0, atol=2.3e-16)
+    # sum is linear and order-insensitive to ~1 ulp * sqrt(n)
+    s = float(z.sum().todense())
+    assert abs(s - (float(x.data.sum()) + float(y.data.sum()))) < 1e-6
+
+
+def test_reduce_consistency_full_size(sp):
+    x = sp.random((1000, 1000, 1000), nnz=1_000_000, random_state=2)
+    total = float(x.sum().todense())
+    for axis in (0, 1, 2, (0, 1), (1, 2)):
+        part = x.sum(axis=axis)
+        assert abs(float(part.sum().todense()) - total) < 1e-7 * abs(total)
+    assert float(x.max().todense()) == float(x.data.max())
+    assert float(x.min().todense()) == 0.0  # implicit zeros fold in
+
+
+def test_config3_tensordot_identity_and_linearity(sp):
+    """config 3 shape class: 3-D COO (256^3 @ 1 %) . dense, axes=1."""
+    n = 256
+    c3 = sp.random((n, n, n), density=0.01, random_state=3)
+    eye = torch.eye(n, dtype=torch.float64, device="cuda")
+    r = sp.tensordot(c3, eye, axes=1)
+    assert torch.equal(r, c3.todense_device())            # contraction with I returns the array, exactly
+    g = torch.Generator(device="cuda").manual_seed(1)
+    d1 = torch.rand((n, 64), generator=g, device="cuda", dtype=torch.float64)
+    d2 = torch.rand((n, 64), generator=g, device="cuda", dtype=torch.float64)
+    lhs = sp.tensordot(c3, d1 + d2, axes=1)
+    rhs = sp.tensordot(c3, d1, axes=1) + sp.tensordot(c3, d2, axes=1)
+    assert torch.allclose(lhs, rhs, rtol=1e-13, atol=1e-14)
+    # GCXS operand of the same array gives the same result (different kernel path: CSC re-compression)
+    g3 = sp.GCXS(c3)  # default compressed_axes = argmin(shape)
+    assert torch.allclose(sp.tensordot(g3, d1, axes=1), sp.tensordot(c3, d1, axes=1), rtol=1e-13, atol=1e-14)
+
+
+def test_config4_sddmm_properties(sp):
+    """config 4 shape class: mask 3e4 x 3e4 @ 0.1 %, K = 256, bf16 operands."""
+    M = 30_000
+    s = sp.random((M, M), density=0.001, random_state=4, dtype=np.float32, idx_dtype=np.int32)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    a = torch.rand((M, 256), generator=g, device="cuda").to(torch.bfloat16)
+    bt = torch.rand((M, 256), generator=g, device="cuda").to(torch.bfloat16)
+    r = sp.sddmm(s, a, bt=bt)
+    assert r.nnz == s.nnz and torch.equal(r.coords, s.coords)   # positive operands: pattern preserved
+    # scaling the mask scales the result exactly (power of two)
+    r2 = sp.sddmm(s * np.float32(2.0), a, bt=bt)
+    assert torch.equal(r2.data, r.data * 2)
+    # all-ones rank-1 operands: out = s * K exactly
+    ones = torch.ones((M, 256), device="cuda", dtype=torch.bfloat16)
+    r3 = sp.sddmm(s, ones, bt=ones)
+    assert torch.equal(r3.data, s.data * 256)
+
+
+def test_spgemm_identity_and_transpose(sp):
+    n = 20_000
+    a = sp.random((n, n), density=5e-4, random_state=5, format="gcxs", compressed_axes=(0,))
+    eye = sp.GCXS((np.ones(n), np.arange(n), np.arange(n + 1)), shape=(n, n), compressed_axes=(0,))
+    r = a @ eye
+    assert isinstance(r, sp.GCXS)
+    assert torch.equal(r.data, a.data) and torch.equal(r.indices.long(), a.indices.long())
+    # (A B)^T == B^T A^T, structure exactly and values to fp tolerance
+    b = sp.random((n, n), density=5e-4, random_state=6, format="gcxs", compressed_axes=(0,))
+    ab = (a @ b).tocoo()
+    btat = (b.T @ a.T).tocoo().transpose((1, 0))
+    assert torch.equal(ab.coords, btat.coords)
+    assert torch.allclose(ab.data, btat.data, rtol=1e-13, atol=0)
+
+
+def test_conversion_roundtrip_full_size(sp):
+    x = sp.random((200, 300, 400), nnz=3_000_000, random_state=7)
+    for ca in ((0,), (2,), (0, 2)):
+        g = sp.GCXS(x, compressed_axes=ca)
+        back = g.tocoo()
+        assert torch.equal(back.coords, x.coords) and torch.equal(back.data, x.data)
+        assert int(g.indptr[-1]) == x.nnz and bool((g.indptr[1:] >= g.indptr[:-1]).all())
+    t = x.transpose((2, 0, 1)).transpose((1, 2, 0))
+    assert torch.equal(t.coords, x.coords) and torch.equal(t.data, x.data)
