@@ -163,13 +163,28 @@ int spamd_ewise_binary(int op, int val_dtype, int64_t n, const void* a, int a_is
  *   30 rad2deg (out dtype = val_dtype); 64 isnan 65 isinf 66 isfinite 67 logical_not 68 signbit (out U8) */
 int spamd_ewise_unary(int op, int val_dtype, int64_t n, const void* a, void* out, void* stream);
 
+/* Merge-path form of the same union, fused with the function and the prune (the default path):
+ *   nblocks = spamd_merge_num_blocks(na, nb);  part[nblocks+1] <- spamd_merge_partition;
+ *   spamd_merge_union(fill=0, ...) -> counts[nblocks]; host: exclusive scan -> offsets, total;
+ *   spamd_merge_union(fill=1, ...) -> out_keys[total] (strictly increasing), out_vals[total].
+ *   out = func(a or fill_a, b or fill_b); entries bit-identical to fill_out are dropped.
+ *   op codes as spamd_ewise_binary (6 = power is not available here); *_bits = raw bit patterns
+ *   of the fill values in val_dtype (fill_out in the output dtype: U8 for ops 32..40). */
+int64_t spamd_merge_num_blocks(int64_t na, int64_t nb);
+int spamd_merge_partition(int64_t na, const int64_t* ka, int64_t nb, const int64_t* kb, int64_t* part,
+                          void* stream);
+int spamd_merge_union(int fill, int op, int val_dtype, int64_t na, const int64_t* ka, const void* va, int64_t nb,
+                      const int64_t* kb, const void* vb, uint64_t fill_a_bits, uint64_t fill_b_bits,
+                      uint64_t fill_out_bits, const int64_t* part, int64_t* counts, const int64_t* offsets,
+                      int64_t* out_keys, void* out_vals, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * A8  Grouped reduce     replaces `_calc_counts_invidx` + `_grouped_reduce` / `ufunc.reduceat`
  *                        (sparse/numba_backend/_coo/core.py:1601-1661; compressed.py:354-386)
  *   heads[i] = 1 where a run starts, offsets = its exclusive scan, nseg = number of runs.
  *   out[g] = data[s_g] op data[s_g+1] op ...; counts[g] = run length (may be NULL).
  *   Short runs: one thread per run, strictly left to right (bit-identical to reduceat).
- *   Long runs (n/nseg >= 128 and seg_start_ws != NULL, nseg+1 int64): one wave per run.
+ *   Long runs (n/nseg >= 24 and seg_start_ws != NULL, nseg+1 int64): one wave per run (tree order).
  *   op: 0 add 1 multiply 2 maximum 3 minimum 4 logical_or 5 logical_and.
  * ------------------------------------------------------------------------------------- */
 int spamd_segment_reduce(int op, int val_dtype, int64_t n, const void* data, const int64_t* heads,

@@ -75,6 +75,10 @@ SIGNATURES = {
     "spamd_spgemm_count": (_int, [_int, _i64, _i64, _vp, _vp, _vp, _vp]),
     "spamd_spgemm_expand": (_int, [_int, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "spamd_sddmm": (_int, [_int, _int, _int, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp]),
+    "spamd_merge_num_blocks": (_i64, [_i64, _i64]),
+    "spamd_merge_partition": (_int, [_i64, _vp, _i64, _vp, _vp, _vp]),
+    "spamd_merge_union": (_int, [_int, _int, _int, _i64, _vp, _vp, _i64, _vp, _vp, _C.c_uint64, _C.c_uint64,
+                                 _C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spamd_has_nan": (_int, [_int, _i64, _vp, _vp, _vp]),
     "spamd_spmm_csr": (_int, [_int, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _u32, _vp]),
 }

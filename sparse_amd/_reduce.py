@@ -26,7 +26,7 @@ def segment_reduce(data, heads, offs, count, op, want_counts=False):
         data = data.view(torch.uint8)
     out = torch.empty(count, dtype=data.dtype, device=dev)
     counts = torch.empty(count, dtype=torch.int64, device=dev) if want_counts else None
-    ws = torch.empty(count + 1, dtype=torch.int64, device=dev) if (count and n // max(count, 1) >= 128) else None
+    ws = torch.empty(count + 1, dtype=torch.int64, device=dev) if (count and n // max(count, 1) >= 24) else None
     code = _ffi.U8 if data.dtype == torch.uint8 else code_of(data.dtype)
     _ffi.call("spamd_segment_reduce", _RED_OPS[op], code, n, ptr(data.contiguous()), ptr(heads), ptr(offs), count,
               ptr(out), ptr(counts), ptr(ws), stream_ptr(dev))

@@ -115,6 +115,41 @@ def union_merge(ka, kb):
     return keys, slotA, slotB
 
 
+def _bits(value, np_dtype):
+    npdt = np.dtype("uint8") if np.dtype(np_dtype) == np.dtype(bool) else np.dtype(np_dtype)
+    return int(np.asarray(value).astype(npdt).reshape(1).view(f"u{npdt.itemsize}")[0])
+
+
+def merge_union(name, ka, va, kb, vb, fill_a, fill_b, fill_out):
+    """Fused merge-path union: (keys, values) of func(a or fill_a, b or fill_b) over the union of
+    two canonical key arrays, results bit-equal to `fill_out` dropped (csrc/merge.hip).
+    `va`/`vb` share the compute dtype; `fill_out` is a NumPy scalar of the output dtype."""
+    code = _BIN[name]
+    devi = require_hip(ka, kb, va, vb)
+    va, vb = _as_u8(va.contiguous()), _as_u8(vb.contiguous())
+    comp_np = dev.np_dtype(va.dtype) if va.dtype != torch.uint8 else np.dtype("uint8")
+    na, nb = int(ka.numel()), int(kb.numel())
+    out_t = torch.uint8 if code in _TO_BOOL_BIN else va.dtype
+    nblocks = int(_ffi.lib().spamd_merge_num_blocks(na, nb))
+    if nblocks == 0:
+        e = torch.empty(0, dtype=out_t, device=devi)
+        return torch.empty(0, dtype=torch.int64, device=devi), (e.view(torch.bool) if code in _TO_BOOL_BIN else e)
+    s = stream_ptr(devi)
+    part = torch.empty(nblocks + 1, dtype=torch.int64, device=devi)
+    _ffi.call("spamd_merge_partition", na, ptr(ka), nb, ptr(kb), ptr(part), s)
+    counts = torch.empty(nblocks + 1, dtype=torch.int64, device=devi)
+    fa, fb = _bits(fill_a, comp_np), _bits(fill_b, comp_np)
+    fo = _bits(fill_out, np.dtype("uint8") if code in _TO_BOOL_BIN else comp_np)
+    args = (code, _CODE[va.dtype], na, ptr(ka), ptr(va), nb, ptr(kb), ptr(vb), fa, fb, fo, ptr(part))
+    _ffi.call("spamd_merge_union", 0, *args, ptr(counts), 0, 0, 0, s)
+    offs = K.exclusive_scan(counts)
+    total = int(offs[-1])
+    keys = torch.empty(total, dtype=torch.int64, device=devi)
+    vals = torch.empty(total, dtype=out_t, device=devi)
+    _ffi.call("spamd_merge_union", 1, *args, 0, ptr(offs), ptr(keys), ptr(vals), s)
+    return keys, (vals.view(torch.bool) if code in _TO_BOOL_BIN else vals)
+
+
 def _func_name(func):
     if func is np.ndarray.astype:
         return "astype"
@@ -294,14 +329,24 @@ def elemwise(func, *args, **kwargs):
     fill = np.asarray(_np_result(func, np.asarray(a.fill_value), np.asarray(b.fill_value))).astype(out_np)[()]
     if a.size == 0:
         return finish(a.linear_loc(), K.convert(a.data, torch_dtype(out_np)), shape, fill, devi)
+    ad, bd = K.convert(a.data, comp_t), K.convert(b.data, comp_t)
+    fa, fb = np.asarray(a.fill_value).astype(comp_np), np.asarray(b.fill_value).astype(comp_np)
+    if code != 6 and (torch_dtype(out_np) == comp_t or code in _TO_BOOL_BIN):
+        # default: one fused merge-path pass (function + prune inside the kernel)
+        fill_in_kernel = fill if code not in _TO_BOOL_BIN else np.uint8(bool(fill))
+        keys, res = merge_union(name, a.linear_loc(), ad, b.linear_loc(), bd, fa, fb, fill_in_kernel)
+        coords = K.delinearize(keys, shape, a.coords.dtype)
+        out = COO(coords, res, shape=shape, has_duplicates=False, sorted=True, fill_value=fill)
+        out._keys = keys
+        return out.asformat(out_type, **out_kwargs) if out_type != "coo" else out
     keys, slotA, slotB = union_merge(a.linear_loc(), b.linear_loc())
     n = int(keys.numel())
-    xa = _full(n, np.asarray(a.fill_value).astype(comp_np), comp_t, devi)
-    xb = _full(n, np.asarray(b.fill_value).astype(comp_np), comp_t, devi)
+    xa = _full(n, fa, comp_t, devi)
+    xb = _full(n, fb, comp_t, devi)
     if a.nnz:
-        K.scatter_into(_as_u8(xa), slotA, _as_u8(K.convert(a.data, comp_t)))
+        K.scatter_into(_as_u8(xa), slotA, _as_u8(ad))
     if b.nnz:
-        K.scatter_into(_as_u8(xb), slotB, _as_u8(K.convert(b.data, comp_t)))
+        K.scatter_into(_as_u8(xb), slotB, _as_u8(bd))
     res = binary_arrays(name, xa, xb)
     if res.dtype != torch_dtype(out_np):
         res = K.convert(res, torch_dtype(out_np))

@@ -406,7 +406,7 @@ extern "C" int spamd_segment_reduce(int op, int val_dtype, int64_t n, const void
   if (n < 0 || nseg < 0) return SPAMD_EINVAL;
   if (n == 0 || nseg == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  const bool long_runs = seg_start_ws != nullptr && (n / nseg) >= 128;
+  const bool long_runs = seg_start_ws != nullptr && (n / nseg) >= 24;
   VAL_SWITCH5(val_dtype, T, {
     if (long_runs) {
       hipLaunchKernelGGL(heads_to_starts_kernel, dim3(grid_for(n + 1)), dim3(256), 0, s, heads, offsets, n, nseg,

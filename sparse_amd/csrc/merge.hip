@@ -1,0 +1,260 @@
+// A7: sorted-coordinate MERGE of two canonical (sorted, duplicate-free) key arrays, fused with the
+// elementwise function and the fill-value prune (reference `_Elemwise.get_result` +
+// `_match_arrays`, sparse/numba_backend/_umath.py:53-92,457-503,576-654).
+//
+// Merge-path formulation (one O(n) streaming pass instead of the reference's argsort + join +
+// concatenate + re-sort, and instead of two binary searches per element):
+//   partition : block p owns merged ranks [p*TILE, (p+1)*TILE); a binary search on that diagonal
+//               gives where its A and B segments start.
+//   count/fill: the block stages its two segments (keys + values, <= TILE items, plus one
+//               look-behind A key and one look-ahead B key) in LDS; every thread finds its own
+//               diagonal inside the tile and merges VT items sequentially.  A key present in both
+//               operands is emitted once, by the thread that takes it from A (ties go A-first, so
+//               its partner is the next B key); out = func(a or fill_a, b or fill_b); results that
+//               are bit-identical to func(fill_a, fill_b) are dropped.  `count` returns per-block
+//               totals (host: exclusive scan), `fill` repeats the merge and writes keys/values.
+// Output keys are strictly increasing by construction: the result is canonical, no re-sort.
+#include "common.h"
+
+namespace spamd {
+
+constexpr int MP_THREADS = 256;
+constexpr int MP_VT = 8;
+constexpr int MP_TILE = MP_THREADS * MP_VT;
+
+// ---- the elementwise functions (same codes as spamd_ewise_binary) --------------------------------
+template <typename T>
+__device__ __forceinline__ T mp_max(T a, T b) {
+  if constexpr (std::is_floating_point<T>::value) return (a != a) ? a : ((b != b) ? b : (a > b ? a : b));
+  else return a > b ? a : b;
+}
+template <typename T>
+__device__ __forceinline__ T mp_min(T a, T b) {
+  if constexpr (std::is_floating_point<T>::value) return (a != a) ? a : ((b != b) ? b : (a < b ? a : b));
+  else return a < b ? a : b;
+}
+
+template <typename T, typename O>
+__device__ __forceinline__ O mp_apply(int op, T a, T b) {
+#pragma clang fp contract(off)
+  if constexpr (std::is_same<O, T>::value) {
+    switch (op) {
+      case 0: return a + b;
+      case 1: return a - b;
+      case 2: return a * b;
+      case 3:
+        if constexpr (std::is_floating_point<T>::value) return a / b;
+        else return b == 0 ? T(0) : a / b;
+      case 4: return mp_max(a, b);
+      case 5: return mp_min(a, b);
+      case 7:
+        if constexpr (std::is_floating_point<T>::value) return (a != a) ? b : ((b != b) ? a : (a > b ? a : b));
+        else return a > b ? a : b;
+      case 8:
+        if constexpr (std::is_floating_point<T>::value) return (a != a) ? b : ((b != b) ? a : (a < b ? a : b));
+        else return a < b ? a : b;
+      case 64: if constexpr (std::is_integral<T>::value) return a & b; else return T(0);
+      case 65: if constexpr (std::is_integral<T>::value) return a | b; else return T(0);
+      case 66: if constexpr (std::is_integral<T>::value) return a ^ b; else return T(0);
+    }
+    return T(0);
+  } else {
+    switch (op) {
+      case 32: return a > b;
+      case 33: return a >= b;
+      case 34: return a < b;
+      case 35: return a <= b;
+      case 36: return a == b;
+      case 37: return a != b;
+      case 38: return (a != T(0)) && (b != T(0));
+      case 39: return (a != T(0)) || (b != T(0));
+      case 40: return (a != T(0)) != (b != T(0));
+    }
+    return O(0);
+  }
+}
+
+template <typename O>
+__device__ __forceinline__ bool mp_same_bits(O x, O y) {
+  if constexpr (sizeof(O) == 8) return __builtin_bit_cast(uint64_t, x) == __builtin_bit_cast(uint64_t, y);
+  else if constexpr (sizeof(O) == 4) return __builtin_bit_cast(uint32_t, x) == __builtin_bit_cast(uint32_t, y);
+  else return x == y;
+}
+
+__global__ void __launch_bounds__(256) mp_partition_kernel(const int64_t* __restrict__ a, int64_t na,
+                                                           const int64_t* __restrict__ b, int64_t nb,
+                                                           int64_t nblocks, int64_t* __restrict__ part) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > nblocks) return;
+  int64_t d = p * MP_TILE;
+  if (d > na + nb) d = na + nb;
+  int64_t lo = d > nb ? d - nb : 0, hi = d < na ? d : na;
+  while (lo < hi) {  // largest i with a[i-1] <= b[d-i]  (ties: A first)
+    const int64_t mid = (lo + hi) >> 1;
+    if (a[mid] <= b[d - 1 - mid]) lo = mid + 1; else hi = mid;
+  }
+  part[p] = lo;
+}
+
+// FILL = false: counts[block] = number of outputs; FILL = true: write them at offs[block] + local rank.
+template <typename T, typename O, bool FILL>
+__global__ void __launch_bounds__(MP_THREADS)
+mp_union_kernel(int op, const int64_t* __restrict__ ka, const T* __restrict__ va, int64_t na,
+                const int64_t* __restrict__ kb, const T* __restrict__ vb, int64_t nb, T fill_a, T fill_b,
+                O fill_out, const int64_t* __restrict__ part, int64_t* __restrict__ counts,
+                const int64_t* __restrict__ offs, int64_t* __restrict__ out_keys, O* __restrict__ out_vals) {
+  __shared__ int64_t sk[MP_TILE + 4];
+  __shared__ T sv[MP_TILE + 4];
+  __shared__ int wave_tot[MP_THREADS / 64];
+  const int tid = threadIdx.x;
+  const int64_t blk = blockIdx.x;
+  const int64_t a0 = part[blk], a1 = part[blk + 1];
+  int64_t d0 = blk * MP_TILE, d1 = (blk + 1) * MP_TILE;
+  if (d1 > na + nb) d1 = na + nb;
+  const int64_t b0 = d0 - a0, b1 = d1 - a1;
+  const int la = (int)(a1 - a0), lb = (int)(b1 - b0);
+  // LDS layout: [0] = a[a0-1] | A segment [1 .. la] | B segment [la+1 .. la+lb] | [la+lb+1] = b[b1]
+  for (int t = tid; t < la + lb + 2; t += MP_THREADS) {
+    int64_t k;
+    T v = T(0);
+    if (t == 0) k = a0 > 0 ? ka[a0 - 1] : (int64_t)-1;
+    else if (t <= la) { k = ka[a0 + t - 1]; v = va[a0 + t - 1]; }
+    else if (t <= la + lb) { k = kb[b0 + (t - la - 1)]; v = vb[b0 + (t - la - 1)]; }
+    else k = b1 < nb ? kb[b1] : INT64_MAX;
+    sk[t] = k;
+    sv[t] = v;
+  }
+  __syncthreads();
+  const int64_t* A = sk + 1;        // A[i], i in [-1, la)
+  const int64_t* B = sk + 1 + la;   // B[j], j in [0, lb]
+  const T* AV = sv + 1;
+  const T* BV = sv + 1 + la;
+  // this thread's diagonal inside the tile
+  int diag = tid * MP_VT;
+  const int total = la + lb;
+  if (diag > total) diag = total;
+  int lo = diag > lb ? diag - lb : 0, hi = diag < la ? diag : la;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (A[mid] <= B[diag - 1 - mid]) lo = mid + 1; else hi = mid;
+  }
+  int i = lo, j = diag - lo;
+  int64_t okey[MP_VT];
+  O oval[MP_VT];
+  int cnt = 0;
+#pragma unroll
+  for (int s = 0; s < MP_VT; ++s) {
+    if (diag + s < total) {
+      const bool takeA = (i < la) && (j >= lb || A[i] <= B[j]);
+      if (takeA) {
+        const int64_t k = A[i];
+        const bool matched = (B[j] == k);  // B[lb] is the look-ahead key (or INT64_MAX)
+        T bvv = fill_b;
+        if (matched) bvv = (j < lb) ? BV[j] : vb[b1];
+        const O r = mp_apply<T, O>(op, AV[i], bvv);
+        if (!mp_same_bits(r, fill_out)) { okey[cnt] = k; oval[cnt] = r; ++cnt; }
+        ++i;
+      } else {
+        const int64_t k = B[j];
+        if (A[i - 1] != k) {  // A[-1] is the look-behind key (or -1): a matched B key was emitted with its A
+          const O r = mp_apply<T, O>(op, fill_a, BV[j]);
+          if (!mp_same_bits(r, fill_out)) { okey[cnt] = k; oval[cnt] = r; ++cnt; }
+        }
+        ++j;
+      }
+    }
+  }
+  // block-wide exclusive scan of cnt (wave shuffles + one LDS hop)
+  const int lane = tid & 63, wv = tid >> 6;
+  int incl = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int n = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += n;
+  }
+  if (lane == 63) wave_tot[wv] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < MP_THREADS / 64; ++w) {
+    if (w < wv) base += wave_tot[w];
+    tot += wave_tot[w];
+  }
+  if constexpr (!FILL) {
+    if (tid == 0) counts[blk] = tot;
+  } else {
+    const int64_t o = offs[blk] + base + (incl - cnt);
+#pragma unroll
+    for (int s = 0; s < MP_VT; ++s) {
+      if (s < cnt) {
+        out_keys[o + s] = okey[s];
+        out_vals[o + s] = oval[s];
+      }
+    }
+  }
+}
+
+template <typename T>
+static T from_bits(uint64_t bits) {
+  if constexpr (sizeof(T) == 8) return __builtin_bit_cast(T, bits);
+  else if constexpr (sizeof(T) == 4) return __builtin_bit_cast(T, (uint32_t)bits);
+  else return (T)bits;
+}
+
+}  // namespace spamd
+
+using namespace spamd;
+
+extern "C" int64_t spamd_merge_num_blocks(int64_t na, int64_t nb) {
+  const int64_t t = na + nb;
+  return t <= 0 ? 0 : (t + MP_TILE - 1) / MP_TILE;
+}
+
+extern "C" int spamd_merge_partition(int64_t na, const int64_t* ka, int64_t nb, const int64_t* kb, int64_t* part,
+                                     void* stream) {
+  if (na < 0 || nb < 0) return SPAMD_EINVAL;
+  const int64_t nblocks = spamd_merge_num_blocks(na, nb);
+  if (nblocks == 0) return 0;
+  hipLaunchKernelGGL(mp_partition_kernel, dim3((unsigned)ceil_div(nblocks + 1, 256)), dim3(256), 0,
+                     (hipStream_t)stream, ka, na, kb, nb, nblocks, part);
+  return launch_status();
+}
+
+// fill == 0: counts[nblocks] <- outputs per block.  fill == 1: offsets[nblocks] (exclusive scan of the
+// counts) -> out_keys / out_vals.  val_dtype F32|F64|I32|I64|U8; comparisons/logical ops write U8.
+extern "C" int spamd_merge_union(int fill, int op, int val_dtype, int64_t na, const int64_t* ka, const void* va,
+                                 int64_t nb, const int64_t* kb, const void* vb, uint64_t fill_a_bits,
+                                 uint64_t fill_b_bits, uint64_t fill_out_bits, const int64_t* part,
+                                 int64_t* counts, const int64_t* offsets, int64_t* out_keys, void* out_vals,
+                                 void* stream) {
+  if (na < 0 || nb < 0) return SPAMD_EINVAL;
+  const int64_t nblocks = spamd_merge_num_blocks(na, nb);
+  if (nblocks == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const bool to_bool = op >= 32 && op < 64;
+  if (op >= 64 && (val_dtype == SPAMD_F32 || val_dtype == SPAMD_F64)) return SPAMD_ETYPE;
+  if (op == 6) return SPAMD_ETYPE;  // power: use the aligned-array path
+#define MP_LAUNCH(T, O)                                                                                       \
+  do {                                                                                                        \
+    if (fill)                                                                                                 \
+      hipLaunchKernelGGL((mp_union_kernel<T, O, true>), dim3((unsigned)nblocks), dim3(MP_THREADS), 0, s, op, ka, \
+                         (const T*)va, na, kb, (const T*)vb, nb, from_bits<T>(fill_a_bits),                   \
+                         from_bits<T>(fill_b_bits), from_bits<O>(fill_out_bits), part, counts, offsets,       \
+                         out_keys, (O*)out_vals);                                                             \
+    else                                                                                                      \
+      hipLaunchKernelGGL((mp_union_kernel<T, O, false>), dim3((unsigned)nblocks), dim3(MP_THREADS), 0, s, op, ka, \
+                         (const T*)va, na, kb, (const T*)vb, nb, from_bits<T>(fill_a_bits),                   \
+                         from_bits<T>(fill_b_bits), from_bits<O>(fill_out_bits), part, counts, offsets,       \
+                         out_keys, (O*)out_vals);                                                             \
+  } while (0)
+  switch (val_dtype) {
+    case SPAMD_F32: if (to_bool) MP_LAUNCH(float, uint8_t); else MP_LAUNCH(float, float); break;
+    case SPAMD_F64: if (to_bool) MP_LAUNCH(double, uint8_t); else MP_LAUNCH(double, double); break;
+    case SPAMD_I32: if (to_bool) MP_LAUNCH(int32_t, uint8_t); else MP_LAUNCH(int32_t, int32_t); break;
+    case SPAMD_I64: if (to_bool) MP_LAUNCH(int64_t, uint8_t); else MP_LAUNCH(int64_t, int64_t); break;
+    case SPAMD_U8: MP_LAUNCH(uint8_t, uint8_t); break;
+    default: return SPAMD_ETYPE;
+  }
+#undef MP_LAUNCH
+  return launch_status();
+}
