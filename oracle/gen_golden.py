@@ -320,6 +320,76 @@ def gen_nd(sp):
     _save("nd", **cases)
 
 
+def gen_matrix(sp):
+    """Breadth: the parameter grids of the reference's own tests — tensordot over operand formats x
+    return_type (tests/test_dot.py:15-80), binary elementwise over ndim 1-4 and {COO,GCXS}
+    (tests/test_elemwise.py:143-203), reductions over dtypes (tests/test_coo.py:43-200)."""
+    cases = {}
+    rng = np.random.default_rng(91)
+    # ---- tensordot grid -------------------------------------------------------------------------
+    grid = [((3, 4, 5), (4, 3), ((1, 0), (0, 1))), ((3, 4), (4, 5), 1), ((4, 5), (5, 6), ((1,), (0,))),
+            ((3, 4, 5), (5, 4, 2), ((1, 2), (1, 0))), ((2, 3, 4), (4, 3, 2), 0 if False else ((2, 1), (0, 1)))]
+    k = 0
+    for sa, sb, axes in grid:
+        a = sp.random(sa, density=0.5, random_state=400 + k)
+        b = sp.random(sb, density=0.5, random_state=500 + k)
+        ops = {"coo": lambda x: x, "gcxs": lambda x: sp.GCXS(x), "dense": lambda x: x.todense()}
+        for fa in ("coo", "gcxs", "dense"):
+            for fb in ("coo", "gcxs", "dense"):
+                if fa == "dense" and fb == "dense":
+                    continue
+                for rt_name, rt in (("none", None), ("coo", sp.COO), ("gcxs", sp.GCXS), ("ndarray", np.ndarray)):
+                    r = sp.tensordot(ops[fa](a), ops[fb](b), axes=axes, return_type=rt)
+                    kind = "ndarray" if isinstance(r, np.ndarray) else r.format
+                    d = r if isinstance(r, np.ndarray) else r.todense()
+                    cases[f"td{k}_{fa}_{fb}_{rt_name}_kind"] = np.array(kind)
+                    cases[f"td{k}_{fa}_{fb}_{rt_name}_nnz"] = np.array(-1 if isinstance(r, np.ndarray) else r.nnz)
+                    if f"td{k}_dense" not in cases:
+                        cases[f"td{k}_dense"] = d
+                    assert np.allclose(d, cases[f"td{k}_dense"])
+        cases.update({f"td{k}_a_coords": a.coords, f"td{k}_a_data": a.data, f"td{k}_a_shape": np.array(sa),
+                      f"td{k}_b_coords": b.coords, f"td{k}_b_data": b.data, f"td{k}_b_shape": np.array(sb),
+                      f"td{k}_axes": np.array(axes, dtype=object) if False else np.array(str(axes))})
+        k += 1
+    cases["n_td"] = np.array(k)
+    # ---- binary elementwise over ndim 1..4 --------------------------------------------------------
+    k = 0
+    for shape in ((17,), (6, 7), (4, 5, 6), (3, 4, 2, 5)):
+        x = sp.random(shape, density=0.4, random_state=600 + k)
+        y = sp.random(shape, density=0.4, random_state=700 + k)
+        x = sp.COO(x.coords, x.data - 0.5, shape=shape)
+        for name in ("add", "subtract", "multiply", "maximum", "greater", "less_equal", "not_equal"):
+            with np.errstate(all="ignore"), warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                r = getattr(np, name)(x, y)
+            cases[f"ew{k}_{name}_coords"], cases[f"ew{k}_{name}_data"] = r.coords, r.data
+            cases[f"ew{k}_{name}_fill"] = np.asarray(r.fill_value)
+            if len(shape) > 1:
+                rg = getattr(np, name)(sp.GCXS(x), sp.GCXS(y))
+                cases[f"ew{k}_{name}_gfmt"] = np.array(rg.format)
+                rm = getattr(np, name)(sp.GCXS(x), y)
+                cases[f"ew{k}_{name}_mfmt"] = np.array(rm.format)
+        cases.update({f"ew{k}_x_coords": x.coords, f"ew{k}_x_data": x.data, f"ew{k}_y_coords": y.coords,
+                      f"ew{k}_y_data": y.data, f"ew{k}_shape": np.array(shape)})
+        k += 1
+    cases["n_ew"] = np.array(k)
+    # ---- reductions over dtypes -------------------------------------------------------------------------
+    k = 0
+    base = sp.random((5, 6, 4), density=0.35, random_state=800)
+    for dt in (np.float64, np.float32, np.int64, np.int32):
+        x = sp.COO(base.coords, ((base.data - 0.4) * (1 if np.dtype(dt).kind == "f" else 20)).astype(dt), shape=base.shape)
+        for name in ("sum", "prod", "max", "min", "mean", "any", "all"):
+            for axis in (None, 0, (0, 2), 1):
+                with np.errstate(all="ignore"), warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    r = getattr(x, name)(axis=axis)
+                cases[f"rd{k}_dense"] = r.todense()
+                cases[f"rd{k}_meta"] = np.array(f"{np.dtype(dt).name}|{name}|{axis}")
+                k += 1
+    cases.update(rd_coords=base.coords, rd_data=base.data, n_rd=np.array(k))
+    _save("matrix", **cases)
+
+
 def main():
     sp = ref_loader.load()
     print("reference:", sp.__file__)
@@ -328,6 +398,7 @@ def main():
     gen_elemwise(sp)
     gen_reduce(sp)
     gen_nd(sp)
+    gen_matrix(sp)
 
 
 if __name__ == "__main__":

@@ -20,7 +20,10 @@ __global__ void __launch_bounds__(256)
 spmm_csr_rowgroup_kernel(int64_t M, int64_t N, const T* __restrict__ a_data,
                          const I* __restrict__ a_idx, const I* __restrict__ a_ptr,
                          const T* __restrict__ b, int64_t ldb, T* __restrict__ out,
-                         int64_t ldo, int64_t panel) {
+                         int64_t ldo, int64_t panel, int64_t k_lo, int64_t k_hi, int accumulate) {
+  // Only stored elements with column index in [k_lo, k_hi) are applied (K-split passes keep the
+  // gathered part of B inside the 4 MiB per-XCD L2); with `accumulate` the pass continues from
+  // the partial sums already in `out` — same k-ascending order, so results are unchanged.
   // blockIdx.y selects a column panel [c_lo, c_hi) of the output.  Inside a panel a lane owns
   // CH groups of VEC contiguous columns, G*VEC columns apart, so one pass over the row's stored
   // elements covers G*VEC*CH columns (wide outputs such as the 512-column tensordot config do
@@ -51,6 +54,11 @@ spmm_csr_rowgroup_kernel(int64_t M, int64_t N, const T* __restrict__ a_data,
         col_ok[h] = col[h] < c_hi;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[h][e] = T(0);
+        if (accumulate && row_ok && col_ok[h]) {
+          const V o = *reinterpret_cast<const V*>(out + row * ldo + col[h]);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc[h][e] = o.v[e];
+        }
       }
 
       for (int64_t p = start; p < end; p += G) {
@@ -61,9 +69,17 @@ spmm_csr_rowgroup_kernel(int64_t M, int64_t N, const T* __restrict__ a_data,
           ci = a_idx[mine];
           vi = a_data[mine];
         }
-        const int cnt = (int)((end - p) < (int64_t)G ? (end - p) : (int64_t)G);
+        int cnt = (int)((end - p) < (int64_t)G ? (end - p) : (int64_t)G);
         constexpr int U = (UNROLL / CH) < 1 ? 1 : (UNROLL / CH);  // keep ~UNROLL gathers in flight
         int j = 0;
+        if (k_hi >= 0) {
+          // sorted columns: the elements of this chunk inside [k_lo, k_hi) are one contiguous run
+          const bool in = (mine < end) && ((int64_t)ci >= k_lo) && ((int64_t)ci < k_hi);
+          const unsigned long long bal = __ballot(in);
+          const unsigned long long grp = (G == SPAMD_WAVE) ? bal : ((bal >> gbase) & ((1ull << (G & 63)) - 1ull));
+          j = grp ? __builtin_ctzll(grp) : 0;
+          cnt = j + __builtin_popcountll(grp);
+        }
         for (; j + U <= cnt; j += U) {
           I cj[U];
           T vj[U];
@@ -126,7 +142,7 @@ struct SpmmVariant {
   int g = 0, vec = 0, unroll = 0;
   int64_t panel = 0;  // 0 = whole N in one pass
   int lds = -1;       // 1: LDS-DMA ring kernel
-  int depth = 0, rb = 0, ch = 0;
+  int depth = 0, rb = 0, ch = 0, ksplit = 0;
 };
 
 // Tuning hook: SPAMD_SPMM_VARIANT="G=32,VEC=2,U=8,PANEL=64" overrides the heuristic.
@@ -143,13 +159,14 @@ static SpmmVariant env_variant() {
   if ((p = strstr(e, "D="))) v.depth = atoi(p + 2);
   if ((p = strstr(e, "RB="))) v.rb = atoi(p + 3);
   if ((p = strstr(e, "CH="))) v.ch = atoi(p + 3);
+  if ((p = strstr(e, "KSPLIT="))) v.ksplit = atoi(p + 7);
   return v;
 }
 
 template <typename T, typename I, int VEC, int G, bool EXACT, int UNROLL, int CH>
 static int launch_rowgroup(int64_t M, int64_t N, const T* a_data, const I* a_idx, const I* a_ptr,
                            const T* b, int64_t ldb, T* out, int64_t ldo, int64_t panel,
-                           hipStream_t s) {
+                           int g_ksplit, int64_t g_K, hipStream_t s) {
   constexpr int RPW = SPAMD_WAVE / G;
   constexpr int WPB = 4;  // waves per 256-thread block
   int64_t blocks = ceil_div(M, (int64_t)RPW * WPB);
@@ -158,10 +175,16 @@ static int launch_rowgroup(int64_t M, int64_t N, const T* a_data, const I* a_idx
   if (blocks < 1) blocks = 1;
   if (panel <= 0 || panel > N) panel = N;
   const unsigned npanels = (unsigned)ceil_div(N, panel);
-  hipLaunchKernelGGL((spmm_csr_rowgroup_kernel<T, I, VEC, G, EXACT, UNROLL, CH>),
-                     dim3((unsigned)blocks, npanels), dim3(256), 0, s, M, N, a_data, a_idx, a_ptr, b,
-                     ldb, out, ldo, panel);
-  return launch_status();
+  const int ks = g_ksplit < 1 ? 1 : g_ksplit;
+  for (int pass = 0; pass < ks; ++pass) {
+    const int64_t k_lo = ks == 1 ? 0 : (g_K * pass) / ks;
+    const int64_t k_hi = ks == 1 ? -1 : (pass == ks - 1 ? (int64_t)1 << 62 : (g_K * (pass + 1)) / ks);
+    hipLaunchKernelGGL((spmm_csr_rowgroup_kernel<T, I, VEC, G, EXACT, UNROLL, CH>),
+                       dim3((unsigned)blocks, npanels), dim3(256), 0, s, M, N, a_data, a_idx, a_ptr, b,
+                       ldb, out, ldo, panel, k_lo, k_hi, pass > 0 ? 1 : 0);
+    if (int rc = launch_status()) return rc;
+  }
+  return 0;
 }
 
 template <typename T, typename I, bool EXACT>
@@ -203,19 +226,22 @@ static int dispatch_shape(int64_t M, int64_t K, int64_t N, const T* a_data, cons
     ch = groups >= 4 ? 4 : (groups >= 2 ? 2 : 1);
   }
   if (ev.ch) ch = ev.ch;
+  // K-split passes (tuning hook only): measured slower than one pass on MI355X (2 passes 3.1 ms
+  // vs 2.6 ms at config 2) — the kernel is bound by per-row issue overheads, not by L2 misses.
+  const int ksplit = ev.ksplit > 0 ? ev.ksplit : 1;
 #define SPAMD_CASE(V, GG)                                                                        \
   if (vec == V && g == GG) {                                                                     \
     if (ch == 4)                                                                                 \
       return launch_rowgroup<T, I, V, GG, EXACT, 8, 4>(M, N, a_data, a_idx, a_ptr, b, ldb, out,  \
-                                                       ldo, panel, s);                           \
+                                                       ldo, panel, ksplit, K, s);                           \
     if (ch == 2)                                                                                 \
       return launch_rowgroup<T, I, V, GG, EXACT, 8, 2>(M, N, a_data, a_idx, a_ptr, b, ldb, out,  \
-                                                       ldo, panel, s);                           \
+                                                       ldo, panel, ksplit, K, s);                           \
     if (unroll == 4)                                                                             \
       return launch_rowgroup<T, I, V, GG, EXACT, 4, 1>(M, N, a_data, a_idx, a_ptr, b, ldb, out,  \
-                                                       ldo, panel, s);                           \
+                                                       ldo, panel, ksplit, K, s);                           \
     return launch_rowgroup<T, I, V, GG, EXACT, 8, 1>(M, N, a_data, a_idx, a_ptr, b, ldb, out,    \
-                                                     ldo, panel, s);                             \
+                                                     ldo, panel, ksplit, K, s);                             \
   }
   SPAMD_CASE(1, 64)
   SPAMD_CASE(2, 64)
