@@ -78,6 +78,19 @@ def main():
     out.append(line("A8 reduce sum(axis=0)", f"COO(1000^3, {z.nnz} nnz) sum over FIRST axis (needs key sort)", ms,
                     z.nnz * 16 + s.nnz * 16, groups=s.nnz))
 
+    # ---- the same rows at 100x the size (streaming regime rather than launch-bound) -----------------
+    if not args.quick:
+        nb = 100_000_000
+        xb = sp.random((1000, 1000, 1000), nnz=nb, random_state=10)
+        yb = sp.random((1000, 1000, 1000), nnz=nb, random_state=11)
+        for name, f in (("add", lambda: xb + yb), ("multiply", lambda: xb * yb)):
+            ms, z = timed(f, reps=3)
+            out.append(line(f"A7 elementwise {name} (1e8 nnz)", f"COO(1000^3, {nb} nnz each) {name}", ms,
+                            2 * nb * 32 + z.nnz * 32, out_nnz=z.nnz))
+        ms, s = timed(lambda: xb.sum(axis=2), reps=3)
+        out.append(line("A8 reduce sum(axis=2) (1e8 nnz)", "runs of ~100 elements, wave per run", ms, nb * 16 + s.nnz * 16))
+        del xb, yb, z, s
+
     # ---- config 3: 3-D COO tensordot with dense, axes=1 ------------------------------------------
     side = 512 if not args.quick else 128
     nnz3 = int(side ** 3 * 0.01)

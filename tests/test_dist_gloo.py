@@ -61,3 +61,34 @@ def test_row_block_sharding_with_allgather_world2(K, N):
     mp.spawn(_worker, args=(world, port, K, N, ret), nprocs=world, join=True)
     spans = sorted(ret.values())
     assert spans[0][0] == 0 and spans[0][1] == spans[1][0] and spans[1][1] == 501
+
+
+def _worker_csr(rank, world, port, ret):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sparse_amd import _dist
+
+    data, idx, ptr = random_csr(403, 97, 0.08, 21, np.float64, np.int64, empty_rows=(0, 402), long_row=200)
+    td, ti, tp = (torch.from_numpy(x) for x in (data, idx, ptr))
+    bounds = _dist.partition_rows_by_nnz(tp, world)
+    d, i, p, r0, r1 = _dist.shard_csr(td, ti, tp, rank, world, bounds)
+    gd, gi, gp = _dist.all_gather_csr(d, i, p)
+    assert torch.equal(gd, td) and torch.equal(gi, ti) and torch.equal(gp, tp)
+    cat, sizes = _dist.all_gather_ragged(torch.arange(rank + 3))
+    assert sizes == [3, 4] and cat.tolist() == [0, 1, 2, 0, 1, 2, 3]
+    ret[rank] = True
+    dist.destroy_process_group()
+
+
+def test_allgather_csr_triplet_world2():
+    """The exchange step of row-sharded SpGEMM: gathering the row-block shards of B reproduces B."""
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_csr, args=(2, port, ret), nprocs=2, join=True)
+    assert len(ret) == 2
