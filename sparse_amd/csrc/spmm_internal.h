@@ -10,4 +10,9 @@ int spmm_csr_ldsring_dispatch(int64_t M, int64_t N, const T* a_data, const I* a_
                               const I* a_ptr, const T* b, int64_t ldb, T* out, int64_t ldo,
                               int depth, int RB, hipStream_t s);
 
+// spmm_csr_tile.hip — K-blocked LDS-tile kernel (fp32, N == 128); SPAMD_ETYPE when it does not apply.
+template <typename I, bool EXACT>
+int spmm_csr_tile_dispatch(int64_t M, int64_t K, int64_t N, const float* a_data, const I* a_idx, const I* a_ptr,
+                           const float* b, int64_t ldb, float* out, int64_t ldo, int rw, int kb, hipStream_t s);
+
 }  // namespace spamd
