@@ -280,9 +280,15 @@ def _dot(a, b, return_type=None):
             data, indices, indptr = K.dot_csr_ndarray_sparse(out_shape, a.data, a.indices, a.indptr, bt)
             out = GCXS((data, indices, indptr), shape=out_shape, compressed_axes=(0,), prune=True)
             return out.tocoo() if rk == "coo" else out
-        # csc @ dense
+        # csc @ dense: re-compress A by rows once (stable key sort) and memoise the CSR twin on the
+        # (immutable) array, so repeated products with a default-compressed tall matrix — the
+        # reference's `format="gcxs"` default is compressed_axes=(argmin(shape),) — pay it once
         if rk in (None, "ndarray"):
-            return io.out(K.dot_csc_ndarray(a.shape, tuple(bt.shape), a.data, a.indices, a.indptr, bt,
+            twin = getattr(a, "_csr_twin", None)
+            if twin is None:
+                twin = K._csc_to_csr(a.shape, a.data, a.indices, a.indptr)
+                a._csr_twin = twin
+            return io.out(K.dot_csr_ndarray(out_shape, twin[0], twin[1], twin[2], bt,
                                             exact=_settings.EXACT_MULADD))
         data, indices, indptr = K.dot_csc_ndarray_sparse(a.shape, tuple(bt.shape), a.data, a.indices,
                                                          a.indptr, bt)

@@ -106,3 +106,17 @@ def test_conversion_roundtrip_full_size(sp):
         assert int(g.indptr[-1]) == x.nnz and bool((g.indptr[1:] >= g.indptr[:-1]).all())
     t = x.transpose((2, 0, 1)).transpose((1, 2, 0))
     assert torch.equal(t.coords, x.coords) and torch.equal(t.data, x.data)
+
+
+def test_csc_default_compression_twin_cache(sp):
+    """The reference's default GCXS compression of a tall matrix is by columns; the hip backend
+    re-compresses by rows once and reuses it: identical results on every call."""
+    a = sp.random((50_000, 2_000), density=0.01, random_state=9, format="gcxs", dtype=np.float32)
+    assert a.compressed_axes == (1,)
+    b = torch.rand((2_000, 128), device="cuda")
+    r1 = a @ b
+    assert getattr(a, "_csr_twin", None) is not None
+    r2 = a @ b
+    assert torch.equal(r1, r2)
+    ref = sp.GCXS(a.tocoo(), compressed_axes=(0,)) @ b
+    assert torch.equal(r1, ref)  # same kernel, same summation order
