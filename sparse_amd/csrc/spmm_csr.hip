@@ -143,6 +143,7 @@ struct SpmmVariant {
   int64_t panel = 0;  // 0 = whole N in one pass
   int lds = -1;       // 1: LDS-DMA ring kernel
   int tile = -1, kb = 0;  // 1: K-blocked LDS-tile kernel
+  int gidx = 0;           // 1: gpr-indexed LDS-tile kernel, 2: its debug build
   int depth = 0, rb = 0, ch = 0, ksplit = 0;
 };
 
@@ -159,6 +160,7 @@ static SpmmVariant env_variant() {
   if ((p = strstr(e, "LDS="))) v.lds = atoi(p + 4);
   if ((p = strstr(e, "TILE="))) v.tile = atoi(p + 5);
   if ((p = strstr(e, "KB="))) v.kb = atoi(p + 3);
+  if ((p = strstr(e, "GIDX="))) v.gidx = atoi(p + 5);
   if ((p = strstr(e, "D="))) v.depth = atoi(p + 2);
   if ((p = strstr(e, "RB="))) v.rb = atoi(p + 3);
   if ((p = strstr(e, "CH="))) v.ch = atoi(p + 3);
@@ -217,6 +219,12 @@ static int dispatch_shape(int64_t M, int64_t K, int64_t N, const T* a_data, cons
   if (ev.vec && ev.vec <= vmax) vec = ev.vec;
   if (ev.unroll) unroll = ev.unroll;
   if (ev.panel > 0 && ev.panel % vec == 0) panel = ev.panel;
+  if constexpr (std::is_same<T, float>::value && !EXACT) {
+    if (ev.gidx) {
+      int rc = spmm_csr_gidx_dispatch<I>(M, K, N, a_data, a_idx, a_ptr, b, ldb, out, ldo, ev.gidx, s);
+      if (rc != SPAMD_ETYPE) return rc;
+    }
+  }
   if constexpr (std::is_same<T, float>::value) {
     if (ev.tile == 1) {
       int rc = spmm_csr_tile_dispatch<I, EXACT>(M, K, N, a_data, a_idx, a_ptr, b, ldb, out, ldo,

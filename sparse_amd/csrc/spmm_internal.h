@@ -15,4 +15,9 @@ template <typename I, bool EXACT>
 int spmm_csr_tile_dispatch(int64_t M, int64_t K, int64_t N, const float* a_data, const I* a_idx, const I* a_ptr,
                            const float* b, int64_t ldb, float* out, int64_t ldo, int rw, int kb, hipStream_t s);
 
+// spmm_csr_gidx.hip — LDS-tile kernel with gpr-indexed accumulators (fp32, N == 128, FMA mode).
+template <typename I>
+int spmm_csr_gidx_dispatch(int64_t M, int64_t K, int64_t N, const float* a_data, const I* a_idx, const I* a_ptr,
+                           const float* b, int64_t ldb, float* out, int64_t ldo, int mode, hipStream_t s);
+
 }  // namespace spamd
