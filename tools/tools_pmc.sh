@@ -17,4 +17,4 @@ for p in $passes; do
     grbm) run grbm GRBM_GUI_ACTIVE ;;
   esac
 done
-python $R/tools_pmc_parse.py $R/gpurun_out/pmc_$tag $needle
+python $R/tools/tools_pmc_parse.py $R/gpurun_out/pmc_$tag $needle
