@@ -125,6 +125,10 @@ int spamd_rows_to_indptr(int idx_dtype, int64_t nnz, const void* rows, int64_t R
 int64_t spamd_sort_pairs_ws_bytes(int64_t n);
 int spamd_sort_pairs(int64_t n, const int64_t* keys_in, int64_t* keys_out, const int64_t* vals_in,
                      int64_t* vals_out, int end_bit, void* ws, int64_t ws_bytes, void* stream);
+/* The same stable sort carrying a 4- or 8-byte VALUE as payload (used by SpGEMM's expand-sort-compress). */
+int64_t spamd_sort_kv_ws_bytes(int val_bytes, int64_t n);
+int spamd_sort_kv(int val_bytes, int64_t n, const int64_t* keys_in, int64_t* keys_out, const void* vals_in,
+                  void* vals_out, int end_bit, void* ws, int64_t ws_bytes, void* stream);
 int spamd_iota(int64_t n, int64_t* out, void* stream);
 /* out[i] = in[0] + ... + in[i-1] for i in [0, n]; both arrays hold n+1 entries (in[n] ignored). */
 int64_t spamd_scan_ws_bytes(int64_t n);

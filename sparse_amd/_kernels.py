@@ -176,6 +176,22 @@ def sort_keys(keys, max_key):
     return ko, po
 
 
+def sort_key_value(keys, vals, max_key):
+    """Stable sort of (int64 key, value) pairs by key; values are moved bit-wise."""
+    dev = require_hip(keys, vals)
+    n = int(keys.numel())
+    if n == 0:
+        return keys, vals
+    ws_bytes = int(_ffi.lib().spamd_sort_kv_ws_bytes(vals.element_size(), n))
+    if ws_bytes < 0:
+        raise _ffi.HipBackendError(f"spamd_sort_kv_ws_bytes failed: {ws_bytes}")
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    ko, vo = torch.empty_like(keys), torch.empty_like(vals)
+    _ffi.call("spamd_sort_kv", vals.element_size(), n, ptr(keys.contiguous()), ptr(ko), ptr(vals.contiguous()), ptr(vo),
+              _key_bits(max_key), ptr(ws), ws_bytes, stream_ptr(dev))
+    return ko, vo
+
+
 def exclusive_scan(flags):
     """`flags` holds n+1 int64 entries (the last is ignored); returns offsets[n+1] with
     offsets[n] = total."""
@@ -464,8 +480,7 @@ def _spgemm_keys(n_row, n_col, a_data, a_indices, a_rows, b_data, b_indices, b_i
             vals = torch.empty(P, dtype=dtr, device=dev)
             _ffi.call("spamd_spgemm_expand", vcode, code_of(it), p, q - p, ptr(a_data), ptr(a_indices), ptr(a_rows),
                       ptr(b_data), ptr(b_indices), ptr(b_indptr), ptr(offs), P, n_col, ptr(keys), ptr(vals), s)
-            keys, perm = sort_keys(keys, max(n_row * n_col - 1, 1))
-            vals = gather(vals, perm)
+            keys, vals = sort_key_value(keys, vals, max(n_row * n_col - 1, 1))
             heads = flag_heads(keys)
             ho = exclusive_scan(heads)
             c = int(ho[-1])

@@ -340,6 +340,40 @@ extern "C" int spamd_sort_pairs(int64_t n, const int64_t* keys_in, int64_t* keys
   return (int)e;
 }
 
+// Same sort with the VALUE as payload (4- or 8-byte values moved bit-wise): SpGEMM sorts its
+// (key, product) pairs directly instead of sorting a permutation and gathering through it.
+extern "C" int64_t spamd_sort_kv_ws_bytes(int val_bytes, int64_t n) {
+  size_t bytes = 0;
+  int64_t* k = nullptr;
+  hipError_t e;
+  if (val_bytes == 8) {
+    uint64_t* v = nullptr;
+    e = rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)(n > 0 ? n : 1), 0, 64, (hipStream_t)0);
+  } else {
+    uint32_t* v = nullptr;
+    e = rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)(n > 0 ? n : 1), 0, 64, (hipStream_t)0);
+  }
+  if (e != hipSuccess) return -(int64_t)e;
+  return (int64_t)bytes + 16;
+}
+
+extern "C" int spamd_sort_kv(int val_bytes, int64_t n, const int64_t* keys_in, int64_t* keys_out, const void* vals_in,
+                             void* vals_out, int end_bit, void* ws, int64_t ws_bytes, void* stream) {
+  if (n < 0 || end_bit < 1 || end_bit > 64) return SPAMD_EINVAL;
+  if (n == 0) return 0;
+  size_t bytes = (size_t)ws_bytes;
+  hipError_t e;
+  if (val_bytes == 8)
+    e = rocprim::radix_sort_pairs(ws, bytes, keys_in, keys_out, (const uint64_t*)vals_in, (uint64_t*)vals_out,
+                                  (size_t)n, 0, (unsigned)end_bit, (hipStream_t)stream);
+  else if (val_bytes == 4)
+    e = rocprim::radix_sort_pairs(ws, bytes, keys_in, keys_out, (const uint32_t*)vals_in, (uint32_t*)vals_out,
+                                  (size_t)n, 0, (unsigned)end_bit, (hipStream_t)stream);
+  else
+    return SPAMD_ETYPE;
+  return (int)e;
+}
+
 extern "C" int spamd_iota(int64_t n, int64_t* out, void* stream) {
   if (n < 0) return SPAMD_EINVAL;
   if (n == 0) return 0;
