@@ -70,6 +70,37 @@ int spamd_spmm_csr(int val_dtype, int idx_dtype, int64_t M, int64_t K, int64_t N
                    unsigned flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * A1 (inspector/executor form)   same product as spamd_spmm_csr for fp32, N == 128, FMA mode, with
+ *   a cached K-tiled copy of A — the role `cusparseSpMM_preprocess`-style inspection plays elsewhere;
+ *   the reference's analogue is the memoised format conversion of `COO(cache=True)`
+ *   (sparse/numba_backend/_coo/core.py:317-338).  Inspector (once per matrix):
+ *     keys   = spamd_csr_to_keys(A)                      row*K + col
+ *     tkeys  = spamd_spmm_tiled_keys(keys)               ((g*ntiles+t)*RG + row%RG)*KB + col%KB
+ *     stable sort of (tkeys, values)                     spamd_sort_kv
+ *     seg_start, nblk = spamd_spmm_tiled_lists(tkeys)    first element / 8-entry blocks of list (g,t)
+ *     blk_off = spamd_exclusive_scan(nblk)               int64[nseg + 1], nseg = groups*ntiles
+ *     blocks  = spamd_spmm_tiled_pack(...)               64-byte blocks of eight (d0, d1):
+ *                                                        d0 = col%KB << 9 | 2 + 2*(row%RG), d1 = value bits;
+ *                                                        lists padded with zero entries
+ *   where groups = ceil(ceil(M/RG) / GPB) * GPB (every wave of the executor grid has lists).
+ *   Executor: spamd_spmm_tiled — B streams through LDS in KB-row tiles (LDS-DMA), each wave pulls
+ *   its blocks with scalar loads and keeps 32 rows of partial sums in a fixed VGPR block addressed
+ *   with s_set_gpr_idx.  RG / KB / GPB / entries per block / slack from spamd_spmm_tiled_params;
+ *   `blocks` must hold total_blocks + slack blocks and be 64-byte aligned.
+ *   Results are bit-identical to spamd_spmm_csr without SPAMD_EXACT_MULADD (sorted column indices).
+ * ------------------------------------------------------------------------------------- */
+int spamd_spmm_tiled_params(int* rows_per_group, int* tile_rows, int* groups_per_block, int* entries_per_block,
+                            int* slack_blocks);
+int spamd_spmm_tiled_keys(int64_t nnz, const int64_t* rowcol_keys, int64_t K, int64_t* tiled_keys, void* stream);
+int spamd_spmm_tiled_lists(int64_t nnz, const int64_t* tiled_keys_sorted, int64_t M, int64_t K, int64_t* seg_start,
+                           int64_t* nblk, void* stream);
+int spamd_spmm_tiled_pack(int64_t nnz, const int64_t* tiled_keys_sorted, const float* vals_sorted,
+                          const int64_t* seg_start, const int64_t* blk_off, int64_t total_blocks, int* blocks,
+                          void* stream);
+int spamd_spmm_tiled(int64_t M, int64_t K, int64_t N, const int* blocks, const int64_t* blk_off, const float* b,
+                     int64_t ldb, float* out, int64_t ldo, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * A10  NaN scan                    replaces `nan_check` (_common.py:51-69), the pass `matmul`
  *                                  runs over every operand before multiplying (:245-246).
  *   *flag (device int32) is set to 1 if any of the n values is NaN, else 0.  `data` must be

@@ -541,3 +541,50 @@ def sddmm_coo(coords, s_data, a, bt):
     _ffi.call("spamd_sddmm", code_of(a.dtype), code_of(sdt), code_of(rows.dtype), nnz, ptr(rows), ptr(cols),
               ptr(s_data), ptr(a), a.stride(0), ptr(bt), bt.stride(0), int(a.shape[1]), ptr(out), stream_ptr(dev))
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# inspector/executor SpMM (csrc/spmm_tiled.hip)
+# ---------------------------------------------------------------------------------------------
+def tiled_params():
+    """(rows per group, B rows per tile, groups per workgroup, entries per block, slack blocks)."""
+    v = [_ct.c_int(0) for _ in range(5)]
+    _ffi.call("spamd_spmm_tiled_params", *[_ct.byref(x) for x in v])
+    return tuple(x.value for x in v)
+
+
+def csr_tiled_layout(a_data, a_indices, a_indptr, M, Kd):
+    """Inspector: the K-tiled block stream of a CSR matrix used by `dot_csr_ndarray_tiled` (fp32).
+    Returns (blocks int32[(total_blocks + slack) * 16], blk_off int64[nseg + 1])."""
+    dev = require_hip(a_data, a_indices, a_indptr)
+    rg, kb, gpb, epb, slack = tiled_params()
+    nnz = int(a_data.numel())
+    ntiles = -(-Kd // kb)
+    groups = -(-(-(-M // rg)) // gpb) * gpb
+    nseg = groups * ntiles
+    s = stream_ptr(dev)
+    rc = csr_to_keys(a_indptr, a_indices, M, Kd)
+    tk = torch.empty_like(rc)
+    _ffi.call("spamd_spmm_tiled_keys", nnz, ptr(rc), Kd, ptr(tk), s)
+    del rc
+    tk, vals = sort_key_value(tk, a_data.to(torch.float32).contiguous(), max(nseg * rg * kb - 1, 1))
+    seg_start = torch.empty(nseg + 1, dtype=torch.int64, device=dev)
+    nblk = torch.empty(nseg + 1, dtype=torch.int64, device=dev)
+    _ffi.call("spamd_spmm_tiled_lists", nnz, ptr(tk), M, Kd, ptr(seg_start), ptr(nblk), s)
+    blk_off = exclusive_scan(nblk)
+    total = int(blk_off[-1])
+    blocks = torch.empty((total + slack) * epb * 2, dtype=torch.int32, device=dev)
+    _ffi.call("spamd_spmm_tiled_pack", nnz, ptr(tk), ptr(vals), ptr(seg_start), ptr(blk_off), total, ptr(blocks), s)
+    return blocks, blk_off
+
+
+def dot_csr_ndarray_tiled(layout, out_shape, Kd, b, out=None):
+    """Executor: C = A @ B from the tiled layout (fp32, N == 128, one FMA per term)."""
+    blocks, blk_off = layout
+    M, N = int(out_shape[0]), int(out_shape[1])
+    dev = require_hip(blocks, blk_off, b)
+    b = b.contiguous()
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    _ffi.call("spamd_spmm_tiled", M, Kd, N, ptr(blocks), ptr(blk_off), ptr(b), N, ptr(out), N, stream_ptr(dev))
+    return out

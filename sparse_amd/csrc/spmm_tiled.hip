@@ -1,0 +1,253 @@
+// A1, inspector/executor form (fp32, N = 128, FMA mode): CSR x dense -> dense with a cached K-tiled
+// copy of A (reference loop: sparse/numba_backend/_common.py:744-753).
+//
+// What round 1 measured: gathering B rows through the vector L1 tops out at
+// ~25 TB/s (2.05 ms at config 2).  LDS is 4-5x faster, but B (K x 512 B) does not fit, so B is streamed
+// through LDS in K-tiles and the partial sums of a row must live in registers from tile to tile.
+// Building each tile's element list on the fly (cursors, windows, readlanes) costs more than the
+// gather it replaces, so the list building is hoisted out of the multiply:
+//
+//   inspector (once per matrix, cached on the container):
+//     elements are re-ordered by (32-row group g, K-tile t, row, column) and written as a stream of
+//     64-byte BLOCKS of eight (d0, d1) entries, d0 = (column-in-tile << 9) | (2 + 2*row-in-group),
+//     d1 = value bits; every (g, t) list is padded to whole blocks with d0 = d1 = 0 (those land in a
+//     junk accumulator).  blk_off[g*ntiles + t] = first block of list (g, t).
+//   executor (every multiply; this kernel):
+//     a workgroup of 16 waves owns 512 rows; wave w owns row group g and keeps its 32 x 128 partial
+//     sums in the fixed VGPR block v[64:127] (lane l: columns 2l, 2l+1 of each row);
+//     B tile t (128 x 128 fp32 = 64 KB) is copied to LDS by LDS-DMA (global_load_lds_dwordx4),
+//     double-buffered, one barrier per tile;
+//     the wave pulls ITS blocks with SCALAR loads (s_load_dwordx16, three blocks in a ring), so an
+//     entry arrives already wave-uniform: d0 is at once the LDS row offset (v_and_or_b32 with the
+//     per-lane base) and — its low 8 bits — the accumulator index for s_set_gpr_idx_idx; d1 is the
+//     scalar multiplicand.  Per entry: 1 VALU address op, 1 ds_read_b64, 1 SALU, 2 v_fma_f32.
+//     No readlanes, no per-row code, no divergence.
+// The inner loops are generated text (tools/gen_tiled_asm.py -> spmm_tiled_asm.inc); the compiler is
+// confined to v0..v39 (amdgpu_num_vgpr) and never sees v40..v127.
+// Per output element the fused multiply-adds happen in the same k-ascending order as in the row-group
+// kernel's FMA mode, so both kernels return bit-identical results (column indices sorted within rows).
+#include "spmm_internal.h"
+#include "spmm_tiled_asm.inc"
+#include <stdlib.h>
+
+namespace spamd {
+
+constexpr int TL_RG = 32;        // rows per wave (row group)
+constexpr int TL_WAVES = 16;     // waves per workgroup
+constexpr int TL_KB = 128;       // B rows per tile
+constexpr int TL_EPB = 8;        // entries per stream block
+constexpr int TL_TILE = TL_KB * 512;
+constexpr int TL_LDS = 2 * TL_TILE;
+constexpr int TL_SLACK_BLOCKS = 4;  // readable blocks past the end of the stream
+
+#define GRID_STRIDE(i, n)                                                          \
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n);        \
+       i += (int64_t)gridDim.x * blockDim.x)
+
+// key = ((g*ntiles + t)*RG + lr)*KB + lc   from the CSR (row*K + col) key
+__global__ void __launch_bounds__(256) tl_keys_kernel(const int64_t* __restrict__ rc_keys, int64_t nnz, int64_t K,
+                                                      int64_t ntiles, int64_t* __restrict__ out) {
+  GRID_STRIDE(i, nnz) {
+    const int64_t k = rc_keys[i];
+    const int64_t row = k / K, col = k - row * K;
+    const int64_t g = row / TL_RG, lr = row - g * TL_RG, t = col / TL_KB, lc = col - t * TL_KB;
+    out[i] = ((g * ntiles + t) * TL_RG + lr) * TL_KB + lc;
+  }
+}
+
+// sorted tiled keys -> seg_start[nseg + 1] (first sorted position of every list; lists may be empty)
+__global__ void __launch_bounds__(256) tl_seg_start_kernel(const int64_t* __restrict__ keys, int64_t nnz,
+                                                           int64_t nseg, int64_t* __restrict__ seg_start) {
+  GRID_STRIDE(i, nnz + 1) {
+    const int64_t hi = i < nnz ? keys[i] / (TL_RG * TL_KB) : nseg;
+    const int64_t lo = i > 0 ? keys[i - 1] / (TL_RG * TL_KB) + 1 : 0;
+    for (int64_t s = lo; s <= hi; ++s) seg_start[s] = i;  // lists lo..hi start at (or are empty before) i
+  }
+}
+
+// nblk[s] = blocks of list s (input of the exclusive scan); nblk[nseg] = 0
+__global__ void __launch_bounds__(256) tl_blocks_kernel(const int64_t* __restrict__ seg_start, int64_t nseg,
+                                                        int64_t* __restrict__ nblk) {
+  GRID_STRIDE(s, nseg + 1) {
+    nblk[s] = s < nseg ? (seg_start[s + 1] - seg_start[s] + TL_EPB - 1) / TL_EPB : 0;
+  }
+}
+
+__global__ void __launch_bounds__(256) tl_pack_kernel(const int64_t* __restrict__ keys, const float* __restrict__ vals,
+                                                      int64_t nnz, const int64_t* __restrict__ seg_start,
+                                                      const int64_t* __restrict__ blk_off, int2* __restrict__ stream) {
+  GRID_STRIDE(i, nnz) {
+    const int64_t k = keys[i];
+    const int64_t lc = k % TL_KB, r1 = k / TL_KB, lr = r1 % TL_RG, s = r1 / TL_RG;
+    const int64_t dst = blk_off[s] * TL_EPB + (i - seg_start[s]);
+    stream[dst] = make_int2((int)((lc << 9) | (2 + 2 * lr)), __builtin_bit_cast(int, vals[i]));
+  }
+}
+
+__device__ __forceinline__ void tl_dma16(unsigned lds_base, const void* src) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+               :
+               : "s"(lds_base), "v"(src)
+               : "memory", "m0");
+}
+
+template <int PK>
+__device__ __forceinline__ void tl_consume(const int* blocks, int nblk, int vbase, int mask) {
+  if (PK)
+    asm volatile(TL_ASM_CONSUME_PK
+                 :
+                 : [ptr] "s"(blocks), [nblk] "s"(nblk), [vbase] "v"(vbase), [mask] "v"(mask)
+                 : "memory", "m0", "scc", TL_CLOB_SGPR, TL_CLOB_TMP, TL_CLOB_ACC);
+  else
+    asm volatile(TL_ASM_CONSUME
+                 :
+                 : [ptr] "s"(blocks), [nblk] "s"(nblk), [vbase] "v"(vbase), [mask] "v"(mask)
+                 : "memory", "m0", "scc", TL_CLOB_SGPR, TL_CLOB_TMP, TL_CLOB_ACC);
+}
+
+// DBG (timing ablations only): 1 = no consume, 2 = no tile DMA.  PK: v_pk_fma_f32 instead of 2 v_fma_f32.
+template <int DBG, int PK>
+__global__ void __launch_bounds__(TL_WAVES * 64) __attribute__((amdgpu_num_vgpr(40)))
+spmm_tiled_kernel(int64_t M, int64_t K, int64_t ntiles, const int* __restrict__ stream,
+                  const int64_t* __restrict__ blk_off, const float* __restrict__ b, int64_t ldb,
+                  float* __restrict__ out, int64_t ldo) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // the only LDS object: starts at LDS byte 0
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = uniform(tid >> 6);
+  const int64_t g = (int64_t)blockIdx.x * TL_WAVES + wv;  // my row group (lists exist for every wave of the grid)
+
+  asm volatile(TL_ASM_ZERO ::: "memory", TL_CLOB_ACC);
+
+  auto issue_tile = [&](int64_t t) {
+    const int64_t kb0 = t * TL_KB;
+    const unsigned buf = (unsigned)(t & 1) * TL_TILE;
+#pragma unroll
+    for (int i = 0; i < TL_TILE / 16 / (TL_WAVES * 64); ++i) {
+      const int e = (i * (TL_WAVES * 64) + tid) * 4;
+      const int r = e >> 7, c = e & 127;
+      if (kb0 + r < K) tl_dma16(buf + (unsigned)(i * TL_WAVES + wv) * 1024u, b + (kb0 + r) * ldb + c);
+    }
+  };
+
+  issue_tile(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // The block stream is read once, by scalar loads that have no hardware prefetcher and only two
+  // blocks in flight per wave: a K$ miss that goes to HBM (~1-2 us) would bound the whole kernel at
+  // ~0.5 TB/s.  So every wave touches the 64-byte lines of its NEXT list with one vector load (lane i
+  // -> line i, result discarded in v61) a whole tile phase ahead: the scalar loads then hit in L2.
+  auto touch_lines = [&](const void* p, int64_t nlines) {
+    if (lane < nlines)
+      asm volatile("global_load_dword v61, %0, off" ::"v"(reinterpret_cast<const char*>(p) + lane * 64) : "memory", "v61");
+  };
+  const int64_t* const myoff = blk_off + g * ntiles;
+  touch_lines(myoff, (ntiles * 8 + 8 + 63) / 64 + 1);
+  int64_t blk_lo = uniform(myoff[0]);
+  int64_t blk_hi = uniform(myoff[1]);
+  touch_lines(stream + blk_lo * (TL_EPB * 2), blk_hi - blk_lo);
+  for (int64_t t = 0; t < ntiles; ++t) {
+    if (t + 1 < ntiles && DBG != 2) issue_tile(t + 1);
+    int64_t blk_nxt = blk_hi;
+    if (t + 1 < ntiles) {
+      blk_nxt = uniform(myoff[t + 2]);
+      if (DBG != 4) touch_lines(stream + blk_hi * (TL_EPB * 2), blk_nxt - blk_hi);
+    }
+    const int nblk = (int)(blk_hi - blk_lo);
+    if (nblk > 0 && DBG != 1)
+      tl_consume<PK>(stream + blk_lo * (TL_EPB * 2), nblk, (int)((unsigned)(t & 1) * TL_TILE) + lane * 8, (int)0xfffffe00);
+    blk_lo = blk_hi;
+    blk_hi = blk_nxt;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t+1 (this wave's share) and the touches have landed
+    __syncthreads();
+  }
+
+  // write my rows
+  const int64_t row0 = g * TL_RG;
+  const int64_t left = M - row0;
+  const int nvalid = left <= 0 ? 0 : (left < TL_RG ? (int)left : TL_RG);
+  float* const obase_p = out + row0 * ldo + lane * 2;
+  const int64_t stride_bytes = ldo * 4;
+  asm volatile(TL_ASM_STORE
+               :
+               : [lo] "v"((unsigned)((uintptr_t)obase_p & 0xffffffffu)), [hi] "v"((unsigned)((uintptr_t)obase_p >> 32)),
+                 [stride] "s"(stride_bytes), [n] "s"(nvalid)
+               : "memory", "scc", "s36", "v60", "v61", TL_CLOB_ACC);
+}
+
+static int64_t tl_grid_groups(int64_t M) { return ceil_div(ceil_div(M, (int64_t)TL_RG), (int64_t)TL_WAVES) * TL_WAVES; }
+
+}  // namespace spamd
+
+using namespace spamd;
+
+extern "C" int spamd_spmm_tiled_params(int* rows_per_group, int* tile_rows, int* groups_per_block,
+                                       int* entries_per_block, int* slack_blocks) {
+  if (rows_per_group) *rows_per_group = TL_RG;
+  if (tile_rows) *tile_rows = TL_KB;
+  if (groups_per_block) *groups_per_block = TL_WAVES;
+  if (entries_per_block) *entries_per_block = TL_EPB;
+  if (slack_blocks) *slack_blocks = TL_SLACK_BLOCKS;
+  return 0;
+}
+
+static unsigned tl_blocks_for(int64_t n) {
+  int64_t blocks = ceil_div(n, (int64_t)256);
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+extern "C" int spamd_spmm_tiled_keys(int64_t nnz, const int64_t* rowcol_keys, int64_t K, int64_t* tiled_keys,
+                                     void* stream) {
+  if (nnz < 0 || K <= 0) return SPAMD_EINVAL;
+  if (nnz == 0) return 0;
+  hipLaunchKernelGGL(tl_keys_kernel, dim3(tl_blocks_for(nnz)), dim3(256), 0, (hipStream_t)stream, rowcol_keys, nnz, K,
+                     ceil_div(K, (int64_t)TL_KB), tiled_keys);
+  return launch_status();
+}
+
+extern "C" int spamd_spmm_tiled_lists(int64_t nnz, const int64_t* tiled_keys_sorted, int64_t M, int64_t K,
+                                      int64_t* seg_start, int64_t* nblk, void* stream) {
+  if (nnz < 0 || M < 0 || K <= 0) return SPAMD_EINVAL;
+  const int64_t nseg = tl_grid_groups(M) * ceil_div(K, (int64_t)TL_KB);
+  hipLaunchKernelGGL(tl_seg_start_kernel, dim3(tl_blocks_for(nnz + 1)), dim3(256), 0, (hipStream_t)stream,
+                     tiled_keys_sorted, nnz, nseg, seg_start);
+  hipLaunchKernelGGL(tl_blocks_kernel, dim3(tl_blocks_for(nseg + 1)), dim3(256), 0, (hipStream_t)stream, seg_start,
+                     nseg, nblk);
+  return launch_status();
+}
+
+extern "C" int spamd_spmm_tiled_pack(int64_t nnz, const int64_t* tiled_keys_sorted, const float* vals_sorted,
+                                     const int64_t* seg_start, const int64_t* blk_off, int64_t total_blocks,
+                                     int* blocks, void* stream) {
+  if (nnz < 0 || total_blocks < 0) return SPAMD_EINVAL;
+  hipError_t e = hipMemsetAsync(blocks, 0, (size_t)(total_blocks + TL_SLACK_BLOCKS) * TL_EPB * 8, (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  if (nnz == 0) return 0;
+  hipLaunchKernelGGL(tl_pack_kernel, dim3(tl_blocks_for(nnz)), dim3(256), 0, (hipStream_t)stream, tiled_keys_sorted,
+                     vals_sorted, nnz, seg_start, blk_off, reinterpret_cast<int2*>(blocks));
+  return launch_status();
+}
+
+extern "C" int spamd_spmm_tiled(int64_t M, int64_t K, int64_t N, const int* blocks, const int64_t* blk_off,
+                                const float* b, int64_t ldb, float* out, int64_t ldo, void* stream) {
+  if (M < 0 || K <= 0 || N != 128) return SPAMD_EINVAL;
+  if (M == 0) return 0;
+  if (((uintptr_t)b % 16) || (ldb % 4) || ((uintptr_t)out % 8) || (ldo % 2) || ((uintptr_t)blocks % 64))
+    return SPAMD_EINVAL;
+  const char* dbg_env = getenv("SPAMD_TILED_DBG");  // timing ablations: 1 = no consume, 2 = no tile DMA, 4 = no stream touch, 8 = pk_fma
+  const int dbg = dbg_env ? atoi(dbg_env) : 0;
+  auto kern = dbg == 1 ? &spmm_tiled_kernel<1, 0>
+            : dbg == 2 ? &spmm_tiled_kernel<2, 0>
+            : dbg == 4 ? &spmm_tiled_kernel<4, 0>
+            : dbg == 8 ? &spmm_tiled_kernel<0, 1> : &spmm_tiled_kernel<0, 0>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     TL_LDS);
+  if (e != hipSuccess) return (int)e;
+  const int64_t blocks_n = tl_grid_groups(M) / TL_WAVES;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks_n), dim3(TL_WAVES * 64), TL_LDS, (hipStream_t)stream, M, K,
+                     ceil_div(K, (int64_t)TL_KB), blocks, blk_off, b, ldb, out, ldo);
+  return launch_status();
+}

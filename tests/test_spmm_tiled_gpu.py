@@ -1,0 +1,53 @@
+"""Inspector/executor SpMM (csrc/spmm_tiled.hip): parity with the CPU oracle and BIT-identity with the
+row-group kernel's FMA mode (same k-ascending fused multiply-adds)."""
+import numpy as np
+import pytest
+import torch
+
+from util import random_csr, random_dense
+
+pytestmark = pytest.mark.gpu
+
+
+def Kn_params():
+    from sparse_amd import _kernels as Kn
+
+    return Kn.tiled_params()
+
+
+def _run(M, K, density, idt, seed=0, **kw):
+    from sparse_amd import _kernels as Kn
+
+    data, idx, ptr = random_csr(M, K, density, seed, np.float32, idt, **kw)
+    b = random_dense(K, 128, seed + 1, np.float32)
+    d = torch.device("cuda")
+    td, ti, tp, tb = (torch.from_numpy(x).to(d) for x in (data, idx, ptr, b))
+    layout = Kn.csr_tiled_layout(td, ti, tp, M, K)
+    got = Kn.dot_csr_ndarray_tiled(layout, (M, 128), K, tb)
+    ref = Kn.dot_csr_ndarray((M, 128), td, ti, tp, tb, exact=False)
+    torch.cuda.synchronize()
+    return (data, idx, ptr, b), got, ref, layout
+
+
+@pytest.mark.parametrize("idt", [np.int32, np.int64])
+@pytest.mark.parametrize("M,K,density", [(300, 200, 0.05), (1000, 3000, 0.01), (257, 64, 0.5), (64, 1000, 0.2),
+                                         (5000, 10000, 0.01), (1, 70, 1.0), (4097, 129, 0.1), (16, 128, 1.0)])
+def test_tiled_bit_identical_to_rowgroup_fma(orc, idt, M, K, density):
+    (data, idx, ptr, b), got, ref, layout = _run(M, K, density, idt)
+    assert torch.equal(got, ref)
+    want = orc.dot_csr_ndarray((M, 128), data, idx, ptr, b)
+    assert np.allclose(got.cpu().numpy(), want, rtol=2e-5, atol=1e-6)
+    blocks, blk_off = layout
+    rg, kb, gpb, epb, slack = Kn_params()
+    assert bool((blk_off[1:] >= blk_off[:-1]).all()) and blocks.numel() == (int(blk_off[-1]) + slack) * epb * 2
+    ent = blocks.view(-1, 2)[: int(blk_off[-1]) * epb].cpu().numpy()
+    real = ent[ent[:, 0] != 0]                                         # padding entries are all-zero
+    assert len(real) == len(data)
+    assert sorted(real[:, 1].view(np.float32).tolist()) == sorted(data.tolist())  # a permutation of A's values
+
+
+def test_tiled_edge_rows():
+    (_, _, _, _), got, ref, _ = _run(777, 900, 0.03, np.int32, seed=3, empty_rows=(0, 1, 2, 400, 401, 776), long_row=300)
+    assert torch.equal(got, ref)
+    (_, _, _, _), got, ref, _ = _run(300, 50, 0.0, np.int32)
+    assert torch.equal(got, ref) and not got.any()
