@@ -235,6 +235,60 @@ def _return_kind(return_type):
     raise TypeError(f"unsupported return_type {return_type!r}")
 
 
+def _tiled_eligible(data, bt, out_shape, Kd):
+    """The inspector/executor kernel covers fp32 x fp32 -> fp32 with N % 128 == 0 in FMA mode; it pays off
+    when the (32-row, 128-column) lists hold more than a block or so on average and the grid fills the chip."""
+    M, N = out_shape
+    if _settings.EXACT_MULADD or _settings.TILED_SPMM == "never":
+        return False
+    if data.dtype != torch.float32 or bt.dtype != torch.float32 or N == 0 or N % 128 or bt.dim() != 2:
+        return False
+    nnz = int(data.numel())
+    return M >= 32768 and nnz * 4096 >= 12 * M * Kd
+
+
+def prepare_spmm(a):
+    """Build (and cache on `a`) the tiled block stream used by `a @ dense`; returns True if `a` now has one.
+    The counterpart of the reference's memoised conversions (`COO(cache=True)`, _coo/core.py:317-338)."""
+    from ._gcxs import GCXS
+
+    if not isinstance(a, GCXS) or a.ndim != 2 or a.data.dtype != torch.float32:
+        return False
+    if getattr(a, "_tiled_layout", None) is None:
+        d, i, p = _csr_triplet(a)
+        a._tiled_layout = K.csr_tiled_layout(d, i, p, int(a.shape[0]), int(a.shape[1]))
+    return True
+
+
+def _csr_triplet(a):
+    """(data, indices, indptr) of a 2-D GCXS compressed by rows; a csc array is re-compressed once (stable
+    key sort) and the CSR twin memoised on the (immutable) array — the reference's `format="gcxs"` default is
+    compressed_axes=(argmin(shape),), so tall matrices arrive as csc."""
+    if a.compressed_axes == (0,):
+        return a.data, a.indices, a.indptr
+    twin = getattr(a, "_csr_twin", None)
+    if twin is None:
+        twin = K._csc_to_csr(a.shape, a.data, a.indices, a.indptr)
+        a._csr_twin = twin
+    return twin
+
+
+def _gcxs_times_dense(a, bt, out_shape):
+    data, indices, indptr = _csr_triplet(a)
+    Kd = int(a.shape[1])
+    if _tiled_eligible(data, bt, out_shape, Kd):
+        layout = getattr(a, "_tiled_layout", None)
+        if layout is None:
+            a._spmm_uses = getattr(a, "_spmm_uses", 0) + 1
+            if _settings.TILED_SPMM == "always" or a._spmm_uses >= 2:
+                prepare_spmm(a)
+                layout = a._tiled_layout
+        if layout is not None:
+            return K.dot_csr_ndarray_tiled(layout, out_shape, Kd, bt)
+    return K.dot_csr_ndarray(out_shape, data, indices, indptr, bt, exact=_settings.EXACT_MULADD)
+
+
+
 def _dot(a, b, return_type=None):
     """2-D x 2-D product: the dispatch table of reference `_common.py:339-503` (Appendix B of
     SURVEY.md), one C-ABI kernel per row of the table."""
@@ -273,23 +327,12 @@ def _dot(a, b, return_type=None):
     if isinstance(a, GCXS) and _is_dense(b):
         bt = io.to_dev(b) if not (isinstance(b, torch.Tensor) and b.is_cuda) else b
         bt = dev.to_device(bt, a.device)
-        if a.compressed_axes == (0,):  # csr @ dense
-            if rk in (None, "ndarray"):
-                return io.out(K.dot_csr_ndarray(out_shape, a.data, a.indices, a.indptr, bt,
-                                                exact=_settings.EXACT_MULADD))
+        if rk in (None, "ndarray"):
+            return io.out(_gcxs_times_dense(a, bt, out_shape))
+        if a.compressed_axes == (0,):  # csr @ dense, sparse result
             data, indices, indptr = K.dot_csr_ndarray_sparse(out_shape, a.data, a.indices, a.indptr, bt)
             out = GCXS((data, indices, indptr), shape=out_shape, compressed_axes=(0,), prune=True)
             return out.tocoo() if rk == "coo" else out
-        # csc @ dense: re-compress A by rows once (stable key sort) and memoise the CSR twin on the
-        # (immutable) array, so repeated products with a default-compressed tall matrix — the
-        # reference's `format="gcxs"` default is compressed_axes=(argmin(shape),) — pay it once
-        if rk in (None, "ndarray"):
-            twin = getattr(a, "_csr_twin", None)
-            if twin is None:
-                twin = K._csc_to_csr(a.shape, a.data, a.indices, a.indptr)
-                a._csr_twin = twin
-            return io.out(K.dot_csr_ndarray(out_shape, twin[0], twin[1], twin[2], bt,
-                                            exact=_settings.EXACT_MULADD))
         data, indices, indptr = K.dot_csc_ndarray_sparse(a.shape, tuple(bt.shape), a.data, a.indices,
                                                          a.indptr, bt)
         out = GCXS((data, indices, indptr), shape=out_shape, compressed_axes=(1,), prune=True)

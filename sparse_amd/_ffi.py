@@ -8,7 +8,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libsparse_amd.so")
+# SPAMD_LIB: load an alternative build of the same ABI (kernel-tuning experiments only)
+LIB_PATH = os.environ.get("SPAMD_LIB") or os.path.join(_HERE, "_lib", "libsparse_amd.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sparse_amd.h")
 
 # dtype codes (include/sparse_amd.h)

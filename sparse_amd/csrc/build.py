@@ -37,7 +37,7 @@ def sources():
 
 
 def _deps():
-    return sorted(glob.glob(os.path.join(HERE, "*.h"))) + [
+    return sorted(glob.glob(os.path.join(HERE, "*.h"))) + sorted(glob.glob(os.path.join(HERE, "*.inc"))) + [
         os.path.join(os.path.dirname(PKG), "include", "sparse_amd.h"), os.path.abspath(__file__)]
 
 

@@ -1,4 +1,4 @@
-// A1, inspector/executor form (fp32, N = 128, FMA mode): CSR x dense -> dense with a cached K-tiled
+// A1, inspector/executor form (fp32, N a multiple of 128, FMA mode): CSR x dense -> dense with a cached K-tiled
 // copy of A (reference loop: sparse/numba_backend/_common.py:744-753).
 //
 // What round 1 measured: gathering B rows through the vector L1 tops out at
@@ -34,10 +34,17 @@ namespace spamd {
 
 constexpr int TL_RG = 32;        // rows per wave (row group)
 constexpr int TL_WAVES = 16;     // waves per workgroup
-constexpr int TL_KB = 128;       // B rows per tile
+#ifndef SPAMD_TL_KB
+#define SPAMD_TL_KB 128
+#define SPAMD_TL_NBUF 2
+#endif
+constexpr int TL_KB = SPAMD_TL_KB;      // B rows per tile (64 or 128: the tile must be a power of two <= 64 KB)
+constexpr int TL_NBUF = SPAMD_TL_NBUF;  // LDS tile buffers: tile t+NBUF-1 is in flight while tile t is consumed
 constexpr int TL_EPB = 8;        // entries per stream block
 constexpr int TL_TILE = TL_KB * 512;
-constexpr int TL_LDS = 2 * TL_TILE;
+constexpr int TL_LDS = TL_NBUF * TL_TILE;
+constexpr int TL_DMA_PER_TILE = TL_TILE / 16 / (TL_WAVES * 64);  // LDS-DMA instructions per wave per tile
+static_assert(TL_LDS <= 160 * 1024 && (TL_TILE & (TL_TILE - 1)) == 0 && TL_DMA_PER_TILE >= 1, "tile geometry");
 constexpr int TL_SLACK_BLOCKS = 4;  // readable blocks past the end of the stream
 
 #define GRID_STRIDE(i, n)                                                          \
@@ -93,7 +100,22 @@ __device__ __forceinline__ void tl_dma16(unsigned lds_base, const void* src) {
 
 template <int PK>
 __device__ __forceinline__ void tl_consume(const int* blocks, int nblk, int vbase, int mask) {
-  if (PK)
+  if (PK == 2)
+    asm volatile(TL_ASM_CONSUME_NOFMA
+                 :
+                 : [ptr] "s"(blocks), [nblk] "s"(nblk), [vbase] "v"(vbase), [mask] "v"(mask)
+                 : "memory", "m0", "scc", TL_CLOB_SGPR, TL_CLOB_TMP, TL_CLOB_ACC);
+  else if (PK == 3)
+    asm volatile(TL_ASM_CONSUME_NOLDS
+                 :
+                 : [ptr] "s"(blocks), [nblk] "s"(nblk), [vbase] "v"(vbase), [mask] "v"(mask)
+                 : "memory", "m0", "scc", TL_CLOB_SGPR, TL_CLOB_TMP, TL_CLOB_ACC);
+  else if (PK == 4)
+    asm volatile(TL_ASM_CONSUME_NOSMEM
+                 :
+                 : [ptr] "s"(blocks), [nblk] "s"(nblk), [vbase] "v"(vbase), [mask] "v"(mask)
+                 : "memory", "m0", "scc", TL_CLOB_SGPR, TL_CLOB_TMP, TL_CLOB_ACC);
+  else if (PK == 1)
     asm volatile(TL_ASM_CONSUME_PK
                  :
                  : [ptr] "s"(blocks), [nblk] "s"(nblk), [vbase] "v"(vbase), [mask] "v"(mask)
@@ -116,52 +138,63 @@ spmm_tiled_kernel(int64_t M, int64_t K, int64_t ntiles, const int* __restrict__ 
   const int lane = tid & 63;
   const int wv = uniform(tid >> 6);
   const int64_t g = (int64_t)blockIdx.x * TL_WAVES + wv;  // my row group (lists exist for every wave of the grid)
+  b += (int64_t)blockIdx.y * 128;                          // column panel of B and of the result
+  out += (int64_t)blockIdx.y * 128;
 
   asm volatile(TL_ASM_ZERO ::: "memory", TL_CLOB_ACC);
 
+  // Tile DMA: every wave issues exactly TL_DMA_PER_TILE instructions per tile, all lanes active (rows
+  // past K are clamped to row K-1: never referenced by an entry) — so vmcnt arithmetic is exact.
   auto issue_tile = [&](int64_t t) {
-    const int64_t kb0 = t * TL_KB;
-    const unsigned buf = (unsigned)(t & 1) * TL_TILE;
+    const int64_t kb0 = (t < ntiles ? t : ntiles - 1) * TL_KB;
+    const unsigned buf = (unsigned)(t % TL_NBUF) * TL_TILE;
 #pragma unroll
-    for (int i = 0; i < TL_TILE / 16 / (TL_WAVES * 64); ++i) {
+    for (int i = 0; i < TL_DMA_PER_TILE; ++i) {
       const int e = (i * (TL_WAVES * 64) + tid) * 4;
-      const int r = e >> 7, c = e & 127;
-      if (kb0 + r < K) tl_dma16(buf + (unsigned)(i * TL_WAVES + wv) * 1024u, b + (kb0 + r) * ldb + c);
+      int64_t r = kb0 + (e >> 7);
+      const int c = e & 127;
+      if (r >= K) r = K - 1;
+      tl_dma16(buf + (unsigned)(i * TL_WAVES + wv) * 1024u, b + r * ldb + c);
     }
   };
 
-  issue_tile(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (DBG != 2)
+    for (int t = 0; t < TL_NBUF - 1; ++t) issue_tile(t);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((TL_NBUF - 2) * TL_DMA_PER_TILE) : "memory");
   __syncthreads();
 
-  // The block stream is read once, by scalar loads that have no hardware prefetcher and only two
-  // blocks in flight per wave: a K$ miss that goes to HBM (~1-2 us) would bound the whole kernel at
-  // ~0.5 TB/s.  So every wave touches the 64-byte lines of its NEXT list with one vector load (lane i
-  // -> line i, result discarded in v61) a whole tile phase ahead: the scalar loads then hit in L2.
-  auto touch_lines = [&](const void* p, int64_t nlines) {
-    if (lane < nlines)
-      asm volatile("global_load_dword v61, %0, off" ::"v"(reinterpret_cast<const char*>(p) + lane * 64) : "memory", "v61");
+  // The block stream is read once, by scalar loads: no hardware prefetcher, and every s_waitcnt on the
+  // LDS reads (lgkmcnt(0): SMEM returns out of order) also waits for the scalar load issued a round
+  // earlier, so its latency must be an L2 hit (~270 cycles), never HBM (~1-2 us: measured 2.25 ms
+  // without this).  Two tile phases ahead, the consuming wave touches the 64-byte lines of that list
+  // with one vector load (lane i -> line i, result discarded in v61): HBM -> this XCD's L2.
+  // (A further scalar-cache prefetch stage was measured slower: K$ hits still cost ~160 cycles and
+  // the scalar return path is 4 B/clk per CU: tools/micro/smem_lat.hip.)
+  auto touch_lines = [&](const void* p, int64_t nlines) {  // always ONE instruction (vmcnt arithmetic)
+    const int64_t l = lane < nlines ? lane : 0;
+    asm volatile("global_load_dword v61, %0, off" ::"v"(reinterpret_cast<const char*>(p) + l * 64) : "memory", "v61");
   };
   const int64_t* const myoff = blk_off + g * ntiles;
+  auto list_start = [&](int64_t t) { return uniform(myoff[t < ntiles ? t : ntiles]); };
   touch_lines(myoff, (ntiles * 8 + 8 + 63) / 64 + 1);
-  int64_t blk_lo = uniform(myoff[0]);
-  int64_t blk_hi = uniform(myoff[1]);
-  touch_lines(stream + blk_lo * (TL_EPB * 2), blk_hi - blk_lo);
+  int64_t o0 = list_start(0), o1 = list_start(1), o2 = list_start(2);  // starts of lists t, t+1, t+2
+  touch_lines(stream + o0 * (TL_EPB * 2), o2 - o0);
   for (int64_t t = 0; t < ntiles; ++t) {
-    if (t + 1 < ntiles && DBG != 2) issue_tile(t + 1);
-    int64_t blk_nxt = blk_hi;
-    if (t + 1 < ntiles) {
-      blk_nxt = uniform(myoff[t + 2]);
-      if (DBG != 4) touch_lines(stream + blk_hi * (TL_EPB * 2), blk_nxt - blk_hi);
-    }
-    const int nblk = (int)(blk_hi - blk_lo);
+    if (DBG != 2) issue_tile(t + TL_NBUF - 1);  // (clamped past the end: keeps the count per iteration fixed)
+    const int nblk = (int)(o1 - o0);
     if (nblk > 0 && DBG != 1)
-      tl_consume<PK>(stream + blk_lo * (TL_EPB * 2), nblk, (int)((unsigned)(t & 1) * TL_TILE) + lane * 8, (int)0xfffffe00);
-    blk_lo = blk_hi;
-    blk_hi = blk_nxt;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t+1 (this wave's share) and the touches have landed
+      tl_consume<PK>(stream + o0 * (TL_EPB * 2), nblk, (int)((unsigned)(t % TL_NBUF) * TL_TILE) + lane * 8,
+                     (int)0xfffffe00);
+    const int64_t o3 = list_start(t + 3);
+    touch_lines(stream + o2 * (TL_EPB * 2), DBG != 4 ? o3 - o2 : 0);
+    o0 = o1;
+    o1 = o2;
+    o2 = o3;
+    // tile t+1 (this wave's share) has landed: everything but the newest NBUF-2 tiles and one touch
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((TL_NBUF - 2) * (TL_DMA_PER_TILE + 1) + 1) : "memory");
     __syncthreads();
   }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
   // write my rows
   const int64_t row0 = g * TL_RG;
@@ -233,21 +266,26 @@ extern "C" int spamd_spmm_tiled_pack(int64_t nnz, const int64_t* tiled_keys_sort
 
 extern "C" int spamd_spmm_tiled(int64_t M, int64_t K, int64_t N, const int* blocks, const int64_t* blk_off,
                                 const float* b, int64_t ldb, float* out, int64_t ldo, void* stream) {
-  if (M < 0 || K <= 0 || N != 128) return SPAMD_EINVAL;
+  if (M < 0 || K <= 0 || N <= 0 || N % 128 != 0 || N / 128 > 65535) return SPAMD_EINVAL;
   if (M == 0) return 0;
   if (((uintptr_t)b % 16) || (ldb % 4) || ((uintptr_t)out % 8) || (ldo % 2) || ((uintptr_t)blocks % 64))
     return SPAMD_EINVAL;
-  const char* dbg_env = getenv("SPAMD_TILED_DBG");  // timing ablations: 1 = no consume, 2 = no tile DMA, 4 = no stream touch, 8 = pk_fma
+  const char* dbg_env = getenv("SPAMD_TILED_DBG");  // timing ablations: 1 = no consume, 2 = no tile DMA, 4 = no stream touch, 8 = two v_fma_f32 instead of v_pk_fma_f32
   const int dbg = dbg_env ? atoi(dbg_env) : 0;
   auto kern = dbg == 1 ? &spmm_tiled_kernel<1, 0>
             : dbg == 2 ? &spmm_tiled_kernel<2, 0>
             : dbg == 4 ? &spmm_tiled_kernel<4, 0>
-            : dbg == 8 ? &spmm_tiled_kernel<0, 1> : &spmm_tiled_kernel<0, 0>;
+            : dbg == 8 ? &spmm_tiled_kernel<0, 0>
+            : dbg == 9 ? &spmm_tiled_kernel<0, 4>
+            : dbg == 10 ? &spmm_tiled_kernel<2, 4>
+            : dbg == 5 ? &spmm_tiled_kernel<0, 2>
+            : dbg == 6 ? &spmm_tiled_kernel<0, 3>
+            : dbg == 7 ? &spmm_tiled_kernel<2, 3> : &spmm_tiled_kernel<0, 1>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      TL_LDS);
   if (e != hipSuccess) return (int)e;
   const int64_t blocks_n = tl_grid_groups(M) / TL_WAVES;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks_n), dim3(TL_WAVES * 64), TL_LDS, (hipStream_t)stream, M, K,
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks_n, (unsigned)(N / 128)), dim3(TL_WAVES * 64), TL_LDS, (hipStream_t)stream, M, K,
                      ceil_div(K, (int64_t)TL_KB), blocks, blk_off, b, ldb, out, ldo);
   return launch_status();
 }

@@ -51,3 +51,76 @@ def test_tiled_edge_rows():
     assert torch.equal(got, ref)
     (_, _, _, _), got, ref, _ = _run(300, 50, 0.0, np.int32)
     assert torch.equal(got, ref) and not got.any()
+
+
+def _product_case(M=40000, K=2000, density=0.01, N=128, seed=5):
+    import sparse_amd as sp
+
+    data, idx, ptr = random_csr(M, K, density, seed, np.float32, np.int32)
+    b = random_dense(K, N, seed + 1, np.float32)
+    d = torch.device("cuda")
+    a = sp.GCXS(tuple(torch.from_numpy(x).to(d) for x in (data, idx, ptr)), shape=(M, K), compressed_axes=(0,))
+    return a, torch.from_numpy(b).to(d), (data, idx, ptr, b)
+
+
+def test_product_path_builds_the_block_stream_on_second_use(orc, monkeypatch):
+    """`a @ dense` (reference `_dot` csr x ndarray row, _common.py:339-503): first product = row-group
+    kernel, second builds and caches the tiled layout; both equal the oracle within fp32 FMA tolerance and
+    are bit-identical to each other."""
+    from sparse_amd import _settings
+
+    monkeypatch.setattr(_settings, "TILED_SPMM", "auto")
+    monkeypatch.setattr(_settings, "EXACT_MULADD", False)
+    a, b, (data, idx, ptr, bh) = _product_case()
+    r1 = a @ b
+    assert getattr(a, "_tiled_layout", None) is None
+    r2 = a @ b
+    assert getattr(a, "_tiled_layout", None) is not None
+    r3 = a @ b
+    assert torch.equal(r1, r2) and torch.equal(r2, r3)
+    want = orc.dot_csr_ndarray((a.shape[0], 128), data, idx, ptr, bh)
+    assert np.allclose(r3.cpu().numpy(), want, rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("N", [256, 384])
+def test_product_path_column_panels(orc, monkeypatch, N):
+    from sparse_amd import _settings, _kernels as Kn
+
+    monkeypatch.setattr(_settings, "TILED_SPMM", "always")
+    monkeypatch.setattr(_settings, "EXACT_MULADD", False)
+    a, b, (data, idx, ptr, bh) = _product_case(N=N, seed=8)
+    got = a @ b
+    assert a._tiled_layout is not None
+    ref = Kn.dot_csr_ndarray((a.shape[0], N), a.data, a.indices, a.indptr, b, exact=False)
+    assert torch.equal(got, ref)
+    want = orc.dot_csr_ndarray((a.shape[0], N), data, idx, ptr, bh)
+    assert np.allclose(got.cpu().numpy(), want, rtol=2e-5, atol=1e-6)
+
+
+def test_product_path_csc_operand_uses_the_csr_twin(orc, monkeypatch):
+    """Default-compressed tall matrix (csc): the cached CSR twin feeds the inspector."""
+    import sparse_amd as sp
+    from sparse_amd import _settings
+
+    monkeypatch.setattr(_settings, "TILED_SPMM", "always")
+    monkeypatch.setattr(_settings, "EXACT_MULADD", False)
+    a, b, (data, idx, ptr, bh) = _product_case(seed=11)
+    acsc = a.change_compressed_axes((1,))
+    got = acsc @ b
+    assert acsc._tiled_layout is not None and acsc._csr_twin is not None
+    want = orc.dot_csr_ndarray((a.shape[0], 128), data, idx, ptr, bh)
+    assert np.allclose(got.cpu().numpy(), want, rtol=2e-5, atol=1e-6)
+
+
+def test_exact_mode_and_ineligible_shapes_keep_the_rowgroup_kernel(monkeypatch):
+    from sparse_amd import _settings
+
+    monkeypatch.setattr(_settings, "TILED_SPMM", "always")
+    monkeypatch.setattr(_settings, "EXACT_MULADD", True)
+    a, b, _ = _product_case(seed=12)
+    a @ b
+    assert getattr(a, "_tiled_layout", None) is None
+    monkeypatch.setattr(_settings, "EXACT_MULADD", False)
+    a2, b2, _ = _product_case(N=64, seed=13)
+    a2 @ b2
+    assert getattr(a2, "_tiled_layout", None) is None
