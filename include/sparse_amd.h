@@ -79,6 +79,7 @@ int spamd_spmm_csr(int val_dtype, int idx_dtype, int64_t M, int64_t K, int64_t N
  *     stable sort of (tkeys, values)                     spamd_sort_kv
  *     seg_start, nblk = spamd_spmm_tiled_lists(tkeys)    first element / 8-entry blocks of list (g,t)
  *     blk_off = spamd_exclusive_scan(nblk)               int64[nseg + 1], nseg = groups*ntiles
+ *     blk_off32 = spamd_convert(I64 -> I32)              what the executor reads (total blocks < 2^31)
  *     blocks  = spamd_spmm_tiled_pack(...)               64-byte blocks of eight (d0, d1):
  *                                                        d0 = col%KB << 9 | 2 + 2*(row%RG), d1 = value bits;
  *                                                        lists padded with zero entries
@@ -97,7 +98,7 @@ int spamd_spmm_tiled_lists(int64_t nnz, const int64_t* tiled_keys_sorted, int64_
 int spamd_spmm_tiled_pack(int64_t nnz, const int64_t* tiled_keys_sorted, const float* vals_sorted,
                           const int64_t* seg_start, const int64_t* blk_off, int64_t total_blocks, int* blocks,
                           void* stream);
-int spamd_spmm_tiled(int64_t M, int64_t K, int64_t N, const int* blocks, const int64_t* blk_off, const float* b,
+int spamd_spmm_tiled(int64_t M, int64_t K, int64_t N, const int* blocks, const int* blk_off32, const float* b,
                      int64_t ldb, float* out, int64_t ldo, void* stream);
 
 /* ---------------------------------------------------------------------------------------

@@ -555,7 +555,7 @@ def tiled_params():
 
 def csr_tiled_layout(a_data, a_indices, a_indptr, M, Kd):
     """Inspector: the K-tiled block stream of a CSR matrix used by `dot_csr_ndarray_tiled` (fp32).
-    Returns (blocks int32[(total_blocks + slack) * 16], blk_off int64[nseg + 1])."""
+    Returns (blocks int32[(total_blocks + slack) * 16], blk_off int32[nseg + 1])."""
     dev = require_hip(a_data, a_indices, a_indptr)
     rg, kb, gpb, epb, slack = tiled_params()
     nnz = int(a_data.numel())
@@ -574,8 +574,10 @@ def csr_tiled_layout(a_data, a_indices, a_indptr, M, Kd):
     blk_off = exclusive_scan(nblk)
     total = int(blk_off[-1])
     blocks = torch.empty((total + slack) * epb * 2, dtype=torch.int32, device=dev)
+    if total >= 2 ** 31:
+        raise ValueError("tiled SpMM layout: more than 2^31 blocks")
     _ffi.call("spamd_spmm_tiled_pack", nnz, ptr(tk), ptr(vals), ptr(seg_start), ptr(blk_off), total, ptr(blocks), s)
-    return blocks, blk_off
+    return blocks, convert(blk_off, torch.int32)
 
 
 def dot_csr_ndarray_tiled(layout, out_shape, Kd, b, out=None):

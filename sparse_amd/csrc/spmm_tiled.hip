@@ -23,7 +23,7 @@
 //     scalar multiplicand.  Per entry: 1 VALU address op, 1 ds_read_b64, 1 SALU, 2 v_fma_f32.
 //     No readlanes, no per-row code, no divergence.
 // The inner loops are generated text (tools/gen_tiled_asm.py -> spmm_tiled_asm.inc); the compiler is
-// confined to v0..v39 (amdgpu_num_vgpr) and never sees v40..v127.
+// confined to v0..v23 (amdgpu_num_vgpr) and never sees v24..v127.
 // Per output element the fused multiply-adds happen in the same k-ascending order as in the row-group
 // kernel's FMA mode, so both kernels return bit-identical results (column indices sorted within rows).
 #include "spmm_internal.h"
@@ -115,6 +115,11 @@ __device__ __forceinline__ void tl_consume(const int* blocks, int nblk, int vbas
                  :
                  : [ptr] "s"(blocks), [nblk] "s"(nblk), [vbase] "v"(vbase), [mask] "v"(mask)
                  : "memory", "m0", "scc", TL_CLOB_SGPR, TL_CLOB_TMP, TL_CLOB_ACC);
+  else if (PK == 5)
+    asm volatile(TL_ASM_CONSUME_PIPE
+                 :
+                 : [ptr] "s"(blocks), [nblk] "s"(nblk), [vbase] "v"(vbase), [mask] "v"(mask)
+                 : "memory", "m0", "scc", TL_CLOB_SGPR, TL_CLOB_TMP, TL_CLOB_ACC);
   else if (PK == 1)
     asm volatile(TL_ASM_CONSUME_PK
                  :
@@ -129,9 +134,9 @@ __device__ __forceinline__ void tl_consume(const int* blocks, int nblk, int vbas
 
 // DBG (timing ablations only): 1 = no consume, 2 = no tile DMA.  PK: v_pk_fma_f32 instead of 2 v_fma_f32.
 template <int DBG, int PK>
-__global__ void __launch_bounds__(TL_WAVES * 64) __attribute__((amdgpu_num_vgpr(40)))
+__global__ void __launch_bounds__(TL_WAVES * 64) __attribute__((amdgpu_num_vgpr(24)))
 spmm_tiled_kernel(int64_t M, int64_t K, int64_t ntiles, const int* __restrict__ stream,
-                  const int64_t* __restrict__ blk_off, const float* __restrict__ b, int64_t ldb,
+                  const int* __restrict__ blk_off, const float* __restrict__ b, int64_t ldb,
                   float* __restrict__ out, int64_t ldo) {
   extern __shared__ __attribute__((aligned(16))) char lds[];  // the only LDS object: starts at LDS byte 0
   const int tid = threadIdx.x;
@@ -143,23 +148,42 @@ spmm_tiled_kernel(int64_t M, int64_t K, int64_t ntiles, const int* __restrict__ 
 
   asm volatile(TL_ASM_ZERO ::: "memory", TL_CLOB_ACC);
 
-  // Tile DMA: every wave issues exactly TL_DMA_PER_TILE instructions per tile, all lanes active (rows
-  // past K are clamped to row K-1: never referenced by an entry) — so vmcnt arithmetic is exact.
-  auto issue_tile = [&](int64_t t) {
-    const int64_t kb0 = (t < ntiles ? t : ntiles - 1) * TL_KB;
-    const unsigned buf = (unsigned)(t % TL_NBUF) * TL_TILE;
+  // Tile DMA: every wave issues exactly TL_DMA_PER_TILE instructions per tile, all lanes active — so
+  // vmcnt arithmetic is exact.  Full tiles: per-thread source pointers advanced by one tile per call
+  // (no 64-bit multiplies in the loop).  The last, partial tile (and the dummy re-issues past the end
+  // that keep the per-iteration count fixed): rows past K are clamped to row K-1, which no entry refers to.
+  const int64_t nfull = K / TL_KB;
+  const int64_t tile_step_bytes = (int64_t)TL_KB * ldb * 4;
+  const char* src[TL_DMA_PER_TILE];
 #pragma unroll
-    for (int i = 0; i < TL_DMA_PER_TILE; ++i) {
-      const int e = (i * (TL_WAVES * 64) + tid) * 4;
-      int64_t r = kb0 + (e >> 7);
-      const int c = e & 127;
-      if (r >= K) r = K - 1;
-      tl_dma16(buf + (unsigned)(i * TL_WAVES + wv) * 1024u, b + r * ldb + c);
+  for (int i = 0; i < TL_DMA_PER_TILE; ++i) {
+    const int e = (i * (TL_WAVES * 64) + tid) * 4;
+    src[i] = reinterpret_cast<const char*>(b + (int64_t)(e >> 7) * ldb + (e & 127));
+  }
+  int64_t next_tile = 0;  // issue_tile is called for t = 0, 1, 2, ... in order
+  auto issue_tile = [&]() {
+    const int64_t t = next_tile++;
+    const unsigned buf = (unsigned)(t % TL_NBUF) * TL_TILE;
+    if (t < nfull) {
+#pragma unroll
+      for (int i = 0; i < TL_DMA_PER_TILE; ++i) {
+        tl_dma16(buf + (unsigned)(i * TL_WAVES + wv) * 1024u, src[i]);
+        src[i] += tile_step_bytes;
+      }
+    } else {
+      const int64_t kb0 = (t < ntiles ? t : ntiles - 1) * TL_KB;
+#pragma unroll
+      for (int i = 0; i < TL_DMA_PER_TILE; ++i) {
+        const int e = (i * (TL_WAVES * 64) + tid) * 4;
+        int64_t r = kb0 + (e >> 7);
+        if (r >= K) r = K - 1;
+        tl_dma16(buf + (unsigned)(i * TL_WAVES + wv) * 1024u, b + r * ldb + (e & 127));
+      }
     }
   };
 
   if (DBG != 2)
-    for (int t = 0; t < TL_NBUF - 1; ++t) issue_tile(t);
+    for (int t = 0; t < TL_NBUF - 1; ++t) issue_tile();
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"((TL_NBUF - 2) * TL_DMA_PER_TILE) : "memory");
   __syncthreads();
 
@@ -174,17 +198,34 @@ spmm_tiled_kernel(int64_t M, int64_t K, int64_t ntiles, const int* __restrict__ 
     const int64_t l = lane < nlines ? lane : 0;
     asm volatile("global_load_dword v61, %0, off" ::"v"(reinterpret_cast<const char*>(p) + l * 64) : "memory", "v61");
   };
-  const int64_t* const myoff = blk_off + g * ntiles;
-  auto list_start = [&](int64_t t) { return uniform(myoff[t < ntiles ? t : ntiles]); };
-  touch_lines(myoff, (ntiles * 8 + 8 + 63) / 64 + 1);
+  // List boundaries of this wave: blk_off[g*ntiles + t], t = 0..ntiles.  64 of them at a time live in one
+  // VGPR (lane <-> tile) and are read with v_readlane: no memory access per tile (a per-tile load would
+  // make the compiler wait vmcnt(0), i.e. for the tile DMA in flight).
+  const int* const myoff = blk_off + g * ntiles;
+  int64_t obase = 0;
+  auto load_offsets = [&](int64_t base) {
+    const int64_t q = base + lane;
+    return myoff[q < ntiles ? q : ntiles];
+  };
+  int offreg = load_offsets(0);
+  asm volatile("" : "+v"(offreg));
+  auto list_start = [&](int64_t t) -> int64_t {  // needs obase <= t < obase + 64 (or t > ntiles: clamped)
+    const int64_t q = t < ntiles ? t : ntiles;
+    return (int64_t)wave_bcast(offreg, (int)(q - obase));
+  };
   int64_t o0 = list_start(0), o1 = list_start(1), o2 = list_start(2);  // starts of lists t, t+1, t+2
   touch_lines(stream + o0 * (TL_EPB * 2), o2 - o0);
   for (int64_t t = 0; t < ntiles; ++t) {
-    if (DBG != 2) issue_tile(t + TL_NBUF - 1);  // (clamped past the end: keeps the count per iteration fixed)
+    if (DBG != 2) issue_tile();  // tile t + NBUF - 1
     const int nblk = (int)(o1 - o0);
     if (nblk > 0 && DBG != 1)
       tl_consume<PK>(stream + o0 * (TL_EPB * 2), nblk, (int)((unsigned)(t % TL_NBUF) * TL_TILE) + lane * 8,
                      (int)0xfffffe00);
+    if (t + 3 <= ntiles && t + 3 - obase >= 64) {  // once per 61 tiles (this load does wait for the DMA)
+      obase = t + 3;
+      offreg = load_offsets(obase);
+      asm volatile("" : "+v"(offreg));  // the wait for this load stays inside the branch
+    }
     const int64_t o3 = list_start(t + 3);
     touch_lines(stream + o2 * (TL_EPB * 2), DBG != 4 ? o3 - o2 : 0);
     o0 = o1;
@@ -264,7 +305,7 @@ extern "C" int spamd_spmm_tiled_pack(int64_t nnz, const int64_t* tiled_keys_sort
   return launch_status();
 }
 
-extern "C" int spamd_spmm_tiled(int64_t M, int64_t K, int64_t N, const int* blocks, const int64_t* blk_off,
+extern "C" int spamd_spmm_tiled(int64_t M, int64_t K, int64_t N, const int* blocks, const int* blk_off,
                                 const float* b, int64_t ldb, float* out, int64_t ldo, void* stream) {
   if (M < 0 || K <= 0 || N <= 0 || N % 128 != 0 || N / 128 > 65535) return SPAMD_EINVAL;
   if (M == 0) return 0;
@@ -280,7 +321,9 @@ extern "C" int spamd_spmm_tiled(int64_t M, int64_t K, int64_t N, const int* bloc
             : dbg == 10 ? &spmm_tiled_kernel<2, 4>
             : dbg == 5 ? &spmm_tiled_kernel<0, 2>
             : dbg == 6 ? &spmm_tiled_kernel<0, 3>
-            : dbg == 7 ? &spmm_tiled_kernel<2, 3> : &spmm_tiled_kernel<0, 1>;
+            : dbg == 7 ? &spmm_tiled_kernel<2, 3>
+            : dbg == 11 ? &spmm_tiled_kernel<0, 1>
+            : dbg == 12 ? &spmm_tiled_kernel<2, 5> : &spmm_tiled_kernel<0, 5>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      TL_LDS);
   if (e != hipSuccess) return (int)e;
