@@ -34,17 +34,15 @@ namespace spamd {
 
 constexpr int TL_RG = 32;        // rows per wave (row group)
 constexpr int TL_WAVES = 16;     // waves per workgroup
-#ifndef SPAMD_TL_KB
-#define SPAMD_TL_KB 128
-#define SPAMD_TL_NBUF 2
-#endif
-constexpr int TL_KB = SPAMD_TL_KB;      // B rows per tile (64 or 128: the tile must be a power of two <= 64 KB)
-constexpr int TL_NBUF = SPAMD_TL_NBUF;  // LDS tile buffers: tile t+NBUF-1 is in flight while tile t is consumed
+constexpr int TL_KB = 128;       // B rows per tile: 64 KB, so that (column << 9) | base addresses a row (v_and_or_b32)
+constexpr int TL_NBUF = 2;       // LDS tile buffers: tile t+1 is in flight while tile t is consumed
+                                 // (64-row tiles with 3-5 buffers were measured 30-40 % slower: twice the
+                                 // barriers and list heads, 17 % padding)
 constexpr int TL_EPB = 8;        // entries per stream block
 constexpr int TL_TILE = TL_KB * 512;
 constexpr int TL_LDS = TL_NBUF * TL_TILE;
 constexpr int TL_DMA_PER_TILE = TL_TILE / 16 / (TL_WAVES * 64);  // LDS-DMA instructions per wave per tile
-static_assert(TL_LDS <= 160 * 1024 && (TL_TILE & (TL_TILE - 1)) == 0 && TL_DMA_PER_TILE >= 1, "tile geometry");
+static_assert(TL_LDS <= 160 * 1024 && TL_TILE == 65536 && TL_DMA_PER_TILE == 4, "tile geometry is baked into gen_tiled_asm.py");
 constexpr int TL_SLACK_BLOCKS = 4;  // readable blocks past the end of the stream
 
 #define GRID_STRIDE(i, n)                                                          \
@@ -98,43 +96,29 @@ __device__ __forceinline__ void tl_dma16(unsigned lds_base, const void* src) {
                : "memory", "m0");
 }
 
-template <int PK>
-__device__ __forceinline__ void tl_consume(const int* blocks, int nblk, int vbase, int mask) {
-  if (PK == 2)
-    asm volatile(TL_ASM_CONSUME_NOFMA
-                 :
-                 : [ptr] "s"(blocks), [nblk] "s"(nblk), [vbase] "v"(vbase), [mask] "v"(mask)
-                 : "memory", "m0", "scc", TL_CLOB_SGPR, TL_CLOB_TMP, TL_CLOB_ACC);
-  else if (PK == 3)
-    asm volatile(TL_ASM_CONSUME_NOLDS
-                 :
-                 : [ptr] "s"(blocks), [nblk] "s"(nblk), [vbase] "v"(vbase), [mask] "v"(mask)
-                 : "memory", "m0", "scc", TL_CLOB_SGPR, TL_CLOB_TMP, TL_CLOB_ACC);
-  else if (PK == 4)
-    asm volatile(TL_ASM_CONSUME_NOSMEM
-                 :
-                 : [ptr] "s"(blocks), [nblk] "s"(nblk), [vbase] "v"(vbase), [mask] "v"(mask)
-                 : "memory", "m0", "scc", TL_CLOB_SGPR, TL_CLOB_TMP, TL_CLOB_ACC);
-  else if (PK == 5)
-    asm volatile(TL_ASM_CONSUME_PIPE
-                 :
-                 : [ptr] "s"(blocks), [nblk] "s"(nblk), [vbase] "v"(vbase), [mask] "v"(mask)
-                 : "memory", "m0", "scc", TL_CLOB_SGPR, TL_CLOB_TMP, TL_CLOB_ACC);
-  else if (PK == 1)
-    asm volatile(TL_ASM_CONSUME_PK
-                 :
-                 : [ptr] "s"(blocks), [nblk] "s"(nblk), [vbase] "v"(vbase), [mask] "v"(mask)
-                 : "memory", "m0", "scc", TL_CLOB_SGPR, TL_CLOB_TMP, TL_CLOB_ACC);
+// One tile phase of a wave (generated asm): the list loop over `nblk` blocks at `blocks`, reading B rows
+// from the LDS tile at vbase, plus `ndma` LDS-DMA instructions of the next tile (destination m0base,
+// +16 KB each; source = the walking pointer v[22:23], +row_step each).  MODE: 0 full, 1 no fma, 2 no LDS/fma.
+template <int MODE>
+__device__ __forceinline__ void tl_phase(const int* blocks, int nblk, int vbase, int mask, int ndma, unsigned m0base,
+                                         int64_t row_step) {
+#define TL_PHASE_OPERANDS                                                                                        \
+  : [ptr] "s"(blocks), [nblk] "s"(nblk), [vbase] "v"(vbase), [mask] "v"(mask), [ndma] "s"(ndma),                 \
+    [m0base] "s"(m0base), [step] "s"(row_step)                                                                   \
+  : "memory", "m0", "scc", TL_CLOB_SGPR, TL_CLOB_TMP, TL_CLOB_ACC
+  if (MODE == 1)
+    asm volatile(TL_ASM_PHASE_NOFMA : TL_PHASE_OPERANDS);
+  else if (MODE == 2)
+    asm volatile(TL_ASM_PHASE_NOLDS : TL_PHASE_OPERANDS);
   else
-    asm volatile(TL_ASM_CONSUME
-                 :
-                 : [ptr] "s"(blocks), [nblk] "s"(nblk), [vbase] "v"(vbase), [mask] "v"(mask)
-                 : "memory", "m0", "scc", TL_CLOB_SGPR, TL_CLOB_TMP, TL_CLOB_ACC);
+    asm volatile(TL_ASM_PHASE : TL_PHASE_OPERANDS);
+#undef TL_PHASE_OPERANDS
 }
 
-// DBG (timing ablations only): 1 = no consume, 2 = no tile DMA.  PK: v_pk_fma_f32 instead of 2 v_fma_f32.
-template <int DBG, int PK>
-__global__ void __launch_bounds__(TL_WAVES * 64) __attribute__((amdgpu_num_vgpr(24)))
+// DBG (timing ablations / instrumentation only): 1 = no list loop, 2 = no tile DMA, 4 = no stream touch,
+// 20 = phase timeline.  MODE: see tl_phase.
+template <int DBG, int MODE>
+__global__ void __launch_bounds__(TL_WAVES * 64) __attribute__((amdgpu_num_vgpr(22)))
 spmm_tiled_kernel(int64_t M, int64_t K, int64_t ntiles, const int* __restrict__ stream,
                   const int* __restrict__ blk_off, const float* __restrict__ b, int64_t ldb,
                   float* __restrict__ out, int64_t ldo) {
@@ -148,43 +132,40 @@ spmm_tiled_kernel(int64_t M, int64_t K, int64_t ntiles, const int* __restrict__ 
 
   asm volatile(TL_ASM_ZERO ::: "memory", TL_CLOB_ACC);
 
-  // Tile DMA: every wave issues exactly TL_DMA_PER_TILE instructions per tile, all lanes active — so
-  // vmcnt arithmetic is exact.  Full tiles: per-thread source pointers advanced by one tile per call
-  // (no 64-bit multiplies in the loop).  The last, partial tile (and the dummy re-issues past the end
-  // that keep the per-iteration count fixed): rows past K are clamped to row K-1, which no entry refers to.
+  // Tile DMA.  A tile is 128 B rows x 512 B = 4 instructions per wave (16 lanes x 16 B per row, 32 rows
+  // per instruction per workgroup... i.e. instruction j of wave w covers rows 32j + 2w, 32j + 2w + 1).
+  // Full tiles are issued from inside the phase asm through a per-thread source pointer that walks down
+  // B 32 rows at a time (v[22:23]); the last, partial tile goes through `issue_partial` with rows past K
+  // clamped to row K-1 (no entry refers to them).
   const int64_t nfull = K / TL_KB;
-  const int64_t tile_step_bytes = (int64_t)TL_KB * ldb * 4;
-  const char* src[TL_DMA_PER_TILE];
-#pragma unroll
-  for (int i = 0; i < TL_DMA_PER_TILE; ++i) {
-    const int e = (i * (TL_WAVES * 64) + tid) * 4;
-    src[i] = reinterpret_cast<const char*>(b + (int64_t)(e >> 7) * ldb + (e & 127));
+  const int64_t row_step = 32 * ldb * 4;
+  {
+    const float* p0 = b + (int64_t)(tid >> 5) * ldb + (tid & 31) * 4;
+    asm volatile("v_mov_b32 v22, %0\n\tv_mov_b32 v23, %1" ::"v"((unsigned)((uintptr_t)p0 & 0xffffffffu)),
+                 "v"((unsigned)((uintptr_t)p0 >> 32))
+                 : "v22", "v23");
   }
-  int64_t next_tile = 0;  // issue_tile is called for t = 0, 1, 2, ... in order
-  auto issue_tile = [&]() {
-    const int64_t t = next_tile++;
-    const unsigned buf = (unsigned)(t % TL_NBUF) * TL_TILE;
-    if (t < nfull) {
+  auto issue_partial = [&](int64_t t) {
+    const unsigned buf = (unsigned)(t & 1) * TL_TILE;
 #pragma unroll
-      for (int i = 0; i < TL_DMA_PER_TILE; ++i) {
-        tl_dma16(buf + (unsigned)(i * TL_WAVES + wv) * 1024u, src[i]);
-        src[i] += tile_step_bytes;
-      }
-    } else {
-      const int64_t kb0 = (t < ntiles ? t : ntiles - 1) * TL_KB;
-#pragma unroll
-      for (int i = 0; i < TL_DMA_PER_TILE; ++i) {
-        const int e = (i * (TL_WAVES * 64) + tid) * 4;
-        int64_t r = kb0 + (e >> 7);
-        if (r >= K) r = K - 1;
-        tl_dma16(buf + (unsigned)(i * TL_WAVES + wv) * 1024u, b + r * ldb + (e & 127));
-      }
+    for (int i = 0; i < TL_DMA_PER_TILE; ++i) {
+      const int e = (i * (TL_WAVES * 64) + tid) * 4;
+      int64_t r = t * TL_KB + (e >> 7);
+      if (r >= K) r = K - 1;
+      tl_dma16(buf + (unsigned)(i * TL_WAVES + wv) * 1024u, b + r * ldb + (e & 127));
     }
   };
+  // returns the number of DMA instructions the phase asm should issue for tile t (0 if handled here / absent)
+  auto plan_tile = [&](int64_t t) -> int {
+    if (DBG == 2 || t >= ntiles) return 0;
+    if (t < nfull) return TL_DMA_PER_TILE;
+    issue_partial(t);
+    return 0;
+  };
+  const unsigned m0wave = (unsigned)wv * 1024u;
 
-  if (DBG != 2)
-    for (int t = 0; t < TL_NBUF - 1; ++t) issue_tile();
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((TL_NBUF - 2) * TL_DMA_PER_TILE) : "memory");
+  tl_phase<MODE>(stream, 0, 0, 0, plan_tile(0), m0wave, row_step);  // tile 0
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   // The block stream is read once, by scalar loads: no hardware prefetcher, and every s_waitcnt on the
@@ -192,8 +173,9 @@ spmm_tiled_kernel(int64_t M, int64_t K, int64_t ntiles, const int* __restrict__ 
   // earlier, so its latency must be an L2 hit (~270 cycles), never HBM (~1-2 us: measured 2.25 ms
   // without this).  Two tile phases ahead, the consuming wave touches the 64-byte lines of that list
   // with one vector load (lane i -> line i, result discarded in v61): HBM -> this XCD's L2.
-  // (A further scalar-cache prefetch stage was measured slower: K$ hits still cost ~160 cycles and
-  // the scalar return path is 4 B/clk per CU: tools/micro/smem_lat.hip.)
+  // (A further scalar-cache prefetch stage — dummy s_load_dword of the next list's lines — was measured
+  // 9 % SLOWER: the scalar memory path takes ~20 cycles per 64-byte request and ~5 per dword request per
+  // CU whether it hits or not (tools/micro/smem_lat.hip), so extra requests cost more than the latency they save.)
   auto touch_lines = [&](const void* p, int64_t nlines) {  // always ONE instruction (vmcnt arithmetic)
     const int64_t l = lane < nlines ? lane : 0;
     asm volatile("global_load_dword v61, %0, off" ::"v"(reinterpret_cast<const char*>(p) + l * 64) : "memory", "v61");
@@ -209,30 +191,41 @@ spmm_tiled_kernel(int64_t M, int64_t K, int64_t ntiles, const int* __restrict__ 
   };
   int offreg = load_offsets(0);
   asm volatile("" : "+v"(offreg));
-  auto list_start = [&](int64_t t) -> int64_t {  // needs obase <= t < obase + 64 (or t > ntiles: clamped)
+  auto list_start = [&](int64_t t) -> int {  // needs obase <= t < obase + 64 (or t > ntiles: clamped)
     const int64_t q = t < ntiles ? t : ntiles;
-    return (int64_t)wave_bcast(offreg, (int)(q - obase));
+    return wave_bcast(offreg, (int)(q - obase));
   };
-  int64_t o0 = list_start(0), o1 = list_start(1), o2 = list_start(2);  // starts of lists t, t+1, t+2
-  touch_lines(stream + o0 * (TL_EPB * 2), o2 - o0);
+  int o0 = list_start(0), o1 = list_start(1), o2 = list_start(2);  // first block of lists t, t+1, t+2
+  touch_lines(stream + (int64_t)o0 * (TL_EPB * 2), o2 - o0);
+
+  // DBG == 20: phase timeline (s_memtime) of every wave of one workgroup, kept in the LDS past the tile
+  // buffers and dumped over that workgroup's first output rows (tools/tiled_timeline.py reads it).
+  unsigned* const tl_dbg = reinterpret_cast<unsigned*>(lds + TL_LDS) + (size_t)wv * 80 * 4;
+  auto stamp = [&](int64_t t, int k) {
+    if (DBG == 20 && t < 80) {
+      const unsigned c = (unsigned)__builtin_amdgcn_s_memtime();
+      if (lane == 0) tl_dbg[t * 4 + k] = c;
+    }
+  };
   for (int64_t t = 0; t < ntiles; ++t) {
-    if (DBG != 2) issue_tile();  // tile t + NBUF - 1
-    const int nblk = (int)(o1 - o0);
-    if (nblk > 0 && DBG != 1)
-      tl_consume<PK>(stream + o0 * (TL_EPB * 2), nblk, (int)((unsigned)(t % TL_NBUF) * TL_TILE) + lane * 8,
-                     (int)0xfffffe00);
+    stamp(t, 0);
+    const int ndma = plan_tile(t + 1);
+    stamp(t, 1);
+    tl_phase<MODE>(stream + (int64_t)o0 * (TL_EPB * 2), DBG == 1 ? 0 : o1 - o0, (int)((unsigned)(t & 1) * TL_TILE) + lane * 8,
+                   (int)0xfffffe00, ndma, (unsigned)((t + 1) & 1) * TL_TILE + m0wave, row_step);
+    stamp(t, 2);
     if (t + 3 <= ntiles && t + 3 - obase >= 64) {  // once per 61 tiles (this load does wait for the DMA)
       obase = t + 3;
       offreg = load_offsets(obase);
       asm volatile("" : "+v"(offreg));  // the wait for this load stays inside the branch
     }
-    const int64_t o3 = list_start(t + 3);
-    touch_lines(stream + o2 * (TL_EPB * 2), DBG != 4 ? o3 - o2 : 0);
+    const int o3 = list_start(t + 3);
+    touch_lines(stream + (int64_t)o2 * (TL_EPB * 2), DBG != 4 ? o3 - o2 : 0);
     o0 = o1;
     o1 = o2;
     o2 = o3;
-    // tile t+1 (this wave's share) has landed: everything but the newest NBUF-2 tiles and one touch
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((TL_NBUF - 2) * (TL_DMA_PER_TILE + 1) + 1) : "memory");
+    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // tile t+1 (this wave's share) has landed; the touch may not
+    stamp(t, 3);
     __syncthreads();
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -248,6 +241,12 @@ spmm_tiled_kernel(int64_t M, int64_t K, int64_t ntiles, const int* __restrict__ 
                : [lo] "v"((unsigned)((uintptr_t)obase_p & 0xffffffffu)), [hi] "v"((unsigned)((uintptr_t)obase_p >> 32)),
                  [stride] "s"(stride_bytes), [n] "s"(nvalid)
                : "memory", "scc", "s36", "v60", "v61", TL_CLOB_ACC);
+  if (DBG == 20 && blockIdx.x == gridDim.x / 2) {
+    __syncthreads();
+    unsigned* dst = reinterpret_cast<unsigned*>(out + (int64_t)blockIdx.x * TL_WAVES * TL_RG * ldo);
+    const unsigned* srcd = reinterpret_cast<const unsigned*>(lds + TL_LDS);
+    for (int i = tid; i < TL_WAVES * 80 * 4; i += TL_WAVES * 64) dst[i] = srcd[i];
+  }
 }
 
 static int64_t tl_grid_groups(int64_t M) { return ceil_div(ceil_div(M, (int64_t)TL_RG), (int64_t)TL_WAVES) * TL_WAVES; }
@@ -311,24 +310,20 @@ extern "C" int spamd_spmm_tiled(int64_t M, int64_t K, int64_t N, const int* bloc
   if (M == 0) return 0;
   if (((uintptr_t)b % 16) || (ldb % 4) || ((uintptr_t)out % 8) || (ldo % 2) || ((uintptr_t)blocks % 64))
     return SPAMD_EINVAL;
-  const char* dbg_env = getenv("SPAMD_TILED_DBG");  // timing ablations: 1 = no consume, 2 = no tile DMA, 4 = no stream touch, 8 = two v_fma_f32 instead of v_pk_fma_f32
+  const char* dbg_env = getenv("SPAMD_TILED_DBG");  // timing ablations: 1 = no list loop, 2 = no tile DMA, 4 = no stream touch, 5 = no fma, 6 = no LDS reads/fma, 20 = timeline
   const int dbg = dbg_env ? atoi(dbg_env) : 0;
   auto kern = dbg == 1 ? &spmm_tiled_kernel<1, 0>
             : dbg == 2 ? &spmm_tiled_kernel<2, 0>
             : dbg == 4 ? &spmm_tiled_kernel<4, 0>
-            : dbg == 8 ? &spmm_tiled_kernel<0, 0>
-            : dbg == 9 ? &spmm_tiled_kernel<0, 4>
-            : dbg == 10 ? &spmm_tiled_kernel<2, 4>
-            : dbg == 5 ? &spmm_tiled_kernel<0, 2>
-            : dbg == 6 ? &spmm_tiled_kernel<0, 3>
-            : dbg == 7 ? &spmm_tiled_kernel<2, 3>
-            : dbg == 11 ? &spmm_tiled_kernel<0, 1>
-            : dbg == 12 ? &spmm_tiled_kernel<2, 5> : &spmm_tiled_kernel<0, 5>;
+            : dbg == 5 ? &spmm_tiled_kernel<0, 1>
+            : dbg == 6 ? &spmm_tiled_kernel<0, 2>
+            : dbg == 20 ? &spmm_tiled_kernel<20, 0> : &spmm_tiled_kernel<0, 0>;
+  const int lds_bytes = TL_LDS + (dbg == 20 ? TL_WAVES * 80 * 16 : 0);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     TL_LDS);
+                                     lds_bytes);
   if (e != hipSuccess) return (int)e;
   const int64_t blocks_n = tl_grid_groups(M) / TL_WAVES;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks_n, (unsigned)(N / 128)), dim3(TL_WAVES * 64), TL_LDS, (hipStream_t)stream, M, K,
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks_n, (unsigned)(N / 128)), dim3(TL_WAVES * 64), lds_bytes, (hipStream_t)stream, M, K,
                      ceil_div(K, (int64_t)TL_KB), blocks, blk_off, b, ldb, out, ldo);
   return launch_status();
 }
