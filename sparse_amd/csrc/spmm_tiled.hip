@@ -96,30 +96,35 @@ __device__ __forceinline__ void tl_dma16(unsigned lds_base, const void* src) {
                : "memory", "m0");
 }
 
-// One tile phase of a wave (generated asm): the list loop over `nblk` blocks at `blocks`, reading B rows
-// from the LDS tile at vbase, plus `ndma` LDS-DMA instructions of the next tile (destination m0base,
-// +16 KB each; source = the walking pointer v[22:23], +row_step each).  MODE: 0 full, 1 no fma, 2 no LDS/fma.
+// Tile phases [t0, te) of a wave (generated asm, tools/gen_tiled_asm.py: `phases`): per phase the list loop
+// over the blocks [o(t), o(t+1)) reading B rows from LDS tile t, the wave's share of the LDS-DMA of tile
+// t+1 (if t+1 < nfull), the scalar request for the first blocks of list t+1, the line touch of list t+2,
+// the DMA wait and the barrier.  o(t) = lane (min(t, ntiles) - obase) of `offreg`; o0..o2 = o(t0..t0+2).
+// MODE: 0 full, 1 no fma, 2 no LDS reads / fma (timing ablations).
 template <int MODE>
-__device__ __forceinline__ void tl_phase(const int* blocks, int nblk, int vbase, int mask, int ndma, unsigned m0base,
-                                         int64_t row_step) {
-#define TL_PHASE_OPERANDS                                                                                        \
-  : [ptr] "s"(blocks), [nblk] "s"(nblk), [vbase] "v"(vbase), [mask] "v"(mask), [ndma] "s"(ndma),                 \
-    [m0base] "s"(m0base), [step] "s"(row_step)                                                                   \
+__device__ __forceinline__ void tl_phases(const int* stream, int t0, int te, int o0, int o1, int o2, int offreg, int obase,
+                                          int ntiles, int nfull, int lane, int mask, unsigned m0wave,
+                                          int64_t row_step) {
+  const unsigned blo = (unsigned)((uintptr_t)stream & 0xffffffffu), bhi = (unsigned)((uintptr_t)stream >> 32);
+  const int lane8 = lane * 8;
+#define TL_PHASES_OPERANDS                                                                                        \
+  : [blo] "s"(blo), [bhi] "s"(bhi), [t0] "s"(t0), [te] "s"(te), [o0] "s"(o0), [o1] "s"(o1), [o2] "s"(o2),         \
+    [obase] "s"(obase), [ntiles] "s"(ntiles), [nfull] "s"(nfull), [m0wave] "s"(m0wave), [step] "s"(row_step),      \
+    [lane] "v"(lane), [lane8] "v"(lane8), [mask] "v"(mask), [offreg] "v"(offreg)                                  \
   : "memory", "m0", "scc", TL_CLOB_SGPR, TL_CLOB_TMP, TL_CLOB_ACC
   if (MODE == 1)
-    asm volatile(TL_ASM_PHASE_NOFMA : TL_PHASE_OPERANDS);
+    asm volatile(TL_ASM_PHASES_NOFMA : TL_PHASES_OPERANDS);
   else if (MODE == 2)
-    asm volatile(TL_ASM_PHASE_NOLDS : TL_PHASE_OPERANDS);
+    asm volatile(TL_ASM_PHASES_NOLDS : TL_PHASES_OPERANDS);
   else
-    asm volatile(TL_ASM_PHASE : TL_PHASE_OPERANDS);
-#undef TL_PHASE_OPERANDS
+    asm volatile(TL_ASM_PHASES : TL_PHASES_OPERANDS);
+#undef TL_PHASES_OPERANDS
 }
 
-// DBG (timing ablations / instrumentation only): 1 = no list loop, 2 = no tile DMA, 4 = no stream touch,
-// 20 = phase timeline.  MODE: see tl_phase.
+// DBG (timing ablation): 2 = no tile DMA.  MODE: see tl_phases.
 template <int DBG, int MODE>
 __global__ void __launch_bounds__(TL_WAVES * 64) __attribute__((amdgpu_num_vgpr(22)))
-spmm_tiled_kernel(int64_t M, int64_t K, int64_t ntiles, const int* __restrict__ stream,
+spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, const int* __restrict__ stream,
                   const int* __restrict__ blk_off, const float* __restrict__ b, int64_t ldb,
                   float* __restrict__ out, int64_t ldo) {
   extern __shared__ __attribute__((aligned(16))) char lds[];  // the only LDS object: starts at LDS byte 0
@@ -132,42 +137,43 @@ spmm_tiled_kernel(int64_t M, int64_t K, int64_t ntiles, const int* __restrict__ 
 
   asm volatile(TL_ASM_ZERO ::: "memory", TL_CLOB_ACC);
 
-  // Tile DMA.  A tile is 128 B rows x 512 B = 4 instructions per wave (16 lanes x 16 B per row, 32 rows
-  // per instruction per workgroup... i.e. instruction j of wave w covers rows 32j + 2w, 32j + 2w + 1).
-  // Full tiles are issued from inside the phase asm through a per-thread source pointer that walks down
-  // B 32 rows at a time (v[22:23]); the last, partial tile goes through `issue_partial` with rows past K
-  // clamped to row K-1 (no entry refers to them).
-  const int64_t nfull = K / TL_KB;
+  // Tile DMA.  A tile is 128 B rows x 512 B; a wave issues 4 of its 64 LDS-DMA instructions (1 KB each:
+  // instruction j of wave w carries rows 32j + 2w and 32j + 2w + 1).  Full tiles are issued from inside
+  // the phase asm through a per-thread source pointer that walks down B 32 rows at a time (v[22:23]);
+  // the last, partial tile goes through `issue_partial`, rows past K clamped to row K-1 (no entry
+  // refers to them).
+  const int nfull = DBG == 2 ? 0 : (int)(K / TL_KB);
   const int64_t row_step = 32 * ldb * 4;
+  const unsigned m0wave = (unsigned)wv * 1024u;
   {
     const float* p0 = b + (int64_t)(tid >> 5) * ldb + (tid & 31) * 4;
     asm volatile("v_mov_b32 v22, %0\n\tv_mov_b32 v23, %1" ::"v"((unsigned)((uintptr_t)p0 & 0xffffffffu)),
                  "v"((unsigned)((uintptr_t)p0 >> 32))
                  : "v22", "v23");
   }
-  auto issue_partial = [&](int64_t t) {
+  auto issue_partial = [&](int t) {
     const unsigned buf = (unsigned)(t & 1) * TL_TILE;
 #pragma unroll
     for (int i = 0; i < TL_DMA_PER_TILE; ++i) {
       const int e = (i * (TL_WAVES * 64) + tid) * 4;
-      int64_t r = t * TL_KB + (e >> 7);
+      int64_t r = (int64_t)t * TL_KB + (e >> 7);
       if (r >= K) r = K - 1;
       tl_dma16(buf + (unsigned)(i * TL_WAVES + wv) * 1024u, b + r * ldb + (e & 127));
     }
   };
-  // returns the number of DMA instructions the phase asm should issue for tile t (0 if handled here / absent)
-  auto plan_tile = [&](int64_t t) -> int {
-    if (DBG == 2 || t >= ntiles) return 0;
-    if (t < nfull) return TL_DMA_PER_TILE;
-    issue_partial(t);
-    return 0;
-  };
-  const unsigned m0wave = (unsigned)wv * 1024u;
+  const bool has_partial = DBG != 2 && (int64_t)nfull * TL_KB < K;  // tile `nfull` is the partial one
 
-  tl_phase<MODE>(stream, 0, 0, 0, plan_tile(0), m0wave, row_step);  // tile 0
+  if (nfull > 0)
+    asm volatile(TL_ASM_TILE0 ::[m0wave] "s"(m0wave), [step] "s"(row_step) : "memory", "m0", "scc", "s39", "s89", "v22", "v23");
+  else if (has_partial)
+    issue_partial(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  // List boundaries of this wave: blk_off[g*ntiles + t], t = 0..ntiles.  64 of them at a time live in one
+  // VGPR (lane <-> tile) and are read with v_readlane.  A chunk of phases runs in one asm block; a new
+  // chunk starts where the offsets register must be reloaded (every 61 tiles) and at the phase that
+  // precedes the partial tile.
   // The block stream is read once, by scalar loads: no hardware prefetcher, and every s_waitcnt on the
   // LDS reads (lgkmcnt(0): SMEM returns out of order) also waits for the scalar load issued a round
   // earlier, so its latency must be an L2 hit (~270 cycles), never HBM (~1-2 us: measured 2.25 ms
@@ -176,57 +182,25 @@ spmm_tiled_kernel(int64_t M, int64_t K, int64_t ntiles, const int* __restrict__ 
   // (A further scalar-cache prefetch stage — dummy s_load_dword of the next list's lines — was measured
   // 9 % SLOWER: the scalar memory path takes ~20 cycles per 64-byte request and ~5 per dword request per
   // CU whether it hits or not (tools/micro/smem_lat.hip), so extra requests cost more than the latency they save.)
-  auto touch_lines = [&](const void* p, int64_t nlines) {  // always ONE instruction (vmcnt arithmetic)
-    const int64_t l = lane < nlines ? lane : 0;
-    asm volatile("global_load_dword v61, %0, off" ::"v"(reinterpret_cast<const char*>(p) + l * 64) : "memory", "v61");
-  };
-  // List boundaries of this wave: blk_off[g*ntiles + t], t = 0..ntiles.  64 of them at a time live in one
-  // VGPR (lane <-> tile) and are read with v_readlane: no memory access per tile (a per-tile load would
-  // make the compiler wait vmcnt(0), i.e. for the tile DMA in flight).
-  const int* const myoff = blk_off + g * ntiles;
-  int64_t obase = 0;
-  auto load_offsets = [&](int64_t base) {
-    const int64_t q = base + lane;
-    return myoff[q < ntiles ? q : ntiles];
-  };
-  int offreg = load_offsets(0);
-  asm volatile("" : "+v"(offreg));
-  auto list_start = [&](int64_t t) -> int {  // needs obase <= t < obase + 64 (or t > ntiles: clamped)
-    const int64_t q = t < ntiles ? t : ntiles;
-    return wave_bcast(offreg, (int)(q - obase));
-  };
-  int o0 = list_start(0), o1 = list_start(1), o2 = list_start(2);  // first block of lists t, t+1, t+2
-  touch_lines(stream + (int64_t)o0 * (TL_EPB * 2), o2 - o0);
-
-  // DBG == 20: phase timeline (s_memtime) of every wave of one workgroup, kept in the LDS past the tile
-  // buffers and dumped over that workgroup's first output rows (tools/tiled_timeline.py reads it).
-  unsigned* const tl_dbg = reinterpret_cast<unsigned*>(lds + TL_LDS) + (size_t)wv * 80 * 4;
-  auto stamp = [&](int64_t t, int k) {
-    if (DBG == 20 && t < 80) {
-      const unsigned c = (unsigned)__builtin_amdgcn_s_memtime();
-      if (lane == 0) tl_dbg[t * 4 + k] = c;
+  const int* const myoff = blk_off + g * (int64_t)ntiles;
+  int t = 0;
+  while (t < ntiles) {
+    const int obase = t;
+    const int q = obase + lane;
+    int offreg = myoff[q < ntiles ? q : ntiles];
+    asm volatile("" : "+v"(offreg));  // (the compiler's wait for this load also drains the DMA: once per chunk)
+    int te = obase + 61 < ntiles ? obase + 61 : ntiles;
+    if (has_partial && t < nfull - 1 && nfull - 1 < te) te = nfull - 1;  // phase nfull-1 must start a chunk
+    if (has_partial && t == nfull - 1) issue_partial(nfull);
+    auto o = [&](int tt) { return wave_bcast(offreg, (tt < ntiles ? tt : ntiles) - obase); };
+    const int o0 = o(t), o1 = o(t + 1), o2 = o(t + 2);
+    if (t == 0) {  // lists 0 and 1 have not been touched by an earlier phase
+      const int n = o2 - o0, l = lane < n ? lane : 0;
+      asm volatile("global_load_dword v61, %0, off" ::"v"(reinterpret_cast<const char*>(stream + (int64_t)o0 * 16) + l * 64)
+                   : "memory", "v61");
     }
-  };
-  for (int64_t t = 0; t < ntiles; ++t) {
-    stamp(t, 0);
-    const int ndma = plan_tile(t + 1);
-    stamp(t, 1);
-    tl_phase<MODE>(stream + (int64_t)o0 * (TL_EPB * 2), DBG == 1 ? 0 : o1 - o0, (int)((unsigned)(t & 1) * TL_TILE) + lane * 8,
-                   (int)0xfffffe00, ndma, (unsigned)((t + 1) & 1) * TL_TILE + m0wave, row_step);
-    stamp(t, 2);
-    if (t + 3 <= ntiles && t + 3 - obase >= 64) {  // once per 61 tiles (this load does wait for the DMA)
-      obase = t + 3;
-      offreg = load_offsets(obase);
-      asm volatile("" : "+v"(offreg));  // the wait for this load stays inside the branch
-    }
-    const int o3 = list_start(t + 3);
-    touch_lines(stream + (int64_t)o2 * (TL_EPB * 2), DBG != 4 ? o3 - o2 : 0);
-    o0 = o1;
-    o1 = o2;
-    o2 = o3;
-    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // tile t+1 (this wave's share) has landed; the touch may not
-    stamp(t, 3);
-    __syncthreads();
+    tl_phases<MODE>(stream, t, te, o0, o1, o2, offreg, obase, ntiles, nfull, lane, (int)0xfffffe00, m0wave, row_step);
+    t = te;
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
@@ -241,12 +215,6 @@ spmm_tiled_kernel(int64_t M, int64_t K, int64_t ntiles, const int* __restrict__ 
                : [lo] "v"((unsigned)((uintptr_t)obase_p & 0xffffffffu)), [hi] "v"((unsigned)((uintptr_t)obase_p >> 32)),
                  [stride] "s"(stride_bytes), [n] "s"(nvalid)
                : "memory", "scc", "s36", "v60", "v61", TL_CLOB_ACC);
-  if (DBG == 20 && blockIdx.x == gridDim.x / 2) {
-    __syncthreads();
-    unsigned* dst = reinterpret_cast<unsigned*>(out + (int64_t)blockIdx.x * TL_WAVES * TL_RG * ldo);
-    const unsigned* srcd = reinterpret_cast<const unsigned*>(lds + TL_LDS);
-    for (int i = tid; i < TL_WAVES * 80 * 4; i += TL_WAVES * 64) dst[i] = srcd[i];
-  }
 }
 
 static int64_t tl_grid_groups(int64_t M) { return ceil_div(ceil_div(M, (int64_t)TL_RG), (int64_t)TL_WAVES) * TL_WAVES; }
@@ -306,24 +274,21 @@ extern "C" int spamd_spmm_tiled_pack(int64_t nnz, const int64_t* tiled_keys_sort
 
 extern "C" int spamd_spmm_tiled(int64_t M, int64_t K, int64_t N, const int* blocks, const int* blk_off,
                                 const float* b, int64_t ldb, float* out, int64_t ldo, void* stream) {
-  if (M < 0 || K <= 0 || N <= 0 || N % 128 != 0 || N / 128 > 65535) return SPAMD_EINVAL;
+  if (M < 0 || K <= 0 || N <= 0 || N % 128 != 0 || N / 128 > 65535 || K / TL_KB >= ((int64_t)1 << 30)) return SPAMD_EINVAL;
   if (M == 0) return 0;
   if (((uintptr_t)b % 16) || (ldb % 4) || ((uintptr_t)out % 8) || (ldo % 2) || ((uintptr_t)blocks % 64))
     return SPAMD_EINVAL;
-  const char* dbg_env = getenv("SPAMD_TILED_DBG");  // timing ablations: 1 = no list loop, 2 = no tile DMA, 4 = no stream touch, 5 = no fma, 6 = no LDS reads/fma, 20 = timeline
+  const char* dbg_env = getenv("SPAMD_TILED_DBG");  // timing ablations: 2 = no tile DMA, 5 = no fma, 6 = no LDS reads/fma
   const int dbg = dbg_env ? atoi(dbg_env) : 0;
-  auto kern = dbg == 1 ? &spmm_tiled_kernel<1, 0>
-            : dbg == 2 ? &spmm_tiled_kernel<2, 0>
-            : dbg == 4 ? &spmm_tiled_kernel<4, 0>
+  auto kern = dbg == 2 ? &spmm_tiled_kernel<2, 0>
             : dbg == 5 ? &spmm_tiled_kernel<0, 1>
-            : dbg == 6 ? &spmm_tiled_kernel<0, 2>
-            : dbg == 20 ? &spmm_tiled_kernel<20, 0> : &spmm_tiled_kernel<0, 0>;
-  const int lds_bytes = TL_LDS + (dbg == 20 ? TL_WAVES * 80 * 16 : 0);
+            : dbg == 6 ? &spmm_tiled_kernel<0, 2> : &spmm_tiled_kernel<0, 0>;
+  const int lds_bytes = TL_LDS;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      lds_bytes);
   if (e != hipSuccess) return (int)e;
   const int64_t blocks_n = tl_grid_groups(M) / TL_WAVES;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks_n, (unsigned)(N / 128)), dim3(TL_WAVES * 64), lds_bytes, (hipStream_t)stream, M, K,
-                     ceil_div(K, (int64_t)TL_KB), blocks, blk_off, b, ldb, out, ldo);
+                     (int)ceil_div(K, (int64_t)TL_KB), blocks, blk_off, b, ldb, out, ldo);
   return launch_status();
 }

@@ -9,10 +9,12 @@ Register map (must match spmm_tiled.hip):
     v22..v23   walking source pointer of the wave's tile-DMA share
     v24..v39   eight ds_read_b64 results, set 1 (software-pipelined loop)
     v40..v43   LDS address temporaries          v44..v59  eight ds_read_b64 results, set 0
-    v60..v61   store address                    v62..v63  junk accumulator (padding entries)
+    v60        LDS base of the current tile + 8*lane    v61  destination of the line touches
+    (v60..v61  store address after the loop)     v62..v63  junk accumulator (padding entries)
     v64..v127  32 rows x (2 columns per lane) partial sums
     s36..s39   stream pointer / block and DMA counters   s40..s87  three 8-entry blocks (16 dwords each)
-    s88..s89   LDS destination of the next tile-DMA instruction
+    s88..s89   temporary / LDS destination of the next tile-DMA instruction
+    s90..s95   tile counter, first blocks of lists t, t+1, t+2, 64-bit temporary
 """
 import os
 
@@ -33,7 +35,7 @@ def p1(buf, dset):
     for i in range(ENTRIES):
         a = ADDR[i % len(ADDR)]
         d = DATASET[dset] + 2 * i
-        o.append(f"v_and_or_b32 v{a}, s{buf + 2 * i}, %[mask], %[vbase]")
+        o.append(f"v_and_or_b32 v{a}, s{buf + 2 * i}, %[mask], v60")
         o.append(f"ds_read_b64 v[{d}:{d + 1}], v{a}")
     return o
 
@@ -64,31 +66,18 @@ def dma_hook(site):
             f"{60 + site}:"]
 
 
-def consume_pipelined(lds=True, fma=True):
-    """One tile phase of a wave.  Software-pipelined list loop: while block r is multiplied (P2), the B rows
+def list_loop(lds=True, fma=True):
+    """The list loop of one tile phase.  Software-pipelined: while block r is multiplied (P2), the B rows
     of block r+1 are already being read from LDS (P1) and block r+3 is being fetched by a scalar load.
-    s38 = blocks left (including the one whose P2 is next); unrolled x6 = lcm(3 SGPR buffers, 2 VGPR data
-    sets).  The wave's share of the NEXT tile's LDS-DMA (s39 instructions) is spread over the rounds (one
-    at the start, one after each round, the rest at the end) instead of being issued in one burst that
-    would stall all 16 waves on the 64 B/clk address path."""
+    Entry: s[36:37] = list pointer, s38 = blocks in the list (> 0), the first min(3, s38) blocks are in
+    (or on their way into) the SGPR ring.  Unrolled x6 = lcm(3 SGPR buffers, 2 VGPR data sets).  The wave's
+    share of the NEXT tile's LDS-DMA (s39 instructions) is spread over the rounds (one at the start, one
+    after each round; the caller issues the rest) instead of one burst that would stall all 16 waves on
+    the 64 B/clk address path."""
     A, B, C = RING
     P1 = p1 if lds else (lambda buf, dset: [])
     P2 = p2 if fma else (lambda buf, dset: [])
-    o = ["s_mov_b64 s[36:37], %[ptr]",
-         "s_mov_b32 s38, %[nblk]",
-         "s_mov_b32 s39, %[ndma]",
-         "s_mov_b32 s89, %[m0base]",
-         "s_cmp_eq_u32 s38, 0",
-         "s_cbranch_scc1 12f",
-         f"s_load_dwordx16 s[{A}:{A + 15}], s[36:37], 0x0",
-         "s_cmp_lt_u32 s38, 2",
-         "s_cbranch_scc1 10f",
-         f"s_load_dwordx16 s[{B}:{B + 15}], s[36:37], 0x40",
-         "s_cmp_lt_u32 s38, 3",
-         "s_cbranch_scc1 10f",
-         f"s_load_dwordx16 s[{C}:{C + 15}], s[36:37], 0x80",
-         "10:"]
-    o += dma_hook(0)
+    o = dma_hook(0)
     o += ["s_waitcnt lgkmcnt(0)"]
     o += P1(A, 0)
     o += ["s_waitcnt lgkmcnt(0)", "11:"]
@@ -109,10 +98,72 @@ def consume_pipelined(lds=True, fma=True):
         o += ["s_waitcnt lgkmcnt(0)"]
         o += dma_hook(2 + 2 * k)
         o += ["s_sub_u32 s38, s38, 1", "s_cmp_eq_u32 s38, 0", "s_cbranch_scc1 12f", f"4{k}:"]
-    o += ["s_add_u32 s36, s36, 0x180", "s_addc_u32 s37, s37, 0", "s_branch 11b", "12:"]
-    # whatever is left of the DMA share (short or empty lists)
-    o += ["13:"] + dma_hook(13)[:-1] + ["s_branch 13b", "73:"]
+    o += ["s_add_u32 s36, s36, 0x180", "s_addc_u32 s37, s37, 0", "s_branch 11b"]
     return o
+
+
+def list_pointer(first_block_sgpr):
+    """s[36:37] = stream base + 64 * first block"""
+    return [f"s_mov_b32 s94, s{first_block_sgpr}", "s_mov_b32 s95, 0", "s_lshl_b64 s[94:95], s[94:95], 6",
+            "s_add_u32 s36, s94, %[blo]", "s_addc_u32 s37, s95, %[bhi]"]
+
+
+def request_first_blocks(lo, hi, tag):
+    """scalar loads of the first min(3, s{hi} - s{lo}) blocks of a list into ring buffers A, B, C (no wait)"""
+    A, B, C = RING
+    return list_pointer(lo) + [
+        f"s_sub_u32 s88, s{hi}, s{lo}",
+        "s_cmp_eq_u32 s88, 0", f"s_cbranch_scc1 {tag}f",
+        f"s_load_dwordx16 s[{A}:{A + 15}], s[36:37], 0x0",
+        "s_cmp_lt_u32 s88, 2", f"s_cbranch_scc1 {tag}f",
+        f"s_load_dwordx16 s[{B}:{B + 15}], s[36:37], 0x40",
+        "s_cmp_lt_u32 s88, 3", f"s_cbranch_scc1 {tag}f",
+        f"s_load_dwordx16 s[{C}:{C + 15}], s[36:37], 0x80",
+        f"{tag}:"]
+
+
+def phases(lds=True, fma=True):
+    """Tile phases t0 .. te-1 of one wave in ONE asm block, so that SGPR state survives the barrier:
+    the first blocks of list t+1 are requested BEFORE the barrier that ends phase t (the scalar path serves
+    one 64-byte request per ~20 cycles per CU; 16 waves x 3 requests right after a barrier idle the CU for
+    ~1000 cycles).  s90 = t, s91/s92/s93 = first block of lists t, t+1, t+2."""
+    o = ["s_mov_b32 s90, %[t0]", "s_mov_b32 s91, %[o0]", "s_mov_b32 s92, %[o1]", "s_mov_b32 s93, %[o2]"]
+    o += request_first_blocks(91, 92, 20)
+    o += ["1:"]
+    o += list_pointer(91)
+    o += ["s_sub_u32 s38, s92, s91",                       # blocks in this list
+          "s_add_u32 s88, s90, 1",                         # next tile: DMA share and LDS destination
+          "s_cmp_lt_u32 s88, %[nfull]", "s_cselect_b32 s39, 4, 0",
+          "s_and_b32 s88, s88, 1", "s_lshl_b32 s88, s88, 16", "s_add_u32 s89, s88, %[m0wave]",
+          "s_and_b32 s88, s90, 1", "s_lshl_b32 s88, s88, 16", "v_or_b32 v60, s88, %[lane8]",  # this tile's LDS base
+          "s_cmp_eq_u32 s38, 0", "s_cbranch_scc1 12f"]
+    o += list_loop(lds, fma)
+    o += ["12:", "13:"] + dma_hook(13)[:-1] + ["s_branch 13b", "73:"]   # the rest of the DMA share
+    # first blocks of the next list (not at the end of the chunk: the ring must be idle when the asm ends)
+    o += ["s_add_u32 s88, s90, 1", "s_cmp_lt_u32 s88, %[te]", "s_cbranch_scc0 21f"]
+    o += request_first_blocks(92, 93, 21)
+    # o3 = first block of list t+3 (lane min(t+3, ntiles) - obase of the offsets register)
+    o += ["s_add_u32 s88, s90, 3", "s_min_u32 s88, s88, %[ntiles]", "s_sub_u32 s88, s88, %[obase]", "s_nop 3",
+          "v_readlane_b32 s88, %[offreg], s88", "s_nop 3"]
+    # touch the lines of list t+2 = blocks [s93, s88): lane i -> line min(i, n-1)  (always ONE instruction)
+    o += ["s_sub_i32 s94, s88, s93", "s_sub_i32 s94, s94, 1", "s_max_i32 s94, s94, 0",
+          "v_min_u32 v42, s94, %[lane]", "v_lshlrev_b32 v42, 6, v42", "v_mov_b32 v43, 0",
+          "s_mov_b32 s94, s93", "s_mov_b32 s95, 0", "s_lshl_b64 s[94:95], s[94:95], 6",
+          "s_add_u32 s94, s94, %[blo]", "s_addc_u32 s95, s95, %[bhi]",
+          "v_lshl_add_u64 v[40:41], s[94:95], 0, v[42:43]",
+          "global_load_dword v61, v[40:41], off"]
+    o += ["s_mov_b32 s91, s92", "s_mov_b32 s92, s93", "s_mov_b32 s93, s88",
+          "s_waitcnt vmcnt(1)",      # tile t+1 (this wave's share) has landed; the touch may still fly
+          "s_barrier",
+          "s_add_u32 s90, s90, 1", "s_cmp_lt_u32 s90, %[te]", "s_cbranch_scc1 1b",
+          "s_waitcnt lgkmcnt(0)"]
+    return o
+
+
+def tile0():
+    """the wave's four DMA instructions of tile 0 (buffer 0), advancing the walking pointer"""
+    o = ["s_mov_b32 s89, %[m0wave]", "s_mov_b32 s39, 4"]
+    return o + ["13:"] + dma_hook(13)[:-1] + ["s_branch 13b", "73:"]
 
 
 def store():
@@ -141,12 +192,13 @@ def clob(prefix, lo, hi):
 
 def main():
     out = ["// GENERATED by tools/gen_tiled_asm.py - do not edit.\n",
-           lit("TL_ASM_PHASE", consume_pipelined()),
-           lit("TL_ASM_PHASE_NOFMA", consume_pipelined(True, False)),
-           lit("TL_ASM_PHASE_NOLDS", consume_pipelined(False, False)),
+           lit("TL_ASM_PHASES", phases()),
+           lit("TL_ASM_PHASES_NOFMA", phases(True, False)),
+           lit("TL_ASM_PHASES_NOLDS", phases(False, False)),
+           lit("TL_ASM_TILE0", tile0()),
            lit("TL_ASM_STORE", store()),
            lit("TL_ASM_ZERO", zero()),
-           f"#define TL_CLOB_SGPR {clob('s', 36, 89)}\n",
+           f"#define TL_CLOB_SGPR {clob('s', 36, 95)}\n",
            f"#define TL_CLOB_TMP {clob('v', 22, 61)}\n",
            f"#define TL_CLOB_ACC {clob('v', 62, 127)}\n"]
     p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "sparse_amd", "csrc", "spmm_tiled_asm.inc")
