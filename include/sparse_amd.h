@@ -91,7 +91,17 @@ int spamd_spmm_csr(int val_dtype, int idx_dtype, int64_t M, int64_t K, int64_t N
  *   Results are bit-identical to spamd_spmm_csr without SPAMD_EXACT_MULADD (sorted column indices).
  * ------------------------------------------------------------------------------------- */
 int spamd_spmm_tiled_params(int* rows_per_group, int* tile_rows, int* groups_per_block, int* entries_per_block,
-                            int* slack_blocks);
+                            int* slack_blocks, int* direct_max_tiles);
+/* Direct (sort-free) inspector for CSR with sorted column indices and ceil(K/KB) <= direct_max_tiles: the tiled
+ * order is a stable partition by tile of every RG-row group of the CSR order.
+ *   spamd_spmm_tiled_count: nblk[nseg+1] (blocks per list, ready for spamd_exclusive_scan), flags[0] = 1 if a row's
+ *                           column indices are not ascending (then use the key-sort recipe above);
+ *   spamd_spmm_tiled_fill:  writes the block stream from (a_data fp32, a_indices, a_indptr) and blk_off. */
+int spamd_spmm_tiled_count(int idx_dtype, int64_t M, int64_t K, const void* a_indices, const void* a_indptr,
+                           int64_t* nblk, int* flags, void* stream);
+int spamd_spmm_tiled_fill(int idx_dtype, int64_t M, int64_t K, const float* a_data, const void* a_indices,
+                          const void* a_indptr, const int64_t* blk_off, int64_t total_blocks, int* blocks,
+                          void* stream);
 int spamd_spmm_tiled_keys(int64_t nnz, const int64_t* rowcol_keys, int64_t K, int64_t* tiled_keys, void* stream);
 int spamd_spmm_tiled_lists(int64_t nnz, const int64_t* tiled_keys_sorted, int64_t M, int64_t K, int64_t* seg_start,
                            int64_t* nblk, void* stream);

@@ -547,37 +547,57 @@ def sddmm_coo(coords, s_data, a, bt):
 # inspector/executor SpMM (csrc/spmm_tiled.hip)
 # ---------------------------------------------------------------------------------------------
 def tiled_params():
-    """(rows per group, B rows per tile, groups per workgroup, entries per block, slack blocks)."""
-    v = [_ct.c_int(0) for _ in range(5)]
+    """(rows per group, B rows per tile, groups per workgroup, entries per block, slack blocks, max tiles of the
+    direct inspector)."""
+    v = [_ct.c_int(0) for _ in range(6)]
     _ffi.call("spamd_spmm_tiled_params", *[_ct.byref(x) for x in v])
     return tuple(x.value for x in v)
 
 
-def csr_tiled_layout(a_data, a_indices, a_indptr, M, Kd):
+def csr_tiled_layout(a_data, a_indices, a_indptr, M, Kd, force_sort=False):
     """Inspector: the K-tiled block stream of a CSR matrix used by `dot_csr_ndarray_tiled` (fp32).
-    Returns (blocks int32[(total_blocks + slack) * 16], blk_off int32[nseg + 1])."""
+    Returns (blocks int32[(total_blocks + slack) * 16], blk_off int32[nseg + 1]).
+    Sorted column indices and a moderate K take the direct two-pass builder (count, scan, fill); anything
+    else the general key-sort recipe."""
     dev = require_hip(a_data, a_indices, a_indptr)
-    rg, kb, gpb, epb, slack = tiled_params()
+    rg, kb, gpb, epb, slack, direct_max = tiled_params()
     nnz = int(a_data.numel())
     ntiles = -(-Kd // kb)
     groups = -(-(-(-M // rg)) // gpb) * gpb
     nseg = groups * ntiles
     s = stream_ptr(dev)
+    vals = a_data.to(torch.float32).contiguous()
+    if not index_dtype_ok(a_indices) or a_indices.dtype != a_indptr.dtype:
+        a_indices, a_indptr = a_indices.to(torch.int64), a_indptr.to(torch.int64)
+
+    def finish(blk_off, fill):
+        total = int(blk_off[-1])
+        if total >= 2 ** 31:
+            raise ValueError("tiled SpMM layout: more than 2^31 blocks")
+        blocks = torch.empty((total + slack) * epb * 2, dtype=torch.int32, device=dev)
+        fill(blk_off, total, blocks)
+        return blocks, convert(blk_off, torch.int32)
+
+    if ntiles <= direct_max and not force_sort:
+        nblk = torch.empty(nseg + 1, dtype=torch.int64, device=dev)
+        flags = torch.empty(1, dtype=torch.int32, device=dev)
+        ic = code_of(a_indices.dtype)
+        ind, ptr_ = a_indices.contiguous(), a_indptr.contiguous()
+        _ffi.call("spamd_spmm_tiled_count", ic, M, Kd, ptr(ind), ptr(ptr_), ptr(nblk), ptr(flags), s)
+        blk_off = exclusive_scan(nblk)
+        if int(flags[0]) == 0:
+            return finish(blk_off, lambda bo, total, blocks: _ffi.call(
+                "spamd_spmm_tiled_fill", ic, M, Kd, ptr(vals), ptr(ind), ptr(ptr_), ptr(bo), total, ptr(blocks), s))
     rc = csr_to_keys(a_indptr, a_indices, M, Kd)
     tk = torch.empty_like(rc)
     _ffi.call("spamd_spmm_tiled_keys", nnz, ptr(rc), Kd, ptr(tk), s)
     del rc
-    tk, vals = sort_key_value(tk, a_data.to(torch.float32).contiguous(), max(nseg * rg * kb - 1, 1))
+    tk, vals = sort_key_value(tk, vals, max(nseg * rg * kb - 1, 1))
     seg_start = torch.empty(nseg + 1, dtype=torch.int64, device=dev)
     nblk = torch.empty(nseg + 1, dtype=torch.int64, device=dev)
     _ffi.call("spamd_spmm_tiled_lists", nnz, ptr(tk), M, Kd, ptr(seg_start), ptr(nblk), s)
-    blk_off = exclusive_scan(nblk)
-    total = int(blk_off[-1])
-    blocks = torch.empty((total + slack) * epb * 2, dtype=torch.int32, device=dev)
-    if total >= 2 ** 31:
-        raise ValueError("tiled SpMM layout: more than 2^31 blocks")
-    _ffi.call("spamd_spmm_tiled_pack", nnz, ptr(tk), ptr(vals), ptr(seg_start), ptr(blk_off), total, ptr(blocks), s)
-    return blocks, convert(blk_off, torch.int32)
+    return finish(exclusive_scan(nblk), lambda bo, total, blocks: _ffi.call(
+        "spamd_spmm_tiled_pack", nnz, ptr(tk), ptr(vals), ptr(seg_start), ptr(bo), total, ptr(blocks), s))
 
 
 def dot_csr_ndarray_tiled(layout, out_shape, Kd, b, out=None):

@@ -7,6 +7,7 @@ WARN_ON_TOO_DENSE = bool(int(os.environ.get("SPARSE_WARN_ON_TOO_DENSE", "0")))
 # hip-backend extras
 NAN_CHECK = bool(int(os.environ.get("SPARSE_AMD_NAN_CHECK", "1")))  # matmul's NaN RuntimeWarning pass
 EXACT_MULADD = bool(int(os.environ.get("SPARSE_AMD_EXACT", "0")))  # bit-exact mul+add instead of FMA
-# CSR x dense products: "auto" builds the K-tiled block stream of a matrix (csrc/spmm_tiled.hip) on its
-# SECOND eligible product and caches it on the array; "always" on the first; "never" keeps the row-group kernel
+# CSR x dense products: "auto" builds the K-tiled block stream of a matrix (csrc/spmm_tiled.hip) at its first
+# eligible product (fp32, N % 128 == 0, FMA mode, large enough) and caches it on the array; "never" keeps the
+# row-group kernel
 TILED_SPMM = os.environ.get("SPARSE_AMD_TILED_SPMM", "auto")

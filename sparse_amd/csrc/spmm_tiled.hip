@@ -89,6 +89,91 @@ __global__ void __launch_bounds__(256) tl_pack_kernel(const int64_t* __restrict_
   }
 }
 
+// ---- direct inspector: CSR with sorted column indices, at most TL_DIRECT_MAX_TILES tiles ------------------
+// The tiled order (g, t, row, column) is a STABLE PARTITION BY TILE of each 32-row group of the CSR order,
+// so no sort is needed: one workgroup per group counts (row, tile) runs in LDS, and an element's slot is
+//   8 * blk_off[g, t] + (elements of tile t in earlier rows of the group) + (position inside its row's run).
+// Two passes over A (count, fill) = ~2 GB of traffic at config 2 instead of a 64-bit radix sort of 10^8 pairs.
+constexpr int TL_DIRECT_MAX_TILES = 256;  // LDS: 2 * 32 * tiles * 4 B (+ tiles * 4) <= 66 KB
+
+template <typename I>
+__device__ __forceinline__ int tl_row_of(const int64_t* rs, int64_t e) {  // largest lr in [0, 32) with rs[lr] <= e
+  int lo = 0;
+#pragma unroll
+  for (int step = 16; step >= 1; step >>= 1)
+    if (rs[lo + step] <= e) lo += step;
+  return lo;
+}
+
+template <typename I>
+__global__ void __launch_bounds__(256) tl_count_kernel(int64_t M, int ntiles, const I* __restrict__ indices,
+                                                       const I* __restrict__ indptr, int64_t* __restrict__ nblk,
+                                                       int* __restrict__ flags) {
+  __shared__ int cnt[TL_DIRECT_MAX_TILES];
+  __shared__ int64_t rs[TL_RG + 1];
+  const int tid = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * TL_RG;
+  if (tid <= TL_RG) {
+    const int64_t r = r0 + tid;
+    rs[tid] = (int64_t)indptr[r < M ? r : M];
+  }
+  for (int t = tid; t < ntiles; t += 256) cnt[t] = 0;
+  __syncthreads();
+  const int64_t e0 = rs[0], e1 = rs[TL_RG];
+  bool bad = false;
+  for (int64_t e = e0 + tid; e < e1; e += 256) {
+    const int64_t c = (int64_t)indices[e];
+    atomicAdd(&cnt[(int)(c / TL_KB)], 1);
+    if (e > e0 && (int64_t)indices[e - 1] > c && rs[tl_row_of<I>(rs, e)] != e) bad = true;  // not a row start
+  }
+  if (bad) flags[0] = 1;
+  __syncthreads();
+  for (int t = tid; t < ntiles; t += 256) nblk[(int64_t)blockIdx.x * ntiles + t] = (cnt[t] + TL_EPB - 1) / TL_EPB;
+}
+
+template <typename I>
+__global__ void __launch_bounds__(256) tl_fill_kernel(int64_t M, int ntiles, const float* __restrict__ vals,
+                                                      const I* __restrict__ indices, const I* __restrict__ indptr,
+                                                      const int64_t* __restrict__ blk_off, int2* __restrict__ stream) {
+  extern __shared__ int tl_fill_lds[];  // before[32][ntiles], runstart[32][ntiles] (relative to e0), slot0[ntiles]
+  __shared__ int64_t rs[TL_RG + 1];
+  int* const before = tl_fill_lds;
+  int* const runstart = before + TL_RG * ntiles;
+  const int tid = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * TL_RG;
+  if (tid <= TL_RG) {
+    const int64_t r = r0 + tid;
+    rs[tid] = (int64_t)indptr[r < M ? r : M];
+  }
+  for (int i = tid; i < TL_RG * ntiles; i += 256) before[i] = 0;
+  __syncthreads();
+  const int64_t e0 = rs[0], e1 = rs[TL_RG];
+  for (int64_t e = e0 + tid; e < e1; e += 256) {
+    const int t = (int)((int64_t)indices[e] / TL_KB);
+    const int lr = tl_row_of<I>(rs, e);
+    atomicAdd(&before[lr * ntiles + t], 1);
+    if (e == rs[lr] || (int)((int64_t)indices[e - 1] / TL_KB) != t) runstart[lr * ntiles + t] = (int)(e - e0);
+  }
+  __syncthreads();
+  for (int t = tid; t < ntiles; t += 256) {  // counts -> number of tile-t elements in earlier rows of the group
+    int run = 0;
+    for (int lr = 0; lr < TL_RG; ++lr) {
+      const int c = before[lr * ntiles + t];
+      before[lr * ntiles + t] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  const int64_t* const goff = blk_off + (int64_t)blockIdx.x * ntiles;
+  for (int64_t e = e0 + tid; e < e1; e += 256) {
+    const int64_t c = (int64_t)indices[e];
+    const int t = (int)(c / TL_KB), lc = (int)(c - (int64_t)t * TL_KB);
+    const int lr = tl_row_of<I>(rs, e);
+    const int64_t dst = goff[t] * TL_EPB + before[lr * ntiles + t] + ((int)(e - e0) - runstart[lr * ntiles + t]);
+    stream[dst] = make_int2((lc << 9) | (2 + 2 * lr), __builtin_bit_cast(int, vals[e]));
+  }
+}
+
 __device__ __forceinline__ void tl_dma16(unsigned lds_base, const void* src) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
                :
@@ -224,7 +309,8 @@ static int64_t tl_grid_groups(int64_t M) { return ceil_div(ceil_div(M, (int64_t)
 using namespace spamd;
 
 extern "C" int spamd_spmm_tiled_params(int* rows_per_group, int* tile_rows, int* groups_per_block,
-                                       int* entries_per_block, int* slack_blocks) {
+                                       int* entries_per_block, int* slack_blocks, int* direct_max_tiles) {
+  if (direct_max_tiles) *direct_max_tiles = TL_DIRECT_MAX_TILES;
   if (rows_per_group) *rows_per_group = TL_RG;
   if (tile_rows) *tile_rows = TL_KB;
   if (groups_per_block) *groups_per_block = TL_WAVES;
@@ -272,6 +358,46 @@ extern "C" int spamd_spmm_tiled_pack(int64_t nnz, const int64_t* tiled_keys_sort
   return launch_status();
 }
 
+extern "C" int spamd_spmm_tiled_count(int idx_dtype, int64_t M, int64_t K, const void* a_indices, const void* a_indptr,
+                                      int64_t* nblk, int* flags, void* stream) {
+  if (M < 0 || K <= 0) return SPAMD_EINVAL;
+  const int64_t ntiles = ceil_div(K, (int64_t)TL_KB);
+  if (ntiles > TL_DIRECT_MAX_TILES) return SPAMD_EINVAL;
+  const int64_t groups = tl_grid_groups(M);
+  hipError_t e = hipMemsetAsync(flags, 0, sizeof(int), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(nblk + groups * ntiles, 0, sizeof(int64_t), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  if (groups == 0) return 0;
+  SPAMD_DISPATCH_IDX(idx_dtype, I, hipLaunchKernelGGL(tl_count_kernel<I>, dim3((unsigned)groups), dim3(256), 0,
+                                                    (hipStream_t)stream, M, (int)ntiles, (const I*)a_indices,
+                                                    (const I*)a_indptr, nblk, flags))
+  return launch_status();
+}
+
+extern "C" int spamd_spmm_tiled_fill(int idx_dtype, int64_t M, int64_t K, const float* a_data, const void* a_indices,
+                                     const void* a_indptr, const int64_t* blk_off, int64_t total_blocks, int* blocks,
+                                     void* stream) {
+  if (M < 0 || K <= 0 || total_blocks < 0) return SPAMD_EINVAL;
+  const int64_t ntiles = ceil_div(K, (int64_t)TL_KB);
+  if (ntiles > TL_DIRECT_MAX_TILES) return SPAMD_EINVAL;
+  hipError_t e = hipMemsetAsync(blocks, 0, (size_t)(total_blocks + TL_SLACK_BLOCKS) * TL_EPB * 8, (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  const int64_t groups = tl_grid_groups(M);
+  if (groups == 0) return 0;
+  const int lds = (int)(2 * TL_RG * ntiles * sizeof(int));
+  SPAMD_DISPATCH_IDX(idx_dtype, I, {
+    auto kern = &tl_fill_kernel<I>;
+    if (lds > 48 * 1024) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(256), lds, (hipStream_t)stream, M, (int)ntiles, a_data,
+                       (const I*)a_indices, (const I*)a_indptr, blk_off, reinterpret_cast<int2*>(blocks));
+  })
+  return launch_status();
+}
+
 extern "C" int spamd_spmm_tiled(int64_t M, int64_t K, int64_t N, const int* blocks, const int* blk_off,
                                 const float* b, int64_t ldb, float* out, int64_t ldo, void* stream) {
   if (M < 0 || K <= 0 || N <= 0 || N % 128 != 0 || N / 128 > 65535 || K / TL_KB >= ((int64_t)1 << 30)) return SPAMD_EINVAL;
@@ -282,7 +408,8 @@ extern "C" int spamd_spmm_tiled(int64_t M, int64_t K, int64_t N, const int* bloc
   const int dbg = dbg_env ? atoi(dbg_env) : 0;
   auto kern = dbg == 2 ? &spmm_tiled_kernel<2, 0>
             : dbg == 5 ? &spmm_tiled_kernel<0, 1>
-            : dbg == 6 ? &spmm_tiled_kernel<0, 2> : &spmm_tiled_kernel<0, 0>;
+            : dbg == 6 ? &spmm_tiled_kernel<0, 2>
+            : dbg == 7 ? &spmm_tiled_kernel<2, 2> : &spmm_tiled_kernel<0, 0>;
   const int lds_bytes = TL_LDS;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      lds_bytes);

@@ -38,7 +38,7 @@ def test_tiled_bit_identical_to_rowgroup_fma(orc, idt, M, K, density):
     want = orc.dot_csr_ndarray((M, 128), data, idx, ptr, b)
     assert np.allclose(got.cpu().numpy(), want, rtol=2e-5, atol=1e-6)
     blocks, blk_off = layout
-    rg, kb, gpb, epb, slack = Kn_params()
+    rg, kb, gpb, epb, slack, _ = Kn_params()
     assert bool((blk_off[1:] >= blk_off[:-1]).all()) and blocks.numel() == (int(blk_off[-1]) + slack) * epb * 2
     ent = blocks.view(-1, 2)[: int(blk_off[-1]) * epb].cpu().numpy()
     real = ent[ent[:, 0] != 0]                                         # padding entries are all-zero
@@ -63,20 +63,23 @@ def _product_case(M=40000, K=2000, density=0.01, N=128, seed=5):
     return a, torch.from_numpy(b).to(d), (data, idx, ptr, b)
 
 
-def test_product_path_builds_the_block_stream_on_second_use(orc, monkeypatch):
-    """`a @ dense` (reference `_dot` csr x ndarray row, _common.py:339-503): first product = row-group
-    kernel, second builds and caches the tiled layout; both equal the oracle within fp32 FMA tolerance and
-    are bit-identical to each other."""
+def test_product_path_builds_and_caches_the_block_stream(orc, monkeypatch):
+    """`a @ dense` (reference `_dot` csr x ndarray row, _common.py:339-503): the first eligible product builds
+    and caches the tiled layout; "never" keeps the row-group kernel; both equal the oracle within fp32 FMA
+    tolerance and are bit-identical to each other."""
     from sparse_amd import _settings
 
-    monkeypatch.setattr(_settings, "TILED_SPMM", "auto")
     monkeypatch.setattr(_settings, "EXACT_MULADD", False)
     a, b, (data, idx, ptr, bh) = _product_case()
+    monkeypatch.setattr(_settings, "TILED_SPMM", "never")
     r1 = a @ b
     assert getattr(a, "_tiled_layout", None) is None
+    monkeypatch.setattr(_settings, "TILED_SPMM", "auto")
     r2 = a @ b
-    assert getattr(a, "_tiled_layout", None) is not None
+    layout = a._tiled_layout
+    assert layout is not None
     r3 = a @ b
+    assert a._tiled_layout is layout
     assert torch.equal(r1, r2) and torch.equal(r2, r3)
     want = orc.dot_csr_ndarray((a.shape[0], 128), data, idx, ptr, bh)
     assert np.allclose(r3.cpu().numpy(), want, rtol=2e-5, atol=1e-6)
@@ -86,7 +89,7 @@ def test_product_path_builds_the_block_stream_on_second_use(orc, monkeypatch):
 def test_product_path_column_panels(orc, monkeypatch, N):
     from sparse_amd import _settings, _kernels as Kn
 
-    monkeypatch.setattr(_settings, "TILED_SPMM", "always")
+    monkeypatch.setattr(_settings, "TILED_SPMM", "auto")
     monkeypatch.setattr(_settings, "EXACT_MULADD", False)
     a, b, (data, idx, ptr, bh) = _product_case(N=N, seed=8)
     got = a @ b
@@ -102,7 +105,7 @@ def test_product_path_csc_operand_uses_the_csr_twin(orc, monkeypatch):
     import sparse_amd as sp
     from sparse_amd import _settings
 
-    monkeypatch.setattr(_settings, "TILED_SPMM", "always")
+    monkeypatch.setattr(_settings, "TILED_SPMM", "auto")
     monkeypatch.setattr(_settings, "EXACT_MULADD", False)
     a, b, (data, idx, ptr, bh) = _product_case(seed=11)
     acsc = a.change_compressed_axes((1,))
@@ -115,7 +118,7 @@ def test_product_path_csc_operand_uses_the_csr_twin(orc, monkeypatch):
 def test_exact_mode_and_ineligible_shapes_keep_the_rowgroup_kernel(monkeypatch):
     from sparse_amd import _settings
 
-    monkeypatch.setattr(_settings, "TILED_SPMM", "always")
+    monkeypatch.setattr(_settings, "TILED_SPMM", "auto")
     monkeypatch.setattr(_settings, "EXACT_MULADD", True)
     a, b, _ = _product_case(seed=12)
     a @ b
@@ -124,3 +127,35 @@ def test_exact_mode_and_ineligible_shapes_keep_the_rowgroup_kernel(monkeypatch):
     a2, b2, _ = _product_case(N=64, seed=13)
     a2 @ b2
     assert getattr(a2, "_tiled_layout", None) is None
+
+
+@pytest.mark.parametrize("idt", [np.int32, np.int64])
+@pytest.mark.parametrize("M,K,density", [(300, 200, 0.05), (5000, 10000, 0.01), (4097, 129, 0.1), (33, 32768, 0.002)])
+def test_direct_inspector_equals_the_key_sort_recipe(idt, M, K, density):
+    """Both inspectors must produce the same block stream bit for bit (same stable order, same padding)."""
+    from sparse_amd import _kernels as Kn
+
+    data, idx, ptr = random_csr(M, K, density, 21, np.float32, idt, empty_rows=(0, 7), long_row=3)
+    d = torch.device("cuda")
+    td, ti, tp = (torch.from_numpy(x).to(d) for x in (data, idx, ptr))
+    b1, o1 = Kn.csr_tiled_layout(td, ti, tp, M, K)
+    b2, o2 = Kn.csr_tiled_layout(td, ti, tp, M, K, force_sort=True)
+    assert torch.equal(o1, o2) and torch.equal(b1, b2)
+
+
+def test_unsorted_rows_fall_back_to_the_key_sort_recipe(orc):
+    from sparse_amd import _kernels as Kn
+
+    M, K = 500, 700
+    data, idx, ptr = random_csr(M, K, 0.05, 22, np.float32, np.int32)
+    idx = idx.copy(); data = data.copy()
+    for r in range(M):  # reverse every row: same matrix, descending column order
+        idx[ptr[r]:ptr[r + 1]] = idx[ptr[r]:ptr[r + 1]][::-1]
+        data[ptr[r]:ptr[r + 1]] = data[ptr[r]:ptr[r + 1]][::-1]
+    b = random_dense(K, 128, 23, np.float32)
+    d = torch.device("cuda")
+    td, ti, tp, tb = (torch.from_numpy(x).to(d) for x in (data, idx, ptr, b))
+    layout = Kn.csr_tiled_layout(td, ti, tp, M, K)
+    got = Kn.dot_csr_ndarray_tiled(layout, (M, 128), K, tb)
+    want = orc.dot_csr_ndarray((M, 128), data, idx, ptr, b)
+    assert np.allclose(got.cpu().numpy(), want, rtol=2e-5, atol=1e-6)
