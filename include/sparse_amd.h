@@ -88,7 +88,8 @@ int spamd_spmm_csr(int val_dtype, int idx_dtype, int64_t M, int64_t K, int64_t N
  *   its blocks with scalar loads and keeps 32 rows of partial sums in a fixed VGPR block addressed
  *   with s_set_gpr_idx.  RG / KB / GPB / entries per block / slack from spamd_spmm_tiled_params;
  *   `blocks` must hold total_blocks + slack blocks and be 64-byte aligned.
- *   Results are bit-identical to spamd_spmm_csr without SPAMD_EXACT_MULADD (sorted column indices).
+ *   flags: SPAMD_EXACT_MULADD as for spamd_spmm_csr.  Results are bit-identical to spamd_spmm_csr with the
+ *   same flags (sorted column indices), hence to the reference loop under SPAMD_EXACT_MULADD.
  * ------------------------------------------------------------------------------------- */
 int spamd_spmm_tiled_params(int* rows_per_group, int* tile_rows, int* groups_per_block, int* entries_per_block,
                             int* slack_blocks, int* direct_max_tiles);
@@ -109,7 +110,7 @@ int spamd_spmm_tiled_pack(int64_t nnz, const int64_t* tiled_keys_sorted, const f
                           const int64_t* seg_start, const int64_t* blk_off, int64_t total_blocks, int* blocks,
                           void* stream);
 int spamd_spmm_tiled(int64_t M, int64_t K, int64_t N, const int* blocks, const int* blk_off32, const float* b,
-                     int64_t ldb, float* out, int64_t ldo, void* stream);
+                     int64_t ldb, float* out, int64_t ldo, unsigned flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * A10  NaN scan                    replaces `nan_check` (_common.py:51-69), the pass `matmul`

@@ -236,10 +236,10 @@ def _return_kind(return_type):
 
 
 def _tiled_eligible(data, bt, out_shape, Kd):
-    """The inspector/executor kernel covers fp32 x fp32 -> fp32 with N % 128 == 0 in FMA mode; it pays off
+    """The inspector/executor kernel covers fp32 x fp32 -> fp32 with N % 128 == 0; it pays off
     when the (32-row, 128-column) lists hold more than a block or so on average and the grid fills the chip."""
     M, N = out_shape
-    if _settings.EXACT_MULADD or _settings.TILED_SPMM == "never":
+    if _settings.TILED_SPMM == "never":
         return False
     if data.dtype != torch.float32 or bt.dtype != torch.float32 or N == 0 or N % 128 or bt.dim() != 2:
         return False
@@ -280,7 +280,7 @@ def _gcxs_times_dense(a, bt, out_shape):
         # the inspector costs about one product (1.5 ms at config 2 against 1.2 ms per tiled and 2.6 ms per
         # row-group product), so it runs at the first eligible product and is cached on the array
         prepare_spmm(a)
-        return K.dot_csr_ndarray_tiled(a._tiled_layout, out_shape, Kd, bt)
+        return K.dot_csr_ndarray_tiled(a._tiled_layout, out_shape, Kd, bt, exact=_settings.EXACT_MULADD)
     return K.dot_csr_ndarray(out_shape, data, indices, indptr, bt, exact=_settings.EXACT_MULADD)
 
 

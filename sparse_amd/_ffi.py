@@ -88,7 +88,7 @@ SIGNATURES = {
     "spamd_spmm_tiled_keys": (_int, [_i64, _vp, _i64, _vp, _vp]),
     "spamd_spmm_tiled_lists": (_int, [_i64, _vp, _i64, _i64, _vp, _vp, _vp]),
     "spamd_spmm_tiled_pack": (_int, [_i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
-    "spamd_spmm_tiled": (_int, [_i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
+    "spamd_spmm_tiled": (_int, [_i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _u32, _vp]),
     "spamd_has_nan": (_int, [_int, _i64, _vp, _vp, _vp]),
     "spamd_spmm_csr": (_int, [_int, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _u32, _vp]),
 }

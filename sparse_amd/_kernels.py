@@ -600,13 +600,15 @@ def csr_tiled_layout(a_data, a_indices, a_indptr, M, Kd, force_sort=False):
         "spamd_spmm_tiled_pack", nnz, ptr(tk), ptr(vals), ptr(seg_start), ptr(bo), total, ptr(blocks), s))
 
 
-def dot_csr_ndarray_tiled(layout, out_shape, Kd, b, out=None):
-    """Executor: C = A @ B from the tiled layout (fp32, N == 128, one FMA per term)."""
+def dot_csr_ndarray_tiled(layout, out_shape, Kd, b, out=None, exact=False):
+    """Executor: C = A @ B from the tiled layout (fp32, N % 128 == 0); `exact` = separate multiply and add
+    (the reference's arithmetic) instead of one FMA per term."""
     blocks, blk_off = layout
     M, N = int(out_shape[0]), int(out_shape[1])
     dev = require_hip(blocks, blk_off, b)
     b = b.contiguous()
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=dev)
-    _ffi.call("spamd_spmm_tiled", M, Kd, N, ptr(blocks), ptr(blk_off), ptr(b), N, ptr(out), N, stream_ptr(dev))
+    _ffi.call("spamd_spmm_tiled", M, Kd, N, ptr(blocks), ptr(blk_off), ptr(b), N, ptr(out), N,
+              _ffi.EXACT_MULADD if exact else 0, stream_ptr(dev))
     return out

@@ -185,7 +185,8 @@ __device__ __forceinline__ void tl_dma16(unsigned lds_base, const void* src) {
 // over the blocks [o(t), o(t+1)) reading B rows from LDS tile t, the wave's share of the LDS-DMA of tile
 // t+1 (if t+1 < nfull), the scalar request for the first blocks of list t+1, the line touch of list t+2,
 // the DMA wait and the barrier.  o(t) = lane (min(t, ntiles) - obase) of `offreg`; o0..o2 = o(t0..t0+2).
-// MODE: 0 full, 1 no fma, 2 no LDS reads / fma (timing ablations).
+// MODE: 0 one fma per term, 3 separate multiply and add (the reference's arithmetic, bit for bit);
+// 1 no fma, 2 no LDS reads / fma (timing ablations).
 template <int MODE>
 __device__ __forceinline__ void tl_phases(const int* stream, int t0, int te, int o0, int o1, int o2, int offreg, int obase,
                                           int ntiles, int nfull, int lane, int mask, unsigned m0wave,
@@ -197,7 +198,9 @@ __device__ __forceinline__ void tl_phases(const int* stream, int t0, int te, int
     [obase] "s"(obase), [ntiles] "s"(ntiles), [nfull] "s"(nfull), [m0wave] "s"(m0wave), [step] "s"(row_step),      \
     [lane] "v"(lane), [lane8] "v"(lane8), [mask] "v"(mask), [offreg] "v"(offreg)                                  \
   : "memory", "m0", "scc", TL_CLOB_SGPR, TL_CLOB_TMP, TL_CLOB_ACC
-  if (MODE == 1)
+  if (MODE == 3)
+    asm volatile(TL_ASM_PHASES_EXACT : TL_PHASES_OPERANDS);
+  else if (MODE == 1)
     asm volatile(TL_ASM_PHASES_NOFMA : TL_PHASES_OPERANDS);
   else if (MODE == 2)
     asm volatile(TL_ASM_PHASES_NOLDS : TL_PHASES_OPERANDS);
@@ -399,7 +402,7 @@ extern "C" int spamd_spmm_tiled_fill(int idx_dtype, int64_t M, int64_t K, const 
 }
 
 extern "C" int spamd_spmm_tiled(int64_t M, int64_t K, int64_t N, const int* blocks, const int* blk_off,
-                                const float* b, int64_t ldb, float* out, int64_t ldo, void* stream) {
+                                const float* b, int64_t ldb, float* out, int64_t ldo, unsigned flags, void* stream) {
   if (M < 0 || K <= 0 || N <= 0 || N % 128 != 0 || N / 128 > 65535 || K / TL_KB >= ((int64_t)1 << 30)) return SPAMD_EINVAL;
   if (M == 0) return 0;
   if (((uintptr_t)b % 16) || (ldb % 4) || ((uintptr_t)out % 8) || (ldo % 2) || ((uintptr_t)blocks % 64))
@@ -409,7 +412,8 @@ extern "C" int spamd_spmm_tiled(int64_t M, int64_t K, int64_t N, const int* bloc
   auto kern = dbg == 2 ? &spmm_tiled_kernel<2, 0>
             : dbg == 5 ? &spmm_tiled_kernel<0, 1>
             : dbg == 6 ? &spmm_tiled_kernel<0, 2>
-            : dbg == 7 ? &spmm_tiled_kernel<2, 2> : &spmm_tiled_kernel<0, 0>;
+            : dbg == 7 ? &spmm_tiled_kernel<2, 2>
+            : (flags & SPAMD_EXACT_MULADD) ? &spmm_tiled_kernel<0, 3> : &spmm_tiled_kernel<0, 0>;
   const int lds_bytes = TL_LDS;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      lds_bytes);

@@ -115,14 +115,35 @@ def test_product_path_csc_operand_uses_the_csr_twin(orc, monkeypatch):
     assert np.allclose(got.cpu().numpy(), want, rtol=2e-5, atol=1e-6)
 
 
-def test_exact_mode_and_ineligible_shapes_keep_the_rowgroup_kernel(monkeypatch):
+@pytest.mark.parametrize("M,K,density", [(300, 200, 0.05), (5000, 10000, 0.01), (4097, 129, 0.1), (64, 1000, 0.2)])
+def test_tiled_exact_mode_is_bit_identical_to_the_reference_loop(orc, M, K, density):
+    """SPAMD_EXACT_MULADD: a rounded product then a rounded add per term in storage order = reference
+    `_dot_csr_ndarray` (_common.py:744-753) bit for bit (the oracle is its C restatement, -ffp-contract=off)."""
+    from sparse_amd import _kernels as Kn
+
+    data, idx, ptr = random_csr(M, K, density, 31, np.float32, np.int32)
+    b = random_dense(K, 128, 32, np.float32)
+    d = torch.device("cuda")
+    td, ti, tp, tb = (torch.from_numpy(x).to(d) for x in (data, idx, ptr, b))
+    layout = Kn.csr_tiled_layout(td, ti, tp, M, K)
+    got = Kn.dot_csr_ndarray_tiled(layout, (M, 128), K, tb, exact=True)
+    ref = Kn.dot_csr_ndarray((M, 128), td, ti, tp, tb, exact=True)
+    want = orc.dot_csr_ndarray((M, 128), data, idx, ptr, b)
+    assert torch.equal(got, ref)
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+def test_exact_mode_uses_the_tiled_path_and_small_n_keeps_the_rowgroup_kernel(monkeypatch):
     from sparse_amd import _settings
 
     monkeypatch.setattr(_settings, "TILED_SPMM", "auto")
     monkeypatch.setattr(_settings, "EXACT_MULADD", True)
     a, b, _ = _product_case(seed=12)
-    a @ b
-    assert getattr(a, "_tiled_layout", None) is None
+    r = a @ b
+    assert getattr(a, "_tiled_layout", None) is not None
+    monkeypatch.setattr(_settings, "TILED_SPMM", "never")
+    assert torch.equal(r, a @ b)
+    monkeypatch.setattr(_settings, "TILED_SPMM", "auto")
     monkeypatch.setattr(_settings, "EXACT_MULADD", False)
     a2, b2, _ = _product_case(N=64, seed=13)
     a2 @ b2

@@ -52,6 +52,22 @@ def p2(buf, dset):
     return o
 
 
+def p2_exact(buf, dset):
+    """reference arithmetic (`out[i, j] += data * b[k, j]`, _common.py:752): a rounded product, then a rounded
+    add - the products overwrite the B rows in place, only the adds run under the gpr-index mode"""
+    o = []
+    for i in range(ENTRIES):
+        d = DATASET[dset] + 2 * i
+        o.append(f"v_pk_mul_f32 v[{d}:{d + 1}], v[{d}:{d + 1}], s[{buf + 2 * i}:{buf + 2 * i + 1}] "
+                 f"op_sel:[0,1] op_sel_hi:[1,1]")
+    for i in range(ENTRIES):
+        d = DATASET[dset] + 2 * i
+        o.append(f"s_set_gpr_idx_on s{buf}, gpr_idx(SRC1,DST)" if i == 0 else f"s_set_gpr_idx_idx s{buf + 2 * i}")
+        o.append(f"v_pk_add_f32 v[{JUNK}:{JUNK + 1}], v[{d}:{d + 1}], v[{JUNK}:{JUNK + 1}]")
+    o.append("s_set_gpr_idx_off")
+    return o
+
+
 def dma_hook(site):
     """Issue one more tile-DMA instruction of the NEXT tile if any are left (s39), from the walking source
     pointer v[22:23] (advanced by 32 B rows) to LDS address s89 (advanced by 16 KB)."""
@@ -66,7 +82,7 @@ def dma_hook(site):
             f"{60 + site}:"]
 
 
-def list_loop(lds=True, fma=True):
+def list_loop(lds=True, fma=True, exact=False):
     """The list loop of one tile phase.  Software-pipelined: while block r is multiplied (P2), the B rows
     of block r+1 are already being read from LDS (P1) and block r+3 is being fetched by a scalar load.
     Entry: s[36:37] = list pointer, s38 = blocks in the list (> 0), the first min(3, s38) blocks are in
@@ -76,7 +92,7 @@ def list_loop(lds=True, fma=True):
     the 64 B/clk address path."""
     A, B, C = RING
     P1 = p1 if lds else (lambda buf, dset: [])
-    P2 = p2 if fma else (lambda buf, dset: [])
+    P2 = (p2_exact if exact else p2) if fma else (lambda buf, dset: [])
     o = dma_hook(0)
     o += ["s_waitcnt lgkmcnt(0)"]
     o += P1(A, 0)
@@ -122,7 +138,7 @@ def request_first_blocks(lo, hi, tag):
         f"{tag}:"]
 
 
-def phases(lds=True, fma=True):
+def phases(lds=True, fma=True, exact=False):
     """Tile phases t0 .. te-1 of one wave in ONE asm block, so that SGPR state survives the barrier:
     the first blocks of list t+1 are requested BEFORE the barrier that ends phase t (the scalar path serves
     one 64-byte request per ~20 cycles per CU; 16 waves x 3 requests right after a barrier idle the CU for
@@ -137,7 +153,7 @@ def phases(lds=True, fma=True):
           "s_and_b32 s88, s88, 1", "s_lshl_b32 s88, s88, 16", "s_add_u32 s89, s88, %[m0wave]",
           "s_and_b32 s88, s90, 1", "s_lshl_b32 s88, s88, 16", "v_or_b32 v60, s88, %[lane8]",  # this tile's LDS base
           "s_cmp_eq_u32 s38, 0", "s_cbranch_scc1 12f"]
-    o += list_loop(lds, fma)
+    o += list_loop(lds, fma, exact)
     o += ["12:", "13:"] + dma_hook(13)[:-1] + ["s_branch 13b", "73:"]   # the rest of the DMA share
     # first blocks of the next list (not at the end of the chunk: the ring must be idle when the asm ends)
     o += ["s_add_u32 s88, s90, 1", "s_cmp_lt_u32 s88, %[te]", "s_cbranch_scc0 21f"]
@@ -193,6 +209,7 @@ def clob(prefix, lo, hi):
 def main():
     out = ["// GENERATED by tools/gen_tiled_asm.py - do not edit.\n",
            lit("TL_ASM_PHASES", phases()),
+           lit("TL_ASM_PHASES_EXACT", phases(True, True, True)),
            lit("TL_ASM_PHASES_NOFMA", phases(True, False)),
            lit("TL_ASM_PHASES_NOLDS", phases(False, False)),
            lit("TL_ASM_TILE0", tile0()),
