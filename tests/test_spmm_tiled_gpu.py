@@ -46,6 +46,17 @@ def test_tiled_bit_identical_to_rowgroup_fma(orc, idt, M, K, density):
     assert sorted(real[:, 1].view(np.float32).tolist()) == sorted(data.tolist())  # a permutation of A's values
 
 
+@pytest.mark.parametrize("M,K,density", [(700, 20000, 0.004), (100, 128, 0.3), (513, 256, 0.1), (2000, 7936, 0.01),
+                                         (40, 16000, 0.02)])
+def test_tiled_phase_chunking_and_tile_edges(orc, M, K, density):
+    """More than 61 / 122 tiles (the phase loop runs in chunks of 61), K an exact multiple of the tile (no
+    partial tile), one tile only."""
+    (data, idx, ptr, b), got, ref, _ = _run(M, K, density, np.int32, seed=41)
+    assert torch.equal(got, ref)
+    want = orc.dot_csr_ndarray((M, 128), data, idx, ptr, b)
+    assert np.allclose(got.cpu().numpy(), want, rtol=2e-5, atol=1e-6)
+
+
 def test_tiled_edge_rows():
     (_, _, _, _), got, ref, _ = _run(777, 900, 0.03, np.int32, seed=3, empty_rows=(0, 1, 2, 400, 401, 776), long_row=300)
     assert torch.equal(got, ref)
