@@ -33,6 +33,28 @@ def segment_reduce(data, heads, offs, count, op, want_counts=False):
     return (out, counts) if want_counts else out
 
 
+def group_reduce(keys, divisor, data, op):
+    """One pass over SORTED keys: runs of equal `keys // divisor` -> (group ids, reduced values, run lengths).
+    C ABI `spamd_group_reduce` (reference `_reduce_calc`, _coo/core.py:1601-1661)."""
+    dev = require_hip(keys, data)
+    n = int(keys.numel())
+    if data.dtype == torch.bool:
+        data = data.view(torch.uint8)
+    code = _ffi.U8 if data.dtype == torch.uint8 else code_of(data.dtype)
+    gids = torch.empty(n, dtype=torch.int64, device=dev)
+    vals = torch.empty(n, dtype=data.dtype, device=dev)
+    counts = torch.empty(n, dtype=torch.int64, device=dev)
+    ng = torch.empty(1, dtype=torch.int64, device=dev)
+    ws_bytes = int(_ffi.lib().spamd_group_reduce_ws_bytes(code, n))
+    if ws_bytes < 0:
+        raise _ffi.HipBackendError(f"spamd_group_reduce_ws_bytes failed: {ws_bytes}")
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    _ffi.call("spamd_group_reduce", _RED_OPS[op], code, n, ptr(keys.contiguous()), int(divisor), ptr(data.contiguous()),
+              ptr(gids), ptr(vals), ptr(counts), ptr(ng), ptr(ws), ws_bytes, stream_ptr(dev))
+    count = int(ng[0])
+    return gids[:count], vals[:count], counts[:count], count
+
+
 def _scalar_dev(value, dtype, dev):
     return torch.tensor([value], dtype=dtype, device=dev)
 
@@ -89,12 +111,7 @@ def reduce_impl(x, method, axis=(0,), keepdims=False, **kwargs):
         keys, perm = K.sort_keys(keys, max(x.size - 1, 1))
         data = K.gather(data, perm)
     if x.nnz:
-        gk = binary_arrays("floor_divide_i64", keys, _scalar_dev(max(n_cols, 1), torch.int64, dev), b_scalar=True)
-        heads = K.flag_heads(gk)
-        offs = K.exclusive_scan(heads)
-        count = int(offs[-1])
-        vals, counts = segment_reduce(data, heads, offs, count, name, want_counts=True)
-        gids = K.compact(gk, heads, offs, count)
+        gids, vals, counts, count = group_reduce(keys, max(n_cols, 1), data, name)
     else:
         count = 0
         vals = data[:0]

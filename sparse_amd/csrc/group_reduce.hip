@@ -1,0 +1,392 @@
+// A8: grouped reduce over sorted keys in two streaming passes (reference `_reduce_calc` / `_reduce_return`,
+// sparse/numba_backend/_coo/core.py:1601-1661 via _sparse_array.py:372-437: `np.ufunc.reduceat` over the runs of
+// equal group ids after sorting by the kept axes).
+//
+// group id = key / divisor, computed on the fly.  Replaces floor_divide + flag_heads + exclusive_scan +
+// segment_reduce + compact (five passes, ~8 GB of traffic for 10^8 stored elements) by
+//   gr_count_kernel   keys -> number of run heads per 2048-element tile (1024 threads x 2)                    (reads 8 B / element)
+//   exclusive scan over the tiles (spamd_exclusive_scan's rocPRIM call, a few thousand entries)
+//   gr_reduce_kernel  keys + values -> every run that ends inside a tile, plus the tile's open head / tail
+//                     partials                                                              (reads 8 B + value)
+//   gr_fixup_kernel   one workgroup: chains the open partials across tiles (runs longer than a tile)
+// A thread owns 2 consecutive elements (one 16-byte key load) and combines them left to right; threads, waves and tiles are combined by
+// a segmented scan in a fixed tree order: results are run-to-run reproducible.  Floating-point sums therefore
+// differ from the reference's reduceat (pairwise for runs of 8+ elements) only by re-association: parity is to
+// 1e-12 relative for f64 sums, exact for integers, max/min and the logical ops.  (rocPRIM's reduce_by_key with a
+// transform/zip iterator was tried first: 4.3 ms per 10^8 elements, slower than the five passes.)
+#include <string.h>
+#include <cstring>
+#include "common.h"
+#include <rocprim/rocprim.hpp>
+
+namespace spamd {
+
+constexpr int GR_THREADS = 1024;
+constexpr int GR_ITEMS = 2;  // 16 bytes of keys per lane: one fully coalesced load per wave (8 items per thread in a
+                             // blocked arrangement = 64 cache lines per wave instruction: measured 2 TB/s)
+constexpr int GR_TILE = GR_THREADS * GR_ITEMS;
+
+// k / d for 0 <= k: reciprocal multiply in double, then an exact integer correction (a hardware 64-bit divide
+// is ~100 instructions)
+struct GroupOf {
+  int64_t d;
+  double rd;
+  __device__ __forceinline__ int64_t operator()(int64_t k) const {
+    int64_t q = (int64_t)((double)k * rd);
+    int64_t r = k - q * d;
+    while (r < 0) { --q; r += d; }
+    while (r >= d) { ++q; r -= d; }
+    return q;
+  }
+};
+
+enum { GR_ADD = 0, GR_MUL, GR_MAX, GR_MIN, GR_OR, GR_AND };
+
+template <typename T>
+__device__ __forceinline__ T gr_apply(int op, T x, T y) {
+  switch (op) {
+    case GR_ADD: return (T)(x + y);
+    case GR_MUL: return (T)(x * y);
+    case GR_MAX: return (x != x) ? x : ((y != y) ? y : (x > y ? x : y));  // NaN propagates (np.maximum)
+    case GR_MIN: return (x != x) ? x : ((y != y) ? y : (x < y ? x : y));
+    case GR_OR: return (T)((x != (T)0) || (y != (T)0));
+    default: return (T)((x != (T)0) && (y != (T)0));
+  }
+}
+
+// a partial result: `c` elements combined into `v` (c == 0: empty)
+template <typename T>
+struct Part {
+  T v;
+  int64_t c;
+};
+template <typename T>
+__device__ __forceinline__ Part<T> gr_join(int op, Part<T> a, Part<T> b) {  // a then b (a is to the left)
+  if (a.c == 0) return b;
+  if (b.c == 0) return a;
+  return Part<T>{gr_apply(op, a.v, b.v), a.c + b.c};
+}
+
+// summary of a span for the segmented scan: does it contain a head, and the partial after its last head
+// (or of the whole span if it has none)
+template <typename T>
+struct Span {
+  Part<T> tail;
+  int heads;
+};
+template <typename T>
+__device__ __forceinline__ Span<T> gr_concat(int op, Span<T> a, Span<T> b) {
+  Span<T> r;
+  r.heads = a.heads + b.heads;
+  r.tail = b.heads ? b.tail : gr_join(op, a.tail, b.tail);
+  return r;
+}
+
+template <typename T>
+__device__ __forceinline__ Span<T> gr_shfl_up(Span<T> s, int delta) {
+  Span<T> r;
+  r.tail.v = __shfl_up(s.tail.v, delta, 64);
+  r.tail.c = __shfl_up(s.tail.c, delta, 64);
+  r.heads = __shfl_up(s.heads, delta, 64);
+  return r;
+}
+
+// Exclusive segmented scan of one Span per thread over a workgroup of NT threads (NT / 64 waves).
+// Returns the concatenation of all spans of lower-numbered threads; *total (if non-null, valid in the last
+// thread... returned to every thread through LDS) receives the whole workgroup's span.
+template <typename T, int NT>
+__device__ __forceinline__ Span<T> gr_block_exclusive(int op, Span<T> mine, Span<T>* lds_wave, Span<T>* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  Span<T> inc = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    Span<T> o = gr_shfl_up(inc, d);
+    if (lane >= d) inc = gr_concat(op, o, inc);
+  }
+  if (lane == 63) lds_wave[wave] = inc;
+  __syncthreads();
+  Span<T> before;  // spans of the earlier waves
+  before.tail.c = 0;
+  before.tail.v = (T)0;
+  before.heads = 0;
+  for (int w = 0; w < wave; ++w) before = gr_concat(op, before, lds_wave[w]);
+  if (total) {
+    Span<T> all = before;
+    for (int w = wave; w < NT / 64; ++w) all = gr_concat(op, all, lds_wave[w]);
+    *total = all;
+  }
+  Span<T> exc = gr_shfl_up(inc, 1);
+  if (lane == 0) {
+    exc.tail.c = 0;
+    exc.tail.v = (T)0;
+    exc.heads = 0;
+  }
+  __syncthreads();
+  return gr_concat(op, before, exc);
+}
+
+// GR_ITEMS consecutive keys of a thread: one 16-byte load when they are all in range (base is even, the array is
+// 16-byte aligned: checked by the caller), else element by element (the last thread of the array)
+__device__ __forceinline__ void gr_load_keys(const int64_t* __restrict__ keys, int64_t base, int64_t n, int64_t (&k)[GR_ITEMS]) {
+  static_assert(GR_ITEMS == 2, "one 16-byte load per thread");
+  if (base + GR_ITEMS <= n) {
+    const Vec<int64_t, 2> v = *reinterpret_cast<const Vec<int64_t, 2>*>(keys + base);
+    k[0] = v.v[0];
+    k[1] = v.v[1];
+  } else {
+    k[0] = keys[base];
+    k[1] = 0;
+  }
+}
+
+__global__ void __launch_bounds__(GR_THREADS) gr_count_kernel(const int64_t* __restrict__ keys, int64_t n, GroupOf gof,
+                                                              int64_t* __restrict__ tile_heads) {
+  __shared__ int wsum[GR_THREADS / 64];
+  const int64_t base = (int64_t)blockIdx.x * GR_TILE + (int64_t)threadIdx.x * GR_ITEMS;
+  int cnt = 0;
+  if (base < n) {
+    int64_t k[GR_ITEMS];
+    gr_load_keys(keys, base, n, k);
+    // the group of the element before mine: lane - 1 has it (its last key), except in lane 0 of a wave
+    const int64_t left = __shfl_up(k[GR_ITEMS - 1], 1, 64);
+    int64_t prev = (threadIdx.x & 63) ? gof(left) : (base > 0 ? gof(keys[base - 1]) : -1);
+#pragma unroll
+    for (int j = 0; j < GR_ITEMS; ++j) {
+      if (base + j < n) {
+        const int64_t g = gof(k[j]);
+        cnt += g != prev;
+        prev = g;
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < GR_THREADS / 64; ++w) t += wsum[w];
+    tile_heads[blockIdx.x] = t;
+  }
+}
+
+// tile_first[b] = index of the first run that STARTS in tile b (exclusive scan of tile_heads).
+// Writes gids / vals / counts of every run that starts in this tile and is closed inside it, and
+//   open_head[b]  = partial of the elements before the tile's first head (they belong to run tile_first[b]-1)
+//   open_tail[b]  = partial after the tile's last head (run tile_first[b+1]-1), or of the whole tile if it has no head
+template <typename T>
+__global__ void __launch_bounds__(GR_THREADS)
+gr_reduce_kernel(int op, const int64_t* __restrict__ keys, const T* __restrict__ data, int64_t n, GroupOf gof,
+                 const int64_t* __restrict__ tile_first, int64_t* __restrict__ gids, T* __restrict__ vals,
+                 int64_t* __restrict__ counts, Part<T>* __restrict__ open_head, Part<T>* __restrict__ open_tail) {
+  __shared__ Span<T> lds_wave[GR_THREADS / 64];
+  const int64_t base = (int64_t)blockIdx.x * GR_TILE + (int64_t)threadIdx.x * GR_ITEMS;
+  int64_t g[GR_ITEMS];
+  T v[GR_ITEMS];
+  bool h[GR_ITEMS];
+  int64_t kk[GR_ITEMS] = {0, 0};
+  if (base < n) gr_load_keys(keys, base, n, kk);
+  // (every lane takes part in the shuffle; lanes past the end hold zeros nobody reads)
+  const int64_t left = __shfl_up(kk[GR_ITEMS - 1], 1, 64);
+  int64_t prev = -1;
+  if (base < n) prev = (threadIdx.x & 63) ? gof(left) : (base > 0 ? gof(keys[base - 1]) : -1);
+  Span<T> mine;
+  mine.heads = 0;
+  mine.tail.c = 0;
+  mine.tail.v = (T)0;
+#pragma unroll
+  for (int j = 0; j < GR_ITEMS; ++j) {
+    h[j] = false;
+    if (base + j < n) {
+      g[j] = gof(kk[j]);
+      v[j] = data[base + j];
+      h[j] = g[j] != prev;
+      prev = g[j];
+      if (h[j]) {
+        mine.heads += 1;
+        mine.tail = Part<T>{v[j], 1};
+      } else {
+        mine.tail = gr_join(op, mine.tail, Part<T>{v[j], 1});
+      }
+    }
+  }
+  Span<T> all;
+  const Span<T> before = gr_block_exclusive<T, GR_THREADS>(op, mine, lds_wave, &all);
+  // second walk: close runs
+  const int64_t first = tile_first[blockIdx.x];
+  int64_t k = before.heads;      // heads seen so far in this tile
+  Part<T> run = before.tail;     // the open run entering my items
+#pragma unroll
+  for (int j = 0; j < GR_ITEMS; ++j) {
+    if (base + j < n) {
+      if (h[j]) {
+        if (k == 0) {
+          open_head[blockIdx.x] = run;  // elements of a run that started in an earlier tile
+        } else {
+          vals[first + k - 1] = run.v;
+          counts[first + k - 1] = run.c;
+        }
+        gids[first + k] = g[j];
+        ++k;
+        run = Part<T>{v[j], 1};
+      } else {
+        run = gr_join(op, run, Part<T>{v[j], 1});
+      }
+    }
+  }
+  if (threadIdx.x == GR_THREADS - 1) {
+    open_tail[blockIdx.x] = all.tail;
+    if (all.heads == 0) open_head[blockIdx.x] = Part<T>{(T)0, 0};  // everything is in open_tail
+  }
+}
+
+// Closing the runs that are open at a tile boundary.  Run tile_first[b] - 1 is open when tile b begins; if tile b
+// has a head it ends there and its value is (open tails since its head) + open_head[b]; the run open at the very
+// end (total - 1) ends at the virtual tile `ntiles`.
+// Fast path, one thread per tile: walk back over at most GR_WALK head-less tiles.  A longer stretch (a run
+// spanning more than ~64k elements) raises *need_chain and the single-workgroup segmented scan below redoes all
+// of them.
+constexpr int GR_WALK = 32;
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+gr_fix_fast_kernel(int op, int64_t ntiles, const int64_t* __restrict__ tile_heads, const int64_t* __restrict__ tile_first,
+                   const Part<T>* __restrict__ open_head, const Part<T>* __restrict__ open_tail, T* __restrict__ vals,
+                   int64_t* __restrict__ counts, int64_t* __restrict__ n_groups, int* __restrict__ need_chain) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;  // 1 .. ntiles
+  if (b > ntiles) return;
+  if (b == ntiles) *n_groups = tile_first[ntiles];
+  if (b < ntiles && tile_heads[b] == 0) return;
+  int64_t s = b - 1;  // first tile of the head-less stretch that precedes b (s == b: none)
+  int steps = 0;
+  while (s >= 0 && tile_heads[s] == 0) {
+    if (++steps > GR_WALK) {
+      *need_chain = 1;
+      return;
+    }
+    --s;
+  }
+  // s = last tile before b that has a head (or -1): the run consists of open_tail[s], the whole tiles s+1 .. b-1
+  // (their open_tail), and open_head[b]
+  Part<T> run{(T)0, 0};
+  for (int64_t t = s < 0 ? 0 : s; t < b; ++t) run = gr_join(op, run, open_tail[t]);
+  if (b < ntiles) run = gr_join(op, run, open_head[b]);
+  const int64_t r = tile_first[b] - 1;
+  if (run.c) {
+    vals[r] = run.v;
+    counts[r] = run.c;
+  }
+}
+
+// One workgroup: the same by a segmented scan over all tiles, for arbitrarily long runs.
+template <typename T>
+__global__ void __launch_bounds__(1024)
+gr_fixup_kernel(int op, int64_t ntiles, const int64_t* __restrict__ tile_heads, const int64_t* __restrict__ tile_first,
+                const Part<T>* __restrict__ open_head, const Part<T>* __restrict__ open_tail, T* __restrict__ vals,
+                int64_t* __restrict__ counts, int64_t* __restrict__ n_groups, const int* __restrict__ need_chain) {
+  __shared__ Span<T> lds_wave[1024 / 64];
+  if (*need_chain == 0) return;
+  const int64_t per = (ntiles + 1023) / 1024;
+  const int64_t b0 = (int64_t)threadIdx.x * per, b1 = b0 + per < ntiles ? b0 + per : ntiles;
+  Span<T> mine;
+  mine.heads = 0;
+  mine.tail.c = 0;
+  mine.tail.v = (T)0;
+  for (int64_t b = b0; b < b1; ++b) {
+    Span<T> s;
+    s.heads = tile_heads[b] ? 1 : 0;
+    s.tail = open_tail[b];
+    mine = gr_concat(op, mine, s);
+  }
+  const Span<T> before = gr_block_exclusive<T, 1024>(op, mine, lds_wave, nullptr);
+  Part<T> carry = before.tail;  // the open run entering tile b0
+  for (int64_t b = b0; b < b1; ++b) {
+    if (tile_heads[b]) {
+      const Part<T> done = gr_join(op, carry, open_head[b]);
+      if (done.c) {
+        vals[tile_first[b] - 1] = done.v;
+        counts[tile_first[b] - 1] = done.c;
+      }
+      carry = open_tail[b];
+    } else {
+      carry = gr_join(op, carry, open_tail[b]);
+    }
+    if (b == ntiles - 1) {
+      const int64_t total = tile_first[ntiles];
+      if (carry.c) {
+        vals[total - 1] = carry.v;
+        counts[total - 1] = carry.c;
+      }
+      *n_groups = total;
+    }
+  }
+}
+
+static int64_t gr_tiles(int64_t n) { return ceil_div(n, (int64_t)GR_TILE); }
+static size_t gr_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+template <typename T>
+static int group_reduce_t(int op, int64_t n, const int64_t* keys, int64_t divisor, const T* data, int64_t* gids, T* vals,
+                          int64_t* counts, int64_t* n_groups, char* ws, size_t ws_bytes, hipStream_t s) {
+  const int64_t nt = gr_tiles(n);
+  // workspace: tile_heads[nt+1] | tile_first[nt+1] | open_head[nt] | open_tail[nt] | scan temp
+  int64_t* tile_heads = reinterpret_cast<int64_t*>(ws);
+  int64_t* tile_first = reinterpret_cast<int64_t*>(ws + gr_align((nt + 1) * 8));
+  Part<T>* open_head = reinterpret_cast<Part<T>*>(ws + 2 * gr_align((nt + 1) * 8));
+  Part<T>* open_tail = reinterpret_cast<Part<T>*>(ws + 2 * gr_align((nt + 1) * 8) + gr_align(nt * sizeof(Part<T>)));
+  int* need_chain = reinterpret_cast<int*>(ws + 2 * gr_align((nt + 1) * 8) + 2 * gr_align(nt * sizeof(Part<T>)));
+  char* scan_ws = reinterpret_cast<char*>(need_chain) + 256;
+  size_t scan_bytes = ws_bytes - (size_t)(scan_ws - ws);
+  hipError_t em = hipMemsetAsync(need_chain, 0, sizeof(int), s);
+  if (em != hipSuccess) return (int)em;
+  const GroupOf gof{divisor, 1.0 / (double)divisor};
+  hipLaunchKernelGGL(gr_count_kernel, dim3((unsigned)nt), dim3(GR_THREADS), 0, s, keys, n, gof, tile_heads);
+  hipError_t e = rocprim::exclusive_scan(scan_ws, scan_bytes, tile_heads, tile_first, (int64_t)0, (size_t)(nt + 1),
+                                         rocprim::plus<int64_t>(), s);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(gr_reduce_kernel<T>, dim3((unsigned)nt), dim3(GR_THREADS), 0, s, op, keys, data, n, gof, tile_first,
+                     gids, vals, counts, open_head, open_tail);
+  hipLaunchKernelGGL(gr_fix_fast_kernel<T>, dim3((unsigned)ceil_div(nt, (int64_t)256)), dim3(256), 0, s, op, nt, tile_heads,
+                     tile_first, open_head, open_tail, vals, counts, n_groups, need_chain);
+  hipLaunchKernelGGL(gr_fixup_kernel<T>, dim3(1), dim3(1024), 0, s, op, nt, tile_heads, tile_first, open_head, open_tail,
+                     vals, counts, n_groups, need_chain);
+  return launch_status();
+}
+
+}  // namespace spamd
+
+using namespace spamd;
+
+extern "C" int64_t spamd_group_reduce_ws_bytes(int val_dtype, int64_t n) {
+  const int64_t nt = gr_tiles(n > 0 ? n : 1);
+  size_t scan = 0;
+  int64_t* p = nullptr;
+  hipError_t e = rocprim::exclusive_scan(nullptr, scan, p, p, (int64_t)0, (size_t)(nt + 1), rocprim::plus<int64_t>(),
+                                         (hipStream_t)0);
+  if (e != hipSuccess) return -(int64_t)e;
+  return (int64_t)(2 * gr_align((nt + 1) * 8) + 2 * gr_align(nt * 16) + 256 + scan + 256);
+}
+
+extern "C" int spamd_group_reduce(int op, int val_dtype, int64_t n, const int64_t* keys, int64_t divisor,
+                                  const void* data, int64_t* group_ids, void* values, int64_t* counts,
+                                  int64_t* n_groups, void* ws, int64_t ws_bytes, void* stream) {
+  if (n < 0 || divisor <= 0 || op < 0 || op > GR_AND) return SPAMD_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) return (int)hipMemsetAsync(n_groups, 0, sizeof(int64_t), s);
+  if (ws_bytes < spamd_group_reduce_ws_bytes(val_dtype, n) || ((uintptr_t)ws % 16) || ((uintptr_t)keys % 16))
+    return SPAMD_EINVAL;
+  // the tile_heads array has nt + 1 entries for the scan; the last one is ignored by it but must be readable
+#define GR_CASE(CODE, T)                                                                                           \
+  case CODE:                                                                                                       \
+    return group_reduce_t<T>(op, n, keys, divisor, (const T*)data, group_ids, (T*)values, counts, n_groups, (char*)ws, \
+                             (size_t)ws_bytes, s);
+  switch (val_dtype) {
+    GR_CASE(SPAMD_F32, float)
+    GR_CASE(SPAMD_F64, double)
+    GR_CASE(SPAMD_I32, int32_t)
+    GR_CASE(SPAMD_I64, int64_t)
+    GR_CASE(SPAMD_U8, uint8_t)
+    default: return SPAMD_ETYPE;
+  }
+#undef GR_CASE
+}

@@ -117,3 +117,29 @@ def test_broadcasting_and_npz_interchange(sp, tmp_path):
         assert set(f.files) == {"data", "indices", "indptr", "compressed_axes", "shape", "fill_value"}
     gy = sp.load_npz(p)
     assert gy.compressed_axes == (1,) and np.array_equal(gy.todense(), x.todense())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.int64, np.float64, np.float32])
+def test_reductions_with_runs_longer_than_a_tile(dtype):
+    """Grouped reduce (csrc/group_reduce.hip): runs that span many 2048-element tiles (full reduction, one long
+    group among short ones) go through the chained fix-up; checked against NumPy on the dense array."""
+    import sparse_amd as sp
+
+    rng = np.random.default_rng(5)
+    shape = (6, 700, 900)
+    dense = np.zeros(shape, dtype=dtype)
+    mask = rng.random(shape) < 0.15
+    mask[2] = True  # one group of 630000 elements when reducing over the last two axes
+    vals = rng.integers(-40, 40, size=int(mask.sum())) if np.dtype(dtype).kind == "i" else rng.random(int(mask.sum())) - 0.4
+    dense[mask] = vals.astype(dtype)
+    x = sp.COO.from_numpy(dense)
+    for axis in (None, (1, 2), 2, (0, 1)):
+        for name in ("sum", "max", "min"):
+            got = getattr(x, name)(axis=axis)
+            want = getattr(dense, name)(axis=axis)
+            got = got.todense() if hasattr(got, "todense") else np.asarray(got)
+            if np.dtype(dtype).kind == "i" or name != "sum":
+                assert np.array_equal(got, want), (name, axis)
+            else:
+                assert np.allclose(got, want, rtol=1e-5 if dtype == np.float32 else 1e-12), (name, axis)
