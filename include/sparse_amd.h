@@ -241,10 +241,11 @@ int spamd_segment_reduce(int op, int val_dtype, int64_t n, const void* data, con
 /* A8 in one pass: runs of equal (keys[i] / divisor) over SORTED keys are reduced together with their lengths
  * (two streaming passes, csrc/group_reduce.hip; fp sums in a fixed, reproducible order).  Outputs hold up to n entries;
  * *n_groups (device int64) receives the number of runs.  op as for spamd_segment_reduce;
- * val_dtype F32 | F64 | I32 | I64 | U8.  Workspace from spamd_group_reduce_ws_bytes. */
+ * val_dtype F32 | F64 | I32 | I64 | U8.  keys < key_bound (0 = unknown; below 2^53 the ids are computed in
+ * double precision).  keys and data 16-byte aligned.  Workspace from spamd_group_reduce_ws_bytes. */
 int64_t spamd_group_reduce_ws_bytes(int val_dtype, int64_t n);
-int spamd_group_reduce(int op, int val_dtype, int64_t n, const int64_t* keys, int64_t divisor, const void* data,
-                       int64_t* group_ids, void* values, int64_t* counts, int64_t* n_groups, void* ws,
+int spamd_group_reduce(int op, int val_dtype, int64_t n, const int64_t* keys, int64_t divisor, int64_t key_bound,
+                       const void* data, int64_t* group_ids, void* values, int64_t* counts, int64_t* n_groups, void* ws,
                        int64_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------

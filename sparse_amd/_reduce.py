@@ -33,7 +33,7 @@ def segment_reduce(data, heads, offs, count, op, want_counts=False):
     return (out, counts) if want_counts else out
 
 
-def group_reduce(keys, divisor, data, op):
+def group_reduce(keys, divisor, data, op, key_bound=0):
     """One pass over SORTED keys: runs of equal `keys // divisor` -> (group ids, reduced values, run lengths).
     C ABI `spamd_group_reduce` (reference `_reduce_calc`, _coo/core.py:1601-1661)."""
     dev = require_hip(keys, data)
@@ -49,7 +49,8 @@ def group_reduce(keys, divisor, data, op):
     if ws_bytes < 0:
         raise _ffi.HipBackendError(f"spamd_group_reduce_ws_bytes failed: {ws_bytes}")
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    _ffi.call("spamd_group_reduce", _RED_OPS[op], code, n, ptr(keys.contiguous()), int(divisor), ptr(data.contiguous()),
+    _ffi.call("spamd_group_reduce", _RED_OPS[op], code, n, ptr(keys.contiguous()), int(divisor), int(key_bound),
+              ptr(data.contiguous()),
               ptr(gids), ptr(vals), ptr(counts), ptr(ng), ptr(ws), ws_bytes, stream_ptr(dev))
     count = int(ng[0])
     return gids[:count], vals[:count], counts[:count], count
@@ -111,7 +112,7 @@ def reduce_impl(x, method, axis=(0,), keepdims=False, **kwargs):
         keys, perm = K.sort_keys(keys, max(x.size - 1, 1))
         data = K.gather(data, perm)
     if x.nnz:
-        gids, vals, counts, count = group_reduce(keys, max(n_cols, 1), data, name)
+        gids, vals, counts, count = group_reduce(keys, max(n_cols, 1), data, name, key_bound=max(int(x.size), 1))
     else:
         count = 0
         vals = data[:0]

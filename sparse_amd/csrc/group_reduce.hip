@@ -4,12 +4,12 @@
 //
 // group id = key / divisor, computed on the fly.  Replaces floor_divide + flag_heads + exclusive_scan +
 // segment_reduce + compact (five passes, ~8 GB of traffic for 10^8 stored elements) by
-//   gr_count_kernel   keys -> number of run heads per 2048-element tile (1024 threads x 2)                    (reads 8 B / element)
+//   gr_count_kernel   keys -> number of run heads per 2048-element tile (512 threads x 4)                    (reads 8 B / element)
 //   exclusive scan over the tiles (spamd_exclusive_scan's rocPRIM call, a few thousand entries)
 //   gr_reduce_kernel  keys + values -> every run that ends inside a tile, plus the tile's open head / tail
 //                     partials                                                              (reads 8 B + value)
 //   gr_fixup_kernel   one workgroup: chains the open partials across tiles (runs longer than a tile)
-// A thread owns 2 consecutive elements (one 16-byte key load) and combines them left to right; threads, waves and tiles are combined by
+// A thread owns 4 consecutive elements and combines them left to right; threads, waves and tiles are combined by
 // a segmented scan in a fixed tree order: results are run-to-run reproducible.  Floating-point sums therefore
 // differ from the reference's reduceat (pairwise for runs of 8+ elements) only by re-association: parity is to
 // 1e-12 relative for f64 sums, exact for integers, max/min and the logical ops.  (rocPRIM's reduce_by_key with a
@@ -21,9 +21,9 @@
 
 namespace spamd {
 
-constexpr int GR_THREADS = 1024;
-constexpr int GR_ITEMS = 2;  // 16 bytes of keys per lane: one fully coalesced load per wave (8 items per thread in a
-                             // blocked arrangement = 64 cache lines per wave instruction: measured 2 TB/s)
+constexpr int GR_THREADS = 512;
+constexpr int GR_ITEMS = 4;  // 32 bytes of keys per lane, two 16-byte loads (8 items per thread was no faster, 2 items
+                             // doubles the segmented-scan work per element)
 constexpr int GR_TILE = GR_THREADS * GR_ITEMS;
 
 // k / d for 0 <= k: reciprocal multiply in double, then an exact integer correction (a hardware 64-bit divide
@@ -36,6 +36,21 @@ struct GroupOf {
     int64_t r = k - q * d;
     while (r < 0) { --q; r += d; }
     while (r >= d) { ++q; r -= d; }
+    return q;
+  }
+};
+
+// The same for keys below 2^53 (every array with fewer than 2^53 elements), entirely in double precision: k, the
+// quotient and the remainder k - q*d are all exactly representable, so one fma decides the +-1 correction and no
+// 64-bit integer multiply or conversion back is needed.  Group ids are compared (and stored) as doubles.
+struct GroupOfD {
+  double d, rd;
+  __device__ __forceinline__ double operator()(int64_t k) const {
+    const double kd = (double)k;
+    double q = __builtin_floor(kd * rd);
+    const double r = __builtin_fma(-q, d, kd);
+    if (r < 0.0) q -= 1.0;
+    if (r >= d) q += 1.0;
     return q;
   }
 };
@@ -55,36 +70,36 @@ __device__ __forceinline__ T gr_apply(int op, T x, T y) {
 }
 
 // a partial result: `c` elements combined into `v` (c == 0: empty)
-template <typename T>
+template <typename T, typename C = int64_t>
 struct Part {
   T v;
-  int64_t c;
+  C c;
 };
-template <typename T>
-__device__ __forceinline__ Part<T> gr_join(int op, Part<T> a, Part<T> b) {  // a then b (a is to the left)
+template <typename T, typename C>
+__device__ __forceinline__ Part<T, C> gr_join(int op, Part<T, C> a, Part<T, C> b) {  // a then b (a is to the left)
   if (a.c == 0) return b;
   if (b.c == 0) return a;
-  return Part<T>{gr_apply(op, a.v, b.v), a.c + b.c};
+  return Part<T, C>{gr_apply(op, a.v, b.v), (C)(a.c + b.c)};
 }
 
 // summary of a span for the segmented scan: does it contain a head, and the partial after its last head
 // (or of the whole span if it has none)
-template <typename T>
+template <typename T, typename C = int64_t>
 struct Span {
-  Part<T> tail;
+  Part<T, C> tail;
   int heads;
 };
-template <typename T>
-__device__ __forceinline__ Span<T> gr_concat(int op, Span<T> a, Span<T> b) {
-  Span<T> r;
+template <typename T, typename C>
+__device__ __forceinline__ Span<T, C> gr_concat(int op, Span<T, C> a, Span<T, C> b) {
+  Span<T, C> r;
   r.heads = a.heads + b.heads;
   r.tail = b.heads ? b.tail : gr_join(op, a.tail, b.tail);
   return r;
 }
 
-template <typename T>
-__device__ __forceinline__ Span<T> gr_shfl_up(Span<T> s, int delta) {
-  Span<T> r;
+template <typename T, typename C>
+__device__ __forceinline__ Span<T, C> gr_shfl_up(Span<T, C> s, int delta) {
+  Span<T, C> r;
   r.tail.v = __shfl_up(s.tail.v, delta, 64);
   r.tail.c = __shfl_up(s.tail.c, delta, 64);
   r.heads = __shfl_up(s.heads, delta, 64);
@@ -94,28 +109,29 @@ __device__ __forceinline__ Span<T> gr_shfl_up(Span<T> s, int delta) {
 // Exclusive segmented scan of one Span per thread over a workgroup of NT threads (NT / 64 waves).
 // Returns the concatenation of all spans of lower-numbered threads; *total (if non-null, valid in the last
 // thread... returned to every thread through LDS) receives the whole workgroup's span.
-template <typename T, int NT>
-__device__ __forceinline__ Span<T> gr_block_exclusive(int op, Span<T> mine, Span<T>* lds_wave, Span<T>* total) {
+template <typename T, typename C, int NT>
+__device__ __forceinline__ Span<T, C> gr_block_exclusive(int op, Span<T, C> mine, Span<T, C>* lds_wave,
+                                                         Span<T, C>* total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  Span<T> inc = mine;
+  Span<T, C> inc = mine;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
-    Span<T> o = gr_shfl_up(inc, d);
+    Span<T, C> o = gr_shfl_up(inc, d);
     if (lane >= d) inc = gr_concat(op, o, inc);
   }
   if (lane == 63) lds_wave[wave] = inc;
   __syncthreads();
-  Span<T> before;  // spans of the earlier waves
+  Span<T, C> before;  // spans of the earlier waves
   before.tail.c = 0;
   before.tail.v = (T)0;
   before.heads = 0;
   for (int w = 0; w < wave; ++w) before = gr_concat(op, before, lds_wave[w]);
   if (total) {
-    Span<T> all = before;
+    Span<T, C> all = before;
     for (int w = wave; w < NT / 64; ++w) all = gr_concat(op, all, lds_wave[w]);
     *total = all;
   }
-  Span<T> exc = gr_shfl_up(inc, 1);
+  Span<T, C> exc = gr_shfl_up(inc, 1);
   if (lane == 0) {
     exc.tail.c = 0;
     exc.tail.v = (T)0;
@@ -125,35 +141,42 @@ __device__ __forceinline__ Span<T> gr_block_exclusive(int op, Span<T> mine, Span
   return gr_concat(op, before, exc);
 }
 
-// GR_ITEMS consecutive keys of a thread: one 16-byte load when they are all in range (base is even, the array is
-// 16-byte aligned: checked by the caller), else element by element (the last thread of the array)
-__device__ __forceinline__ void gr_load_keys(const int64_t* __restrict__ keys, int64_t base, int64_t n, int64_t (&k)[GR_ITEMS]) {
-  static_assert(GR_ITEMS == 2, "one 16-byte load per thread");
+// GR_ITEMS consecutive elements of a thread: 16-byte loads when they are all in range (base is a multiple of 4, the
+// arrays are 16-byte aligned: checked by the caller), else element by element (the last thread of the array)
+template <typename E>
+__device__ __forceinline__ void gr_load(const E* __restrict__ p, int64_t base, int64_t n, E (&x)[GR_ITEMS]) {
+  constexpr int PER = sizeof(E) >= 16 ? 1 : (int)(16 / sizeof(E));     // elements per 16-byte load
+  constexpr int W = PER < GR_ITEMS ? PER : GR_ITEMS;
   if (base + GR_ITEMS <= n) {
-    const Vec<int64_t, 2> v = *reinterpret_cast<const Vec<int64_t, 2>*>(keys + base);
-    k[0] = v.v[0];
-    k[1] = v.v[1];
+#pragma unroll
+    for (int j = 0; j < GR_ITEMS; j += W) {
+      const Vec<E, W> v = *reinterpret_cast<const Vec<E, W>*>(p + base + j);
+#pragma unroll
+      for (int e = 0; e < W; ++e) x[j + e] = v.v[e];
+    }
   } else {
-    k[0] = keys[base];
-    k[1] = 0;
+#pragma unroll
+    for (int j = 0; j < GR_ITEMS; ++j) x[j] = base + j < n ? p[base + j] : (E)0;
   }
 }
 
-__global__ void __launch_bounds__(GR_THREADS) gr_count_kernel(const int64_t* __restrict__ keys, int64_t n, GroupOf gof,
+template <typename G>
+__global__ void __launch_bounds__(GR_THREADS) gr_count_kernel(const int64_t* __restrict__ keys, int64_t n, G gof,
                                                               int64_t* __restrict__ tile_heads) {
+  using GT = decltype(gof((int64_t)0));
   __shared__ int wsum[GR_THREADS / 64];
   const int64_t base = (int64_t)blockIdx.x * GR_TILE + (int64_t)threadIdx.x * GR_ITEMS;
   int cnt = 0;
   if (base < n) {
     int64_t k[GR_ITEMS];
-    gr_load_keys(keys, base, n, k);
+    gr_load(keys, base, n, k);
     // the group of the element before mine: lane - 1 has it (its last key), except in lane 0 of a wave
     const int64_t left = __shfl_up(k[GR_ITEMS - 1], 1, 64);
-    int64_t prev = (threadIdx.x & 63) ? gof(left) : (base > 0 ? gof(keys[base - 1]) : -1);
+    GT prev = (threadIdx.x & 63) ? gof(left) : (base > 0 ? gof(keys[base - 1]) : (GT)-1);
 #pragma unroll
     for (int j = 0; j < GR_ITEMS; ++j) {
       if (base + j < n) {
-        const int64_t g = gof(k[j]);
+        const GT g = gof(k[j]);
         cnt += g != prev;
         prev = g;
       }
@@ -174,23 +197,33 @@ __global__ void __launch_bounds__(GR_THREADS) gr_count_kernel(const int64_t* __r
 // Writes gids / vals / counts of every run that starts in this tile and is closed inside it, and
 //   open_head[b]  = partial of the elements before the tile's first head (they belong to run tile_first[b]-1)
 //   open_tail[b]  = partial after the tile's last head (run tile_first[b+1]-1), or of the whole tile if it has no head
-template <typename T>
+template <typename T, typename G>
 __global__ void __launch_bounds__(GR_THREADS)
-gr_reduce_kernel(int op, const int64_t* __restrict__ keys, const T* __restrict__ data, int64_t n, GroupOf gof,
+gr_reduce_kernel(int op, const int64_t* __restrict__ keys, const T* __restrict__ data, int64_t n, G gof,
                  const int64_t* __restrict__ tile_first, int64_t* __restrict__ gids, T* __restrict__ vals,
                  int64_t* __restrict__ counts, Part<T>* __restrict__ open_head, Part<T>* __restrict__ open_tail) {
-  __shared__ Span<T> lds_wave[GR_THREADS / 64];
+  using GT = decltype(gof((int64_t)0));
+  using C = int;  // run lengths inside a tile fit 32 bits (one shuffle less per scan step)
+  __shared__ Span<T, C> lds_wave[GR_THREADS / 64];
   const int64_t base = (int64_t)blockIdx.x * GR_TILE + (int64_t)threadIdx.x * GR_ITEMS;
-  int64_t g[GR_ITEMS];
+  GT g[GR_ITEMS];
   T v[GR_ITEMS];
   bool h[GR_ITEMS];
-  int64_t kk[GR_ITEMS] = {0, 0};
-  if (base < n) gr_load_keys(keys, base, n, kk);
+  int64_t kk[GR_ITEMS];
+#pragma unroll
+  for (int j = 0; j < GR_ITEMS; ++j) {
+    kk[j] = 0;
+    v[j] = (T)0;
+  }
+  if (base < n) {
+    gr_load(keys, base, n, kk);
+    gr_load(data, base, n, v);
+  }
   // (every lane takes part in the shuffle; lanes past the end hold zeros nobody reads)
   const int64_t left = __shfl_up(kk[GR_ITEMS - 1], 1, 64);
-  int64_t prev = -1;
-  if (base < n) prev = (threadIdx.x & 63) ? gof(left) : (base > 0 ? gof(keys[base - 1]) : -1);
-  Span<T> mine;
+  GT prev = (GT)-1;
+  if (base < n) prev = (threadIdx.x & 63) ? gof(left) : (base > 0 ? gof(keys[base - 1]) : (GT)-1);
+  Span<T, C> mine;
   mine.heads = 0;
   mine.tail.c = 0;
   mine.tail.v = (T)0;
@@ -199,43 +232,42 @@ gr_reduce_kernel(int op, const int64_t* __restrict__ keys, const T* __restrict__
     h[j] = false;
     if (base + j < n) {
       g[j] = gof(kk[j]);
-      v[j] = data[base + j];
       h[j] = g[j] != prev;
       prev = g[j];
       if (h[j]) {
         mine.heads += 1;
-        mine.tail = Part<T>{v[j], 1};
+        mine.tail = Part<T, C>{v[j], 1};
       } else {
-        mine.tail = gr_join(op, mine.tail, Part<T>{v[j], 1});
+        mine.tail = gr_join(op, mine.tail, Part<T, C>{v[j], 1});
       }
     }
   }
-  Span<T> all;
-  const Span<T> before = gr_block_exclusive<T, GR_THREADS>(op, mine, lds_wave, &all);
+  Span<T, C> all;
+  const Span<T, C> before = gr_block_exclusive<T, C, GR_THREADS>(op, mine, lds_wave, &all);
   // second walk: close runs
   const int64_t first = tile_first[blockIdx.x];
   int64_t k = before.heads;      // heads seen so far in this tile
-  Part<T> run = before.tail;     // the open run entering my items
+  Part<T, C> run = before.tail;  // the open run entering my items
 #pragma unroll
   for (int j = 0; j < GR_ITEMS; ++j) {
     if (base + j < n) {
       if (h[j]) {
         if (k == 0) {
-          open_head[blockIdx.x] = run;  // elements of a run that started in an earlier tile
+          open_head[blockIdx.x] = Part<T>{run.v, run.c};  // elements of a run that started in an earlier tile
         } else {
           vals[first + k - 1] = run.v;
           counts[first + k - 1] = run.c;
         }
-        gids[first + k] = g[j];
+        gids[first + k] = (int64_t)g[j];
         ++k;
-        run = Part<T>{v[j], 1};
+        run = Part<T, C>{v[j], 1};
       } else {
-        run = gr_join(op, run, Part<T>{v[j], 1});
+        run = gr_join(op, run, Part<T, C>{v[j], 1});
       }
     }
   }
   if (threadIdx.x == GR_THREADS - 1) {
-    open_tail[blockIdx.x] = all.tail;
+    open_tail[blockIdx.x] = Part<T>{all.tail.v, all.tail.c};
     if (all.heads == 0) open_head[blockIdx.x] = Part<T>{(T)0, 0};  // everything is in open_tail
   }
 }
@@ -298,7 +330,7 @@ gr_fixup_kernel(int op, int64_t ntiles, const int64_t* __restrict__ tile_heads, 
     s.tail = open_tail[b];
     mine = gr_concat(op, mine, s);
   }
-  const Span<T> before = gr_block_exclusive<T, 1024>(op, mine, lds_wave, nullptr);
+  const Span<T> before = gr_block_exclusive<T, int64_t, 1024>(op, mine, lds_wave, nullptr);
   Part<T> carry = before.tail;  // the open run entering tile b0
   for (int64_t b = b0; b < b1; ++b) {
     if (tile_heads[b]) {
@@ -326,8 +358,9 @@ static int64_t gr_tiles(int64_t n) { return ceil_div(n, (int64_t)GR_TILE); }
 static size_t gr_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 template <typename T>
-static int group_reduce_t(int op, int64_t n, const int64_t* keys, int64_t divisor, const T* data, int64_t* gids, T* vals,
-                          int64_t* counts, int64_t* n_groups, char* ws, size_t ws_bytes, hipStream_t s) {
+static int group_reduce_t(int op, int64_t n, const int64_t* keys, int64_t divisor, int64_t key_bound, const T* data,
+                          int64_t* gids, T* vals, int64_t* counts, int64_t* n_groups, char* ws, size_t ws_bytes,
+                          hipStream_t s) {
   const int64_t nt = gr_tiles(n);
   // workspace: tile_heads[nt+1] | tile_first[nt+1] | open_head[nt] | open_tail[nt] | scan temp
   int64_t* tile_heads = reinterpret_cast<int64_t*>(ws);
@@ -339,13 +372,23 @@ static int group_reduce_t(int op, int64_t n, const int64_t* keys, int64_t diviso
   size_t scan_bytes = ws_bytes - (size_t)(scan_ws - ws);
   hipError_t em = hipMemsetAsync(need_chain, 0, sizeof(int), s);
   if (em != hipSuccess) return (int)em;
+  // keys are < key_bound (the caller's array size): below 2^53 the group ids are computed in double precision
+  const bool small = key_bound > 0 && key_bound <= ((int64_t)1 << 53);
   const GroupOf gof{divisor, 1.0 / (double)divisor};
-  hipLaunchKernelGGL(gr_count_kernel, dim3((unsigned)nt), dim3(GR_THREADS), 0, s, keys, n, gof, tile_heads);
+  const GroupOfD gofd{(double)divisor, 1.0 / (double)divisor};
+  if (small)
+    hipLaunchKernelGGL(gr_count_kernel<GroupOfD>, dim3((unsigned)nt), dim3(GR_THREADS), 0, s, keys, n, gofd, tile_heads);
+  else
+    hipLaunchKernelGGL(gr_count_kernel<GroupOf>, dim3((unsigned)nt), dim3(GR_THREADS), 0, s, keys, n, gof, tile_heads);
   hipError_t e = rocprim::exclusive_scan(scan_ws, scan_bytes, tile_heads, tile_first, (int64_t)0, (size_t)(nt + 1),
                                          rocprim::plus<int64_t>(), s);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(gr_reduce_kernel<T>, dim3((unsigned)nt), dim3(GR_THREADS), 0, s, op, keys, data, n, gof, tile_first,
-                     gids, vals, counts, open_head, open_tail);
+  if (small)
+    hipLaunchKernelGGL((gr_reduce_kernel<T, GroupOfD>), dim3((unsigned)nt), dim3(GR_THREADS), 0, s, op, keys, data, n, gofd,
+                       tile_first, gids, vals, counts, open_head, open_tail);
+  else
+    hipLaunchKernelGGL((gr_reduce_kernel<T, GroupOf>), dim3((unsigned)nt), dim3(GR_THREADS), 0, s, op, keys, data, n, gof,
+                       tile_first, gids, vals, counts, open_head, open_tail);
   hipLaunchKernelGGL(gr_fix_fast_kernel<T>, dim3((unsigned)ceil_div(nt, (int64_t)256)), dim3(256), 0, s, op, nt, tile_heads,
                      tile_first, open_head, open_tail, vals, counts, n_groups, need_chain);
   hipLaunchKernelGGL(gr_fixup_kernel<T>, dim3(1), dim3(1024), 0, s, op, nt, tile_heads, tile_first, open_head, open_tail,
@@ -368,17 +411,17 @@ extern "C" int64_t spamd_group_reduce_ws_bytes(int val_dtype, int64_t n) {
 }
 
 extern "C" int spamd_group_reduce(int op, int val_dtype, int64_t n, const int64_t* keys, int64_t divisor,
-                                  const void* data, int64_t* group_ids, void* values, int64_t* counts,
+                                  int64_t key_bound, const void* data, int64_t* group_ids, void* values, int64_t* counts,
                                   int64_t* n_groups, void* ws, int64_t ws_bytes, void* stream) {
   if (n < 0 || divisor <= 0 || op < 0 || op > GR_AND) return SPAMD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (n == 0) return (int)hipMemsetAsync(n_groups, 0, sizeof(int64_t), s);
-  if (ws_bytes < spamd_group_reduce_ws_bytes(val_dtype, n) || ((uintptr_t)ws % 16) || ((uintptr_t)keys % 16))
+  if (ws_bytes < spamd_group_reduce_ws_bytes(val_dtype, n) || ((uintptr_t)ws % 16) || ((uintptr_t)keys % 16) || ((uintptr_t)data % 16))
     return SPAMD_EINVAL;
   // the tile_heads array has nt + 1 entries for the scan; the last one is ignored by it but must be readable
 #define GR_CASE(CODE, T)                                                                                           \
   case CODE:                                                                                                       \
-    return group_reduce_t<T>(op, n, keys, divisor, (const T*)data, group_ids, (T*)values, counts, n_groups, (char*)ws, \
+    return group_reduce_t<T>(op, n, keys, divisor, key_bound, (const T*)data, group_ids, (T*)values, counts, n_groups, (char*)ws, \
                              (size_t)ws_bytes, s);
   switch (val_dtype) {
     GR_CASE(SPAMD_F32, float)
