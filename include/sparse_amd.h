@@ -238,6 +238,12 @@ int spamd_segment_reduce(int op, int val_dtype, int64_t n, const void* data, con
                          const int64_t* offsets, int64_t nseg, void* out, int64_t* counts,
                          int64_t* seg_start_ws, void* stream);
 
+/* A8 epilogue in one launch: fold the implicit fill entries of each group into vals[i] (reference
+ * _sparse_array.py:405-422).  counts[i] = stored elements of group i, n_cols = elements per group; the fill value
+ * is passed both as double and as int64 (the one matching val_dtype is used).  add/multiply use the closed form
+ * in the work dtype (float64 for floating results), the other ops fold fv in once where counts[i] != n_cols. */
+int spamd_reduce_fill(int op, int val_dtype, int64_t n, void* vals, const int64_t* counts, int64_t n_cols, double fill_f,
+                      int64_t fill_i, void* stream);
 /* A8 in one pass: runs of equal (keys[i] / divisor) over SORTED keys are reduced together with their lengths
  * (two streaming passes, csrc/group_reduce.hip; fp sums in a fixed, reproducible order).  Outputs hold up to n entries;
  * *n_groups (device int64) receives the number of runs.  op as for spamd_segment_reduce;

@@ -121,25 +121,17 @@ def reduce_impl(x, method, axis=(0,), keepdims=False, **kwargs):
 
     result_fill = np.asarray(fv).astype(res_np_dtype)[()] if name not in ("logical_or", "logical_and") else np.bool_(fv)
     if count:
-        ncols_t = _scalar_dev(n_cols, torch.int64, dev)
-        if super_ufunc is None:
-            # groups with implicit fill entries fold the fill value in once (reference :405-408)
-            missing = binary_arrays("not_equal", counts, ncols_t, b_scalar=True)
-            fvt = _scalar_dev(result_fill.item(), vals.dtype if vals.dtype != torch.uint8 else torch.uint8, dev)
-            folded = binary_arrays(name, vals, fvt, b_scalar=True)
-            vals = select(missing, folded, vals)
-        else:
-            # add / multiply closed form (reference :409-422)
-            n_fill = binary_arrays("subtract", ncols_t, counts, a_scalar=True)
-            work_np = np.result_type(res_np_dtype, np.float64) if res_np_dtype.kind == "f" else res_np_dtype
-            nf = K.convert(n_fill, torch_dtype(work_np))
-            fvw = _scalar_dev(np.asarray(fv).astype(work_np).item(), torch_dtype(work_np), dev)
-            contrib = binary_arrays("multiply" if name == "add" else "power", fvw, nf, a_scalar=True)
-            ident = _scalar_dev(method.identity, torch_dtype(work_np), dev)
-            is_zero = binary_arrays("equal", n_fill, _scalar_dev(0, torch.int64, dev), b_scalar=True)
-            contrib = select(is_zero, ident.expand(count).contiguous(), contrib)
-            vw = K.convert(vals, torch_dtype(work_np))
-            vals = K.convert(binary_arrays(name, vw, contrib), vals.dtype)
+        # fold the implicit fill entries of every group in (reference :405-422): one launch
+        vcode = _ffi.U8 if vals.dtype == torch.uint8 else code_of(vals.dtype)
+        fvn = np.asarray(result_fill if super_ufunc is None else fv)
+        with np.errstate(all="ignore"):
+            if fvn.dtype.kind == "c":
+                raise NotImplementedError("complex reductions are not on the hip backend's path")
+            fill_f = float(fvn.astype(np.float64)) if fvn.dtype.kind != "b" else float(bool(fvn))
+            fill_i = int(fvn.astype(res_np_dtype if res_np_dtype.kind in "iu" else np.int64)) if np.isfinite(fill_f) else 0
+        vals = vals.contiguous()
+        _ffi.call("spamd_reduce_fill", _RED_OPS[name], vcode, count, ptr(vals), ptr(counts.contiguous()), int(n_cols),
+                  fill_f, fill_i, stream_ptr(dev))
     if super_ufunc is not None:
         with np.errstate(all="ignore"):
             result_fill = np.asarray(super_ufunc(fv, n_cols)).astype(res_np_dtype)[()]

@@ -119,7 +119,14 @@ __device__ __forceinline__ T bin_tt(int op, T a, T b) {
     case B_POW:
       if constexpr (std::is_same<T, float>::value) return powf(a, b);
       else if constexpr (std::is_same<T, double>::value) return pow(a, b);
-      else { T r = 1; for (T k = 0; k < b; ++k) r *= a; return r; }
+      else {  // integer power by squaring: same wrap-around result as b successive multiplications
+        T r = 1;
+        for (T e = b; e > 0; e >>= 1) {
+          if (e & 1) r *= a;
+          a *= a;
+        }
+        return r;
+      }
   }
   return T(0);
 }
@@ -396,6 +403,52 @@ extern "C" int spamd_ewise_unary(int op, int val_dtype, int64_t n, const void* a
       hipLaunchKernelGGL(unary_tb_kernel<T>, dim3(grid_for(n)), dim3(256), 0, s, op, (const T*)a, n, (uint8_t*)out);
     else
       hipLaunchKernelGGL(unary_tt_kernel<T>, dim3(grid_for(n)), dim3(256), 0, s, op, (const T*)a, n, (T*)out);
+  })
+  return launch_status();
+}
+
+// A8 epilogue: fold the implicit fill entries of every group into its reduced value in ONE kernel (reference
+// _sparse_array.py:405-422; it was nine elementwise launches and four host-to-device scalar copies):
+//   add / multiply   closed form  value (+|*) (n_fill == 0 ? identity : fv*n_fill | fv**n_fill), evaluated in the work
+//                    dtype (float64 for floating results, the result dtype for integers) and cast back;
+//   other ops        op(value, fv) for the groups that have at least one implicit entry.
+template <typename T>
+__global__ void __launch_bounds__(256) reduce_fill_kernel(int op, int64_t n, T* __restrict__ vals,
+                                                          const int64_t* __restrict__ counts, int64_t n_cols,
+                                                          double fv_f, int64_t fv_i) {
+#pragma clang fp contract(off)
+  GRID_STRIDE(i, n) {
+    const int64_t n_fill = n_cols - counts[i];
+    if (op == R_ADD || op == R_MUL) {
+      if constexpr (std::is_floating_point<T>::value) {
+        double contrib;
+        if (n_fill == 0) contrib = op == R_ADD ? 0.0 : 1.0;
+        else contrib = op == R_ADD ? fv_f * (double)n_fill : pow(fv_f, (double)n_fill);
+        const double v = (double)vals[i];
+        vals[i] = (T)(op == R_ADD ? v + contrib : v * contrib);
+      } else {
+        T contrib;
+        if (n_fill == 0) contrib = op == R_ADD ? T(0) : T(1);
+        else contrib = op == R_ADD ? (T)((T)fv_i * (T)n_fill) : bin_tt<T>(B_POW, (T)fv_i, (T)n_fill);
+        vals[i] = op == R_ADD ? (T)(vals[i] + contrib) : (T)(vals[i] * contrib);
+      }
+    } else if (n_fill != 0) {
+      T fv;
+      if constexpr (std::is_floating_point<T>::value) fv = (T)fv_f;
+      else fv = (T)fv_i;
+      vals[i] = red<T>(op, vals[i], fv);
+    }
+  }
+}
+
+extern "C" int spamd_reduce_fill(int op, int val_dtype, int64_t n, void* vals, const int64_t* counts, int64_t n_cols,
+                                 double fill_f, int64_t fill_i, void* stream) {
+  if (n < 0 || op < R_ADD || op > R_AND) return SPAMD_EINVAL;
+  if (n == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  VAL_SWITCH5(val_dtype, T, {
+    hipLaunchKernelGGL(reduce_fill_kernel<T>, dim3(grid_for(n)), dim3(256), 0, s, op, n, (T*)vals, counts, n_cols, fill_f,
+                       fill_i);
   })
   return launch_status();
 }
