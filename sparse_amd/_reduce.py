@@ -109,8 +109,11 @@ def reduce_impl(x, method, axis=(0,), keepdims=False, **kwargs):
     order = kept + tuple(axis)
     if order != tuple(range(x.ndim)) and x.nnz:
         keys = K.permute_keys(keys, x.shape, order)
-        keys, perm = K.sort_keys(keys, max(x.size - 1, 1))
-        data = K.gather(data, perm)
+        if data.element_size() in (4, 8):  # the values ride along as the sort payload (no permutation + gather)
+            keys, data = K.sort_key_value(keys, data, max(x.size - 1, 1))
+        else:
+            keys, perm = K.sort_keys(keys, max(x.size - 1, 1))
+            data = K.gather(data, perm)
     if x.nnz:
         gids, vals, counts, count = group_reduce(keys, max(n_cols, 1), data, name, key_bound=max(int(x.size), 1))
     else:
@@ -190,8 +193,11 @@ def var_impl(x, axis=None, dtype=None, ddof=0, keepdims=False):
     order = kept + tuple(axis)
     if order != tuple(range(x.ndim)) and x.nnz:
         keys = K.permute_keys(keys, x.shape, order)
-        keys, perm = K.sort_keys(keys, max(x.size - 1, 1))
-        data = K.gather(data, perm)
+        if data.element_size() in (4, 8):  # the values ride along as the sort payload (no permutation + gather)
+            keys, data = K.sort_key_value(keys, data, max(x.size - 1, 1))
+        else:
+            keys, perm = K.sort_keys(keys, max(x.size - 1, 1))
+            data = K.gather(data, perm)
     denom = max(rcount - ddof, 0)
     if x.nnz:
         one64 = _scalar_dev(1, torch.int64, dev)
