@@ -107,16 +107,54 @@ class COO(SparseArray, NDArrayOperatorsMixin):
                           "dense array. You may want to use a dense array here instead.", RuntimeWarning, stacklevel=1)
 
         self._keys = None  # sorted C-order linear keys when known (device int64[nnz])
+        self._coords_dtype = self.__dict__["_coords"].dtype
         if not sorted or has_duplicates:
             self._canonicalize(do_sort=not sorted, do_sum=has_duplicates)
         if prune:
             self._prune()
 
+    # ---- coordinates: materialised lazily --------------------------------------------------------
+    # Every kernel on the path works on the sorted C-order linear keys (`_keys`); the [ndim, nnz] coordinate
+    # matrix the reference stores is only needed at the API boundary, so results built from keys
+    # (`_from_sorted_keys`: elementwise, transpose, reshape, from_numpy) split them into coordinates on first
+    # access of `.coords` (saves 24 B per element of writes for a 3-D result that is consumed by another op).
+    @property
+    def coords(self):
+        c = self.__dict__.get("_coords")
+        if c is None:
+            c = K.delinearize(self._keys, self.shape, self._coords_dtype)
+            self.__dict__["_coords"] = c
+        return c
+
+    @coords.setter
+    def coords(self, value):
+        self.__dict__["_coords"] = value
+
+    @property
+    def _index_dtype(self):
+        c = self.__dict__.get("_coords")
+        return c.dtype if c is not None else self._coords_dtype
+
+    @classmethod
+    def _from_sorted_keys(cls, keys, data, shape, fill_value, idx_dtype, prune=False):
+        """Canonical COO from sorted, duplicate-free linear keys; coordinates are produced on demand."""
+        out = cls.__new__(cls)
+        out.__dict__["_coords"] = None
+        out._coords_dtype = idx_dtype
+        out._keys = keys
+        out.data = data
+        out.shape = tuple(int(d) for d in shape)
+        out.fill_value = fill_value
+        out._cache = None
+        if prune:
+            out._prune()
+        return out
+
     # ---- canonical form (Appendix D1) ---------------------------------------------------------
     def linear_loc(self):
         """C-order linear index of every stored element (reference core.py `linear_loc`)."""
         if getattr(self, "_keys", None) is None or self._keys.numel() != self.nnz:
-            return K.linearize(self.coords, self.shape)
+            self._keys = K.linearize(self.coords, self.shape)
         return self._keys
 
     def _canonicalize(self, do_sort, do_sum):
@@ -170,14 +208,17 @@ class COO(SparseArray, NDArrayOperatorsMixin):
         count = int(offs[-1])
         if count == self.nnz:
             return
-        self.coords = K.compact(self.coords, flags, offs, count)
+        if self.__dict__.get("_coords") is not None:
+            self.coords = K.compact(self.coords, flags, offs, count)
         self.data = K.compact(self.data, flags, offs, count)
         if getattr(self, "_keys", None) is not None:
             self._keys = K.compact(self._keys, flags, offs, count)
 
     # ---- construction / copies ---------------------------------------------------------------
     def _make_shallow_copy_of(self, other):
-        self.coords, self.data, self.shape = other.coords, other.data, other.shape
+        self.__dict__["_coords"] = other.__dict__.get("_coords")
+        self._coords_dtype = other._index_dtype
+        self.data, self.shape = other.data, other.shape
         self.fill_value = other.fill_value
         self._cache = None
         self._keys = getattr(other, "_keys", None)
@@ -220,10 +261,7 @@ class COO(SparseArray, NDArrayOperatorsMixin):
         keys = K.compact(iota, flags, offs, count)
         data = K.compact(flat, flags, offs, count)
         it = torch.int64 if idx_dtype is None or np.dtype(idx_dtype).itemsize > 4 else torch.int32
-        coords = K.delinearize(keys, shape, it)
-        out = cls(coords, data, shape=shape, has_duplicates=False, sorted=True, fill_value=fill_value)
-        out._keys = keys
-        return out
+        return cls._from_sorted_keys(keys, data, shape, fill_value, it)
 
     @classmethod
     def from_scipy_sparse(cls, x, /, *, fill_value=None, device=None):
@@ -261,7 +299,8 @@ class COO(SparseArray, NDArrayOperatorsMixin):
     # ---- properties ----------------------------------------------------------------------------
     @property
     def nnz(self):
-        return int(self.coords.shape[1])
+        c = self.__dict__.get("_coords")
+        return int(c.shape[1]) if c is not None else int(self.data.numel())
 
     @property
     def format(self):
@@ -269,7 +308,8 @@ class COO(SparseArray, NDArrayOperatorsMixin):
 
     @property
     def nbytes(self):
-        return self.data.numel() * self.data.element_size() + self.coords.numel() * self.coords.element_size()
+        isz = 8 if self._index_dtype == torch.int64 else 4
+        return self.data.numel() * self.data.element_size() + self.nnz * self.ndim * isz
 
     @property
     def T(self):
@@ -307,9 +347,7 @@ class COO(SparseArray, NDArrayOperatorsMixin):
         shape = tuple(self.shape[ax] for ax in axes)
         keys = K.permute_keys(self.linear_loc(), self.shape, axes)
         keys, perm = K.sort_keys(keys, max(self.size - 1, 1))
-        out = COO(K.delinearize(keys, shape, self.coords.dtype), K.gather(self.data, perm), shape=shape,
-                  has_duplicates=False, sorted=True, fill_value=self.fill_value)
-        out._keys = keys
+        out = COO._from_sorted_keys(keys, K.gather(self.data, perm), shape, self.fill_value, self._index_dtype)
         if self._cache is not None:
             self._cache[("transpose", axes)] = out
             while len(self._cache) > 3:
@@ -333,12 +371,10 @@ class COO(SparseArray, NDArrayOperatorsMixin):
         if self._cache is not None and ("reshape", shape) in self._cache:
             return self._cache[("reshape", shape)]
         keys = self.linear_loc()
-        it = self.coords.dtype
+        it = self._index_dtype
         if it == torch.int32 and shape and max(shape) >= 2 ** 31:
             it = torch.int64
-        coords = K.delinearize(keys, shape, it)
-        out = COO(coords, self.data, shape=shape, has_duplicates=False, sorted=True, fill_value=self.fill_value)
-        out._keys = keys
+        out = COO._from_sorted_keys(keys, self.data, shape, self.fill_value, it)
         if self._cache is not None:
             self._cache[("reshape", shape)] = out
             while len(self._cache) > 3:

@@ -204,9 +204,7 @@ def elemwise(func, *args, **kwargs):
             data = K.compact(_as_u8(data), flags, offs, cnt)
             data = data.view(torch.bool) if fill.dtype == np.dtype(bool) and data.dtype == torch.uint8 else data
         ref = next(a for a in proc if isinstance(a, COO))
-        coords = K.delinearize(keys, shape, ref.coords.dtype)
-        out = COO(coords, data, shape=shape, has_duplicates=False, sorted=True, fill_value=fill)
-        out._keys = keys
+        out = COO._from_sorted_keys(keys, data, shape, fill, ref._index_dtype)
         return out.asformat(out_type, **out_kwargs) if out_type != "coo" else out
 
     coo_args = [a for a in proc if isinstance(a, COO)]
@@ -335,9 +333,7 @@ def elemwise(func, *args, **kwargs):
         # default: one fused merge-path pass (function + prune inside the kernel)
         fill_in_kernel = fill if code not in _TO_BOOL_BIN else np.uint8(bool(fill))
         keys, res = merge_union(name, a.linear_loc(), ad, b.linear_loc(), bd, fa, fb, fill_in_kernel)
-        coords = K.delinearize(keys, shape, a.coords.dtype)
-        out = COO(coords, res, shape=shape, has_duplicates=False, sorted=True, fill_value=fill)
-        out._keys = keys
+        out = COO._from_sorted_keys(keys, res, shape, fill, a._index_dtype)
         return out.asformat(out_type, **out_kwargs) if out_type != "coo" else out
     keys, slotA, slotB = union_merge(a.linear_loc(), b.linear_loc())
     n = int(keys.numel())
