@@ -65,7 +65,14 @@ def main():
     nnz = 1_000_000 // q
     x = sp.random((1000, 1000, 1000), nnz=nnz, random_state=0)
     y = sp.random((1000, 1000, 1000), nnz=nnz, random_state=1)
-    for name, f in (("add", lambda: x + y), ("multiply", lambda: x * y)):
+    def with_coords(f):  # results are built on linear keys; `.coords` splits them on demand
+        def g():
+            r = f()
+            r.coords
+            return r
+        return g
+
+    for name, f in (("add", lambda: x + y), ("multiply", lambda: x * y), ("add + .coords", with_coords(lambda: x + y))):
         ms, z = timed(f)
         b = 2 * nnz * (3 * 8 + 8) + z.nnz * (3 * 8 + 8)
         out.append(line(f"A7 elementwise {name}", f"COO(1000^3, {nnz} nnz, f64/int64) {name} COO", ms, b,
@@ -83,12 +90,13 @@ def main():
         nb = 100_000_000
         xb = sp.random((1000, 1000, 1000), nnz=nb, random_state=10)
         yb = sp.random((1000, 1000, 1000), nnz=nb, random_state=11)
-        for name, f in (("add", lambda: xb + yb), ("multiply", lambda: xb * yb)):
+        for name, f in (("add", lambda: xb + yb), ("multiply", lambda: xb * yb),
+                        ("add + .coords", with_coords(lambda: xb + yb))):
             ms, z = timed(f, reps=3)
             out.append(line(f"A7 elementwise {name} (1e8 nnz)", f"COO(1000^3, {nb} nnz each) {name}", ms,
                             2 * nb * 32 + z.nnz * 32, out_nnz=z.nnz))
         ms, s = timed(lambda: xb.sum(axis=2), reps=3)
-        out.append(line("A8 reduce sum(axis=2) (1e8 nnz)", "runs of ~100 elements, wave per run", ms, nb * 16 + s.nnz * 16))
+        out.append(line("A8 reduce sum(axis=2) (1e8 nnz)", "runs of ~100 elements, two-pass grouped reduce", ms, nb * 16 + s.nnz * 16))
         del xb, yb, z, s
 
     # ---- config 3: 3-D COO tensordot with dense, axes=1 ------------------------------------------
