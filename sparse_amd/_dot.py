@@ -236,15 +236,18 @@ def _return_kind(return_type):
 
 
 def _tiled_eligible(data, bt, out_shape, Kd):
-    """The inspector/executor kernel covers fp32 x fp32 -> fp32 with N % 128 == 0; it pays off
-    when the (32-row, 128-column) lists hold more than a block or so on average and the grid fills the chip."""
+    """The inspector/executor kernel covers fp32 x fp32 -> fp32 with N % 128 == 0.  Thresholds measured on
+    MI355X (tools/tiled_crossover.py): it needs >= 128 workgroups of 512 rows to beat the row-group kernel, and
+    its (32-row x 128-column) lists must hold ~12 stored elements on average — 6 when B is too large for the
+    row-group kernel's gathers to stay in cache (>= 16 MB).  The inspector costs about one row-group product, so a
+    single product breaks even and every further one is ~2x faster."""
     M, N = out_shape
     if _settings.TILED_SPMM == "never":
         return False
     if data.dtype != torch.float32 or bt.dtype != torch.float32 or N == 0 or N % 128 or bt.dim() != 2:
         return False
-    nnz = int(data.numel())
-    return M >= 32768 and nnz * 4096 >= 12 * M * Kd
+    per_list = int(data.numel()) * 4096 / max(M * Kd, 1)
+    return M >= 65536 and (per_list >= 12 or (per_list >= 6 and Kd * N * 4 >= (16 << 20)))
 
 
 def prepare_spmm(a):

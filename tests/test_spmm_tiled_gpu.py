@@ -64,7 +64,7 @@ def test_tiled_edge_rows():
     assert torch.equal(got, ref) and not got.any()
 
 
-def _product_case(M=40000, K=2000, density=0.01, N=128, seed=5):
+def _product_case(M=70000, K=1500, density=0.01, N=128, seed=5):
     import sparse_amd as sp
 
     data, idx, ptr = random_csr(M, K, density, seed, np.float32, np.int32)
