@@ -193,6 +193,13 @@ def main():
         torch.cuda.synchronize()
         preprocess_warm_ms = (time.perf_counter() - t_pre) * 1e3   # the same build with a warm allocator
 
+    # the NaN pass of the reference's `matmul` (_common.py:245-246) is switched off in the timed region; its cost per
+    # product (values of A: memoised on the array after the first product; B: scanned every time) is reported
+    _settings.NAN_CHECK = True
+    _dot.check_class_nan(a)
+    nan_check_ms = dev_time(lambda: (_dot.check_class_nan(a), _dot.check_class_nan(b_full)), 5)
+    _settings.NAN_CHECK = False
+
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
@@ -239,7 +246,7 @@ def main():
                 "mul_add": "separate (bit-exact)" if args.exact else "fma",
                 "kernel": "spmm_tiled (cached block stream)" if tiled else "spmm_csr_rowgroup",
                 "preprocess_ms": preprocess_ms, "preprocess_warm_ms": preprocess_warm_ms,
-                "first_call_ms": first_call_ms,
+                "first_call_ms": first_call_ms, "nan_check_ms_per_product": nan_check_ms,
                 "first_call_gflops": flops / (first_call_ms * 1e-3) / 1e9 if first_call_ms else None,
             },
             "roofline": {

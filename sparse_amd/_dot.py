@@ -159,6 +159,18 @@ def check_class_nan(x):
         raise ValueError(f"Unsupported type {type(x)}")
     if data.numel() == 0 or not (data.is_floating_point() or data.is_complex()):
         return False
+    if isinstance(x, (COO, GCXS)):
+        # the stored values of an array do not change between products: remember the verdict per (buffer, version)
+        key = (data.data_ptr(), int(data.numel()), int(data._version))
+        memo = getattr(x, "_nan_memo", None)
+        if memo is not None and memo[0] == key:
+            return memo[1]
+        res = K.has_nan(data)
+        try:
+            x._nan_memo = (key, res)
+        except AttributeError:
+            pass
+        return res
     return K.has_nan(data)
 
 
