@@ -270,6 +270,25 @@ int spamd_spgemm_expand(int val_dtype, int idx_dtype, int64_t p0, int64_t np, co
                         const void* b_indptr, const int64_t* offsets, int64_t P, int64_t n_col, int64_t* keys,
                         void* vals, void* stream);
 
+/* A4 / A5, row-local form (csrc/spgemm_rows.hip): the products of an output row are expanded, radix-sorted by column
+ * and summed inside LDS by one workgroup; bit-identical to the expand-sort-compress above, without writing or
+ * sorting the products in HBM.  Usable when no output row has more products (and no A row more elements) than
+ * spamd_spgemm_rows_capacity(val_dtype) and n_col < 2^31 - 1; otherwise use the global form.
+ *   spamd_spgemm_row_products: prod[n_row + 1] (last entry zeroed) and maxes[2] = {max prod, longest A row};
+ *   caller: prod_off = spamd_exclusive_scan(prod), scratch tmp_cols/tmp_vals of prod_off[n_row] entries;
+ *   spamd_spgemm_rows: rows of C into the scratch at prod_off[row], their lengths into nnz_row[n_row + 1];
+ *   caller: out_indptr = spamd_exclusive_scan(nnz_row);
+ *   spamd_spgemm_pack: scratch -> (out_indices int64, out_data), columns ascending inside every row. */
+int spamd_spgemm_row_products(int idx_dtype, int64_t n_row, const void* a_indptr, const void* a_indices,
+                              const void* b_indptr, int64_t* prod, int64_t* maxes, void* stream);
+int64_t spamd_spgemm_rows_capacity(int val_dtype);
+int spamd_spgemm_rows(int val_dtype, int idx_dtype, int64_t n_row, int64_t n_col, const void* a_indptr,
+                      const void* a_indices, const void* a_data, const void* b_indptr, const void* b_indices,
+                      const void* b_data, const int64_t* prod_off, int64_t max_prod, int* tmp_cols, void* tmp_vals,
+                      int64_t* nnz_row, void* stream);
+int spamd_spgemm_pack(int val_dtype, int64_t n_row, const int64_t* prod_off, const int64_t* out_indptr,
+                      const int* tmp_cols, const void* tmp_vals, int64_t* out_indices, void* out_data, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * A9  SDDMM      out[n] = s[n] * sum_k A[rows[n], k] * Bt[cols[n], k]
  *   replaces the reference's formulation `s * (a @ b)` (examples/sddmm_example.py:51-52: a dense

@@ -492,10 +492,55 @@ def _spgemm_keys(n_row, n_col, a_data, a_indices, a_rows, b_data, b_indices, b_i
     return (torch.cat(out_keys), torch.cat(out_vals)) if len(out_keys) > 1 else (out_keys[0], out_vals[0])
 
 
+SPGEMM_ROW_LOCAL = True  # tuning hook: False = always the global expand-sort-compress
+
+
+def _spgemm_rows(n_row, n_col, a_data, a_indices, a_indptr, b_data, b_indices, b_indptr):
+    """Row-local SpGEMM (csrc/spgemm_rows.hip): (data, int64 indices, int64 indptr) of A @ B, or None when a
+    row is too heavy for LDS (the caller then uses the global expand-sort-compress)."""
+    dev = require_hip(a_data, b_data)
+    dtr = torch_dtype(dot_dtype(a_data.dtype, b_data.dtype))
+    vcode = code_of(dtr)
+    if n_col >= 2 ** 31 - 1 or n_row == 0:
+        return None
+    a_data = a_data.to(dtr).contiguous() if a_data.dtype != dtr else a_data.contiguous()
+    b_data = b_data.to(dtr).contiguous() if b_data.dtype != dtr else b_data.contiguous()
+    (a_indices, a_indptr, b_indices, b_indptr), it = _unify_index(a_indices.contiguous(), a_indptr.contiguous(),
+                                                                  b_indices.contiguous(), b_indptr.contiguous())
+    s = stream_ptr(dev)
+    prod = torch.empty(n_row + 1, dtype=torch.int64, device=dev)
+    maxes = torch.empty(2, dtype=torch.int64, device=dev)
+    _ffi.call("spamd_spgemm_row_products", code_of(it), n_row, ptr(a_indptr), ptr(a_indices), ptr(b_indptr), ptr(prod),
+              ptr(maxes), s)
+    prod_off = exclusive_scan(prod)
+    max_prod, max_arow = (int(v) for v in maxes.tolist())
+    cap = int(_ffi.lib().spamd_spgemm_rows_capacity(vcode))
+    if max_prod > cap or max_arow > cap:
+        return None
+    total = int(prod_off[-1])
+    tmp_cols = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+    tmp_vals = torch.empty(max(total, 1), dtype=dtr, device=dev)
+    nnz_row = torch.zeros(n_row + 1, dtype=torch.int64, device=dev)
+    _ffi.call("spamd_spgemm_rows", vcode, code_of(it), n_row, n_col, ptr(a_indptr), ptr(a_indices), ptr(a_data),
+              ptr(b_indptr), ptr(b_indices), ptr(b_data), ptr(prod_off), max_prod, ptr(tmp_cols), ptr(tmp_vals),
+              ptr(nnz_row), s)
+    out_ptr = exclusive_scan(nnz_row)
+    nnz = int(out_ptr[-1])
+    out_idx = torch.empty(nnz, dtype=torch.int64, device=dev)
+    out_val = torch.empty(nnz, dtype=dtr, device=dev)
+    _ffi.call("spamd_spgemm_pack", vcode, n_row, ptr(prod_off), ptr(out_ptr), ptr(tmp_cols), ptr(tmp_vals), ptr(out_idx),
+              ptr(out_val), s)
+    return out_val, out_idx, out_ptr
+
+
 def dot_csr_csr(out_shape, a_data, b_data, a_indices, b_indices, a_indptr, b_indptr):
     """CSR @ CSR -> (data, indices, indptr) with int64 indices — `_dot_csr_csr`
     (reference _common.py:639-717).  Explicit zeros are kept (the GCXS constructor prunes)."""
     n_row, n_col = int(out_shape[0]), int(out_shape[1])
+    if SPGEMM_ROW_LOCAL:
+        res = _spgemm_rows(n_row, n_col, a_data, a_indices, a_indptr, b_data, b_indices, b_indptr)
+        if res is not None:
+            return res
     a_rows = csr_to_keys(a_indptr, torch.zeros_like(a_indices), n_row, 1)  # row id of every A element
     keys, data = _spgemm_keys(n_row, n_col, a_data, a_indices, a_rows, b_data, b_indices, b_indptr)
     indptr, indices = keys_to_csr(keys, n_row, n_col, torch.int64)
@@ -507,6 +552,13 @@ def dot_coo_coo(out_shape, a_coords, b_coords, a_data, b_data, n_inner):
     construction of reference _common.py:450-475,907-976.  `n_inner` = a.shape[1] = b.shape[0]."""
     n_row, n_col = int(out_shape[0]), int(out_shape[1])
     b_indptr = rows_to_indptr(b_coords[0], int(n_inner))
+    if SPGEMM_ROW_LOCAL:
+        a_indptr = rows_to_indptr(a_coords[0], n_row)
+        res = _spgemm_rows(n_row, n_col, a_data, a_coords[1], a_indptr, b_data, b_coords[1], b_indptr)
+        if res is not None:
+            data, indices, indptr = res
+            keys = csr_to_keys(indptr, indices, n_row, n_col)
+            return delinearize(keys, (n_row, n_col), torch.int64), data
     a_rows = convert(a_coords[0].contiguous(), torch.int64)
     keys, data = _spgemm_keys(n_row, n_col, a_data, a_coords[1], a_rows, b_data, b_coords[1], b_indptr)
     return delinearize(keys, (n_row, n_col), torch.int64), data
