@@ -149,6 +149,8 @@ int spamd_flag_heads(int64_t n, const int64_t* keys, int64_t* flags, void* strea
  * `equivalent`, _utils.py:448-452: -0.0 is not 0.0).  elem_bytes in {1,2,4,8}. */
 int spamd_flag_ne_bits(int elem_bytes, int64_t n, const void* data, uint64_t fill_bits, int64_t* flags,
                        void* stream);
+/* *count (device int64) = number of elements bit-identical to fill_bits: the cheap test that a prune has nothing to do */
+int spamd_count_eq_bits(int elem_bytes, int64_t n, const void* data, uint64_t fill_bits, int64_t* count, void* stream);
 /* dst[offsets[i]] = src[i] where flags[i] != 0  (stream compaction after an exclusive scan) */
 int spamd_compact(int elem_bytes, int64_t n, const void* src, const int64_t* flags, const int64_t* offsets,
                   void* dst, void* stream);

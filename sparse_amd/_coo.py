@@ -203,6 +203,8 @@ class COO(SparseArray, NDArrayOperatorsMixin):
         """Drop stored elements bit-identical to the fill value (reference core.py:1355-1371)."""
         if self.nnz == 0:
             return
+        if self.nnz >= K.PRUNE_COUNT_FIRST and K.count_eq_bits(self.data, self.fill_value) == 0:
+            return
         flags = K.flag_ne_bits(self.data, self.fill_value)
         offs = K.exclusive_scan(flags)
         count = int(offs[-1])

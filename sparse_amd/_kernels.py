@@ -228,6 +228,22 @@ def flag_ne_bits(data, fill_value):
     return f
 
 
+def count_eq_bits(data, fill_value):
+    """Number of stored elements bit-identical to fill_value (one read-only pass)."""
+    dev = require_hip(data)
+    if data.numel() == 0:
+        return 0
+    npdt = np_dtype(data.dtype)
+    bits = int(np.asarray(fill_value, dtype=npdt).reshape(1).view(f"u{npdt.itemsize}")[0])
+    c = torch.empty(1, dtype=torch.int64, device=dev)
+    _ffi.call("spamd_count_eq_bits", data.element_size(), data.numel(), ptr(data.contiguous()), bits, ptr(c),
+              stream_ptr(dev))
+    return int(c[0])
+
+
+PRUNE_COUNT_FIRST = 1 << 22   # above this many elements a prune first counts the fill values (usually zero)
+
+
 def compact(src, flags, offsets, count):
     """Stream compaction of a 1-D tensor or of every row of a 2-D [k, n] tensor."""
     dev = require_hip(src)

@@ -99,6 +99,18 @@ __global__ void __launch_bounds__(256) flag_ne_bits_kernel(const U* __restrict__
   GRID_STRIDE(i, n) flags[i] = data[i] != fill ? 1 : 0;
 }
 
+// *count += number of elements bit-identical to `fill` (the common case of a prune is that there are none:
+// one read-only pass then replaces flags + scan + compaction)
+template <typename U>
+__global__ void __launch_bounds__(256) count_eq_bits_kernel(const U* __restrict__ data, int64_t n, U fill,
+                                                            unsigned long long* __restrict__ count) {
+  unsigned long long c = 0;
+  GRID_STRIDE(i, n) c += data[i] == fill ? 1 : 0;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+}
+
 template <typename U>
 __global__ void __launch_bounds__(256) compact_kernel(const U* __restrict__ src, int64_t n,
                                                       const int64_t* __restrict__ flags,
@@ -264,6 +276,18 @@ extern "C" int spamd_flag_ne_bits(int elem_bytes, int64_t n, const void* data, u
   if (n == 0) return 0;
   SPAMD_BYTES_SWITCH(elem_bytes, U, hipLaunchKernelGGL(flag_ne_bits_kernel<U>, dim3(grid_for(n)), dim3(256), 0,
                                                        (hipStream_t)stream, (const U*)data, n, (U)fill_bits, flags))
+  return launch_status();
+}
+
+extern "C" int spamd_count_eq_bits(int elem_bytes, int64_t n, const void* data, uint64_t fill_bits, int64_t* count,
+                                   void* stream) {
+  if (n < 0) return SPAMD_EINVAL;
+  hipError_t e = hipMemsetAsync(count, 0, sizeof(int64_t), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  if (n == 0) return 0;
+  SPAMD_BYTES_SWITCH(elem_bytes, U, hipLaunchKernelGGL(count_eq_bits_kernel<U>, dim3(grid_for(n)), dim3(256), 0,
+                                                       (hipStream_t)stream, (const U*)data, n, (U)fill_bits,
+                                                       reinterpret_cast<unsigned long long*>(count)))
   return launch_status();
 }
 

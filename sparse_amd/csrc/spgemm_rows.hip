@@ -46,7 +46,12 @@ __global__ void __launch_bounds__(256) spgemm_row_products_kernel(int64_t n_row,
 
 template <int BLOCK, int ITEMS, typename V>
 struct RowSortLayout {
-  using sort_t = rocprim::block_radix_sort<int, BLOCK, ITEMS, V>;
+#ifndef SPAMD_SPG_RB
+#define SPAMD_SPG_RB 0
+#define SPAMD_SPG_ALG default_for_radix_sort
+#endif
+  using sort_t = rocprim::block_radix_sort<int, BLOCK, ITEMS, V, 1, 1, SPAMD_SPG_RB,
+                                           rocprim::block_radix_rank_algorithm::SPAMD_SPG_ALG>;
   using scan_t = rocprim::block_scan<int, BLOCK>;
   static constexpr int N = BLOCK * ITEMS;
   static constexpr size_t sorted_bytes = (size_t)N * (sizeof(int) + sizeof(V));
@@ -154,8 +159,13 @@ spgemm_rowsort_kernel(int64_t n_col, int col_bits, const I* __restrict__ a_ptr, 
 #pragma unroll
       for (int j = 0; j < ITEMS; ++j) {
         if (on[j]) {
+#ifdef SPAMD_SPG_SKIP_LOADS
+          keys[j] = (int)(q[j] & 0xffff);
+          vals[j] = av[j];
+#else
           keys[j] = (int)b_idx[q[j]];
           vals[j] = av[j] * b_val[q[j]];
+#endif
         }
       }
     }
@@ -164,7 +174,9 @@ spgemm_rowsort_kernel(int64_t n_col, int col_bits, const I* __restrict__ a_ptr, 
   }
   __syncthreads();  // prefix[] is dead: the sort reuses the memory
 
+#ifndef SPAMD_SPG_SKIP_SORT
   typename L::sort_t().sort(keys, vals, *reinterpret_cast<typename L::sort_t::storage_type*>(raw), 0, col_bits);
+#endif
   __syncthreads();
   int* const sk = reinterpret_cast<int*>(raw);
   V* const sv = reinterpret_cast<V*>(raw + (size_t)L::N * sizeof(int));
@@ -260,10 +272,15 @@ static int rowsort_all(int64_t n_row, int64_t n_col, const I* a_ptr, const I* a_
     if (rc) return rc;
   }
   if (max_prod > C::c2) {
-    if constexpr (sizeof(V) <= 4)
-      rc = launch_rowsort<1024, 16, V, I>(n_row, n_col, col_bits, a_ptr, a_idx, a_val, b_ptr, b_idx, b_val, prod_off, C::c2,
-                                          C::c3, tmp_cols, tmp_vals, nnz_row, s);
-    else
+    if constexpr (sizeof(V) <= 4) {
+      constexpr int64_t c2b = 1024 * 10;
+      rc = launch_rowsort<1024, 10, V, I>(n_row, n_col, col_bits, a_ptr, a_idx, a_val, b_ptr, b_idx, b_val, prod_off, C::c2, c2b,
+                                          tmp_cols, tmp_vals, nnz_row, s);
+      if (rc) return rc;
+      if (max_prod > c2b)
+        rc = launch_rowsort<1024, 16, V, I>(n_row, n_col, col_bits, a_ptr, a_idx, a_val, b_ptr, b_idx, b_val, prod_off, c2b,
+                                            C::c3, tmp_cols, tmp_vals, nnz_row, s);
+    } else
       rc = launch_rowsort<1024, 12, V, I>(n_row, n_col, col_bits, a_ptr, a_idx, a_val, b_ptr, b_idx, b_val, prod_off, C::c2,
                                           C::c3, tmp_cols, tmp_vals, nnz_row, s);
   }
