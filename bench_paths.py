@@ -161,7 +161,7 @@ def main():
                   idx_dtype=np.int32, format="gcxs", compressed_axes=(0,))
     ms, c = timed(lambda: g @ g, reps=3, warm=2)
     prods = float((g.indptr[1:] - g.indptr[:-1]).double()[g.indices.long()].sum())
-    out.append(line("A4 SpGEMM G@G (expand-sort-compress)", f"GCXS {n4}x{n4}, {g.nnz} nnz, {int(prods)} products -> {c.nnz} nnz",
+    out.append(line("A4 SpGEMM G@G (row-local expand-sort-compress in LDS)", f"GCXS {n4}x{n4}, {g.nnz} nnz, {int(prods)} products -> {c.nnz} nnz",
                     ms, g.nnz * 8 + prods * 8 + c.nnz * 8, flops=2.0 * prods))
 
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

@@ -100,3 +100,59 @@ def test_spgemm_row_chunking(sp, monkeypatch):
     assert torch.equal(whole.coords, parts.coords) and torch.equal(whole.data, parts.data)
     ref = a.to_scipy_sparse() @ b.to_scipy_sparse()
     assert parts.nnz == ref.nnz and np.allclose(parts.todense(), ref.toarray(), rtol=1e-13)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int64])
+def test_spgemm_row_local_matches_global_esc_across_size_classes(dtype):
+    """csrc/spgemm_rows.hip serves output rows by size class (512 .. 16384 products); every class must give the
+    same bits as the global expand-sort-compress (reference `_dot_csr_csr`, _common.py:639-717), and a row that is
+    too heavy for LDS makes the whole product fall back."""
+    import sparse_amd as sp
+    from sparse_amd import _kernels as Kn
+
+    rng = np.random.default_rng(3)
+    n = 3000
+    # rows of A with 1 .. 160 elements against B rows of 1 .. 110 elements: products per row from 1 to ~17000
+    rows, cols = [], []
+    for i in range(n):
+        k = 1 + (i * 160) // n
+        rows += [i] * k
+        cols += list(rng.choice(n, size=k, replace=False))
+    a_dense_vals = (rng.integers(-9, 9, size=len(rows)) if np.dtype(dtype).kind == "i" else rng.random(len(rows)) - 0.5).astype(dtype)
+    a = sp.COO(np.array([rows, cols]), a_dense_vals, shape=(n, n)).asformat("gcxs", compressed_axes=(0,))
+    rows, cols = [], []
+    for i in range(n):
+        k = 1 + (i * 110) // n
+        rows += [i] * k
+        cols += list(rng.choice(n, size=k, replace=False))
+    b_vals = (rng.integers(-9, 9, size=len(rows)) if np.dtype(dtype).kind == "i" else rng.random(len(rows)) - 0.5).astype(dtype)
+    b = sp.COO(np.array([rows, cols]), b_vals, shape=(n, n)).asformat("gcxs", compressed_axes=(0,))
+    old = Kn.SPGEMM_ROW_LOCAL
+    try:
+        Kn.SPGEMM_ROW_LOCAL = True
+        c1 = a @ b
+        Kn.SPGEMM_ROW_LOCAL = False
+        c2 = a @ b
+    finally:
+        Kn.SPGEMM_ROW_LOCAL = old
+    assert torch.equal(c1.indptr.long(), c2.indptr.long()) and torch.equal(c1.indices.long(), c2.indices.long())
+    assert torch.equal(c1.data, c2.data)
+    want = a.todense() @ b.todense()
+    got = c1.todense()
+    assert np.array_equal(got, want) if np.dtype(dtype).kind == "i" else np.allclose(got, want, rtol=1e-5, atol=1e-6)
+
+
+def test_spgemm_heavy_row_falls_back():
+    import sparse_amd as sp
+    from sparse_amd import _kernels as Kn
+
+    n = 600
+    rng = np.random.default_rng(4)
+    dense_a = (rng.random((n, n)) < 0.02) * rng.random((n, n))
+    dense_a[7, :] = rng.random(n)          # one dense row of A ...
+    dense_b = (rng.random((n, n)) < 0.2) * rng.random((n, n))   # ... times ~120 elements per B row: 72000 products
+    a = sp.COO.from_numpy(dense_a).asformat("gcxs", compressed_axes=(0,))
+    b = sp.COO.from_numpy(dense_b).asformat("gcxs", compressed_axes=(0,))
+    assert Kn._spgemm_rows(n, n, a.data, a.indices, a.indptr, b.data, b.indices, b.indptr) is None
+    c = a @ b
+    assert np.allclose(c.todense(), dense_a @ dense_b, rtol=1e-12, atol=1e-14)
