@@ -21,6 +21,10 @@
 
 namespace spamd {
 
+__device__ __forceinline__ int64_t max_seen(const int64_t* p) {  // a stale read only costs a redundant atomic
+  return __builtin_nontemporal_load(p);
+}
+
 template <typename I>
 __global__ void __launch_bounds__(256) spgemm_row_products_kernel(int64_t n_row, const I* __restrict__ a_ptr,
                                                                   const I* __restrict__ a_idx, const I* __restrict__ b_ptr,
@@ -28,8 +32,11 @@ __global__ void __launch_bounds__(256) spgemm_row_products_kernel(int64_t n_row,
   // one wave per row
   const int lane = threadIdx.x & 63;
   const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (row >= n_row) return;
-  const int64_t a0 = (int64_t)a_ptr[row], a1 = (int64_t)a_ptr[row + 1];
+  int64_t a0 = 0, a1 = 0;
+  if (row < n_row) {
+    a0 = (int64_t)a_ptr[row];
+    a1 = (int64_t)a_ptr[row + 1];
+  }
   int64_t s = 0;
   for (int64_t e = a0 + lane; e < a1; e += 64) {
     const int64_t k = (int64_t)a_idx[e];
@@ -37,10 +44,23 @@ __global__ void __launch_bounds__(256) spgemm_row_products_kernel(int64_t n_row,
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+  // block maxima first: 10^5 same-address atomics from every wave serialise (2 ms); one pair per workgroup does not
+  __shared__ int64_t wmax[2][4];
   if (lane == 0) {
-    prod[row] = s;
-    atomicMax(reinterpret_cast<unsigned long long*>(maxes), (unsigned long long)s);
-    atomicMax(reinterpret_cast<unsigned long long*>(maxes + 1), (unsigned long long)(a1 - a0));
+    if (row < n_row) prod[row] = s;
+    wmax[0][threadIdx.x >> 6] = s;
+    wmax[1][threadIdx.x >> 6] = a1 - a0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t m0 = 0, m1 = 0;
+    const int64_t first = (int64_t)blockIdx.x * 4;
+    for (int w = 0; w < 4 && first + w < n_row; ++w) {
+      m0 = wmax[0][w] > m0 ? wmax[0][w] : m0;
+      m1 = wmax[1][w] > m1 ? wmax[1][w] : m1;
+    }
+    if (m0 > max_seen(maxes)) atomicMax(reinterpret_cast<unsigned long long*>(maxes), (unsigned long long)m0);
+    if (m1 > max_seen(maxes + 1)) atomicMax(reinterpret_cast<unsigned long long*>(maxes + 1), (unsigned long long)m1);
   }
 }
 
