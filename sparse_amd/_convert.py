@@ -106,6 +106,10 @@ def gcxs_relayout(x, shape, axes, compressed_axes, transpose=False, reshape=Fals
     (`convert._transpose`, reference _compressed/convert.py:210-273): returns the new
     (data, indices, indptr)."""
     shape = tuple(int(s) for s in shape)
+    if (x.ndim == 2 and not transpose and not reshape and len(x.compressed_axes) == 1 and len(compressed_axes) == 1
+            and tuple(compressed_axes) != tuple(x.compressed_axes)):
+        c = x.compressed_axes[0]
+        return K.csx_swap_2d(x.data, x.indices, x.indptr, shape[c], shape[1 - c])
     keys = gcxs_natural_keys(x)
     nat_shape = x.shape
     if transpose:
@@ -119,8 +123,11 @@ def gcxs_relayout(x, shape, axes, compressed_axes, transpose=False, reshape=Fals
     R = prod(rshape[: len(compressed_axes)])
     C = prod(rshape[len(compressed_axes):])
     keys = K.permute_keys(keys, shape, order)
-    keys, perm = K.sort_keys(keys, max(prod(shape) - 1, 1))
-    data = K.gather(x.data, perm)
+    if x.data.element_size() in (4, 8) and x.data.dtype != torch.bool:
+        keys, data = K.sort_key_value(keys, x.data, max(prod(shape) - 1, 1))  # the values ride along as the payload
+    else:
+        keys, perm = K.sort_keys(keys, max(prod(shape) - 1, 1))
+        data = K.gather(x.data, perm)
     it = _pick_index_dtype(x.indices.dtype, max(R, C, x.nnz))
     indptr, indices = K.keys_to_csr(keys, R, C, it)
     return (data, indices, indptr)

@@ -333,16 +333,38 @@ def convert(t, dtype):
 # ---------------------------------------------------------------------------------------------
 # the rest of the `_dot_*` kernel family (reference _common.py:758-1158), built on the kernels above
 # ---------------------------------------------------------------------------------------------
+def csx_swap_2d(data, indices, indptr, n_major, n_minor):
+    """Re-compress a 2-D compressed matrix along its other axis (CSR <-> CSC): returns (data, indices, indptr) with
+    n_minor + 1 pointers.  The input is ordered by (major, minor), so a STABLE sort on the minor index alone gives
+    (minor, major) order: ceil(log2(n_minor)) key bits instead of log2(n_major * n_minor), and the major ids and
+    4-byte values ride along packed into one 8-byte payload (no permutation + gathers).
+    (`_transpose` / change_compressed_axes, reference _compressed/convert.py:210-273, compressed.py:388-423)."""
+    dev = require_hip(data, indices, indptr)
+    nnz = int(indices.numel())
+    it = indices.dtype if index_dtype_ok(indices) else torch.int64
+    if nnz == 0:
+        return data, indices.to(it), torch.zeros(n_minor + 1, dtype=it, device=dev)
+    major = csr_to_keys(indptr, torch.zeros_like(indices), n_major, 1)     # major id of every stored element
+    keys = convert(indices.contiguous(), torch.int64)
+    if data.element_size() == 4 and n_major < 2 ** 31:
+        payload = torch.stack([major.to(torch.int32), data.contiguous().view(torch.int32)], dim=1).view(torch.int64)
+        keys, payload = sort_key_value(keys, payload.reshape(-1), max(n_minor - 1, 1))
+        pr = payload.view(torch.int32).reshape(nnz, 2)
+        new_indices = pr[:, 0].contiguous().to(it)
+        new_data = pr[:, 1].contiguous().view(data.dtype)
+    else:
+        keys, perm = sort_keys(keys, max(n_minor - 1, 1))
+        new_indices = gather(major, perm).to(it)
+        new_data = gather(data, perm)
+    new_indptr = rows_to_indptr(keys, n_minor).to(it)
+    return new_data, new_indices, new_indptr
+
+
 def _csc_to_csr(a_shape, a_data, a_indices, a_indptr):
     """(M x K) stored by columns -> CSR arrays.  Stable: within a row the columns ascend, so
     the CSR product accumulates in the same k order as the reference's column sweep."""
     M, Kd = int(a_shape[0]), int(a_shape[1])
-    keys = csr_to_keys(a_indptr, a_indices, Kd, M)          # col * M + row
-    keys = permute_keys(keys, (Kd, M), (1, 0))              # row * K + col
-    keys, perm = sort_keys(keys, max(M * Kd - 1, 1))
-    it = a_indices.dtype if index_dtype_ok(a_indices) else torch.int64
-    indptr, indices = keys_to_csr(keys, M, Kd, it)
-    return gather(a_data, perm), indices, indptr
+    return csx_swap_2d(a_data, a_indices, a_indptr, Kd, M)
 
 
 def dot_csc_ndarray(a_shape, b_shape, a_data, a_indices, a_indptr, b, *, exact=False):
