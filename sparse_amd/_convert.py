@@ -60,8 +60,11 @@ def coo_to_gcxs_arrays(x, compressed_axes=None, idx_dtype=None):
     data = x.data
     if order != list(range(x.ndim)):
         keys = K.permute_keys(keys, x.shape, order)
-        keys, perm = K.sort_keys(keys, max(x.size - 1, 1))
-        data = K.gather(data, perm)
+        if data.element_size() in (4, 8) and data.dtype != torch.bool:
+            keys, data = K.sort_key_value(keys, data, max(x.size - 1, 1))  # the values ride along as the payload
+        else:
+            keys, perm = K.sort_keys(keys, max(x.size - 1, 1))
+            data = K.gather(data, perm)
     indptr, indices = K.keys_to_csr(keys, R, C, it)
     return ((data, indices, indptr), x.shape, tuple(compressed_axes), x.fill_value)
 
