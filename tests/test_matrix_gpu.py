@@ -111,7 +111,7 @@ def test_spgemm_row_local_matches_global_esc_across_size_classes(dtype):
     from sparse_amd import _kernels as Kn
 
     rng = np.random.default_rng(3)
-    n = 3000
+    n = 1200
     # rows of A with 1 .. 160 elements against B rows of 1 .. 110 elements: products per row from 1 to ~17000
     rows, cols = [], []
     for i in range(n):
@@ -128,6 +128,7 @@ def test_spgemm_row_local_matches_global_esc_across_size_classes(dtype):
     b_vals = (rng.integers(-9, 9, size=len(rows)) if np.dtype(dtype).kind == "i" else rng.random(len(rows)) - 0.5).astype(dtype)
     b = sp.COO(np.array([rows, cols]), b_vals, shape=(n, n)).asformat("gcxs", compressed_axes=(0,))
     old = Kn.SPGEMM_ROW_LOCAL
+    assert Kn._spgemm_rows(n, n, a.data, a.indices, a.indptr, b.data, b.indices, b.indptr) is not None
     try:
         Kn.SPGEMM_ROW_LOCAL = True
         c1 = a @ b
