@@ -274,8 +274,8 @@ int spamd_spgemm_expand(int val_dtype, int idx_dtype, int64_t p0, int64_t np, co
 
 /* A4 / A5, row-local form (csrc/spgemm_rows.hip): the products of an output row are expanded, radix-sorted by column
  * and summed inside LDS by one workgroup; bit-identical to the expand-sort-compress above, without writing or
- * sorting the products in HBM.  Usable when no output row has more products (and no A row more elements) than
- * spamd_spgemm_rows_capacity(val_dtype) and n_col < 2^31 - 1; otherwise use the global form.
+ * sorting the products in HBM.  Rows with more products than spamd_spgemm_rows_capacity(val_dtype) are skipped: the
+ * caller computes those with the global form and merges them with spamd_spgemm_unpack.  n_col < 2^31 - 1.
  *   spamd_spgemm_row_products: prod[n_row + 1] (last entry zeroed) and maxes[2] = {max prod, longest A row};
  *   caller: prod_off = spamd_exclusive_scan(prod), scratch tmp_cols/tmp_vals of prod_off[n_row] entries;
  *   spamd_spgemm_rows: rows of C into the scratch at prod_off[row], their lengths into nnz_row[n_row + 1];
@@ -288,6 +288,11 @@ int spamd_spgemm_rows(int val_dtype, int idx_dtype, int64_t n_row, int64_t n_col
                       const void* a_indices, const void* a_data, const void* b_indptr, const void* b_indices,
                       const void* b_data, const int64_t* prod_off, int64_t max_prod, int* tmp_cols, void* tmp_vals,
                       int64_t* nnz_row, void* stream);
+/* rows too heavy for the row-local kernel: computed by the global form, given as CSR over all n_row rows (int64
+ * columns), copied into the scratch at their product offset; nnz_row[row] is set for the listed rows */
+int spamd_spgemm_unpack(int val_dtype, int64_t n_heavy, const int64_t* heavy_rows, const int64_t* src_indptr,
+                        const int64_t* src_indices, const void* src_data, const int64_t* prod_off, int* tmp_cols,
+                        void* tmp_vals, int64_t* nnz_row, void* stream);
 int spamd_spgemm_pack(int val_dtype, int64_t n_row, const int64_t* prod_off, const int64_t* out_indptr,
                       const int* tmp_cols, const void* tmp_vals, int64_t* out_indices, void* out_data, void* stream);
 

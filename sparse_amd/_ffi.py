@@ -86,6 +86,7 @@ SIGNATURES = {
     "spamd_spgemm_row_products": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spamd_spgemm_rows_capacity": (_i64, [_int]),
     "spamd_spgemm_rows": (_int, [_int, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "spamd_spgemm_unpack": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spamd_spgemm_pack": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spamd_reduce_fill": (_int, [_int, _int, _i64, _vp, _vp, _i64, _C.c_double, _i64, _vp]),
     "spamd_group_reduce_ws_bytes": (_i64, [_int, _i64]),

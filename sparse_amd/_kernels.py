@@ -522,7 +522,7 @@ def _spgemm_keys(n_row, n_col, a_data, a_indices, a_rows, b_data, b_indices, b_i
             heads = flag_heads(keys)
             ho = exclusive_scan(heads)
             c = int(ho[-1])
-            out_vals.append(segment_reduce(vals, heads, ho, c, "add"))
+            out_vals.append(segment_reduce(vals, heads, ho, c, "add", sequential=True))
             out_keys.append(compact(keys, heads, ho, c))
         p = q
     if not out_keys:
@@ -534,8 +534,9 @@ SPGEMM_ROW_LOCAL = True  # tuning hook: False = always the global expand-sort-co
 
 
 def _spgemm_rows(n_row, n_col, a_data, a_indices, a_indptr, b_data, b_indices, b_indptr):
-    """Row-local SpGEMM (csrc/spgemm_rows.hip): (data, int64 indices, int64 indptr) of A @ B, or None when a
-    row is too heavy for LDS (the caller then uses the global expand-sort-compress)."""
+    """Row-local SpGEMM (csrc/spgemm_rows.hip): (data, int64 indices, int64 indptr) of A @ B.  Rows too heavy for LDS
+    are computed by the global expand-sort-compress and merged in; None when most of the work is in such rows (the
+    caller then uses the global form throughout)."""
     dev = require_hip(a_data, b_data)
     dtr = torch_dtype(dot_dtype(a_data.dtype, b_data.dtype))
     vcode = code_of(dtr)
@@ -553,15 +554,37 @@ def _spgemm_rows(n_row, n_col, a_data, a_indices, a_indptr, b_data, b_indices, b
     prod_off = exclusive_scan(prod)
     max_prod, max_arow = (int(v) for v in maxes.tolist())
     cap = int(_ffi.lib().spamd_spgemm_rows_capacity(vcode))
-    if max_prod > cap or max_arow > cap:
-        return None
     total = int(prod_off[-1])
+    heavy_rows = None
+    if max_prod > cap or max_arow > cap:
+        # rows too heavy for LDS (products, or A elements to stage) go through the global expand-sort-compress
+        arow_len = (a_indptr[1:] - a_indptr[:-1]).to(torch.int64)
+        heavy = (prod[:n_row] > cap) | (arow_len > cap)
+        heavy_rows = torch.nonzero(heavy).reshape(-1)
+        if int(heavy_rows.numel()) * 4 > n_row or int(prod[:n_row][heavy].sum()) * 2 > total:
+            return None  # mostly heavy: the global form throughout
     tmp_cols = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
     tmp_vals = torch.empty(max(total, 1), dtype=dtr, device=dev)
     nnz_row = torch.zeros(n_row + 1, dtype=torch.int64, device=dev)
-    _ffi.call("spamd_spgemm_rows", vcode, code_of(it), n_row, n_col, ptr(a_indptr), ptr(a_indices), ptr(a_data),
-              ptr(b_indptr), ptr(b_indices), ptr(b_data), ptr(prod_off), max_prod, ptr(tmp_cols), ptr(tmp_vals),
-              ptr(nnz_row), s)
+    if heavy_rows is None:
+        _ffi.call("spamd_spgemm_rows", vcode, code_of(it), n_row, n_col, ptr(a_indptr), ptr(a_indices), ptr(a_data),
+                  ptr(b_indptr), ptr(b_indices), ptr(b_data), ptr(prod_off), max_prod, ptr(tmp_cols), ptr(tmp_vals),
+                  ptr(nnz_row), s)
+    else:
+        # (the kernels skip every row with more products than the capacity by themselves; rows that are heavy only by
+        # their A length are rare enough to send everything to the global form)
+        if bool(((arow_len > cap) & (prod[:n_row] <= cap)).any()):
+            return None
+        _ffi.call("spamd_spgemm_rows", vcode, code_of(it), n_row, n_col, ptr(a_indptr), ptr(a_indices), ptr(a_data),
+                  ptr(b_indptr), ptr(b_indices), ptr(b_data), ptr(prod_off), cap, ptr(tmp_cols), ptr(tmp_vals),
+                  ptr(nnz_row), s)
+        a_rows = csr_to_keys(a_indptr, torch.zeros_like(a_indices), n_row, 1)
+        sel = heavy[a_rows]
+        hkeys, hvals = _spgemm_keys(n_row, n_col, a_data[sel], a_indices[sel], a_rows[sel].contiguous(), b_data,
+                                    b_indices, b_indptr)
+        hptr, hidx = keys_to_csr(hkeys, n_row, n_col, torch.int64)
+        _ffi.call("spamd_spgemm_unpack", vcode, int(heavy_rows.numel()), ptr(heavy_rows.contiguous()), ptr(hptr),
+                  ptr(hidx), ptr(hvals.contiguous()), ptr(prod_off), ptr(tmp_cols), ptr(tmp_vals), ptr(nnz_row), s)
     out_ptr = exclusive_scan(nnz_row)
     nnz = int(out_ptr[-1])
     out_idx = torch.empty(nnz, dtype=torch.int64, device=dev)

@@ -18,15 +18,18 @@ _RED_OPS = {"add": 0, "multiply": 1, "maximum": 2, "minimum": 3, "logical_or": 4
 _SUPER = {"add": np.multiply, "multiply": np.power}
 
 
-def segment_reduce(data, heads, offs, count, op, want_counts=False):
-    """Reduce every run of `data` delimited by `heads` (int64 flags, n+1 entries) with `op`."""
+def segment_reduce(data, heads, offs, count, op, want_counts=False, sequential=False):
+    """Reduce every run of `data` delimited by `heads` (int64 flags, n+1 entries) with `op`.  `sequential`: always
+    one thread per run, strictly left to right (the reference's `sums[j] += ...` order, bit for bit), also when
+    the runs are long enough for the faster wave-per-run tree."""
     dev = require_hip(data)
     n = int(data.numel())
     if data.dtype == torch.bool:
         data = data.view(torch.uint8)
     out = torch.empty(count, dtype=data.dtype, device=dev)
     counts = torch.empty(count, dtype=torch.int64, device=dev) if want_counts else None
-    ws = torch.empty(count + 1, dtype=torch.int64, device=dev) if (count and n // max(count, 1) >= 24) else None
+    ws = (torch.empty(count + 1, dtype=torch.int64, device=dev)
+          if (count and n // max(count, 1) >= 24 and not sequential) else None)
     code = _ffi.U8 if data.dtype == torch.uint8 else code_of(data.dtype)
     _ffi.call("spamd_segment_reduce", _RED_OPS[op], code, n, ptr(data.contiguous()), ptr(heads), ptr(offs), count,
               ptr(out), ptr(counts), ptr(ws), stream_ptr(dev))

@@ -248,6 +248,23 @@ __global__ void __launch_bounds__(256) spgemm_pack_kernel(const int64_t* __restr
   }
 }
 
+// heavy rows come from the global expand-sort-compress as CSR over ALL rows (src_ptr, int64 columns): put them into
+// the scratch at their product offset and record their lengths, so that the pack kernel treats every row alike
+template <typename V>
+__global__ void __launch_bounds__(256) spgemm_unpack_kernel(const int64_t* __restrict__ rows, const int64_t* __restrict__ src_ptr,
+                                                            const int64_t* __restrict__ src_idx, const V* __restrict__ src_val,
+                                                            const int64_t* __restrict__ prod_off, int* __restrict__ tmp_cols,
+                                                            V* __restrict__ tmp_vals, int64_t* __restrict__ nnz_row) {
+  const int64_t row = rows[blockIdx.x];
+  const int64_t src = src_ptr[row], dst = prod_off[row];
+  const int64_t n = src_ptr[row + 1] - src;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    tmp_cols[dst + i] = (int)src_idx[src + i];
+    tmp_vals[dst + i] = src_val[src + i];
+  }
+  if (threadIdx.x == 0) nnz_row[row] = n;
+}
+
 template <int BLOCK, int ITEMS, typename V, typename I>
 static int launch_rowsort(int64_t n_row, int64_t n_col, int col_bits, const I* a_ptr, const I* a_idx, const V* a_val,
                           const I* b_ptr, const I* b_idx, const V* b_val, const int64_t* prod_off, int64_t lo, int64_t hi,
@@ -335,14 +352,17 @@ extern "C" int64_t spamd_spgemm_rows_capacity(int val_dtype) {
 
 // Row-local expand / sort / compress.  prod_off = exclusive scan of prod (n_row + 1); tmp_cols / tmp_vals hold
 // prod_off[n_row] entries; nnz_row[n_row + 1] receives the row lengths of C (last entry untouched).
-// Requires max_prod and the longest A row <= spamd_spgemm_rows_capacity, n_col < 2^31 - 1.
+// Rows with more products than spamd_spgemm_rows_capacity are left out (see spamd_spgemm_unpack); rows whose A row is
+// longer than the capacity must be left to the global form by the caller as well.  n_col < 2^31 - 1.
 extern "C" int spamd_spgemm_rows(int val_dtype, int idx_dtype, int64_t n_row, int64_t n_col, const void* a_indptr,
                                  const void* a_indices, const void* a_data, const void* b_indptr, const void* b_indices,
                                  const void* b_data, const int64_t* prod_off, int64_t max_prod, int* tmp_cols, void* tmp_vals,
                                  int64_t* nnz_row, void* stream) {
   if (n_row < 0 || n_col < 0 || n_col >= 2147483647LL) return SPAMD_EINVAL;
   if (n_row == 0) return 0;
-  if (max_prod > spamd_spgemm_rows_capacity(val_dtype)) return SPAMD_EINVAL;
+  // rows with more products than the capacity are skipped (nnz_row stays as the caller initialised it): the caller
+  // computes them with the global form and hands them over through spamd_spgemm_unpack
+  if (max_prod > spamd_spgemm_rows_capacity(val_dtype)) max_prod = spamd_spgemm_rows_capacity(val_dtype);
   hipStream_t s = (hipStream_t)stream;
   SPAMD_DISPATCH_VAL(val_dtype, V, {
     SPAMD_DISPATCH_IDX(idx_dtype, I, return (rowsort_all<V, I>(n_row, n_col, (const I*)a_indptr, (const I*)a_indices,
@@ -351,6 +371,18 @@ extern "C" int spamd_spgemm_rows(int val_dtype, int idx_dtype, int64_t n_row, in
                                                                nnz_row, s)))
   })
   return SPAMD_ETYPE;
+}
+
+extern "C" int spamd_spgemm_unpack(int val_dtype, int64_t n_heavy, const int64_t* heavy_rows, const int64_t* src_indptr,
+                                   const int64_t* src_indices, const void* src_data, const int64_t* prod_off, int* tmp_cols,
+                                   void* tmp_vals, int64_t* nnz_row, void* stream) {
+  if (n_heavy < 0) return SPAMD_EINVAL;
+  if (n_heavy == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  SPAMD_DISPATCH_VAL(val_dtype, V, hipLaunchKernelGGL(spgemm_unpack_kernel<V>, dim3((unsigned)n_heavy), dim3(256), 0, s, heavy_rows,
+                                                      src_indptr, src_indices, (const V*)src_data, prod_off, tmp_cols,
+                                                      (V*)tmp_vals, nnz_row))
+  return launch_status();
 }
 
 extern "C" int spamd_spgemm_pack(int val_dtype, int64_t n_row, const int64_t* prod_off, const int64_t* out_indptr,

@@ -143,15 +143,44 @@ def test_spgemm_row_local_matches_global_esc_across_size_classes(dtype):
     assert np.array_equal(got, want) if np.dtype(dtype).kind == "i" else np.allclose(got, want, rtol=1e-5, atol=1e-6)
 
 
-def test_spgemm_heavy_row_falls_back():
+def test_spgemm_heavy_rows_are_merged_from_the_global_form():
+    """A few rows with more products than fit in LDS: those rows come from the global expand-sort-compress, all
+    others from the row-local kernel; the result is bit-identical to the global form throughout."""
+    import sparse_amd as sp
+    from sparse_amd import _kernels as Kn
+
+    n = 2500
+    rng = np.random.default_rng(4)
+    # (np.where, not mask * values: False * negative = -0.0, which is a stored element bit-wise)
+    dense_a = np.where(rng.random((n, n)) < 0.01, rng.random((n, n)) - 0.5, 0.0)
+    dense_a[7, :] = rng.random(n) - 0.5      # dense rows of A times ~75 elements per B row: ~190000 products each
+    dense_a[1999, ::2] = 0.25
+    dense_b = np.where(rng.random((n, n)) < 0.03, rng.random((n, n)) - 0.5, 0.0)
+    a = sp.COO.from_numpy(dense_a).asformat("gcxs", compressed_axes=(0,))
+    b = sp.COO.from_numpy(dense_b).asformat("gcxs", compressed_axes=(0,))
+    res = Kn._spgemm_rows(n, n, a.data, a.indices, a.indptr, b.data, b.indices, b.indptr)
+    assert res is not None
+    old = Kn.SPGEMM_ROW_LOCAL
+    try:
+        Kn.SPGEMM_ROW_LOCAL = True
+        c1 = a @ b
+        Kn.SPGEMM_ROW_LOCAL = False
+        c2 = a @ b
+    finally:
+        Kn.SPGEMM_ROW_LOCAL = old
+    assert torch.equal(c1.indptr.long(), c2.indptr.long()) and torch.equal(c1.indices.long(), c2.indices.long())
+    assert torch.equal(c1.data, c2.data)
+    assert np.allclose(c1.todense(), dense_a @ dense_b, rtol=1e-12, atol=1e-14)
+
+
+def test_spgemm_mostly_heavy_falls_back():
     import sparse_amd as sp
     from sparse_amd import _kernels as Kn
 
     n = 600
     rng = np.random.default_rng(4)
-    dense_a = (rng.random((n, n)) < 0.02) * rng.random((n, n))
-    dense_a[7, :] = rng.random(n)          # one dense row of A ...
-    dense_b = (rng.random((n, n)) < 0.2) * rng.random((n, n))   # ... times ~120 elements per B row: 72000 products
+    dense_a = (rng.random((n, n)) < 0.5) * rng.random((n, n))
+    dense_b = (rng.random((n, n)) < 0.2) * rng.random((n, n))   # ~300 x 120 = 36000 products in every row
     a = sp.COO.from_numpy(dense_a).asformat("gcxs", compressed_axes=(0,))
     b = sp.COO.from_numpy(dense_b).asformat("gcxs", compressed_axes=(0,))
     assert Kn._spgemm_rows(n, n, a.data, a.indices, a.indptr, b.data, b.indices, b.indptr) is None
