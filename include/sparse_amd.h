@@ -70,47 +70,49 @@ int spamd_spmm_csr(int val_dtype, int idx_dtype, int64_t M, int64_t K, int64_t N
                    unsigned flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------
- * A1 (inspector/executor form)   same product as spamd_spmm_csr for fp32, N == 128, FMA mode, with
- *   a cached K-tiled copy of A — the role `cusparseSpMM_preprocess`-style inspection plays elsewhere;
- *   the reference's analogue is the memoised format conversion of `COO(cache=True)`
- *   (sparse/numba_backend/_coo/core.py:317-338).  Inspector (once per matrix):
+ * A1 (inspector/executor form)   same product as spamd_spmm_csr for F32 (N % 128 == 0) and F64 (N % 64 == 0),
+ *   both arithmetic modes, with a cached K-tiled copy of A — the role `cusparseSpMM_preprocess`-style
+ *   inspection plays elsewhere; the reference's analogue is the memoised format conversion of
+ *   `COO(cache=True)` (sparse/numba_backend/_coo/core.py:317-338).  Inspector (once per matrix):
  *     keys   = spamd_csr_to_keys(A)                      row*K + col
  *     tkeys  = spamd_spmm_tiled_keys(keys)               ((g*ntiles+t)*RG + row%RG)*KB + col%KB
  *     stable sort of (tkeys, values)                     spamd_sort_kv
- *     seg_start, nblk = spamd_spmm_tiled_lists(tkeys)    first element / 8-entry blocks of list (g,t)
+ *     seg_start, nblk = spamd_spmm_tiled_lists(tkeys)    first element / blocks of list (g,t)
  *     blk_off = spamd_exclusive_scan(nblk)               int64[nseg + 1], nseg = groups*ntiles
  *     blk_off32 = spamd_convert(I64 -> I32)              what the executor reads (total blocks < 2^31)
- *     blocks  = spamd_spmm_tiled_pack(...)               64-byte blocks of eight (d0, d1):
- *                                                        d0 = col%KB << 9 | 2 + 2*(row%RG), d1 = value bits;
+ *     blocks  = spamd_spmm_tiled_pack(...)               64-byte blocks, d0 = col%KB << 9 | 2 + 2*(row%RG):
+ *                                                        F32: eight (d0, value bits);
+ *                                                        F64: five d0, one pad dword, five (value lo, value hi);
  *                                                        lists padded with zero entries
  *   where groups = ceil(ceil(M/RG) / GPB) * GPB (every wave of the executor grid has lists).
- *   Executor: spamd_spmm_tiled — B streams through LDS in KB-row tiles (LDS-DMA), each wave pulls
- *   its blocks with scalar loads and keeps 32 rows of partial sums in a fixed VGPR block addressed
- *   with s_set_gpr_idx.  RG / KB / GPB / entries per block / slack from spamd_spmm_tiled_params;
+ *   Executor: spamd_spmm_tiled — a workgroup covers a panel of 512 bytes of the output rows (128 F32 or 64 F64
+ *   columns; wider N = more panels); B streams through LDS in KB-row tiles (LDS-DMA), each wave pulls its blocks
+ *   with scalar loads and keeps 32 rows of partial sums in a fixed VGPR block addressed with s_set_gpr_idx.
+ *   RG / KB / GPB / entries per block / slack / panel width from spamd_spmm_tiled_params(val_dtype);
  *   `blocks` must hold total_blocks + slack blocks and be 64-byte aligned.
  *   flags: SPAMD_EXACT_MULADD as for spamd_spmm_csr.  Results are bit-identical to spamd_spmm_csr with the
  *   same flags (sorted column indices), hence to the reference loop under SPAMD_EXACT_MULADD.
  * ------------------------------------------------------------------------------------- */
-int spamd_spmm_tiled_params(int* rows_per_group, int* tile_rows, int* groups_per_block, int* entries_per_block,
-                            int* slack_blocks, int* direct_max_tiles);
+int spamd_spmm_tiled_params(int val_dtype, int* rows_per_group, int* tile_rows, int* groups_per_block,
+                            int* entries_per_block, int* slack_blocks, int* direct_max_tiles, int* panel_cols);
 /* Direct (sort-free) inspector for CSR with sorted column indices and ceil(K/KB) <= direct_max_tiles: the tiled
  * order is a stable partition by tile of every RG-row group of the CSR order.
  *   spamd_spmm_tiled_count: nblk[nseg+1] (blocks per list, ready for spamd_exclusive_scan), flags[0] = 1 if a row's
  *                           column indices are not ascending (then use the key-sort recipe above);
- *   spamd_spmm_tiled_fill:  writes the block stream from (a_data fp32, a_indices, a_indptr) and blk_off. */
-int spamd_spmm_tiled_count(int idx_dtype, int64_t M, int64_t K, const void* a_indices, const void* a_indptr,
-                           int64_t* nblk, int* flags, void* stream);
-int spamd_spmm_tiled_fill(int idx_dtype, int64_t M, int64_t K, const float* a_data, const void* a_indices,
+ *   spamd_spmm_tiled_fill:  writes the block stream from (a_data of val_dtype, a_indices, a_indptr) and blk_off. */
+int spamd_spmm_tiled_count(int val_dtype, int idx_dtype, int64_t M, int64_t K, const void* a_indices,
+                           const void* a_indptr, int64_t* nblk, int* flags, void* stream);
+int spamd_spmm_tiled_fill(int val_dtype, int idx_dtype, int64_t M, int64_t K, const void* a_data, const void* a_indices,
                           const void* a_indptr, const int64_t* blk_off, int64_t total_blocks, int* blocks,
                           void* stream);
 int spamd_spmm_tiled_keys(int64_t nnz, const int64_t* rowcol_keys, int64_t K, int64_t* tiled_keys, void* stream);
-int spamd_spmm_tiled_lists(int64_t nnz, const int64_t* tiled_keys_sorted, int64_t M, int64_t K, int64_t* seg_start,
-                           int64_t* nblk, void* stream);
-int spamd_spmm_tiled_pack(int64_t nnz, const int64_t* tiled_keys_sorted, const float* vals_sorted,
+int spamd_spmm_tiled_lists(int val_dtype, int64_t nnz, const int64_t* tiled_keys_sorted, int64_t M, int64_t K,
+                           int64_t* seg_start, int64_t* nblk, void* stream);
+int spamd_spmm_tiled_pack(int val_dtype, int64_t nnz, const int64_t* tiled_keys_sorted, const void* vals_sorted,
                           const int64_t* seg_start, const int64_t* blk_off, int64_t total_blocks, int* blocks,
                           void* stream);
-int spamd_spmm_tiled(int64_t M, int64_t K, int64_t N, const int* blocks, const int* blk_off32, const float* b,
-                     int64_t ldb, float* out, int64_t ldo, unsigned flags, void* stream);
+int spamd_spmm_tiled(int val_dtype, int64_t M, int64_t K, int64_t N, const int* blocks, const int* blk_off32,
+                     const void* b, int64_t ldb, void* out, int64_t ldo, unsigned flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * A10  NaN scan                    replaces `nan_check` (_common.py:51-69), the pass `matmul`

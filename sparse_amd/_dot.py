@@ -247,31 +247,47 @@ def _return_kind(return_type):
     raise TypeError(f"unsupported return_type {return_type!r}")
 
 
+def _tiled_dtype(data, bt):
+    """value type of the tiled kernel for this product (the reference's result dtype rule `_dot_dtype`,
+    _common.py:635-636, restricted to what the kernel covers): float32 x float32, or float64 with float32/64."""
+    if data.dtype == torch.float32 and bt.dtype == torch.float32:
+        return torch.float32
+    if {data.dtype, bt.dtype} <= {torch.float32, torch.float64}:
+        return torch.float64
+    return None
+
+
 def _tiled_eligible(data, bt, out_shape, Kd):
-    """The inspector/executor kernel covers fp32 x fp32 -> fp32 with N % 128 == 0.  Thresholds measured on
-    MI355X (tools/tiled_crossover.py): it needs >= 128 workgroups of 512 rows to beat the row-group kernel, and
-    its (32-row x 128-column) lists must hold ~12 stored elements on average — 6 when B is too large for the
-    row-group kernel's gathers to stay in cache (>= 16 MB).  The inspector costs about one row-group product, so a
-    single product breaks even and every further one is ~2x faster."""
+    """The inspector/executor kernel covers float32 (N % 128 == 0) and float64 (N % 64 == 0) products.  Thresholds
+    measured on MI355X (tools/tiled_crossover.py): it needs >= 128 workgroups of 512 rows to beat the row-group
+    kernel, and its (32-row x 128-column) lists must hold ~12 stored elements on average — 6 when B is too large for
+    the row-group kernel's gathers to stay in cache (>= 16 MB).  The inspector costs about one row-group product, so
+    a single product breaks even and every further one is 2-3x faster."""
     M, N = out_shape
-    if _settings.TILED_SPMM == "never":
+    if _settings.TILED_SPMM == "never" or bt.dim() != 2:
         return False
-    if data.dtype != torch.float32 or bt.dtype != torch.float32 or N == 0 or N % 128 or bt.dim() != 2:
+    dt = _tiled_dtype(data, bt)
+    if dt is None or N == 0 or N % (128 if dt == torch.float32 else 64):
         return False
     per_list = int(data.numel()) * 4096 / max(M * Kd, 1)
-    return M >= 65536 and (per_list >= 12 or (per_list >= 6 and Kd * N * 4 >= (16 << 20)))
+    return M >= 65536 and (per_list >= 12 or (per_list >= 6 and Kd * N * bt.element_size() >= (16 << 20)))
 
 
-def prepare_spmm(a):
-    """Build (and cache on `a`) the tiled block stream used by `a @ dense`; returns True if `a` now has one.
-    The counterpart of the reference's memoised conversions (`COO(cache=True)`, _coo/core.py:317-338)."""
+def prepare_spmm(a, dtype=None):
+    """Build (and cache on `a`) the tiled block stream used by `a @ dense` for value type `dtype` (default: a's own
+    if float32/float64); returns True if `a` now has one.  The counterpart of the reference's memoised conversions
+    (`COO(cache=True)`, _coo/core.py:317-338)."""
     from ._gcxs import GCXS
 
-    if not isinstance(a, GCXS) or a.ndim != 2 or a.data.dtype != torch.float32:
+    if not isinstance(a, GCXS) or a.ndim != 2:
         return False
-    if getattr(a, "_tiled_layout", None) is None:
+    dtype = dtype or (a.data.dtype if a.data.dtype in K.TILED_DTYPES else None)
+    if dtype not in K.TILED_DTYPES:
+        return False
+    layouts = a.__dict__.setdefault("_tiled_layouts", {})
+    if dtype not in layouts:
         d, i, p = _csr_triplet(a)
-        a._tiled_layout = K.csr_tiled_layout(d, i, p, int(a.shape[0]), int(a.shape[1]))
+        layouts[dtype] = K.csr_tiled_layout(d, i, p, int(a.shape[0]), int(a.shape[1]), dtype=dtype)
     return True
 
 
@@ -294,8 +310,9 @@ def _gcxs_times_dense(a, bt, out_shape):
     if _tiled_eligible(data, bt, out_shape, Kd):
         # the inspector costs about one product (1.5 ms at config 2 against 1.2 ms per tiled and 2.6 ms per
         # row-group product), so it runs at the first eligible product and is cached on the array
-        prepare_spmm(a)
-        return K.dot_csr_ndarray_tiled(a._tiled_layout, out_shape, Kd, bt, exact=_settings.EXACT_MULADD)
+        dt = _tiled_dtype(data, bt)
+        prepare_spmm(a, dt)
+        return K.dot_csr_ndarray_tiled(a._tiled_layouts[dt], out_shape, Kd, bt.to(dt), exact=_settings.EXACT_MULADD)
     return K.dot_csr_ndarray(out_shape, data, indices, indptr, bt, exact=_settings.EXACT_MULADD)
 
 

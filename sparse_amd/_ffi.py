@@ -91,13 +91,13 @@ SIGNATURES = {
     "spamd_reduce_fill": (_int, [_int, _int, _i64, _vp, _vp, _i64, _C.c_double, _i64, _vp]),
     "spamd_group_reduce_ws_bytes": (_i64, [_int, _i64]),
     "spamd_group_reduce": (_int, [_int, _int, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
-    "spamd_spmm_tiled_params": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
-    "spamd_spmm_tiled_count": (_int, [_int, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
-    "spamd_spmm_tiled_fill": (_int, [_int, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "spamd_spmm_tiled_params": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "spamd_spmm_tiled_count": (_int, [_int, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "spamd_spmm_tiled_fill": (_int, [_int, _int, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "spamd_spmm_tiled_keys": (_int, [_i64, _vp, _i64, _vp, _vp]),
-    "spamd_spmm_tiled_lists": (_int, [_i64, _vp, _i64, _i64, _vp, _vp, _vp]),
-    "spamd_spmm_tiled_pack": (_int, [_i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
-    "spamd_spmm_tiled": (_int, [_i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _u32, _vp]),
+    "spamd_spmm_tiled_lists": (_int, [_int, _i64, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "spamd_spmm_tiled_pack": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "spamd_spmm_tiled": (_int, [_int, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _u32, _vp]),
     "spamd_has_nan": (_int, [_int, _i64, _vp, _vp, _vp]),
     "spamd_spmm_csr": (_int, [_int, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _u32, _vp]),
 }

@@ -659,27 +659,35 @@ def sddmm_coo(coords, s_data, a, bt):
 # ---------------------------------------------------------------------------------------------
 # inspector/executor SpMM (csrc/spmm_tiled.hip)
 # ---------------------------------------------------------------------------------------------
-def tiled_params():
+def tiled_params(dtype=torch.float32):
     """(rows per group, B rows per tile, groups per workgroup, entries per block, slack blocks, max tiles of the
-    direct inspector)."""
-    v = [_ct.c_int(0) for _ in range(6)]
-    _ffi.call("spamd_spmm_tiled_params", *[_ct.byref(x) for x in v])
+    direct inspector, columns per panel) for float32 / float64 values."""
+    v = [_ct.c_int(0) for _ in range(7)]
+    _ffi.call("spamd_spmm_tiled_params", code_of(torch_dtype(dtype)), *[_ct.byref(x) for x in v])
     return tuple(x.value for x in v)
 
 
-def csr_tiled_layout(a_data, a_indices, a_indptr, M, Kd, force_sort=False):
-    """Inspector: the K-tiled block stream of a CSR matrix used by `dot_csr_ndarray_tiled` (fp32).
-    Returns (blocks int32[(total_blocks + slack) * 16], blk_off int32[nseg + 1]).
+TILED_DTYPES = (torch.float32, torch.float64)
+
+
+def csr_tiled_layout(a_data, a_indices, a_indptr, M, Kd, force_sort=False, dtype=None):
+    """Inspector: the K-tiled block stream of a CSR matrix used by `dot_csr_ndarray_tiled`, for float32 or float64
+    values (`dtype`, default: a_data's if it is one of them, else float32).
+    Returns (blocks int32[(total_blocks + slack) * 16], blk_off int32[nseg + 1], value dtype).
     Sorted column indices and a moderate K take the direct two-pass builder (count, scan, fill); anything
     else the general key-sort recipe."""
     dev = require_hip(a_data, a_indices, a_indptr)
-    rg, kb, gpb, epb, slack, direct_max = tiled_params()
+    if dtype is None:
+        dtype = a_data.dtype if a_data.dtype in TILED_DTYPES else torch.float32
+    dtype = torch_dtype(dtype)
+    vc = code_of(dtype)
+    rg, kb, gpb, epb, slack, direct_max, _ = tiled_params(dtype)
     nnz = int(a_data.numel())
     ntiles = -(-Kd // kb)
     groups = -(-(-(-M // rg)) // gpb) * gpb
     nseg = groups * ntiles
     s = stream_ptr(dev)
-    vals = a_data.to(torch.float32).contiguous()
+    vals = a_data.to(dtype).contiguous()
     if not index_dtype_ok(a_indices) or a_indices.dtype != a_indptr.dtype:
         a_indices, a_indptr = a_indices.to(torch.int64), a_indptr.to(torch.int64)
 
@@ -687,20 +695,20 @@ def csr_tiled_layout(a_data, a_indices, a_indptr, M, Kd, force_sort=False):
         total = int(blk_off[-1])
         if total >= 2 ** 31:
             raise ValueError("tiled SpMM layout: more than 2^31 blocks")
-        blocks = torch.empty((total + slack) * epb * 2, dtype=torch.int32, device=dev)
+        blocks = torch.empty((total + slack) * 16, dtype=torch.int32, device=dev)
         fill(blk_off, total, blocks)
-        return blocks, convert(blk_off, torch.int32)
+        return blocks, convert(blk_off, torch.int32), dtype
 
     if ntiles <= direct_max and not force_sort:
         nblk = torch.empty(nseg + 1, dtype=torch.int64, device=dev)
         flags = torch.empty(1, dtype=torch.int32, device=dev)
         ic = code_of(a_indices.dtype)
         ind, ptr_ = a_indices.contiguous(), a_indptr.contiguous()
-        _ffi.call("spamd_spmm_tiled_count", ic, M, Kd, ptr(ind), ptr(ptr_), ptr(nblk), ptr(flags), s)
+        _ffi.call("spamd_spmm_tiled_count", vc, ic, M, Kd, ptr(ind), ptr(ptr_), ptr(nblk), ptr(flags), s)
         blk_off = exclusive_scan(nblk)
         if int(flags[0]) == 0:
             return finish(blk_off, lambda bo, total, blocks: _ffi.call(
-                "spamd_spmm_tiled_fill", ic, M, Kd, ptr(vals), ptr(ind), ptr(ptr_), ptr(bo), total, ptr(blocks), s))
+                "spamd_spmm_tiled_fill", vc, ic, M, Kd, ptr(vals), ptr(ind), ptr(ptr_), ptr(bo), total, ptr(blocks), s))
     rc = csr_to_keys(a_indptr, a_indices, M, Kd)
     tk = torch.empty_like(rc)
     _ffi.call("spamd_spmm_tiled_keys", nnz, ptr(rc), Kd, ptr(tk), s)
@@ -708,20 +716,22 @@ def csr_tiled_layout(a_data, a_indices, a_indptr, M, Kd, force_sort=False):
     tk, vals = sort_key_value(tk, vals, max(nseg * rg * kb - 1, 1))
     seg_start = torch.empty(nseg + 1, dtype=torch.int64, device=dev)
     nblk = torch.empty(nseg + 1, dtype=torch.int64, device=dev)
-    _ffi.call("spamd_spmm_tiled_lists", nnz, ptr(tk), M, Kd, ptr(seg_start), ptr(nblk), s)
+    _ffi.call("spamd_spmm_tiled_lists", vc, nnz, ptr(tk), M, Kd, ptr(seg_start), ptr(nblk), s)
     return finish(exclusive_scan(nblk), lambda bo, total, blocks: _ffi.call(
-        "spamd_spmm_tiled_pack", nnz, ptr(tk), ptr(vals), ptr(seg_start), ptr(bo), total, ptr(blocks), s))
+        "spamd_spmm_tiled_pack", vc, nnz, ptr(tk), ptr(vals), ptr(seg_start), ptr(bo), total, ptr(blocks), s))
 
 
 def dot_csr_ndarray_tiled(layout, out_shape, Kd, b, out=None, exact=False):
-    """Executor: C = A @ B from the tiled layout (fp32, N % 128 == 0); `exact` = separate multiply and add
-    (the reference's arithmetic) instead of one FMA per term."""
-    blocks, blk_off = layout
+    """Executor: C = A @ B from the tiled layout (float32: N % 128 == 0, float64: N % 64 == 0); `exact` = separate
+    multiply and add (the reference's arithmetic) instead of one FMA per term."""
+    blocks, blk_off, dtype = layout
     M, N = int(out_shape[0]), int(out_shape[1])
     dev = require_hip(blocks, blk_off, b)
+    if b.dtype != dtype:
+        raise TypeError(f"tiled layout holds {dtype} values, B is {b.dtype}")
     b = b.contiguous()
     if out is None:
-        out = torch.empty((M, N), dtype=torch.float32, device=dev)
-    _ffi.call("spamd_spmm_tiled", M, Kd, N, ptr(blocks), ptr(blk_off), ptr(b), N, ptr(out), N,
+        out = torch.empty((M, N), dtype=dtype, device=dev)
+    _ffi.call("spamd_spmm_tiled", code_of(dtype), M, Kd, N, ptr(blocks), ptr(blk_off), ptr(b), N, ptr(out), N,
               _ffi.EXACT_MULADD if exact else 0, stream_ptr(dev))
     return out

@@ -38,7 +38,35 @@ constexpr int TL_KB = 128;       // B rows per tile: 64 KB, so that (column << 9
 constexpr int TL_NBUF = 2;       // LDS tile buffers: tile t+1 is in flight while tile t is consumed
                                  // (64-row tiles with 3-5 buffers were measured 30-40 % slower: twice the
                                  // barriers and list heads, 17 % padding)
-constexpr int TL_EPB = 8;        // entries per stream block
+constexpr int TL_BLOCK_INTS = 16; // a stream block is 64 bytes
+
+// Per value type: entries per block and where an entry lives inside its block.
+//   float : 8 x (d0, value bits)                                           columns per lane 2 (v_pk_fma_f32), panel 128
+//   double: d0 of 5 entries, one pad dword, 5 x (value lo, value hi)       columns per lane 1 (v_fma_f64),    panel  64
+// In both cases a B row of the panel is 512 bytes in the LDS tile and a lane reads 8 of them with ds_read_b64.
+template <typename T>
+struct TlFmt;
+template <>
+struct TlFmt<float> {
+  static constexpr int EPB = 8, PANEL = 128;
+  __device__ static void put(int* stream, int64_t entry, int d0, float v) {
+    int* b = stream + (entry / EPB) * TL_BLOCK_INTS + (entry % EPB) * 2;
+    b[0] = d0;
+    b[1] = __builtin_bit_cast(int, v);
+  }
+};
+template <>
+struct TlFmt<double> {
+  static constexpr int EPB = 5, PANEL = 64;
+  __device__ static void put(int* stream, int64_t entry, int d0, double v) {
+    int* b = stream + (entry / EPB) * TL_BLOCK_INTS;
+    const int slot = (int)(entry % EPB);
+    const long long bits = __builtin_bit_cast(long long, v);
+    b[slot] = d0;
+    b[6 + 2 * slot] = (int)(bits & 0xffffffffLL);
+    b[7 + 2 * slot] = (int)(bits >> 32);
+  }
+};
 constexpr int TL_TILE = TL_KB * 512;
 constexpr int TL_LDS = TL_NBUF * TL_TILE;
 constexpr int TL_DMA_PER_TILE = TL_TILE / 16 / (TL_WAVES * 64);  // LDS-DMA instructions per wave per tile
@@ -71,21 +99,22 @@ __global__ void __launch_bounds__(256) tl_seg_start_kernel(const int64_t* __rest
 }
 
 // nblk[s] = blocks of list s (input of the exclusive scan); nblk[nseg] = 0
-__global__ void __launch_bounds__(256) tl_blocks_kernel(const int64_t* __restrict__ seg_start, int64_t nseg,
+__global__ void __launch_bounds__(256) tl_blocks_kernel(const int64_t* __restrict__ seg_start, int64_t nseg, int epb,
                                                         int64_t* __restrict__ nblk) {
   GRID_STRIDE(s, nseg + 1) {
-    nblk[s] = s < nseg ? (seg_start[s + 1] - seg_start[s] + TL_EPB - 1) / TL_EPB : 0;
+    nblk[s] = s < nseg ? (seg_start[s + 1] - seg_start[s] + epb - 1) / epb : 0;
   }
 }
 
-__global__ void __launch_bounds__(256) tl_pack_kernel(const int64_t* __restrict__ keys, const float* __restrict__ vals,
+template <typename T>
+__global__ void __launch_bounds__(256) tl_pack_kernel(const int64_t* __restrict__ keys, const T* __restrict__ vals,
                                                       int64_t nnz, const int64_t* __restrict__ seg_start,
-                                                      const int64_t* __restrict__ blk_off, int2* __restrict__ stream) {
+                                                      const int64_t* __restrict__ blk_off, int* __restrict__ stream) {
   GRID_STRIDE(i, nnz) {
     const int64_t k = keys[i];
     const int64_t lc = k % TL_KB, r1 = k / TL_KB, lr = r1 % TL_RG, s = r1 / TL_RG;
-    const int64_t dst = blk_off[s] * TL_EPB + (i - seg_start[s]);
-    stream[dst] = make_int2((int)((lc << 9) | (2 + 2 * lr)), __builtin_bit_cast(int, vals[i]));
+    const int64_t dst = blk_off[s] * TlFmt<T>::EPB + (i - seg_start[s]);
+    TlFmt<T>::put(stream, dst, (int)((lc << 9) | (2 + 2 * lr)), vals[i]);
   }
 }
 
@@ -106,7 +135,7 @@ __device__ __forceinline__ int tl_row_of(const int64_t* rs, int64_t e) {  // lar
 }
 
 template <typename I>
-__global__ void __launch_bounds__(256) tl_count_kernel(int64_t M, int ntiles, const I* __restrict__ indices,
+__global__ void __launch_bounds__(256) tl_count_kernel(int64_t M, int ntiles, int epb, const I* __restrict__ indices,
                                                        const I* __restrict__ indptr, int64_t* __restrict__ nblk,
                                                        int* __restrict__ flags) {
   __shared__ int cnt[TL_DIRECT_MAX_TILES];
@@ -128,13 +157,13 @@ __global__ void __launch_bounds__(256) tl_count_kernel(int64_t M, int ntiles, co
   }
   if (bad) flags[0] = 1;
   __syncthreads();
-  for (int t = tid; t < ntiles; t += 256) nblk[(int64_t)blockIdx.x * ntiles + t] = (cnt[t] + TL_EPB - 1) / TL_EPB;
+  for (int t = tid; t < ntiles; t += 256) nblk[(int64_t)blockIdx.x * ntiles + t] = (cnt[t] + epb - 1) / epb;
 }
 
-template <typename I>
-__global__ void __launch_bounds__(256) tl_fill_kernel(int64_t M, int ntiles, const float* __restrict__ vals,
+template <typename I, typename T>
+__global__ void __launch_bounds__(256) tl_fill_kernel(int64_t M, int ntiles, const T* __restrict__ vals,
                                                       const I* __restrict__ indices, const I* __restrict__ indptr,
-                                                      const int64_t* __restrict__ blk_off, int2* __restrict__ stream) {
+                                                      const int64_t* __restrict__ blk_off, int* __restrict__ stream) {
   extern __shared__ int tl_fill_lds[];  // before[32][ntiles], runstart[32][ntiles] (relative to e0), slot0[ntiles]
   __shared__ int64_t rs[TL_RG + 1];
   int* const before = tl_fill_lds;
@@ -169,8 +198,8 @@ __global__ void __launch_bounds__(256) tl_fill_kernel(int64_t M, int ntiles, con
     const int64_t c = (int64_t)indices[e];
     const int t = (int)(c / TL_KB), lc = (int)(c - (int64_t)t * TL_KB);
     const int lr = tl_row_of<I>(rs, e);
-    const int64_t dst = goff[t] * TL_EPB + before[lr * ntiles + t] + ((int)(e - e0) - runstart[lr * ntiles + t]);
-    stream[dst] = make_int2((lc << 9) | (2 + 2 * lr), __builtin_bit_cast(int, vals[e]));
+    const int64_t dst = goff[t] * TlFmt<T>::EPB + before[lr * ntiles + t] + ((int)(e - e0) - runstart[lr * ntiles + t]);
+    TlFmt<T>::put(stream, dst, (lc << 9) | (2 + 2 * lr), vals[e]);
   }
 }
 
@@ -185,8 +214,8 @@ __device__ __forceinline__ void tl_dma16(unsigned lds_base, const void* src) {
 // over the blocks [o(t), o(t+1)) reading B rows from LDS tile t, the wave's share of the LDS-DMA of tile
 // t+1 (if t+1 < nfull), the scalar request for the first blocks of list t+1, the line touch of list t+2,
 // the DMA wait and the barrier.  o(t) = lane (min(t, ntiles) - obase) of `offreg`; o0..o2 = o(t0..t0+2).
-// MODE: 0 one fma per term, 3 separate multiply and add (the reference's arithmetic, bit for bit);
-// 1 no fma, 2 no LDS reads / fma (timing ablations).
+// MODE: 0 one fma per term, 3 separate multiply and add (the reference's arithmetic, bit for bit); 4 / 5 the same
+// for float64 (5-entry blocks, one column per lane); 1 no fma, 2 no LDS reads / fma (timing ablations).
 template <int MODE>
 __device__ __forceinline__ void tl_phases(const int* stream, int t0, int te, int o0, int o1, int o2, int offreg, int obase,
                                           int ntiles, int nfull, int lane, int mask, unsigned m0wave,
@@ -198,7 +227,11 @@ __device__ __forceinline__ void tl_phases(const int* stream, int t0, int te, int
     [obase] "s"(obase), [ntiles] "s"(ntiles), [nfull] "s"(nfull), [m0wave] "s"(m0wave), [step] "s"(row_step),      \
     [lane] "v"(lane), [lane8] "v"(lane8), [mask] "v"(mask), [offreg] "v"(offreg)                                  \
   : "memory", "m0", "scc", TL_CLOB_SGPR, TL_CLOB_TMP, TL_CLOB_ACC
-  if (MODE == 3)
+  if (MODE == 4)
+    asm volatile(TL_ASM_PHASES_F64 : TL_PHASES_OPERANDS);
+  else if (MODE == 5)
+    asm volatile(TL_ASM_PHASES_F64_EXACT : TL_PHASES_OPERANDS);
+  else if (MODE == 3)
     asm volatile(TL_ASM_PHASES_EXACT : TL_PHASES_OPERANDS);
   else if (MODE == 1)
     asm volatile(TL_ASM_PHASES_NOFMA : TL_PHASES_OPERANDS);
@@ -210,18 +243,20 @@ __device__ __forceinline__ void tl_phases(const int* stream, int t0, int te, int
 }
 
 // DBG (timing ablation): 2 = no tile DMA.  MODE: see tl_phases.
-template <int DBG, int MODE>
+template <int DBG, int MODE, typename T>
 __global__ void __launch_bounds__(TL_WAVES * 64) __attribute__((amdgpu_num_vgpr(22)))
 spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, const int* __restrict__ stream,
-                  const int* __restrict__ blk_off, const float* __restrict__ b, int64_t ldb,
-                  float* __restrict__ out, int64_t ldo) {
+                  const int* __restrict__ blk_off, const T* __restrict__ b, int64_t ldb,
+                  T* __restrict__ out, int64_t ldo) {
+  constexpr int PANEL = TlFmt<T>::PANEL;            // columns per workgroup: 512 bytes of every B row
+  constexpr int CPL = PANEL / 64;                   // columns per lane
   extern __shared__ __attribute__((aligned(16))) char lds[];  // the only LDS object: starts at LDS byte 0
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = uniform(tid >> 6);
   const int64_t g = (int64_t)blockIdx.x * TL_WAVES + wv;  // my row group (lists exist for every wave of the grid)
-  b += (int64_t)blockIdx.y * 128;                          // column panel of B and of the result
-  out += (int64_t)blockIdx.y * 128;
+  b += (int64_t)blockIdx.y * PANEL;                        // column panel of B and of the result
+  out += (int64_t)blockIdx.y * PANEL;
 
   asm volatile(TL_ASM_ZERO ::: "memory", TL_CLOB_ACC);
 
@@ -231,10 +266,10 @@ spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, const int* __restrict__ stre
   // the last, partial tile goes through `issue_partial`, rows past K clamped to row K-1 (no entry
   // refers to them).
   const int nfull = DBG == 2 ? 0 : (int)(K / TL_KB);
-  const int64_t row_step = 32 * ldb * 4;
+  const int64_t row_step = 32 * ldb * (int64_t)sizeof(T);
   const unsigned m0wave = (unsigned)wv * 1024u;
   {
-    const float* p0 = b + (int64_t)(tid >> 5) * ldb + (tid & 31) * 4;
+    const T* p0 = b + (int64_t)(tid >> 5) * ldb + (tid & 31) * (16 / (int)sizeof(T));
     asm volatile("v_mov_b32 v22, %0\n\tv_mov_b32 v23, %1" ::"v"((unsigned)((uintptr_t)p0 & 0xffffffffu)),
                  "v"((unsigned)((uintptr_t)p0 >> 32))
                  : "v22", "v23");
@@ -243,10 +278,11 @@ spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, const int* __restrict__ stre
     const unsigned buf = (unsigned)(t & 1) * TL_TILE;
 #pragma unroll
     for (int i = 0; i < TL_DMA_PER_TILE; ++i) {
-      const int e = (i * (TL_WAVES * 64) + tid) * 4;
-      int64_t r = (int64_t)t * TL_KB + (e >> 7);
+      const int e = (i * (TL_WAVES * 64) + tid) * 16;  // byte inside the tile (512 bytes per row)
+      int64_t r = (int64_t)t * TL_KB + (e >> 9);
       if (r >= K) r = K - 1;
-      tl_dma16(buf + (unsigned)(i * TL_WAVES + wv) * 1024u, b + r * ldb + (e & 127));
+      tl_dma16(buf + (unsigned)(i * TL_WAVES + wv) * 1024u,
+               reinterpret_cast<const char*>(b + r * ldb) + (e & 511));
     }
   };
   const bool has_partial = DBG != 2 && (int64_t)nfull * TL_KB < K;  // tile `nfull` is the partial one
@@ -296,8 +332,8 @@ spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, const int* __restrict__ stre
   const int64_t row0 = g * TL_RG;
   const int64_t left = M - row0;
   const int nvalid = left <= 0 ? 0 : (left < TL_RG ? (int)left : TL_RG);
-  float* const obase_p = out + row0 * ldo + lane * 2;
-  const int64_t stride_bytes = ldo * 4;
+  T* const obase_p = out + row0 * ldo + lane * CPL;
+  const int64_t stride_bytes = ldo * (int64_t)sizeof(T);
   asm volatile(TL_ASM_STORE
                :
                : [lo] "v"((unsigned)((uintptr_t)obase_p & 0xffffffffu)), [hi] "v"((unsigned)((uintptr_t)obase_p >> 32)),
@@ -311,14 +347,19 @@ static int64_t tl_grid_groups(int64_t M) { return ceil_div(ceil_div(M, (int64_t)
 
 using namespace spamd;
 
-extern "C" int spamd_spmm_tiled_params(int* rows_per_group, int* tile_rows, int* groups_per_block,
-                                       int* entries_per_block, int* slack_blocks, int* direct_max_tiles) {
+static int tl_epb(int val_dtype) { return val_dtype == SPAMD_F32 ? TlFmt<float>::EPB : (val_dtype == SPAMD_F64 ? TlFmt<double>::EPB : 0); }
+
+extern "C" int spamd_spmm_tiled_params(int val_dtype, int* rows_per_group, int* tile_rows, int* groups_per_block,
+                                       int* entries_per_block, int* slack_blocks, int* direct_max_tiles,
+                                       int* panel_cols) {
+  if (!tl_epb(val_dtype)) return SPAMD_ETYPE;
   if (direct_max_tiles) *direct_max_tiles = TL_DIRECT_MAX_TILES;
   if (rows_per_group) *rows_per_group = TL_RG;
   if (tile_rows) *tile_rows = TL_KB;
   if (groups_per_block) *groups_per_block = TL_WAVES;
-  if (entries_per_block) *entries_per_block = TL_EPB;
+  if (entries_per_block) *entries_per_block = tl_epb(val_dtype);
   if (slack_blocks) *slack_blocks = TL_SLACK_BLOCKS;
+  if (panel_cols) *panel_cols = val_dtype == SPAMD_F32 ? TlFmt<float>::PANEL : TlFmt<double>::PANEL;
   return 0;
 }
 
@@ -338,32 +379,43 @@ extern "C" int spamd_spmm_tiled_keys(int64_t nnz, const int64_t* rowcol_keys, in
   return launch_status();
 }
 
-extern "C" int spamd_spmm_tiled_lists(int64_t nnz, const int64_t* tiled_keys_sorted, int64_t M, int64_t K,
+extern "C" int spamd_spmm_tiled_lists(int val_dtype, int64_t nnz, const int64_t* tiled_keys_sorted, int64_t M, int64_t K,
                                       int64_t* seg_start, int64_t* nblk, void* stream) {
   if (nnz < 0 || M < 0 || K <= 0) return SPAMD_EINVAL;
+  if (!tl_epb(val_dtype)) return SPAMD_ETYPE;
   const int64_t nseg = tl_grid_groups(M) * ceil_div(K, (int64_t)TL_KB);
   hipLaunchKernelGGL(tl_seg_start_kernel, dim3(tl_blocks_for(nnz + 1)), dim3(256), 0, (hipStream_t)stream,
                      tiled_keys_sorted, nnz, nseg, seg_start);
   hipLaunchKernelGGL(tl_blocks_kernel, dim3(tl_blocks_for(nseg + 1)), dim3(256), 0, (hipStream_t)stream, seg_start,
-                     nseg, nblk);
+                     nseg, tl_epb(val_dtype), nblk);
   return launch_status();
 }
 
-extern "C" int spamd_spmm_tiled_pack(int64_t nnz, const int64_t* tiled_keys_sorted, const float* vals_sorted,
+static int tl_clear_blocks(int64_t total_blocks, int* blocks, hipStream_t s) {
+  return (int)hipMemsetAsync(blocks, 0, (size_t)(total_blocks + TL_SLACK_BLOCKS) * TL_BLOCK_INTS * sizeof(int), s);
+}
+
+extern "C" int spamd_spmm_tiled_pack(int val_dtype, int64_t nnz, const int64_t* tiled_keys_sorted, const void* vals_sorted,
                                      const int64_t* seg_start, const int64_t* blk_off, int64_t total_blocks,
                                      int* blocks, void* stream) {
   if (nnz < 0 || total_blocks < 0) return SPAMD_EINVAL;
-  hipError_t e = hipMemsetAsync(blocks, 0, (size_t)(total_blocks + TL_SLACK_BLOCKS) * TL_EPB * 8, (hipStream_t)stream);
-  if (e != hipSuccess) return (int)e;
+  if (!tl_epb(val_dtype)) return SPAMD_ETYPE;
+  int rc = tl_clear_blocks(total_blocks, blocks, (hipStream_t)stream);
+  if (rc) return rc;
   if (nnz == 0) return 0;
-  hipLaunchKernelGGL(tl_pack_kernel, dim3(tl_blocks_for(nnz)), dim3(256), 0, (hipStream_t)stream, tiled_keys_sorted,
-                     vals_sorted, nnz, seg_start, blk_off, reinterpret_cast<int2*>(blocks));
+  if (val_dtype == SPAMD_F32)
+    hipLaunchKernelGGL(tl_pack_kernel<float>, dim3(tl_blocks_for(nnz)), dim3(256), 0, (hipStream_t)stream, tiled_keys_sorted,
+                       (const float*)vals_sorted, nnz, seg_start, blk_off, blocks);
+  else
+    hipLaunchKernelGGL(tl_pack_kernel<double>, dim3(tl_blocks_for(nnz)), dim3(256), 0, (hipStream_t)stream, tiled_keys_sorted,
+                       (const double*)vals_sorted, nnz, seg_start, blk_off, blocks);
   return launch_status();
 }
 
-extern "C" int spamd_spmm_tiled_count(int idx_dtype, int64_t M, int64_t K, const void* a_indices, const void* a_indptr,
-                                      int64_t* nblk, int* flags, void* stream) {
+extern "C" int spamd_spmm_tiled_count(int val_dtype, int idx_dtype, int64_t M, int64_t K, const void* a_indices,
+                                      const void* a_indptr, int64_t* nblk, int* flags, void* stream) {
   if (M < 0 || K <= 0) return SPAMD_EINVAL;
+  if (!tl_epb(val_dtype)) return SPAMD_ETYPE;
   const int64_t ntiles = ceil_div(K, (int64_t)TL_KB);
   if (ntiles > TL_DIRECT_MAX_TILES) return SPAMD_EINVAL;
   const int64_t groups = tl_grid_groups(M);
@@ -373,53 +425,81 @@ extern "C" int spamd_spmm_tiled_count(int idx_dtype, int64_t M, int64_t K, const
   if (e != hipSuccess) return (int)e;
   if (groups == 0) return 0;
   SPAMD_DISPATCH_IDX(idx_dtype, I, hipLaunchKernelGGL(tl_count_kernel<I>, dim3((unsigned)groups), dim3(256), 0,
-                                                    (hipStream_t)stream, M, (int)ntiles, (const I*)a_indices,
-                                                    (const I*)a_indptr, nblk, flags))
+                                                    (hipStream_t)stream, M, (int)ntiles, tl_epb(val_dtype),
+                                                    (const I*)a_indices, (const I*)a_indptr, nblk, flags))
   return launch_status();
 }
 
-extern "C" int spamd_spmm_tiled_fill(int idx_dtype, int64_t M, int64_t K, const float* a_data, const void* a_indices,
-                                     const void* a_indptr, const int64_t* blk_off, int64_t total_blocks, int* blocks,
-                                     void* stream) {
+template <typename I, typename T>
+static int tl_launch_fill(int64_t M, int64_t ntiles, const T* a_data, const I* a_indices, const I* a_indptr,
+                          const int64_t* blk_off, int* blocks, hipStream_t s) {
+  const int lds = (int)(2 * TL_RG * ntiles * sizeof(int));
+  auto kern = &tl_fill_kernel<I, T>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)tl_grid_groups(M)), dim3(256), lds, s, M, (int)ntiles, a_data, a_indices, a_indptr,
+                     blk_off, blocks);
+  return launch_status();
+}
+
+extern "C" int spamd_spmm_tiled_fill(int val_dtype, int idx_dtype, int64_t M, int64_t K, const void* a_data,
+                                     const void* a_indices, const void* a_indptr, const int64_t* blk_off,
+                                     int64_t total_blocks, int* blocks, void* stream) {
   if (M < 0 || K <= 0 || total_blocks < 0) return SPAMD_EINVAL;
+  if (!tl_epb(val_dtype)) return SPAMD_ETYPE;
   const int64_t ntiles = ceil_div(K, (int64_t)TL_KB);
   if (ntiles > TL_DIRECT_MAX_TILES) return SPAMD_EINVAL;
-  hipError_t e = hipMemsetAsync(blocks, 0, (size_t)(total_blocks + TL_SLACK_BLOCKS) * TL_EPB * 8, (hipStream_t)stream);
-  if (e != hipSuccess) return (int)e;
-  const int64_t groups = tl_grid_groups(M);
-  if (groups == 0) return 0;
-  const int lds = (int)(2 * TL_RG * ntiles * sizeof(int));
+  int rc = tl_clear_blocks(total_blocks, blocks, (hipStream_t)stream);
+  if (rc) return rc;
+  if (tl_grid_groups(M) == 0) return 0;
   SPAMD_DISPATCH_IDX(idx_dtype, I, {
-    auto kern = &tl_fill_kernel<I>;
-    if (lds > 48 * 1024) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(256), lds, (hipStream_t)stream, M, (int)ntiles, a_data,
-                       (const I*)a_indices, (const I*)a_indptr, blk_off, reinterpret_cast<int2*>(blocks));
+    if (val_dtype == SPAMD_F32)
+      return tl_launch_fill<I, float>(M, ntiles, (const float*)a_data, (const I*)a_indices, (const I*)a_indptr, blk_off,
+                                      blocks, (hipStream_t)stream);
+    return tl_launch_fill<I, double>(M, ntiles, (const double*)a_data, (const I*)a_indices, (const I*)a_indptr, blk_off,
+                                     blocks, (hipStream_t)stream);
   })
+  return SPAMD_ETYPE;
+}
+
+template <typename T, typename KERN>
+static int tl_launch(KERN kern, int64_t M, int64_t K, int64_t N, const int* blocks, const int* blk_off, const T* b,
+                     int64_t ldb, T* out, int64_t ldo, hipStream_t s) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS);
+  if (e != hipSuccess) return (int)e;
+  const int64_t blocks_n = tl_grid_groups(M) / TL_WAVES;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks_n, (unsigned)(N / TlFmt<T>::PANEL)), dim3(TL_WAVES * 64), TL_LDS, s, M, K,
+                     (int)ceil_div(K, (int64_t)TL_KB), blocks, blk_off, b, ldb, out, ldo);
   return launch_status();
 }
 
-extern "C" int spamd_spmm_tiled(int64_t M, int64_t K, int64_t N, const int* blocks, const int* blk_off,
-                                const float* b, int64_t ldb, float* out, int64_t ldo, unsigned flags, void* stream) {
-  if (M < 0 || K <= 0 || N <= 0 || N % 128 != 0 || N / 128 > 65535 || K / TL_KB >= ((int64_t)1 << 30)) return SPAMD_EINVAL;
+extern "C" int spamd_spmm_tiled(int val_dtype, int64_t M, int64_t K, int64_t N, const int* blocks, const int* blk_off,
+                                const void* b, int64_t ldb, void* out, int64_t ldo, unsigned flags, void* stream) {
+  if (!tl_epb(val_dtype)) return SPAMD_ETYPE;
+  const int panel = val_dtype == SPAMD_F32 ? TlFmt<float>::PANEL : TlFmt<double>::PANEL;
+  const int esz = val_dtype == SPAMD_F32 ? 4 : 8;
+  if (M < 0 || K <= 0 || N <= 0 || N % panel != 0 || N / panel > 65535 || K / TL_KB >= ((int64_t)1 << 30)) return SPAMD_EINVAL;
   if (M == 0) return 0;
-  if (((uintptr_t)b % 16) || (ldb % 4) || ((uintptr_t)out % 8) || (ldo % 2) || ((uintptr_t)blocks % 64))
+  if (((uintptr_t)b % 16) || ((ldb * esz) % 16) || ((uintptr_t)out % 8) || ((ldo * esz) % 8) || ((uintptr_t)blocks % 64))
     return SPAMD_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const bool exact = (flags & SPAMD_EXACT_MULADD) != 0;
+  if (val_dtype == SPAMD_F64) {
+    const double* bb = (const double*)b;
+    double* oo = (double*)out;
+    return exact ? tl_launch<double>(&spmm_tiled_kernel<0, 5, double>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, s)
+                 : tl_launch<double>(&spmm_tiled_kernel<0, 4, double>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, s);
+  }
+  const float* bb = (const float*)b;
+  float* oo = (float*)out;
   const char* dbg_env = getenv("SPAMD_TILED_DBG");  // timing ablations: 2 = no tile DMA, 5 = no fma, 6 = no LDS reads/fma
   const int dbg = dbg_env ? atoi(dbg_env) : 0;
-  auto kern = dbg == 2 ? &spmm_tiled_kernel<2, 0>
-            : dbg == 5 ? &spmm_tiled_kernel<0, 1>
-            : dbg == 6 ? &spmm_tiled_kernel<0, 2>
-            : dbg == 7 ? &spmm_tiled_kernel<2, 2>
-            : (flags & SPAMD_EXACT_MULADD) ? &spmm_tiled_kernel<0, 3> : &spmm_tiled_kernel<0, 0>;
-  const int lds_bytes = TL_LDS;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     lds_bytes);
-  if (e != hipSuccess) return (int)e;
-  const int64_t blocks_n = tl_grid_groups(M) / TL_WAVES;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks_n, (unsigned)(N / 128)), dim3(TL_WAVES * 64), lds_bytes, (hipStream_t)stream, M, K,
-                     (int)ceil_div(K, (int64_t)TL_KB), blocks, blk_off, b, ldb, out, ldo);
-  return launch_status();
+  if (dbg == 2) return tl_launch<float>(&spmm_tiled_kernel<2, 0, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, s);
+  if (dbg == 5) return tl_launch<float>(&spmm_tiled_kernel<0, 1, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, s);
+  if (dbg == 6) return tl_launch<float>(&spmm_tiled_kernel<0, 2, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, s);
+  if (dbg == 7) return tl_launch<float>(&spmm_tiled_kernel<2, 2, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, s);
+  return exact ? tl_launch<float>(&spmm_tiled_kernel<0, 3, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, s)
+               : tl_launch<float>(&spmm_tiled_kernel<0, 0, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, s);
 }

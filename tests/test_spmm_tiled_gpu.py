@@ -37,8 +37,8 @@ def test_tiled_bit_identical_to_rowgroup_fma(orc, idt, M, K, density):
     assert torch.equal(got, ref)
     want = orc.dot_csr_ndarray((M, 128), data, idx, ptr, b)
     assert np.allclose(got.cpu().numpy(), want, rtol=2e-5, atol=1e-6)
-    blocks, blk_off = layout
-    rg, kb, gpb, epb, slack, _ = Kn_params()
+    blocks, blk_off, _ = layout
+    rg, kb, gpb, epb, slack, _, _ = Kn_params()
     assert bool((blk_off[1:] >= blk_off[:-1]).all()) and blocks.numel() == (int(blk_off[-1]) + slack) * epb * 2
     ent = blocks.view(-1, 2)[: int(blk_off[-1]) * epb].cpu().numpy()
     real = ent[ent[:, 0] != 0]                                         # padding entries are all-zero
@@ -84,13 +84,13 @@ def test_product_path_builds_and_caches_the_block_stream(orc, monkeypatch):
     a, b, (data, idx, ptr, bh) = _product_case()
     monkeypatch.setattr(_settings, "TILED_SPMM", "never")
     r1 = a @ b
-    assert getattr(a, "_tiled_layout", None) is None
+    assert not getattr(a, "_tiled_layouts", None)
     monkeypatch.setattr(_settings, "TILED_SPMM", "auto")
     r2 = a @ b
-    layout = a._tiled_layout
+    layout = a._tiled_layouts[torch.float32]
     assert layout is not None
     r3 = a @ b
-    assert a._tiled_layout is layout
+    assert a._tiled_layouts[torch.float32] is layout
     assert torch.equal(r1, r2) and torch.equal(r2, r3)
     want = orc.dot_csr_ndarray((a.shape[0], 128), data, idx, ptr, bh)
     assert np.allclose(r3.cpu().numpy(), want, rtol=2e-5, atol=1e-6)
@@ -104,7 +104,7 @@ def test_product_path_column_panels(orc, monkeypatch, N):
     monkeypatch.setattr(_settings, "EXACT_MULADD", False)
     a, b, (data, idx, ptr, bh) = _product_case(N=N, seed=8)
     got = a @ b
-    assert a._tiled_layout is not None
+    assert a._tiled_layouts
     ref = Kn.dot_csr_ndarray((a.shape[0], N), a.data, a.indices, a.indptr, b, exact=False)
     assert torch.equal(got, ref)
     want = orc.dot_csr_ndarray((a.shape[0], N), data, idx, ptr, bh)
@@ -121,7 +121,7 @@ def test_product_path_csc_operand_uses_the_csr_twin(orc, monkeypatch):
     a, b, (data, idx, ptr, bh) = _product_case(seed=11)
     acsc = a.change_compressed_axes((1,))
     got = acsc @ b
-    assert acsc._tiled_layout is not None and acsc._csr_twin is not None
+    assert acsc._tiled_layouts and acsc._csr_twin is not None
     want = orc.dot_csr_ndarray((a.shape[0], 128), data, idx, ptr, bh)
     assert np.allclose(got.cpu().numpy(), want, rtol=2e-5, atol=1e-6)
 
@@ -151,14 +151,14 @@ def test_exact_mode_uses_the_tiled_path_and_small_n_keeps_the_rowgroup_kernel(mo
     monkeypatch.setattr(_settings, "EXACT_MULADD", True)
     a, b, _ = _product_case(seed=12)
     r = a @ b
-    assert getattr(a, "_tiled_layout", None) is not None
+    assert getattr(a, "_tiled_layouts", None)
     monkeypatch.setattr(_settings, "TILED_SPMM", "never")
     assert torch.equal(r, a @ b)
     monkeypatch.setattr(_settings, "TILED_SPMM", "auto")
     monkeypatch.setattr(_settings, "EXACT_MULADD", False)
     a2, b2, _ = _product_case(N=64, seed=13)
     a2 @ b2
-    assert getattr(a2, "_tiled_layout", None) is None
+    assert not getattr(a2, "_tiled_layouts", None)
 
 
 @pytest.mark.parametrize("idt", [np.int32, np.int64])
@@ -170,8 +170,8 @@ def test_direct_inspector_equals_the_key_sort_recipe(idt, M, K, density):
     data, idx, ptr = random_csr(M, K, density, 21, np.float32, idt, empty_rows=(0, 7), long_row=3)
     d = torch.device("cuda")
     td, ti, tp = (torch.from_numpy(x).to(d) for x in (data, idx, ptr))
-    b1, o1 = Kn.csr_tiled_layout(td, ti, tp, M, K)
-    b2, o2 = Kn.csr_tiled_layout(td, ti, tp, M, K, force_sort=True)
+    b1, o1, _ = Kn.csr_tiled_layout(td, ti, tp, M, K)
+    b2, o2, _ = Kn.csr_tiled_layout(td, ti, tp, M, K, force_sort=True)
     assert torch.equal(o1, o2) and torch.equal(b1, b2)
 
 
@@ -191,3 +191,50 @@ def test_unsorted_rows_fall_back_to_the_key_sort_recipe(orc):
     got = Kn.dot_csr_ndarray_tiled(layout, (M, 128), K, tb)
     want = orc.dot_csr_ndarray((M, 128), data, idx, ptr, b)
     assert np.allclose(got.cpu().numpy(), want, rtol=2e-5, atol=1e-6)
+
+
+# ---- float64 (the reference's default dtype): one column per lane, 64-column panels, 5-entry blocks ------------
+@pytest.mark.parametrize("N", [64, 128, 192])
+@pytest.mark.parametrize("M,K,density", [(300, 200, 0.05), (5000, 10000, 0.01), (4097, 129, 0.1), (700, 20000, 0.004),
+                                         (1, 70, 1.0)])
+def test_tiled_f64_bit_identical_to_rowgroup_and_reference(orc, M, K, density, N):
+    from sparse_amd import _kernels as Kn
+
+    data, idx, ptr = random_csr(M, K, density, 51, np.float64, np.int32, empty_rows=(0,) if M > 10 else ())
+    b = random_dense(K, N, 52, np.float64)
+    d = torch.device("cuda")
+    td, ti, tp, tb = (torch.from_numpy(x).to(d) for x in (data, idx, ptr, b))
+    layout = Kn.csr_tiled_layout(td, ti, tp, M, K)
+    assert layout[2] == torch.float64
+    for exact in (False, True):
+        got = Kn.dot_csr_ndarray_tiled(layout, (M, N), K, tb, exact=exact)
+        ref = Kn.dot_csr_ndarray((M, N), td, ti, tp, tb, exact=exact)
+        assert torch.equal(got, ref), exact
+    want = orc.dot_csr_ndarray((M, N), data, idx, ptr, b)
+    assert np.array_equal(got.cpu().numpy().view(np.uint64), want.view(np.uint64))   # exact mode = reference bits
+    b1, o1, _ = layout
+    b2, o2, _ = Kn.csr_tiled_layout(td, ti, tp, M, K, force_sort=True)
+    assert torch.equal(o1, o2) and torch.equal(b1, b2)
+
+
+def test_product_path_float64_and_mixed_precision(orc, monkeypatch):
+    """float64 operands take the float64 block stream; float32 values x float64 B promote like the reference
+    (`_dot_dtype`, _common.py:635-636) and build a second, float64 stream of the same matrix."""
+    from sparse_amd import _settings
+    import sparse_amd as sp
+
+    monkeypatch.setattr(_settings, "TILED_SPMM", "auto")
+    monkeypatch.setattr(_settings, "EXACT_MULADD", True)
+    data, idx, ptr = random_csr(70000, 1500, 0.01, 61, np.float64, np.int32)
+    b = random_dense(1500, 64, 62, np.float64)
+    d = torch.device("cuda")
+    a = sp.GCXS(tuple(torch.from_numpy(x).to(d) for x in (data, idx, ptr)), shape=(70000, 1500), compressed_axes=(0,))
+    r = a @ torch.from_numpy(b).to(d)
+    assert torch.float64 in a._tiled_layouts and r.dtype == torch.float64
+    assert np.array_equal(r.cpu().numpy(), orc.dot_csr_ndarray((70000, 64), data, idx, ptr, b))
+    a32 = sp.GCXS((torch.from_numpy(data.astype(np.float32)).to(d), a.indices, a.indptr), shape=(70000, 1500),
+                  compressed_axes=(0,))
+    r2 = a32 @ torch.from_numpy(b).to(d)
+    assert r2.dtype == torch.float64 and torch.float64 in a32._tiled_layouts
+    want = orc.dot_csr_ndarray((70000, 64), data.astype(np.float32).astype(np.float64), idx, ptr, b)
+    assert np.array_equal(r2.cpu().numpy(), want)

@@ -18,7 +18,8 @@ Register map (must match spmm_tiled.hip):
 """
 import os
 
-ENTRIES = 8
+ENTRIES = 8      # entries per 16-dword block: 8 x (d0, f32 value) or, for f64, 5 d0 + pad + 5 x (value lo, hi)
+F64 = False
 RING = (40, 56, 72)
 ADDR = (40, 41, 42, 43)
 DATA0 = 44
@@ -29,13 +30,22 @@ ROWS = 32
 DATASET = (44, 24)
 
 
+def d0_reg(buf, i):
+    return buf + i if F64 else buf + 2 * i
+
+
+def val_pair(buf, i):
+    """SGPR pair holding the value of entry i (f64: the value itself; f32: (d0, value), selected with op_sel)"""
+    return (buf + 6 + 2 * i, buf + 7 + 2 * i) if F64 else (buf + 2 * i, buf + 2 * i + 1)
+
+
 def p1(buf, dset):
     """addresses + LDS reads of the block held in SGPR buffer `buf` into VGPR data set `dset`"""
     o = []
     for i in range(ENTRIES):
         a = ADDR[i % len(ADDR)]
         d = DATASET[dset] + 2 * i
-        o.append(f"v_and_or_b32 v{a}, s{buf + 2 * i}, %[mask], v60")
+        o.append(f"v_and_or_b32 v{a}, s{d0_reg(buf, i)}, %[mask], v60")
         o.append(f"ds_read_b64 v[{d}:{d + 1}], v{a}")
     return o
 
@@ -45,9 +55,14 @@ def p2(buf, dset):
     o = []
     for i in range(ENTRIES):
         d = DATASET[dset] + 2 * i
-        o.append(f"s_set_gpr_idx_on s{buf}, gpr_idx(SRC2,DST)" if i == 0 else f"s_set_gpr_idx_idx s{buf + 2 * i}")
-        o.append(f"v_pk_fma_f32 v[{JUNK}:{JUNK + 1}], v[{d}:{d + 1}], s[{buf + 2 * i}:{buf + 2 * i + 1}], "
-                 f"v[{JUNK}:{JUNK + 1}] op_sel:[0,1,0] op_sel_hi:[1,1,1]")
+        lo, hi = val_pair(buf, i)
+        o.append(f"s_set_gpr_idx_on s{d0_reg(buf, 0)}, gpr_idx(SRC2,DST)" if i == 0
+                 else f"s_set_gpr_idx_idx s{d0_reg(buf, i)}")
+        if F64:
+            o.append(f"v_fma_f64 v[{JUNK}:{JUNK + 1}], s[{lo}:{hi}], v[{d}:{d + 1}], v[{JUNK}:{JUNK + 1}]")
+        else:
+            o.append(f"v_pk_fma_f32 v[{JUNK}:{JUNK + 1}], v[{d}:{d + 1}], s[{lo}:{hi}], "
+                     f"v[{JUNK}:{JUNK + 1}] op_sel:[0,1,0] op_sel_hi:[1,1,1]")
     o.append("s_set_gpr_idx_off")
     return o
 
@@ -58,12 +73,19 @@ def p2_exact(buf, dset):
     o = []
     for i in range(ENTRIES):
         d = DATASET[dset] + 2 * i
-        o.append(f"v_pk_mul_f32 v[{d}:{d + 1}], v[{d}:{d + 1}], s[{buf + 2 * i}:{buf + 2 * i + 1}] "
-                 f"op_sel:[0,1] op_sel_hi:[1,1]")
+        lo, hi = val_pair(buf, i)
+        if F64:
+            o.append(f"v_mul_f64 v[{d}:{d + 1}], v[{d}:{d + 1}], s[{lo}:{hi}]")
+        else:
+            o.append(f"v_pk_mul_f32 v[{d}:{d + 1}], v[{d}:{d + 1}], s[{lo}:{hi}] op_sel:[0,1] op_sel_hi:[1,1]")
     for i in range(ENTRIES):
         d = DATASET[dset] + 2 * i
-        o.append(f"s_set_gpr_idx_on s{buf}, gpr_idx(SRC1,DST)" if i == 0 else f"s_set_gpr_idx_idx s{buf + 2 * i}")
-        o.append(f"v_pk_add_f32 v[{JUNK}:{JUNK + 1}], v[{d}:{d + 1}], v[{JUNK}:{JUNK + 1}]")
+        o.append(f"s_set_gpr_idx_on s{d0_reg(buf, 0)}, gpr_idx(SRC1,DST)" if i == 0
+                 else f"s_set_gpr_idx_idx s{d0_reg(buf, i)}")
+        if F64:
+            o.append(f"v_add_f64 v[{JUNK}:{JUNK + 1}], v[{d}:{d + 1}], v[{JUNK}:{JUNK + 1}]")
+        else:
+            o.append(f"v_pk_add_f32 v[{JUNK}:{JUNK + 1}], v[{d}:{d + 1}], v[{JUNK}:{JUNK + 1}]")
     o.append("s_set_gpr_idx_off")
     return o
 
@@ -206,12 +228,23 @@ def clob(prefix, lo, hi):
     return ", ".join(f'"{prefix}{i}"' for i in range(lo, hi + 1))
 
 
+def f64_variants():
+    """the same phases for float64: one column per lane (v_fma_f64 on a register pair), 5 entries per block"""
+    global ENTRIES, F64
+    ENTRIES, F64 = 5, True
+    try:
+        return [lit("TL_ASM_PHASES_F64", phases()), lit("TL_ASM_PHASES_F64_EXACT", phases(True, True, True))]
+    finally:
+        ENTRIES, F64 = 8, False
+
+
 def main():
     out = ["// GENERATED by tools/gen_tiled_asm.py - do not edit.\n",
            lit("TL_ASM_PHASES", phases()),
            lit("TL_ASM_PHASES_EXACT", phases(True, True, True)),
            lit("TL_ASM_PHASES_NOFMA", phases(True, False)),
            lit("TL_ASM_PHASES_NOLDS", phases(False, False)),
+           *f64_variants(),
            lit("TL_ASM_TILE0", tile0()),
            lit("TL_ASM_STORE", store()),
            lit("TL_ASM_ZERO", zero()),
