@@ -154,6 +154,19 @@ def main():
     ms, g = timed(lambda: sp.GCXS.from_coo(coo, compressed_axes=(1,)), reps=3)
     out.append(line("A6 COO->GCXS(ca=1)", f"{nn} nnz (key permute + radix sort + split)", ms, nn * 12 + nn * 8))
 
+    # ---- A1 in float64 (the reference's default dtype) at the config-2 shape ---------------------------------
+    if not args.quick:
+        d64, i64_, p64 = make_csr_device(1_000_000, 10_000, 0.01, seed=9, dtype=torch.float64)
+        a64 = sp.GCXS((d64, i64_, p64), shape=(1_000_000, 10_000), compressed_axes=(0,))
+        b64 = torch.rand((10_000, 128), device=dev, dtype=torch.float64)
+        a64 @ b64
+        ms, r = timed(lambda: a64 @ b64, reps=5)
+        nn64 = int(d64.numel())
+        out.append(line("A1 GCXS x dense, float64 (tiled kernel)", "GCXS(CSR) 1e6x1e4 @1% (1e8 nnz, f64/int32) x dense 1e4x128",
+                        ms, nn64 * 12 + 10_000 * 128 * 8 + 1_000_000 * 128 * 8, flops=2.0 * nn64 * 128))
+        del a64, d64, i64_, p64, b64, r
+        torch.cuda.empty_cache()
+
     # ---- A4: SpGEMM at a single-GPU size --------------------------------------------------------------
     torch.cuda.empty_cache()  # the ESC workspace (~38 GB) should not fight the caching allocator
     n4 = 100_000 // q
