@@ -9,7 +9,7 @@
 // accumulated by exactly one lane in storage (k-ascending) order -> the summation order is
 // the reference's, and the result is deterministic.  `out` is written exactly once per
 // element (no zero-fill + read-modify-write as in the reference).
-#include "spmm_internal.h"
+#include "common.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -141,10 +141,7 @@ spmm_csr_rowgroup_kernel(int64_t M, int64_t N, const T* __restrict__ a_data,
 struct SpmmVariant {
   int g = 0, vec = 0, unroll = 0;
   int64_t panel = 0;  // 0 = whole N in one pass
-  int lds = -1;       // 1: LDS-DMA ring kernel
-  int tile = -1, kb = 0;  // 1: K-blocked LDS-tile kernel
-  int gidx = 0;           // 1: gpr-indexed LDS-tile kernel, 2: its debug build
-  int depth = 0, rb = 0, ch = 0, ksplit = 0;
+  int ch = 0, ksplit = 0;
 };
 
 // Tuning hook: SPAMD_SPMM_VARIANT="G=32,VEC=2,U=8,PANEL=64" overrides the heuristic.
@@ -157,12 +154,6 @@ static SpmmVariant env_variant() {
   if ((p = strstr(e, "VEC="))) v.vec = atoi(p + 4);
   if ((p = strstr(e, "U="))) v.unroll = atoi(p + 2);
   if ((p = strstr(e, "PANEL="))) v.panel = atoll(p + 6);
-  if ((p = strstr(e, "LDS="))) v.lds = atoi(p + 4);
-  if ((p = strstr(e, "TILE="))) v.tile = atoi(p + 5);
-  if ((p = strstr(e, "KB="))) v.kb = atoi(p + 3);
-  if ((p = strstr(e, "GIDX="))) v.gidx = atoi(p + 5);
-  if ((p = strstr(e, "D="))) v.depth = atoi(p + 2);
-  if ((p = strstr(e, "RB="))) v.rb = atoi(p + 3);
   if ((p = strstr(e, "CH="))) v.ch = atoi(p + 3);
   if ((p = strstr(e, "KSPLIT="))) v.ksplit = atoi(p + 7);
   return v;
@@ -219,24 +210,6 @@ static int dispatch_shape(int64_t M, int64_t K, int64_t N, const T* a_data, cons
   if (ev.vec && ev.vec <= vmax) vec = ev.vec;
   if (ev.unroll) unroll = ev.unroll;
   if (ev.panel > 0 && ev.panel % vec == 0) panel = ev.panel;
-  if constexpr (std::is_same<T, float>::value && !EXACT) {
-    if (ev.gidx) {
-      int rc = spmm_csr_gidx_dispatch<I>(M, K, N, a_data, a_idx, a_ptr, b, ldb, out, ldo, ev.gidx, s);
-      if (rc != SPAMD_ETYPE) return rc;
-    }
-  }
-  if constexpr (std::is_same<T, float>::value) {
-    if (ev.tile == 1) {
-      int rc = spmm_csr_tile_dispatch<I, EXACT>(M, K, N, a_data, a_idx, a_ptr, b, ldb, out, ldo,
-                                                ev.rb ? ev.rb : 16, ev.kb ? ev.kb : 128, s);
-      if (rc != SPAMD_ETYPE) return rc;
-    }
-  }
-  if (ev.lds == 1 && K * ldb * (int64_t)sizeof(T) < ((int64_t)1 << 46)) {
-    int rc = spmm_csr_ldsring_dispatch<T, I, EXACT>(M, N, a_data, a_idx, a_ptr, b, ldb, out, ldo,
-                                                    ev.depth ? ev.depth : 8, ev.rb ? ev.rb : 32, s);
-    if (rc != SPAMD_ETYPE) return rc;
-  }
   // column groups per lane: cover the panel in one pass over A when it is at most 4 groups wide
   int ch = 1;
   {

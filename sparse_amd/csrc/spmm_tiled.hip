@@ -26,7 +26,7 @@
 // confined to v0..v23 (amdgpu_num_vgpr) and never sees v24..v127.
 // Per output element the fused multiply-adds happen in the same k-ascending order as in the row-group
 // kernel's FMA mode, so both kernels return bit-identical results (column indices sorted within rows).
-#include "spmm_internal.h"
+#include "common.h"
 #include "spmm_tiled_asm.inc"
 #include <stdlib.h>
 

@@ -124,10 +124,9 @@ def test_full_size_linearity_property():
     assert torch.equal(col, want)
 
 
-VARIANTS = ["LDS=1,D=8,RB=32", "LDS=1,D=4,RB=5", "LDS=1,D=16,RB=64", "LDS=1,D=8,RB=1", "G=32,VEC=2,U=8", "G=16,VEC=1,U=4,PANEL=32", "G=64,VEC=1,U=4",
+VARIANTS = ["G=32,VEC=2,U=8", "G=16,VEC=1,U=4,PANEL=32", "G=64,VEC=1,U=4",
             "G=64,VEC=2,CH=2", "G=16,VEC=2,CH=4", "G=32,VEC=1,CH=4,PANEL=64",
-            "KSPLIT=2", "KSPLIT=3,G=32,VEC=2", "KSPLIT=5,G=16,VEC=1",
-            "TILE=1,RB=16,KB=128", "TILE=1,RB=16,KB=64", "TILE=1,RB=8,KB=128", "TILE=1,RB=16,KB=32"]
+            "KSPLIT=2", "KSPLIT=3,G=32,VEC=2", "KSPLIT=5,G=16,VEC=1"]
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
