@@ -143,3 +143,23 @@ def test_reductions_with_runs_longer_than_a_tile(dtype):
                 assert np.array_equal(got, want), (name, axis)
             else:
                 assert np.allclose(got, want, rtol=1e-5 if dtype == np.float32 else 1e-12), (name, axis)
+
+
+@pytest.mark.gpu
+def test_prune_count_first_path(monkeypatch):
+    """Large prunes first count the fill values (one read-only pass) and stop when there are none; the path is
+    forced here for small arrays: nothing to prune, something to prune, -0.0 is not a fill value (bit-wise)."""
+    import sparse_amd as sp
+    from sparse_amd import _kernels as Kn
+
+    monkeypatch.setattr(Kn, "PRUNE_COUNT_FIRST", 1)
+    coords = np.array([[0, 0, 1, 2, 2], [1, 3, 0, 2, 4]])
+    full = sp.COO(coords, np.array([1.0, 2.0, 3.0, 4.0, 5.0]), shape=(3, 5), prune=True)
+    assert full.nnz == 5 and Kn.count_eq_bits(full.data, 0.0) == 0
+    some = sp.COO(coords, np.array([1.0, 0.0, 3.0, -0.0, 0.0]), shape=(3, 5), prune=True)
+    assert some.nnz == 3 and np.array_equal(some.todense()[[0, 1, 2], [1, 0, 2]], [1.0, 3.0, -0.0])
+    assert np.signbit(some.todense()[2, 2])
+    g = sp.GCXS(some, compressed_axes=(0,))
+    assert g.nnz == 3
+    ints = sp.COO(coords, np.array([1, 0, 0, 7, 0], dtype=np.int32), shape=(3, 5), prune=True)
+    assert ints.nnz == 2 and Kn.count_eq_bits(torch.tensor([1, 0, 0, 7, 0], dtype=torch.int32, device="cuda"), 0) == 3
