@@ -74,7 +74,9 @@ struct RowSortLayout {
                                            rocprim::block_radix_rank_algorithm::SPAMD_SPG_ALG>;
   using scan_t = rocprim::block_scan<int, BLOCK>;
   static constexpr int N = BLOCK * ITEMS;
-  static constexpr size_t sorted_bytes = (size_t)N * (sizeof(int) + sizeof(V));
+  // after the sort only the VALUES, one head flag per product and every thread's last column go to LDS (the columns
+  // stay in registers): half the footprint of (column, value) pairs, i.e. two workgroups per CU for the big classes
+  static constexpr size_t sorted_bytes = (size_t)N * (sizeof(V) + 1) + (size_t)BLOCK * sizeof(int) + 64;
   static constexpr int STAGE = N < 2048 ? N : 2048;  // A elements staged per pass
   static constexpr size_t prefix_bytes = ((size_t)STAGE + 2) * sizeof(int) + (size_t)STAGE * (sizeof(int64_t) + sizeof(V)) + 16;
   static constexpr size_t a(size_t x, size_t y) { return x > y ? x : y; }
@@ -83,7 +85,7 @@ struct RowSortLayout {
 
 // rows with lo < products <= hi; V is the value type moved bit-wise except for the multiply / add
 template <int BLOCK, int ITEMS, typename V, typename I>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK == 512 ? 4 : 1, 8)))
 spgemm_rowsort_kernel(int64_t n_col, int col_bits, const I* __restrict__ a_ptr, const I* __restrict__ a_idx,
                       const V* __restrict__ a_val, const I* __restrict__ b_ptr, const I* __restrict__ b_idx,
                       const V* __restrict__ b_val, const int64_t* __restrict__ prod_off, int64_t lo, int64_t hi,
@@ -198,34 +200,38 @@ spgemm_rowsort_kernel(int64_t n_col, int col_bits, const I* __restrict__ a_ptr, 
   typename L::sort_t().sort(keys, vals, *reinterpret_cast<typename L::sort_t::storage_type*>(raw), 0, col_bits);
 #endif
   __syncthreads();
-  int* const sk = reinterpret_cast<int*>(raw);
-  V* const sv = reinterpret_cast<V*>(raw + (size_t)L::N * sizeof(int));
+  V* const sv = reinterpret_cast<V*>(raw);
+  int* const lastkey = reinterpret_cast<int*>(raw + (size_t)L::N * sizeof(V));
+  unsigned char* const hd = reinterpret_cast<unsigned char*>(lastkey + BLOCK);
+  lastkey[tid] = keys[ITEMS - 1];
 #pragma unroll
-  for (int j = 0; j < ITEMS; ++j) {
-    sk[tid * ITEMS + j] = keys[j];
-    sv[tid * ITEMS + j] = vals[j];
-  }
+  for (int j = 0; j < ITEMS; ++j) sv[tid * ITEMS + j] = vals[j];
   __syncthreads();
 
   // ---- compress: heads of runs of equal columns
   int nheads = 0;
   bool head[ITEMS];
+  {
+    int prev = tid ? lastkey[tid - 1] : -1;
 #pragma unroll
-  for (int j = 0; j < ITEMS; ++j) {
-    const int p = tid * ITEMS + j;
-    head[j] = p < P && (p == 0 || sk[p] != sk[p - 1]);
-    nheads += head[j];
+    for (int j = 0; j < ITEMS; ++j) {
+      const int p = tid * ITEMS + j;
+      head[j] = p < P && keys[j] != prev;
+      prev = keys[j];
+      hd[p] = head[j] || p >= P;  // (padding counts as a head: it ends the last run)
+      nheads += head[j];
+    }
   }
   int rank, total;
-  typename L::scan_t().exclusive_scan(nheads, rank, 0, total, scan_storage);
+  typename L::scan_t().exclusive_scan(nheads, rank, 0, total, scan_storage);  // (its barriers also publish hd[])
+  __syncthreads();
 #pragma unroll
   for (int j = 0; j < ITEMS; ++j) {
     if (head[j]) {
       const int p = tid * ITEMS + j;
-      const int c = sk[p];
-      V acc = sv[p];
-      for (int q = p + 1; q < P && sk[q] == c; ++q) acc = acc + sv[q];
-      tmp_cols[base + rank] = c;
+      V acc = vals[j];
+      for (int q = p + 1; q < L::N && !hd[q]; ++q) acc = acc + sv[q];
+      tmp_cols[base + rank] = keys[j];
       tmp_vals[base + rank] = acc;
       ++rank;
     }
@@ -284,7 +290,7 @@ static int launch_rowsort(int64_t n_row, int64_t n_col, int col_bits, const I* a
 // size classes: (workgroup, items per thread); the last one bounds what the row-local path accepts
 template <typename V>
 struct RowClasses {
-  static constexpr int64_t c0 = 256 * 2, c1 = 256 * 8, c2 = 1024 * 4;
+  static constexpr int64_t c0 = 256 * 2, c1 = 256 * 8, c2 = 512 * 8;
   static constexpr int64_t c3 = sizeof(V) <= 4 ? 1024 * 16 : 1024 * 12;  // 128 KB / 144 KB of sorted (column, value) pairs
 };
 
@@ -304,22 +310,30 @@ static int rowsort_all(int64_t n_row, int64_t n_col, const I* a_ptr, const I* a_
     if (rc) return rc;
   }
   if (max_prod > C::c1) {
-    rc = launch_rowsort<1024, 4, V, I>(n_row, n_col, col_bits, a_ptr, a_idx, a_val, b_ptr, b_idx, b_val, prod_off, C::c1, C::c2,
-                                       tmp_cols, tmp_vals, nnz_row, s);
+    rc = launch_rowsort<512, 8, V, I>(n_row, n_col, col_bits, a_ptr, a_idx, a_val, b_ptr, b_idx, b_val, prod_off, C::c1, C::c2,
+                                      tmp_cols, tmp_vals, nnz_row, s);
     if (rc) return rc;
   }
   if (max_prod > C::c2) {
+    // 512-thread workgroups with many items per thread: two of them fit a CU (LDS and registers), so the global
+    // latencies of one row overlap the sort of another; the 1024-thread class only takes what they cannot hold
     if constexpr (sizeof(V) <= 4) {
-      constexpr int64_t c2b = 1024 * 10;
-      rc = launch_rowsort<1024, 10, V, I>(n_row, n_col, col_bits, a_ptr, a_idx, a_val, b_ptr, b_idx, b_val, prod_off, C::c2, c2b,
-                                          tmp_cols, tmp_vals, nnz_row, s);
+      constexpr int64_t c2b = 512 * 24;
+      rc = launch_rowsort<512, 24, V, I>(n_row, n_col, col_bits, a_ptr, a_idx, a_val, b_ptr, b_idx, b_val, prod_off, C::c2, c2b,
+                                         tmp_cols, tmp_vals, nnz_row, s);
       if (rc) return rc;
       if (max_prod > c2b)
         rc = launch_rowsort<1024, 16, V, I>(n_row, n_col, col_bits, a_ptr, a_idx, a_val, b_ptr, b_idx, b_val, prod_off, c2b,
                                             C::c3, tmp_cols, tmp_vals, nnz_row, s);
-    } else
-      rc = launch_rowsort<1024, 12, V, I>(n_row, n_col, col_bits, a_ptr, a_idx, a_val, b_ptr, b_idx, b_val, prod_off, C::c2,
-                                          C::c3, tmp_cols, tmp_vals, nnz_row, s);
+    } else {
+      constexpr int64_t c2b = 512 * 12;
+      rc = launch_rowsort<512, 12, V, I>(n_row, n_col, col_bits, a_ptr, a_idx, a_val, b_ptr, b_idx, b_val, prod_off, C::c2, c2b,
+                                         tmp_cols, tmp_vals, nnz_row, s);
+      if (rc) return rc;
+      if (max_prod > c2b)
+        rc = launch_rowsort<1024, 12, V, I>(n_row, n_col, col_bits, a_ptr, a_idx, a_val, b_ptr, b_idx, b_val, prod_off, c2b,
+                                            C::c3, tmp_cols, tmp_vals, nnz_row, s);
+    }
   }
   return rc;
 }
