@@ -267,7 +267,7 @@ def _tiled_eligible(data, bt, out_shape, Kd):
     if _settings.TILED_SPMM == "never" or bt.dim() != 2:
         return False
     dt = _tiled_dtype(data, bt)
-    if dt is None or N == 0 or N % (128 if dt == torch.float32 else 64):
+    if dt is None or N < (64 if dt == torch.float32 else 32):   # narrower results: the row-group kernel
         return False
     per_list = int(data.numel()) * 4096 / max(M * Kd, 1)
     return M >= 65536 and (per_list >= 12 or (per_list >= 6 and Kd * N * bt.element_size() >= (16 << 20)))
@@ -312,7 +312,18 @@ def _gcxs_times_dense(a, bt, out_shape):
         # row-group product), so it runs at the first eligible product and is cached on the array
         dt = _tiled_dtype(data, bt)
         prepare_spmm(a, dt)
-        return K.dot_csr_ndarray_tiled(a._tiled_layouts[dt], out_shape, Kd, bt.to(dt), exact=_settings.EXACT_MULADD)
+        M, N = out_shape
+        panel = 128 if dt == torch.float32 else 64
+        bt = bt.to(dt)
+        if N % panel:
+            # a workgroup covers whole 512-byte column panels: zero-pad B (small) to the next panel and slice the
+            # result (one extra pass over C; still 3-5x faster than the row-group kernel for wide results)
+            npad = -(-N // panel) * panel
+            bp = torch.zeros((Kd, npad), dtype=dt, device=bt.device)
+            bp[:, :N] = bt
+            res = K.dot_csr_ndarray_tiled(a._tiled_layouts[dt], (M, npad), Kd, bp, exact=_settings.EXACT_MULADD)
+            return res[:, :N].contiguous()
+        return K.dot_csr_ndarray_tiled(a._tiled_layouts[dt], out_shape, Kd, bt, exact=_settings.EXACT_MULADD)
     return K.dot_csr_ndarray(out_shape, data, indices, indptr, bt, exact=_settings.EXACT_MULADD)
 
 

@@ -156,9 +156,24 @@ def test_exact_mode_uses_the_tiled_path_and_small_n_keeps_the_rowgroup_kernel(mo
     assert torch.equal(r, a @ b)
     monkeypatch.setattr(_settings, "TILED_SPMM", "auto")
     monkeypatch.setattr(_settings, "EXACT_MULADD", False)
-    a2, b2, _ = _product_case(N=64, seed=13)
+    a2, b2, _ = _product_case(N=32, seed=13)
     a2 @ b2
     assert not getattr(a2, "_tiled_layouts", None)
+
+
+@pytest.mark.parametrize("N", [64, 100, 130, 300])
+def test_product_path_pads_ragged_result_widths(orc, monkeypatch, N):
+    """N that is not a whole number of column panels: B is zero-padded to the next panel and the result sliced;
+    exact mode stays bit-identical to the reference loop."""
+    from sparse_amd import _settings
+
+    monkeypatch.setattr(_settings, "TILED_SPMM", "auto")
+    monkeypatch.setattr(_settings, "EXACT_MULADD", True)
+    a, b, (data, idx, ptr, bh) = _product_case(N=N, seed=14)
+    got = a @ b
+    assert a._tiled_layouts and got.shape == (a.shape[0], N) and got.is_contiguous()
+    want = orc.dot_csr_ndarray((a.shape[0], N), data, idx, ptr, bh)
+    assert np.array_equal(got.cpu().numpy(), want)
 
 
 @pytest.mark.parametrize("idt", [np.int32, np.int64])
