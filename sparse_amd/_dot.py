@@ -277,9 +277,10 @@ def prepare_spmm(a, dtype=None):
     """Build (and cache on `a`) the tiled block stream used by `a @ dense` for value type `dtype` (default: a's own
     if float32/float64); returns True if `a` now has one.  The counterpart of the reference's memoised conversions
     (`COO(cache=True)`, _coo/core.py:317-338)."""
+    from ._coo import COO
     from ._gcxs import GCXS
 
-    if not isinstance(a, GCXS) or a.ndim != 2:
+    if not isinstance(a, (GCXS, COO)) or a.ndim != 2:
         return False
     dtype = dtype or (a.data.dtype if a.data.dtype in K.TILED_DTYPES else None)
     if dtype not in K.TILED_DTYPES:
@@ -295,6 +296,14 @@ def _csr_triplet(a):
     """(data, indices, indptr) of a 2-D GCXS compressed by rows; a csc array is re-compressed once (stable
     key sort) and the CSR twin memoised on the (immutable) array — the reference's `format="gcxs"` default is
     compressed_axes=(argmin(shape),), so tall matrices arrive as csc."""
+    from ._coo import COO
+
+    if isinstance(a, COO):  # canonical 2-D COO is CSR order already: only the row pointers are missing
+        view = getattr(a, "_csr_view", None)
+        if view is None:
+            view = (a.data, a.coords[1].contiguous(), K.rows_to_indptr(a.coords[0], int(a.shape[0])))
+            a._csr_view = view
+        return view
     if a.compressed_axes == (0,):
         return a.data, a.indices, a.indptr
     twin = getattr(a, "_csr_twin", None)
@@ -305,9 +314,18 @@ def _csr_triplet(a):
 
 
 def _gcxs_times_dense(a, bt, out_shape):
+    """GCXS or canonical 2-D COO times dense."""
+    from ._coo import COO
+
     data, indices, indptr = _csr_triplet(a)
     Kd = int(a.shape[1])
-    if _tiled_eligible(data, bt, out_shape, Kd):
+    use_tiled = _tiled_eligible(data, bt, out_shape, Kd)
+    if use_tiled and isinstance(a, COO) and not getattr(a, "_tiled_layouts", None):
+        # COO operands of `tensordot` are usually temporaries (an N-D array reshaped to 2-D): the inspector only pays
+        # for an array that is multiplied again, so a COO gets its block stream at its SECOND eligible product
+        a._spmm_uses = getattr(a, "_spmm_uses", 0) + 1
+        use_tiled = a._spmm_uses >= 2
+    if use_tiled:
         # the inspector costs about one product (1.5 ms at config 2 against 1.2 ms per tiled and 2.6 ms per
         # row-group product), so it runs at the first eligible product and is cached on the array
         dt = _tiled_dtype(data, bt)
@@ -411,7 +429,7 @@ def _dot(a, b, return_type=None):
     if isinstance(a, COO) and _is_dense(b):
         bt = dev.to_device(b, a.device)
         if rk in (None, "ndarray"):
-            return io.out(K.dot_coo_ndarray(a.coords, a.data, bt, out_shape, exact=_settings.EXACT_MULADD))
+            return io.out(_gcxs_times_dense(a, bt, out_shape))
         coords, data = K.dot_coo_ndarray_sparse(a.coords, a.data, bt, out_shape)
         out = COO(coords, data, shape=out_shape, has_duplicates=False, sorted=True)
         return out.asformat("gcxs") if rk == "gcxs" else out

@@ -253,3 +253,20 @@ def test_product_path_float64_and_mixed_precision(orc, monkeypatch):
     assert r2.dtype == torch.float64 and torch.float64 in a32._tiled_layouts
     want = orc.dot_csr_ndarray((70000, 64), data.astype(np.float32).astype(np.float64), idx, ptr, b)
     assert np.array_equal(r2.cpu().numpy(), want)
+
+
+def test_coo_operand_gets_the_block_stream_at_its_second_product(orc, monkeypatch):
+    """`COO @ dense` (reference `_dot_coo_ndarray`, _common.py:979-1014): a canonical 2-D COO is CSR order plus row
+    pointers; temporaries (first product) keep the row-group kernel, an array multiplied again gets the tiled path."""
+    from sparse_amd import _settings
+
+    monkeypatch.setattr(_settings, "TILED_SPMM", "auto")
+    monkeypatch.setattr(_settings, "EXACT_MULADD", True)
+    a, b, (data, idx, ptr, bh) = _product_case(seed=15)
+    c = a.tocoo()
+    r1 = c @ b
+    assert not getattr(c, "_tiled_layouts", None)
+    r2 = c @ b
+    assert c._tiled_layouts
+    want = orc.dot_csr_ndarray((a.shape[0], 128), data, idx, ptr, bh)
+    assert torch.equal(r1, r2) and np.array_equal(r2.cpu().numpy(), want)
