@@ -183,12 +183,35 @@ mp_union_kernel(int op, const int64_t* __restrict__ ka, const T* __restrict__ va
   if constexpr (!FILL) {
     if (tid == 0) counts[blk] = tot;
   } else {
-    const int64_t o = offs[blk] + base + (incl - cnt);
+    // stage the tile's outputs in LDS (the input staging area is dead now) and copy them out with consecutive lanes on
+    // consecutive elements: writing each thread's run of up to MP_VT outputs straight from registers puts every lane
+    // of a store instruction on a different cache line (measured 2.4 ms instead of 1.6 ms for 1.9e8 outputs)
+    // (sparse outputs — e.g. a product of two disjoint-ish operands — are not worth the two extra barriers)
+    static_assert(sizeof(O) <= sizeof(T), "the output staging area reuses sv");
+    O* const so = reinterpret_cast<O*>(sv);
+    const int lbase = base + (incl - cnt);
+    const int64_t o = offs[blk];
+    if (tot * 4 >= MP_TILE) {
+      __syncthreads();  // everyone is done reading sk / sv
 #pragma unroll
-    for (int s = 0; s < MP_VT; ++s) {
-      if (s < cnt) {
-        out_keys[o + s] = okey[s];
-        out_vals[o + s] = oval[s];
+      for (int s = 0; s < MP_VT; ++s) {
+        if (s < cnt) {
+          sk[lbase + s] = okey[s];
+          so[lbase + s] = oval[s];
+        }
+      }
+      __syncthreads();
+      for (int t = tid; t < tot; t += MP_THREADS) {
+        out_keys[o + t] = sk[t];
+        out_vals[o + t] = so[t];
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < MP_VT; ++s) {
+        if (s < cnt) {
+          out_keys[o + lbase + s] = okey[s];
+          out_vals[o + lbase + s] = oval[s];
+        }
       }
     }
   }
