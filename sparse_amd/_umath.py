@@ -120,6 +120,9 @@ def _bits(value, np_dtype):
     return int(np.asarray(value).astype(npdt).reshape(1).view(f"u{npdt.itemsize}")[0])
 
 
+MERGE_SINGLE_PASS = True   # tuning hook: False = count pass + scan + fill pass
+
+
 def merge_union(name, ka, va, kb, vb, fill_a, fill_b, fill_out):
     """Fused merge-path union: (keys, values) of func(a or fill_a, b or fill_b) over the union of
     two canonical key arrays, results bit-equal to `fill_out` dropped (csrc/merge.hip).
@@ -137,10 +140,21 @@ def merge_union(name, ka, va, kb, vb, fill_a, fill_b, fill_out):
     s = stream_ptr(devi)
     part = torch.empty(nblocks + 1, dtype=torch.int64, device=devi)
     _ffi.call("spamd_merge_partition", na, ptr(ka), nb, ptr(kb), ptr(part), s)
-    counts = torch.empty(nblocks + 1, dtype=torch.int64, device=devi)
+    counts = torch.empty(nblocks + 2, dtype=torch.int64, device=devi)
     fa, fb = _bits(fill_a, comp_np), _bits(fill_b, comp_np)
     fo = _bits(fill_out, np.dtype("uint8") if code in _TO_BOOL_BIN else comp_np)
     args = (code, _CODE[va.dtype], na, ptr(ka), ptr(va), nb, ptr(kb), ptr(vb), fa, fb, fo, ptr(part))
+    if MERGE_SINGLE_PASS:
+        # one pass: tiles chain their output offsets by look-back; room for the worst case, trimmed afterwards
+        keys = torch.empty(na + nb, dtype=torch.int64, device=devi)
+        vals = torch.empty(na + nb, dtype=out_t, device=devi)
+        _ffi.call("spamd_merge_union", 2, *args, ptr(counts), 0, ptr(keys), ptr(vals), s)
+        total = int(counts[nblocks + 1])
+        if total * 2 < na + nb:   # a sparse result should not pin the worst-case buffers
+            keys, vals = keys[:total].clone(), vals[:total].clone()
+        else:
+            keys, vals = keys[:total], vals[:total]
+        return keys, (vals.view(torch.bool) if code in _TO_BOOL_BIN else vals)
     _ffi.call("spamd_merge_union", 0, *args, ptr(counts), 0, 0, 0, s)
     offs = K.exclusive_scan(counts)
     total = int(offs[-1])

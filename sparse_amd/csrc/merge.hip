@@ -18,7 +18,7 @@
 
 namespace spamd {
 
-constexpr int MP_THREADS = 256;
+constexpr int MP_THREADS = 512;
 constexpr int MP_VT = 8;
 constexpr int MP_TILE = MP_THREADS * MP_VT;
 
@@ -96,8 +96,12 @@ __global__ void __launch_bounds__(256) mp_partition_kernel(const int64_t* __rest
   part[p] = lo;
 }
 
-// FILL = false: counts[block] = number of outputs; FILL = true: write them at offs[block] + local rank.
-template <typename T, typename O, bool FILL>
+// MODE 0: counts[block] = number of outputs.  MODE 1: write them at offs[block] + local rank.
+// MODE 2: single pass — tiles are taken in ticket order and every tile obtains its output offset by looking back
+// at its predecessors' published totals (`counts` then holds nblocks state words, zero-initialised, + the ticket
+// counter + the grand total): the count pass (a full extra read of both operands) disappears; the outputs must
+// have room for na + nb elements.
+template <typename T, typename O, int MODE>
 __global__ void __launch_bounds__(MP_THREADS)
 mp_union_kernel(int op, const int64_t* __restrict__ ka, const T* __restrict__ va, int64_t na,
                 const int64_t* __restrict__ kb, const T* __restrict__ vb, int64_t nb, T fill_a, T fill_b,
@@ -106,8 +110,16 @@ mp_union_kernel(int op, const int64_t* __restrict__ ka, const T* __restrict__ va
   __shared__ int64_t sk[MP_TILE + 4];
   __shared__ T sv[MP_TILE + 4];
   __shared__ int wave_tot[MP_THREADS / 64];
+  constexpr bool FILL = MODE != 0;
   const int tid = threadIdx.x;
-  const int64_t blk = blockIdx.x;
+  int64_t blk = blockIdx.x;
+  const int64_t nblocks = gridDim.x;
+  if constexpr (MODE == 2) {  // ticket order = start order: a tile only ever waits for tiles that are already running
+    __shared__ int64_t ticket;
+    if (tid == 0) ticket = (int64_t)atomicAdd(reinterpret_cast<unsigned long long*>(counts + nblocks), 1ull);
+    __syncthreads();
+    blk = ticket;
+  }
   const int64_t a0 = part[blk], a1 = part[blk + 1];
   int64_t d0 = blk * MP_TILE, d1 = (blk + 1) * MP_TILE;
   if (d1 > na + nb) d1 = na + nb;
@@ -190,7 +202,49 @@ mp_union_kernel(int op, const int64_t* __restrict__ ka, const T* __restrict__ va
     static_assert(sizeof(O) <= sizeof(T), "the output staging area reuses sv");
     O* const so = reinterpret_cast<O*>(sv);
     const int lbase = base + (incl - cnt);
-    const int64_t o = offs[blk];
+    int64_t o;
+    if constexpr (MODE == 1) {
+      o = offs[blk];
+    } else {
+      // decoupled look-back on one word per tile: (1 << 62 | own total) = "aggregate known", (2 << 62 | inclusive
+      // prefix) = "prefix known"; the value travels inside the flag word, so no fence is needed
+      __shared__ int64_t excl_s;
+      if (tid < 64) {  // wave 0 looks back 64 predecessors at a time
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(counts);
+        const unsigned long long mask = (1ull << 62) - 1;
+        if (tid == 0 && blk > 0)
+          __hip_atomic_store(&st[blk], (1ull << 62) | (unsigned long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long excl = 0;
+        int64_t hi = blk - 1;  // newest predecessor not yet accounted for
+        while (hi >= 0) {
+          const int64_t j = hi - tid;
+          unsigned long long v = 2ull << 62;  // lanes past tile 0 behave like "prefix known, value 0"
+          if (j >= 0) v = __hip_atomic_load(&st[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long flag = v >> 62;
+          const unsigned long long have_prefix = __ballot(flag == 2);
+          const unsigned long long missing = __ballot(flag == 0);
+          // the window is usable up to the nearest lane with a prefix, if no lane before it is still missing
+          const int first_prefix = have_prefix ? __builtin_ctzll(have_prefix) : 64;
+          const unsigned long long before = first_prefix >= 64 ? ~0ull : ((1ull << first_prefix) - 1);
+          if (missing & (before | (first_prefix < 64 ? (1ull << first_prefix) : 0))) continue;  // spin: re-read the window
+          unsigned long long part = (tid <= first_prefix || first_prefix >= 64) ? (v & mask) : 0;
+          if (first_prefix < 64 && tid > first_prefix) part = 0;
+#pragma unroll
+          for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+          excl += part;
+          if (first_prefix < 64) break;
+          hi -= 64;
+        }
+        if (tid == 0) {
+          __hip_atomic_store(&st[blk], (2ull << 62) | (excl + (unsigned long long)tot), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+          if (blk == nblocks - 1) counts[nblocks + 1] = (int64_t)(excl + (unsigned long long)tot);
+          excl_s = (int64_t)excl;
+        }
+      }
+      __syncthreads();
+      o = excl_s;
+    }
     if (tot * 4 >= MP_TILE) {
       __syncthreads();  // everyone is done reading sk / sv
 #pragma unroll
@@ -244,7 +298,9 @@ extern "C" int spamd_merge_partition(int64_t na, const int64_t* ka, int64_t nb, 
 }
 
 // fill == 0: counts[nblocks] <- outputs per block.  fill == 1: offsets[nblocks] (exclusive scan of the
-// counts) -> out_keys / out_vals.  val_dtype F32|F64|I32|I64|U8; comparisons/logical ops write U8.
+// counts) -> out_keys / out_vals.  fill == 2: single pass; counts = nblocks + 2 int64 of workspace (zeroed here),
+// counts[nblocks + 1] receives the number of outputs, out_keys / out_vals hold na + nb elements.
+// val_dtype F32|F64|I32|I64|U8; comparisons/logical ops write U8.
 extern "C" int spamd_merge_union(int fill, int op, int val_dtype, int64_t na, const int64_t* ka, const void* va,
                                  int64_t nb, const int64_t* kb, const void* vb, uint64_t fill_a_bits,
                                  uint64_t fill_b_bits, uint64_t fill_out_bits, const int64_t* part,
@@ -254,18 +310,27 @@ extern "C" int spamd_merge_union(int fill, int op, int val_dtype, int64_t na, co
   const int64_t nblocks = spamd_merge_num_blocks(na, nb);
   if (nblocks == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
+  if (fill == 2) {
+    hipError_t e = hipMemsetAsync(counts, 0, (size_t)(nblocks + 2) * sizeof(int64_t), s);
+    if (e != hipSuccess) return (int)e;
+  }
   const bool to_bool = op >= 32 && op < 64;
   if (op >= 64 && (val_dtype == SPAMD_F32 || val_dtype == SPAMD_F64)) return SPAMD_ETYPE;
   if (op == 6) return SPAMD_ETYPE;  // power: use the aligned-array path
 #define MP_LAUNCH(T, O)                                                                                       \
   do {                                                                                                        \
-    if (fill)                                                                                                 \
-      hipLaunchKernelGGL((mp_union_kernel<T, O, true>), dim3((unsigned)nblocks), dim3(MP_THREADS), 0, s, op, ka, \
+    if (fill == 2)                                                                                            \
+      hipLaunchKernelGGL((mp_union_kernel<T, O, 2>), dim3((unsigned)nblocks), dim3(MP_THREADS), 0, s, op, ka,    \
+                         (const T*)va, na, kb, (const T*)vb, nb, from_bits<T>(fill_a_bits),                   \
+                         from_bits<T>(fill_b_bits), from_bits<O>(fill_out_bits), part, counts, offsets,       \
+                         out_keys, (O*)out_vals);                                                             \
+    else if (fill)                                                                                            \
+      hipLaunchKernelGGL((mp_union_kernel<T, O, 1>), dim3((unsigned)nblocks), dim3(MP_THREADS), 0, s, op, ka,    \
                          (const T*)va, na, kb, (const T*)vb, nb, from_bits<T>(fill_a_bits),                   \
                          from_bits<T>(fill_b_bits), from_bits<O>(fill_out_bits), part, counts, offsets,       \
                          out_keys, (O*)out_vals);                                                             \
     else                                                                                                      \
-      hipLaunchKernelGGL((mp_union_kernel<T, O, false>), dim3((unsigned)nblocks), dim3(MP_THREADS), 0, s, op, ka, \
+      hipLaunchKernelGGL((mp_union_kernel<T, O, 0>), dim3((unsigned)nblocks), dim3(MP_THREADS), 0, s, op, ka,    \
                          (const T*)va, na, kb, (const T*)vb, nb, from_bits<T>(fill_a_bits),                   \
                          from_bits<T>(fill_b_bits), from_bits<O>(fill_out_bits), part, counts, offsets,       \
                          out_keys, (O*)out_vals);                                                             \
