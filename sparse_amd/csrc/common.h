@@ -135,6 +135,43 @@ inline int launch_status() {
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+#ifdef __HIPCC__
+// Decoupled look-back over one 64-bit state word per tile (zero-initialised): (1 << 62 | own total) = "aggregate
+// known", (2 << 62 | inclusive prefix) = "prefix known"; the value travels inside the flag word, so no fence is
+// needed.  Called by the 64 lanes of ONE wave (lane = 0..63); returns the sum of the totals of tiles 0 .. blk-1 in
+// every lane and publishes this tile's inclusive prefix.  Tiles must be numbered in start order (a ticket taken with
+// an atomic at tile start), so that a tile only ever waits for tiles that are already running.
+__device__ __forceinline__ unsigned long long lookback_exclusive(unsigned long long* st, int64_t blk, unsigned long long tot,
+                                                                 int lane) {
+  const unsigned long long mask = (1ull << 62) - 1;
+  if (lane == 0 && blk > 0)
+    __hip_atomic_store(&st[blk], (1ull << 62) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned long long excl = 0;
+  int64_t hi = blk - 1;  // newest predecessor not yet accounted for
+  while (hi >= 0) {
+    const int64_t j = hi - lane;
+    unsigned long long v = 2ull << 62;  // lanes past tile 0 behave like "prefix known, value 0"
+    if (j >= 0) v = __hip_atomic_load(&st[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long flag = v >> 62;
+    const unsigned long long have_prefix = __ballot(flag == 2);
+    const unsigned long long missing = __ballot(flag == 0);
+    // the window is usable up to the nearest lane with a prefix, if no lane up to there is still missing
+    const int first_prefix = have_prefix ? __builtin_ctzll(have_prefix) : 64;
+    const unsigned long long upto = first_prefix >= 63 ? ~0ull : ((2ull << first_prefix) - 1);
+    if (missing & upto) continue;  // spin: re-read the window
+    unsigned long long part = lane <= first_prefix ? (v & mask) : 0;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+    excl += part;
+    if (first_prefix < 64) break;
+    hi -= 64;
+  }
+  if (lane == 0)
+    __hip_atomic_store(&st[blk], (2ull << 62) | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return excl;
+}
+#endif
+
 }  // namespace spamd
 
 // Dispatch helpers: call F<T,I>(...) for runtime dtype codes.

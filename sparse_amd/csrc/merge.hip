@@ -206,38 +206,11 @@ mp_union_kernel(int op, const int64_t* __restrict__ ka, const T* __restrict__ va
     if constexpr (MODE == 1) {
       o = offs[blk];
     } else {
-      // decoupled look-back on one word per tile: (1 << 62 | own total) = "aggregate known", (2 << 62 | inclusive
-      // prefix) = "prefix known"; the value travels inside the flag word, so no fence is needed
       __shared__ int64_t excl_s;
       if (tid < 64) {  // wave 0 looks back 64 predecessors at a time
-        unsigned long long* st = reinterpret_cast<unsigned long long*>(counts);
-        const unsigned long long mask = (1ull << 62) - 1;
-        if (tid == 0 && blk > 0)
-          __hip_atomic_store(&st[blk], (1ull << 62) | (unsigned long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned long long excl = 0;
-        int64_t hi = blk - 1;  // newest predecessor not yet accounted for
-        while (hi >= 0) {
-          const int64_t j = hi - tid;
-          unsigned long long v = 2ull << 62;  // lanes past tile 0 behave like "prefix known, value 0"
-          if (j >= 0) v = __hip_atomic_load(&st[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const unsigned long long flag = v >> 62;
-          const unsigned long long have_prefix = __ballot(flag == 2);
-          const unsigned long long missing = __ballot(flag == 0);
-          // the window is usable up to the nearest lane with a prefix, if no lane before it is still missing
-          const int first_prefix = have_prefix ? __builtin_ctzll(have_prefix) : 64;
-          const unsigned long long before = first_prefix >= 64 ? ~0ull : ((1ull << first_prefix) - 1);
-          if (missing & (before | (first_prefix < 64 ? (1ull << first_prefix) : 0))) continue;  // spin: re-read the window
-          unsigned long long part = (tid <= first_prefix || first_prefix >= 64) ? (v & mask) : 0;
-          if (first_prefix < 64 && tid > first_prefix) part = 0;
-#pragma unroll
-          for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
-          excl += part;
-          if (first_prefix < 64) break;
-          hi -= 64;
-        }
+        const unsigned long long excl = lookback_exclusive(reinterpret_cast<unsigned long long*>(counts), blk,
+                                                           (unsigned long long)tot, tid);
         if (tid == 0) {
-          __hip_atomic_store(&st[blk], (2ull << 62) | (excl + (unsigned long long)tot), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
           if (blk == nblocks - 1) counts[nblocks + 1] = (int64_t)(excl + (unsigned long long)tot);
           excl_s = (int64_t)excl;
         }
