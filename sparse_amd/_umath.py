@@ -156,7 +156,7 @@ def merge_union(name, ka, va, kb, vb, fill_a, fill_b, fill_out):
             keys, vals = keys[:total], vals[:total]
         return keys, (vals.view(torch.bool) if code in _TO_BOOL_BIN else vals)
     _ffi.call("spamd_merge_union", 0, *args, ptr(counts), 0, 0, 0, s)
-    offs = K.exclusive_scan(counts)
+    offs = K.exclusive_scan(counts[:nblocks + 1])   # n counts + one ignored slot (the last slot is single-pass only)
     total = int(offs[-1])
     keys = torch.empty(total, dtype=torch.int64, device=devi)
     vals = torch.empty(total, dtype=out_t, device=devi)

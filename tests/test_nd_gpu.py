@@ -163,3 +163,25 @@ def test_prune_count_first_path(monkeypatch):
     assert g.nnz == 3
     ints = sp.COO(coords, np.array([1, 0, 0, 7, 0], dtype=np.int32), shape=(3, 5), prune=True)
     assert ints.nnz == 2 and Kn.count_eq_bits(torch.tensor([1, 0, 0, 7, 0], dtype=torch.int32, device="cuda"), 0) == 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nnz", [(0, 5), (4096, 4096), (4097, 1), (300_000, 171_873), (171_873, 171_873)])
+def test_merge_single_pass_matches_count_scan_fill(monkeypatch, nnz):
+    """The elementwise merge exists in two forms (csrc/merge.hip): one pass with look-back offsets (default) and
+    count + scan + fill.  Both must give the same canonical result, including full operands (every key shared),
+    tile-boundary sizes and an empty operand; checked against the dense arithmetic as well."""
+    import sparse_amd as sp
+    from sparse_amd import _umath as U
+
+    shape = (39, 39, 113)  # 171873 cells
+    x = sp.random(shape, nnz=nnz[0], random_state=3)
+    y = sp.random(shape, nnz=nnz[1], random_state=4)
+    for f in (lambda a, b: a + b, lambda a, b: a * b, lambda a, b: np.maximum(a, b)):
+        monkeypatch.setattr(U, "MERGE_SINGLE_PASS", True)
+        r1 = f(x, y)
+        monkeypatch.setattr(U, "MERGE_SINGLE_PASS", False)
+        r2 = f(x, y)
+        assert r1.nnz == r2.nnz <= x.nnz + y.nnz
+        assert torch.equal(r1.linear_loc(), r2.linear_loc()) and torch.equal(r1.data, r2.data)
+        assert np.array_equal(r1.todense(), f(x.todense(), y.todense()))

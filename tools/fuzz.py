@@ -1,0 +1,69 @@
+"""Randomised cross-checks of kernels that exist in two forms (run on the GPU box):
+   tiled vs row-group SpMM (bit-identical, both arithmetic modes, fp32/fp64), single-pass vs two-pass merge,
+   row-local vs global SpGEMM, grouped reduce vs a float64 scatter-add.   python tools/fuzz.py [seconds]"""
+import sys, time, numpy as np, torch
+sys.path.insert(0, "/root/repo")
+import sparse_amd as sp
+from sparse_amd import _kernels as K, _umath as U
+from bench import make_csr_device
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(time.time()))
+t_end = time.time() + budget
+n = {"spmm": 0, "merge": 0, "spgemm": 0, "reduce": 0}
+while time.time() < t_end:
+    # ---- SpMM
+    M = int(rng.choice([1, 31, 513, 5000, 70001, 200000]))
+    Kd = int(rng.choice([1, 127, 128, 129, 1000, 7936, 16000, 33000]))
+    dens = float(rng.choice([0.0, 0.001, 0.01, 0.05, 0.3]))
+    if M * Kd * dens > 3e7:
+        dens = 3e7 / (M * Kd)
+    dt = torch.float32 if rng.random() < 0.5 else torch.float64
+    panel = 128 if dt == torch.float32 else 64
+    N = panel * int(rng.integers(1, 4))
+    data, idx, ptr = make_csr_device(M, Kd, dens, seed=int(rng.integers(1 << 30)), dtype=dt,
+                                     idx_dtype=torch.int32 if rng.random() < 0.7 else torch.int64)
+    b = torch.randn((Kd, N), device="cuda", dtype=dt)
+    layout = K.csr_tiled_layout(data, idx, ptr, M, Kd)
+    for exact in (False, True):
+        got = K.dot_csr_ndarray_tiled(layout, (M, N), Kd, b, exact=exact)
+        ref = K.dot_csr_ndarray((M, N), data, idx, ptr, b, exact=exact)
+        assert torch.equal(got, ref), ("spmm", M, Kd, dens, dt, N, exact)
+    n["spmm"] += 1
+    # ---- merge (elementwise add / multiply / maximum) single-pass vs two-pass
+    shape = (int(rng.integers(1, 300)), int(rng.integers(1, 300)), int(rng.integers(1, 300)))
+    size = shape[0] * shape[1] * shape[2]
+    nnz = int(min(size, rng.integers(0, 3_000_000)))
+    x = sp.random(shape, nnz=nnz, random_state=int(rng.integers(1 << 30)))
+    y = sp.random(shape, nnz=int(min(size, rng.integers(0, 3_000_000))), random_state=int(rng.integers(1 << 30)))
+    for f in (lambda a, c: a + c, lambda a, c: a * c, lambda a, c: np.maximum(a, c)):
+        U.MERGE_SINGLE_PASS = True
+        r1 = f(x, y)
+        U.MERGE_SINGLE_PASS = False
+        r2 = f(x, y)
+        U.MERGE_SINGLE_PASS = True
+        assert torch.equal(r1.linear_loc(), r2.linear_loc()) and torch.equal(r1.data, r2.data), ("merge", shape)
+    n["merge"] += 1
+    # ---- grouped reduce vs scatter-add in float64
+    ax = int(rng.integers(0, 3))
+    s = x.sum(axis=ax).todense()
+    want = torch.zeros(shape, dtype=torch.float64, device="cuda")
+    if x.nnz:
+        want[tuple(x.coords.long())] = x.data.double()
+    assert np.allclose(s, want.sum(dim=ax).cpu().numpy(), rtol=1e-11, atol=1e-13), ("reduce", shape, ax)
+    n["reduce"] += 1
+    # ---- SpGEMM
+    ng = int(rng.choice([50, 2000, 20000]))
+    dg = float(rng.choice([0.0005, 0.005, 0.02]))
+    g1 = sp.random((ng, ng), density=dg, random_state=int(rng.integers(1 << 30)), format="gcxs", compressed_axes=(0,))
+    g2 = sp.random((ng, ng), density=dg, random_state=int(rng.integers(1 << 30)), format="gcxs", compressed_axes=(0,))
+    K.SPGEMM_ROW_LOCAL = True
+    c1 = g1 @ g2
+    K.SPGEMM_ROW_LOCAL = False
+    c2 = g1 @ g2
+    K.SPGEMM_ROW_LOCAL = True
+    assert torch.equal(c1.indptr.long(), c2.indptr.long()) and torch.equal(c1.indices.long(), c2.indices.long()) \
+        and torch.equal(c1.data, c2.data), ("spgemm", ng, dg)
+    n["spgemm"] += 1
+torch.cuda.synchronize()
+print("fuzz ok:", n)
