@@ -236,7 +236,7 @@ int spamd_merge_union(int fill, int op, int val_dtype, int64_t na, const int64_t
  *   out[g] = data[s_g] op data[s_g+1] op ...; counts[g] = run length (may be NULL).
  *   Short runs: one thread per run, strictly left to right (bit-identical to reduceat).
  *   Long runs (n/nseg >= 24 and seg_start_ws != NULL, nseg+1 int64): one wave per run (tree order).
- *   op: 0 add 1 multiply 2 maximum 3 minimum 4 logical_or 5 logical_and.
+ *   op: 0 add 1 multiply 2 maximum 3 minimum 4 logical_or 5 logical_and 6 fmax 7 fmin (NaN-skipping).
  * ------------------------------------------------------------------------------------- */
 int spamd_segment_reduce(int op, int val_dtype, int64_t n, const void* data, const int64_t* heads,
                          const int64_t* offsets, int64_t nseg, void* out, int64_t* counts,

@@ -390,6 +390,63 @@ def gen_matrix(sp):
     _save("matrix", **cases)
 
 
+def gen_select(sp):
+    """N3: `where`, NaN-skipping reductions, creation functions (reference _coo/common.py:334-733,
+    _common.py:1561-1857)."""
+    cases = {}
+    shape = (5, 6, 7)
+    rng = np.random.default_rng(91)
+
+    def arr(seed, density, nan=0.0):
+        r = np.random.default_rng(seed)
+        d = np.zeros(shape)
+        m = r.random(shape) < density
+        d[m] = r.random(int(m.sum())) - 0.4
+        if nan:
+            d[r.random(shape) < nan] = np.nan
+        return d
+
+    c, x, y = arr(1, 0.4), arr(2, 0.5), arr(3, 0.3)
+    xn = arr(4, 0.5, nan=0.2)
+    xn[1, 2, :] = np.nan
+    cases.update(shape=np.array(shape), c=c, x=x, y=y, xn=xn)
+    sc, sx, sy, sxn = (sp.COO.from_numpy(a) for a in (c > 0, x, y, xn))
+    k = 0
+    for label, r in (("where(c,x,y)", sp.where(sc, sx, sy)), ("where(c,2.5,y)", sp.where(sc, 2.5, sy)),
+                     ("where(c,x,-1.0)", sp.where(sc, sx, -1.0)), ("where(isnan(xn),0,xn)", sp.where(np.isnan(sxn), 0, sxn)),
+                     ("where(xn,x,y)", sp.where(sxn, sx, sy))):
+        cases[f"w{k}_label"] = np.array(label)
+        cases[f"w{k}_dense"] = r.todense()
+        cases[f"w{k}_nnz"] = np.array(r.nnz)
+        cases[f"w{k}_fill"] = np.asarray(r.fill_value)
+        k += 1
+    cases["n_where"] = np.array(k)
+    for j, a in enumerate(sp.where(sy)):
+        cases[f"w1arg_{j}"] = np.asarray(a)
+    k = 0
+    for name in ("nansum", "nanprod", "nanmax", "nanmin", "nanmean"):
+        for axis in (None, 0, 2, (0, 1)):
+            with np.errstate(all="ignore"), warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                r = getattr(sp, name)(sxn, axis=axis)
+            cases[f"n{k}_name"] = np.array(name)
+            cases[f"n{k}_axis"] = np.array(-99 if axis is None else axis)
+            cases[f"n{k}_dense"] = r.todense() if hasattr(r, "todense") else np.asarray(r)
+            cases[f"n{k}_nnz"] = np.array(getattr(r, "nnz", -1))
+            cases[f"n{k}_fill"] = np.asarray(getattr(r, "fill_value", 0))
+            k += 1
+    cases["n_nan"] = np.array(k)
+    for j, (n, m, kk) in enumerate(((4, None, 0), (3, 5, 1), (5, 3, -2), (3, 3, 7))):
+        e = sp.eye(n, m, k=kk, dtype=np.float32)
+        cases[f"eye{j}_args"] = np.array([n, -1 if m is None else m, kk])
+        cases[f"eye{j}_coords"] = e.coords
+        cases[f"eye{j}_data"] = e.data
+    f = sp.full((2, 3), 7, dtype=np.int32)
+    cases.update(full_fill=np.asarray(f.fill_value), full_nnz=np.array(f.nnz), full_dense=f.todense(),
+                 ones_plus=(sx + sp.ones(shape)).todense())
+    _save("select", **cases)
+
+
 def main():
     sp = ref_loader.load()
     print("reference:", sp.__file__)
@@ -399,6 +456,7 @@ def main():
     gen_reduce(sp)
     gen_nd(sp)
     gen_matrix(sp)
+    gen_select(sp)
 
 
 if __name__ == "__main__":

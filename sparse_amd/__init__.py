@@ -20,10 +20,14 @@ from ._umath import elemwise
 from ._batched import concatenate, stack
 from ._broadcast import broadcast_to
 from ._io import load_npz, save_npz
-from ._api import (all, any, asarray, astype, matrix_transpose, max, mean, min, permute_dims, prod, random, reshape,
-                   sddmm, std, sum, var, vecdot)
+from ._api import (all, any, argwhere, asarray, astype, empty, empty_like, expand_dims, eye, full, full_like,
+                   matrix_transpose, max, mean, min, moveaxis, nanmax, nanmean, nanmin, nanprod, nanreduce, nansum, nonzero,
+                   ones, ones_like, permute_dims, prod, random, reshape, sddmm, squeeze, std, sum, var, vecdot, where, zeros,
+                   zeros_like)
 from ._ffi import HipBackendError
 
-__all__ = ["COO", "GCXS", "SparseArray", "HipBackendError", "all", "any", "as_coo", "asarray", "astype", "broadcast_to", "concatenate", "dot",
-           "elemwise", "load_npz", "matmul", "matrix_transpose", "max", "mean", "min", "permute_dims", "prod", "random", "reshape",
-           "save_npz", "sddmm", "stack", "std", "sum", "tensordot", "var", "vecdot"]
+__all__ = ["COO", "GCXS", "SparseArray", "HipBackendError", "all", "any", "argwhere", "as_coo", "asarray", "astype", "broadcast_to",
+           "concatenate", "dot", "elemwise", "empty", "empty_like", "expand_dims", "eye", "full", "full_like", "load_npz", "matmul",
+           "matrix_transpose", "max", "mean", "min", "moveaxis", "nanmax", "nanmean", "nanmin", "nanprod", "nanreduce", "nansum",
+           "nonzero", "ones", "ones_like", "permute_dims", "prod", "random", "reshape", "save_npz", "sddmm", "squeeze", "stack", "std",
+           "sum", "tensordot", "var", "vecdot", "where", "zeros", "zeros_like"]

@@ -136,3 +136,215 @@ def matrix_transpose(x, /):
 def vecdot(x1, x2, /, *, axis=-1):
     """sum(x1 * x2, axis) (reference `vecdot`, _common.py)."""
     return (x1 * x2).sum(axis=axis)
+
+
+# ---- creation (reference _common.py:1561-1857: arrays with no stored element and the value as fill value) ----------
+def full(shape, fill_value, dtype=None, format="coo", order="C", *, device=None, **kwargs):
+    """Array of `shape` whose every element is `fill_value`: nnz = 0, the value is the fill value (reference
+    `full`, _common.py:1628-1681)."""
+    if dtype is None:
+        dtype = np.array(fill_value).dtype
+    if not isinstance(shape, tuple):
+        shape = (shape,)
+    if order not in {"C", None}:
+        raise NotImplementedError("Currently, only 'C' and None are supported.")
+    d = torch.device(device) if device is not None else dev.default_device()
+    out = COO(torch.zeros((len(shape), 0), dtype=torch.int64, device=d),
+              torch.zeros(0, dtype=dev.torch_dtype(np.dtype(dtype)), device=d), shape=shape,
+              fill_value=np.asarray(fill_value).astype(dtype)[()], has_duplicates=False, sorted=True)
+    return out.asformat(format, **kwargs) if format != "coo" else out
+
+
+def full_like(a, fill_value, dtype=None, shape=None, format=None, *, device=None, **kwargs):
+    if format is None and not isinstance(a, np.ndarray):
+        format = type(a).__name__.lower()
+    elif format is None:
+        format = "coo"
+    if hasattr(a, "compressed_axes") and kwargs.get("compressed_axes") is None and format == "gcxs" and shape is None:
+        kwargs["compressed_axes"] = a.compressed_axes
+    return full(a.shape if shape is None else shape, fill_value, dtype=(a.dtype if dtype is None else dtype),
+                format=format, device=device if device is not None else getattr(a, "device", None), **kwargs)
+
+
+def zeros(shape, dtype=float, format="coo", *, device=None, **kwargs):
+    return full(shape, 0, dtype=np.dtype(dtype), format=format, device=device, **kwargs)
+
+
+def ones(shape, dtype=float, format="coo", *, device=None, **kwargs):
+    return full(shape, 1, dtype=np.dtype(dtype), format=format, device=device, **kwargs)
+
+
+def empty(shape, dtype=float, format="coo", *, device=None, **kwargs):
+    return full(shape, 0, dtype=np.dtype(dtype), format=format, device=device, **kwargs)
+
+
+def zeros_like(a, dtype=None, shape=None, format=None, *, device=None, **kwargs):
+    return full_like(a, 0, dtype=dtype, shape=shape, format=format, device=device, **kwargs)
+
+
+def ones_like(a, dtype=None, shape=None, format=None, *, device=None, **kwargs):
+    return full_like(a, 1, dtype=dtype, shape=shape, format=format, device=device, **kwargs)
+
+
+def empty_like(a, dtype=None, shape=None, format=None, *, device=None, **kwargs):
+    return full_like(a, 0, dtype=dtype, shape=shape, format=format, device=device, **kwargs)
+
+
+def eye(N, M=None, k=0, dtype=float, format="coo", *, device=None, **kwargs):
+    """Ones on the k-th diagonal of an N x M array (reference `eye`, _common.py:1561-1625); coordinates are
+    generated on the device."""
+    N, M, k = int(N), int(N if M is None else M), int(k)
+    length = builtins.min(N, M)
+    if k > 0:
+        length = builtins.max(builtins.min(length, M - k), 0)
+    elif k < 0:
+        length = builtins.max(builtins.min(length, N + k), 0)
+    if length == 0:
+        return zeros((N, M), dtype=dtype, format=format, device=device, **kwargs)
+    d = torch.device(device) if device is not None else dev.default_device()
+    rows = torch.arange(length, dtype=torch.int64, device=d) + builtins.max(-k, 0)  # memory plumbing: an index ramp
+    coords = torch.stack([rows, rows + k])
+    data = torch.ones(length, dtype=dev.torch_dtype(np.dtype(dtype)), device=d)
+    out = COO(coords, data, shape=(N, M), has_duplicates=False, sorted=True)
+    return out.asformat(format, **kwargs) if format != "coo" else out
+
+
+# ---- selection and NaN-skipping reductions (reference _coo/common.py:334-733) ------------------------------------------
+def where(condition, x=None, y=None):
+    """`np.where` for sparse operands; with one argument, the coordinates of the stored elements (reference
+    _coo/common.py:534-581)."""
+    from ._umath import elemwise
+    from ._utils import check_zero_fill_value
+
+    if x is None and y is None:
+        check_zero_fill_value(condition)
+        return tuple(as_coo(condition).coords)
+    if (x is None) != (y is None):
+        raise ValueError("either both or neither of x and y should be given")
+    return elemwise(np.where, condition, x, y)
+
+
+def nonzero(x, /):
+    """Coordinates of the stored elements, one array per dimension (reference `nonzero`)."""
+    from ._utils import check_zero_fill_value
+
+    check_zero_fill_value(x)
+    return tuple(as_coo(x).coords)
+
+
+def argwhere(a):
+    """Stored coordinates, one row per element (reference `argwhere`, _coo/common.py:584-611)."""
+    return torch.stack(list(where(a)), dim=1) if a.ndim else torch.zeros((a.nnz, 0), dtype=torch.int64)
+
+
+def _replace_nan(x, value):
+    if np.dtype(x.dtype).kind != "f":
+        return x
+    return where(np.isnan(x), value, x)
+
+
+def nanreduce(x, method, identity=None, axis=None, keepdims=False, **kwargs):
+    """NaN-skipping reduction: NaNs are replaced by the identity of `method`, then `reduce` (reference
+    `nanreduce`, _coo/common.py:696-732)."""
+    arr = _replace_nan(as_coo(x), method.identity if identity is None else identity)
+    return arr.reduce(method, axis, keepdims, **kwargs)
+
+
+def nansum(x, axis=None, keepdims=False, dtype=None, out=None):
+    assert out is None
+    return nanreduce(as_coo(x), np.add, axis=axis, keepdims=keepdims, dtype=dtype)
+
+
+def nanprod(x, axis=None, keepdims=False, dtype=None, out=None):
+    assert out is None
+    return nanreduce(as_coo(x), np.multiply, axis=axis, keepdims=keepdims, dtype=dtype)
+
+
+def _contains_nan(ar):
+    if isinstance(ar, SparseArray):
+        if np.dtype(ar.dtype).kind != "f":
+            return False
+        if ar.nnz != ar.size and np.isnan(ar.fill_value):
+            return True
+        return bool(K.has_nan(ar.data)) if ar.nnz else False
+    return bool(np.isnan(ar))
+
+
+def _nan_extreme(x, method, axis, keepdims, dtype):
+    import warnings
+
+    ar = as_coo(x).reduce(method, axis=axis, keepdims=keepdims, dtype=dtype)
+    if _contains_nan(ar):
+        warnings.warn("All-NaN slice encountered", RuntimeWarning, stacklevel=2)
+    return ar
+
+
+def nanmax(x, axis=None, keepdims=False, dtype=None, out=None):
+    """Maximum skipping NaNs = reduce with np.fmax (reference `nanmax`, _coo/common.py:431-464)."""
+    assert out is None
+    return _nan_extreme(x, np.fmax, axis, keepdims, dtype)
+
+
+def nanmin(x, axis=None, keepdims=False, dtype=None, out=None):
+    assert out is None
+    return _nan_extreme(x, np.fmin, axis, keepdims, dtype)
+
+
+def nanmean(x, axis=None, keepdims=False, dtype=None, out=None):
+    """Mean over the non-NaN elements (reference `nanmean`, _coo/common.py:364-415: same composition)."""
+    import warnings
+
+    assert out is None
+    x = as_coo(x)
+    if np.dtype(x.dtype).kind != "f":
+        return x.mean(axis=axis, keepdims=keepdims, dtype=dtype)
+    mask = np.isnan(x)
+    x2 = where(mask, 0, x)
+    nancount = mask.sum(axis=axis, dtype="i8", keepdims=keepdims)
+    if axis is None:
+        axis = tuple(range(x.ndim))
+    elif not isinstance(axis, tuple):
+        axis = (axis,)
+    den = 1
+    for i in axis:
+        den *= x.shape[i]
+    den = den - nancount
+    if (den == 0).any():
+        warnings.warn("Mean of empty slice", RuntimeWarning, stacklevel=1)
+    num = x2.sum(axis=axis, dtype=dtype, keepdims=keepdims)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        if num.ndim:
+            return np.true_divide(num, den, casting="unsafe")
+        return (num / den).astype(dtype if dtype is not None else x.dtype)
+
+
+# ---- shape helpers of the array-API surface ---------------------------------------------------------------------------
+def moveaxis(a, source, destination):
+    src = [s % a.ndim for s in ((source,) if isinstance(source, int) else source)]
+    dst = [d % a.ndim for d in ((destination,) if isinstance(destination, int) else destination)]
+    if len(src) != len(dst):
+        raise ValueError("`source` and `destination` arguments must have the same number of elements")
+    order = [n for n in range(a.ndim) if n not in src]
+    for d, s in sorted(zip(dst, src)):
+        order.insert(d, s)
+    return a.transpose(order)
+
+
+def expand_dims(x, /, *, axis=0):
+    axes = (axis,) if isinstance(axis, int) else tuple(axis)
+    nd = x.ndim + len(axes)
+    axes = sorted(a % nd for a in axes)
+    shape = list(x.shape)
+    for a in axes:
+        shape.insert(a, 1)
+    return x.reshape(tuple(shape))
+
+
+def squeeze(x, /, axis=None):
+    if axis is None:
+        axes = tuple(i for i, s in enumerate(x.shape) if s == 1)
+    else:
+        axes = tuple(a % x.ndim for a in ((axis,) if isinstance(axis, int) else axis))
+        if builtins.any(x.shape[a] != 1 for a in axes):
+            raise ValueError("cannot select an axis to squeeze out which has size not equal to one")
+    return x.reshape(tuple(s for i, s in enumerate(x.shape) if i not in axes))

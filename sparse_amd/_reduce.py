@@ -14,7 +14,7 @@ from . import _kernels as K
 from ._device import code_of, np_dtype, ptr, require_hip, stream_ptr, torch_dtype
 from ._utils import equivalent, normalize_axis, prod
 
-_RED_OPS = {"add": 0, "multiply": 1, "maximum": 2, "minimum": 3, "logical_or": 4, "logical_and": 5}
+_RED_OPS = {"add": 0, "multiply": 1, "maximum": 2, "minimum": 3, "logical_or": 4, "logical_and": 5, "fmax": 6, "fmin": 7}
 _SUPER = {"add": np.multiply, "multiply": np.power}
 
 

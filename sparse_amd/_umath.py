@@ -164,6 +164,70 @@ def merge_union(name, ka, va, kb, vb, fill_a, fill_b, fill_out):
     return keys, (vals.view(torch.bool) if code in _TO_BOOL_BIN else vals)
 
 
+def _where(proc, finish):
+    """`np.where(condition, x, y)` over COO / scalar operands (reference `where`, _coo/common.py:534-581, which is
+    `elemwise(np.where, ...)`): one sorted-key union of the sparse operands, each operand materialised on the union
+    (stored value or its fill value), a device select, and the usual prune against where(fills)."""
+    from ._broadcast import broadcast_shapes, broadcast_to
+    from ._coo import COO
+
+    sparse = [v for v in proc if isinstance(v, COO)]
+    if any(not isinstance(v, COO) and not _scalar_like(v) for v in proc):
+        raise NotImplementedError("where() with a dense (non-scalar) operand is not on the hip backend's path")
+    shape = broadcast_shapes(*[v.shape for v in sparse])
+    ops = [broadcast_to(v, shape) if isinstance(v, COO) else v for v in proc]
+    devi = sparse[0].device
+
+    def scalar_of(v):
+        return np.asarray(v.item() if isinstance(v, torch.Tensor) else v)[()]
+
+    def like(v):  # dtype-carrying stand-in; Python scalars stay weak (NEP 50)
+        if isinstance(v, COO):
+            return np.zeros(1, dtype=v.dtype)
+        return v.item() if isinstance(v, torch.Tensor) else v
+
+    fills = [np.asarray(v.fill_value)[()] if isinstance(v, COO) else scalar_of(v) for v in ops]
+    out_np = _np_result(np.where, np.ones(1, dtype=bool), like(ops[1]), like(ops[2])).dtype
+    if out_np not in (np.dtype("f4"), np.dtype("f8"), np.dtype("i4"), np.dtype("i8"), np.dtype("bool")):
+        raise NotImplementedError(f"dtype {out_np} is not supported by the hip backend's where path")
+    out_t = torch_dtype(out_np)
+    fill = np.asarray(np.where(bool(fills[0]), fills[1], fills[2])).astype(out_np)[()]
+    # union of the stored positions, with every operand's slots in it
+    keys, slots = None, []
+    for v in ops:
+        if not isinstance(v, COO):
+            slots.append(None)
+            continue
+        k = v.linear_loc()
+        if keys is None:
+            keys = k
+            n = int(k.numel())
+            iota = torch.empty(n, dtype=torch.int64, device=devi)
+            if n:
+                _ffi.call("spamd_iota", n, ptr(iota), stream_ptr(devi))
+            slots.append(iota)
+        else:
+            keys, s_old, s_new = union_merge(keys, k)
+            slots = [None if s is None else K.gather(s_old, s) for s in slots]
+            slots.append(s_new)
+    n = int(keys.numel())
+
+    def on_union(v, slot, fv, dtype):
+        fvn = np.asarray(fv).astype(dev.np_dtype(dtype) if dtype != torch.bool else bool)
+        full = _full(n, fvn if dtype != torch.bool else np.uint8(bool(fvn)), torch.uint8 if dtype == torch.bool else dtype, devi)
+        if isinstance(v, COO) and v.nnz:
+            K.scatter_into(full, slot, _as_u8(K.convert(v.data, dtype)))
+        return full
+
+    cond = on_union(ops[0], slots[0], bool(fills[0]), torch.bool)
+    xv = on_union(ops[1], slots[1], fills[1], out_t)
+    yv = on_union(ops[2], slots[2], fills[2], out_t)
+    res = select(cond, xv, yv) if n else xv
+    if out_t == torch.bool:
+        res = res.view(torch.bool)
+    return finish(keys, res, shape, fill, devi)
+
+
 def _func_name(func):
     if func is np.ndarray.astype:
         return "astype"
@@ -254,6 +318,8 @@ def elemwise(func, *args, **kwargs):
             res, fill = K.convert(res, torch_dtype(dtype_kw)), fill.astype(dtype_kw)
         return finish(x.linear_loc(), res, shape, np.asarray(fill)[()], devi)
 
+    if name == "where" and len(proc) == 3 and not kwargs and dtype_kw is None:
+        return _where(proc, finish)
     if len(proc) != 2 or name not in _BIN or kwargs:
         raise NotImplementedError(f"elemwise({func}) with {len(proc)} operands is not on the hip backend's path")
     a, b = proc

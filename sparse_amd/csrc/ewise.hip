@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(256) unary_tb_kernel(int op, const T* __restri
 }
 
 // ---- grouped reduce -----------------------------------------------------------------------------
-enum RedOp { R_ADD = 0, R_MUL, R_MAX, R_MIN, R_OR, R_AND };
+enum RedOp { R_ADD = 0, R_MUL, R_MAX, R_MIN, R_OR, R_AND, R_FMAX, R_FMIN };
 
 template <typename T>
 __device__ __forceinline__ T red(int op, T a, T b) {
@@ -261,6 +261,8 @@ __device__ __forceinline__ T red(int op, T a, T b) {
     case R_MIN: return np_min(a, b);
     case R_OR: return (T)((a != T(0)) || (b != T(0)));
     case R_AND: return (T)((a != T(0)) && (b != T(0)));
+    case R_FMAX: return bin_tt<T>(B_FMAX, a, b);  // NaN-skipping (np.fmax / np.fmin): nanmax, nanmin
+    case R_FMIN: return bin_tt<T>(B_FMIN, a, b);
   }
   return a;
 }
@@ -443,7 +445,7 @@ __global__ void __launch_bounds__(256) reduce_fill_kernel(int op, int64_t n, T* 
 
 extern "C" int spamd_reduce_fill(int op, int val_dtype, int64_t n, void* vals, const int64_t* counts, int64_t n_cols,
                                  double fill_f, int64_t fill_i, void* stream) {
-  if (n < 0 || op < R_ADD || op > R_AND) return SPAMD_EINVAL;
+  if (n < 0 || op < R_ADD || op > R_FMIN) return SPAMD_EINVAL;
   if (n == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   VAL_SWITCH5(val_dtype, T, {

@@ -57,7 +57,7 @@ struct GroupOfD {
   }
 };
 
-enum { GR_ADD = 0, GR_MUL, GR_MAX, GR_MIN, GR_OR, GR_AND };
+enum { GR_ADD = 0, GR_MUL, GR_MAX, GR_MIN, GR_OR, GR_AND, GR_FMAX, GR_FMIN };
 
 template <typename T>
 __device__ __forceinline__ T gr_apply(int op, T x, T y) {
@@ -67,6 +67,8 @@ __device__ __forceinline__ T gr_apply(int op, T x, T y) {
     case GR_MAX: return (x != x) ? x : ((y != y) ? y : (x > y ? x : y));  // NaN propagates (np.maximum)
     case GR_MIN: return (x != x) ? x : ((y != y) ? y : (x < y ? x : y));
     case GR_OR: return (T)((x != (T)0) || (y != (T)0));
+    case GR_FMAX: return (x != x) ? y : ((y != y) ? x : (x > y ? x : y));  // NaN is skipped (np.fmax)
+    case GR_FMIN: return (x != x) ? y : ((y != y) ? x : (x < y ? x : y));
     default: return (T)((x != (T)0) && (y != (T)0));
   }
 }
@@ -415,7 +417,7 @@ extern "C" int64_t spamd_group_reduce_ws_bytes(int val_dtype, int64_t n) {
 extern "C" int spamd_group_reduce(int op, int val_dtype, int64_t n, const int64_t* keys, int64_t divisor,
                                   int64_t key_bound, const void* data, int64_t* group_ids, void* values, int64_t* counts,
                                   int64_t* n_groups, void* ws, int64_t ws_bytes, void* stream) {
-  if (n < 0 || divisor <= 0 || op < 0 || op > GR_AND) return SPAMD_EINVAL;
+  if (n < 0 || divisor <= 0 || op < 0 || op > GR_FMIN) return SPAMD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (n == 0) return (int)hipMemsetAsync(n_groups, 0, sizeof(int64_t), s);
   if (ws_bytes < spamd_group_reduce_ws_bytes(val_dtype, n) || ((uintptr_t)ws % 16) || ((uintptr_t)keys % 16) || ((uintptr_t)data % 16))
