@@ -17,6 +17,7 @@ from ._coo import COO, as_coo
 from ._gcxs import GCXS
 from ._dot import dot, matmul, tensordot
 from ._umath import elemwise
+from ._einsum import einsum
 from ._batched import concatenate, stack
 from ._broadcast import broadcast_to
 from ._io import load_npz, save_npz
@@ -27,7 +28,7 @@ from ._api import (all, any, argwhere, asarray, astype, empty, empty_like, expan
 from ._ffi import HipBackendError
 
 __all__ = ["COO", "GCXS", "SparseArray", "HipBackendError", "all", "any", "argwhere", "as_coo", "asarray", "astype", "broadcast_to",
-           "concatenate", "dot", "elemwise", "empty", "empty_like", "expand_dims", "eye", "full", "full_like", "load_npz", "matmul",
+           "concatenate", "dot", "einsum", "elemwise", "empty", "empty_like", "expand_dims", "eye", "full", "full_like", "load_npz", "matmul",
            "matrix_transpose", "max", "mean", "min", "moveaxis", "nanmax", "nanmean", "nanmin", "nanprod", "nanreduce", "nansum",
            "nonzero", "ones", "ones_like", "permute_dims", "prod", "random", "reshape", "save_npz", "sddmm", "squeeze", "stack", "std",
            "sum", "tensordot", "var", "vecdot", "where", "zeros", "zeros_like"]

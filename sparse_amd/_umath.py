@@ -370,26 +370,48 @@ def elemwise(func, *args, **kwargs):
     if a_sp != b_sp:
         x, d = (a, b) if a_sp else (b, a)
         dt = dev.to_device(d, devi)
+        dense_shape = tuple(dt.shape)
         if tuple(dt.shape) != tuple(shape):
-            from ._broadcast import broadcast_shapes
+            from ._broadcast import broadcast_shapes, broadcast_to
 
-            if broadcast_shapes(tuple(dt.shape), tuple(shape)) != tuple(shape):
-                raise ValueError("Performing a mixed sparse-dense operation that would result in a dense array. "
-                                 "Please make sure that func(sparse_fill_values, ndarrays) is a constant array.")
+            common = broadcast_shapes(tuple(dt.shape), tuple(shape))
+            if common != tuple(shape):   # the sparse side broadcasts too (e.g. einsum's aligned multiply)
+                x = broadcast_to(x, common)
+                shape = common
             dt = dt.broadcast_to(shape).contiguous()  # view + copy: memory plumbing only
-        # the result stays sparse only if func(fill, dense) is constant (reference :525-548)
-        probe_fill = _np_result(func, *((np.asarray(x.fill_value), np.zeros(1, dev.np_dtype(dt.dtype))) if a_sp
-                                        else (np.zeros(1, dev.np_dtype(dt.dtype)), np.asarray(x.fill_value))))
-        fill = np.asarray(probe_fill).reshape(-1)[0].astype(out_np)
+        # the result stays sparse only if func(fill, dense) is constant (reference `_get_fill_value`, :505-555:
+        # the fill value is element 0 of func(fills, dense); "constant" is judged with == or both-NaN, so that
+        # 0 * (-1.5) = -0.0 still counts as the zero fill)
         fvx = dev_scalar(x.fill_value)
         dflat = K.convert(dt.reshape(-1), comp_t)
         allfill = binary_arrays(name, fvx, dflat, a_scalar=True) if a_sp else binary_arrays(name, dflat, fvx, b_scalar=True)
         if allfill.dtype != torch_dtype(out_np):
             allfill = K.convert(allfill, torch_dtype(out_np))
-        nonconst = K.flag_ne_bits(_as_u8(allfill), fill if out_np != np.dtype(bool) else np.uint8(bool(fill)))
-        if int(K.exclusive_scan(nonconst)[-1]) != 0:
-            raise ValueError("Performing a mixed sparse-dense operation that would result in a dense array. "
-                             "Please make sure that func(sparse_fill_values, ndarrays) is a constant array.")
+        if allfill.numel():
+            fill = np.asarray(allfill[:1].cpu().numpy())[0]
+            if out_np == np.dtype(bool):
+                fill = np.bool_(fill)
+            fill_t = allfill[:1].contiguous()
+            differs = binary_arrays("not_equal", _as_u8(allfill) if out_np == np.dtype(bool) else allfill, 
+                                    _as_u8(fill_t) if out_np == np.dtype(bool) else fill_t, b_scalar=True, out_bool_as=torch.uint8)
+            if out_np.kind == "f" and np.isnan(fill):   # NaN == NaN for this purpose
+                differs = unary_array("logical_not", unary_array("isnan", allfill)).view(torch.uint8)
+            nonconst = int(differs.numel()) - K.count_eq_bits(differs, 0)
+        else:
+            probe_fill = _np_result(func, *((np.asarray(x.fill_value), np.zeros(1, dev.np_dtype(dt.dtype))) if a_sp
+                                            else (np.zeros(1, dev.np_dtype(dt.dtype)), np.asarray(x.fill_value))))
+            fill = np.asarray(probe_fill).reshape(-1)[0].astype(out_np)
+            nonconst = 0
+        if nonconst:
+            if tuple(x.shape) != dense_shape:
+                raise ValueError("Performing a mixed sparse-dense operation that would result in a dense array. "
+                                 "Please make sure that func(sparse_fill_values, ndarrays) is a constant array.")
+            # same shapes: the reference densifies the sparse operand and returns the dense result (:463-465)
+            xdense = K.convert(x.todense_device().reshape(-1), comp_t)
+            res = binary_arrays(name, xdense, dflat) if a_sp else binary_arrays(name, dflat, xdense)
+            if res.dtype != torch_dtype(out_np):
+                res = K.convert(res, torch_dtype(out_np))
+            return res.reshape(shape)
         keys = x.linear_loc()
         dvals = K.gather(dflat, keys)
         xd = K.convert(x.data, comp_t)

@@ -72,7 +72,14 @@ def test_exception_parity(sp):
     with pytest.raises(ValueError, match="shapes of a and b are not broadcastable"):
         sp.matmul(sp.random((2, 3, 4), density=0.5, random_state=0), sp.random((3, 4, 5), density=0.5, random_state=1))
     with pytest.raises(ValueError, match="would result in a dense array"):
-        _ = x + np.ones((3, 4))
+        _ = x + np.arange(4.0)          # func(fill, dense) varies and the dense operand is the smaller one
+    r = x + np.ones((3, 4))             # func(fill, dense) is constant: sparse result whose fill value is that constant
+    assert isinstance(r, sp.COO) and r.fill_value == 1.0 and r.nnz == 2 and np.array_equal(r.todense(), x.todense() + 1)
+    d = np.arange(12.0).reshape(3, 4)
+    r = x + d                           # varies, same shape: the reference returns the dense result (_umath.py:463-465)
+    assert not isinstance(r, sp.SparseArray) and np.array_equal(np.asarray(r.cpu()), x.todense() + d)
+    r = x * -np.ones((3, 4))            # 0 * -1 = -0.0 everywhere: still the (signed) zero fill, result stays sparse
+    assert isinstance(r, sp.COO) and r.nnz == 2 and np.signbit(r.fill_value) and np.array_equal(r.todense(), x.todense() * -1.0)
     with pytest.raises(ValueError, match="would produce a dense result"):
         np.subtract.reduce(x + 1, axis=0)
     with pytest.raises(RuntimeError, match="Cannot convert a sparse array to dense automatically"):
@@ -166,7 +173,7 @@ def test_prune_count_first_path(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nnz", [(0, 5), (4096, 4096), (4097, 1), (300_000, 171_873), (171_873, 171_873)])
+@pytest.mark.parametrize("nnz", [(0, 5), (4096, 4096), (4097, 1), (100_000, 171_873), (171_873, 171_873)])
 def test_merge_single_pass_matches_count_scan_fill(monkeypatch, nnz):
     """The elementwise merge exists in two forms (csrc/merge.hip): one pass with look-back offsets (default) and
     count + scan + fill.  Both must give the same canonical result, including full operands (every key shared),
