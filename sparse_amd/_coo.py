@@ -387,7 +387,8 @@ class COO(SparseArray, NDArrayOperatorsMixin):
         return self.reshape(-1)
 
     def __getitem__(self, index):
-        """Only the forms N-D `matmul` needs: `x[(None,) * k]` (new leading axes) and `x[i]`."""
+        """Basic indexing (integers, slices, None, Ellipsis); the two forms N-D `matmul` uses — `x[(None,) * k]` and
+        `x[i]` — have direct paths, everything else goes through `_indexing.getitem`."""
         if isinstance(index, tuple) and all(i is None for i in index):
             k = len(index)
             if k == 0:
@@ -397,11 +398,13 @@ class COO(SparseArray, NDArrayOperatorsMixin):
                       sorted=True, fill_value=self.fill_value)
             out._keys = getattr(self, "_keys", None)
             return out
-        if isinstance(index, (int, np.integer)):
+        if isinstance(index, (int, np.integer)) and self.ndim > 1:
             from ._batched import take_leading
 
-            return take_leading(self, int(index))
-        raise NotImplementedError("general indexing is outside the hip backend's hot path (SURVEY.md §8f N2)")
+            return take_leading(self, int(index))   # contiguous key range: two binary searches, no mask
+        from ._indexing import getitem
+
+        return getitem(self, index)
 
     # ---- format conversion -----------------------------------------------------------------------
     def asformat(self, format, **kwargs):
@@ -415,6 +418,91 @@ class COO(SparseArray, NDArrayOperatorsMixin):
 
             return GCXS.from_coo(self, **kwargs)
         raise NotImplementedError(f"format {format!r} is not available in the hip backend")
+
+    def tocsr(self):
+        """`scipy.sparse.csr_array` of a 2-D array (reference core.py:1200-1251); the row compression runs on the
+        device, only the three result arrays cross to the host."""
+        return self._to_scipy_compressed(0)
+
+    def tocsc(self):
+        """`scipy.sparse.csc_array` (reference core.py:1253-1291)."""
+        return self._to_scipy_compressed(1)
+
+    def _to_scipy_compressed(self, axis):
+        import scipy.sparse
+
+        from ._gcxs import GCXS
+        from ._utils import check_zero_fill_value
+
+        check_zero_fill_value(self)
+        if self.ndim != 2:
+            raise ValueError("This array must be two-dimensional for this conversion to work.")
+        g = GCXS.from_coo(self, compressed_axes=(axis,))
+        arrays = (g.data.cpu().numpy(), g.indices.cpu().numpy(), g.indptr.cpu().numpy())
+        return (scipy.sparse.csr_array if axis == 0 else scipy.sparse.csc_array)(arrays, shape=self.shape)
+
+    @classmethod
+    def from_iter(cls, x, shape=None, fill_value=None, dtype=None, device=None):
+        """COO from `{(i, j, ...): value}`, an iterable of `((i, j, ...), value)` pairs, or `(data, (rows, cols, ...))`
+        (reference `from_iter`, core.py:469-560).  The iterable is a host object; it is packed once and uploaded."""
+        from collections.abc import Sized
+
+        if isinstance(x, dict):
+            x = list(x.items())
+        if not isinstance(x, Sized):
+            x = list(x)
+        if len(x) != 2 and not all(len(item) == 2 for item in x):
+            raise ValueError("Invalid iterable to convert to COO.")
+        if not x:
+            nd = 0 if shape is None else len(shape)
+            coords, data, shape = np.empty((nd, 0), dtype=np.int64), np.empty(0, dtype=dtype), (() if shape is None else shape)
+        elif not isinstance(x[0][0], Iterable):
+            coords, data = np.stack([np.asarray(c) for c in x[1]], axis=0), np.asarray(x[0], dtype=dtype)
+        else:
+            coords, data = np.array([item[0] for item in x]).T, np.array([item[1] for item in x], dtype=dtype)
+        if not (coords.ndim == 2 and data.ndim == 1 and coords.shape[1] == data.shape[0]
+                and np.issubdtype(coords.dtype, np.integer)):
+            raise ValueError("Invalid iterable to convert to COO.")
+        return cls(coords, data, shape=shape, fill_value=fill_value, device=device)
+
+    def broadcast_to(self, shape):
+        from ._broadcast import broadcast_to
+
+        return broadcast_to(self, shape)
+
+    def nonzero(self):
+        """Coordinates of the stored elements, one device array per dimension (reference core.py `nonzero`)."""
+        from ._utils import check_zero_fill_value
+
+        check_zero_fill_value(self)
+        if self.ndim == 0:
+            raise ValueError("`nonzero` is undefined for `self.ndim == 0`.")
+        return tuple(self.coords)
+
+    def swapaxes(self, axis1, axis2):
+        axes = list(range(self.ndim))
+        axes[axis1], axes[axis2] = axes[axis2], axes[axis1]
+        return self.transpose(axes)
+
+    def squeeze(self, axis=None):
+        from ._api import squeeze
+
+        return squeeze(self, axis=axis)
+
+    # pickling: the state is host arrays (a pickle must not depend on the GPU it was written from); loading puts
+    # the array on the current default device (reference core.py:293-298 keeps the same 4-tuple)
+    def __getstate__(self):
+        return (self.coords.cpu().numpy(), self.data.cpu().numpy(), self.shape, self.fill_value)
+
+    def __setstate__(self, state):
+        coords, data, shape, fill_value = state
+        d = dev.default_device()
+        self.data = dev.to_device(data, d)
+        self.__dict__["_coords"] = torch.from_numpy(np.ascontiguousarray(coords)).to(d)
+        self._coords_dtype = self.__dict__["_coords"].dtype
+        self.shape, self.fill_value = tuple(shape), fill_value
+        self._keys = None
+        self._cache = None
 
     def maybe_densify(self, max_size=1000, min_density=0.25):
         if self.size <= max_size or self.density >= min_density:

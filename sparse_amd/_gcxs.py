@@ -88,6 +88,24 @@ class GCXS(SparseArray, NDArrayOperatorsMixin):
                     compressed_axes=self.compressed_axes, fill_value=self.fill_value)
 
     @classmethod
+    def from_iter(cls, x, shape=None, compressed_axes=None, fill_value=None, idx_dtype=None, device=None):
+        """GCXS from the iterable forms `COO.from_iter` accepts (reference compressed.py `from_iter`)."""
+        from ._coo import COO
+
+        return cls.from_coo(COO.from_iter(x, shape, fill_value, device=device), compressed_axes, idx_dtype)
+
+    # pickling: host arrays only, derived layouts (CSR twin, tiled SpMM layout, NaN verdict) are not part of the state
+    def __getstate__(self):
+        return (self.data.cpu().numpy(), self.indices.cpu().numpy(), self.indptr.cpu().numpy(), self.shape,
+                self._compressed_axes, self.fill_value)
+
+    def __setstate__(self, state):
+        data, indices, indptr, shape, compressed_axes, fill_value = state
+        d = dev.default_device()
+        self.data, self.indices, self.indptr = (dev.to_device(a, d) for a in (data, indices, indptr))
+        self.shape, self._compressed_axes, self.fill_value = tuple(shape), compressed_axes, fill_value
+
+    @classmethod
     def from_numpy(cls, x, compressed_axes=None, fill_value=None, idx_dtype=None, device=None):
         from ._coo import COO
 
@@ -288,11 +306,13 @@ class GCXS(SparseArray, NDArrayOperatorsMixin):
         """Only the forms N-D `matmul` needs: `x[(None,) * k]` and `x[i]`."""
         if isinstance(index, tuple) and all(i is None for i in index):
             return self.tocoo()[index].asformat("gcxs") if index else self
-        if isinstance(index, (int, np.integer)):
+        if isinstance(index, (int, np.integer)) and self.ndim > 1:
             from ._batched import take_leading
 
             return take_leading(self, int(index))
-        raise NotImplementedError("general indexing is outside the hip backend's hot path (SURVEY.md §8f N2)")
+        from ._indexing import getitem
+
+        return getitem(self, index)
 
     def dot(self, other):
         from ._dot import dot

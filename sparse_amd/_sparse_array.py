@@ -262,6 +262,12 @@ class SparseArray:
     def __int__(self):
         return self._to_scalar(int)
 
+    def __complex__(self):
+        return self._to_scalar(complex)
+
+    def __index__(self):
+        return self._to_scalar(int)
+
     def _to_scalar(self, builtin):
         if self.size != 1 or self.shape != ():
             raise ValueError(f"{builtin} can be computed for one-element arrays only.")

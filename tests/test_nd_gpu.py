@@ -192,3 +192,93 @@ def test_merge_single_pass_matches_count_scan_fill(monkeypatch, nnz):
         assert r1.nnz == r2.nnz <= x.nnz + y.nnz
         assert torch.equal(r1.linear_loc(), r2.linear_loc()) and torch.equal(r1.data, r2.data)
         assert np.array_equal(r1.todense(), f(x.todense(), y.todense()))
+
+
+@pytest.mark.gpu
+def test_interchange_pickle_scipy_iter():
+    """pickling (host-array state, reference core.py:293-298), scipy CSR/CSC export
+    (core.py:1200-1291), `from_iter` (core.py:469-560), and the small shape helpers."""
+    import pickle
+
+    import scipy.sparse
+
+    import sparse_amd as sp
+
+    x = sp.random((7, 9), density=0.4, random_state=2)
+    g = sp.GCXS.from_coo(x, compressed_axes=(1,))
+    g @ torch.ones((9, 2), device="cuda", dtype=torch.float64)   # populates caches that must not be pickled
+    for a in (x, g, x + 1):
+        b = pickle.loads(pickle.dumps(a))
+        assert type(b) is type(a) and b.shape == a.shape and b.fill_value == a.fill_value and b.nnz == a.nnz
+        assert np.array_equal(b.todense(), a.todense())
+    assert pickle.loads(pickle.dumps(g)).compressed_axes == (1,) and len(pickle.dumps(g)) < 2 * g.nbytes + 2000
+    csr, csc = x.tocsr(), x.tocsc()
+    assert isinstance(csr, scipy.sparse.csr_array) and isinstance(csc, scipy.sparse.csc_array)
+    assert np.array_equal(csr.toarray(), x.todense()) and np.array_equal(csc.toarray(), x.todense())
+    assert csr.has_sorted_indices and csc.has_sorted_indices
+    with pytest.raises(ValueError):
+        sp.random((2, 3, 4), density=0.5, random_state=0).tocsr()
+    with pytest.raises(ValueError):
+        (x + 1).tocsc()
+    want = np.array([[1, 0], [0, 1]])
+    for it in ([((0, 0), 1), ((1, 1), 1)], {(0, 0): 1, (1, 1): 1}, ([1, 1], ([0, 1], [0, 1])), iter([((0, 0), 1), ((1, 1), 1)])):
+        assert np.array_equal(sp.COO.from_iter(it, shape=(2, 2)).todense(), want)
+    assert np.array_equal(sp.GCXS.from_iter({(0, 0): 1, (1, 1): 1}, shape=(2, 2), compressed_axes=(1,)).todense(), want)
+    assert sp.COO.from_iter([], shape=(3, 2)).nnz == 0
+    with pytest.raises(ValueError):
+        sp.COO.from_iter([(1, 2, 3)], shape=(2, 2))
+    d = x.todense()
+    assert np.array_equal(x.swapaxes(0, 1).todense(), d.swapaxes(0, 1))
+    assert np.array_equal(x[None].squeeze().todense(), d) and x.broadcast_to((2, 7, 9)).shape == (2, 7, 9)
+    assert all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(x.nonzero(), d.nonzero()))
+    one = sp.COO.from_numpy(np.array(3))
+    assert complex(one) == 3 + 0j and [10, 20, 30, 40][one] == 40
+
+
+@pytest.mark.gpu
+def test_basic_indexing_matches_numpy():
+    """Integers, slices with any step, None and Ellipsis on COO and GCXS (reference _coo/indexing.py:12-133),
+    checked against NumPy on the dense array over a table of index expressions plus random ones."""
+    import sparse_amd as sp
+
+    rng = np.random.default_rng(21)
+    d = rng.random((6, 7, 8)) * (rng.random((6, 7, 8)) < 0.4)
+    x = sp.COO.from_numpy(d)
+    g = sp.GCXS.from_coo(x, compressed_axes=(0,))
+    s_ = np.s_
+    table = [s_[2], s_[-1], s_[1:4], s_[:, 3], s_[..., 5], s_[1, 2, 3], s_[1, :, 3], s_[::2], s_[::-1], s_[5:1:-2],
+             s_[:, ::3, 1:7:2], s_[None], s_[:, None, 2], s_[..., None], s_[3:3], s_[10:20], s_[-3:], s_[:, -2::-3],
+             s_[1:2, 1:2, 1:2], s_[None, 2, ..., None, 4], s_[()], s_[...], s_[0, ::-1, ::-1]]
+    for _ in range(40):
+        ix = []
+        for n in d.shape:
+            kind = rng.integers(0, 4)
+            if kind == 0:
+                ix.append(int(rng.integers(-n, n)))
+            elif kind == 1:
+                ix.append(slice(*(None if rng.random() < 0.3 else int(v) for v in rng.integers(-n - 1, n + 2, 2)),
+                                int(rng.choice([-3, -2, -1, 1, 2, 3]))))
+            elif kind == 2:
+                ix.append(slice(None))
+            else:
+                ix.extend([None, slice(None)])
+        table.append(tuple(ix))
+    for idx in table:
+        want = d[idx]
+        for arr in (x, g):
+            got = arr[idx]
+            if np.ndim(want) == 0:
+                assert not isinstance(got, sp.SparseArray) and got == want, idx
+            else:
+                assert got.shape == want.shape and np.array_equal(got.todense(), want), idx
+                assert got.nnz == np.count_nonzero(want), idx
+    assert isinstance(g[1:3], sp.GCXS) and isinstance(x[1:3], sp.COO)
+    y = (x + 2)[::2, 1]      # the fill value travels
+    assert y.fill_value == 2 and np.array_equal(y.todense(), (d + 2)[::2, 1])
+    v = sp.COO.from_numpy(np.array([0.0, 1.5, 0.0, 2.5]))
+    assert v[1] == 1.5 and v[2] == 0.0 and v[-1] == 2.5
+    for bad in (s_[6], s_[0, 0, 0, 0], s_[..., ...]):
+        with pytest.raises(IndexError):
+            x[bad]
+    with pytest.raises(NotImplementedError):
+        x[[0, 1]]
