@@ -119,6 +119,63 @@ def stack(arrays, axis=0):
     return out.asformat("gcxs") if all_gcxs else out
 
 
+def block_diagonal_csr(a):
+    """The batch of matrices a[..., M, K] as ONE CSR matrix: block b sits at rows [b*M, (b+1)*M) and columns
+    [b*K, (b+1)*K).  With row = key // K (rows of the stacked (B*M, K) view) the new linear key is
+    row * (B*K) + (row // M) * K + key % K — monotone in the old key, so the canonical order is kept and the
+    CSR arrays follow from one `keys_to_csr` pass."""
+    from ._convert import _pick_index_dtype
+    from ._coo import as_coo
+    from ._gcxs import GCXS
+    from ._umath import binary_arrays
+
+    c = as_coo(a)
+    M, Kd = c.shape[-2], c.shape[-1]
+    B = 1
+    for s in c.shape[:-2]:
+        B *= s
+    keys = c.linear_loc()
+    dev = c.device
+
+    def sc(v):
+        return torch.tensor([v], dtype=torch.int64, device=dev)
+
+    if c.nnz:
+        row = binary_arrays("floor_divide_i64", keys, sc(max(Kd, 1)), b_scalar=True)
+        col = binary_arrays("subtract", keys, binary_arrays("multiply", row, sc(Kd), b_scalar=True))
+        blk = binary_arrays("floor_divide_i64", row, sc(max(M, 1)), b_scalar=True)
+        keys = binary_arrays("add", binary_arrays("multiply", row, sc(B * Kd), b_scalar=True),
+                             binary_arrays("add", binary_arrays("multiply", blk, sc(Kd), b_scalar=True), col))
+    it = _pick_index_dtype(c._index_dtype, max(B * M, B * Kd, c.nnz))
+    indptr, indices = K.keys_to_csr(keys, B * M, B * Kd, it)
+    return GCXS((c.data, indices, indptr), shape=(B * M, B * Kd), compressed_axes=(0,), fill_value=c.fill_value)
+
+
+def matmul_blockdiag(a, b):
+    """Batched `a @ b` for a sparse `a[..., M, K]` and `b[..., K, N]` with the SAME leading axes, as a single 2-D
+    product: blockdiag(a) (B*M x B*K) times b stacked to (B*K, N).  One kernel launch sequence for the whole batch
+    (SpMM for a dense b, SpGEMM for a sparse b) instead of the reference's Python loop over slices
+    (`_matmul_recurser`, _common.py:278-293); every output row still accumulates its own block in k order."""
+    from ._dot import dot
+    from ._sparse_array import SparseArray
+
+    lead = tuple(a.shape[:-2])
+    M, Kd, N = a.shape[-2], a.shape[-1], b.shape[-1]
+    B = 1
+    for s in lead:
+        B *= s
+    big = block_diagonal_csr(a)
+    if isinstance(b, SparseArray):
+        res = dot(big, b.reshape((B * Kd, N)))
+        res = res.reshape(lead + (M, N))
+        from ._gcxs import GCXS
+
+        return res if isinstance(a, GCXS) and isinstance(b, GCXS) else res.asformat("coo")
+    bt = b if isinstance(b, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(b)).to(a.device)
+    res = dot(big, bt.reshape(B * Kd, N))
+    return res.reshape(lead + (M, N))
+
+
 def matmul_batched(a, b):
     """`_matmul_recurser` (reference _common.py:278-293): loop over the broadcast leading axis,
     2-D `dot` per slice, stack the results."""

@@ -203,8 +203,10 @@ def matmul(a, b):
     for i, j in zip(a.shape[:-2], b.shape[:-2]):
         if i != 1 and j != 1 and i != j:
             raise ValueError("shapes of a and b are not broadcastable")
-    from ._batched import matmul_batched
+    from ._batched import matmul_batched, matmul_blockdiag
 
+    if isinstance(a, SparseArray) and tuple(a.shape[:-2]) == tuple(b.shape[:-2]) and prod(a.shape[:-2]) > 0:
+        return matmul_blockdiag(a, b)   # the whole batch as one block-diagonal product
     return matmul_batched(a, b)
 
 

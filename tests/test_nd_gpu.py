@@ -282,3 +282,34 @@ def test_basic_indexing_matches_numpy():
             x[bad]
     with pytest.raises(NotImplementedError):
         x[[0, 1]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lead", [(5,), (2, 3), (1,), (4, 1)])
+def test_batched_matmul_is_one_block_diagonal_product(lead):
+    """`a @ b` with equal leading axes runs as blockdiag(a) @ stacked(b) (sparse_amd/_batched.py): same values as
+    the per-slice loop of the reference's `_matmul_recurser` (_common.py:278-293) and as NumPy on dense arrays."""
+    import sparse_amd as sp
+    from sparse_amd._batched import block_diagonal_csr, matmul_batched
+
+    rng = np.random.default_rng(31)
+    M, Kd, N = 37, 29, 16
+    da = rng.random(lead + (M, Kd)) * (rng.random(lead + (M, Kd)) < 0.2)
+    db = rng.random(lead + (Kd, N))
+    dbs = db * (rng.random(db.shape) < 0.3)
+    a = sp.COO.from_numpy(da)
+    big = block_diagonal_csr(a)
+    B = int(np.prod(lead))
+    want_big = np.zeros((B * M, B * Kd))
+    for i, blk in enumerate(da.reshape(B, M, Kd)):
+        want_big[i * M:(i + 1) * M, i * Kd:(i + 1) * Kd] = blk
+    assert big.shape == (B * M, B * Kd) and np.array_equal(big.todense(), want_big)
+    r = a @ torch.from_numpy(db).cuda()
+    assert tuple(r.shape) == lead + (M, N) and np.allclose(r.cpu().numpy(), da @ db, rtol=1e-13, atol=1e-15)
+    loop = matmul_batched(a, torch.from_numpy(db).cuda())
+    assert torch.equal(r, loop)                          # same accumulation order as slice-by-slice
+    rs = a @ sp.COO.from_numpy(dbs)
+    assert isinstance(rs, sp.COO) and np.allclose(rs.todense(), da @ dbs, rtol=1e-13, atol=1e-15)
+    rg = sp.GCXS.from_coo(a) @ sp.GCXS.from_coo(sp.COO.from_numpy(dbs))
+    assert isinstance(rg, sp.GCXS) and np.allclose(rg.todense(), da @ dbs, rtol=1e-13, atol=1e-15)
+    assert np.allclose((a @ db).cpu().numpy() if isinstance(a @ db, torch.Tensor) else (a @ db), da @ db, rtol=1e-13)
