@@ -226,7 +226,7 @@ __device__ __forceinline__ void tl_phases(const int* stream, int t0, int te, int
   : [blo] "s"(blo), [bhi] "s"(bhi), [t0] "s"(t0), [te] "s"(te), [o0] "s"(o0), [o1] "s"(o1), [o2] "s"(o2),         \
     [obase] "s"(obase), [ntiles] "s"(ntiles), [nfull] "s"(nfull), [m0wave] "s"(m0wave), [step] "s"(row_step),      \
     [lane] "v"(lane), [lane8] "v"(lane8), [mask] "v"(mask), [offreg] "v"(offreg)                                  \
-  : "memory", "m0", "scc", TL_CLOB_SGPR, TL_CLOB_TMP, TL_CLOB_ACC
+  : "memory", "m0", "scc", "vcc", TL_CLOB_SGPR, TL_CLOB_TMP, TL_CLOB_ACC
   if (MODE == 4)
     asm volatile(TL_ASM_PHASES_F64 : TL_PHASES_OPERANDS);
   else if (MODE == 5)
@@ -288,7 +288,7 @@ spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, const int* __restrict__ stre
   const bool has_partial = DBG != 2 && (int64_t)nfull * TL_KB < K;  // tile `nfull` is the partial one
 
   if (nfull > 0)
-    asm volatile(TL_ASM_TILE0 ::[m0wave] "s"(m0wave), [step] "s"(row_step) : "memory", "m0", "scc", "s39", "s89", "v22", "v23");
+    asm volatile(TL_ASM_TILE0 ::[m0wave] "s"(m0wave), [step] "s"(row_step) : "memory", "m0", "scc", "vcc", "s89", "v22", "v23");
   else if (has_partial)
     issue_partial(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -12,7 +12,8 @@ Register map (must match spmm_tiled.hip):
     v60        LDS base of the current tile + 8*lane    v61  destination of the line touches
     (v60..v61  store address after the loop)     v62..v63  junk accumulator (padding entries)
     v64..v127  32 rows x (2 columns per lane) partial sums
-    s36..s39   stream pointer / block and DMA counters   s40..s87  three 8-entry blocks (16 dwords each)
+    s36..s38   stream pointer / block counter (s39 free; pending DMA instructions: VCC as a mask of ones)
+    s40..s87   three 8-entry blocks (16 dwords each)
     s88..s89   temporary / LDS destination of the next tile-DMA instruction
     s90..s95   tile counter, first blocks of lists t, t+1, t+2, 64-bit temporary
 """
@@ -90,18 +91,21 @@ def p2_exact(buf, dset):
     return o
 
 
-def dma_hook(site):
-    """Issue one more tile-DMA instruction of the NEXT tile if any are left (s39), from the walking source
-    pointer v[22:23] (advanced by 32 B rows) to LDS address s89 (advanced by 16 KB)."""
-    return ["s_cmp_eq_u32 s39, 0",
-            f"s_cbranch_scc1 {60 + site}f",
-            "s_mov_b32 m0, s89",
-            "s_nop 0",
-            "global_load_lds_dwordx4 v[22:23], off",
+def dma_body():
+    """one tile-DMA instruction of the NEXT tile: from the walking source pointer v[22:23] (advanced by 32 B rows)
+    to LDS address s89 (advanced by 16 KB; the s_add also is the wait state M0 needs before an LDS-DMA), and one
+    bit less in the pending mask (VCC)"""
+    return ["s_mov_b32 m0, s89",
             "s_add_u32 s89, s89, 0x4000",
+            "global_load_lds_dwordx4 v[22:23], off",
             "v_lshl_add_u64 v[22:23], %[step], 0, v[22:23]",
-            "s_sub_u32 s39, s39, 1",
-            f"{60 + site}:"]
+            "s_lshr_b64 vcc, vcc, 1"]
+
+
+def dma_hook():
+    """Issue one more tile-DMA instruction if any are left.  The pending count lives in VCC as a mask of ones so
+    that the test is a single s_cbranch_vccz (SCC is clobbered when an instruction is issued)."""
+    return ["s_cbranch_vccz 6f"] + dma_body() + ["6:"]
 
 
 def list_loop(lds=True, fma=True, exact=False):
@@ -109,99 +113,118 @@ def list_loop(lds=True, fma=True, exact=False):
     of block r+1 are already being read from LDS (P1) and block r+3 is being fetched by a scalar load.
     Entry: s[36:37] = list pointer, s38 = blocks in the list (> 0), the first min(3, s38) blocks are in
     (or on their way into) the SGPR ring.  Unrolled x6 = lcm(3 SGPR buffers, 2 VGPR data sets).  The wave's
-    share of the NEXT tile's LDS-DMA (s39 instructions) is spread over the rounds (one at the start, one
-    after each round; the caller issues the rest) instead of one burst that would stall all 16 waves on
-    the 64 B/clk address path."""
-    A, B, C = RING
+    share of the NEXT tile's LDS-DMA is spread over the rounds (one at the start, one after each block; the
+    caller issues the rest) instead of one burst that would stall all 16 waves on the 64 B/clk address path.
+    The last three blocks of a list leave the loop for a straight-line tail (one per loop position, out of
+    line): lists are short (~5 blocks), so per-block loop bookkeeping is a large share of the issue slots."""
     P1 = p1 if lds else (lambda buf, dset: [])
     P2 = (p2_exact if exact else p2) if fma else (lambda buf, dset: [])
-    o = dma_hook(0)
+    o = dma_hook()
     o += ["s_waitcnt lgkmcnt(0)"]
-    o += P1(A, 0)
+    o += P1(RING[0], 0)
     o += ["s_waitcnt lgkmcnt(0)", "11:"]
     for k in range(6):
         cur, nxt = RING[k % 3], RING[(k + 1) % 3]
         dc, dn = k % 2, (k + 1) % 2
         off = (k + 3) * 64
-        # fast path: at least 4 blocks left -> block r+1 exists and block r+3 is fetched
+        # at least 4 blocks left -> block r+1 exists and block r+3 is fetched
         o += ["s_cmp_lt_u32 s38, 4", f"s_cbranch_scc1 3{k}f"]
         o += P1(nxt, dn) + P2(cur, dc)
         o += ["s_waitcnt lgkmcnt(0)", f"s_load_dwordx16 s[{cur}:{cur + 15}], s[36:37], {hex(off)}"]
-        o += dma_hook(1 + 2 * k)
-        o += ["s_sub_u32 s38, s38, 1", f"s_branch 4{k}f"]
-        # slow path: the last three blocks of the list
-        o += [f"3{k}:", "s_cmp_lt_u32 s38, 2", f"s_cbranch_scc1 5{k}f"]
-        o += P1(nxt, dn)
-        o += [f"5{k}:"] + P2(cur, dc)
-        o += ["s_waitcnt lgkmcnt(0)"]
-        o += dma_hook(2 + 2 * k)
-        o += ["s_sub_u32 s38, s38, 1", "s_cmp_eq_u32 s38, 0", "s_cbranch_scc1 12f", f"4{k}:"]
+        o += dma_hook()
+        o += ["s_sub_u32 s38, s38, 1"]
     o += ["s_add_u32 s36, s36, 0x180", "s_addc_u32 s37, s37, 0", "s_branch 11b"]
+    for k in range(6):   # tails: s38 in 1..3 blocks left, the ring holds all of them
+        cur, nxt, nx2 = RING[k % 3], RING[(k + 1) % 3], RING[(k + 2) % 3]
+        dc, dn = k % 2, (k + 1) % 2
+        o += [f"3{k}:", "s_cmp_lt_u32 s38, 2", "s_cbranch_scc1 7f"]
+        o += P1(nxt, dn)
+        o += ["7:"] + P2(cur, dc) + ["s_waitcnt lgkmcnt(0)"] + dma_hook()
+        o += ["s_cmp_lt_u32 s38, 2", "s_cbranch_scc1 12f", "s_cmp_lt_u32 s38, 3", "s_cbranch_scc1 7f"]
+        o += P1(nx2, dc)
+        o += ["7:"] + P2(nxt, dn) + ["s_waitcnt lgkmcnt(0)"] + dma_hook()
+        o += ["s_cmp_lt_u32 s38, 3", "s_cbranch_scc1 12f"]
+        o += P2(nx2, dc) + dma_hook()
+        if k != 5:
+            o += ["s_branch 12f"]
     return o
 
 
 def list_pointer(first_block_sgpr):
     """s[36:37] = stream base + 64 * first block"""
-    return [f"s_mov_b32 s94, s{first_block_sgpr}", "s_mov_b32 s95, 0", "s_lshl_b64 s[94:95], s[94:95], 6",
-            "s_add_u32 s36, s94, %[blo]", "s_addc_u32 s37, s95, %[bhi]"]
+    f = first_block_sgpr
+    return [f"s_lshl_b32 s36, s{f}, 6", f"s_lshr_b32 s37, s{f}, 26",
+            "s_add_u32 s36, s36, %[blo]", "s_addc_u32 s37, s37, %[bhi]"]
 
 
-def request_first_blocks(lo, hi, tag):
-    """scalar loads of the first min(3, s{hi} - s{lo}) blocks of a list into ring buffers A, B, C (no wait)"""
+def request_first_blocks(lo, hi, done, slow):
+    """scalar loads of the first min(3, s{hi} - s{lo}) blocks of a list into ring buffers A, B, C (no wait);
+    lists shorter than three blocks go through the stub `request_stub`"""
     A, B, C = RING
     return list_pointer(lo) + [
         f"s_sub_u32 s88, s{hi}, s{lo}",
-        "s_cmp_eq_u32 s88, 0", f"s_cbranch_scc1 {tag}f",
+        "s_cmp_lt_u32 s88, 3", f"s_cbranch_scc1 {slow}f",
         f"s_load_dwordx16 s[{A}:{A + 15}], s[36:37], 0x0",
-        "s_cmp_lt_u32 s88, 2", f"s_cbranch_scc1 {tag}f",
         f"s_load_dwordx16 s[{B}:{B + 15}], s[36:37], 0x40",
-        "s_cmp_lt_u32 s88, 3", f"s_cbranch_scc1 {tag}f",
         f"s_load_dwordx16 s[{C}:{C + 15}], s[36:37], 0x80",
-        f"{tag}:"]
+        f"{done}:"]
+
+
+def request_stub(done, slow):
+    A, B, C = RING
+    return [f"{slow}:",
+            "s_cmp_eq_u32 s88, 0", f"s_cbranch_scc1 {done}b",
+            f"s_load_dwordx16 s[{A}:{A + 15}], s[36:37], 0x0",
+            "s_cmp_lt_u32 s88, 2", f"s_cbranch_scc1 {done}b",
+            f"s_load_dwordx16 s[{B}:{B + 15}], s[36:37], 0x40",
+            f"s_branch {done}b"]
 
 
 def phases(lds=True, fma=True, exact=False):
     """Tile phases t0 .. te-1 of one wave in ONE asm block, so that SGPR state survives the barrier:
     the first blocks of list t+1 are requested BEFORE the barrier that ends phase t (the scalar path serves
     one 64-byte request per ~20 cycles per CU; 16 waves x 3 requests right after a barrier idle the CU for
-    ~1000 cycles).  s90 = t, s91/s92/s93 = first block of lists t, t+1, t+2."""
-    o = ["s_mov_b32 s90, %[t0]", "s_mov_b32 s91, %[o0]", "s_mov_b32 s92, %[o1]", "s_mov_b32 s93, %[o2]"]
-    o += request_first_blocks(91, 92, 20)
-    o += ["1:"]
-    o += list_pointer(91)
-    o += ["s_sub_u32 s38, s92, s91",                       # blocks in this list
-          "s_add_u32 s88, s90, 1",                         # next tile: DMA share and LDS destination
-          "s_cmp_lt_u32 s88, %[nfull]", "s_cselect_b32 s39, 4, 0",
-          "s_and_b32 s88, s88, 1", "s_lshl_b32 s88, s88, 16", "s_add_u32 s89, s88, %[m0wave]",
-          "s_and_b32 s88, s90, 1", "s_lshl_b32 s88, s88, 16", "v_or_b32 v60, s88, %[lane8]",  # this tile's LDS base
+    ~1000 cycles).  s90 = t, s91/s92/s93 = first block of lists t, t+1, t+2; s[36:37] = pointer of list t on
+    entry to a phase (left there by the request of its first blocks).  v60 (LDS base of the tile being read)
+    and s89 (LDS destination of the tile being loaded) toggle between the two buffers once per phase."""
+    o = ["s_mov_b32 s90, %[t0]", "s_mov_b32 s91, %[o0]", "s_mov_b32 s92, %[o1]", "s_mov_b32 s93, %[o2]",
+         "s_add_u32 s88, s90, 1", "s_and_b32 s88, s88, 1", "s_lshl_b32 s88, s88, 16", "s_add_u32 s89, s88, %[m0wave]",
+         "s_and_b32 s88, s90, 1", "s_lshl_b32 s88, s88, 16", "v_or_b32 v60, s88, %[lane8]"]
+    o += request_first_blocks(91, 92, 20, 22)
+    o += ["1:",
+          "s_sub_u32 s38, s92, s91",                       # blocks in this list
+          "s_add_u32 s88, s90, 1",                         # next tile: four DMA instructions if it is a full one
+          "s_cmp_lt_u32 s88, %[nfull]", "s_cselect_b64 vcc, 15, 0",
+          "s_and_b32 s89, s89, 0x1ffff",                   # buffer 1 + 64 KB wraps to buffer 0
           "s_cmp_eq_u32 s38, 0", "s_cbranch_scc1 12f"]
     o += list_loop(lds, fma, exact)
-    o += ["12:", "13:"] + dma_hook(13)[:-1] + ["s_branch 13b", "73:"]   # the rest of the DMA share
+    o += ["12:", "13:", "s_cbranch_vccz 14f"] + dma_body() + ["s_branch 13b", "14:"]   # the rest of the DMA share
     # first blocks of the next list (not at the end of the chunk: the ring must be idle when the asm ends)
     o += ["s_add_u32 s88, s90, 1", "s_cmp_lt_u32 s88, %[te]", "s_cbranch_scc0 21f"]
-    o += request_first_blocks(92, 93, 21)
-    # o3 = first block of list t+3 (lane min(t+3, ntiles) - obase of the offsets register)
-    o += ["s_add_u32 s88, s90, 3", "s_min_u32 s88, s88, %[ntiles]", "s_sub_u32 s88, s88, %[obase]", "s_nop 3",
-          "v_readlane_b32 s88, %[offreg], s88", "s_nop 3"]
+    o += request_first_blocks(92, 93, 21, 23)
+    # o3 = first block of list t+3 (lane min(t+3, ntiles) - obase of the offsets register); the SALU -> v_readlane
+    # lane-select hazard (4 wait states) is covered by the address arithmetic of the line touch
+    o += ["s_add_u32 s38, s90, 3", "s_min_u32 s38, s38, %[ntiles]", "s_sub_u32 s38, s38, %[obase]",
+          "s_lshl_b32 s94, s93, 6", "s_lshr_b32 s95, s93, 26", "s_add_u32 s94, s94, %[blo]", "s_addc_u32 s95, s95, %[bhi]",
+          "v_readlane_b32 s88, %[offreg], s38",
+          "s_mov_b32 s91, s92", "s_mov_b32 s92, s93",
+          "v_xor_b32 v60, 0x10000, v60"]
     # touch the lines of list t+2 = blocks [s93, s88): lane i -> line min(i, n-1)  (always ONE instruction)
-    o += ["s_sub_i32 s94, s88, s93", "s_sub_i32 s94, s94, 1", "s_max_i32 s94, s94, 0",
-          "v_min_u32 v42, s94, %[lane]", "v_lshlrev_b32 v42, 6, v42", "v_mov_b32 v43, 0",
-          "s_mov_b32 s94, s93", "s_mov_b32 s95, 0", "s_lshl_b64 s[94:95], s[94:95], 6",
-          "s_add_u32 s94, s94, %[blo]", "s_addc_u32 s95, s95, %[bhi]",
-          "v_lshl_add_u64 v[40:41], s[94:95], 0, v[42:43]",
-          "global_load_dword v61, v[40:41], off"]
-    o += ["s_mov_b32 s91, s92", "s_mov_b32 s92, s93", "s_mov_b32 s93, s88",
+    o += ["s_sub_i32 s38, s88, s93", "s_sub_i32 s38, s38, 1", "s_max_i32 s38, s38, 0",
+          "v_min_u32 v42, s38, %[lane]", "v_lshlrev_b32 v42, 6, v42",
+          "global_load_dword v61, v42, s[94:95]"]
+    o += ["s_mov_b32 s93, s88",
           "s_waitcnt vmcnt(1)",      # tile t+1 (this wave's share) has landed; the touch may still fly
           "s_barrier",
           "s_add_u32 s90, s90, 1", "s_cmp_lt_u32 s90, %[te]", "s_cbranch_scc1 1b",
-          "s_waitcnt lgkmcnt(0)"]
+          "s_waitcnt lgkmcnt(0)", "s_branch 29f"]
+    o += request_stub(20, 22) + request_stub(21, 23) + ["29:"]
     return o
 
 
 def tile0():
     """the wave's four DMA instructions of tile 0 (buffer 0), advancing the walking pointer"""
-    o = ["s_mov_b32 s89, %[m0wave]", "s_mov_b32 s39, 4"]
-    return o + ["13:"] + dma_hook(13)[:-1] + ["s_branch 13b", "73:"]
+    return ["s_mov_b32 s89, %[m0wave]", "s_mov_b64 vcc, 15", "13:", "s_cbranch_vccz 14f"] + dma_body() + ["s_branch 13b", "14:"]
 
 
 def store():
