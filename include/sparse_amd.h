@@ -90,7 +90,8 @@ int spamd_spmm_csr(int val_dtype, int idx_dtype, int64_t M, int64_t K, int64_t N
  *   with scalar loads and keeps 32 rows of partial sums in a fixed VGPR block addressed with s_set_gpr_idx.
  *   RG / KB / GPB / entries per block / slack / panel width from spamd_spmm_tiled_params(val_dtype);
  *   `blocks` must hold total_blocks + slack blocks and be 64-byte aligned.
- *   flags: SPAMD_EXACT_MULADD as for spamd_spmm_csr.  Results are bit-identical to spamd_spmm_csr with the
+ *   flags: SPAMD_EXACT_MULADD as for spamd_spmm_csr; bits 8..15 (optional tuning hint, 0 = default): 64-byte lines of
+ *   each list to prefetch into L2 two tile phases ahead (~1.5 x the mean blocks per list).  Results are bit-identical to spamd_spmm_csr with the
  *   same flags (sorted column indices), hence to the reference loop under SPAMD_EXACT_MULADD.
  * ------------------------------------------------------------------------------------- */
 int spamd_spmm_tiled_params(int val_dtype, int* rows_per_group, int* tile_rows, int* groups_per_block,

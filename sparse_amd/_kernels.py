@@ -732,6 +732,9 @@ def dot_csr_ndarray_tiled(layout, out_shape, Kd, b, out=None, exact=False):
     b = b.contiguous()
     if out is None:
         out = torch.empty((M, N), dtype=dtype, device=dev)
+    # prefetch hint: ~1.5 x the mean number of 64-byte blocks per (row group, tile) list
+    lists = max(int(blk_off.numel()) - 1, 1)
+    hint = min(64, max(6, int(1.5 * (int(blocks.numel()) // 16) / lists) + 3))
     _ffi.call("spamd_spmm_tiled", code_of(dtype), M, Kd, N, ptr(blocks), ptr(blk_off), ptr(b), N, ptr(out), N,
-              _ffi.EXACT_MULADD if exact else 0, stream_ptr(dev))
+              (_ffi.EXACT_MULADD if exact else 0) | (hint << 8), stream_ptr(dev))
     return out

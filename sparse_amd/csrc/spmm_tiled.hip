@@ -218,14 +218,15 @@ __device__ __forceinline__ void tl_dma16(unsigned lds_base, const void* src) {
 // for float64 (5-entry blocks, one column per lane); 1 no fma, 2 no LDS reads / fma (timing ablations).
 template <int MODE>
 __device__ __forceinline__ void tl_phases(const int* stream, int t0, int te, int o0, int o1, int o2, int offreg, int obase,
-                                          int ntiles, int nfull, int lane, int mask, unsigned m0wave,
+                                          int ntiles, int nfull, int toff, int mask, unsigned m0wave,
                                           int64_t row_step) {
+  const int lane = threadIdx.x & 63;
   const unsigned blo = (unsigned)((uintptr_t)stream & 0xffffffffu), bhi = (unsigned)((uintptr_t)stream >> 32);
   const int lane8 = lane * 8;
 #define TL_PHASES_OPERANDS                                                                                        \
   : [blo] "s"(blo), [bhi] "s"(bhi), [t0] "s"(t0), [te] "s"(te), [o0] "s"(o0), [o1] "s"(o1), [o2] "s"(o2),         \
     [obase] "s"(obase), [ntiles] "s"(ntiles), [nfull] "s"(nfull), [m0wave] "s"(m0wave), [step] "s"(row_step),      \
-    [lane] "v"(lane), [lane8] "v"(lane8), [mask] "v"(mask), [offreg] "v"(offreg)                                  \
+    [toff] "v"(toff), [lane8] "v"(lane8), [mask] "v"(mask), [offreg] "v"(offreg)                                  \
   : "memory", "m0", "scc", "vcc", TL_CLOB_SGPR, TL_CLOB_TMP, TL_CLOB_ACC
   if (MODE == 4)
     asm volatile(TL_ASM_PHASES_F64 : TL_PHASES_OPERANDS);
@@ -245,7 +246,7 @@ __device__ __forceinline__ void tl_phases(const int* stream, int t0, int te, int
 // DBG (timing ablation): 2 = no tile DMA.  MODE: see tl_phases.
 template <int DBG, int MODE, typename T>
 __global__ void __launch_bounds__(TL_WAVES * 64) __attribute__((amdgpu_num_vgpr(22)))
-spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, const int* __restrict__ stream,
+spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, int touch_lines, const int* __restrict__ stream,
                   const int* __restrict__ blk_off, const T* __restrict__ b, int64_t ldb,
                   T* __restrict__ out, int64_t ldo) {
   constexpr int PANEL = TlFmt<T>::PANEL;            // columns per workgroup: 512 bytes of every B row
@@ -307,6 +308,7 @@ spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, const int* __restrict__ stre
   // 9 % SLOWER: the scalar memory path takes ~20 cycles per 64-byte request and ~5 per dword request per
   // CU whether it hits or not (tools/micro/smem_lat.hip), so extra requests cost more than the latency they save.)
   const int* const myoff = blk_off + g * (int64_t)ntiles;
+  const int toff = (lane < touch_lines ? lane : touch_lines - 1) * 64;  // byte offset of the line this lane touches
   int t = 0;
   while (t < ntiles) {
     const int obase = t;
@@ -323,7 +325,7 @@ spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, const int* __restrict__ stre
       asm volatile("global_load_dword v61, %0, off" ::"v"(reinterpret_cast<const char*>(stream + (int64_t)o0 * 16) + l * 64)
                    : "memory", "v61");
     }
-    tl_phases<MODE>(stream, t, te, o0, o1, o2, offreg, obase, ntiles, nfull, lane, (int)0xfffffe00, m0wave, row_step);
+    tl_phases<MODE>(stream, t, te, o0, o1, o2, offreg, obase, ntiles, nfull, toff, (int)0xfffffe00, m0wave, row_step);
     t = te;
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -466,12 +468,12 @@ extern "C" int spamd_spmm_tiled_fill(int val_dtype, int idx_dtype, int64_t M, in
 
 template <typename T, typename KERN>
 static int tl_launch(KERN kern, int64_t M, int64_t K, int64_t N, const int* blocks, const int* blk_off, const T* b,
-                     int64_t ldb, T* out, int64_t ldo, hipStream_t s) {
+                     int64_t ldb, T* out, int64_t ldo, int touch_lines, hipStream_t s) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS);
   if (e != hipSuccess) return (int)e;
   const int64_t blocks_n = tl_grid_groups(M) / TL_WAVES;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks_n, (unsigned)(N / TlFmt<T>::PANEL)), dim3(TL_WAVES * 64), TL_LDS, s, M, K,
-                     (int)ceil_div(K, (int64_t)TL_KB), blocks, blk_off, b, ldb, out, ldo);
+                     (int)ceil_div(K, (int64_t)TL_KB), touch_lines, blocks, blk_off, b, ldb, out, ldo);
   return launch_status();
 }
 
@@ -486,20 +488,25 @@ extern "C" int spamd_spmm_tiled(int val_dtype, int64_t M, int64_t K, int64_t N, 
     return SPAMD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const bool exact = (flags & SPAMD_EXACT_MULADD) != 0;
+  // lines of a list that are pulled into L2 two phases ahead (flags bits 8..15; 0 = default): the launcher derives
+  // it from the mean list length, longer lists pay the HBM latency on their remaining blocks
+  int touch = (int)((flags >> 8) & 0xffu);
+  if (touch == 0) touch = 12;
+  if (touch > 64) touch = 64;
   if (val_dtype == SPAMD_F64) {
     const double* bb = (const double*)b;
     double* oo = (double*)out;
-    return exact ? tl_launch<double>(&spmm_tiled_kernel<0, 5, double>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, s)
-                 : tl_launch<double>(&spmm_tiled_kernel<0, 4, double>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, s);
+    return exact ? tl_launch<double>(&spmm_tiled_kernel<0, 5, double>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, s)
+                 : tl_launch<double>(&spmm_tiled_kernel<0, 4, double>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, s);
   }
   const float* bb = (const float*)b;
   float* oo = (float*)out;
   const char* dbg_env = getenv("SPAMD_TILED_DBG");  // timing ablations: 2 = no tile DMA, 5 = no fma, 6 = no LDS reads/fma
   const int dbg = dbg_env ? atoi(dbg_env) : 0;
-  if (dbg == 2) return tl_launch<float>(&spmm_tiled_kernel<2, 0, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, s);
-  if (dbg == 5) return tl_launch<float>(&spmm_tiled_kernel<0, 1, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, s);
-  if (dbg == 6) return tl_launch<float>(&spmm_tiled_kernel<0, 2, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, s);
-  if (dbg == 7) return tl_launch<float>(&spmm_tiled_kernel<2, 2, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, s);
-  return exact ? tl_launch<float>(&spmm_tiled_kernel<0, 3, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, s)
-               : tl_launch<float>(&spmm_tiled_kernel<0, 0, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, s);
+  if (dbg == 2) return tl_launch<float>(&spmm_tiled_kernel<2, 0, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, s);
+  if (dbg == 5) return tl_launch<float>(&spmm_tiled_kernel<0, 1, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, s);
+  if (dbg == 6) return tl_launch<float>(&spmm_tiled_kernel<0, 2, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, s);
+  if (dbg == 7) return tl_launch<float>(&spmm_tiled_kernel<2, 2, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, s);
+  return exact ? tl_launch<float>(&spmm_tiled_kernel<0, 3, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, s)
+               : tl_launch<float>(&spmm_tiled_kernel<0, 0, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, s);
 }

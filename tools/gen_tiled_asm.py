@@ -40,14 +40,19 @@ def val_pair(buf, i):
     return (buf + 6 + 2 * i, buf + 7 + 2 * i) if F64 else (buf + 2 * i, buf + 2 * i + 1)
 
 
+P1_GROUP = int(os.environ.get("TL_P1_GROUP", "4"))   # address computations issued back to back before their LDS reads
+
+
 def p1(buf, dset):
     """addresses + LDS reads of the block held in SGPR buffer `buf` into VGPR data set `dset`"""
     o = []
-    for i in range(ENTRIES):
-        a = ADDR[i % len(ADDR)]
-        d = DATASET[dset] + 2 * i
-        o.append(f"v_and_or_b32 v{a}, s{d0_reg(buf, i)}, %[mask], v60")
-        o.append(f"ds_read_b64 v[{d}:{d + 1}], v{a}")
+    for g0 in range(0, ENTRIES, P1_GROUP):
+        grp = range(g0, min(g0 + P1_GROUP, ENTRIES))
+        for i in grp:
+            o.append(f"v_and_or_b32 v{ADDR[i % len(ADDR)]}, s{d0_reg(buf, i)}, %[mask], v60")
+        for i in grp:
+            d = DATASET[dset] + 2 * i
+            o.append(f"ds_read_b64 v[{d}:{d + 1}], v{ADDR[i % len(ADDR)]}")
     return o
 
 
@@ -122,31 +127,36 @@ def list_loop(lds=True, fma=True, exact=False):
     o = dma_hook()
     o += ["s_waitcnt lgkmcnt(0)"]
     o += P1(RING[0], 0)
-    o += ["s_waitcnt lgkmcnt(0)", "11:"]
+    o += ["s_waitcnt lgkmcnt(0)",
+          "s_cmp_lt_u32 s38, 4", "s_cbranch_scc1 40f",      # short list: the checked tail
+          "s_sub_u32 s38, s38, 3",                           # s38 = blocks the loop may take before three are left
+          "11:"]
     for k in range(6):
         cur, nxt = RING[k % 3], RING[(k + 1) % 3]
         dc, dn = k % 2, (k + 1) % 2
         off = (k + 3) * 64
-        # at least 4 blocks left -> block r+1 exists and block r+3 is fetched
-        o += ["s_cmp_lt_u32 s38, 4", f"s_cbranch_scc1 3{k}f"]
+        # more than three blocks left -> block r+1 exists and block r+3 is fetched
+        o += ["s_sub_u32 s38, s38, 1", f"s_cbranch_scc1 3{k}f"]
         o += P1(nxt, dn) + P2(cur, dc)
         o += ["s_waitcnt lgkmcnt(0)", f"s_load_dwordx16 s[{cur}:{cur + 15}], s[36:37], {hex(off)}"]
         o += dma_hook()
-        o += ["s_sub_u32 s38, s38, 1"]
     o += ["s_add_u32 s36, s36, 0x180", "s_addc_u32 s37, s37, 0", "s_branch 11b"]
-    for k in range(6):   # tails: s38 in 1..3 blocks left, the ring holds all of them
+    for k in range(6):   # exactly three blocks left, all in the ring: straight line
         cur, nxt, nx2 = RING[k % 3], RING[(k + 1) % 3], RING[(k + 2) % 3]
         dc, dn = k % 2, (k + 1) % 2
-        o += [f"3{k}:", "s_cmp_lt_u32 s38, 2", "s_cbranch_scc1 7f"]
-        o += P1(nxt, dn)
-        o += ["7:"] + P2(cur, dc) + ["s_waitcnt lgkmcnt(0)"] + dma_hook()
-        o += ["s_cmp_lt_u32 s38, 2", "s_cbranch_scc1 12f", "s_cmp_lt_u32 s38, 3", "s_cbranch_scc1 7f"]
-        o += P1(nx2, dc)
-        o += ["7:"] + P2(nxt, dn) + ["s_waitcnt lgkmcnt(0)"] + dma_hook()
-        o += ["s_cmp_lt_u32 s38, 3", "s_cbranch_scc1 12f"]
-        o += P2(nx2, dc) + dma_hook()
-        if k != 5:
-            o += ["s_branch 12f"]
+        o += [f"3{k}:"] + P1(nxt, dn) + P2(cur, dc) + ["s_waitcnt lgkmcnt(0)"] + dma_hook()
+        o += P1(nx2, dc) + P2(nxt, dn) + ["s_waitcnt lgkmcnt(0)"] + dma_hook()
+        o += P2(nx2, dc) + dma_hook() + ["s_branch 12f"]
+    # a list of one to three blocks (ring position 0)
+    cur, nxt, nx2 = RING
+    o += ["40:", "s_cmp_lt_u32 s38, 2", "s_cbranch_scc1 7f"]
+    o += P1(nxt, 1)
+    o += ["7:"] + P2(cur, 0) + ["s_waitcnt lgkmcnt(0)"] + dma_hook()
+    o += ["s_cmp_lt_u32 s38, 2", "s_cbranch_scc1 12f", "s_cmp_lt_u32 s38, 3", "s_cbranch_scc1 7f"]
+    o += P1(nx2, 0)
+    o += ["7:"] + P2(nxt, 1) + ["s_waitcnt lgkmcnt(0)"] + dma_hook()
+    o += ["s_cmp_lt_u32 s38, 3", "s_cbranch_scc1 12f"]
+    o += P2(nx2, 0) + dma_hook()
     return o
 
 
@@ -208,11 +218,10 @@ def phases(lds=True, fma=True, exact=False):
           "s_lshl_b32 s94, s93, 6", "s_lshr_b32 s95, s93, 26", "s_add_u32 s94, s94, %[blo]", "s_addc_u32 s95, s95, %[bhi]",
           "v_readlane_b32 s88, %[offreg], s38",
           "s_mov_b32 s91, s92", "s_mov_b32 s92, s93",
-          "v_xor_b32 v60, 0x10000, v60"]
-    # touch the lines of list t+2 = blocks [s93, s88): lane i -> line min(i, n-1)  (always ONE instruction)
-    o += ["s_sub_i32 s38, s88, s93", "s_sub_i32 s38, s38, 1", "s_max_i32 s38, s38, 0",
-          "v_min_u32 v42, s38, %[lane]", "v_lshlrev_b32 v42, 6, v42",
-          "global_load_dword v61, v42, s[94:95]"]
+          "v_xor_b32 v60, 0x10000, v60",
+          # touch the first lines of list t+2 (lane i -> line min(i, L-1), L chosen by the launcher from the mean
+          # list length): always ONE instruction; lists are consecutive, so lines past a short list are the next one's
+          "global_load_dword v61, %[toff], s[94:95]"]
     o += ["s_mov_b32 s93, s88",
           "s_waitcnt vmcnt(1)",      # tile t+1 (this wave's share) has landed; the touch may still fly
           "s_barrier",
