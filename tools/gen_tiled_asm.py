@@ -40,7 +40,8 @@ def val_pair(buf, i):
     return (buf + 6 + 2 * i, buf + 7 + 2 * i) if F64 else (buf + 2 * i, buf + 2 * i + 1)
 
 
-P1_GROUP = int(os.environ.get("TL_P1_GROUP", "4"))   # address computations issued back to back before their LDS reads
+P1_GROUP = int(os.environ.get("TL_P1_GROUP", "4"))
+DMA_AT_START = int(os.environ.get("TL_DMA_AT_START", "2"))   # tile-DMA instructions issued before the first block of a list   # address computations issued back to back before their LDS reads
 
 
 def p1(buf, dset):
@@ -124,7 +125,9 @@ def list_loop(lds=True, fma=True, exact=False):
     line): lists are short (~5 blocks), so per-block loop bookkeeping is a large share of the issue slots."""
     P1 = p1 if lds else (lambda buf, dset: [])
     P2 = (p2_exact if exact else p2) if fma else (lambda buf, dset: [])
-    o = dma_hook()
+    o = []
+    for _ in range(DMA_AT_START):
+        o += dma_hook()
     o += ["s_waitcnt lgkmcnt(0)"]
     o += P1(RING[0], 0)
     o += ["s_waitcnt lgkmcnt(0)",
