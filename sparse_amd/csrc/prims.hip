@@ -20,9 +20,23 @@ constexpr int MAXD = SPAMD_MAX_NDIM;
 struct DimPack {
   int64_t a[MAXD];  // meaning depends on the kernel (strides / dims)
   int64_t b[MAXD];
+  double inv[MAXD];  // 1.0 / b[d] for the reciprocal-division paths
   int32_t p[MAXD];
   int32_t n;
 };
+
+// floor(r / d) for r < 2^52 through the FP64 pipe: the truncated product with 1/d is off by at most one either way
+// (r and the quotient are exact doubles, 1/d carries 2^-53 relative error), two compares repair it.  A 64-bit integer
+// division is ~100 emulated instructions on CDNA; this is ~10, and every key <-> coordinate conversion does one per
+// dimension per stored element.
+template <typename U>
+__device__ __forceinline__ U div_recip(U r, U d, double inv) {
+  U q = (U)((double)r * inv);
+  const U back = q * d;
+  if (back > r) --q;
+  else if (r - back >= d) ++q;
+  return q;
+}
 
 static inline unsigned grid_for(int64_t n, int per_thread = 1) {
   int64_t b = ceil_div(n, (int64_t)256 * per_thread);
@@ -57,6 +71,22 @@ __global__ void __launch_bounds__(256) delinearize_kernel(const int64_t* __restr
   }
 }
 
+// the same for C-order strides and fewer than 2^52 (U = uint64_t) / 2^32 (U = uint32_t) cells: peel the dimensions off
+// from the last one, one reciprocal division each
+template <typename I, typename U>
+__global__ void __launch_bounds__(256) delinearize_corder_kernel(const int64_t* __restrict__ keys, int64_t nnz,
+                                                                 DimPack dp, I* __restrict__ coords, int64_t cstride) {
+  GRID_STRIDE(i, nnz) {
+    U r = (U)keys[i];
+    for (int d = dp.n - 1; d > 0; --d) {
+      const U q = div_recip<U>(r, (U)dp.b[d], dp.inv[d]);
+      coords[(int64_t)d * cstride + i] = (I)(r - q * (U)dp.b[d]);
+      r = q;
+    }
+    coords[i] = (I)r;
+  }
+}
+
 // out_key = ravel(permute(unravel(in_key, src_shape)))   dp.a = src strides, dp.b = src dims,
 // dp.p[d] = source axis feeding destination axis d (destination is C-order over permuted dims)
 __global__ void __launch_bounds__(256) permute_keys_kernel(const int64_t* __restrict__ in, int64_t nnz,
@@ -69,6 +99,22 @@ __global__ void __launch_bounds__(256) permute_keys_kernel(const int64_t* __rest
       r = r * dp.b[s] + (k / dp.a[s]) % dp.b[s];
     }
     out[i] = r;
+  }
+}
+
+// C-order source and fewer than 2^52 / 2^32 cells: dp.a[s] = DESTINATION stride of source axis s
+template <typename U>
+__global__ void __launch_bounds__(256) permute_keys_corder_kernel(const int64_t* __restrict__ in, int64_t nnz,
+                                                                  DimPack dp, int64_t* __restrict__ out) {
+  GRID_STRIDE(i, nnz) {
+    U r = (U)in[i];
+    int64_t acc = 0;
+    for (int s = dp.n - 1; s > 0; --s) {
+      const U q = div_recip<U>(r, (U)dp.b[s], dp.inv[s]);
+      acc += (int64_t)(r - q * (U)dp.b[s]) * dp.a[s];
+      r = q;
+    }
+    out[i] = acc + (int64_t)r * dp.a[0];
   }
 }
 
@@ -200,6 +246,17 @@ static int fill_dims(DimPack& dp, int ndim, const int64_t* a, const int64_t* b, 
   return 0;
 }
 
+// 0: not C-order strides of `dims` (or too many cells); 1: fewer than 2^32 cells; 2: fewer than 2^52 cells
+static int corder_class(int ndim, const int64_t* strides, const int64_t* dims) {
+  unsigned __int128 size = 1;
+  for (int d = ndim - 1; d >= 0; --d) {
+    if (dims[d] <= 0 || (unsigned __int128)strides[d] != size) return 0;
+    size *= (unsigned __int128)dims[d];
+    if (size >= ((unsigned __int128)1 << 52)) return 0;
+  }
+  return size < ((unsigned __int128)1 << 32) ? 1 : 2;
+}
+
 }  // namespace spamd
 
 using namespace spamd;
@@ -238,8 +295,18 @@ extern "C" int spamd_coo_delinearize(int idx_dtype, int ndim, int64_t nnz, const
   DimPack dp;
   if (int rc = fill_dims(dp, ndim, strides, dims, nullptr)) return rc;
   if (nnz == 0 || ndim == 0) return 0;
-  SPAMD_IDX_SWITCH(idx_dtype, I, hipLaunchKernelGGL(delinearize_kernel<I>, dim3(grid_for(nnz)), dim3(256), 0,
-                                                    (hipStream_t)stream, keys, nnz, dp, (I*)coords, coord_stride))
+  const int cls = corder_class(ndim, strides, dims);
+  for (int d = 0; d < ndim; ++d) dp.inv[d] = 1.0 / (double)dims[d];
+  if (cls == 1) {
+    SPAMD_IDX_SWITCH(idx_dtype, I, hipLaunchKernelGGL((delinearize_corder_kernel<I, uint32_t>), dim3(grid_for(nnz)), dim3(256),
+                                                      0, (hipStream_t)stream, keys, nnz, dp, (I*)coords, coord_stride))
+  } else if (cls == 2) {
+    SPAMD_IDX_SWITCH(idx_dtype, I, hipLaunchKernelGGL((delinearize_corder_kernel<I, uint64_t>), dim3(grid_for(nnz)), dim3(256),
+                                                      0, (hipStream_t)stream, keys, nnz, dp, (I*)coords, coord_stride))
+  } else {
+    SPAMD_IDX_SWITCH(idx_dtype, I, hipLaunchKernelGGL(delinearize_kernel<I>, dim3(grid_for(nnz)), dim3(256), 0,
+                                                      (hipStream_t)stream, keys, nnz, dp, (I*)coords, coord_stride))
+  }
   return launch_status();
 }
 
@@ -249,6 +316,23 @@ extern "C" int spamd_permute_keys(int ndim, int64_t nnz, const int64_t* keys_in,
   DimPack dp;
   if (int rc = fill_dims(dp, ndim, src_strides, src_dims, perm)) return rc;
   if (nnz == 0) return 0;
+  const int cls = corder_class(ndim, src_strides, src_dims);
+  if (cls) {
+    // destination stride of every source axis (the destination is C-order over the permuted dims)
+    int64_t dst = 1;
+    for (int d = ndim - 1; d >= 0; --d) {
+      dp.a[perm[d]] = dst;
+      dst *= src_dims[perm[d]];
+    }
+    for (int d = 0; d < ndim; ++d) dp.inv[d] = 1.0 / (double)src_dims[d];
+    if (cls == 1)
+      hipLaunchKernelGGL(permute_keys_corder_kernel<uint32_t>, dim3(grid_for(nnz)), dim3(256), 0, (hipStream_t)stream,
+                         keys_in, nnz, dp, keys_out);
+    else
+      hipLaunchKernelGGL(permute_keys_corder_kernel<uint64_t>, dim3(grid_for(nnz)), dim3(256), 0, (hipStream_t)stream,
+                         keys_in, nnz, dp, keys_out);
+    return launch_status();
+  }
   hipLaunchKernelGGL(permute_keys_kernel, dim3(grid_for(nnz)), dim3(256), 0, (hipStream_t)stream, keys_in, nnz, dp,
                      keys_out);
   return launch_status();

@@ -313,3 +313,33 @@ def test_batched_matmul_is_one_block_diagonal_product(lead):
     rg = sp.GCXS.from_coo(a) @ sp.GCXS.from_coo(sp.COO.from_numpy(dbs))
     assert isinstance(rg, sp.GCXS) and np.allclose(rg.todense(), da @ dbs, rtol=1e-13, atol=1e-15)
     assert np.allclose((a @ db).cpu().numpy() if isinstance(a @ db, torch.Tensor) else (a @ db), da @ db, rtol=1e-13)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1000, 1000, 1000), (65536, 65535), (3, 1, 7, 2, 5), (2 ** 31 - 1, 2), (2 ** 20, 2 ** 20, 4094),
+                                   (2 ** 26, 2 ** 26 - 3), (2 ** 30, 2 ** 30), (1, 1), (7,)])
+def test_key_coordinate_conversions_match_numpy(shape):
+    """`delinearize` / `permute_keys` (csrc/prims.hip) take a reciprocal-division path below 2^32 and below 2^52 cells
+    and the generic 64-bit division above: all three against NumPy, with keys at the ends of the range and at
+    multiples of the dimensions (where a truncated quotient estimate is off by one)."""
+    from sparse_amd import _kernels as Kn
+
+    size = int(np.prod([int(s) for s in shape], dtype=object))
+    rng = np.random.default_rng(41)
+    special = [0, size - 1, size // 2]
+    for d in shape:
+        special += [min(size - 1, m * d + o) for m in (1, 2, size // max(d, 1) - 1) for o in (-1, 0, 1) if 0 <= m * d + o]
+    keys = np.unique(np.concatenate([np.array([k for k in special if 0 <= k < size], dtype=np.int64),
+                                     rng.integers(0, size, 5000, dtype=np.int64),
+                                     size - 1 - rng.integers(0, min(size, 1000), 200, dtype=np.int64)]))
+    tk = torch.from_numpy(keys).cuda()
+    got = Kn.delinearize(tk, shape, torch.int64).cpu().numpy()
+    want = np.stack(np.unravel_index(keys, shape))
+    assert np.array_equal(got, want)
+    if max(shape) < 2 ** 31:
+        assert np.array_equal(Kn.delinearize(tk, shape, torch.int32).cpu().numpy(), want.astype(np.int32))
+    if len(shape) > 1:
+        for perm in (tuple(reversed(range(len(shape)))), tuple(np.roll(np.arange(len(shape)), 1).tolist())):
+            pk = Kn.permute_keys(tk, shape, perm).cpu().numpy()
+            pshape = tuple(shape[a] for a in perm)
+            assert np.array_equal(pk, np.ravel_multi_index(tuple(want[a] for a in perm), pshape))
