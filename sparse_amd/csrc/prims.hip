@@ -179,9 +179,10 @@ __global__ void __launch_bounds__(256) scatter_kernel(const U* __restrict__ src,
 __global__ void __launch_bounds__(256) iota_kernel(int64_t* out, int64_t n) { GRID_STRIDE(i, n) out[i] = i; }
 
 // sorted keys (row*C + col) -> indptr[R+1] (lower_bound of r*C) and indices[nnz] (key % C)
-template <typename I>
+template <typename I, int CLS>  // CLS: 0 generic 64-bit modulo, 1 / 2 reciprocal division (R*C < 2^32 / < 2^52)
 __global__ void __launch_bounds__(256) keys_to_csr_kernel(const int64_t* __restrict__ keys, int64_t nnz, int64_t R,
-                                                          int64_t C, I* __restrict__ indptr, I* __restrict__ indices) {
+                                                          int64_t C, double invC, I* __restrict__ indptr,
+                                                          I* __restrict__ indices) {
   const int64_t total = (R + 1) > nnz ? (R + 1) : nnz;
   GRID_STRIDE(i, total) {
     if (i <= R) {
@@ -193,7 +194,17 @@ __global__ void __launch_bounds__(256) keys_to_csr_kernel(const int64_t* __restr
       }
       indptr[i] = (I)lo;
     }
-    if (i < nnz) indices[i] = (I)(keys[i] % C);
+    if (i < nnz) {
+      if constexpr (CLS == 1) {
+        const uint32_t k = (uint32_t)keys[i];
+        indices[i] = (I)(k - div_recip<uint32_t>(k, (uint32_t)C, invC) * (uint32_t)C);
+      } else if constexpr (CLS == 2) {
+        const uint64_t k = (uint64_t)keys[i];
+        indices[i] = (I)(k - div_recip<uint64_t>(k, (uint64_t)C, invC) * (uint64_t)C);
+      } else {
+        indices[i] = (I)(keys[i] % C);
+      }
+    }
   }
 }
 
@@ -404,9 +415,15 @@ extern "C" int spamd_keys_to_csr(int idx_dtype, int64_t nnz, const int64_t* keys
                                  void* indices, void* stream) {
   if (nnz < 0 || R < 0 || C < 0) return SPAMD_EINVAL;
   const int64_t total = (R + 1) > nnz ? (R + 1) : nnz;
-  SPAMD_IDX_SWITCH(idx_dtype, I, hipLaunchKernelGGL(keys_to_csr_kernel<I>, dim3(grid_for(total)), dim3(256), 0,
-                                                    (hipStream_t)stream, keys, nnz, R, C > 0 ? C : 1, (I*)indptr,
-                                                    (I*)indices))
+  const int64_t Cn = C > 0 ? C : 1;
+  const unsigned __int128 cells = (unsigned __int128)(R > 0 ? R : 1) * (unsigned __int128)Cn;
+  const int cls = cells < ((unsigned __int128)1 << 32) ? 1 : (cells < ((unsigned __int128)1 << 52) ? 2 : 0);
+  const double invC = 1.0 / (double)Cn;
+#define SPAMD_K2C(CLS)                                                                                               \
+  SPAMD_IDX_SWITCH(idx_dtype, I, hipLaunchKernelGGL((keys_to_csr_kernel<I, CLS>), dim3(grid_for(total)), dim3(256), 0, \
+                                                    (hipStream_t)stream, keys, nnz, R, Cn, invC, (I*)indptr, (I*)indices))
+  if (cls == 1) { SPAMD_K2C(1) } else if (cls == 2) { SPAMD_K2C(2) } else { SPAMD_K2C(0) }
+#undef SPAMD_K2C
   return launch_status();
 }
 
