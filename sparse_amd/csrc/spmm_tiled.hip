@@ -71,7 +71,7 @@ constexpr int TL_TILE = TL_KB * 512;
 constexpr int TL_LDS = TL_NBUF * TL_TILE;
 constexpr int TL_DMA_PER_TILE = TL_TILE / 16 / (TL_WAVES * 64);  // LDS-DMA instructions per wave per tile
 static_assert(TL_LDS <= 160 * 1024 && TL_TILE == 65536 && TL_DMA_PER_TILE == 4, "tile geometry is baked into gen_tiled_asm.py");
-constexpr int TL_SLACK_BLOCKS = 4;  // readable blocks past the end of the stream
+constexpr int TL_SLACK_BLOCKS = 68;  // readable blocks past the end of the stream: the fixed-width line touch (<= 64 lines) + ring over-read
 
 #define GRID_STRIDE(i, n)                                                          \
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n);        \

@@ -134,3 +134,16 @@ def test_nnz_balanced_row_partition():
             sizes = [int(p[0].numel()) for p in pieces]
             assert max(sizes) <= int(indptr[-1]) / world + 20000  # balanced up to one row
     assert [row_bounds(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+
+
+def test_tiled_stream_slack_covers_the_line_touch(hiplib):
+    """The tiled SpMM executor prefetches up to 64 lines (64-byte blocks) past the start of a list and its scalar ring
+    over-reads up to 3 blocks: the readable slack the inspector appends to the stream must cover both (a shorter
+    slack is an out-of-bounds read at the end of the allocation — found by tools/fuzz.py with the caching allocator
+    switched off)."""
+    import ctypes as C
+
+    vals = [C.c_int() for _ in range(7)]
+    for code in (0, 1):   # SPAMD_F32, SPAMD_F64
+        assert hiplib.spamd_spmm_tiled_params(code, *[C.byref(v) for v in vals]) == 0
+        assert vals[4].value >= 64 + 3

@@ -8,6 +8,7 @@ from sparse_amd import _kernels as K, _umath as U
 from bench import make_csr_device
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+ONLY_SPMM = len(sys.argv) > 2 and sys.argv[2] == "spmm"   # with PYTORCH_NO_CUDA_MEMORY_CACHING=1: catches reads past a buffer
 rng = np.random.default_rng(int(time.time()))
 t_end = time.time() + budget
 n = {"spmm": 0, "merge": 0, "spgemm": 0, "reduce": 0}
@@ -30,6 +31,9 @@ while time.time() < t_end:
         ref = K.dot_csr_ndarray((M, N), data, idx, ptr, b, exact=exact)
         assert torch.equal(got, ref), ("spmm", M, Kd, dens, dt, N, exact)
     n["spmm"] += 1
+    if ONLY_SPMM:
+        del data, idx, ptr, b, layout, got, ref
+        continue
     # ---- merge (elementwise add / multiply / maximum) single-pass vs two-pass
     shape = (int(rng.integers(1, 300)), int(rng.integers(1, 300)), int(rng.integers(1, 300)))
     size = shape[0] * shape[1] * shape[2]
