@@ -9,13 +9,13 @@
 //
 //   inspector (once per matrix, cached on the container):
 //     elements are re-ordered by (32-row group g, K-tile t, row, column) and written as a stream of
-//     64-byte BLOCKS of eight (d0, d1) entries, d0 = (column-in-tile << 9) | (2 + 2*row-in-group),
+//     64-byte BLOCKS of eight (d0, d1) entries, d0 = LDS row offset of the column-in-tile | (2 + 2*row-in-group),
 //     d1 = value bits; every (g, t) list is padded to whole blocks with d0 = d1 = 0 (those land in a
 //     junk accumulator).  blk_off[g*ntiles + t] = first block of list (g, t).
 //   executor (every multiply; this kernel):
 //     a workgroup of 16 waves owns 512 rows; wave w owns row group g and keeps its 32 x 128 partial
 //     sums in the fixed VGPR block v[64:127] (lane l: columns 2l, 2l+1 of each row);
-//     B tile t (128 x 128 fp32 = 64 KB) is copied to LDS by LDS-DMA (global_load_lds_dwordx4),
+//     B tile t (160 x 128 fp32 = 80 KB) is copied to LDS by LDS-DMA (global_load_lds_dwordx4),
 //     double-buffered, one barrier per tile;
 //     the wave pulls ITS blocks with SCALAR loads (s_load_dwordx16, three blocks in a ring), so an
 //     entry arrives already wave-uniform: d0 is at once the LDS row offset (v_and_or_b32 with the
@@ -34,10 +34,15 @@ namespace spamd {
 
 constexpr int TL_RG = 32;        // rows per wave (row group)
 constexpr int TL_WAVES = 16;     // waves per workgroup
-constexpr int TL_KB = 128;       // B rows per tile: 64 KB, so that (column << 9) | base addresses a row (v_and_or_b32)
+constexpr int TL_KB = TL_ASM_KB;  // B rows per tile (tools/gen_tiled_asm.py: 160 = all of the 160 KB LDS in two buffers)
 constexpr int TL_NBUF = 2;       // LDS tile buffers: tile t+1 is in flight while tile t is consumed
                                  // (64-row tiles with 3-5 buffers were measured 30-40 % slower: twice the
-                                 // barriers and list heads, 17 % padding)
+                                 // barriers and list heads, 17 % padding; 128-row tiles 6 % slower than 160)
+// LDS layout: the two buffers are interleaved in 1 KB units (= one LDS-DMA instruction = two B rows), row r of buffer b
+// lives at ((r >> 1) * 2 + b) * 1024 + (r & 1) * 512.  The row part of that address is what an entry carries in d0
+// (bits 9 and 11..), the buffer bit (10) and the lane offset (3..8) are the per-lane base: one v_and_or_b32 makes the
+// address for any tile height, without the power-of-two buffer size a plain (column << 9) | base would need.
+__host__ __device__ constexpr int tl_d0(int lc, int lr) { return ((lc >> 1) << 11) | ((lc & 1) << 9) | (2 + 2 * lr); }
 constexpr int TL_BLOCK_INTS = 16; // a stream block is 64 bytes
 
 // Per value type: entries per block and where an entry lives inside its block.
@@ -70,7 +75,8 @@ struct TlFmt<double> {
 constexpr int TL_TILE = TL_KB * 512;
 constexpr int TL_LDS = TL_NBUF * TL_TILE;
 constexpr int TL_DMA_PER_TILE = TL_TILE / 16 / (TL_WAVES * 64);  // LDS-DMA instructions per wave per tile
-static_assert(TL_LDS <= 160 * 1024 && TL_TILE == 65536 && TL_DMA_PER_TILE == 4, "tile geometry is baked into gen_tiled_asm.py");
+static_assert(TL_LDS <= 160 * 1024 && TL_KB % 32 == 0 && TL_DMA_PER_TILE == TL_ASM_DMA_PER_TILE,
+              "tile geometry is baked into gen_tiled_asm.py");
 constexpr int TL_SLACK_BLOCKS = 68;  // readable blocks past the end of the stream: the fixed-width line touch (<= 64 lines) + ring over-read
 
 #define GRID_STRIDE(i, n)                                                          \
@@ -114,7 +120,7 @@ __global__ void __launch_bounds__(256) tl_pack_kernel(const int64_t* __restrict_
     const int64_t k = keys[i];
     const int64_t lc = k % TL_KB, r1 = k / TL_KB, lr = r1 % TL_RG, s = r1 / TL_RG;
     const int64_t dst = blk_off[s] * TlFmt<T>::EPB + (i - seg_start[s]);
-    TlFmt<T>::put(stream, dst, (int)((lc << 9) | (2 + 2 * lr)), vals[i]);
+    TlFmt<T>::put(stream, dst, tl_d0((int)lc, (int)lr), vals[i]);
   }
 }
 
@@ -199,7 +205,7 @@ __global__ void __launch_bounds__(256) tl_fill_kernel(int64_t M, int ntiles, con
     const int t = (int)(c / TL_KB), lc = (int)(c - (int64_t)t * TL_KB);
     const int lr = tl_row_of<I>(rs, e);
     const int64_t dst = goff[t] * TlFmt<T>::EPB + before[lr * ntiles + t] + ((int)(e - e0) - runstart[lr * ntiles + t]);
-    TlFmt<T>::put(stream, dst, (lc << 9) | (2 + 2 * lr), vals[e]);
+    TlFmt<T>::put(stream, dst, tl_d0(lc, lr), vals[e]);
   }
 }
 
@@ -261,14 +267,14 @@ spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, int touch_lines, const int* 
 
   asm volatile(TL_ASM_ZERO ::: "memory", TL_CLOB_ACC);
 
-  // Tile DMA.  A tile is 128 B rows x 512 B; a wave issues 4 of its 64 LDS-DMA instructions (1 KB each:
+  // Tile DMA.  A tile is TL_KB B rows x 512 B; a wave issues TL_KB/32 of its LDS-DMA instructions (1 KB each:
   // instruction j of wave w carries rows 32j + 2w and 32j + 2w + 1).  Full tiles are issued from inside
   // the phase asm through a per-thread source pointer that walks down B 32 rows at a time (v[22:23]);
   // the last, partial tile goes through `issue_partial`, rows past K clamped to row K-1 (no entry
   // refers to them).
   const int nfull = DBG == 2 ? 0 : (int)(K / TL_KB);
   const int64_t row_step = 32 * ldb * (int64_t)sizeof(T);
-  const unsigned m0wave = (unsigned)wv * 1024u;
+  const unsigned m0wave = (unsigned)wv * 2048u;  // LDS offset of this wave's first row pair (buffer 0)
   {
     const T* p0 = b + (int64_t)(tid >> 5) * ldb + (tid & 31) * (16 / (int)sizeof(T));
     asm volatile("v_mov_b32 v22, %0\n\tv_mov_b32 v23, %1" ::"v"((unsigned)((uintptr_t)p0 & 0xffffffffu)),
@@ -276,13 +282,12 @@ spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, int touch_lines, const int* 
                  : "v22", "v23");
   }
   auto issue_partial = [&](int t) {
-    const unsigned buf = (unsigned)(t & 1) * TL_TILE;
 #pragma unroll
     for (int i = 0; i < TL_DMA_PER_TILE; ++i) {
       const int e = (i * (TL_WAVES * 64) + tid) * 16;  // byte inside the tile (512 bytes per row)
       int64_t r = (int64_t)t * TL_KB + (e >> 9);
       if (r >= K) r = K - 1;
-      tl_dma16(buf + (unsigned)(i * TL_WAVES + wv) * 1024u,
+      tl_dma16(((unsigned)(i * TL_WAVES + wv) * 2u + (unsigned)(t & 1)) * 1024u,   // row pair i*16 + wv of buffer t & 1
                reinterpret_cast<const char*>(b + r * ldb) + (e & 511));
     }
   };

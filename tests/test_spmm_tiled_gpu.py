@@ -31,7 +31,8 @@ def _run(M, K, density, idt, seed=0, **kw):
 
 @pytest.mark.parametrize("idt", [np.int32, np.int64])
 @pytest.mark.parametrize("M,K,density", [(300, 200, 0.05), (1000, 3000, 0.01), (257, 64, 0.5), (64, 1000, 0.2),
-                                         (5000, 10000, 0.01), (1, 70, 1.0), (4097, 129, 0.1), (16, 128, 1.0)])
+                                         (5000, 10000, 0.01), (1, 70, 1.0), (4097, 129, 0.1), (16, 128, 1.0), (333, 160, 0.3),
+                                         (333, 161, 0.3), (90, 159, 1.0), (64, 321, 0.5)])
 def test_tiled_bit_identical_to_rowgroup_fma(orc, idt, M, K, density):
     (data, idx, ptr, b), got, ref, layout = _run(M, K, density, idt)
     assert torch.equal(got, ref)
@@ -47,7 +48,8 @@ def test_tiled_bit_identical_to_rowgroup_fma(orc, idt, M, K, density):
 
 
 @pytest.mark.parametrize("M,K,density", [(700, 20000, 0.004), (100, 128, 0.3), (513, 256, 0.1), (2000, 7936, 0.01),
-                                         (40, 16000, 0.02)])
+                                         (40, 16000, 0.02), (100, 320, 0.3), (700, 9760, 0.01), (300, 9920, 0.02),
+                                         (50, 19680, 0.01)])
 def test_tiled_phase_chunking_and_tile_edges(orc, M, K, density):
     """More than 61 / 122 tiles (the phase loop runs in chunks of 61), K an exact multiple of the tile (no
     partial tile), one tile only."""

@@ -40,8 +40,11 @@ def val_pair(buf, i):
     return (buf + 6 + 2 * i, buf + 7 + 2 * i) if F64 else (buf + 2 * i, buf + 2 * i + 1)
 
 
-P1_GROUP = int(os.environ.get("TL_P1_GROUP", "4"))
-DMA_AT_START = int(os.environ.get("TL_DMA_AT_START", "2"))   # tile-DMA instructions issued before the first block of a list   # address computations issued back to back before their LDS reads
+P1_GROUP = int(os.environ.get("TL_P1_GROUP", "4"))          # address computations issued back to back before their LDS reads
+DMA_AT_START = int(os.environ.get("TL_DMA_AT_START", "2"))  # tile-DMA instructions issued before the first block of a list
+KB = int(os.environ.get("TL_KB", "160"))                    # B rows per LDS tile (multiple of 32; 2 x KB x 512 B <= 160 KB)
+DMA_PER_TILE = KB // 32                                      # LDS-DMA instructions per wave per tile
+PENDING = (1 << DMA_PER_TILE) - 1                            # VCC mask of a full tile's pending DMA instructions
 
 
 def p1(buf, dset):
@@ -99,10 +102,11 @@ def p2_exact(buf, dset):
 
 def dma_body():
     """one tile-DMA instruction of the NEXT tile: from the walking source pointer v[22:23] (advanced by 32 B rows)
-    to LDS address s89 (advanced by 16 KB; the s_add also is the wait state M0 needs before an LDS-DMA), and one
+    to LDS address s89 (advanced by 16 row pairs = 32 KB of the interleaved buffers; the s_add also is the wait state
+    M0 needs before an LDS-DMA), and one
     bit less in the pending mask (VCC)"""
     return ["s_mov_b32 m0, s89",
-            "s_add_u32 s89, s89, 0x4000",
+            "s_add_u32 s89, s89, 0x8000",
             "global_load_lds_dwordx4 v[22:23], off",
             "v_lshl_add_u64 v[22:23], %[step], 0, v[22:23]",
             "s_lshr_b64 vcc, vcc, 1"]
@@ -201,14 +205,13 @@ def phases(lds=True, fma=True, exact=False):
     entry to a phase (left there by the request of its first blocks).  v60 (LDS base of the tile being read)
     and s89 (LDS destination of the tile being loaded) toggle between the two buffers once per phase."""
     o = ["s_mov_b32 s90, %[t0]", "s_mov_b32 s91, %[o0]", "s_mov_b32 s92, %[o1]", "s_mov_b32 s93, %[o2]",
-         "s_add_u32 s88, s90, 1", "s_and_b32 s88, s88, 1", "s_lshl_b32 s88, s88, 16", "s_add_u32 s89, s88, %[m0wave]",
-         "s_and_b32 s88, s90, 1", "s_lshl_b32 s88, s88, 16", "v_or_b32 v60, s88, %[lane8]"]
+         "s_add_u32 s88, s90, 1", "s_and_b32 s88, s88, 1", "s_lshl_b32 s88, s88, 10", "s_add_u32 s89, s88, %[m0wave]",
+         "s_and_b32 s88, s90, 1", "s_lshl_b32 s88, s88, 10", "v_or_b32 v60, s88, %[lane8]"]
     o += request_first_blocks(91, 92, 20, 22)
     o += ["1:",
           "s_sub_u32 s38, s92, s91",                       # blocks in this list
           "s_add_u32 s88, s90, 1",                         # next tile: four DMA instructions if it is a full one
-          "s_cmp_lt_u32 s88, %[nfull]", "s_cselect_b64 vcc, 15, 0",
-          "s_and_b32 s89, s89, 0x1ffff",                   # buffer 1 + 64 KB wraps to buffer 0
+          "s_cmp_lt_u32 s88, %[nfull]", f"s_cselect_b64 vcc, {PENDING}, 0",
           "s_cmp_eq_u32 s38, 0", "s_cbranch_scc1 12f"]
     o += list_loop(lds, fma, exact)
     o += ["12:", "13:", "s_cbranch_vccz 14f"] + dma_body() + ["s_branch 13b", "14:"]   # the rest of the DMA share
@@ -221,7 +224,8 @@ def phases(lds=True, fma=True, exact=False):
           "s_lshl_b32 s94, s93, 6", "s_lshr_b32 s95, s93, 26", "s_add_u32 s94, s94, %[blo]", "s_addc_u32 s95, s95, %[bhi]",
           "v_readlane_b32 s88, %[offreg], s38",
           "s_mov_b32 s91, s92", "s_mov_b32 s92, s93",
-          "v_xor_b32 v60, 0x10000, v60",
+          "v_xor_b32 v60, 0x400, v60",
+          "s_and_b32 s89, s89, 0x7fff", "s_xor_b32 s89, s89, 0x400",   # back to the wave's first row pair, other buffer
           # touch the first lines of list t+2 (lane i -> line min(i, L-1), L chosen by the launcher from the mean
           # list length): always ONE instruction; lists are consecutive, so lines past a short list are the next one's
           "global_load_dword v61, %[toff], s[94:95]"]
@@ -236,7 +240,7 @@ def phases(lds=True, fma=True, exact=False):
 
 def tile0():
     """the wave's four DMA instructions of tile 0 (buffer 0), advancing the walking pointer"""
-    return ["s_mov_b32 s89, %[m0wave]", "s_mov_b64 vcc, 15", "13:", "s_cbranch_vccz 14f"] + dma_body() + ["s_branch 13b", "14:"]
+    return ["s_mov_b32 s89, %[m0wave]", f"s_mov_b64 vcc, {PENDING}", "13:", "s_cbranch_vccz 14f"] + dma_body() + ["s_branch 13b", "14:"]
 
 
 def store():
@@ -275,6 +279,7 @@ def f64_variants():
 
 def main():
     out = ["// GENERATED by tools/gen_tiled_asm.py - do not edit.\n",
+           f"#define TL_ASM_KB {KB}\n#define TL_ASM_DMA_PER_TILE {DMA_PER_TILE}\n",
            lit("TL_ASM_PHASES", phases()),
            lit("TL_ASM_PHASES_EXACT", phases(True, True, True)),
            lit("TL_ASM_PHASES_NOFMA", phases(True, False)),
