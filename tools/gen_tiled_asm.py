@@ -45,6 +45,7 @@ DMA_AT_START = int(os.environ.get("TL_DMA_AT_START", "2"))  # tile-DMA instructi
 KB = int(os.environ.get("TL_KB", "160"))                    # B rows per LDS tile (multiple of 32; 2 x KB x 512 B <= 160 KB)
 DMA_PER_TILE = KB // 32                                      # LDS-DMA instructions per wave per tile
 PENDING = (1 << DMA_PER_TILE) - 1                            # VCC mask of a full tile's pending DMA instructions
+TAIL_HOOKS = int(os.environ.get("TL_TAIL_HOOKS", "0"))      # DMA hooks inside the three-block tails (the rest waits for the list end)
 
 
 def p1(buf, dset):
@@ -151,9 +152,10 @@ def list_loop(lds=True, fma=True, exact=False):
     for k in range(6):   # exactly three blocks left, all in the ring: straight line
         cur, nxt, nx2 = RING[k % 3], RING[(k + 1) % 3], RING[(k + 2) % 3]
         dc, dn = k % 2, (k + 1) % 2
-        o += [f"3{k}:"] + P1(nxt, dn) + P2(cur, dc) + ["s_waitcnt lgkmcnt(0)"] + dma_hook()
-        o += P1(nx2, dc) + P2(nxt, dn) + ["s_waitcnt lgkmcnt(0)"] + dma_hook()
-        o += P2(nx2, dc) + dma_hook() + ["s_branch 12f"]
+        th = [dma_hook() if j < TAIL_HOOKS else [] for j in range(3)]
+        o += [f"3{k}:"] + P1(nxt, dn) + P2(cur, dc) + ["s_waitcnt lgkmcnt(0)"] + th[0]
+        o += P1(nx2, dc) + P2(nxt, dn) + ["s_waitcnt lgkmcnt(0)"] + th[1]
+        o += P2(nx2, dc) + th[2] + ["s_branch 12f"]
     # a list of one to three blocks (ring position 0)
     cur, nxt, nx2 = RING
     o += ["40:", "s_cmp_lt_u32 s38, 2", "s_cbranch_scc1 7f"]
