@@ -16,7 +16,6 @@ import argparse
 import json
 import os
 import sys
-import time
 
 import numpy as np
 import torch

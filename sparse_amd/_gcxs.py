@@ -13,7 +13,7 @@ import torch
 
 from . import _device as dev
 from ._sparse_array import NDArrayOperatorsMixin, SparseArray
-from ._utils import can_store, check_compressed_axes, normalize_axis, prod, zero_of_dtype
+from ._utils import check_compressed_axes, normalize_axis, prod, zero_of_dtype
 
 
 def _is_scipy_sparse(x):

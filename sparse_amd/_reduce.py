@@ -11,7 +11,7 @@ import torch
 
 from . import _ffi
 from . import _kernels as K
-from ._device import code_of, np_dtype, ptr, require_hip, stream_ptr, torch_dtype
+from ._device import code_of, ptr, require_hip, stream_ptr, torch_dtype
 from ._utils import equivalent, normalize_axis, prod
 
 _RED_OPS = {"add": 0, "multiply": 1, "maximum": 2, "minimum": 3, "logical_or": 4, "logical_and": 5, "fmax": 6, "fmin": 7}
@@ -66,7 +66,6 @@ def _scalar_dev(value, dtype, dev):
 def reduce_impl(x, method, axis=(0,), keepdims=False, **kwargs):
     from ._coo import COO
     from ._gcxs import GCXS
-    from ._umath import binary_arrays, select
 
     name = getattr(method, "__name__", str(method))
     out_gcxs = isinstance(x, GCXS)

@@ -11,7 +11,7 @@ from numbers import Integral
 
 import numpy as np
 
-from ._utils import equivalent, normalize_axis, zero_of_dtype
+from ._utils import normalize_axis, zero_of_dtype
 
 # add -> multiply, multiply -> power: the closed form that folds the implicit fill values of a
 # group into a sum / product (reference _sparse_array.py:14, used at :409-421)

@@ -15,8 +15,7 @@ import torch
 from . import _device as dev
 from . import _ffi
 from . import _kernels as K
-from ._device import code_of, ptr, require_hip, stream_ptr, torch_dtype
-from ._utils import equivalent
+from ._device import ptr, require_hip, stream_ptr, torch_dtype
 
 # NumPy ufunc name -> (kind, C-ABI op code)   (codes: include/sparse_amd.h)
 _BIN = {"add": 0, "subtract": 1, "multiply": 2, "divide": 3, "true_divide": 3, "maximum": 4, "minimum": 5,
