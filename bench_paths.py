@@ -111,6 +111,15 @@ def main():
         out.append(line(f"A3 tensordot COO x dense ({np.dtype(dt).name}/{it})",
                         f"COO({side}^3 @1%, {nnz3} nnz) . dense({side},{side}), axes=1 (incl. N-D->2-D reshape)", ms, b,
                         flops=2.0 * nnz3 * N))
+        # repeated products with the SAME operand: with `enable_caching()` (reference `COO(cache=True)`, core.py:317-338) the
+        # reshaped 2-D operand is memoised, so its tiled block stream is built at the second product and reused
+        c3.enable_caching()
+        for _ in range(3):
+            sp.tensordot(c3, d, axes=1)
+        ms, r = timed(lambda: sp.tensordot(c3, d, axes=1))
+        out.append(line(f"A3 tensordot, cached operand ({np.dtype(dt).name}/{it})",
+                        "same product, operand created with caching: tiled executor from the third call on", ms, b,
+                        flops=2.0 * nnz3 * N))
         at = c3.reshape((M, side))
         from sparse_amd import _kernels as K
 
