@@ -47,8 +47,8 @@ def test_reduce_consistency_full_size(sp):
 
 
 def test_config3_tensordot_identity_and_linearity(sp):
-    """config 3 shape class: 3-D COO (256^3 @ 1 %) . dense, axes=1."""
-    n = 256
+    """config 3 at full size: 3-D COO (512^3 @ 1 %, 1 342 177 stored elements) . dense (512, ·), axes=1."""
+    n = 512
     c3 = sp.random((n, n, n), density=0.01, random_state=3)
     eye = torch.eye(n, dtype=torch.float64, device="cuda")
     r = sp.tensordot(c3, eye, axes=1)
@@ -65,8 +65,8 @@ def test_config3_tensordot_identity_and_linearity(sp):
 
 
 def test_config4_sddmm_properties(sp):
-    """config 4 shape class: mask 3e4 x 3e4 @ 0.1 %, K = 256, bf16 operands."""
-    M = 30_000
+    """config 4 at full size: mask 1e5 x 1e5 @ 0.1 % (1e7 samples), K = 256, bf16 operands."""
+    M = 100_000
     s = sp.random((M, M), density=0.001, random_state=4, dtype=np.float32, idx_dtype=np.int32)
     g = torch.Generator(device="cuda").manual_seed(2)
     a = torch.rand((M, 256), generator=g, device="cuda").to(torch.bfloat16)
@@ -83,14 +83,15 @@ def test_config4_sddmm_properties(sp):
 
 
 def test_spgemm_identity_and_transpose(sp):
-    n = 20_000
-    a = sp.random((n, n), density=5e-4, random_state=5, format="gcxs", compressed_axes=(0,))
+    n = 100_000   # the single-GPU SpGEMM size of bench_paths.py (1e7 stored elements per operand at 1e-3 would be 1e9
+    # products: here 2.5e-4 keeps the transposed product and the comparison in a few GB)
+    a = sp.random((n, n), density=2.5e-4, random_state=5, format="gcxs", compressed_axes=(0,))
     eye = sp.GCXS((np.ones(n), np.arange(n), np.arange(n + 1)), shape=(n, n), compressed_axes=(0,))
     r = a @ eye
     assert isinstance(r, sp.GCXS)
     assert torch.equal(r.data, a.data) and torch.equal(r.indices.long(), a.indices.long())
     # (A B)^T == B^T A^T, structure exactly and values to fp tolerance
-    b = sp.random((n, n), density=5e-4, random_state=6, format="gcxs", compressed_axes=(0,))
+    b = sp.random((n, n), density=2.5e-4, random_state=6, format="gcxs", compressed_axes=(0,))
     ab = (a @ b).tocoo()
     btat = (b.T @ a.T).tocoo().transpose((1, 0))
     assert torch.equal(ab.coords, btat.coords)
