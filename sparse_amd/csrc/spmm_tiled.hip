@@ -32,8 +32,13 @@
 
 namespace spamd {
 
-constexpr int TL_RG = 32;        // rows per wave (row group)
-constexpr int TL_WAVES = 16;     // waves per workgroup
+constexpr int TL_RG = TL_ASM_RG;        // rows per wave (row group)
+constexpr int TL_WAVES = TL_ASM_WAVES;  // waves per workgroup
+#ifndef SPAMD_TL_EXPERIMENTAL
+// the generator is parameterised (TL_RG / TL_WAVES in tools/gen_tiled_asm.py), but only this geometry is validated:
+// a first 64-row x 8-wave build (2 waves per SIMD, 256 registers) faulted on the GPU and was not pursued this round
+static_assert(TL_RG == 32 && TL_WAVES == 16, "unvalidated tiled-SpMM geometry: build with -DSPAMD_TL_EXPERIMENTAL");
+#endif
 constexpr int TL_KB = TL_ASM_KB;  // B rows per tile (tools/gen_tiled_asm.py: 160 = all of the 160 KB LDS in two buffers)
 constexpr int TL_NBUF = 2;       // LDS tile buffers: tile t+1 is in flight while tile t is consumed
                                  // (64-row tiles with 3-5 buffers were measured 30-40 % slower: twice the
@@ -129,13 +134,14 @@ __global__ void __launch_bounds__(256) tl_pack_kernel(const int64_t* __restrict_
 // so no sort is needed: one workgroup per group counts (row, tile) runs in LDS, and an element's slot is
 //   8 * blk_off[g, t] + (elements of tile t in earlier rows of the group) + (position inside its row's run).
 // Two passes over A (count, fill) = ~2 GB of traffic at config 2 instead of a 64-bit radix sort of 10^8 pairs.
-constexpr int TL_DIRECT_MAX_TILES = 256;  // LDS: 2 * 32 * tiles * 4 B (+ tiles * 4) <= 66 KB
+constexpr int TL_DIRECT_MAX_TILES = 256;  // LDS: 2 * TL_RG * tiles * 4 B (+ tiles * 4) <= 66 KB (132 KB for 64-row groups)
 
 template <typename I>
-__device__ __forceinline__ int tl_row_of(const int64_t* rs, int64_t e) {  // largest lr in [0, 32) with rs[lr] <= e
+__device__ __forceinline__ int tl_row_of(const int64_t* rs, int64_t e) {  // largest lr in [0, TL_RG) with rs[lr] <= e
+  static_assert((TL_RG & (TL_RG - 1)) == 0, "bisection over a power-of-two row group");
   int lo = 0;
 #pragma unroll
-  for (int step = 16; step >= 1; step >>= 1)
+  for (int step = TL_RG / 2; step >= 1; step >>= 1)
     if (rs[lo + step] <= e) lo += step;
   return lo;
 }
@@ -273,7 +279,7 @@ spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, int touch_lines, const int* 
   // the last, partial tile goes through `issue_partial`, rows past K clamped to row K-1 (no entry
   // refers to them).
   const int nfull = DBG == 2 ? 0 : (int)(K / TL_KB);
-  const int64_t row_step = 32 * ldb * (int64_t)sizeof(T);
+  const int64_t row_step = (2 * TL_WAVES) * ldb * (int64_t)sizeof(T);  // rows covered by one round of DMA instructions
   const unsigned m0wave = (unsigned)wv * 2048u;  // LDS offset of this wave's first row pair (buffer 0)
   {
     const T* p0 = b + (int64_t)(tid >> 5) * ldb + (tid & 31) * (16 / (int)sizeof(T));

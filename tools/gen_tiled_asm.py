@@ -24,8 +24,10 @@ F64 = False
 RING = (40, 56, 72)
 ADDR = (40, 41, 42, 43)
 DATA0 = 44
-JUNK = 62
-ROWS = 32
+ROWS = int(os.environ.get("TL_RG", "32"))     # rows per wave: 2 accumulator registers each, v[2*ROWS : 4*ROWS)
+WAVES = int(os.environ.get("TL_WAVES", "16"))  # waves per workgroup (ROWS * WAVES rows share one B tile)
+ACC0 = 2 * ROWS
+JUNK = ACC0 - 2                               # junk accumulator pair (padding entries), just below the accumulators
 
 
 DATASET = (44, 24)
@@ -43,7 +45,7 @@ def val_pair(buf, i):
 P1_GROUP = int(os.environ.get("TL_P1_GROUP", "4"))          # address computations issued back to back before their LDS reads
 DMA_AT_START = int(os.environ.get("TL_DMA_AT_START", "2"))  # tile-DMA instructions issued before the first block of a list
 KB = int(os.environ.get("TL_KB", "160"))                    # B rows per LDS tile (multiple of 32; 2 x KB x 512 B <= 160 KB)
-DMA_PER_TILE = KB // 32                                      # LDS-DMA instructions per wave per tile
+DMA_PER_TILE = KB // (2 * WAVES)                             # LDS-DMA instructions per wave per tile
 PENDING = (1 << DMA_PER_TILE) - 1                            # VCC mask of a full tile's pending DMA instructions
 TAIL_HOOKS = int(os.environ.get("TL_TAIL_HOOKS", "0"))      # DMA hooks inside the three-block tails (the rest waits for the list end)
 
@@ -107,7 +109,7 @@ def dma_body():
     M0 needs before an LDS-DMA), and one
     bit less in the pending mask (VCC)"""
     return ["s_mov_b32 m0, s89",
-            "s_add_u32 s89, s89, 0x8000",
+            f"s_add_u32 s89, s89, {hex(WAVES * 2048)}",
             "global_load_lds_dwordx4 v[22:23], off",
             "v_lshl_add_u64 v[22:23], %[step], 0, v[22:23]",
             "s_lshr_b64 vcc, vcc, 1"]
@@ -249,7 +251,7 @@ def store():
     o = ["v_mov_b32 v60, %[lo]", "v_mov_b32 v61, %[hi]", "s_mov_b32 s36, 0"]
     for j in range(ROWS):
         o += ["s_cmp_ge_i32 s36, %[n]", "s_cbranch_scc1 9f",
-              f"global_store_dwordx2 v[60:61], v[{64 + 2 * j}:{65 + 2 * j}], off nt",
+              f"global_store_dwordx2 v[60:61], v[{ACC0 + 2 * j}:{ACC0 + 1 + 2 * j}], off nt",
               "v_lshl_add_u64 v[60:61], %[stride], 0, v[60:61]",
               "s_add_i32 s36, s36, 1"]
     o.append("9:")
@@ -257,7 +259,7 @@ def store():
 
 
 def zero():
-    return [f"v_mov_b32 v{r}, 0" for r in range(JUNK, 128)]
+    return [f"v_mov_b32 v{r}, 0" for r in range(JUNK, ACC0 + 2 * ROWS)]
 
 
 def lit(name, lines):
@@ -281,7 +283,7 @@ def f64_variants():
 
 def main():
     out = ["// GENERATED by tools/gen_tiled_asm.py - do not edit.\n",
-           f"#define TL_ASM_KB {KB}\n#define TL_ASM_DMA_PER_TILE {DMA_PER_TILE}\n",
+           f"#define TL_ASM_KB {KB}\n#define TL_ASM_DMA_PER_TILE {DMA_PER_TILE}\n#define TL_ASM_RG {ROWS}\n#define TL_ASM_WAVES {WAVES}\n",
            lit("TL_ASM_PHASES", phases()),
            lit("TL_ASM_PHASES_EXACT", phases(True, True, True)),
            lit("TL_ASM_PHASES_NOFMA", phases(True, False)),
@@ -292,7 +294,7 @@ def main():
            lit("TL_ASM_ZERO", zero()),
            f"#define TL_CLOB_SGPR {clob('s', 36, 95)}\n",
            f"#define TL_CLOB_TMP {clob('v', 22, 61)}\n",
-           f"#define TL_CLOB_ACC {clob('v', 62, 127)}\n"]
+           f"#define TL_CLOB_ACC {clob('v', JUNK, ACC0 + 2 * ROWS - 1)}\n"]
     p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "sparse_amd", "csrc", "spmm_tiled_asm.inc")
     with open(p, "w") as f:
         f.write("\n".join(out))
