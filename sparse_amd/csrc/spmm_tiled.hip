@@ -23,7 +23,7 @@
 //     scalar multiplicand.  Per entry: 1 VALU address op, 1 ds_read_b64, 1 SALU, 2 v_fma_f32.
 //     No readlanes, no per-row code, no divergence.
 // The inner loops are generated text (tools/gen_tiled_asm.py -> spmm_tiled_asm.inc); the compiler is
-// confined to v0..v23 (amdgpu_num_vgpr) and never sees v24..v127.
+// asked to stay in v0..v21 (amdgpu_num_vgpr; tools/check_tiled_regs.py verifies it never touches v22.. outside the asm).
 // Per output element the fused multiply-adds happen in the same k-ascending order as in the row-group
 // kernel's FMA mode, so both kernels return bit-identical results (column indices sorted within rows).
 #include "common.h"
@@ -35,9 +35,10 @@ namespace spamd {
 constexpr int TL_RG = TL_ASM_RG;        // rows per wave (row group)
 constexpr int TL_WAVES = TL_ASM_WAVES;  // waves per workgroup
 #ifndef SPAMD_TL_EXPERIMENTAL
-// the generator is parameterised (TL_RG / TL_WAVES in tools/gen_tiled_asm.py), but only this geometry is validated:
-// a first 64-row x 8-wave build (2 waves per SIMD, 256 registers) faulted on the GPU and was not pursued this round
-static_assert(TL_RG == 32 && TL_WAVES == 16, "unvalidated tiled-SpMM geometry: build with -DSPAMD_TL_EXPERIMENTAL");
+// the generator is parameterised (TL_RG / TL_WAVES in tools/gen_tiled_asm.py).  64 rows x 8 waves (2 waves per SIMD, 256
+// registers) passes the parity tests but is 8 % slower with the same two-data-set pipeline (1.04 vs 0.96 ms at config 2):
+// two waves per SIMD do not cover the LDS / scalar latencies.  The shipped geometry is the one the tests run.
+static_assert(TL_RG == 32 && TL_WAVES == 16, "experimental tiled-SpMM geometry: build with -DSPAMD_TL_EXPERIMENTAL");
 #endif
 constexpr int TL_KB = TL_ASM_KB;  // B rows per tile (tools/gen_tiled_asm.py: 160 = all of the 160 KB LDS in two buffers)
 constexpr int TL_NBUF = 2;       // LDS tile buffers: tile t+1 is in flight while tile t is consumed
@@ -231,11 +232,12 @@ __device__ __forceinline__ void tl_dma16(unsigned lds_base, const void* src) {
 template <int MODE>
 __device__ __forceinline__ void tl_phases(const int* stream, int t0, int te, int o0, int o1, int o2, int offreg, int obase,
                                           int ntiles, int nfull, int toff, int mask, unsigned m0wave,
-                                          int64_t row_step) {
+                                          int64_t row_step, uint64_t& dptr) {
   const int lane = threadIdx.x & 63;
   const unsigned blo = (unsigned)((uintptr_t)stream & 0xffffffffu), bhi = (unsigned)((uintptr_t)stream >> 32);
   const int lane8 = lane * 8;
 #define TL_PHASES_OPERANDS                                                                                        \
+  [dptr] "+v"(dptr)                                                                                               \
   : [blo] "s"(blo), [bhi] "s"(bhi), [t0] "s"(t0), [te] "s"(te), [o0] "s"(o0), [o1] "s"(o1), [o2] "s"(o2),         \
     [obase] "s"(obase), [ntiles] "s"(ntiles), [nfull] "s"(nfull), [m0wave] "s"(m0wave), [step] "s"(row_step),      \
     [toff] "v"(toff), [lane8] "v"(lane8), [mask] "v"(mask), [offreg] "v"(offreg)                                  \
@@ -275,18 +277,16 @@ spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, int touch_lines, const int* 
 
   // Tile DMA.  A tile is TL_KB B rows x 512 B; a wave issues TL_KB/32 of its LDS-DMA instructions (1 KB each:
   // instruction j of wave w carries rows 32j + 2w and 32j + 2w + 1).  Full tiles are issued from inside
-  // the phase asm through a per-thread source pointer that walks down B 32 rows at a time (v[22:23]);
+  // the phase asm through a per-thread source pointer that walks down B one round of rows at a time (`dptr`);
   // the last, partial tile goes through `issue_partial`, rows past K clamped to row K-1 (no entry
   // refers to them).
   const int nfull = DBG == 2 ? 0 : (int)(K / TL_KB);
   const int64_t row_step = (2 * TL_WAVES) * ldb * (int64_t)sizeof(T);  // rows covered by one round of DMA instructions
   const unsigned m0wave = (unsigned)wv * 2048u;  // LDS offset of this wave's first row pair (buffer 0)
-  {
-    const T* p0 = b + (int64_t)(tid >> 5) * ldb + (tid & 31) * (16 / (int)sizeof(T));
-    asm volatile("v_mov_b32 v22, %0\n\tv_mov_b32 v23, %1" ::"v"((unsigned)((uintptr_t)p0 & 0xffffffffu)),
-                 "v"((unsigned)((uintptr_t)p0 >> 32))
-                 : "v22", "v23");
-  }
+  // walking source pointer of this thread's share of the tile DMA: an in/out operand of the asm blocks, so that it
+  // lives in registers the compiler knows about (state parked in "clobbered" registers between asm blocks is only safe
+  // while the compiler happens not to need them)
+  uint64_t dptr = (uint64_t)(uintptr_t)(b + (int64_t)(tid >> 5) * ldb + (tid & 31) * (16 / (int)sizeof(T)));
   auto issue_partial = [&](int t) {
 #pragma unroll
     for (int i = 0; i < TL_DMA_PER_TILE; ++i) {
@@ -300,7 +300,7 @@ spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, int touch_lines, const int* 
   const bool has_partial = DBG != 2 && (int64_t)nfull * TL_KB < K;  // tile `nfull` is the partial one
 
   if (nfull > 0)
-    asm volatile(TL_ASM_TILE0 ::[m0wave] "s"(m0wave), [step] "s"(row_step) : "memory", "m0", "scc", "vcc", "s89", "v22", "v23");
+    asm volatile(TL_ASM_TILE0 : [dptr] "+v"(dptr) : [m0wave] "s"(m0wave), [step] "s"(row_step) : "memory", "m0", "scc", "vcc", "s89");
   else if (has_partial)
     issue_partial(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -336,7 +336,7 @@ spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, int touch_lines, const int* 
       asm volatile("global_load_dword v61, %0, off" ::"v"(reinterpret_cast<const char*>(stream + (int64_t)o0 * 16) + l * 64)
                    : "memory", "v61");
     }
-    tl_phases<MODE>(stream, t, te, o0, o1, o2, offreg, obase, ntiles, nfull, toff, (int)0xfffffe00, m0wave, row_step);
+    tl_phases<MODE>(stream, t, te, o0, o1, o2, offreg, obase, ntiles, nfull, toff, (int)0xfffffe00, m0wave, row_step, dptr);
     t = te;
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

@@ -147,3 +147,18 @@ def test_tiled_stream_slack_covers_the_line_touch(hiplib):
     for code in (0, 1):   # SPAMD_F32, SPAMD_F64
         assert hiplib.spamd_spmm_tiled_params(code, *[C.byref(v) for v in vals]) == 0
         assert vals[4].value >= 64 + 3
+
+
+def test_compiler_stays_out_of_the_tiled_kernel_accumulators():
+    """The tiled SpMM executor keeps its accumulators in fixed VGPRs across several asm blocks; the compiler's own code
+    runs between them.  tools/check_tiled_regs.py cross-compiles the kernel and verifies that no compiler-generated
+    instruction touches that register block (a dropped `amdgpu_num_vgpr` request would corrupt results silently)."""
+    import shutil
+    import subprocess
+    import sys
+
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_tiled_regs.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

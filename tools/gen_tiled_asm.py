@@ -6,7 +6,7 @@ executor (csrc/spmm_tiled.hip) as C string literals.  Run after changing the reg
 
 Register map (must match spmm_tiled.hip):
     v0..v21    compiler (kernel is capped with amdgpu_num_vgpr(22))
-    v22..v23   walking source pointer of the wave's tile-DMA share
+    (the walking source pointer of the wave's tile-DMA share is an in/out operand: the compiler keeps it)
     v24..v39   eight ds_read_b64 results, set 1 (software-pipelined loop)
     v40..v43   LDS address temporaries          v44..v59  eight ds_read_b64 results, set 0
     v60        LDS base of the current tile + 8*lane    v61  destination of the line touches
@@ -104,14 +104,14 @@ def p2_exact(buf, dset):
 
 
 def dma_body():
-    """one tile-DMA instruction of the NEXT tile: from the walking source pointer v[22:23] (advanced by 32 B rows)
+    """one tile-DMA instruction of the NEXT tile: from the walking source pointer %[dptr] (a compiler-owned in/out register pair, advanced one round of B rows)
     to LDS address s89 (advanced by 16 row pairs = 32 KB of the interleaved buffers; the s_add also is the wait state
     M0 needs before an LDS-DMA), and one
     bit less in the pending mask (VCC)"""
     return ["s_mov_b32 m0, s89",
             f"s_add_u32 s89, s89, {hex(WAVES * 2048)}",
-            "global_load_lds_dwordx4 v[22:23], off",
-            "v_lshl_add_u64 v[22:23], %[step], 0, v[22:23]",
+            "global_load_lds_dwordx4 %[dptr], off",
+            "v_lshl_add_u64 %[dptr], %[step], 0, %[dptr]",
             "s_lshr_b64 vcc, vcc, 1"]
 
 
@@ -293,7 +293,7 @@ def main():
            lit("TL_ASM_STORE", store()),
            lit("TL_ASM_ZERO", zero()),
            f"#define TL_CLOB_SGPR {clob('s', 36, 95)}\n",
-           f"#define TL_CLOB_TMP {clob('v', 22, 61)}\n",
+           f"#define TL_CLOB_TMP {clob('v', 24, 61)}\n",
            f"#define TL_CLOB_ACC {clob('v', JUNK, ACC0 + 2 * ROWS - 1)}\n"]
     p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "sparse_amd", "csrc", "spmm_tiled_asm.inc")
     with open(p, "w") as f:
