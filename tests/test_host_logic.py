@@ -162,3 +162,61 @@ def test_compiler_stays_out_of_the_tiled_kernel_accumulators():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_tiled_regs.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+class _Shape:
+    def __init__(self, *shape):
+        self.shape = shape
+
+
+@pytest.mark.parametrize("call,terms,out", [
+    (("ab,bc", _Shape(2, 3), _Shape(3, 4)), ["ab", "bc"], "ac"),
+    (("ab,bc->ca", _Shape(2, 3), _Shape(3, 4)), ["ab", "bc"], "ca"),
+    (("...ab,...b->...a", _Shape(5, 2, 3), _Shape(3)), ["zab", "b"], "za"),
+    (("a...,a...", _Shape(2, 3, 4), _Shape(2, 4)), ["ayz", "az"], "yz"),
+    (("aab->b", _Shape(2, 2, 3)), ["aab"], "b"),
+    (("ba", _Shape(2, 3)), ["ba"], "ab"),
+    ((_Shape(4, 4), [0, 0]), ["AA"], ""),
+    ((_Shape(4, 4), [Ellipsis, 1], [Ellipsis]), ["zB"], "z"),
+    ((",ab,->ab", _Shape(), _Shape(2, 3), _Shape()), ["", "ab", ""], "ab"),
+])
+def test_einsum_subscript_normalisation(call, terms, out):
+    """`parse_einsum` (sparse_amd/_einsum.py): explicit labels for every ellipsis (right-aligned), the classical implicit
+    output (ellipsis labels, then the labels that occur once, sorted), the sublist calling form — the grammar of
+    `numpy.einsum` that the reference's parser accepts (_common.py:1163-1323)."""
+    from sparse_amd._einsum import parse_einsum
+
+    got_terms, got_out, arrays = parse_einsum(call)
+    assert got_terms == terms and got_out == out and len(arrays) == len(terms)
+
+
+@pytest.mark.parametrize("bad,exc", [(("a+b->c", _Shape(2), _Shape(2)), ValueError), (("i->&", _Shape(2)), ValueError),
+                                     (("i->ij", _Shape(2)), ValueError), (("ij->jij", _Shape(2, 2)), ValueError),
+                                     (("a..,a...", _Shape(2), _Shape(2)), ValueError), ((".i...", _Shape(2, 2)), ValueError),
+                                     (("a,a->->", _Shape(2), _Shape(2)), ValueError), ((), ValueError),
+                                     (("ab", _Shape(2)), ValueError), (("a", _Shape(2, 2)), ValueError),
+                                     ((0, _Shape(2), _Shape(2)), TypeError), (([0, 0], _Shape(2), _Shape(2)), TypeError)])
+def test_einsum_subscript_errors(bad, exc):
+    from sparse_amd._einsum import parse_einsum
+
+    with pytest.raises(exc):
+        parse_einsum(bad)
+
+
+def test_basic_index_normalisation():
+    """`_indexing._normalise`: ellipsis expansion, trailing full slices, and the IndexError / NotImplementedError
+    contracts, independent of any device work."""
+    from sparse_amd._indexing import _normalise
+
+    full = slice(None)
+    assert _normalise(2, 3) == (2, full, full)
+    assert _normalise((Ellipsis, 1), 3) == (full, full, 1)
+    assert _normalise((0, Ellipsis, None, 1), 4) == (0, full, full, None, 1)
+    assert _normalise((None, slice(1, 3)), 2) == (None, slice(1, 3), full)
+    assert _normalise((), 0) == ()
+    for bad in ((0, 0, 0), (Ellipsis, Ellipsis), ("a",), (1.5,)):
+        with pytest.raises(IndexError):
+            _normalise(bad, 2)
+    for fancy in ([0, 1], np.array([0, 1])):
+        with pytest.raises(NotImplementedError):
+            _normalise((fancy,), 2)
