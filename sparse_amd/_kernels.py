@@ -668,6 +668,7 @@ def tiled_params(dtype=torch.float32):
 
 
 TILED_DTYPES = (torch.float32, torch.float64)
+_TOUCH_OVERRIDE = int(__import__("os").environ.get("SPARSE_AMD_TILED_TOUCH", "0"))   # tuning hook: lines prefetched per list
 
 
 def csr_tiled_layout(a_data, a_indices, a_indptr, M, Kd, force_sort=False, dtype=None):
@@ -735,6 +736,8 @@ def dot_csr_ndarray_tiled(layout, out_shape, Kd, b, out=None, exact=False):
     # prefetch hint: ~1.5 x the mean number of 64-byte blocks per (row group, tile) list
     lists = max(int(blk_off.numel()) - 1, 1)
     hint = min(64, max(6, int(1.5 * (int(blocks.numel()) // 16) / lists) + 3))
+    if _TOUCH_OVERRIDE:
+        hint = _TOUCH_OVERRIDE
     _ffi.call("spamd_spmm_tiled", code_of(dtype), M, Kd, N, ptr(blocks), ptr(blk_off), ptr(b), N, ptr(out), N,
               (_ffi.EXACT_MULADD if exact else 0) | (hint << 8), stream_ptr(dev))
     return out
