@@ -447,6 +447,42 @@ def gen_select(sp):
     _save("select", **cases)
 
 
+def gen_einsum(sp):
+    """N4: einsum through the real reference (`_common.py:1400-1476`): values, result format and dtype."""
+    cases = {}
+    pats = ["ab,bc->ac", "ab,cb", "abc,cd->abd", "aab,bc->ac", "ab,ab->a", "a,ab,abc->abc", "abc->ca", "aa->a", "ab,bc,cd->ad",
+            "...ab,...b->...a", "bca,cdb,dbf,afc->", "ab,b->ab"]
+    rng = np.random.default_rng(77)
+    for k, pat in enumerate(pats):
+        terms = pat.split("->")[0].split(",")
+        ops = []
+        for j, t in enumerate(terms):
+            nd = len(t.replace("...", "x"))
+            d = rng.random((4,) * nd) - 0.3
+            d[rng.random(d.shape) < 0.6] = 0.0
+            cases[f"e{k}_op{j}"] = d
+            ops.append(sp.COO.from_numpy(d))
+        r = sp.einsum(pat, *ops)
+        cases[f"e{k}_pat"] = np.array(pat)
+        cases[f"e{k}_n"] = np.array(len(ops))
+        cases[f"e{k}_dense"] = r.todense()
+        cases[f"e{k}_nnz"] = np.array(r.nnz)
+    cases["n_einsum"] = np.array(len(pats))
+    # result formats (reference tests/test_einsum.py `format_test_cases`)
+    a = rng.random((2, 2, 2)); a[rng.random(a.shape) < 0.4] = 0
+    b = rng.random((2, 2, 2)); b[rng.random(b.shape) < 0.4] = 0
+    cases.update(fa=a, fb=b)
+    fm = []
+    for fa_, fb_ in (("coo", "coo"), ("gcxs", "gcxs"), ("coo", "gcxs"), ("coo", "dense"), ("dense", "gcxs")):
+        oa = a if fa_ == "dense" else sp.COO.from_numpy(a).asformat(fa_)
+        ob = b if fb_ == "dense" else sp.COO.from_numpy(b).asformat(fb_)
+        r = sp.einsum("abc,cda->abd", oa, ob)
+        fm.append(f"{fa_},{fb_},{type(r).__name__.lower()}")
+        cases[f"f_{fa_}_{fb_}"] = r.todense()
+    cases["formats"] = np.array(fm)
+    _save("einsum", **cases)
+
+
 def main():
     sp = ref_loader.load()
     print("reference:", sp.__file__)
@@ -457,6 +493,7 @@ def main():
     gen_nd(sp)
     gen_matrix(sp)
     gen_select(sp)
+    gen_einsum(sp)
 
 
 if __name__ == "__main__":

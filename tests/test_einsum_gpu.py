@@ -113,3 +113,28 @@ def test_einsum_spmm_pattern_uses_the_matmul_kernels():
     assert r.format == "gcxs" and np.array_equal(r.todense(), (a @ b).cpu().numpy())
     r2 = sp.einsum("ij,jk->ki", a, b)
     assert np.array_equal(r2.todense(), (a @ b).cpu().numpy().T)
+
+
+@pytest.mark.gpu
+def test_einsum_against_reference_fixture():
+    """tests/golden/einsum.npz: what the real reference's `einsum` returned for the same operands
+    (oracle/gen_golden.py `gen_einsum`) — values, stored-element counts and result formats."""
+    import os
+
+    import sparse_amd as sp
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "einsum.npz"))
+    for k in range(int(g["n_einsum"])):
+        pat = str(g[f"e{k}_pat"])
+        ops = [sp.COO.from_numpy(g[f"e{k}_op{j}"]) for j in range(int(g[f"e{k}_n"]))]
+        r = sp.einsum(pat, *ops)
+        want = g[f"e{k}_dense"]
+        assert r.shape == want.shape and np.allclose(r.todense(), want, rtol=1e-13, atol=1e-15), pat
+        assert r.nnz <= max(int(g[f"e{k}_nnz"]), 1), pat   # never more stored elements than the reference keeps
+    a, b = g["fa"], g["fb"]
+    for entry in g["formats"]:
+        fa_, fb_, want_fmt = str(entry).split(",")
+        oa = a if fa_ == "dense" else sp.COO.from_numpy(a).asformat(fa_)
+        ob = b if fb_ == "dense" else sp.COO.from_numpy(b).asformat(fb_)
+        r = sp.einsum("abc,cda->abd", oa, ob)
+        assert r.format == want_fmt and np.allclose(r.todense(), g[f"f_{fa_}_{fb_}"], rtol=1e-13, atol=1e-15), entry
