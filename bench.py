@@ -1,33 +1,35 @@
 #!/usr/bin/env python
 """bench.py — BASELINE.json headline metric: GCXS(CSR) x dense SpMM on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling strong|weak]
 
-Workload (BASELINE.json configs[1]): A = CSR 10^6 x 10^4 at 1 % (exactly 10^8 stored
-elements, uniform, sorted column indices, int32 indices, explicit compressed_axes=(0,)),
-B = dense 10^4 x 128 fp32, C = A @ B dense 10^6 x 128 fp32.  Inputs are generated on the
-device (synthetic) and are resident in HBM before the timed region.  One "step" = one SpMM
-through the product path (`sparse_amd.matmul`).  The product path caches a K-tiled block stream of A
-on the array at its first product (inspector/executor: C ABI `spamd_spmm_tiled*`,
-csrc/spmm_tiled.hip); the bench builds it before the warm-up and reports the one-time cost as
-`config.preprocess_ms` (`preprocess_warm_ms` with a warm allocator) and the rate of the cache-less kernel
-(`spamd_spmm_csr`) as
-`config.first_call_gflops` — `value` is the steady state of repeated products with the same A.
-`--no-tiled` benches the cache-less kernel only.
+Workload (BASELINE.json configs[1]): A = CSR 10^6 x 10^4 at 1 % (exactly 10^8 stored elements, uniform, sorted column
+indices, int32 indices, explicit compressed_axes=(0,)), B = dense 10^4 x 128 fp32, C = A @ B dense 10^6 x 128 fp32.
+Inputs are generated on the device (synthetic) and are resident in HBM before the timed region.  One "step" = one
+product through the product API (`sparse_amd.matmul`, the reference's NaN pass of `matmul` INCLUDED).  The product path
+caches a K-tiled block stream of A on the array at its first product (inspector/executor: C ABI `spamd_spmm_tiled*`,
+csrc/spmm_tiled.hip); `value` is the steady state of repeated products with the same A, and the same line carries what
+a FIRST product costs (`config.first_call_ms` = inspector + executor with a warm allocator, `first_call_cold_ms` = the
+same in a fresh process, `rowgroup_ms` = the general cache-less kernel).  `--no-tiled` benches the row-group kernel only.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling — every rank owns a
-10^6-row block of a (N*10^6) x 10^4 matrix (row-block sharding of the compressed axis), B is
-row-sharded and each step starts with one RCCL all-gather of B (the path's only exchange
-step); C stays row-sharded.  value = N * flops / max-over-ranks time.
+N > 1: `python bench.py --gpus N` re-launches itself under `python -m torch.distributed.run` (one rank per GPU, RCCL);
+launched by torch.distributed.run directly it reads RANK / LOCAL_RANK / WORLD_SIZE.  Two modes:
+  --scaling strong (default)  the ONE 10^8-nnz matrix is split into N nnz-balanced row blocks (`partition_rows_by_nnz`);
+                              B arrives row-sharded and every step starts with one RCCL all-gather of B (the path's only
+                              exchange step); C stays row-sharded.  value = total flops / max-over-ranks time.
+  --scaling weak              every rank owns its own 10^6-row block of an (N*10^6) x 10^4 matrix; same exchange.
 
-The JSON line also carries `roofline` (HBM-bound, algorithmic bytes / measured kernel time;
-`traffic` from the committed rocprofv3 PMC pass if present) and, on rank 0 at N=1,
-`cpu_baseline`: the oracle's single-thread C restatement of the reference loop timed on
-this box's host CPU.
+The JSON line also carries `roofline` (HBM-bound: algorithmic bytes of one launch / the kernel's average duration,
+measured with HIP events around K back-to-back launches of the executor on the launch stream; `traffic` is read from the
+committed rocprofv3 PMC pass and labelled with its source), on rank 0 at N=1 `cpu_baseline` (the oracle's single-thread
+C restatement of the reference loop, rebuilt with -march=native on this box, plus SciPy's csr @ dense as an independent
+cross-check) and `paths`: the other rows of SURVEY.md section 8 at BASELINE.json's sizes (bench_paths.py).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,7 +40,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_MEASURED_GBS = 6290.0  # float4 copy on this part (same guide): the achievable streaming rate
 
 
 def make_csr_device(M, K, density, seed, idx_dtype=torch.int32, dtype=torch.float32, device="cuda"):
@@ -74,37 +77,97 @@ def algorithmic_bytes(M, K, N, nnz, val_bytes, idx_bytes):
     return read, write
 
 
+def dev_time(fn, reps):
+    """Average milliseconds per call, HIP events on torch's current stream (the stream every C-ABI call launches on)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
 def cpu_baseline(data, idx, ptr, b, M, N, gpu_out):
-    """Oracle (single-thread C restatement of `_dot_csr_ndarray`) on the host CPU, same inputs."""
+    """The reference loop on the host CPU, same inputs, ONE thread (the reference's kernels are
+    `@numba.jit(nopython=True, nogil=True)` without prange): (1) the oracle's C restatement rebuilt on THIS box with
+    -march=native, whole workload once; (2) SciPy's `csr_array @ ndarray` on the same inputs as an
+    independent single-thread implementation.  Both are compared with each other and with the GPU."""
     from oracle import build as obuild, oracle
 
-    obuild.build()
+    native = True
+    try:
+        oracle.use_library(obuild.build(native=True))
+    except Exception:
+        native = False
+        obuild.build()
     h = [t.cpu().numpy() for t in (data, idx, ptr, b)]
     t0 = time.perf_counter()
     out = oracle.dot_csr_ndarray((M, N), *h)
     dt = time.perf_counter() - t0
+    oracle.use_library(None)
     flops = 2.0 * h[0].shape[0] * N
     got = gpu_out.cpu().numpy()
     denom = np.maximum(np.abs(out), 1e-30)
     rel = float(np.max(np.abs(got - out) / denom))
-    return {
+    res = {
         "value": flops / dt / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port",
         "sample": f"full workload once: M={M} nnz={h[0].shape[0]} N={N} fp32, {dt:.2f} s on 1 of "
-                  f"{os.cpu_count()} host cores (oracle/oracle.c, gcc -O3 -ffp-contract=off)",
-        "seconds": dt, "gpu_vs_cpu_max_rel_err": rel,
+                  f"{os.cpu_count()} host cores (oracle/oracle.c, gcc -O3 "
+                  f"{'-march=native ' if native else ''}-ffp-contract=off)",
+        "seconds": dt, "gpu_vs_cpu_max_rel_err": rel, "march_native": native,
     }
+    try:
+        import scipy.sparse as ss
+
+        threads = None
+        try:
+            from threadpoolctl import threadpool_limits
+
+            threads = threadpool_limits(limits=1)
+        except Exception:
+            pass
+        a = ss.csr_array((h[0], h[1], h[2]), shape=(M, h[3].shape[0]))
+        t0 = time.perf_counter()
+        ref = a @ h[3]
+        dts = time.perf_counter() - t0
+        if threads is not None:
+            threads.restore_original_limits()
+        res["scipy"] = {"value": flops / dts / 1e9, "unit": "GFLOP/s", "seconds": dts, "cores": 1,
+                        "what": "scipy.sparse.csr_array @ ndarray (csr_matvecs, single thread), whole workload once",
+                        "oracle_vs_scipy_max_rel_err": float(np.max(np.abs(ref - out) / denom)),
+                        "gpu_vs_scipy_max_rel_err": float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-30)))}
+    except Exception as e:
+        res["scipy"] = {"error": repr(e)}
+    return res
 
 
 def load_traffic(kernel_substr):
-    """HBM-side bytes per launch of the named kernel from the committed rocprofv3 PMC pass
-    (profiles/traffic.json: {"kernels": {substr: {"traffic_bytes_per_launch": ...}}}), or None."""
+    """(HBM-side bytes per launch of the named kernel, where the number comes from).  The bytes are NOT measured in this
+    run: they come from the committed rocprofv3 PMC passes (profiles/traffic.json, collected with tools/tools_pmc.sh in
+    separate --pmc runs of this very script and corrected as MI355X_MICROARCH.md prescribes)."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
-        return t["kernels"][kernel_substr]["traffic_bytes_per_launch"]
+        k = t["kernels"][kernel_substr]
+        return k["traffic_bytes_per_launch"], f"profiles/traffic.json (round {k.get('round', t.get('round'))} PMC pass)"
     except Exception:
-        return None
+        return None, None
+
+
+def relaunch_distributed(n):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -112,93 +175,93 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--rows", type=int, default=1_000_000)
     ap.add_argument("--cols", type=int, default=10_000)
     ap.add_argument("--n", type=int, default=128)
     ap.add_argument("--density", type=float, default=0.01)
     ap.add_argument("--idx", choices=["int32", "int64"], default="int32")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-paths", action="store_true", help="skip the other section-8 rows (`paths`)")
+    ap.add_argument("--no-nan-check", action="store_true", help="switch matmul's NaN pass off in the timed region")
     ap.add_argument("--exact", action="store_true", help="bit-exact mul+add instead of FMA")
     ap.add_argument("--no-tiled", action="store_true", help="row-group kernel only (no cached block stream)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} HIP device(s) visible")
+        raise SystemExit(relaunch_distributed(args.gpus))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run "
-                             "(one rank per GPU)")
-        args.gpus = world
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "WORLD_SIZE" in os.environ:
         import torch.distributed as dist
 
         dist.init_process_group(backend="nccl", device_id=device)
+        world = dist.get_world_size()   # what RCCL actually formed, not what the flag asked for
+        rank = dist.get_rank()
 
     import sparse_amd
-    from sparse_amd import _settings
+    from sparse_amd import _dist, _dot, _kernels, _settings
 
-    _settings.NAN_CHECK = False  # the reference's matmul NaN pass is reported separately
+    _settings.NAN_CHECK = not args.no_nan_check  # package default: on (the reference's `matmul` scans both operands)
     _settings.EXACT_MULADD = bool(args.exact)
     if args.no_tiled:
         _settings.TILED_SPMM = "never"
 
     M, K, N = args.rows, args.cols, args.n
     idt = torch.int32 if args.idx == "int32" else torch.int64
-    data, idx, ptr = make_csr_device(M, K, args.density, seed=1234 + rank, idx_dtype=idt, device=device)
+    strong = args.scaling == "strong"
+    if strong:
+        # every rank generates the SAME matrix (same seed) and keeps its nnz-balanced row block
+        data_g, idx_g, ptr_g = make_csr_device(M, K, args.density, seed=1234, idx_dtype=idt, device=device)
+        bounds = _dist.partition_rows_by_nnz(ptr_g, world)
+        data, idx, ptr, r0, r1 = _dist.shard_csr(data_g, idx_g, ptr_g, rank, world, bounds)
+        data, idx, ptr = data.contiguous(), idx.contiguous(), ptr.contiguous()
+        global_nnz = int(data_g.numel())
+        del data_g, idx_g, ptr_g
+        Mloc = r1 - r0
+    else:
+        data, idx, ptr = make_csr_device(M, K, args.density, seed=1234 + rank, idx_dtype=idt, device=device)
+        Mloc = M
+        global_nnz = None
     nnz = int(data.numel())
-    a = sparse_amd.GCXS((data, idx, ptr), shape=(M, K), compressed_axes=(0,))
+    a = sparse_amd.GCXS((data, idx, ptr), shape=(Mloc, K), compressed_axes=(0,))
     g = torch.Generator(device=device).manual_seed(99)
     b_full = torch.rand((K, N), generator=g, device=device, dtype=torch.float32)
-    if world > 1:
-        from sparse_amd import _dist
-
+    sharded_b = dist is not None and world > 1
+    if sharded_b:
         b_shard = _dist.row_shard(b_full, rank, world).contiguous()
 
     def step():
-        if world > 1:
-            b = _dist.all_gather_rows(b_shard, K)
-        else:
-            b = b_full
+        b = _dist.all_gather_rows(b_shard, K) if sharded_b else b_full
         return sparse_amd.matmul(a, b)
 
-    def dev_time(fn, reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps
-
-    # cache-less kernel (what a first product with this A costs), then the one-time inspector
-    from sparse_amd import _dot, _kernels
-
-    first_call_ms = preprocess_ms = preprocess_warm_ms = None
+    # ---- what a FIRST product with this A costs (rank-local; all of it outside the timed region) -----------------------
+    rowgroup_ms = first_call_cold_ms = first_call_ms = inspector_ms = None
     tiled = False
-    if _dot._tiled_eligible(a.data, b_full, (M, N), K):
-        rowgroup = lambda: _kernels.dot_csr_ndarray((M, N), data, idx, ptr, b_full, exact=False)
+    if _dot._tiled_eligible(a.data, b_full, (Mloc, N), K):
+        rowgroup = lambda: _kernels.dot_csr_ndarray((Mloc, N), data, idx, ptr, b_full, exact=False)
         rowgroup()
-        first_call_ms = dev_time(rowgroup, 5)
-        t_pre = time.perf_counter()
-        tiled = _dot.prepare_spmm(a)
-        torch.cuda.synchronize()
-        preprocess_ms = (time.perf_counter() - t_pre) * 1e3        # first build: includes ~1 GB of fresh allocations
-        t_pre = time.perf_counter()
-        _kernels.csr_tiled_layout(data, idx, ptr, M, K)
-        torch.cuda.synchronize()
-        preprocess_warm_ms = (time.perf_counter() - t_pre) * 1e3   # the same build with a warm allocator
+        rowgroup_ms = dev_time(rowgroup, 5)   # the general cache-less kernel (every dtype / shape the executor does not take)
 
-    # the NaN pass of the reference's `matmul` (_common.py:245-246) is switched off in the timed region; its cost per
-    # product (values of A: memoised on the array after the first product; B: scanned every time) is reported
-    _settings.NAN_CHECK = True
-    _dot.check_class_nan(a)
-    nan_check_ms = dev_time(lambda: (_dot.check_class_nan(a), _dot.check_class_nan(b_full)), 5)
-    _settings.NAN_CHECK = False
+        def first_product():
+            _dot.drop_derived(a)               # forget the cached block stream: inspector + executor, as at a first product
+            return _dot._gcxs_times_dense(a, b_full, (Mloc, N))
+
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        first_product()
+        torch.cuda.synchronize()
+        first_call_cold_ms = (time.perf_counter() - t0) * 1e3   # fresh process: includes ~1 GB of first-time allocations
+        first_call_ms = dev_time(first_product, 3)             # warm allocator (a program that has multiplied before)
+        inspector_ms = dev_time(lambda: _kernels.csr_tiled_layout(data, idx, ptr, Mloc, K), 3)
+        tiled = _dot.prepare_spmm(a)
 
     for _ in range(args.warmup):
         out = step()
@@ -206,62 +269,98 @@ def main():
     if dist is not None:
         dist.barrier()
         torch.cuda.synchronize()
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record()
     for _ in range(args.steps):
         out = step()
-    ev1.record()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
         torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
 
     tmax = torch.tensor([wall], device=device, dtype=torch.float64)
+    nnz_all = torch.tensor([float(nnz)], device=device, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        gathered = [torch.zeros_like(nnz_all) for _ in range(world)]
+        dist.all_gather(gathered, nnz_all)
+        nnz_ranks = [int(t.item()) for t in gathered]
+    else:
+        nnz_ranks = [nnz]
     wall = float(tmax.item())
     ms_per_step = wall / args.steps * 1e3
 
+    # ---- the dominant kernel alone: K back-to-back launches of the executor between two HIP events --------------------
+    if tiled:
+        layout = a._tiled_layouts[torch.float32]
+        kern = lambda: _kernels.dot_csr_ndarray_tiled(layout, (Mloc, N), K, b_full, out=out, exact=bool(args.exact))
+    else:
+        kern = lambda: _kernels.dot_csr_ndarray((Mloc, N), data, idx, ptr, b_full, exact=bool(args.exact), out=out)
+    kern()
+    kernel_ms = dev_time(kern, args.steps)
+    nan_check_ms = None
+    if _settings.NAN_CHECK:
+        _settings.NAN_CHECK = False
+        no_nan_ms = dev_time(lambda: sparse_amd.matmul(a, b_full), args.steps)
+        _settings.NAN_CHECK = True
+        with_nan_ms = dev_time(lambda: sparse_amd.matmul(a, b_full), args.steps)
+        nan_check_ms = with_nan_ms - no_nan_ms
+
     if rank == 0:
-        flops = 2.0 * nnz * N
-        rd, wr = algorithmic_bytes(M, K, N, nnz, 4, 4 if idt == torch.int32 else 8)
-        kernel_ms = dev_ms / args.steps  # HIP events on the launch stream, kernel(s) only at N=1
+        total_nnz = sum(nnz_ranks)
+        flops_total = 2.0 * total_nnz * N
+        flops_local = 2.0 * nnz * N
+        ib = 4 if idt == torch.int32 else 8
+        rd, wr = algorithmic_bytes(Mloc, K, N, nnz, 4, ib)
         ach = (rd + wr) / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_src = load_traffic("spmm_tiled" if tiled else "spmm_csr")
         line = {
             "metric": "GCXS x dense SpMM throughput (GFLOP/s)",
-            "value": world * flops / (ms_per_step * 1e-3) / 1e9,
+            "value": flops_total / (ms_per_step * 1e-3) / 1e9,
             "unit": "GFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"GCXS(CSR, compressed_axes=(0,)) {M}x{K} @ {args.density:g} "
-                            f"({nnz} nnz/GPU, {args.idx} indices) x dense {K}x{N} fp32 -> dense {M}x{N}",
-                "per_gpu_rows": M, "nnz_per_gpu": nnz, "idx_dtype": args.idx,
-                "parallelism": f"row-block x{world}" + (" + all-gather(B)" if world > 1 else ""),
+                "workload": (f"GCXS(CSR, compressed_axes=(0,)) {M}x{K} @ {args.density:g} ({global_nnz} nnz, {args.idx} indices)"
+                             f" split into {world} nnz-balanced row block(s)" if strong else
+                             f"GCXS(CSR, compressed_axes=(0,)) {world}x({M}x{K}) @ {args.density:g} ({nnz} nnz/GPU, {args.idx} indices)")
+                            + f" x dense {K}x{N} fp32 -> dense, row-sharded",
+                "world_size": world, "nnz_per_rank": nnz_ranks,
+                "nnz_imbalance": max(nnz_ranks) / (total_nnz / world) if total_nnz else 1.0,
+                "rows_rank0": Mloc, "idx_dtype": args.idx,
+                "parallelism": f"row-block x{world}" + (" + RCCL all-gather(B) per step" if sharded_b else ""),
                 "mul_add": "separate (bit-exact)" if args.exact else "fma",
+                "nan_check_in_timed_region": bool(_settings.NAN_CHECK), "nan_check_ms_per_product": nan_check_ms,
                 "kernel": "spmm_tiled (cached block stream)" if tiled else "spmm_csr_rowgroup",
-                "preprocess_ms": preprocess_ms, "preprocess_warm_ms": preprocess_warm_ms,
-                "first_call_ms": first_call_ms, "nan_check_ms_per_product": nan_check_ms,
-                "first_call_gflops": flops / (first_call_ms * 1e-3) / 1e9 if first_call_ms else None,
+                "first_call_ms": first_call_ms, "first_call_cold_ms": first_call_cold_ms,
+                "first_call_gflops": flops_local / (first_call_ms * 1e-3) / 1e9 if first_call_ms else None,
+                "inspector_ms": inspector_ms, "rowgroup_ms": rowgroup_ms,
+                "rowgroup_gflops": flops_local / (rowgroup_ms * 1e-3) / 1e9 if rowgroup_ms else None,
             },
             "roofline": {
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": load_traffic("spmm_tiled" if tiled else "spmm_csr"),
+                "frac": ach / HBM_PEAK_GBS, "frac_of_measured_copy_rate": ach / HBM_MEASURED_GBS,
+                "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes": rd + wr, "algorithmic_read_bytes": rd,
                 "read_only_frac": rd / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "kernel_ms": kernel_ms, "gflops_per_gpu": flops / (kernel_ms * 1e-3) / 1e9,
+                "kernel_ms": kernel_ms, "gflops_per_gpu": flops_local / (kernel_ms * 1e-3) / 1e9,
+                "what": "rank 0's launch: algorithmic bytes of its row block / average of `steps` back-to-back executor launches (HIP events)",
             },
         }
         if world == 1 and not args.no_cpu:
             try:
-                line["cpu_baseline"] = cpu_baseline(data, idx, ptr, b_full, M, N, out)
+                line["cpu_baseline"] = cpu_baseline(data, idx, ptr, b_full, Mloc, N, out)
             except Exception as e:  # the bench line must still be printed
                 line["cpu_baseline"] = {"error": repr(e)}
+        if world == 1 and not args.no_paths:
+            del out
+            try:
+                import bench_paths
+
+                line["paths"] = bench_paths.run(int64_of=(data, idx, ptr, b_full, M, K, N), verbose=False)
+            except Exception as e:
+                line["paths"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

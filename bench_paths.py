@@ -1,27 +1,32 @@
 #!/usr/bin/env python
-"""bench_paths.py — the other rows of SURVEY.md §8(a) at BASELINE.json's config sizes.
+"""bench_paths.py — the other rows of SURVEY.md section 8(a) at BASELINE.json's config sizes.
 
-bench.py carries the headline metric (config 2, A1).  This script times the remaining
-hot-path rows through the product API with inputs resident in HBM, and reports each against
-its own roofline (algorithmic bytes per SURVEY.md §8d / kernel time at 8 TB/s):
+bench.py carries the headline metric (config 2, A1) and embeds `run()`'s result as `paths` in its JSON line.  Each row is
+timed through the product API (or the raw-array kernel layer where stated) with inputs resident in HBM, HIP events on
+the launch stream, and reported against its own HBM roofline: algorithmic bytes / time / 8 TB/s.
+Where the CPU can check the result in seconds, the row carries a `cpu_baseline` leg: the oracle (oracle/oracle.py, test
+infrastructure) evaluates the same inputs — or a stated sample of them — on ONE host core, is timed, and the GPU result
+is compared with it (`max_rel_err`; 0.0 = bit-identical).
 
-    python bench_paths.py [--quick]      -> one JSON line per row, also written to
-                                            gpurun_out/paths.json
+    python bench_paths.py [--quick] [--rows A3,A7,...]   -> the dict as JSON (also gpurun_out/paths.json)
 
-Rows: A7 elementwise add/mul + A8 sum on config 1; A3 3-D COO tensordot (config 3, f64 and
-f32); A9 SDDMM (config 4, bf16 in / fp32 acc); A2 CSC x dense incl. the CSC->CSR
-re-compression; A6 COO->GCXS conversion; A4 SpGEMM at a single-GPU size.
+Rows: A7 elementwise add/multiply and A8 sums on config 1 (+ the same at 10^8 nnz: the streaming regime); A3 3-D COO
+tensordot (config 3, f64/int64 and f32/int32); A9 SDDMM (config 4; sampled kernel and the MFMA dense-tile kernel, plus a
+block-clustered mask where the dense tiles win); A4 SpGEMM at one GPU's share of config 5; A6 conversions; A2 CSC x
+dense; A1 with int64 indices and in float64.
 """
 import argparse
 import json
 import os
 import sys
+import time
 
 import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 HBM = 8000.0
 
 
@@ -38,156 +43,283 @@ def timed(fn, reps=5, warm=1):
     return e0.elapsed_time(e1) / reps, r
 
 
-def line(row, workload, ms, bytes_alg, flops=None, **extra):
-    d = {"row": row, "workload": workload, "ms": ms, "algorithmic_bytes": bytes_alg,
-         "GBps": bytes_alg / ms / 1e6, "frac_hbm_8TBs": bytes_alg / ms / 1e6 / HBM}
+def row(workload, ms, bytes_alg, flops=None, **extra):
+    d = {"workload": workload, "ms": ms, "algorithmic_bytes": int(bytes_alg),
+         "GBps": bytes_alg / ms / 1e6, "frac": bytes_alg / ms / 1e6 / HBM}
     if flops:
         d["GFLOPs"] = flops / ms / 1e6
     d.update(extra)
-    print(json.dumps(d), flush=True)
     return d
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--quick", action="store_true", help="1/10 sizes")
-    args = ap.parse_args()
-    q = 10 if args.quick else 1
-    import sparse_amd as sp
-    from sparse_amd import _settings
+def rel_err(got, want):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    if got.shape != want.shape:
+        return float("inf")
+    if got.size == 0:
+        return 0.0
+    return float(np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-300)))
 
+
+def cpu_leg(fn, sample):
+    t0 = time.perf_counter()
+    want = fn()
+    return want, {"seconds": time.perf_counter() - t0, "cores": 1, "kind": "port", "sample": sample}
+
+
+def run(quick=False, only=None, verbose=True, int64_of=None):
+    """Returns {row id: {...}}.  `int64_of` = (data, idx, ptr, b, M, K, N) of bench.py's config-2 operands: the A1 row
+    with the reference-default int64 indices is timed on the same matrix."""
+    import sparse_amd as sp
+    from sparse_amd import _dot, _kernels as K, _settings
+    from oracle import oracle
+
+    q = 10 if quick else 1
+    nan_was = _settings.NAN_CHECK
     _settings.NAN_CHECK = False
-    out = []
+    out = {}
     dev = torch.device("cuda")
 
-    # ---- config 1: COO + COO, (1000,1000,1000), 1e6 nnz each, f64 / int64 -----------------------
-    nnz = 1_000_000 // q
-    x = sp.random((1000, 1000, 1000), nnz=nnz, random_state=0)
-    y = sp.random((1000, 1000, 1000), nnz=nnz, random_state=1)
-    def with_coords(f):  # results are built on linear keys; `.coords` splits them on demand
-        def g():
-            r = f()
-            r.coords
-            return r
-        return g
+    def want(rid):
+        return only is None or any(rid.startswith(o) for o in only)
 
-    for name, f in (("add", lambda: x + y), ("multiply", lambda: x * y), ("add + .coords", with_coords(lambda: x + y))):
-        ms, z = timed(f)
-        b = 2 * nnz * (3 * 8 + 8) + z.nnz * (3 * 8 + 8)
-        out.append(line(f"A7 elementwise {name}", f"COO(1000^3, {nnz} nnz, f64/int64) {name} COO", ms, b,
-                        out_nnz=z.nnz))
-    z = x + y
-    ms, s = timed(lambda: z.sum(axis=2))
-    out.append(line("A8 reduce sum(axis=2)", f"COO(1000^3, {z.nnz} nnz) sum over last axis", ms,
-                    z.nnz * 16 + s.nnz * 16, groups=s.nnz))
-    ms, s = timed(lambda: z.sum(axis=0))
-    out.append(line("A8 reduce sum(axis=0)", f"COO(1000^3, {z.nnz} nnz) sum over FIRST axis (needs key sort)", ms,
-                    z.nnz * 16 + s.nnz * 16, groups=s.nnz))
+    def emit(rid, d):
+        out[rid] = d
+        if verbose:
+            print(json.dumps({"row": rid, **d}), flush=True)
 
-    # ---- the same rows at 100x the size (streaming regime rather than launch-bound) -----------------
-    if not args.quick:
-        nb = 100_000_000
-        xb = sp.random((1000, 1000, 1000), nnz=nb, random_state=10)
-        yb = sp.random((1000, 1000, 1000), nnz=nb, random_state=11)
-        for name, f in (("add", lambda: xb + yb), ("multiply", lambda: xb * yb),
-                        ("add + .coords", with_coords(lambda: xb + yb))):
-            ms, z = timed(f, reps=3)
-            out.append(line(f"A7 elementwise {name} (1e8 nnz)", f"COO(1000^3, {nb} nnz each) {name}", ms,
-                            2 * nb * 32 + z.nnz * 32, out_nnz=z.nnz))
-        ms, s = timed(lambda: xb.sum(axis=2), reps=3)
-        out.append(line("A8 reduce sum(axis=2) (1e8 nnz)", "runs of ~100 elements, two-pass grouped reduce", ms, nb * 16 + s.nnz * 16))
-        del xb, yb, z, s
+    # ---- A1 with int64 indices (the reference's default index width) on bench.py's own matrix -------------------------
+    if int64_of is not None and want("A1_int64"):
+        data, idx, ptr, b, M, Kd, N = int64_of
+        i64, p64 = idx.to(torch.int64), ptr.to(torch.int64)
+        a64 = sp.GCXS((data, i64, p64), shape=(M, Kd), compressed_axes=(0,))
+        nnz = int(data.numel())
+        bytes64 = nnz * 12 + (M + 1) * 8 + Kd * N * 4 + M * N * 4
+        ms_rg, _ = timed(lambda: K.dot_csr_ndarray((M, N), data, i64, p64, b), reps=3)
+        ms_first, _ = timed(lambda: (_dot.drop_derived(a64), _dot._gcxs_times_dense(a64, b, (M, N)))[1], reps=3)
+        ms, r = timed(lambda: a64 @ b, reps=10)
+        emit("A1_int64_idx", row(f"config 2 with int64 indices/indptr: GCXS(CSR) {M}x{Kd} ({nnz} nnz) x dense {Kd}x{N} fp32", ms, bytes64,
+                                 flops=2.0 * nnz * N, first_call_ms=ms_first, rowgroup_ms=ms_rg,
+                                 rowgroup_frac=bytes64 / ms_rg / 1e6 / HBM,
+                                 note="steady state reads the cached block stream (index width no longer matters); "
+                                      "first_call_ms = inspector + executor, rowgroup_ms = the cache-less kernel on int64 indices"))
+        del a64, i64, p64, r
+        torch.cuda.empty_cache()
 
-    # ---- config 3: 3-D COO tensordot with dense, axes=1 ------------------------------------------
-    side = 512 if not args.quick else 128
-    nnz3 = int(side ** 3 * 0.01)
-    for dt, it in ((np.float64, "int64"), (np.float32, "int32")):
-        c3 = sp.random((side, side, side), nnz=nnz3, random_state=2, dtype=dt, idx_dtype=np.dtype(it))
-        d = torch.rand((side, side), device=dev, dtype=torch.float64).to(torch.float64 if dt == np.float64 else torch.float32)
-        ms, r = timed(lambda: sp.tensordot(c3, d, axes=1))
-        vb, ib = np.dtype(dt).itemsize, np.dtype(it).itemsize
-        M, N = side * side, side
-        b = nnz3 * (2 * ib + vb) + side * N * vb + M * N * vb
-        out.append(line(f"A3 tensordot COO x dense ({np.dtype(dt).name}/{it})",
-                        f"COO({side}^3 @1%, {nnz3} nnz) . dense({side},{side}), axes=1 (incl. N-D->2-D reshape)", ms, b,
-                        flops=2.0 * nnz3 * N))
-        # repeated products with the SAME operand: with `enable_caching()` (reference `COO(cache=True)`, core.py:317-338) the
-        # reshaped 2-D operand is memoised, so its tiled block stream is built at the second product and reused
-        c3.enable_caching()
-        for _ in range(3):
-            sp.tensordot(c3, d, axes=1)
-        ms, r = timed(lambda: sp.tensordot(c3, d, axes=1))
-        out.append(line(f"A3 tensordot, cached operand ({np.dtype(dt).name}/{it})",
-                        "same product, operand created with caching: tiled executor from the third call on", ms, b,
-                        flops=2.0 * nnz3 * N))
-        at = c3.reshape((M, side))
-        from sparse_amd import _kernels as K
+    # ---- config 1: COO + COO, (1000,1000,1000), 1e6 nnz each, f64 / int64 ---------------------------------------------
+    if want("A7") or want("A8"):
+        nnz = 1_000_000 // q
+        x = sp.random((1000, 1000, 1000), nnz=nnz, random_state=0)
+        y = sp.random((1000, 1000, 1000), nnz=nnz, random_state=1)
+        hx = (x.linear_loc().cpu().numpy(), x.data.cpu().numpy())
+        hy = (y.linear_loc().cpu().numpy(), y.data.cpu().numpy())
+        for name, f, uf in (("add", lambda: x + y, np.add), ("multiply", lambda: x * y, np.multiply)):
+            if not want("A7"):
+                break
+            ms, z = timed(f)
+            b = 2 * nnz * (3 * 8 + 8) + z.nnz * (3 * 8 + 8)
+            (wk, wv, _, _), leg = cpu_leg(lambda: oracle.elemwise_zero_fill(uf, hx[0], hx[1], hy[0], hy[1]),
+                                          "whole workload once (oracle.elemwise_zero_fill: NumPy sorted-key union of the "
+                                          "reference's mask enumeration, _umath.py:457-503)")
+            leg["keys_bit_exact"] = bool(np.array_equal(z.linear_loc().cpu().numpy(), wk))
+            leg["max_rel_err"] = rel_err(z.data.cpu().numpy(), wv) if leg["keys_bit_exact"] else None
+            emit(f"A7_{name}_config1", row(f"config 1: COO(1000^3, {nnz} nnz, f64/int64) {name} COO", ms, b, out_nnz=z.nnz,
+                                           cpu_baseline=leg))
+        if want("A8"):
+            z = x + y
+            hk, hv = z.linear_loc().cpu().numpy(), z.data.cpu().numpy()
+            for ax in (2, 0):
+                ms, s = timed(lambda: z.sum(axis=ax))
 
-        ms, r = timed(lambda: K.dot_coo_ndarray(at.coords, at.data, d, (M, N)))
-        out.append(line(f"A3 kernel only ({np.dtype(dt).name}/{it})", "rows->indptr + CSR kernel on the reshaped operand",
-                        ms, b, flops=2.0 * nnz3 * N))
+                def cpu_sum():
+                    if ax == 2:
+                        grp, vals = hk // 1000, hv
+                    else:   # kept axes first: stable sort by (j, k), the reference's transpose + reshape (_coo/core.py:1601-1661)
+                        grp = hk % 1_000_000
+                        o = np.argsort(grp, kind="stable")
+                        grp, vals = grp[o], hv[o]
+                    red, heads, _ = oracle.grouped_reduce(vals, grp, np.add)
+                    return grp[heads], red
 
-    # ---- config 4: SDDMM mask 1e5 x 1e5 @ 0.1 %, K = 256, bf16 ------------------------------------
-    Ms = 100_000 // (3 if args.quick else 1)
-    nnz4 = int(Ms * Ms * 0.001)
-    s = sp.random((Ms, Ms), nnz=nnz4, random_state=3, dtype=np.float32, idx_dtype=np.int32)
-    for dtn, tdt, esz in (("bf16", torch.bfloat16, 2), ("f32", torch.float32, 4)):
-        a = torch.rand((Ms, 256), device=dev).to(tdt)
-        bt = torch.rand((Ms, 256), device=dev).to(tdt)
-        from sparse_amd import _kernels as K
+                (wk, wv), leg = cpu_leg(cpu_sum, "whole workload once (oracle.grouped_reduce: stable sort + np.add.reduceat)")
+                leg["keys_bit_exact"] = bool(np.array_equal(s.linear_loc().cpu().numpy(), wk))
+                leg["max_rel_err"] = rel_err(s.data.cpu().numpy(), wv) if leg["keys_bit_exact"] else None
+                emit(f"A8_sum_axis{ax}_config1", row(f"config 1: COO(1000^3, {z.nnz} nnz).sum(axis={ax})"
+                                                     + (" (needs a key sort)" if ax == 0 else ""), ms,
+                                                     z.nnz * 16 + s.nnz * 16, groups=s.nnz, cpu_baseline=leg))
+        del x, y
+        if not quick and want("A7_1e8"):
+            nb = 100_000_000
+            xb = sp.random((1000, 1000, 1000), nnz=nb, random_state=10)
+            yb = sp.random((1000, 1000, 1000), nnz=nb, random_state=11)
+            for name, f in (("add", lambda: xb + yb), ("multiply", lambda: xb * yb)):
+                ms, z = timed(f, reps=3)
+                emit(f"A7_1e8_{name}", row(f"COO(1000^3, {nb} nnz each) {name} (streaming regime)", ms, 2 * nb * 32 + z.nnz * 32,
+                                           out_nnz=z.nnz))
+            ms, s = timed(lambda: xb.sum(axis=2), reps=3)
+            emit("A8_1e8_sum_axis2", row("COO(1000^3, 1e8 nnz).sum(axis=2): runs of ~100 elements", ms, nb * 16 + s.nnz * 16))
+            del xb, yb, z, s
+            torch.cuda.empty_cache()
 
-        ms, r = timed(lambda: K.sddmm_coo(s.coords, s.data, a, bt))
-        b = nnz4 * (2 * 4 + 4) + 2 * Ms * 256 * esz + nnz4 * 4
-        out.append(line(f"A9 SDDMM kernel ({dtn} in, fp32 acc)", f"mask COO({Ms}x{Ms}, {nnz4} nnz) (.) A({Ms}x256) Bt({Ms}x256)",
-                        ms, b, flops=2.0 * 256 * nnz4, gather_bytes=nnz4 * 2 * 256 * esz,
-                        gather_TBps=nnz4 * 2 * 256 * esz / ms / 1e9))
+    # ---- config 3: 3-D COO tensordot with dense, axes=1 ----------------------------------------------------------------
+    if want("A3"):
+        side = 512 if not quick else 128
+        nnz3 = int(side ** 3 * 0.01)
+        for dt, it in ((np.float64, "int64"), (np.float32, "int32")):
+            c3 = sp.random((side, side, side), nnz=nnz3, random_state=2, dtype=dt, idx_dtype=np.dtype(it))
+            d = torch.rand((side, side), device=dev, dtype=torch.float64).to(torch.float64 if dt == np.float64 else torch.float32)
+            ms, r = timed(lambda: sp.tensordot(c3, d, axes=1))
+            vb, ib = np.dtype(dt).itemsize, np.dtype(it).itemsize
+            M, N = side * side, side
+            b = nnz3 * (2 * ib + vb) + side * N * vb + M * N * vb
+            at = c3.reshape((M, side))
+            hc, hd, hb = at.coords.cpu().numpy(), at.data.cpu().numpy(), d.cpu().numpy()
+            wr, leg = cpu_leg(lambda: oracle.dot_coo_ndarray(hc, hd, hb, (M, N)),
+                              "whole workload once (oracle.c restatement of _dot_coo_ndarray)")
+            leg["value"], leg["unit"] = 2.0 * nnz3 * N / leg["seconds"] / 1e9, "GFLOP/s"
+            leg["max_rel_err"] = rel_err(r.reshape(M, N).cpu().numpy(), wr)
+            ms_k, _ = timed(lambda: K.dot_coo_ndarray(at.coords, at.data, d, (M, N)))
+            emit(f"A3_tensordot_{np.dtype(dt).name}", row(
+                f"config 3: COO({side}^3 @1%, {nnz3} nnz, {np.dtype(dt).name}/{it}) . dense({side},{side}), axes=1 "
+                "(N-D -> 2-D reshape included)", ms, b, flops=2.0 * nnz3 * N, kernel_only_ms=ms_k, cpu_baseline=leg))
+            del c3, at, r
 
-    # ---- A2 / A6: CSC x dense and format conversion at config-2/10 size ----------------------------
-    from bench import make_csr_device
+    # ---- config 4: SDDMM mask 1e5 x 1e5 @ 0.1 %, K = 256 ----------------------------------------------------------------
+    if want("A9"):
+        Ms = 100_000 // (3 if quick else 1)
+        nnz4 = int(Ms * Ms * 0.001)
+        s = sp.random((Ms, Ms), nnz=nnz4, random_state=3, dtype=np.float32, idx_dtype=np.int32)
+        rng = np.random.default_rng(0)
+        pick = np.sort(rng.choice(nnz4, size=min(20000, nnz4), replace=False))
+        hrow, hcol = s.coords[0][pick].cpu().numpy(), s.coords[1][pick].cpu().numpy()
+        hs = s.data[pick].cpu().numpy().astype(np.float64)
+        for dtn, tdt, esz in (("bf16", torch.bfloat16, 2), ("f32", torch.float32, 4)):
+            a = torch.rand((Ms, 256), device=dev).to(tdt)
+            bt = torch.rand((Ms, 256), device=dev).to(tdt)
+            ms, r = timed(lambda: K.sddmm_coo(s.coords, s.data, a, bt))
+            b = nnz4 * (2 * 4 + 4) + 2 * Ms * 256 * esz + nnz4 * 4
+            ha, hb = a[hrow].to(torch.float64).cpu().numpy(), bt[hcol].to(torch.float64).cpu().numpy()
+            wv, leg = cpu_leg(lambda: hs * np.einsum("ik,ik->i", ha, hb),
+                              f"{len(pick)} of {nnz4} samples in float64 on the host (the reference forms the whole dense product)")
+            terms = np.abs(hs) * np.einsum("ik,ik->i", np.abs(ha), np.abs(hb))
+            leg["max_err_over_sum_abs_terms"] = float(np.max(np.abs(r[pick].cpu().numpy().astype(np.float64) - wv) / terms))
+            emit(f"A9_sddmm_{dtn}", row(f"config 4: mask COO({Ms}x{Ms}, {nnz4} nnz) (.) A({Ms}x256) Bt({Ms}x256), {dtn} in / fp32 acc, "
+                                        "sampled kernel", ms, b, flops=2.0 * 256 * nnz4, gather_bytes=nnz4 * 2 * 256 * esz,
+                                        gather_TBps=nnz4 * 2 * 256 * esz / ms / 1e9, cpu_baseline=leg))
+        if hasattr(K, "sddmm_tiles") and want("A9_mfma"):
+            out.update(_sddmm_mfma_rows(sp, K, s, Ms, quick, emit))
+        del s, a, bt, r
+        torch.cuda.empty_cache()
 
-    M2, K2 = 1_000_000 // (10 * q) * 10, 10_000
-    M2 = max(M2 // 10, 1000)
-    data, idx, ptr = make_csr_device(M2, K2, 0.01, seed=5)
-    a_csr = sp.GCXS((data, idx, ptr), shape=(M2, K2), compressed_axes=(0,))
-    nn = a_csr.nnz
-    ms, a_csc = timed(lambda: a_csr.change_compressed_axes((1,)), reps=3)
-    out.append(line("A6 change_compressed_axes CSR->CSC", f"GCXS {M2}x{K2} @1% ({nn} nnz, f32/int32)", ms,
-                    2 * nn * 8 + (M2 + K2) * 4))
-    bmat = torch.rand((K2, 128), device=dev)
-    ms, r = timed(lambda: a_csc @ bmat, reps=3)
-    out.append(line("A2 CSC x dense (re-compress + SpMM)", f"GCXS(csc) {M2}x{K2} @1% x dense {K2}x128", ms,
-                    nn * 8 + K2 * 128 * 4 + M2 * 128 * 4, flops=2.0 * nn * 128))
-    ms, coo = timed(lambda: a_csr.tocoo(), reps=3)
-    out.append(line("A6 GCXS->COO", f"{nn} nnz", ms, nn * 8 + nn * 12))
-    ms, g = timed(lambda: sp.GCXS.from_coo(coo, compressed_axes=(1,)), reps=3)
-    out.append(line("A6 COO->GCXS(ca=1)", f"{nn} nnz (key permute + radix sort + split)", ms, nn * 12 + nn * 8))
+    # ---- A2 / A6: CSC x dense and format conversion at 10^7 nnz --------------------------------------------------------
+    if want("A6") or want("A2"):
+        from bench import make_csr_device
 
-    # ---- A1 in float64 (the reference's default dtype) at the config-2 shape ---------------------------------
-    if not args.quick:
+        M2, K2 = (100_000 // q), 10_000
+        data, idx, ptr = make_csr_device(M2, K2, 0.01, seed=5)
+        a_csr = sp.GCXS((data, idx, ptr), shape=(M2, K2), compressed_axes=(0,))
+        nn = a_csr.nnz
+        ms, a_csc = timed(lambda: a_csr.change_compressed_axes((1,)), reps=3)
+        ok = None
+        try:
+            import scipy.sparse as ss
+
+            ref = ss.csr_array((data.cpu().numpy(), idx.cpu().numpy(), ptr.cpu().numpy()), shape=(M2, K2)).tocsc()
+            ok = bool(np.array_equal(ref.indices, a_csc.indices.cpu().numpy()) and np.array_equal(ref.indptr, a_csc.indptr.cpu().numpy())
+                      and np.array_equal(ref.data, a_csc.data.cpu().numpy()))
+        except Exception:
+            pass
+        emit("A6_csr_to_csc", row(f"GCXS {M2}x{K2} @1% ({nn} nnz, f32/int32) change_compressed_axes CSR->CSC", ms,
+                                  2 * nn * 8 + (M2 + K2) * 4, bit_identical_to_scipy_tocsc=ok))
+        bmat = torch.rand((K2, 128), device=dev)
+        ms, r = timed(lambda: a_csc @ bmat, reps=3)
+        emit("A2_csc_x_dense", row(f"GCXS(csc) {M2}x{K2} @1% x dense {K2}x128 (CSR twin memoised after the first product)", ms,
+                                   nn * 8 + K2 * 128 * 4 + M2 * 128 * 4, flops=2.0 * nn * 128))
+        ms, coo = timed(lambda: a_csr.tocoo(), reps=3)
+        emit("A6_gcxs_to_coo", row(f"GCXS -> COO, {nn} nnz", ms, nn * 8 + nn * 12))
+        ms, g = timed(lambda: sp.GCXS.from_coo(coo, compressed_axes=(1,)), reps=3)
+        emit("A6_coo_to_gcxs", row(f"COO -> GCXS(compressed_axes=(1,)), {nn} nnz (key permute + radix sort + split)", ms, nn * 12 + nn * 8))
+        del a_csr, a_csc, coo, g, r, data, idx, ptr
+
+    # ---- A1 in float64 (the reference's default dtype) at the config-2 shape ------------------------------------------
+    if not quick and want("A1_f64"):
+        from bench import make_csr_device
+
         d64, i64_, p64 = make_csr_device(1_000_000, 10_000, 0.01, seed=9, dtype=torch.float64)
         a64 = sp.GCXS((d64, i64_, p64), shape=(1_000_000, 10_000), compressed_axes=(0,))
         b64 = torch.rand((10_000, 128), device=dev, dtype=torch.float64)
         a64 @ b64
         ms, r = timed(lambda: a64 @ b64, reps=5)
         nn64 = int(d64.numel())
-        out.append(line("A1 GCXS x dense, float64 (tiled kernel)", "GCXS(CSR) 1e6x1e4 @1% (1e8 nnz, f64/int32) x dense 1e4x128",
-                        ms, nn64 * 12 + 10_000 * 128 * 8 + 1_000_000 * 128 * 8, flops=2.0 * nn64 * 128))
+        emit("A1_f64", row("config-2 shape in float64: GCXS(CSR) 1e6x1e4 @1% (1e8 nnz, f64/int32) x dense 1e4x128", ms,
+                           nn64 * 12 + 10_000 * 128 * 8 + 1_000_000 * 128 * 8, flops=2.0 * nn64 * 128))
         del a64, d64, i64_, p64, b64, r
         torch.cuda.empty_cache()
 
-    # ---- A4: SpGEMM at a single-GPU size --------------------------------------------------------------
-    torch.cuda.empty_cache()  # the ESC workspace (~38 GB) should not fight the caching allocator
-    n4 = 100_000 // q
-    g = sp.random((n4, n4), density=1e-4 * (q if args.quick else 1) * 10, random_state=7, dtype=np.float32,
-                  idx_dtype=np.int32, format="gcxs", compressed_axes=(0,))
-    ms, c = timed(lambda: g @ g, reps=3, warm=2)
-    prods = float((g.indptr[1:] - g.indptr[:-1]).double()[g.indices.long()].sum())
-    out.append(line("A4 SpGEMM G@G (row-local expand-sort-compress in LDS)", f"GCXS {n4}x{n4}, {g.nnz} nnz, {int(prods)} products -> {c.nnz} nnz",
-                    ms, g.nnz * 8 + prods * 8 + c.nnz * 8, flops=2.0 * prods))
+    # ---- A4: SpGEMM, one GPU's share of config 5 (10^6 x 10^6 @ 1e-4, squared, 8 row blocks) ----------------------------
+    if want("A4"):
+        torch.cuda.empty_cache()
+        n5 = 1_000_000 // q
+        share = 8
+        gB = sp.random((n5, n5), density=1e-4 * (q if quick else 1), random_state=7, dtype=np.float32, idx_dtype=np.int32,
+                       format="gcxs", compressed_axes=(0,))
+        rows = n5 // share
+        p1 = int(gB.indptr[rows])
+        gA = sp.GCXS((gB.data[:p1].contiguous(), gB.indices[:p1].contiguous(), gB.indptr[:rows + 1].contiguous()),
+                     shape=(rows, n5), compressed_axes=(0,))
+        ms, c = timed(lambda: gA @ gB, reps=3, warm=1)
+        prods = float((gB.indptr[1:] - gB.indptr[:-1]).double()[gA.indices.long()].sum())
+        # sampled check: 200 rows of the block against the oracle's Gustavson restatement on the host
+        rng = np.random.default_rng(1)
+        pick = np.sort(rng.choice(rows, size=min(200, rows), replace=False))
+        hA = [t.cpu().numpy() for t in (gA.data, gA.indices, gA.indptr)]
+        hB = [t.cpu().numpy() for t in (gB.data, gB.indices, gB.indptr)]
+        sub_ptr = np.zeros(len(pick) + 1, dtype=hA[2].dtype)
+        segs = [np.arange(hA[2][r_], hA[2][r_ + 1]) for r_ in pick]
+        sub_ptr[1:] = np.cumsum([len(s_) for s_ in segs])
+        sel = np.concatenate(segs) if segs else np.zeros(0, dtype=np.int64)
+        (wd, wi, wp), leg = cpu_leg(lambda: oracle.dot_csr_csr((len(pick), n5), hA[0][sel], hB[0], hA[1][sel], hB[1], sub_ptr, hB[2]),
+                                    f"{len(pick)} of {rows} rows of the block (oracle.c restatement of _dot_csr_csr), canonically sorted")
+        cp, ci, cd = c.indptr.cpu().numpy(), None, None
+        worst, same_cols = 0.0, True
+        ci_all, cd_all = c.indices, c.data
+        for j, r_ in enumerate(pick):
+            lo, hi = int(cp[r_]), int(cp[r_ + 1])
+            gi, gd = ci_all[lo:hi].cpu().numpy(), cd_all[lo:hi].cpu().numpy()
+            wl, wh = int(wp[j]), int(wp[j + 1])
+            o = np.argsort(wi[wl:wh], kind="stable")
+            keep = wd[wl:wh][o].view(np.uint32) != 0   # the GCXS constructor prunes explicit +0.0 results
+            same_cols &= bool(np.array_equal(gi, wi[wl:wh][o][keep]))
+            if same_cols:
+                worst = max(worst, rel_err(gd, wd[wl:wh][o][keep]))
+        leg["indices_bit_exact"], leg["max_rel_err"] = same_cols, worst
+        emit("A4_spgemm_config5_share", row(
+            f"one of {share} row blocks of config 5: GCXS({rows}x{n5}, {gA.nnz} nnz) @ GCXS({n5}x{n5}, {gB.nnz} nnz), {int(prods)} products "
+            f"-> {c.nnz} nnz (f32/int32)", ms, gA.nnz * 8 + prods * 8 + c.nnz * 8, flops=2.0 * prods, products=prods,
+            ns_per_product=ms * 1e6 / max(prods, 1), cpu_baseline=leg))
+        del gA, gB, c
 
+    _settings.NAN_CHECK = nan_was
+    return out
+
+
+def _sddmm_mfma_rows(sp, K, s, Ms, quick, emit):
+    """A9 with the MFMA dense-tile kernel: config 4's uniform mask (expected: the sampled kernel wins) and a
+    block-clustered mask of the same nnz (dense 32x32 tiles: MFMA wins).  Filled in by the round-2 MFMA path."""
+    from sparse_amd import _sddmm_tiles
+
+    return _sddmm_tiles.bench_rows(sp, K, s, Ms, quick, emit, row, timed)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true", help="1/10 sizes")
+    ap.add_argument("--rows", default=None, help="comma-separated row-id prefixes (A7,A3,...)")
+    args = ap.parse_args()
+    res = run(quick=args.quick, only=args.rows.split(",") if args.rows else None)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "paths.json"), "w") as f:
-        json.dump(out, f, indent=1)
+        json.dump(res, f, indent=1)
 
 
 if __name__ == "__main__":

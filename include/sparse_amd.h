@@ -122,6 +122,11 @@ int spamd_spmm_tiled(int val_dtype, int64_t M, int64_t K, int64_t N, const int* 
  *   16-byte aligned.  val_dtype: F32 | F64 (I32 | I64 accepted: flag = 0).
  * ------------------------------------------------------------------------------------- */
 int spamd_has_nan(int val_dtype, int64_t n, const void* data, int* flag, void* stream);
+/* The same scan, asynchronous: `host_flag` is the device-accessible address of a PINNED host int the caller has set
+ * to 0; the kernel stores 1 there if it meets a NaN.  The caller records an event behind this call and reads the int
+ * after waiting on that event alone, so the product queued behind the scan is not drained (reference: the blocking
+ * `check_class_nan` pass of `matmul`, _common.py:245-246). */
+int spamd_has_nan_async(int val_dtype, int64_t n, const void* data, int* host_flag, void* stream);
 
 /* =======================================================================================
  * T1-T3 / A6  Canonicalisation and format conversion on 64-bit C-order linear keys.
@@ -144,6 +149,11 @@ int spamd_coo_delinearize(int idx_dtype, int ndim, int64_t nnz, const int64_t* k
 /* keys_out = C-order key after moving source axis perm[d] to destination position d */
 int spamd_permute_keys(int ndim, int64_t nnz, const int64_t* keys_in, const int64_t* src_strides,
                        const int64_t* src_dims, const int32_t* perm, int64_t* keys_out, void* stream);
+/* flag[0] = 1 if any coords[d][i] lies outside [0, dims[d]) (device int32[1]).  The reference constructor
+ * (_coo/core.py:198-291) trusts its caller; this backend checks, because a bad coordinate becomes an
+ * out-of-bounds key for spamd_scatter. */
+int spamd_coords_check(int idx_dtype, int ndim, int64_t nnz, const void* coords, int64_t coord_stride,
+                       const int64_t* dims, int* flag, void* stream);
 /* flags2[0] = keys not non-decreasing, flags2[1] = some adjacent keys equal (device int32[2]) */
 int spamd_keys_check(int64_t n, const int64_t* keys, int* flags2, void* stream);
 /* flags[i] = 1 where a run of equal keys starts (int64 0/1, ready for spamd_exclusive_scan) */

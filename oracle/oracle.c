@@ -12,7 +12,9 @@
  * oracle/gen_golden.py produced by executing the real reference source).
  * Single-threaded, like the reference (`@numba.jit(nopython=True, nogil=True)`, no prange).
  *
- * Build: see oracle/build.py  (gcc -O3 -march=native -ffp-contract=off -shared -fPIC).
+ * Build: see oracle/build.py — the checker is `gcc -O3 -ffp-contract=off -shared -fPIC` (generic x86-64, so the .so
+ * built in the container also runs on the GPU box); bench.py's cpu_baseline leg rebuilds it ON the timed box with
+ * -march=native added (oracle/_build/liboracle_native.so).
  */
 #include <stdint.h>
 #include <stdlib.h>

@@ -22,6 +22,13 @@ _SUFFIX = {np.dtype("float32"): "f32", np.dtype("float64"): "f64",
            np.dtype("int32"): "i32", np.dtype("int64"): "i64"}
 
 
+def use_library(path):
+    """Swap the loaded shared library (bench.py's cpu_baseline leg: the -march=native build of the same source,
+    oracle/build.py `build(native=True)`); returns the previous path-or-None.  `None` restores the default."""
+    global _LIB
+    _LIB = None if path is None else ctypes.CDLL(path)
+
+
 def lib():
     global _LIB
     if _LIB is None:

@@ -55,8 +55,8 @@ def sddmm(s, a, b=None, *, bt=None):
     return out.asformat("gcxs", compressed_axes=s.compressed_axes) if out_gcxs else out
 
 
-def random(shape, density=None, nnz=None, random_state=None, format="coo", fill_value=None, idx_dtype=None,
-           dtype=np.float64, device=None, **kwargs):
+def random(shape, density=None, nnz=None, random_state=None, data_rvs=None, format="coo", fill_value=None,
+           idx_dtype=None, dtype=None, device=None, **kwargs):
     """Random sparse array generated ON THE DEVICE: uniform-without-replacement positions,
     values U[0, 1) — the distribution of the reference's `sparse.random` (_utils.py:221-346; its
     Vitter sampler is a sequential loop).  The random stream is torch's, not NumPy's: same
@@ -77,7 +77,15 @@ def random(shape, density=None, nnz=None, random_state=None, format="coo", fill_
         raise ValueError(f"Cannot generate {nnz} nonzero elements for an array with {size} total elements.")
     d = torch.device(device) if device is not None else dev.default_device()
     g = torch.Generator(device=d)
-    g.manual_seed(int(random_state) if random_state is not None else torch.seed() % (2 ** 31))
+    if random_state is None:
+        seed = int(np.random.SeedSequence().generate_state(1)[0])   # fresh entropy; torch's global RNG is left alone
+    elif isinstance(random_state, np.random.Generator):
+        seed = int(random_state.integers(2 ** 31))
+    elif isinstance(random_state, np.random.RandomState):
+        seed = int(random_state.randint(2 ** 31))
+    else:
+        seed = int(random_state)
+    g.manual_seed(seed % (2 ** 63))
     if nnz > size // 2 and size <= 2 ** 31:
         keys = torch.randperm(size, generator=g, device=d)[:nnz].sort().values
     else:
@@ -90,7 +98,14 @@ def random(shape, density=None, nnz=None, random_state=None, format="coo", fill_
             keep = torch.ones(keys.numel(), dtype=torch.bool, device=d)
             keep[torch.randperm(keys.numel(), generator=g, device=d)[: keys.numel() - nnz]] = False
             keys = keys[keep]
-    data = torch.rand(nnz, generator=g, device=d, dtype=torch.float64).to(dev.torch_dtype(dtype))
+    if data_rvs is not None:
+        # the reference's contract (_utils.py:313-322): data_rvs(nnz) returns the stored values; evaluated on the host
+        vals = np.asarray(data_rvs(nnz))
+        if vals.shape != (nnz,):
+            raise ValueError("data_rvs must return an array of length nnz")
+            data = torch.from_numpy(np.ascontiguousarray(vals if dtype is None else vals.astype(dtype))).to(d)
+    else:
+        data = torch.rand(nnz, generator=g, device=d, dtype=torch.float64).to(dev.torch_dtype(dtype or np.float64))
     it = torch.int64 if idx_dtype is None or np.dtype(idx_dtype).itemsize > 4 else torch.int32
     coords = K.delinearize(keys.contiguous(), shape, it)
     out = COO(coords, data, shape=shape, has_duplicates=False, sorted=True, fill_value=fill_value)

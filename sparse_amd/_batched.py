@@ -171,7 +171,9 @@ def matmul_blockdiag(a, b):
         from ._gcxs import GCXS
 
         return res if isinstance(a, GCXS) and isinstance(b, GCXS) else res.asformat("coo")
-    bt = b if isinstance(b, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(b)).to(a.device)
+    # a NumPy `b` goes through `dot` as an ndarray, so the result comes back as an ndarray (drop-in: NumPy in -> NumPy
+    # out, like the 2-D path and the per-slice loop); a device tensor stays on the device
+    bt = b if isinstance(b, torch.Tensor) else np.ascontiguousarray(b)
     res = dot(big, bt.reshape(B * Kd, N))
     return res.reshape(lead + (M, N))
 

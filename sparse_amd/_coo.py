@@ -166,6 +166,10 @@ class COO(SparseArray, NDArrayOperatorsMixin):
                 keys = torch.zeros(self.nnz, dtype=torch.int64, device=self.device)
                 self._sum_runs(keys)
             return
+        if not K.coords_in_range(self.coords, self.shape):
+            # (the reference trusts its caller here; an out-of-range coordinate would turn into an out-of-bounds
+            # scatter on the device, so this backend refuses it)
+            raise IndexError(f"coords contain entries outside the array shape {self.shape}")
         keys = K.linearize(self.coords, self.shape)
         unsorted, dup = K.keys_check(keys)
         if do_sort and unsorted:
@@ -224,6 +228,9 @@ class COO(SparseArray, NDArrayOperatorsMixin):
         self.fill_value = other.fill_value
         self._cache = None
         self._keys = getattr(other, "_keys", None)
+        from ._dot import drop_derived
+
+        drop_derived(self)   # CSR view / tiled block streams / NaN verdict were built from the old buffers
 
     def copy(self, deep=True):
         if not deep:
@@ -293,6 +300,9 @@ class COO(SparseArray, NDArrayOperatorsMixin):
     def to_scipy_sparse(self, accept_fv=None):
         import scipy.sparse
 
+        from ._utils import check_fill_value
+
+        check_fill_value(self, accept_fv=accept_fv)
         if self.ndim != 2:
             raise ValueError("Can only convert a 2-dimensional array to a Scipy sparse matrix.")
         c = dev.to_numpy(self.coords)

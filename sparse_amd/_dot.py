@@ -143,9 +143,10 @@ def tensordot(a, b, axes=2, *, return_type=None):
     return res.reshape(tuple(olda + oldb))
 
 
-def check_class_nan(x):
+def check_class_nan(x, deferred=False):
     """True if any stored value / dense element is NaN (reference _common.py:72-92, the full
-    pass `matmul` makes before multiplying, :245)."""
+    pass `matmul` makes before multiplying, :245).  `deferred=True` returns either a bool (known without a scan) or a
+    zero-argument callable that yields the verdict of a scan already launched on the stream."""
     from ._coo import COO
     from ._gcxs import GCXS
 
@@ -165,12 +166,21 @@ def check_class_nan(x):
         memo = getattr(x, "_nan_memo", None)
         if memo is not None and memo[0] == key:
             return memo[1]
-        res = K.has_nan(data)
-        try:
-            x._nan_memo = (key, res)
-        except AttributeError:
-            pass
-        return res
+
+        def remember(res):
+            try:
+                x._nan_memo = (key, res)
+            except AttributeError:
+                pass
+            return res
+
+        if deferred:
+            probe = K.has_nan_async(data)
+            return probe if isinstance(probe, bool) else (lambda: remember(probe.result()))
+        return remember(K.has_nan(data))
+    if deferred:
+        probe = K.has_nan_async(data)
+        return probe if isinstance(probe, bool) else probe.result
     return K.has_nan(data)
 
 
@@ -179,9 +189,19 @@ def matmul(a, b):
     check_zero_fill_value(a, b)
     if not hasattr(a, "ndim") or not hasattr(b, "ndim"):
         raise TypeError(f"Cannot perform dot product on types {type(a)}, {type(b)}")
-    if _settings.NAN_CHECK and (check_class_nan(a) or check_class_nan(b)):
+    if not _settings.NAN_CHECK:
+        return _matmul(a, b)
+    # the reference scans both operands before multiplying (_common.py:245-246) only to WARN; here the scans are
+    # launched, the product is queued behind them, and the verdicts are read afterwards from pinned host memory (the
+    # host waits for the scan kernels only, never for the product)
+    probes = [check_class_nan(a, deferred=True), check_class_nan(b, deferred=True)]
+    res = _matmul(a, b)
+    if builtins.any(p if isinstance(p, bool) else p() for p in probes):
         warnings.warn("Nan will not be propagated in matrix multiplication", RuntimeWarning, stacklevel=1)
+    return res
 
+
+def _matmul(a, b):
     if b.ndim <= 2:
         return dot(a, b)
     if a.ndim <= 2:
@@ -275,6 +295,37 @@ def _tiled_eligible(data, bt, out_shape, Kd):
     return M >= 65536 and (per_list >= 12 or (per_list >= 6 and Kd * N * bt.element_size() >= (16 << 20)))
 
 
+DERIVED_CACHES = ("_csr_view", "_csr_twin", "_tiled_layouts", "_spmm_uses", "_nan_memo", "_derived_stamp")
+
+
+def drop_derived(a):
+    """Forget every layout derived from the stored arrays of `a` (CSR view / twin, tiled block streams, NaN verdict).
+    Called whenever the container's buffers are replaced (`_make_shallow_copy_of`, the `out=` path of ufuncs)."""
+    for name in DERIVED_CACHES:
+        a.__dict__.pop(name, None)
+
+
+def _stamp(a):
+    """Identity + version of every stored buffer the derived layouts are built from: in-place writes (`a.data *= 2`,
+    `a.data[i] = x`) bump torch's version counter, a replaced buffer changes the pointer."""
+    bufs = [a.data]
+    if hasattr(a, "indices"):
+        bufs += [a.indices, a.indptr]
+    else:
+        c = a.__dict__.get("_coords")
+        k = getattr(a, "_keys", None)
+        bufs += [t for t in (c, k) if t is not None]
+    return tuple((t.data_ptr(), int(t.numel()), int(t._version)) for t in bufs if isinstance(t, torch.Tensor))
+
+
+def _validate_derived(a):
+    """Drop the derived layouts of `a` if any stored buffer changed since they were built."""
+    st = _stamp(a)
+    if a.__dict__.get("_derived_stamp") != st:
+        drop_derived(a)
+        a.__dict__["_derived_stamp"] = st
+
+
 def prepare_spmm(a, dtype=None):
     """Build (and cache on `a`) the tiled block stream used by `a @ dense` for value type `dtype` (default: a's own
     if float32/float64); returns True if `a` now has one.  The counterpart of the reference's memoised conversions
@@ -287,6 +338,7 @@ def prepare_spmm(a, dtype=None):
     dtype = dtype or (a.data.dtype if a.data.dtype in K.TILED_DTYPES else None)
     if dtype not in K.TILED_DTYPES:
         return False
+    _validate_derived(a)
     layouts = a.__dict__.setdefault("_tiled_layouts", {})
     if dtype not in layouts:
         d, i, p = _csr_triplet(a)
@@ -300,6 +352,7 @@ def _csr_triplet(a):
     compressed_axes=(argmin(shape),), so tall matrices arrive as csc."""
     from ._coo import COO
 
+    _validate_derived(a)
     if isinstance(a, COO):  # canonical 2-D COO is CSR order already: only the row pointers are missing
         view = getattr(a, "_csr_view", None)
         if view is None:

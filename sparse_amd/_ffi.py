@@ -52,6 +52,7 @@ SIGNATURES = {
     "spamd_coo_delinearize": (_int, [_int, _int, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     "spamd_permute_keys": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spamd_keys_check": (_int, [_i64, _vp, _vp, _vp]),
+    "spamd_coords_check": (_int, [_int, _int, _i64, _vp, _i64, _vp, _vp, _vp]),
     "spamd_flag_heads": (_int, [_i64, _vp, _vp, _vp]),
     "spamd_flag_ne_bits": (_int, [_int, _i64, _vp, _C.c_uint64, _vp, _vp]),
     "spamd_count_eq_bits": (_int, [_int, _i64, _vp, _C.c_uint64, _vp, _vp]),
@@ -99,6 +100,7 @@ SIGNATURES = {
     "spamd_spmm_tiled_pack": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "spamd_spmm_tiled": (_int, [_int, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _u32, _vp]),
     "spamd_has_nan": (_int, [_int, _i64, _vp, _vp, _vp]),
+    "spamd_has_nan_async": (_int, [_int, _i64, _vp, _vp, _vp]),
     "spamd_spmm_csr": (_int, [_int, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _u32, _vp]),
 }
 

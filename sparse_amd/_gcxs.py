@@ -340,10 +340,16 @@ class GCXS(SparseArray, NDArrayOperatorsMixin):
         self.shape = other.shape
         self._compressed_axes = other.compressed_axes
         self.fill_value = other.fill_value
+        from ._dot import drop_derived
+
+        drop_derived(self)   # CSR twin / tiled block streams / NaN verdict were built from the old buffers
 
     def to_scipy_sparse(self, accept_fv=None):
         import scipy.sparse
 
+        from ._utils import check_fill_value
+
+        check_fill_value(self, accept_fv=accept_fv)
         if self.ndim != 2:
             raise ValueError("Can only convert a 2-dimensional array to a Scipy sparse matrix.")
         cls = scipy.sparse.csr_matrix if self.compressed_axes == (0,) else scipy.sparse.csc_matrix

@@ -2,7 +2,9 @@
 
 Each function takes device tensors (raw arrays, no containers), allocates and returns fresh
 outputs — the reference's ownership rule — and launches exactly one C-ABI
-entry point of libsparse_amd.so on the current HIP stream.  No arithmetic happens in torch.
+entry point of libsparse_amd.so (a few for the composite kernels) on the current HIP stream.  The arithmetic of the
+path (products, sums, sorts, scans, merges) happens in that library; torch is used for allocation, views, dtype
+casts of operands and host<->device copies.
 """
 import torch
 
@@ -65,6 +67,39 @@ def has_nan(data):
     flag = torch.empty(1, dtype=torch.int32, device=dev)
     _ffi.call("spamd_has_nan", code_of(data.dtype), data.numel(), ptr(data), ptr(flag), stream_ptr(dev))
     return bool(flag.item())
+
+
+class NanProbe:
+    """A NaN scan in flight: the kernel writes its verdict into a pinned host int; `result()` waits for the event
+    recorded right behind the scan — NOT for whatever was queued after it — and reads the int."""
+
+    _pool = []
+
+    def __init__(self, data):
+        dev = require_hip(data)
+        self.flag = NanProbe._pool.pop() if NanProbe._pool else torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.flag[0] = 0
+        self.event = torch.cuda.Event()
+        _ffi.call("spamd_has_nan_async", code_of(data.dtype), data.numel(), ptr(data), self.flag.data_ptr(), stream_ptr(dev))
+        self.event.record(torch.cuda.current_stream(dev))
+        self._keep = data  # the scanned buffer must outlive the kernel
+
+    def result(self):
+        self.event.synchronize()
+        res = bool(int(self.flag[0]))
+        NanProbe._pool.append(self.flag)
+        self._keep = self.flag = None
+        return res
+
+
+def has_nan_async(data):
+    """`has_nan` without draining the stream: returns a NanProbe (or False when `data` cannot hold a NaN)."""
+    if data.numel() == 0 or not data.is_floating_point():
+        return False
+    data = data.contiguous()
+    if data.data_ptr() % 16:
+        data = data.clone()
+    return NanProbe(data)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -155,6 +190,20 @@ def keys_check(keys):
     _ffi.call("spamd_keys_check", keys.numel(), ptr(keys), ptr(flags), stream_ptr(dev))
     f = flags.tolist()
     return bool(f[0]), bool(f[1])
+
+
+def coords_in_range(coords, shape):
+    """True if every coordinate lies in [0, shape[d]) — one read-only pass, 4 bytes copied back."""
+    dev = require_hip(coords)
+    ndim, nnz = int(coords.shape[0]), int(coords.shape[1])
+    if ndim == 0 or nnz == 0:
+        return True
+    _check_ndim(ndim)
+    coords = coords.contiguous()
+    flag = torch.empty(1, dtype=torch.int32, device=dev)
+    _ffi.call("spamd_coords_check", code_of(coords.dtype), ndim, nnz, ptr(coords), nnz, _harr64(shape), ptr(flag),
+              stream_ptr(dev))
+    return int(flag.item()) == 0
 
 
 def sort_keys(keys, max_key):

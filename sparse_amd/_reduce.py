@@ -24,8 +24,11 @@ def segment_reduce(data, heads, offs, count, op, want_counts=False, sequential=F
     the runs are long enough for the faster wave-per-run tree."""
     dev = require_hip(data)
     n = int(data.numel())
-    if data.dtype == torch.bool:
+    was_bool = data.dtype == torch.bool
+    if was_bool:
+        # NumPy's boolean add / multiply are logical or / and: the 0/1 bytes must never be summed as integers
         data = data.view(torch.uint8)
+        op = {"add": "logical_or", "maximum": "logical_or", "multiply": "logical_and", "minimum": "logical_and"}.get(op, op)
     out = torch.empty(count, dtype=data.dtype, device=dev)
     counts = torch.empty(count, dtype=torch.int64, device=dev) if want_counts else None
     ws = (torch.empty(count + 1, dtype=torch.int64, device=dev)
@@ -33,6 +36,8 @@ def segment_reduce(data, heads, offs, count, op, want_counts=False, sequential=F
     code = _ffi.U8 if data.dtype == torch.uint8 else code_of(data.dtype)
     _ffi.call("spamd_segment_reduce", _RED_OPS[op], code, n, ptr(data.contiguous()), ptr(heads), ptr(offs), count,
               ptr(out), ptr(counts), ptr(ws), stream_ptr(dev))
+    if was_bool:
+        out = out.view(torch.bool)
     return (out, counts) if want_counts else out
 
 

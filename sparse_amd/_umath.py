@@ -29,6 +29,8 @@ _UN = {"negative": 0, "absolute": 1, "abs": 1, "fabs": 1, "sqrt": 2, "exp": 3, "
        "rad2deg": 30, "degrees": 30, "isnan": 64, "isinf": 65, "isfinite": 66, "logical_not": 67, "signbit": 68,
        "conjugate": 22, "conj": 22, "real": 22}
 _TO_BOOL_BIN = set(range(32, 41))
+_BOOL_ARITH = {"add": "logical_or", "maximum": "logical_or", "fmax": "logical_or",
+               "multiply": "logical_and", "minimum": "logical_and", "fmin": "logical_and"}
 _CODE = {torch.float32: _ffi.F32, torch.float64: _ffi.F64, torch.int32: _ffi.I32, torch.int64: _ffi.I64,
          torch.uint8: _ffi.U8, torch.bool: _ffi.U8}
 
@@ -344,6 +346,10 @@ def elemwise(func, *args, **kwargs):
     code = _BIN[name]
     in_np = np.result_type(np_like(a), np_like(b))
     comp_np = in_np if code in _TO_BOOL_BIN or code >= 64 else out_np
+    if comp_np == np.dtype(bool) and name in _BOOL_ARITH:
+        # NumPy's boolean arithmetic is logical (True + True is True): never a raw uint8 add on the 0/1 bytes
+        name = _BOOL_ARITH[name]
+        code = _BIN[name]
     if comp_np not in (np.dtype("f4"), np.dtype("f8"), np.dtype("i4"), np.dtype("i8"), np.dtype("bool"), np.dtype("u1")):
         raise NotImplementedError(f"dtype {comp_np} is not supported by the hip backend's elemwise path")
     comp_t = torch_dtype(comp_np)

@@ -65,6 +65,17 @@ def check_zero_fill_value(*args, loose=True):
             )
 
 
+def check_fill_value(x, /, *, accept_fv=None):
+    """ValueError unless `x.fill_value` is one of `accept_fv` (default: zero only) — the export guard of
+    `to_scipy_sparse` (reference numba_backend/_utils.py:537-559; message is part of the contract)."""
+    if accept_fv is None:
+        accept_fv = [0]
+    if not isinstance(accept_fv, Iterable):
+        accept_fv = [accept_fv]
+    if not any(equivalent(fv, x.fill_value, loose=True) for fv in accept_fv):
+        raise ValueError(f"x.fill_value={x.fill_value!r} but should be in {accept_fv}.")
+
+
 def check_compressed_axes(ndim, compressed_axes):
     """GCXS `compressed_axes` must be a strictly increasing tuple of in-range integer axes that
     leaves at least one axis uncompressed; same ValueError messages as the reference

@@ -5,7 +5,10 @@
 
 namespace spamd {
 
-template <typename T>
+// HOST_FLAG: `flag` is pinned (device-mapped) HOST memory that the caller zeroed before the launch; a plain
+// system-scope store of 1 needs no PCIe atomics, and the host reads it after waiting on an event recorded behind this
+// kernel — so the verdict arrives without draining the product that was queued after the scan.
+template <typename T, bool HOST_FLAG = false>
 __global__ void __launch_bounds__(256) has_nan_kernel(const T* __restrict__ x, int64_t n, int* flag) {
   constexpr int VEC = 16 / sizeof(T);
   using V = Vec<T, VEC>;
@@ -20,7 +23,10 @@ __global__ void __launch_bounds__(256) has_nan_kernel(const T* __restrict__ x, i
     for (int e = 0; e < VEC; ++e) bad |= (v.v[e] != v.v[e]);
   }
   for (int64_t i = nvec * VEC + tid; i < n; i += stride) bad |= (x[i] != x[i]);
-  if (__any(bad) && (threadIdx.x & (SPAMD_WAVE - 1)) == 0) atomicOr(flag, 1);
+  if (__any(bad) && (threadIdx.x & (SPAMD_WAVE - 1)) == 0) {
+    if constexpr (HOST_FLAG) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else atomicOr(flag, 1);
+  }
 }
 
 }  // namespace spamd
@@ -47,6 +53,35 @@ extern "C" int spamd_has_nan(int val_dtype, int64_t n, const void* data, int* fl
     case SPAMD_I32:
     case SPAMD_I64:
       return 0;  // integers cannot hold NaN
+    default:
+      return SPAMD_ETYPE;
+  }
+  return launch_status();
+}
+
+// The same scan with the verdict written straight into pinned host memory (`host_flag`: device-accessible pointer of a
+// pinned int the CALLER has set to 0).  Asynchronous: the caller records an event behind it and reads the int after
+// waiting on that event only.
+extern "C" int spamd_has_nan_async(int val_dtype, int64_t n, const void* data, int* host_flag, void* stream) {
+  using namespace spamd;
+  if (n < 0 || !host_flag) return SPAMD_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) return 0;
+  if (((uintptr_t)data % 16) != 0) return SPAMD_EINVAL;
+  int64_t blocks = ceil_div(n, 256 * 4);
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  switch (val_dtype) {
+    case SPAMD_F32:
+      hipLaunchKernelGGL((has_nan_kernel<float, true>), dim3((unsigned)blocks), dim3(256), 0, s, (const float*)data, n,
+                         host_flag);
+      break;
+    case SPAMD_F64:
+      hipLaunchKernelGGL((has_nan_kernel<double, true>), dim3((unsigned)blocks), dim3(256), 0, s, (const double*)data, n,
+                         host_flag);
+      break;
+    case SPAMD_I32:
+    case SPAMD_I64:
+      return 0;
     default:
       return SPAMD_ETYPE;
   }

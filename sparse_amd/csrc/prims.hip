@@ -61,6 +61,21 @@ __global__ void __launch_bounds__(256) linearize_kernel(const I* __restrict__ co
   }
 }
 
+// flag[0] |= any coordinate outside [0, dims[d])  (the reference trusts its caller; here an out-of-range coordinate
+// would become an out-of-bounds key for `scatter` in todense)
+template <typename I>
+__global__ void __launch_bounds__(256) coords_check_kernel(const I* __restrict__ coords, int64_t cstride,
+                                                           int64_t nnz, DimPack dp, int* __restrict__ flag) {
+  bool bad = false;
+  GRID_STRIDE(i, nnz) {
+    for (int d = 0; d < dp.n; ++d) {
+      const int64_t c = (int64_t)coords[(int64_t)d * cstride + i];
+      bad |= c < 0 || c >= dp.b[d];
+    }
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
 // coords[d][p] = (keys[p] / stride[d]) % dim[d]          (reference core.py:1090-1098 / unravel)
 template <typename I>
 __global__ void __launch_bounds__(256) delinearize_kernel(const int64_t* __restrict__ keys, int64_t nnz,
@@ -296,6 +311,19 @@ extern "C" int spamd_coo_linearize(int idx_dtype, int ndim, int64_t nnz, const v
   if (nnz == 0) return 0;
   SPAMD_IDX_SWITCH(idx_dtype, I, hipLaunchKernelGGL(linearize_kernel<I>, dim3(grid_for(nnz)), dim3(256), 0,
                                                     (hipStream_t)stream, (const I*)coords, coord_stride, nnz, dp, keys))
+  return launch_status();
+}
+
+extern "C" int spamd_coords_check(int idx_dtype, int ndim, int64_t nnz, const void* coords, int64_t coord_stride,
+                                  const int64_t* dims, int* flag, void* stream) {
+  if (nnz < 0 || !flag) return SPAMD_EINVAL;
+  DimPack dp;
+  if (int rc = fill_dims(dp, ndim, nullptr, dims, nullptr)) return rc;
+  hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  if (nnz == 0 || ndim == 0) return 0;
+  SPAMD_IDX_SWITCH(idx_dtype, I, hipLaunchKernelGGL(coords_check_kernel<I>, dim3(grid_for(nnz)), dim3(256), 0,
+                                                    (hipStream_t)stream, (const I*)coords, coord_stride, nnz, dp, flag))
   return launch_status();
 }
 

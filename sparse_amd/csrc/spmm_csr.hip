@@ -144,9 +144,11 @@ struct SpmmVariant {
   int ch = 0, ksplit = 0;
 };
 
-// Tuning hook: SPAMD_SPMM_VARIANT="G=32,VEC=2,U=8,PANEL=64" overrides the heuristic.
+// Tuning hook, compiled ONLY into -DSPAMD_TUNING builds (tools/build_variant.sh): SPAMD_SPMM_VARIANT="G=32,VEC=2,U=8,PANEL=64"
+// overrides the heuristic.  The shipped library never reads the environment.
 static SpmmVariant env_variant() {
   SpmmVariant v;
+#ifdef SPAMD_TUNING
   const char* e = getenv("SPAMD_SPMM_VARIANT");
   if (!e) return v;
   const char* p;
@@ -156,6 +158,7 @@ static SpmmVariant env_variant() {
   if ((p = strstr(e, "PANEL="))) v.panel = atoll(p + 6);
   if ((p = strstr(e, "CH="))) v.ch = atoi(p + 3);
   if ((p = strstr(e, "KSPLIT="))) v.ksplit = atoi(p + 7);
+#endif
   return v;
 }
 

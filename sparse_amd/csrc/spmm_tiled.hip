@@ -29,6 +29,8 @@
 #include "common.h"
 #include "spmm_tiled_asm.inc"
 #include <stdlib.h>
+#include <mutex>
+#include <set>
 
 namespace spamd {
 
@@ -477,11 +479,22 @@ extern "C" int spamd_spmm_tiled_fill(int val_dtype, int idx_dtype, int64_t M, in
   return SPAMD_ETYPE;
 }
 
+static int tl_set_lds_once(const void* kern) {
+  static std::mutex mu;
+  static std::set<const void*> done;
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count(kern)) return 0;
+  hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS);
+  if (e != hipSuccess) return (int)e;
+  done.insert(kern);
+  return 0;
+}
+
 template <typename T, typename KERN>
 static int tl_launch(KERN kern, int64_t M, int64_t K, int64_t N, const int* blocks, const int* blk_off, const T* b,
                      int64_t ldb, T* out, int64_t ldo, int touch_lines, hipStream_t s) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS);
-  if (e != hipSuccess) return (int)e;
+  // the 160 KB dynamic-LDS opt-in is a per-function attribute: set once per kernel, not on every multiply
+  if (int rc = tl_set_lds_once(reinterpret_cast<const void*>(kern))) return rc;
   const int64_t blocks_n = tl_grid_groups(M) / TL_WAVES;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks_n, (unsigned)(N / TlFmt<T>::PANEL)), dim3(TL_WAVES * 64), TL_LDS, s, M, K,
                      (int)ceil_div(K, (int64_t)TL_KB), touch_lines, blocks, blk_off, b, ldb, out, ldo);
@@ -512,12 +525,16 @@ extern "C" int spamd_spmm_tiled(int val_dtype, int64_t M, int64_t K, int64_t N, 
   }
   const float* bb = (const float*)b;
   float* oo = (float*)out;
-  const char* dbg_env = getenv("SPAMD_TILED_DBG");  // timing ablations: 2 = no tile DMA, 5 = no fma, 6 = no LDS reads/fma
+#ifdef SPAMD_TUNING
+  // timing ablations (WRONG RESULTS by design), only in -DSPAMD_TUNING builds: 2 = no tile DMA, 5 = no fma, 6 = no LDS
+  // reads/fma, 7 = neither DMA nor LDS reads nor fma.  The shipped library never reads the environment.
+  const char* dbg_env = getenv("SPAMD_TILED_DBG");
   const int dbg = dbg_env ? atoi(dbg_env) : 0;
   if (dbg == 2) return tl_launch<float>(&spmm_tiled_kernel<2, 0, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, s);
   if (dbg == 5) return tl_launch<float>(&spmm_tiled_kernel<0, 1, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, s);
   if (dbg == 6) return tl_launch<float>(&spmm_tiled_kernel<0, 2, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, s);
   if (dbg == 7) return tl_launch<float>(&spmm_tiled_kernel<2, 2, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, s);
+#endif
   return exact ? tl_launch<float>(&spmm_tiled_kernel<0, 3, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, s)
                : tl_launch<float>(&spmm_tiled_kernel<0, 0, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, s);
 }

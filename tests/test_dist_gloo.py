@@ -92,3 +92,61 @@ def test_allgather_csr_triplet_world2():
     ret = mgr.dict()
     mp.spawn(_worker_csr, args=(2, port, ret), nprocs=2, join=True)
     assert len(ret) == 2
+
+
+def _worker_sddmm(rank, world, port, ret):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sparse_amd import _dist
+
+    # the sharding of `sharded_sddmm`: mask rows and A rows co-sharded by nnz-balanced row blocks,
+    # Bt (n_cols x K) row-sharded and gathered once; the local sampled products are evaluated here in NumPy float64
+    # (no GPU in this container) — under test are the row blocks and the collective
+    M, Ncols, Kd = 211, 157, 24
+    data, idx, ptr = random_csr(M, Ncols, 0.06, 31, np.float64, np.int64, empty_rows=(5, 6), long_row=100)
+    a = random_dense(M, Kd, 32, np.float64)
+    bt = random_dense(Ncols, Kd, 33, np.float64)
+    tp = torch.from_numpy(ptr)
+    bounds = _dist.partition_rows_by_nnz(tp, world)
+    d, i, p, r0, r1 = _dist.shard_csr(torch.from_numpy(data), torch.from_numpy(idx), tp, rank, world, bounds)
+    bt_full = _dist.all_gather_rows(_dist.row_shard(torch.from_numpy(bt), rank, world), Ncols)
+    assert torch.equal(bt_full, torch.from_numpy(bt))
+    a_local = a[r0:r1]
+    rows = np.repeat(np.arange(r1 - r0), np.diff(p.numpy()))
+    local = d.numpy() * np.einsum("ik,ik->i", a_local[rows], bt_full.numpy()[i.numpy()])
+    rows_g = np.repeat(np.arange(M), np.diff(ptr))
+    whole = data * np.einsum("ik,ik->i", a[rows_g], bt[idx])
+    assert np.array_equal(local, whole[ptr[r0]:ptr[r1]])
+    nnz = torch.tensor([float(d.numel())])
+    gathered = [torch.zeros_like(nnz) for _ in range(world)]
+    dist.all_gather(gathered, nnz)
+    ret[rank] = [int(t.item()) for t in gathered]
+    dist.destroy_process_group()
+
+
+def test_sharded_sddmm_plumbing_world2():
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_sddmm, args=(2, port, ret), nprocs=2, join=True)
+    per_rank = ret[0]
+    assert per_rank == ret[1] and abs(per_rank[0] - per_rank[1]) <= 157 + 1   # nnz-balanced up to one (long) row
+
+
+def test_partition_rows_by_nnz_strong_scaling_balance():
+    """bench.py --scaling strong splits ONE matrix into nnz-balanced row blocks: at 8 blocks of a uniform matrix the
+    heaviest block is within one row of the mean."""
+    from sparse_amd import _dist
+
+    data, idx, ptr = random_csr(4000, 500, 0.05, 41, np.float32, np.int32)
+    tp = torch.from_numpy(ptr)
+    for world in (1, 2, 4, 8):
+        b = _dist.partition_rows_by_nnz(tp, world)
+        assert b[0] == 0 and b[-1] == 4000 and all(x <= y for x, y in zip(b, b[1:]))
+        per = [int(ptr[b[r + 1]] - ptr[b[r]]) for r in range(world)]
+        assert sum(per) == len(data) and max(per) - len(data) / world <= 500

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import random_csr, random_dense
+from util import assert_within_fma_bound, random_csr, random_dense
 
 pytestmark = pytest.mark.gpu
 
@@ -37,7 +37,7 @@ def test_tiled_bit_identical_to_rowgroup_fma(orc, idt, M, K, density):
     (data, idx, ptr, b), got, ref, layout = _run(M, K, density, idt)
     assert torch.equal(got, ref)
     want = orc.dot_csr_ndarray((M, 128), data, idx, ptr, b)
-    assert np.allclose(got.cpu().numpy(), want, rtol=2e-5, atol=1e-6)
+    assert_within_fma_bound(got.cpu().numpy(), want, data, idx, ptr, b)   # the executor itself, 1e-6 * sum|a_k b_k|
     blocks, blk_off, _ = layout
     rg, kb, gpb, epb, slack, _, _ = Kn_params()
     assert bool((blk_off[1:] >= blk_off[:-1]).all()) and blocks.numel() == (int(blk_off[-1]) + slack) * epb * 2
@@ -56,7 +56,7 @@ def test_tiled_phase_chunking_and_tile_edges(orc, M, K, density):
     (data, idx, ptr, b), got, ref, _ = _run(M, K, density, np.int32, seed=41)
     assert torch.equal(got, ref)
     want = orc.dot_csr_ndarray((M, 128), data, idx, ptr, b)
-    assert np.allclose(got.cpu().numpy(), want, rtol=2e-5, atol=1e-6)
+    assert_within_fma_bound(got.cpu().numpy(), want, data, idx, ptr, b)
 
 
 def test_tiled_edge_rows():
@@ -95,7 +95,7 @@ def test_product_path_builds_and_caches_the_block_stream(orc, monkeypatch):
     assert a._tiled_layouts[torch.float32] is layout
     assert torch.equal(r1, r2) and torch.equal(r2, r3)
     want = orc.dot_csr_ndarray((a.shape[0], 128), data, idx, ptr, bh)
-    assert np.allclose(r3.cpu().numpy(), want, rtol=2e-5, atol=1e-6)
+    assert_within_fma_bound(r3.cpu().numpy(), want, data, idx, ptr, bh)
 
 
 @pytest.mark.parametrize("N", [256, 384])
@@ -110,7 +110,7 @@ def test_product_path_column_panels(orc, monkeypatch, N):
     ref = Kn.dot_csr_ndarray((a.shape[0], N), a.data, a.indices, a.indptr, b, exact=False)
     assert torch.equal(got, ref)
     want = orc.dot_csr_ndarray((a.shape[0], N), data, idx, ptr, bh)
-    assert np.allclose(got.cpu().numpy(), want, rtol=2e-5, atol=1e-6)
+    assert_within_fma_bound(got.cpu().numpy(), want, data, idx, ptr, bh)
 
 
 def test_product_path_csc_operand_uses_the_csr_twin(orc, monkeypatch):
@@ -125,7 +125,7 @@ def test_product_path_csc_operand_uses_the_csr_twin(orc, monkeypatch):
     got = acsc @ b
     assert acsc._tiled_layouts and acsc._csr_twin is not None
     want = orc.dot_csr_ndarray((a.shape[0], 128), data, idx, ptr, bh)
-    assert np.allclose(got.cpu().numpy(), want, rtol=2e-5, atol=1e-6)
+    assert_within_fma_bound(got.cpu().numpy(), want, data, idx, ptr, bh)
 
 
 @pytest.mark.parametrize("M,K,density", [(300, 200, 0.05), (5000, 10000, 0.01), (4097, 129, 0.1), (64, 1000, 0.2)])
@@ -207,7 +207,7 @@ def test_unsorted_rows_fall_back_to_the_key_sort_recipe(orc):
     layout = Kn.csr_tiled_layout(td, ti, tp, M, K)
     got = Kn.dot_csr_ndarray_tiled(layout, (M, 128), K, tb)
     want = orc.dot_csr_ndarray((M, 128), data, idx, ptr, b)
-    assert np.allclose(got.cpu().numpy(), want, rtol=2e-5, atol=1e-6)
+    assert_within_fma_bound(got.cpu().numpy(), want, data, idx, ptr, b)
 
 
 # ---- float64 (the reference's default dtype): one column per lane, 64-column panels, 5-entry blocks ------------

@@ -31,3 +31,22 @@ def random_dense(K, N, seed, dtype=np.float32):
     if np.dtype(dtype).kind == "f":
         return (rng.random((K, N)) - 0.5).astype(dtype)
     return rng.integers(-50, 50, size=(K, N)).astype(dtype)
+
+
+F32_FMA_RTOL = 1e-6   # north_star: "numerics within 1e-6 rel of reference" — measured against sum_k |a_k b_k|
+
+
+def assert_within_fma_bound(got, want, data, idx, ptr, b, rtol=None):
+    """|got - want| <= rtol * sum_k |a_k| |b_kj| element by element (the sum evaluated in float64): the only
+    difference between one FMA per term and the reference's rounded multiply + rounded add is one rounding per term,
+    so the bound scales with the magnitude of the terms, not of the (possibly cancelling) result."""
+    import scipy.sparse as sps
+
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape and got.dtype == want.dtype
+    M, K = len(ptr) - 1, b.shape[0]
+    absum = sps.csr_matrix((np.abs(data).astype(np.float64), idx, ptr), shape=(M, K)) @ np.abs(b).astype(np.float64)
+    if rtol is None:
+        rtol = F32_FMA_RTOL if got.dtype == np.float32 else 1e-14
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    assert np.all(err <= rtol * absum + 1e-300), f"max err / bound = {np.max(err / (rtol * absum + 1e-300)):.3f}"
