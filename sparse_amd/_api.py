@@ -103,7 +103,7 @@ def random(shape, density=None, nnz=None, random_state=None, data_rvs=None, form
         vals = np.asarray(data_rvs(nnz))
         if vals.shape != (nnz,):
             raise ValueError("data_rvs must return an array of length nnz")
-            data = torch.from_numpy(np.ascontiguousarray(vals if dtype is None else vals.astype(dtype))).to(d)
+        data = torch.from_numpy(np.ascontiguousarray(vals if dtype is None else vals.astype(dtype))).to(d)
     else:
         data = torch.rand(nnz, generator=g, device=d, dtype=torch.float64).to(dev.torch_dtype(dtype or np.float64))
     it = torch.int64 if idx_dtype is None or np.dtype(idx_dtype).itemsize > 4 else torch.int32

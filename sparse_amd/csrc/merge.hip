@@ -37,6 +37,20 @@ __device__ __forceinline__ T mp_min(T a, T b) {
 template <typename T, typename O>
 __device__ __forceinline__ O mp_apply(int op, T a, T b) {
 #pragma clang fp contract(off)
+  if constexpr (std::is_same<O, uint8_t>::value) {
+    // comparisons / logical ops produce 0/1 bytes whatever the operand type (T may itself be uint8_t: bool operands)
+    switch (op) {
+      case 32: return a > b;
+      case 33: return a >= b;
+      case 34: return a < b;
+      case 35: return a <= b;
+      case 36: return a == b;
+      case 37: return a != b;
+      case 38: return (a != T(0)) && (b != T(0));
+      case 39: return (a != T(0)) || (b != T(0));
+      case 40: return (a != T(0)) != (b != T(0));
+    }
+  }
   if constexpr (std::is_same<O, T>::value) {
     switch (op) {
       case 0: return a + b;
@@ -59,17 +73,6 @@ __device__ __forceinline__ O mp_apply(int op, T a, T b) {
     }
     return T(0);
   } else {
-    switch (op) {
-      case 32: return a > b;
-      case 33: return a >= b;
-      case 34: return a < b;
-      case 35: return a <= b;
-      case 36: return a == b;
-      case 37: return a != b;
-      case 38: return (a != T(0)) && (b != T(0));
-      case 39: return (a != T(0)) || (b != T(0));
-      case 40: return (a != T(0)) != (b != T(0));
-    }
     return O(0);
   }
 }
