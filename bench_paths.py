@@ -206,8 +206,8 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
             emit(f"A9_sddmm_{dtn}", row(f"config 4: mask COO({Ms}x{Ms}, {nnz4} nnz) (.) A({Ms}x256) Bt({Ms}x256), {dtn} in / fp32 acc, "
                                         "sampled kernel", ms, b, flops=2.0 * 256 * nnz4, gather_bytes=nnz4 * 2 * 256 * esz,
                                         gather_TBps=nnz4 * 2 * 256 * esz / ms / 1e9, cpu_baseline=leg))
-        if hasattr(K, "sddmm_tiles") and want("A9_mfma"):
-            out.update(_sddmm_mfma_rows(sp, K, s, Ms, quick, emit))
+        if want("A9_mfma"):
+            _sddmm_mfma_rows(sp, K, s, Ms, emit)
         del s, a, bt, r
         torch.cuda.empty_cache()
 
@@ -303,12 +303,42 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
     return out
 
 
-def _sddmm_mfma_rows(sp, K, s, Ms, quick, emit):
-    """A9 with the MFMA dense-tile kernel: config 4's uniform mask (expected: the sampled kernel wins) and a
-    block-clustered mask of the same nnz (dense 32x32 tiles: MFMA wins).  Filled in by the round-2 MFMA path."""
-    from sparse_amd import _sddmm_tiles
-
-    return _sddmm_tiles.bench_rows(sp, K, s, Ms, quick, emit, row, timed)
+def _sddmm_mfma_rows(sp, K, s, Ms, emit):
+    """A9 with per-tile dispatch between the sampled kernel and the bf16 matrix-core tile kernel (csrc/sddmm_mfma.hip):
+    config 4's uniform mask (no tile qualifies: the dispatcher must cost nothing) and a block-clustered mask of the
+    same size (70 % of the samples in 32 x 32 tiles filled at 50 %), each checked on 20000 samples in float64."""
+    dev = s.device
+    a = (torch.rand((Ms, 256), device=dev) - 0.5).to(torch.bfloat16)
+    bt = (torch.rand((Ms, 256), device=dev) - 0.5).to(torch.bfloat16)
+    rng = np.random.default_rng(1)
+    nnz = s.nnz
+    nt = int(0.7 * nnz) // 512
+    tiles = rng.choice((Ms // 32) ** 2, nt, replace=False)
+    pos = np.argsort(rng.random((nt, 1024)), axis=1)[:, :512]
+    r = (tiles // (Ms // 32))[:, None] * 32 + pos // 32
+    c = (tiles % (Ms // 32))[:, None] * 32 + pos % 32
+    lin = np.unique(np.concatenate([(r.astype(np.int64) * Ms + c).ravel(), rng.choice(Ms * Ms, nnz - nt * 512, replace=False)]))
+    clustered = sp.COO(np.stack([lin // Ms, lin % Ms]).astype(np.int32), rng.random(lin.size).astype(np.float32), shape=(Ms, Ms))
+    for tag, mask in (("uniform", s), ("clustered", clustered)):
+        plan = K.sddmm_plan(mask.coords, mask.shape)
+        f = lambda: (K.sddmm_coo_mfma(plan, mask.coords, mask.shape, mask.data, a, bt)
+                     if plan.n_dense_samples >= K.SDDMM_MFMA_MIN_SHARE * plan.nnz else K.sddmm_coo(mask.coords, mask.data, a, bt))
+        ms, got = timed(f)
+        ms_s, _ = timed(lambda: K.sddmm_coo(mask.coords, mask.data, a, bt))
+        pick = np.sort(rng.choice(mask.nnz, size=min(20000, mask.nnz), replace=False))
+        hrow, hcol = mask.coords[0][pick].cpu().numpy(), mask.coords[1][pick].cpu().numpy()
+        hs = mask.data[pick].cpu().numpy().astype(np.float64)
+        ha, hb = a[hrow].to(torch.float64).cpu().numpy(), bt[hcol].to(torch.float64).cpu().numpy()
+        want_v = hs * np.einsum("ik,ik->i", ha, hb)
+        terms = np.abs(hs) * np.einsum("ik,ik->i", np.abs(ha), np.abs(hb))
+        err = float(np.max(np.abs(got[pick].cpu().numpy().astype(np.float64) - want_v) / terms))
+        ntile = int(plan.tiles.numel())
+        emit(f"A9_mfma_{tag}", row(
+            f"SDDMM, per-tile dispatch, {tag} mask COO({Ms}x{Ms}, {mask.nnz} nnz), bf16 K=256: {ntile} tiles "
+            f"({plan.n_dense_samples} samples) on v_mfma_f32_32x32x16_bf16, the rest sampled", ms,
+            mask.nnz * 16 + 4 * Ms * 256, flops=2.0 * 256 * mask.nnz, sampled_kernel_ms=ms_s, speedup_vs_sampled=ms_s / ms,
+            dense_tiles=ntile, tile_product_TFLOPs=2.0 * ntile * 32 * 32 * 256 / ms / 1e9 if ntile else 0.0,
+            max_err_over_sum_abs_terms=err))
 
 
 def main():

@@ -320,6 +320,23 @@ int spamd_sddmm(int in_dtype, int s_dtype, int idx_dtype, int64_t nnz, const voi
                 const void* s_data, const void* A, int64_t lda, const void* Bt, int64_t ldb, int64_t K, void* out,
                 void* stream);
 
+/* A9, dense-tile form (north_star: "MFMA used only on the dense tile of SDDMM"): the 32 x 32 tiles of the mask that
+ * hold at least `threshold` samples are computed as one 32 x 32 x K bf16 product on the matrix cores
+ * (v_mfma_f32_32x32x16_bf16, fp32 accumulate) and sampled from LDS; every other sample goes to spamd_sddmm.
+ * Same reference formulation (examples/sddmm_example.py:51-52).  Plan: spamd_sddmm_tile_keys -> stable sort of the keys
+ * with the sample index as payload (spamd_sort_pairs) -> spamd_flag_heads / spamd_exclusive_scan / spamd_compact give
+ * seg_start[nseg + 1] -> spamd_sddmm_tile_classify -> scan + compact give the list of dense tiles and of left-over
+ * samples.  bf16 operands only, K a multiple of 16, 16-byte aligned rows. */
+int spamd_sddmm_tile_size(void);
+int spamd_sddmm_tile_keys(int idx_dtype, int64_t nnz, const void* rows, const void* cols, int64_t tile_cols,
+                          int64_t* keys, void* stream);
+int spamd_sddmm_tile_classify(int64_t nseg, const int64_t* seg_start, int64_t threshold, int64_t* tile_flag,
+                              int64_t* sample_flag, void* stream);
+int spamd_sddmm_mfma_tiles(int idx_dtype, int64_t ntiles, const int64_t* tiles, const int64_t* seg_start,
+                           const int64_t* keys_sorted, const int64_t* perm, int64_t tile_cols, int64_t M, int64_t N,
+                           const void* rows, const void* cols, const float* s_data, const void* A, int64_t lda,
+                           const void* Bt, int64_t ldb, int64_t K, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,7 +50,17 @@ def sddmm(s, a, b=None, *, bt=None):
     btt = dev.to_device(bt, sc.device) if bt is not None else dev.to_device(b, sc.device).t().contiguous()
     if at.shape[0] != s.shape[0] or btt.shape[0] != s.shape[1] or at.shape[1] != btt.shape[1]:
         raise ValueError("shape-mismatch for sum")
-    vals = K.sddmm_coo(sc.coords, sc.data, at, btt)
+    vals = None
+    if at.dtype == torch.bfloat16 and btt.dtype == torch.bfloat16 and sc.nnz >= K.SDDMM_TILE_THRESHOLD and at.shape[1] % 16 == 0:
+        # populated 32 x 32 tiles of the mask go to the matrix cores; the plan depends on the pattern only and is kept
+        # on the mask (dropped with its other derived layouts when the coordinates change)
+        plan = getattr(sc, "_sddmm_plan", None)
+        if plan is None or plan.nnz != sc.nnz or plan.threshold != K.SDDMM_TILE_THRESHOLD:
+            plan = K.sddmm_plan(sc.coords, sc.shape)
+            sc._sddmm_plan = plan
+        vals = K.sddmm_coo_mfma(plan, sc.coords, sc.shape, sc.data, at, btt)
+    if vals is None:
+        vals = K.sddmm_coo(sc.coords, sc.data, at, btt)
     out = COO(sc.coords, vals, shape=s.shape, has_duplicates=False, sorted=True, prune=True)
     return out.asformat("gcxs", compressed_axes=s.compressed_axes) if out_gcxs else out
 

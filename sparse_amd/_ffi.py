@@ -80,6 +80,11 @@ SIGNATURES = {
     "spamd_spgemm_count": (_int, [_int, _i64, _i64, _vp, _vp, _vp, _vp]),
     "spamd_spgemm_expand": (_int, [_int, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "spamd_sddmm": (_int, [_int, _int, _int, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp]),
+    "spamd_sddmm_tile_size": (_int, []),
+    "spamd_sddmm_tile_keys": (_int, [_int, _i64, _vp, _vp, _i64, _vp, _vp]),
+    "spamd_sddmm_tile_classify": (_int, [_i64, _vp, _i64, _vp, _vp, _vp]),
+    "spamd_sddmm_mfma_tiles": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64,
+                                      _i64, _vp, _vp]),
     "spamd_merge_num_blocks": (_i64, [_i64, _i64]),
     "spamd_merge_partition": (_int, [_i64, _vp, _i64, _vp, _vp, _vp]),
     "spamd_merge_union": (_int, [_int, _int, _int, _i64, _vp, _vp, _i64, _vp, _vp, _C.c_uint64, _C.c_uint64,

@@ -705,6 +705,85 @@ def sddmm_coo(coords, s_data, a, bt):
     return out
 
 
+SDDMM_TILE_THRESHOLD = 56      # samples per 32 x 32 mask tile from which the matrix-core tile product is the cheaper one (measured crossover ~52: tools/sddmm_crossover.py)
+SDDMM_MFMA_MIN_SHARE = 0.05    # below this share of samples in dense tiles the plain sampled kernel takes everything
+
+
+class SddmmPlan:
+    """Per-mask dispatch between the matrix-core tile kernel and the sampled kernel (csrc/sddmm_mfma.hip):
+    `tiles` = runs (in `seg_start`) of the tiles that take the MFMA path, `rest` = sample indices left to the sampled
+    kernel.  Depends on the coordinates only: cached on the mask by `sparse_amd.sddmm`."""
+
+    __slots__ = ("keys", "perm", "seg_start", "tiles", "rest", "tile_cols", "n_dense_samples", "nnz", "threshold")
+
+
+def sddmm_plan(coords, shape, threshold=None):
+    dev = require_hip(coords)
+    threshold = SDDMM_TILE_THRESHOLD if threshold is None else int(threshold)
+    rows, cols = coords[0].contiguous(), coords[1].contiguous()
+    if not index_dtype_ok(rows):
+        rows, cols = rows.to(torch.int64), cols.to(torch.int64)
+    nnz = int(rows.numel())
+    ts = int(_ffi.lib().spamd_sddmm_tile_size())
+    tile_rows, tile_cols = -(-int(shape[0]) // ts), -(-int(shape[1]) // ts)
+    p = SddmmPlan()
+    p.nnz, p.tile_cols, p.threshold = nnz, tile_cols, threshold
+    s = stream_ptr(dev)
+    keys = torch.empty(nnz, dtype=torch.int64, device=dev)
+    _ffi.call("spamd_sddmm_tile_keys", code_of(rows.dtype), nnz, ptr(rows), ptr(cols), tile_cols, ptr(keys), s)
+    p.keys, p.perm = sort_keys(keys, max(tile_rows * tile_cols - 1, 1))
+    heads = flag_heads(p.keys)
+    hoff = exclusive_scan(heads)
+    nseg = int(hoff[-1])
+    iota = torch.empty(nnz + 1, dtype=torch.int64, device=dev)
+    _ffi.call("spamd_iota", nnz + 1, ptr(iota), s)
+    seg_start = torch.empty(nseg + 1, dtype=torch.int64, device=dev)
+    if nseg:
+        _ffi.call("spamd_compact", 8, nnz, ptr(iota), ptr(heads), ptr(hoff), ptr(seg_start), s)
+    seg_start[nseg:] = nnz   # (one 8-byte fill: the end of the last run)
+    p.seg_start = seg_start
+    tflag, sflag = new_flags(nseg, dev), new_flags(nnz, dev)
+    _ffi.call("spamd_sddmm_tile_classify", nseg, ptr(seg_start), threshold, ptr(tflag), ptr(sflag), s)
+    toff, soff = exclusive_scan(tflag), exclusive_scan(sflag)
+    ntile, nrest = int(toff[-1]), int(soff[-1])
+    p.tiles = compact(iota[:nseg].contiguous(), tflag, toff, ntile) if nseg else torch.empty(0, dtype=torch.int64, device=dev)
+    p.rest = compact(p.perm, sflag, soff, nrest)
+    p.n_dense_samples = nnz - nrest
+    return p
+
+
+def sddmm_coo_mfma(plan, coords, shape, s_data, a, bt, out=None, force=False):
+    """SDDMM with per-tile dispatch (bf16 operands): dense tiles on the matrix cores, the rest through the sampled
+    kernel.  Returns None when the plan leaves (almost) everything to the sampled kernel and `force` is not set."""
+    dev = require_hip(coords, s_data, a, bt)
+    if a.dtype != torch.bfloat16 or bt.dtype != torch.bfloat16:
+        raise TypeError("the matrix-core SDDMM path takes bfloat16 operands")
+    Kd = int(a.shape[1])
+    if Kd % 16 or Kd == 0:
+        return None
+    if not force and plan.n_dense_samples < SDDMM_MFMA_MIN_SHARE * plan.nnz:
+        return None
+    a, bt = a.contiguous(), bt.contiguous()
+    s_data = s_data.to(torch.float32).contiguous()
+    rows, cols = coords[0].contiguous(), coords[1].contiguous()
+    if not index_dtype_ok(rows):
+        rows, cols = rows.to(torch.int64), cols.to(torch.int64)
+    if out is None:
+        out = torch.empty(plan.nnz, dtype=torch.float32, device=dev)
+    s = stream_ptr(dev)
+    _ffi.call("spamd_sddmm_mfma_tiles", code_of(rows.dtype), int(plan.tiles.numel()), ptr(plan.tiles), ptr(plan.seg_start),
+              ptr(plan.keys), ptr(plan.perm), plan.tile_cols, int(shape[0]), int(shape[1]), ptr(rows), ptr(cols), ptr(s_data),
+              ptr(a), a.stride(0), ptr(bt), bt.stride(0), Kd, ptr(out), s)
+    nrest = int(plan.rest.numel())
+    if nrest:
+        sub = torch.empty(nrest, dtype=torch.float32, device=dev)
+        rr, cc, ss = gather(rows, plan.rest), gather(cols, plan.rest), gather(s_data, plan.rest)
+        _ffi.call("spamd_sddmm", code_of(a.dtype), code_of(torch.float32), code_of(rr.dtype), nrest, ptr(rr), ptr(cc), ptr(ss),
+                  ptr(a), a.stride(0), ptr(bt), bt.stride(0), Kd, ptr(sub), s)
+        scatter_into(out, plan.rest, sub)
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # inspector/executor SpMM (csrc/spmm_tiled.hip)
 # ---------------------------------------------------------------------------------------------

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=/root/repo
 tag=${1:-r01}; needle=${2:-spmm_csr}; shift; shift
 passes=${@:-fetch write}
-run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_$tag/$name -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu > $R/gpurun_out/pmc_$tag/$name.log 2>&1; }
+run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_$tag/$name -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu --no-paths > $R/gpurun_out/pmc_$tag/$name.log 2>&1; }
 mkdir -p $R/gpurun_out/pmc_$tag
 for p in $passes; do
   case $p in
