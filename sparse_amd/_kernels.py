@@ -705,7 +705,7 @@ def sddmm_coo(coords, s_data, a, bt):
     return out
 
 
-SDDMM_TILE_THRESHOLD = 56      # samples per 32 x 32 mask tile from which the matrix-core tile product is the cheaper one (measured crossover ~52: tools/sddmm_crossover.py)
+SDDMM_TILE_THRESHOLD = 48      # samples per 32 x 32 mask tile from which the matrix-core tile product is the cheaper one (measured crossover ~40: tools/sddmm_crossover.py, profiles/r02_sddmm_crossover.txt)
 SDDMM_MFMA_MIN_SHARE = 0.05    # below this share of samples in dense tiles the plain sampled kernel takes everything
 
 

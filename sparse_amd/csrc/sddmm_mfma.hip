@@ -110,6 +110,73 @@ __global__ void __launch_bounds__(256) sddmm_mfma_kernel(int64_t ntiles, const i
   }
 }
 
+// K = 16 * KS known at compile time (64, 128, 256): a wave takes SD_GROUP consecutive dense tiles of the list (sorted by
+// tile row, then tile column) and keeps the A panel of the current tile row in registers (KS operand registers of 16 bytes
+// per lane): tiles of one tile row - the common case for banded / block-diagonal masks - then fetch only their Bt panel,
+// i.e. 16 KB instead of 32 KB per tile at K = 256 (the tile kernel is bound by fetching its panels, not by the MFMAs).
+constexpr int SD_GROUP = 4;
+
+template <typename I, int KS>
+__global__ void __launch_bounds__(256) sddmm_mfma_rowreuse_kernel(int64_t ntiles, const int64_t* __restrict__ tiles,
+                                                                  const int64_t* __restrict__ seg_start,
+                                                                  const int64_t* __restrict__ keys_sorted,
+                                                                  const int64_t* __restrict__ perm, int64_t tile_cols, int64_t M,
+                                                                  int64_t N, const I* __restrict__ rows,
+                                                                  const I* __restrict__ cols, const float* __restrict__ s_data,
+                                                                  const __bf16* __restrict__ A, int64_t lda,
+                                                                  const __bf16* __restrict__ Bt, int64_t ldb,
+                                                                  float* __restrict__ out) {
+  __shared__ float tile_lds[4][SD_TILE][SD_TILE + 1];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  float(*P)[SD_TILE + 1] = tile_lds[wv];
+  const int64_t d0 = ((int64_t)blockIdx.x * 4 + wv) * SD_GROUP;
+  sd_bf16x8 areg[KS];
+  int64_t cur_tr = -1;
+  for (int g = 0; g < SD_GROUP; ++g) {
+    const int64_t d = d0 + g;
+    if (d >= ntiles) break;
+    const int64_t s = tiles[d];
+    const int64_t first = seg_start[s], last = seg_start[s + 1];
+    const int64_t key = keys_sorted[first];
+    const int64_t tr = key / tile_cols, tc = key - tr * tile_cols;
+    if (tr != cur_tr) {
+      int64_t ar = tr * SD_TILE + (lane & 31);
+      if (ar >= M) ar = M - 1;
+      const __bf16* ap = A + ar * lda + (lane >> 5) * 8;
+#pragma unroll
+      for (int q = 0; q < KS; ++q) areg[q] = *reinterpret_cast<const sd_bf16x8*>(ap + q * 16);
+      cur_tr = tr;
+    }
+    int64_t bc = tc * SD_TILE + (lane & 31);
+    if (bc >= N) bc = N - 1;
+    const __bf16* bp = Bt + bc * ldb + (lane >> 5) * 8;
+    sd_f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+#pragma unroll
+    for (int q0 = 0; q0 < KS; q0 += 4) {
+      sd_bf16x8 b0 = *reinterpret_cast<const sd_bf16x8*>(bp + q0 * 16), b1 = *reinterpret_cast<const sd_bf16x8*>(bp + q0 * 16 + 16);
+      sd_bf16x8 b2 = *reinterpret_cast<const sd_bf16x8*>(bp + q0 * 16 + 32), b3 = *reinterpret_cast<const sd_bf16x8*>(bp + q0 * 16 + 48);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[q0], b0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[q0 + 1], b1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[q0 + 2], b2, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[q0 + 3], b3, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) P[(v & 3) + 8 * (v >> 2) + 4 * (lane >> 5)][lane & 31] = acc[v];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    const int64_t r0 = tr * SD_TILE, c0 = tc * SD_TILE;
+    for (int64_t i = first + lane; i < last; i += 64) {
+      const int64_t n = perm[i];
+      const int li = (int)((int64_t)rows[n] - r0), lj = (int)((int64_t)cols[n] - c0);
+      out[n] = s_data[n] * P[li][lj];
+    }
+    __builtin_amdgcn_wave_barrier();   // the next tile overwrites P: this wave's LDS reads above are issued before it
+  }
+}
+
 }  // namespace spamd
 
 using namespace spamd;
@@ -148,6 +215,19 @@ extern "C" int spamd_sddmm_mfma_tiles(int idx_dtype, int64_t ntiles, const int64
   if (ntiles < 0 || K <= 0 || K % 16 != 0 || M <= 0 || N <= 0 || tile_cols <= 0) return SPAMD_EINVAL;
   if (ntiles == 0) return 0;
   if (((uintptr_t)A % 16) || ((uintptr_t)Bt % 16) || ((lda * 2) % 16) || ((ldb * 2) % 16)) return SPAMD_EINVAL;
+#define SD_ROWREUSE(KS)                                                                                                    \
+  SPAMD_DISPATCH_IDX(idx_dtype, I,                                                                                          \
+                     hipLaunchKernelGGL((sddmm_mfma_rowreuse_kernel<I, KS>), dim3((unsigned)ceil_div(ntiles, (int64_t)(4 * SD_GROUP))), \
+                                        dim3(256), 0, (hipStream_t)stream, ntiles, tiles, seg_start, keys_sorted, perm, tile_cols, \
+                                        M, N, (const I*)rows, (const I*)cols, s_data, (const __bf16*)A, lda, (const __bf16*)Bt,  \
+                                        ldb, out))                                                                          \
+  return launch_status();
+  if (ntiles >= 4 * SD_GROUP * 1024) {   // (a short tile list fills the chip better with one wave per tile)
+    if (K == 256) { SD_ROWREUSE(16) }
+    if (K == 128) { SD_ROWREUSE(8) }
+    if (K == 64) { SD_ROWREUSE(4) }
+  }
+#undef SD_ROWREUSE
   SPAMD_DISPATCH_IDX(idx_dtype, I,
                      hipLaunchKernelGGL(sddmm_mfma_kernel<I>, dim3((unsigned)ceil_div(ntiles, (int64_t)4)), dim3(256), 0,
                                         (hipStream_t)stream, ntiles, tiles, seg_start, keys_sorted, perm, tile_cols, M, N,
