@@ -483,6 +483,30 @@ def gen_einsum(sp):
     _save("einsum", **cases)
 
 
+def gen_general(sp):
+    """N2/N3: arbitrary callables, N operands, keywords, dense operands, non-zero-fill var/std, broadcast N-D matmul -
+    the cases of tests/general_cases.py evaluated by the reference (`_Elemwise`, _umath.py:392-751; `_matmul_recurser`,
+    _common.py:278-293; `var/std`, _sparse_array.py:704-876)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import general_cases as gc
+
+    inp = gc.inputs()
+    out = {f"in_{k}": v for k, v in inp.items()}
+    for k, (name, fn) in enumerate(gc.CASES):
+        r = gc.evaluate(sp, fn, inp)
+        out[f"c{k}_name"] = np.array(name)
+        out[f"c{k}_kind"] = np.array(r["kind"])
+        if r["kind"] == "error":
+            out[f"c{k}_error"] = np.array(r["error"])
+            print(f"    {name}: raises {r['error']}")
+            continue
+        out[f"c{k}_dense"] = r["dense"]
+        if r["kind"] == "sparse":
+            out[f"c{k}_nnz"], out[f"c{k}_fill"], out[f"c{k}_cls"] = np.array(r["nnz"]), r["fill"], np.array(r["cls"])
+    out["n_cases"] = np.array(len(gc.CASES))
+    _save("general", **out)
+
+
 def main():
     sp = ref_loader.load()
     print("reference:", sp.__file__)
@@ -494,6 +518,7 @@ def main():
     gen_matrix(sp)
     gen_select(sp)
     gen_einsum(sp)
+    gen_general(sp)
 
 
 if __name__ == "__main__":

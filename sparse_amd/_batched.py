@@ -178,6 +178,96 @@ def matmul_blockdiag(a, b):
     return res.reshape(lead + (M, N))
 
 
+def _prod(xs):
+    n = 1
+    for x in xs:
+        n *= int(x)
+    return n
+
+
+def _swap_last(x):
+    """x with its last two axes exchanged (sparse: a key permutation + sort; dense: a strided view made contiguous)"""
+    from ._sparse_array import SparseArray
+
+    nd = x.ndim
+    perm = tuple(range(nd - 2)) + (nd - 1, nd - 2)
+    if isinstance(x, SparseArray):
+        return x.transpose(perm)
+    if isinstance(x, torch.Tensor):
+        return x.permute(perm).contiguous()
+    return np.ascontiguousarray(np.transpose(x, perm))
+
+
+def matmul_broadcast(a, b):
+    """`a @ b` for N-D operands whose leading axes BROADCAST (sizes 1 against n), as one product instead of the
+    reference's Python recursion over slices (`_matmul_recurser`, _common.py:278-293).  With the leading axes split into
+    E (both operands have the axis), A (only `a` does, `b` has 1) and B (only `b` does):
+
+        out[e, x, y, m, n] = sum_k a[e, x, m, k] * b[e, y, k, n]
+                           = ( a viewed as [E, (A*M), K] )  @  ( b viewed as [E, K, (B*N)] )      per e,
+
+    i.e. an equal-leading-axes batch (`matmul_blockdiag`, or a plain 2-D product when E is empty) of taller / wider
+    matrices, followed by a reshape to [E, A, M, B, N] and a transposition into the broadcast order.  The views are key
+    permutations for sparse operands and strided copies for dense ones; every output element still sums its own k terms
+    in k order.  `a` dense and `b` sparse goes through (b^T a^T)^T."""
+    from ._dot import dot
+    from ._gcxs import GCXS
+    from ._sparse_array import SparseArray
+
+    if not isinstance(a, SparseArray):
+        r = matmul_broadcast(_swap_last(b), _swap_last(a))
+        return _swap_last(r)
+    nd = a.ndim
+    la, lb = tuple(a.shape[:-2]), tuple(b.shape[:-2])
+    M, Kd, N = int(a.shape[-2]), int(a.shape[-1]), int(b.shape[-1])
+    E = [d for d in range(nd - 2) if la[d] == lb[d]]
+    A = [d for d in range(nd - 2) if la[d] != lb[d] and lb[d] == 1]
+    B = [d for d in range(nd - 2) if la[d] != lb[d] and la[d] == 1]
+    eshape, ashape, bshape = [la[d] for d in E], [la[d] for d in A], [lb[d] for d in B]
+    nA, nB = _prod(ashape), _prod(bshape)
+    b_sparse = isinstance(b, SparseArray)
+
+    # a -> [E..., A..., M, K] (its B axes have length 1: dropped by the reshape), then [E..., A*M, K]
+    perm_a = E + A + B + [nd - 2, nd - 1]
+    a2 = a if perm_a == list(range(nd)) else a.transpose(perm_a)
+    a2 = a2.reshape(tuple(eshape) + (nA * M, Kd))
+    # b -> [E..., K, B..., N] (its A axes have length 1), then [E..., K, B*N]
+    perm_b = E + A + [nd - 2] + B + [nd - 1]
+    if b_sparse:
+        b2 = b if perm_b == list(range(nd)) else b.transpose(perm_b)
+        b2 = b2.reshape(tuple(eshape) + (Kd, nB * N))
+    else:
+        was_numpy = not isinstance(b, torch.Tensor)
+        bt = torch.from_numpy(np.ascontiguousarray(b)) if was_numpy else b
+        b2 = bt.permute(perm_b).reshape(tuple(eshape) + (Kd, nB * N))
+        b2 = np.ascontiguousarray(b2.numpy()) if was_numpy else b2.contiguous()
+    res = matmul_blockdiag(a2, b2) if eshape else dot(a2, b2)
+    # [E..., A*M, B*N] -> [E..., A..., M, B..., N] -> broadcast order [lead..., M, N]
+    mid = tuple(eshape) + tuple(ashape) + (M,) + tuple(bshape) + (N,)
+    pos, src = {}, 0
+    for d in E:
+        pos[d] = src
+        src += 1
+    for d in A:
+        pos[d] = src
+        src += 1
+    m_pos = src
+    src += 1
+    for d in B:
+        pos[d] = src
+        src += 1
+    n_pos = src
+    back = [pos[d] for d in range(nd - 2)] + [m_pos, n_pos]
+    if isinstance(res, SparseArray):
+        res = res.reshape(mid)
+        if back != list(range(len(mid))):
+            res = res.transpose(back)
+        return res if isinstance(a, GCXS) and isinstance(b, GCXS) else res.asformat("coo")
+    if isinstance(res, torch.Tensor):
+        return res.reshape(mid).permute(back).contiguous()
+    return np.ascontiguousarray(np.transpose(res.reshape(mid), back))
+
+
 def matmul_batched(a, b):
     """`_matmul_recurser` (reference _common.py:278-293): loop over the broadcast leading axis,
     2-D `dot` per slice, stack the results."""

@@ -223,11 +223,13 @@ def _matmul(a, b):
     for i, j in zip(a.shape[:-2], b.shape[:-2]):
         if i != 1 and j != 1 and i != j:
             raise ValueError("shapes of a and b are not broadcastable")
-    from ._batched import matmul_batched, matmul_blockdiag
+    from ._batched import matmul_batched, matmul_blockdiag, matmul_broadcast
 
-    if isinstance(a, SparseArray) and tuple(a.shape[:-2]) == tuple(b.shape[:-2]) and prod(a.shape[:-2]) > 0:
+    if prod(a.shape) == 0 or prod(b.shape) == 0:
+        return matmul_batched(a, b)     # empty batches / matrices: the reference's recursion handles every corner
+    if isinstance(a, SparseArray) and tuple(a.shape[:-2]) == tuple(b.shape[:-2]):
         return matmul_blockdiag(a, b)   # the whole batch as one block-diagonal product
-    return matmul_batched(a, b)
+    return matmul_broadcast(a, b)       # broadcast leading axes (and dense @ sparse): still one product
 
 
 def dot(a, b):

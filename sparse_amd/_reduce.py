@@ -181,7 +181,9 @@ def var_impl(x, axis=None, dtype=None, ddof=0, keepdims=False):
     if out_gcxs:
         x = x.tocoo()
     if not equivalent(x.fill_value, 0, loose=True):
-        raise NotImplementedError("var/std with a non-zero fill value is not on the hip backend's path")
+        # the variance is shift-invariant: var(x) = var(x - fill), and x - fill has a zero background (entries that
+        # become exactly 0 drop out of the stored set, which is what they then are)
+        x = x - np.asarray(x.fill_value)[()]
     axis = normalize_axis(axis, x.ndim)
     if axis is None:
         axis = tuple(range(x.ndim))

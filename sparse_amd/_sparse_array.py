@@ -52,7 +52,36 @@ class SparseArray:
         return self.data.device
 
     def to_device(self, device, /, *, stream=None):
-        raise NotImplementedError
+        """Array-API device move (reference _sparse_array.py:54-59, which knows only "cpu" and returns `self`).  Here
+        the stored arrays are HIP device tensors: the same device returns `self`, another HIP device returns a copy
+        whose buffers live there (derived layouts are rebuilt on demand), anything else is refused with the
+        reference's exception type."""
+        import copy as _copy
+
+        import torch
+
+        from ._dot import drop_derived
+
+        if stream is not None:
+            raise ValueError("The stream argument to to_device() is not supported")
+        d = torch.device(device) if not isinstance(device, torch.device) else device
+        if d.type != "cuda":
+            raise ValueError(f"Unsupported device {device!r}: sparse_amd arrays live in HIP device memory")
+        cur = self.device
+        if d.index is None:
+            d = torch.device("cuda", torch.cuda.current_device() if cur.index is None else cur.index)
+        if d == cur:
+            return self
+        out = _copy.copy(self)
+        drop_derived(out)
+        out.__dict__.pop("_sddmm_plan", None)
+        for name in ("data", "coords", "indices", "indptr", "_keys"):
+            t = getattr(self, name, None)
+            if isinstance(t, torch.Tensor):
+                setattr(out, name, t.to(d))
+        if getattr(out, "_cache", None) is not None:
+            out._cache = type(out._cache)()
+        return out
 
     @property
     def ndim(self):

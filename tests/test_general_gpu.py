@@ -1,0 +1,58 @@
+"""N2 / N3: the general elementwise algorithm (any callable, any number of operands, keywords,
+dense operands, non-zero fill values), var/std with a fill value and broadcast N-D matmul, against what the REAL reference
+returned for the same inputs (tests/golden/general.npz, written by oracle/gen_golden.py `gen_general` from the cases in
+tests/general_cases.py)."""
+import os
+
+import numpy as np
+import pytest
+
+import general_cases as gc
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "general.npz"))
+
+
+@pytest.mark.parametrize("k", range(len(gc.CASES)), ids=[c[0] for c in gc.CASES])
+def test_case_matches_the_reference(k):
+    import sparse_amd as sp
+
+    name, fn = gc.CASES[k]
+    assert str(G[f"c{k}_name"]) == name, "tests/golden/general.npz is stale: run oracle/gen_golden.py"
+    inp = {key[3:]: G[key] for key in G.files if key.startswith("in_")}
+    got = gc.evaluate(sp, fn, inp)
+    kind = str(G[f"c{k}_kind"])
+    assert got["kind"] == kind, (name, got)
+    if kind == "error":
+        assert got["error"] == str(G[f"c{k}_error"]), name
+        return
+    want = G[f"c{k}_dense"]
+    assert got["dense"].shape == want.shape and got["dense"].dtype == want.dtype, name
+    if "matmul" in name or "var" in name or "std" in name:      # sums: same terms, another order
+        assert np.allclose(got["dense"], want, rtol=1e-12, atol=1e-14, equal_nan=True), name
+    else:                                                          # elementwise: the same function on the same values
+        assert np.array_equal(got["dense"], want, equal_nan=True), name
+    if kind == "sparse":
+        assert got["cls"] == str(G[f"c{k}_cls"]), name
+        assert np.allclose(np.asarray(got["fill"], dtype=np.float64), np.asarray(G[f"c{k}_fill"], dtype=np.float64),
+                           rtol=1e-12, atol=0, equal_nan=True), name
+        if "var" not in name and "std" not in name:   # (a variance that cancels to 0 exactly in one order need not in another)
+            assert got["nnz"] == int(G[f"c{k}_nnz"]), name
+
+
+def test_to_device_round_trip():
+    import torch
+
+    import sparse_amd as sp
+
+    x = sp.random((30, 40), density=0.1, random_state=3)
+    assert x.to_device(x.device) is x and x.to_device("cuda") is x
+    g = sp.GCXS(x)
+    assert g.to_device(torch.device("cuda", x.device.index or 0)) is g
+    with pytest.raises(ValueError):
+        x.to_device("cpu")
+    with pytest.raises(ValueError):
+        x.to_device(x.device, stream=1)
+    if torch.cuda.device_count() > 1:
+        y = x.to_device("cuda:1")
+        assert y.device.index == 1 and np.array_equal(y.todense(), x.todense())
