@@ -285,10 +285,12 @@ int spamd_spgemm_expand(int val_dtype, int idx_dtype, int64_t p0, int64_t np, co
                         const void* b_indptr, const int64_t* offsets, int64_t P, int64_t n_col, int64_t* keys,
                         void* vals, void* stream);
 
-/* A4 / A5, row-local form (csrc/spgemm_rows.hip): the products of an output row are expanded, radix-sorted by column
- * and summed inside LDS by one workgroup; bit-identical to the expand-sort-compress above, without writing or
- * sorting the products in HBM.  Rows with more products than spamd_spgemm_rows_capacity(val_dtype) are skipped: the
- * caller computes those with the global form and merges them with spamd_spgemm_unpack.  n_col < 2^31 - 1.
+/* A4 / A5, row-local form (csrc/spgemm_rows.hip): the products of an output row are expanded, ordered by column
+ * (bucket by the high column bits, then rank inside the small buckets: hand-written, no library sort) and summed
+ * inside LDS by one workgroup; bit-identical to the expand-sort-compress above, without writing or sorting the
+ * products in HBM.  Rows with more products than spamd_spgemm_rows_capacity(...) are skipped and rows with a column that
+ * collects more than 64 products are declined (nnz_row = -1): the caller computes those with the global form and merges
+ * them with spamd_spgemm_unpack.  n_col < 2^31 - 1.
  *   spamd_spgemm_row_products: prod[n_row + 1] (last entry zeroed) and maxes[2] = {max prod, longest A row};
  *   caller: prod_off = spamd_exclusive_scan(prod), scratch tmp_cols/tmp_vals of prod_off[n_row] entries;
  *   spamd_spgemm_rows: rows of C into the scratch at prod_off[row], their lengths into nnz_row[n_row + 1];
@@ -296,11 +298,15 @@ int spamd_spgemm_expand(int val_dtype, int idx_dtype, int64_t p0, int64_t np, co
  *   spamd_spgemm_pack: scratch -> (out_indices int64, out_data), columns ascending inside every row. */
 int spamd_spgemm_row_products(int idx_dtype, int64_t n_row, const void* a_indptr, const void* a_indices,
                               const void* b_indptr, int64_t* prod, int64_t* maxes, void* stream);
-int64_t spamd_spgemm_rows_capacity(int val_dtype);
+int64_t spamd_spgemm_rows_capacity(int val_dtype, int64_t n_col, int64_t max_arow);
 int spamd_spgemm_rows(int val_dtype, int idx_dtype, int64_t n_row, int64_t n_col, const void* a_indptr,
                       const void* a_indices, const void* a_data, const void* b_indptr, const void* b_indices,
-                      const void* b_data, const int64_t* prod_off, int64_t max_prod, int* tmp_cols, void* tmp_vals,
-                      int64_t* nnz_row, void* stream);
+                      const void* b_data, const int64_t* prod_off, int64_t max_prod, int64_t max_arow, int* tmp_cols,
+                      void* tmp_vals, int64_t* nnz_row, void* stream);
+/* which rows are left to the global form: flags[n_row + 1] for spamd_exclusive_scan + spamd_compact, counts[3] = {rows,
+ * their products, rows heavy only by their A length}; nnz_row NULL before the row kernel, else rows with -1 count too */
+int spamd_spgemm_classify_rows(int idx_dtype, int64_t n_row, const int64_t* prod, const void* a_indptr,
+                               const int64_t* nnz_row, int64_t cap, int64_t* flags, int64_t* counts, void* stream);
 /* rows too heavy for the row-local kernel: computed by the global form, given as CSR over all n_row rows (int64
  * columns), copied into the scratch at their product offset; nnz_row[row] is set for the listed rows */
 int spamd_spgemm_unpack(int val_dtype, int64_t n_heavy, const int64_t* heavy_rows, const int64_t* src_indptr,

@@ -90,8 +90,9 @@ SIGNATURES = {
     "spamd_merge_union": (_int, [_int, _int, _int, _i64, _vp, _vp, _i64, _vp, _vp, _C.c_uint64, _C.c_uint64,
                                  _C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spamd_spgemm_row_products": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "spamd_spgemm_rows_capacity": (_i64, [_int]),
-    "spamd_spgemm_rows": (_int, [_int, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "spamd_spgemm_rows_capacity": (_i64, [_int, _i64, _i64]),
+    "spamd_spgemm_rows": (_int, [_int, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "spamd_spgemm_classify_rows": (_int, [_int, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "spamd_spgemm_unpack": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spamd_spgemm_pack": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spamd_reduce_fill": (_int, [_int, _int, _i64, _vp, _vp, _i64, _C.c_double, _i64, _vp]),

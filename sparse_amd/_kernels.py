@@ -582,6 +582,9 @@ def _spgemm_keys(n_row, n_col, a_data, a_indices, a_rows, b_data, b_indices, b_i
 SPGEMM_ROW_LOCAL = True  # tuning hook: False = always the global expand-sort-compress
 
 
+SPGEMM_STATS = {}   # last row-local product: rows, rows left to the global form (diagnostics for the benches)
+
+
 def _spgemm_rows(n_row, n_col, a_data, a_indices, a_indptr, b_data, b_indices, b_indptr):
     """Row-local SpGEMM (csrc/spgemm_rows.hip): (data, int64 indices, int64 indptr) of A @ B.  Rows too heavy for LDS
     are computed by the global expand-sort-compress and merged in; None when most of the work is in such rows (the
@@ -602,37 +605,47 @@ def _spgemm_rows(n_row, n_col, a_data, a_indices, a_indptr, b_data, b_indices, b
               ptr(maxes), s)
     prod_off = exclusive_scan(prod)
     max_prod, max_arow = (int(v) for v in maxes.tolist())
-    cap = int(_ffi.lib().spamd_spgemm_rows_capacity(vcode))
+    cap = int(_ffi.lib().spamd_spgemm_rows_capacity(vcode, n_col, max_arow))
     total = int(prod_off[-1])
-    heavy_rows = None
+
+    def classify(nnz_row):
+        """(flags[n_row + 1], rows, their products, rows heavy only by their A length) - csrc/spgemm_rows.hip"""
+        flags = new_flags(n_row, dev)
+        counts = torch.empty(3, dtype=torch.int64, device=dev)
+        _ffi.call("spamd_spgemm_classify_rows", code_of(it), n_row, ptr(prod), ptr(a_indptr), ptr(nnz_row) if nnz_row is not None else 0,
+                  cap, ptr(flags), ptr(counts), s)
+        return (flags, *[int(v) for v in counts.tolist()])
+
     if max_prod > cap or max_arow > cap:
         # rows too heavy for LDS (products, or A elements to stage) go through the global expand-sort-compress
-        arow_len = (a_indptr[1:] - a_indptr[:-1]).to(torch.int64)
-        heavy = (prod[:n_row] > cap) | (arow_len > cap)
-        heavy_rows = torch.nonzero(heavy).reshape(-1)
-        if int(heavy_rows.numel()) * 4 > n_row or int(prod[:n_row][heavy].sum()) * 2 > total:
-            return None  # mostly heavy: the global form throughout
+        _, n_heavy, heavy_products, n_arow_only = classify(None)
+        if n_heavy * 4 > n_row or heavy_products * 4 > total * 3 or n_arow_only:
+            return None  # mostly heavy (or rows heavy only by their A length): the global form throughout
     tmp_cols = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
     tmp_vals = torch.empty(max(total, 1), dtype=dtr, device=dev)
     nnz_row = torch.zeros(n_row + 1, dtype=torch.int64, device=dev)
-    if heavy_rows is None:
-        _ffi.call("spamd_spgemm_rows", vcode, code_of(it), n_row, n_col, ptr(a_indptr), ptr(a_indices), ptr(a_data),
-                  ptr(b_indptr), ptr(b_indices), ptr(b_data), ptr(prod_off), max_prod, ptr(tmp_cols), ptr(tmp_vals),
-                  ptr(nnz_row), s)
-    else:
-        # (the kernels skip every row with more products than the capacity by themselves; rows that are heavy only by
-        # their A length are rare enough to send everything to the global form)
-        if bool(((arow_len > cap) & (prod[:n_row] <= cap)).any()):
-            return None
-        _ffi.call("spamd_spgemm_rows", vcode, code_of(it), n_row, n_col, ptr(a_indptr), ptr(a_indices), ptr(a_data),
-                  ptr(b_indptr), ptr(b_indices), ptr(b_data), ptr(prod_off), cap, ptr(tmp_cols), ptr(tmp_vals),
-                  ptr(nnz_row), s)
-        a_rows = csr_to_keys(a_indptr, torch.zeros_like(a_indices), n_row, 1)
-        sel = heavy[a_rows]
-        hkeys, hvals = _spgemm_keys(n_row, n_col, a_data[sel], a_indices[sel], a_rows[sel].contiguous(), b_data,
+    _ffi.call("spamd_spgemm_rows", vcode, code_of(it), n_row, n_col, ptr(a_indptr), ptr(a_indices), ptr(a_data),
+              ptr(b_indptr), ptr(b_indices), ptr(b_data), ptr(prod_off), min(max_prod, cap), max_arow, ptr(tmp_cols),
+              ptr(tmp_vals), ptr(nnz_row), s)
+    # rows above the capacity were skipped, rows with a column of more than 64 products were declined (nnz_row = -1):
+    # both are computed by the global form and copied into the scratch
+    flags, n_heavy, _, _ = classify(nnz_row)
+    SPGEMM_STATS["rows"], SPGEMM_STATS["heavy_or_declined"] = n_row, n_heavy
+    if n_heavy:
+        iota = torch.empty(max(n_row, int(a_indices.numel())) + 1, dtype=torch.int64, device=dev)
+        _ffi.call("spamd_iota", int(iota.numel()), ptr(iota), s)
+        heavy_rows = compact(iota[:n_row], flags, exclusive_scan(flags), n_heavy)
+        a_rows = csr_to_keys(a_indptr, torch.zeros_like(a_indices), n_row, 1)   # row id of every A element
+        nA = int(a_indices.numel())
+        eflags = new_flags(nA, dev)
+        _ffi.call("spamd_gather", 8, nA, ptr(flags), ptr(a_rows), ptr(eflags), s)
+        eflags[nA:] = 0
+        eoff = exclusive_scan(eflags)
+        sel = compact(iota[:nA], eflags, eoff, int(eoff[-1]))               # A elements of those rows
+        hkeys, hvals = _spgemm_keys(n_row, n_col, gather(a_data, sel), gather(a_indices, sel), gather(a_rows, sel), b_data,
                                     b_indices, b_indptr)
         hptr, hidx = keys_to_csr(hkeys, n_row, n_col, torch.int64)
-        _ffi.call("spamd_spgemm_unpack", vcode, int(heavy_rows.numel()), ptr(heavy_rows.contiguous()), ptr(hptr),
+        _ffi.call("spamd_spgemm_unpack", vcode, n_heavy, ptr(heavy_rows.contiguous()), ptr(hptr),
                   ptr(hidx), ptr(hvals.contiguous()), ptr(prod_off), ptr(tmp_cols), ptr(tmp_vals), ptr(nnz_row), s)
     out_ptr = exclusive_scan(nnz_row)
     nnz = int(out_ptr[-1])

@@ -7,17 +7,17 @@
 // One workgroup per output row:
 //   expand   product p of the row -> (A element e, offset inside B row k_e) by a binary search in an LDS prefix
 //            array of the B row lengths; key = column, value = a * b (one rounded multiply);
-//   sort     rocprim::block_radix_sort on the column bits (stable LSD: products of equal column stay in the
-//            order of A's elements, i.e. the reference's k order);
-//   compress every run of equal columns is summed left to right by the thread that owns its head
-//            (`sums[j] += ...` in the reference's order: bit-identical), heads are ranked by a block scan.
+//   order    bucket by the high column bits with LDS atomics, then rank inside the ~5-element buckets (no sort network,
+//            no radix sort; see "the row kernel" below);
+//   compress every run of equal columns is summed left to right, in the order of A's elements, by its head product
+//            (`sums[j] += ...` in the reference's order: bit-identical).
 // Rows are written to a scratch area at their product offset (an upper bound of their length); a second kernel
 // packs them once the row lengths are scanned.  Rows are served by size class (workgroup size x items per thread);
 // a row whose products (or A elements) exceed the largest class makes the caller fall back to spgemm.hip.
 #include <string.h>
 #include <cstring>
+#include <mutex>
 #include "common.h"
-#include <rocprim/rocprim.hpp>
 
 namespace spamd {
 
@@ -64,66 +64,141 @@ __global__ void __launch_bounds__(256) spgemm_row_products_kernel(int64_t n_row,
   }
 }
 
-template <int BLOCK, int ITEMS, typename V>
-struct RowSortLayout {
-#ifndef SPAMD_SPG_RB
-#define SPAMD_SPG_RB 0
-#define SPAMD_SPG_ALG default_for_radix_sort
-#endif
-  using sort_t = rocprim::block_radix_sort<int, BLOCK, ITEMS, V, 1, 1, SPAMD_SPG_RB,
-                                           rocprim::block_radix_rank_algorithm::SPAMD_SPG_ALG>;
-  using scan_t = rocprim::block_scan<int, BLOCK>;
-  static constexpr int N = BLOCK * ITEMS;
-  // after the sort only the VALUES, one head flag per product and every thread's last column go to LDS (the columns
-  // stay in registers): half the footprint of (column, value) pairs, i.e. two workgroups per CU for the big classes
-  static constexpr size_t sorted_bytes = (size_t)N * (sizeof(V) + 1) + (size_t)BLOCK * sizeof(int) + 64;
-  static constexpr int STAGE = N < 2048 ? N : 2048;  // A elements staged per pass
+// ---- the row kernel: bucket + rank --------------------------------------------------------------------------------------
+// An output row's P products (P <= N = BLOCK * ITEMS) are ordered by column WITHOUT a sort network or a radix sort:
+//   1. bucket   b = floor(column * buckets / n_col) (about one bucket per two products, monotone in the column); every product takes a slot in its bucket
+//               with one LDS atomic (arrival order: arbitrary), an exclusive scan of the bucket sizes gives the bucket starts,
+//               and (key, value) go to LDS at start[b] + slot, key = (column << EB) | e with e = index of the A element
+//               the product comes from.  Products of one column come from distinct A elements (a B row holds a column
+//               once), so keys are unique and (column, e) IS the reference's summation order (`sums[j] += ...` over A's
+//               elements in order, _common.py:690-705).
+//   2. rank     a bucket holds ~2.5 products: ONE thread reads it into registers, orders it by key with a compare-exchange
+//               network and sums every run of equal columns left to right (increasing e: bit-identical to the reference);
+//               the run heads (column, sum) go back into the bucket's own LDS slots, their number into a head counter.
+//   3. emit     an exclusive scan of the head counters gives each bucket's first output slot; buckets are in column order
+//               and sorted inside, so rows come out column-sorted and neighbouring threads write neighbouring entries.
+// ~6 LDS accesses per product and 7 barriers per row against a 5-pass block radix sort before (13 of 27 ms).
+// The scans are hand-written (wave shuffles + one LDS hop); nothing here comes from a library.
+// A bucket with more than 16 products (in the end: a column of B that collects many products of one row) makes the
+// kernel decline the row (nnz_row = -1): the caller routes it through the global form like the rows above the capacity.
+constexpr int SPG_BUCKET_MAX = 16;      // products one bucket may hold (registers of the thread that ranks it)
+
+template <int BLOCK>
+__device__ __forceinline__ int spg_block_exclusive_scan(int v, int* wsum, int& total) {
+  // wsum: BLOCK / 64 + 1 ints of LDS.  Two barriers.
+  constexpr int NW = BLOCK / 64;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) wsum[wid] = x;
+  __syncthreads();
+  if (wid == 0) {
+    int w = lane < NW ? wsum[lane] : 0;
+    int xs = w;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int y = __shfl_up(xs, d, 64);
+      if (lane >= d) xs += y;
+    }
+    if (lane < NW) wsum[lane] = xs - w;
+    if (lane == 63) wsum[NW] = xs;
+  }
+  __syncthreads();
+  total = wsum[NW];
+  return x - v + wsum[wid];
+}
+
+// exclusive scan of arr[0 .. NB) in place, arr[NB] = total; NB a multiple of BLOCK
+template <int BLOCK, int NB>
+__device__ __forceinline__ int spg_scan_array(int* arr, int* wsum) {
+  constexpr int EPT = NB / BLOCK;
+  static_assert(NB % BLOCK == 0 && EPT >= 1, "bucket count is a multiple of the workgroup size");
+  int loc[EPT];
+  int mine = 0;
+#pragma unroll
+  for (int j = 0; j < EPT; ++j) {
+    loc[j] = arr[threadIdx.x * EPT + j];
+    mine += loc[j];
+  }
+  int total;
+  int run = spg_block_exclusive_scan<BLOCK>(mine, wsum, total);
+#pragma unroll
+  for (int j = 0; j < EPT; ++j) {
+    arr[threadIdx.x * EPT + j] = run;
+    run += loc[j];
+  }
+  if (threadIdx.x == 0) arr[NB] = total;
+  __syncthreads();
+  return total;
+}
+
+template <int BLOCK, int ITEMS, int PASSES, typename KEY, typename V>
+struct RowRankLayout {
+  static constexpr int N = BLOCK * ITEMS;                    // products a row may have
+  // products one pass may hold in LDS: with several passes a pass gets 1/PASSES of the products only on average
+  // (uniform columns: +- sqrt(N) / 2), so it has room for 9/8 of its share before the row is declined
+  static constexpr int CAPP = PASSES == 1 ? N : (N / PASSES) * 9 / 8;
+  static constexpr int pow2_at_least(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+  static constexpr int NBP = pow2_at_least(CAPP / 2 > BLOCK ? CAPP / 2 : BLOCK);   // buckets per pass: a power of two, a multiple of BLOCK
+  static constexpr int STAGE = CAPP < 2048 ? CAPP : 2048;    // A elements staged per chunk
   static constexpr size_t prefix_bytes = ((size_t)STAGE + 2) * sizeof(int) + (size_t)STAGE * (sizeof(int64_t) + sizeof(V)) + 16;
-  static constexpr size_t a(size_t x, size_t y) { return x > y ? x : y; }
-  static constexpr size_t bytes = a(a(sizeof(typename sort_t::storage_type), sorted_bytes), prefix_bytes);
+  static constexpr size_t items_bytes = (size_t)CAPP * (sizeof(KEY) + sizeof(V));
+  static constexpr size_t region = ((prefix_bytes > items_bytes ? prefix_bytes : items_bytes) + 15) / 16 * 16;
+  static constexpr size_t bytes = region + (size_t)(NBP + 1) * sizeof(int) + 16;
 };
 
-// rows with lo < products <= hi; V is the value type moved bit-wise except for the multiply / add
-template <int BLOCK, int ITEMS, typename V, typename I>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK == 512 ? 4 : 1, 8)))
-spgemm_rowsort_kernel(int64_t n_col, int col_bits, const I* __restrict__ a_ptr, const I* __restrict__ a_idx,
+// rows with lo < products <= hi; V is the value type moved bit-wise except for the multiply / add.
+// PASSES > 1: the column range is cut into PASSES equal bucket ranges that go through LDS one after the other (the
+// products stay in registers), so that a 15360-product row needs 77 KB of LDS instead of 150 KB and TWO workgroups share
+// a CU - the global-load latencies of one row's expansion then overlap the other row's ranking (one 1024-thread
+// workgroup per CU measured 31 ms at 10^9 products, exposed latency throughout).
+template <int BLOCK, int ITEMS, int PASSES, typename KEY, typename V, typename I>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 512 ? 4 : 1, 8)))
+spgemm_rowrank_kernel(int64_t n_col, int col_bits, int ebits, const I* __restrict__ a_ptr, const I* __restrict__ a_idx,
                       const V* __restrict__ a_val, const I* __restrict__ b_ptr, const I* __restrict__ b_idx,
                       const V* __restrict__ b_val, const int64_t* __restrict__ prod_off, int64_t lo, int64_t hi,
                       int* __restrict__ tmp_cols, V* __restrict__ tmp_vals, int64_t* __restrict__ nnz_row) {
 #pragma clang fp contract(off)
-  using L = RowSortLayout<BLOCK, ITEMS, V>;
+  using L = RowRankLayout<BLOCK, ITEMS, PASSES, KEY, V>;
+  constexpr int NBP = L::NBP, CAPP = L::CAPP;
   extern __shared__ __attribute__((aligned(16))) char raw[];
-  __shared__ typename L::scan_t::storage_type scan_storage;
+  __shared__ int wsum[BLOCK / 64 + 2];
+  __shared__ int declined;
   const int64_t row = blockIdx.x;
   const int64_t base = prod_off[row];
-  const int64_t P = prod_off[row + 1] - base;
-  if (P <= lo || P > hi) {
-    if (P == 0 && lo < 0 && threadIdx.x == 0) nnz_row[row] = 0;
+  const int64_t P64 = prod_off[row + 1] - base;
+  if (P64 <= lo || P64 > hi) {
+    if (P64 == 0 && lo < 0 && threadIdx.x == 0) nnz_row[row] = 0;
     return;
   }
   const int tid = threadIdx.x;
   const int64_t a0 = (int64_t)a_ptr[row];
-  const int nA = (int)((int64_t)a_ptr[row + 1] - a0);  // <= N (checked by the caller)
+  const int nA = (int)((int64_t)a_ptr[row + 1] - a0);  // < 2^ebits (checked by the caller)
+  const KEY kmax = ~(KEY)0;
 
   // ---- stage the A row in LDS: prefix[e] = products of the A elements before e (prefix[nA] = P), the start of B
   // row k_e and the A value.  (Every product then needs only LDS lookups and ONE independent pair of global loads;
   // chasing a_idx -> b_ptr -> b_idx per product serialises three memory latencies per item: 81 ms instead of ~10.)
+  // Product p of the row belongs to thread p / ITEMS; its key is (column << ebits) | index of its A element.
   constexpr int STAGE = L::STAGE;
   int* const prefix = reinterpret_cast<int*>(raw);
   int64_t* const bstart = reinterpret_cast<int64_t*>(raw + (size_t)(STAGE + 1) * sizeof(int) + 4);
   V* const aval = reinterpret_cast<V*>(reinterpret_cast<char*>(bstart) + (size_t)STAGE * sizeof(int64_t));
-  int keys[ITEMS];
+  KEY keys[ITEMS];
   V vals[ITEMS];
 #pragma unroll
   for (int j = 0; j < ITEMS; ++j) {
-    keys[j] = (int)n_col;  // sentinel: sorts after every real column
+    keys[j] = kmax;  // no product
     vals[j] = V(0);
   }
+  if (tid == 0) declined = 0;
   int chunk_done = 0;
   for (int c0 = 0; c0 < nA; c0 += STAGE) {  // chunks of STAGE A elements (one chunk unless the A row is very long)
     const int cn = nA - c0 < STAGE ? nA - c0 : STAGE;
-    // products of the chunks before this one
-    // (chunk_base is recomputed from scratch per chunk: rows with more than STAGE elements are rare)
     constexpr int EPT = (STAGE + BLOCK - 1) / BLOCK;
     int len[EPT];
     int mine = 0;
@@ -140,8 +215,8 @@ spgemm_rowsort_kernel(int64_t n_col, int col_bits, const I* __restrict__ a_ptr, 
       }
       mine += len[j];
     }
-    int before, chunk_total;
-    typename L::scan_t().exclusive_scan(mine, before, 0, chunk_total, scan_storage);
+    int chunk_total;
+    int before = spg_block_exclusive_scan<BLOCK>(mine, wsum, chunk_total);
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
       const int e = tid * EPT + j;
@@ -163,80 +238,192 @@ spgemm_rowsort_kernel(int64_t n_col, int col_bits, const I* __restrict__ a_ptr, 
         }
         e = l;
       }
-      int64_t q[ITEMS];
-      V av[ITEMS];
-      bool on[ITEMS];
+      constexpr int G = 8;   // loads in flight per thread (a register budget, not a latency one: 512 threads x 8 x 2)
 #pragma unroll
-      for (int j = 0; j < ITEMS; ++j) {
-        const int p = p0 + j;
-        on[j] = p >= 0 && p < chunk_total;
-        q[j] = 0;
-        av[j] = V(0);
-        if (on[j]) {
-          while (prefix[e + 1] <= p) ++e;
-          q[j] = bstart[e] + (p - prefix[e]);
-          av[j] = aval[e];
+      for (int j0 = 0; j0 < ITEMS; j0 += G) {
+        int64_t q[G];
+        V av[G];
+        int ee[G];
+        bool on[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const int p = p0 + j0 + g;
+          on[g] = j0 + g < ITEMS && p >= 0 && p < chunk_total;
+          q[g] = 0;
+          av[g] = V(0);
+          ee[g] = 0;
+          if (on[g]) {
+            while (prefix[e + 1] <= p) ++e;
+            q[g] = bstart[e] + (p - prefix[e]);
+            av[g] = aval[e];
+            ee[g] = c0 + e;
+          }
         }
-      }
 #pragma unroll
-      for (int j = 0; j < ITEMS; ++j) {
-        if (on[j]) {
-#ifdef SPAMD_SPG_SKIP_LOADS
-          keys[j] = (int)(q[j] & 0xffff);
-          vals[j] = av[j];
-#else
-          keys[j] = (int)b_idx[q[j]];
-          vals[j] = av[j] * b_val[q[j]];
-#endif
+        for (int g = 0; g < G; ++g) {
+          if (j0 + g < ITEMS && on[g]) {
+            keys[j0 + g] = ((KEY)(unsigned)b_idx[q[g]] << ebits) | (KEY)(unsigned)ee[g];
+            vals[j0 + g] = av[g] * b_val[q[g]];
+          }
         }
       }
     }
     chunk_done += chunk_total;
     __syncthreads();
   }
-  __syncthreads();  // prefix[] is dead: the sort reuses the memory
 
-#ifndef SPAMD_SPG_SKIP_SORT
-  typename L::sort_t().sort(keys, vals, *reinterpret_cast<typename L::sort_t::storage_type*>(raw), 0, col_bits);
-#endif
-  __syncthreads();
-  V* const sv = reinterpret_cast<V*>(raw);
-  int* const lastkey = reinterpret_cast<int*>(raw + (size_t)L::N * sizeof(V));
-  unsigned char* const hd = reinterpret_cast<unsigned char*>(lastkey + BLOCK);
-  lastkey[tid] = keys[ITEMS - 1];
+  KEY* const lkey = reinterpret_cast<KEY*>(raw);
+  V* const lval = reinterpret_cast<V*>(raw + (size_t)CAPP * sizeof(KEY));
+  int* const cnt = reinterpret_cast<int*>(raw + L::region);
+  // global bucket of a column: floor(column * scale / 2^32) with scale = floor(NBP * PASSES * 2^32 / n_col) (or the
+  // column itself when there are fewer columns than buckets): monotone in the column, < NBP * PASSES, and the passes get
+  // equal shares of the COLUMN RANGE (a plain shift of the column would hand pass 0 the share 2^k / n_col)
+  const uint64_t scale = (uint64_t)n_col <= (uint64_t)(NBP * PASSES) ? ((uint64_t)1 << 32)
+                                                                     : (((uint64_t)(NBP * PASSES)) << 32) / (uint64_t)n_col;
+  auto bucket_of = [&](KEY key) { return (int)(((uint64_t)(key >> ebits) * scale) >> 32); };
+  int row_total = 0;
+
+  for (int pass = 0; pass < PASSES; ++pass) {
+    const int b_lo = pass * NBP;   // this pass ranks the buckets [b_lo, b_lo + NBP)
+    // ---- 1. bucket ---------------------------------------------------------------------------------------------------
+    for (int i = tid; i <= NBP; i += BLOCK) cnt[i] = 0;
+    __syncthreads();   // (also: the staging area / the previous pass's items are dead)
+    // a product's slot inside its bucket, 5 bits each, six to a register (31 = not in this pass, or a bucket that
+    // overflows SPG_BUCKET_MAX and gets the row declined below): 30 products cost 5 registers instead of 30
+    constexpr int SW = (ITEMS + 5) / 6;
+    unsigned slots[SW];
 #pragma unroll
-  for (int j = 0; j < ITEMS; ++j) sv[tid * ITEMS + j] = vals[j];
-  __syncthreads();
-
-  // ---- compress: heads of runs of equal columns
-  int nheads = 0;
-  bool head[ITEMS];
-  {
-    int prev = tid ? lastkey[tid - 1] : -1;
+    for (int w = 0; w < SW; ++w) slots[w] = 0;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-      const int p = tid * ITEMS + j;
-      head[j] = p < P && keys[j] != prev;
-      prev = keys[j];
-      hd[p] = head[j] || p >= P;  // (padding counts as a head: it ends the last run)
-      nheads += head[j];
+      const int b = bucket_of(keys[j]) - b_lo;
+      unsigned sl = 31u;
+      if (keys[j] != kmax && b >= 0 && b < NBP) {
+        const unsigned got = (unsigned)atomicAdd(&cnt[b], 1);
+        sl = got < (unsigned)SPG_BUCKET_MAX ? got : 31u;
+      }
+      slots[j / 6] |= sl << (5 * (j % 6));
     }
-  }
-  int rank, total;
-  typename L::scan_t().exclusive_scan(nheads, rank, 0, total, scan_storage);  // (its barriers also publish hd[])
-  __syncthreads();
+    __syncthreads();
+    const int in_pass = spg_scan_array<BLOCK, NBP>(cnt, wsum);   // cnt[b] = first LDS position of bucket b
+    if (in_pass > CAPP) {   // block-uniform: a skewed column distribution, this pass does not fit LDS
+      if (tid == 0) nnz_row[row] = -1;
+      return;
+    }
 #pragma unroll
-  for (int j = 0; j < ITEMS; ++j) {
-    if (head[j]) {
-      const int p = tid * ITEMS + j;
-      V acc = vals[j];
-      for (int q = p + 1; q < L::N && !hd[q]; ++q) acc = acc + sv[q];
-      tmp_cols[base + rank] = keys[j];
-      tmp_vals[base + rank] = acc;
-      ++rank;
+    for (int j = 0; j < ITEMS; ++j) {
+      const unsigned sl = (slots[j / 6] >> (5 * (j % 6))) & 31u;
+      if (sl != 31u) {
+        const int at = cnt[bucket_of(keys[j]) - b_lo] + (int)sl;
+        lkey[at] = keys[j];
+        lval[at] = vals[j];
+      }
     }
+    __syncthreads();
+
+    // ---- 2. rank: one thread per bucket ----------------------------------------------------------------------------------
+    // The bucket (~2 products, at most SPG_BUCKET_MAX) is read into registers ONCE, ordered there by (column, A element)
+    // with a compare-exchange network, and its runs of equal columns are summed left to right; the heads (column, sum)
+    // go back into the bucket's own LDS slots.  No dependent LDS round trips, no divergence beyond the 8 / 16 split.
+    constexpr int BPT = NBP / BLOCK;   // consecutive buckets per thread
+    int hc[BPT];
+    int mine = 0;
+#pragma unroll
+    for (int bb = 0; bb < BPT; ++bb) {
+      const int b = tid * BPT + bb;
+      const int s0 = cnt[b];
+      const int c = cnt[b + 1] - s0;
+      hc[bb] = 0;
+      if (c > SPG_BUCKET_MAX) {
+        declined = 1;
+        continue;
+      }
+      if (c == 0) continue;
+      KEY k[SPG_BUCKET_MAX];
+      V v[SPG_BUCKET_MAX];
+#pragma unroll
+      for (int i = 0; i < SPG_BUCKET_MAX; ++i) {
+        const bool on = i < c && (i < 8 || c > 8);
+        k[i] = on ? lkey[s0 + i] : kmax;
+        v[i] = on ? lval[s0 + i] : V(0);
+      }
+#define SPG_CE(x, y)                              \
+  {                                               \
+    const bool sw = k[y] < k[x];                  \
+    const KEY tk = sw ? k[y] : k[x];              \
+    k[y] = sw ? k[x] : k[y];                      \
+    k[x] = tk;                                    \
+    const V tv = sw ? v[y] : v[x];                \
+    v[y] = sw ? v[x] : v[y];                      \
+    v[x] = tv;                                    \
   }
-  if (tid == 0) nnz_row[row] = total;
+      if (c > 8) {
+        // 16 keys: bitonic sorting network (80 compare-exchanges, all static indices)
+#pragma unroll
+        for (int size = 2; size <= SPG_BUCKET_MAX; size <<= 1) {
+#pragma unroll
+          for (int stride = size >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+            for (int i = 0; i < SPG_BUCKET_MAX; ++i) {
+              const int j = i ^ stride;
+              if (j > i) {
+                if ((i & size) == 0) SPG_CE(i, j) else SPG_CE(j, i)
+              }
+            }
+          }
+        }
+      } else if (c > 1) {
+        // 8 keys: the 19-exchange network
+        SPG_CE(0, 1) SPG_CE(2, 3) SPG_CE(4, 5) SPG_CE(6, 7)
+        SPG_CE(0, 2) SPG_CE(1, 3) SPG_CE(4, 6) SPG_CE(5, 7)
+        SPG_CE(1, 2) SPG_CE(5, 6) SPG_CE(0, 4) SPG_CE(3, 7)
+        SPG_CE(1, 5) SPG_CE(2, 6)
+        SPG_CE(1, 4) SPG_CE(3, 6)
+        SPG_CE(2, 4) SPG_CE(3, 5)
+        SPG_CE(3, 4)
+      }
+#undef SPG_CE
+      // runs of equal columns, summed in increasing A-element order; a run ends where the next column differs
+      int h = 0;
+      V acc = V(0);
+#pragma unroll
+      for (int i = 0; i < SPG_BUCKET_MAX; ++i) {
+        if (i < c) {
+          const KEY col = k[i] >> ebits;
+          const bool first = i == 0 || (k[i ? i - 1 : 0] >> ebits) != col;
+          acc = first ? v[i] : acc + v[i];
+          const bool last = i + 1 == c || (k[i + 1 < SPG_BUCKET_MAX ? i + 1 : i] >> ebits) != col;
+          if (last) {
+            lkey[s0 + h] = col;
+            lval[s0 + h] = acc;
+            ++h;
+          }
+        }
+      }
+      hc[bb] = h;
+      mine += h;
+    }
+    // ---- 3. emit: the thread's buckets are consecutive, so one scan of the per-thread head counts places them
+    int pass_total;
+    int at = spg_block_exclusive_scan<BLOCK>(mine, wsum, pass_total);   // (its barriers also publish `declined`)
+    if (declined) {   // block-uniform: a bucket (in the end: a column) collects too many products of this row
+      if (tid == 0) nnz_row[row] = -1;
+      return;
+    }
+    int64_t o = base + row_total + at;
+#pragma unroll
+    for (int bb = 0; bb < BPT; ++bb) {
+      const int s0 = cnt[tid * BPT + bb];
+      for (int i = 0; i < hc[bb]; ++i) {
+        tmp_cols[o] = (int)lkey[s0 + i];
+        tmp_vals[o] = lval[s0 + i];
+        ++o;
+      }
+    }
+    row_total += pass_total;
+    if (PASSES > 1) __syncthreads();   // the next pass re-uses cnt / lkey / lval, which the emission above still reads
+  }
+  if (tid == 0) nnz_row[row] = row_total;
 }
 
 // pack the rows: out[indptr[row] + i] = tmp[prod_off[row] + i], i < nnz(row); one workgroup per row
@@ -271,71 +458,99 @@ __global__ void __launch_bounds__(256) spgemm_unpack_kernel(const int64_t* __res
   if (threadIdx.x == 0) nnz_row[row] = n;
 }
 
-template <int BLOCK, int ITEMS, typename V, typename I>
-static int launch_rowsort(int64_t n_row, int64_t n_col, int col_bits, const I* a_ptr, const I* a_idx, const V* a_val,
-                          const I* b_ptr, const I* b_idx, const V* b_val, const int64_t* prod_off, int64_t lo, int64_t hi,
-                          int* tmp_cols, V* tmp_vals, int64_t* nnz_row, hipStream_t s) {
-  using L = RowSortLayout<BLOCK, ITEMS, V>;
-  auto kern = &spgemm_rowsort_kernel<BLOCK, ITEMS, V, I>;
+template <int BLOCK, int ITEMS, int PASSES, typename KEY, typename V, typename I>
+static int launch_rowrank(int64_t n_row, int64_t n_col, int col_bits, int ebits, const I* a_ptr, const I* a_idx,
+                          const V* a_val, const I* b_ptr, const I* b_idx, const V* b_val, const int64_t* prod_off, int64_t lo,
+                          int64_t hi, int* tmp_cols, V* tmp_vals, int64_t* nnz_row, hipStream_t s) {
+  using L = RowRankLayout<BLOCK, ITEMS, PASSES, KEY, V>;
+  static_assert(L::bytes <= 80 * 1024 - 128, "two 512-thread workgroups of a row class share the 160 KB of a CU");
+  auto kern = &spgemm_rowrank_kernel<BLOCK, ITEMS, PASSES, KEY, V, I>;
   if (L::bytes > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)L::bytes);
-    if (e != hipSuccess) return (int)e;
+    static std::mutex mu;
+    static bool done = false;   // (one flag per template instantiation)
+    std::lock_guard<std::mutex> lock(mu);
+    if (!done) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)L::bytes);
+      if (e != hipSuccess) return (int)e;
+      done = true;
+    }
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)n_row), dim3(BLOCK), L::bytes, s, n_col, col_bits, a_ptr, a_idx, a_val, b_ptr,
+  hipLaunchKernelGGL(kern, dim3((unsigned)n_row), dim3(BLOCK), L::bytes, s, n_col, col_bits, ebits, a_ptr, a_idx, a_val, b_ptr,
                      b_idx, b_val, prod_off, lo, hi, tmp_cols, tmp_vals, nnz_row);
   return launch_status();
 }
 
-// size classes: (workgroup, items per thread); the last one bounds what the row-local path accepts
-template <typename V>
+// size classes (products per row): 1024, 4096 (one pass through LDS), 8192 and the largest one (two passes over halves of
+// the column range; <= 78 KB of LDS each, so two workgroups per CU) for (key width, value width):
+//   32-bit keys (column bits + A-element bits <= 32) with 4-byte values: 12288; 64-bit keys with 8-byte values: 7168;
+//   every other combination: 8192 - and twice that with 1024 threads and four passes (one workgroup per CU: rare rows)
+template <typename KEY, typename V>
 struct RowClasses {
-  static constexpr int64_t c0 = 256 * 2, c1 = 256 * 8, c2 = 512 * 8;
-  static constexpr int64_t c3 = sizeof(V) <= 4 ? 1024 * 16 : 1024 * 12;  // 128 KB / 144 KB of sorted (column, value) pairs
+  static constexpr int MID = sizeof(KEY) + sizeof(V) <= 12 ? 16 : 14;  // (16-byte items: 14 per thread keep a pass under 80 KB)
+  static constexpr int64_t c0 = 256 * 4, c1 = 512 * 8, c2 = 512 * MID;
+  static constexpr int TOP = sizeof(KEY) + sizeof(V) <= 8 ? 24 : MID;  // (more products per thread spill: 512 x 30 -> 182 registers)
+  static constexpr int64_t c3 = 512 * TOP;
+  static constexpr int64_t c4 = 1024 * TOP;   // 1024 threads, four passes: the same LDS per pass, one workgroup per CU (rare rows)
 };
 
-template <typename V, typename I>
-static int rowsort_all(int64_t n_row, int64_t n_col, const I* a_ptr, const I* a_idx, const V* a_val, const I* b_ptr,
-                       const I* b_idx, const V* b_val, const int64_t* prod_off, int64_t max_prod, int* tmp_cols,
+static int spg_bits(int64_t n) {   // smallest b with 2^b > n
+  int b = 1;
+  while (((int64_t)1 << b) <= n) ++b;
+  return b;
+}
+
+template <typename KEY, typename V, typename I>
+static int rowrank_all(int64_t n_row, int64_t n_col, int col_bits, int ebits, const I* a_ptr, const I* a_idx, const V* a_val,
+                       const I* b_ptr, const I* b_idx, const V* b_val, const int64_t* prod_off, int64_t max_prod, int* tmp_cols,
                        V* tmp_vals, int64_t* nnz_row, hipStream_t s) {
-  int col_bits = 1;
-  while (((int64_t)1 << col_bits) <= n_col) ++col_bits;  // the sentinel n_col must be representable
-  using C = RowClasses<V>;
-  int rc = launch_rowsort<256, 2, V, I>(n_row, n_col, col_bits, a_ptr, a_idx, a_val, b_ptr, b_idx, b_val, prod_off, -1, C::c0,
-                                        tmp_cols, tmp_vals, nnz_row, s);
-  if (rc) return rc;
-  if (max_prod > C::c0) {
-    rc = launch_rowsort<256, 8, V, I>(n_row, n_col, col_bits, a_ptr, a_idx, a_val, b_ptr, b_idx, b_val, prod_off, C::c0, C::c1,
-                                      tmp_cols, tmp_vals, nnz_row, s);
-    if (rc) return rc;
+  using C = RowClasses<KEY, V>;
+#define SPG_CLASS(BLOCK, ITEMS, PASSES, LO, HI)                                                                               \
+  {                                                                                                                           \
+    int rc = launch_rowrank<BLOCK, ITEMS, PASSES, KEY, V, I>(n_row, n_col, col_bits, ebits, a_ptr, a_idx, a_val, b_ptr, b_idx,  \
+                                                             b_val, prod_off, LO, HI, tmp_cols, tmp_vals, nnz_row, s);        \
+    if (rc) return rc;                                                                                                        \
   }
-  if (max_prod > C::c1) {
-    rc = launch_rowsort<512, 8, V, I>(n_row, n_col, col_bits, a_ptr, a_idx, a_val, b_ptr, b_idx, b_val, prod_off, C::c1, C::c2,
-                                      tmp_cols, tmp_vals, nnz_row, s);
-    if (rc) return rc;
-  }
-  if (max_prod > C::c2) {
-    // 512-thread workgroups with many items per thread: two of them fit a CU (LDS and registers), so the global
-    // latencies of one row overlap the sort of another; the 1024-thread class only takes what they cannot hold
-    if constexpr (sizeof(V) <= 4) {
-      constexpr int64_t c2b = 512 * 24;
-      rc = launch_rowsort<512, 24, V, I>(n_row, n_col, col_bits, a_ptr, a_idx, a_val, b_ptr, b_idx, b_val, prod_off, C::c2, c2b,
-                                         tmp_cols, tmp_vals, nnz_row, s);
-      if (rc) return rc;
-      if (max_prod > c2b)
-        rc = launch_rowsort<1024, 16, V, I>(n_row, n_col, col_bits, a_ptr, a_idx, a_val, b_ptr, b_idx, b_val, prod_off, c2b,
-                                            C::c3, tmp_cols, tmp_vals, nnz_row, s);
-    } else {
-      constexpr int64_t c2b = 512 * 12;
-      rc = launch_rowsort<512, 12, V, I>(n_row, n_col, col_bits, a_ptr, a_idx, a_val, b_ptr, b_idx, b_val, prod_off, C::c2, c2b,
-                                         tmp_cols, tmp_vals, nnz_row, s);
-      if (rc) return rc;
-      if (max_prod > c2b)
-        rc = launch_rowsort<1024, 12, V, I>(n_row, n_col, col_bits, a_ptr, a_idx, a_val, b_ptr, b_idx, b_val, prod_off, c2b,
-                                            C::c3, tmp_cols, tmp_vals, nnz_row, s);
+  SPG_CLASS(256, 4, 1, -1, C::c0)
+  if (max_prod > C::c0) SPG_CLASS(512, 8, 1, C::c0, C::c1)
+  if (max_prod > C::c1) SPG_CLASS(512, C::MID, 2, C::c1, C::c2)
+  if (max_prod > C::c2 && C::c3 > C::c2) SPG_CLASS(512, C::TOP, 2, C::c2, C::c3)
+  if (max_prod > C::c3) SPG_CLASS(1024, C::TOP, 4, C::c3, C::c4)
+#undef SPG_CLASS
+  return 0;
+}
+
+// flags[row] = 1 for the rows the row-local kernel cannot take: more products or A elements than `cap`, or declined by the
+// kernel (nnz_row[row] < 0, when nnz_row is given).  counts[0] += such rows, counts[1] += their products, counts[2] += rows
+// that are heavy ONLY by the length of their A row.
+template <typename I>
+__global__ void __launch_bounds__(256) spgemm_classify_kernel(int64_t n_row, const int64_t* __restrict__ prod,
+                                                              const I* __restrict__ a_ptr, const int64_t* __restrict__ nnz_row,
+                                                              int64_t cap, int64_t* __restrict__ flags,
+                                                              unsigned long long* __restrict__ counts) {
+  unsigned long long c0 = 0, c1 = 0, c2 = 0;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_row; r += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t alen = (int64_t)a_ptr[r + 1] - (int64_t)a_ptr[r];
+    const bool by_prod = prod[r] > cap, by_a = alen > cap, by_kernel = nnz_row != nullptr && nnz_row[r] < 0;
+    const bool h = by_prod || by_a || by_kernel;
+    flags[r] = h ? 1 : 0;
+    if (h) {
+      ++c0;
+      c1 += (unsigned long long)prod[r];
+      if (by_a && !by_prod) ++c2;
     }
   }
-  return rc;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    c0 += __shfl_xor(c0, d, 64);
+    c1 += __shfl_xor(c1, d, 64);
+    c2 += __shfl_xor(c2, d, 64);
+  }
+  if ((threadIdx.x & 63) == 0 && c0) {
+    atomicAdd(counts, c0);
+    atomicAdd(counts + 1, c1);
+    atomicAdd(counts + 2, c2);
+  }
 }
 
 }  // namespace spamd
@@ -359,32 +574,66 @@ extern "C" int spamd_spgemm_row_products(int idx_dtype, int64_t n_row, const voi
   return launch_status();
 }
 
-// Largest number of products (and of A elements) per row the row-local path takes for this value size.
-extern "C" int64_t spamd_spgemm_rows_capacity(int val_dtype) {
-  return (val_dtype == SPAMD_F32 || val_dtype == SPAMD_I32) ? RowClasses<float>::c3 : RowClasses<double>::c3;
+// Largest number of products (and of A elements) per row the row-local path takes: depends on the value size and on
+// whether (column, A-element index) fits a 32-bit key for this product (n_col columns, A rows of at most max_arow elements).
+extern "C" int64_t spamd_spgemm_rows_capacity(int val_dtype, int64_t n_col, int64_t max_arow) {
+  const bool k32 = spg_bits(n_col) + spg_bits(max_arow > 0 ? max_arow - 1 : 0) <= 32;
+  const bool v4 = val_dtype == SPAMD_F32 || val_dtype == SPAMD_I32;
+  if (k32) return v4 ? RowClasses<uint32_t, float>::c4 : RowClasses<uint32_t, double>::c4;
+  return v4 ? RowClasses<uint64_t, float>::c4 : RowClasses<uint64_t, double>::c4;
 }
 
-// Row-local expand / sort / compress.  prod_off = exclusive scan of prod (n_row + 1); tmp_cols / tmp_vals hold
-// prod_off[n_row] entries; nnz_row[n_row + 1] receives the row lengths of C (last entry untouched).
-// Rows with more products than spamd_spgemm_rows_capacity are left out (see spamd_spgemm_unpack); rows whose A row is
-// longer than the capacity must be left to the global form by the caller as well.  n_col < 2^31 - 1.
+// Row-local expand / bucket / rank / emit.  prod_off = exclusive scan of prod (n_row + 1); tmp_cols / tmp_vals hold
+// prod_off[n_row] entries; nnz_row[n_row + 1] receives the row lengths of C (last entry untouched), or -1 for a row the
+// kernel declined (one of its columns collects more than 64 products: the caller computes such rows with the global form
+// and hands them over through spamd_spgemm_unpack, like the rows above the capacity, which are skipped: their nnz_row
+// stays as the caller initialised it).  Rows whose A row is longer than the capacity must be left to the global form by
+// the caller as well.  max_arow = longest A row (spamd_spgemm_row_products).  n_col < 2^31 - 1.
 extern "C" int spamd_spgemm_rows(int val_dtype, int idx_dtype, int64_t n_row, int64_t n_col, const void* a_indptr,
                                  const void* a_indices, const void* a_data, const void* b_indptr, const void* b_indices,
-                                 const void* b_data, const int64_t* prod_off, int64_t max_prod, int* tmp_cols, void* tmp_vals,
-                                 int64_t* nnz_row, void* stream) {
-  if (n_row < 0 || n_col < 0 || n_col >= 2147483647LL) return SPAMD_EINVAL;
+                                 const void* b_data, const int64_t* prod_off, int64_t max_prod, int64_t max_arow,
+                                 int* tmp_cols, void* tmp_vals, int64_t* nnz_row, void* stream) {
+  if (n_row < 0 || n_col < 0 || n_col >= 2147483647LL || max_arow < 0) return SPAMD_EINVAL;
   if (n_row == 0) return 0;
-  // rows with more products than the capacity are skipped (nnz_row stays as the caller initialised it): the caller
-  // computes them with the global form and hands them over through spamd_spgemm_unpack
-  if (max_prod > spamd_spgemm_rows_capacity(val_dtype)) max_prod = spamd_spgemm_rows_capacity(val_dtype);
+  const int64_t cap = spamd_spgemm_rows_capacity(val_dtype, n_col, max_arow);
+  if (max_prod > cap) max_prod = cap;
+  const int col_bits = spg_bits(n_col);                       // the "gone" marker n_col must be representable
+  const int ebits = spg_bits(max_arow > 0 ? max_arow - 1 : 0);
+  const bool k32 = col_bits + ebits <= 32;
+  if (!k32 && col_bits + ebits > 64) return SPAMD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   SPAMD_DISPATCH_VAL(val_dtype, V, {
-    SPAMD_DISPATCH_IDX(idx_dtype, I, return (rowsort_all<V, I>(n_row, n_col, (const I*)a_indptr, (const I*)a_indices,
-                                                               (const V*)a_data, (const I*)b_indptr, (const I*)b_indices,
-                                                               (const V*)b_data, prod_off, max_prod, tmp_cols, (V*)tmp_vals,
-                                                               nnz_row, s)))
+    SPAMD_DISPATCH_IDX(idx_dtype, I, {
+      if (k32)
+        return (rowrank_all<uint32_t, V, I>(n_row, n_col, col_bits, ebits, (const I*)a_indptr, (const I*)a_indices,
+                                            (const V*)a_data, (const I*)b_indptr, (const I*)b_indices, (const V*)b_data,
+                                            prod_off, max_prod, tmp_cols, (V*)tmp_vals, nnz_row, s));
+      return (rowrank_all<uint64_t, V, I>(n_row, n_col, col_bits, ebits, (const I*)a_indptr, (const I*)a_indices,
+                                          (const V*)a_data, (const I*)b_indptr, (const I*)b_indices, (const V*)b_data, prod_off,
+                                          max_prod, tmp_cols, (V*)tmp_vals, nnz_row, s));
+    })
   })
   return SPAMD_ETYPE;
+}
+
+// Which rows are left to the global form (see spamd_spgemm_rows): flags[n_row + 1] (int64, ready for
+// spamd_exclusive_scan + spamd_compact; last entry zeroed) and counts[3] = {rows, their products, rows heavy only by their
+// A length} (device int64[3], zeroed here).  nnz_row may be NULL (before the row kernel ran).
+extern "C" int spamd_spgemm_classify_rows(int idx_dtype, int64_t n_row, const int64_t* prod, const void* a_indptr,
+                                          const int64_t* nnz_row, int64_t cap, int64_t* flags, int64_t* counts, void* stream) {
+  if (n_row < 0) return SPAMD_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(counts, 0, 3 * sizeof(int64_t), s);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(flags + n_row, 0, sizeof(int64_t), s);
+  if (e != hipSuccess) return (int)e;
+  if (n_row == 0) return 0;
+  int64_t blocks = ceil_div(n_row, (int64_t)256);
+  if (blocks > 4096) blocks = 4096;
+  SPAMD_DISPATCH_IDX(idx_dtype, I, hipLaunchKernelGGL(spgemm_classify_kernel<I>, dim3((unsigned)blocks), dim3(256), 0, s, n_row,
+                                                      prod, (const I*)a_indptr, nnz_row, cap, flags,
+                                                      reinterpret_cast<unsigned long long*>(counts)))
+  return launch_status();
 }
 
 extern "C" int spamd_spgemm_unpack(int val_dtype, int64_t n_heavy, const int64_t* heavy_rows, const int64_t* src_indptr,

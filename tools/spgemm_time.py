@@ -14,5 +14,6 @@ def run(local):
     return (time.perf_counter() - t) / 3 * 1e3, c
 tl, cl = run(True)
 tg, cg = run(False)
+print("row-local stats:", K.SPGEMM_STATS)
 print(f"n={n4} nnz={g.nnz}: row-local {tl:.2f} ms, global ESC {tg:.2f} ms, out nnz {cl.nnz}")
 print("identical:", torch.equal(cl.indptr.long(), cg.indptr.long()), torch.equal(cl.indices.long(), cg.indices.long()), torch.equal(cl.data, cg.data))
