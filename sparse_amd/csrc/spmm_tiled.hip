@@ -8,13 +8,13 @@
 // gather it replaces, so the list building is hoisted out of the multiply:
 //
 //   inspector (once per matrix, cached on the container):
-//     elements are re-ordered by (32-row group g, K-tile t, row, column) and written as a stream of
+//     elements are re-ordered by (35-row group g, K-tile t, row, column) and written as a stream of
 //     64-byte BLOCKS of eight (d0, d1) entries, d0 = LDS row offset of the column-in-tile | (2 + 2*row-in-group),
 //     d1 = value bits; every (g, t) list is padded to whole blocks with d0 = d1 = 0 (those land in a
 //     junk accumulator).  blk_off[g*ntiles + t] = first block of list (g, t).
 //   executor (every multiply; this kernel):
-//     a workgroup of 16 waves owns 512 rows; wave w owns row group g and keeps its 32 x 128 partial
-//     sums in the fixed VGPR block v[64:127] (lane l: columns 2l, 2l+1 of each row);
+//     a workgroup of 16 waves owns 560 rows; wave w owns row group g and keeps its 35 x 128 partial
+//     sums in the fixed VGPR block v[58:127] (lane l: columns 2l, 2l+1 of each row);
 //     B tile t (160 x 128 fp32 = 80 KB) is copied to LDS by LDS-DMA (global_load_lds_dwordx4),
 //     double-buffered, one barrier per tile;
 //     the wave pulls ITS blocks with SCALAR loads (s_load_dwordx16, three blocks in a ring), so an
@@ -40,7 +40,10 @@ constexpr int TL_WAVES = TL_ASM_WAVES;  // waves per workgroup
 // the generator is parameterised (TL_RG / TL_WAVES in tools/gen_tiled_asm.py).  64 rows x 8 waves (2 waves per SIMD, 256
 // registers) passes the parity tests but is 8 % slower with the same two-data-set pipeline (1.04 vs 0.96 ms at config 2):
 // two waves per SIMD do not cover the LDS / scalar latencies.  The shipped geometry is the one the tests run.
-static_assert(TL_RG == 32 && TL_WAVES == 16, "experimental tiled-SpMM geometry: build with -DSPAMD_TL_EXPERIMENTAL");
+// 35 rows per wave (70 accumulator registers: the LDS address of an entry is computed into its own result register, which
+// freed the four address temporaries) x 16 waves = 560 rows per B tile: 8.6 % less tile DMA than 32 x 16 and, at config 2,
+// 1786 workgroups = 6.98 rounds of the 256 CUs instead of 7.63 (8 rounds).
+static_assert(TL_RG == 35 && TL_WAVES == 16, "experimental tiled-SpMM geometry: build with -DSPAMD_TL_EXPERIMENTAL");
 #endif
 constexpr int TL_KB = TL_ASM_KB;  // B rows per tile (tools/gen_tiled_asm.py: 160 = all of the 160 KB LDS in two buffers)
 constexpr int TL_NBUF = 2;       // LDS tile buffers: tile t+1 is in flight while tile t is consumed
@@ -137,15 +140,19 @@ __global__ void __launch_bounds__(256) tl_pack_kernel(const int64_t* __restrict_
 // so no sort is needed: one workgroup per group counts (row, tile) runs in LDS, and an element's slot is
 //   8 * blk_off[g, t] + (elements of tile t in earlier rows of the group) + (position inside its row's run).
 // Two passes over A (count, fill) = ~2 GB of traffic at config 2 instead of a 64-bit radix sort of 10^8 pairs.
-constexpr int TL_DIRECT_MAX_TILES = 256;  // LDS: 2 * TL_RG * tiles * 4 B (+ tiles * 4) <= 66 KB (132 KB for 64-row groups)
+constexpr int TL_DIRECT_MAX_TILES = 256;  // LDS: 2 * TL_RG * tiles * 4 B (+ tiles * 4) <= 73 KB (35-row groups)
 
 template <typename I>
 __device__ __forceinline__ int tl_row_of(const int64_t* rs, int64_t e) {  // largest lr in [0, TL_RG) with rs[lr] <= e
-  static_assert((TL_RG & (TL_RG - 1)) == 0, "bisection over a power-of-two row group");
-  int lo = 0;
+  static_assert(TL_RG <= 64, "six bisection steps");
+  int lo = 0, hi = TL_RG;   // invariant: rs[lo] <= e < rs[hi] (rs[TL_RG] = end of the group)
 #pragma unroll
-  for (int step = TL_RG / 2; step >= 1; step >>= 1)
-    if (rs[lo + step] <= e) lo += step;
+  for (int it = 0; it < 6; ++it) {
+    const int mid = (lo + hi) >> 1;
+    if (hi - lo > 1) {
+      if (rs[mid] <= e) lo = mid; else hi = mid;
+    }
+  }
   return lo;
 }
 
@@ -316,7 +323,7 @@ spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, int touch_lines, const int* 
   // LDS reads (lgkmcnt(0): SMEM returns out of order) also waits for the scalar load issued a round
   // earlier, so its latency must be an L2 hit (~270 cycles), never HBM (~1-2 us: measured 2.25 ms
   // without this).  Two tile phases ahead, the consuming wave touches the 64-byte lines of that list
-  // with one vector load (lane i -> line i, result discarded in v61): HBM -> this XCD's L2.
+  // with one vector load (lane i -> line i, result discarded in v23): HBM -> this XCD's L2.
   // (A further scalar-cache prefetch stage — dummy s_load_dword of the next list's lines — was measured
   // 9 % SLOWER: the scalar memory path takes ~20 cycles per 64-byte request and ~5 per dword request per
   // CU whether it hits or not (tools/micro/smem_lat.hip), so extra requests cost more than the latency they save.)
@@ -335,8 +342,8 @@ spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, int touch_lines, const int* 
     const int o0 = o(t), o1 = o(t + 1), o2 = o(t + 2);
     if (t == 0) {  // lists 0 and 1 have not been touched by an earlier phase
       const int n = o2 - o0, l = lane < n ? lane : 0;
-      asm volatile("global_load_dword v61, %0, off" ::"v"(reinterpret_cast<const char*>(stream + (int64_t)o0 * 16) + l * 64)
-                   : "memory", "v61");
+      asm volatile("global_load_dword v23, %0, off" ::"v"(reinterpret_cast<const char*>(stream + (int64_t)o0 * 16) + l * 64)
+                   : "memory", "v23");
     }
     tl_phases<MODE>(stream, t, te, o0, o1, o2, offreg, obase, ntiles, nfull, toff, (int)0xfffffe00, m0wave, row_step, dptr);
     t = te;
@@ -353,7 +360,7 @@ spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, int touch_lines, const int* 
                :
                : [lo] "v"((unsigned)((uintptr_t)obase_p & 0xffffffffu)), [hi] "v"((unsigned)((uintptr_t)obase_p >> 32)),
                  [stride] "s"(stride_bytes), [n] "s"(nvalid)
-               : "memory", "scc", "s36", "v60", "v61", TL_CLOB_ACC);
+               : "memory", "scc", "s36", "v22", "v23", TL_CLOB_ACC);
 }
 
 static int64_t tl_grid_groups(int64_t M) { return ceil_div(ceil_div(M, (int64_t)TL_RG), (int64_t)TL_WAVES) * TL_WAVES; }

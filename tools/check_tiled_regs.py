@@ -6,7 +6,7 @@ compiler's code runs (chunk loop, partial-tile DMA, list offsets).  `amdgpu_num_
 in v0..v21, but LLVM drops that request when it conflicts with its occupancy bounds, so this script checks the
 compiled code instead: every instruction of the spmm_tiled kernels OUTSIDE the `;;#ASMSTART` / `;;#ASMEND` regions
 may only use registers below the accumulator block (the first register of TL_CLOB_ACC in the generated include:
-v62 for the 32-row geometry).  Scratch registers of the asm (v24..v61) are dead between asm blocks and free for the
+v56 for the 35-row geometry).  Scratch registers of the asm (v22..v55) are dead between asm blocks and free for the
 compiler; the walking DMA pointer is an in/out operand.
 
     python tools/check_tiled_regs.py [extra hipcc flags]      exit code 1 on a violation

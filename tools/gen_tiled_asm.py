@@ -7,11 +7,14 @@ executor (csrc/spmm_tiled.hip) as C string literals.  Run after changing the reg
 Register map (must match spmm_tiled.hip):
     v0..v21    compiler (kernel is capped with amdgpu_num_vgpr(22))
     (the walking source pointer of the wave's tile-DMA share is an in/out operand: the compiler keeps it)
+    v22        LDS base of the current tile + 8*lane    v23  destination of the line touches
+    (v22..v23  store address after the loop)
     v24..v39   eight ds_read_b64 results, set 1 (software-pipelined loop)
-    v40..v43   LDS address temporaries          v44..v59  eight ds_read_b64 results, set 0
-    v60        LDS base of the current tile + 8*lane    v61  destination of the line touches
-    (v60..v61  store address after the loop)     v62..v63  junk accumulator (padding entries)
-    v64..v127  32 rows x (2 columns per lane) partial sums
+    v40..v55   eight ds_read_b64 results, set 0
+               (an entry's LDS address is computed INTO the low register of its result pair: no address temporaries,
+               which is what makes room for 35 instead of 32 rows per wave)
+    v56..v57   junk accumulator (padding entries)
+    v58..v127  35 rows x (2 columns per lane) partial sums
     s36..s38   stream pointer / block counter (s39 free; pending DMA instructions: VCC as a mask of ones)
     s40..s87   three 8-entry blocks (16 dwords each)
     s88..s89   temporary / LDS destination of the next tile-DMA instruction
@@ -22,15 +25,16 @@ import os
 ENTRIES = 8      # entries per 16-dword block: 8 x (d0, f32 value) or, for f64, 5 d0 + pad + 5 x (value lo, hi)
 F64 = False
 RING = (40, 56, 72)
-ADDR = (40, 41, 42, 43)
-DATA0 = 44
-ROWS = int(os.environ.get("TL_RG", "32"))     # rows per wave: 2 accumulator registers each, v[2*ROWS : 4*ROWS)
+ROWS = int(os.environ.get("TL_RG", "35"))     # rows per wave: 2 accumulator registers each, v[128 - 2*ROWS : 128)
 WAVES = int(os.environ.get("TL_WAVES", "16"))  # waves per workgroup (ROWS * WAVES rows share one B tile)
-ACC0 = 2 * ROWS
+ACC0 = 128 - 2 * ROWS
 JUNK = ACC0 - 2                               # junk accumulator pair (padding entries), just below the accumulators
+BASE = 22                                     # LDS base of the current tile + 8*lane
+TOUCH = 23                                    # destination of the line touches
 
 
-DATASET = (44, 24)
+DATASET = (40, 24)
+assert JUNK >= DATASET[0] + 16, "accumulators collide with the data sets"
 
 
 def d0_reg(buf, i):
@@ -56,10 +60,11 @@ def p1(buf, dset):
     for g0 in range(0, ENTRIES, P1_GROUP):
         grp = range(g0, min(g0 + P1_GROUP, ENTRIES))
         for i in grp:
-            o.append(f"v_and_or_b32 v{ADDR[i % len(ADDR)]}, s{d0_reg(buf, i)}, %[mask], v60")
+            d = DATASET[dset] + 2 * i
+            o.append(f"v_and_or_b32 v{d}, s{d0_reg(buf, i)}, %[mask], v{BASE}")
         for i in grp:
             d = DATASET[dset] + 2 * i
-            o.append(f"ds_read_b64 v[{d}:{d + 1}], v{ADDR[i % len(ADDR)]}")
+            o.append(f"ds_read_b64 v[{d}:{d + 1}], v{d}")
     return o
 
 
@@ -206,11 +211,11 @@ def phases(lds=True, fma=True, exact=False):
     the first blocks of list t+1 are requested BEFORE the barrier that ends phase t (the scalar path serves
     one 64-byte request per ~20 cycles per CU; 16 waves x 3 requests right after a barrier idle the CU for
     ~1000 cycles).  s90 = t, s91/s92/s93 = first block of lists t, t+1, t+2; s[36:37] = pointer of list t on
-    entry to a phase (left there by the request of its first blocks).  v60 (LDS base of the tile being read)
+    entry to a phase (left there by the request of its first blocks).  v22 (LDS base of the tile being read)
     and s89 (LDS destination of the tile being loaded) toggle between the two buffers once per phase."""
     o = ["s_mov_b32 s90, %[t0]", "s_mov_b32 s91, %[o0]", "s_mov_b32 s92, %[o1]", "s_mov_b32 s93, %[o2]",
          "s_add_u32 s88, s90, 1", "s_and_b32 s88, s88, 1", "s_lshl_b32 s88, s88, 10", "s_add_u32 s89, s88, %[m0wave]",
-         "s_and_b32 s88, s90, 1", "s_lshl_b32 s88, s88, 10", "v_or_b32 v60, s88, %[lane8]"]
+         "s_and_b32 s88, s90, 1", "s_lshl_b32 s88, s88, 10", f"v_or_b32 v{BASE}, s88, %[lane8]"]
     o += request_first_blocks(91, 92, 20, 22)
     o += ["1:",
           "s_sub_u32 s38, s92, s91",                       # blocks in this list
@@ -228,11 +233,11 @@ def phases(lds=True, fma=True, exact=False):
           "s_lshl_b32 s94, s93, 6", "s_lshr_b32 s95, s93, 26", "s_add_u32 s94, s94, %[blo]", "s_addc_u32 s95, s95, %[bhi]",
           "v_readlane_b32 s88, %[offreg], s38",
           "s_mov_b32 s91, s92", "s_mov_b32 s92, s93",
-          "v_xor_b32 v60, 0x400, v60",
+          f"v_xor_b32 v{BASE}, 0x400, v{BASE}",
           "s_and_b32 s89, s89, 0x7fff", "s_xor_b32 s89, s89, 0x400",   # back to the wave's first row pair, other buffer
           # touch the first lines of list t+2 (lane i -> line min(i, L-1), L chosen by the launcher from the mean
           # list length): always ONE instruction; lists are consecutive, so lines past a short list are the next one's
-          "global_load_dword v61, %[toff], s[94:95]"]
+          f"global_load_dword v{TOUCH}, %[toff], s[94:95]"]
     o += ["s_mov_b32 s93, s88",
           "s_waitcnt vmcnt(1)",      # tile t+1 (this wave's share) has landed; the touch may still fly
           "s_barrier",
@@ -248,11 +253,11 @@ def tile0():
 
 
 def store():
-    o = ["v_mov_b32 v60, %[lo]", "v_mov_b32 v61, %[hi]", "s_mov_b32 s36, 0"]
+    o = [f"v_mov_b32 v{BASE}, %[lo]", f"v_mov_b32 v{BASE + 1}, %[hi]", "s_mov_b32 s36, 0"]
     for j in range(ROWS):
         o += ["s_cmp_ge_i32 s36, %[n]", "s_cbranch_scc1 9f",
-              f"global_store_dwordx2 v[60:61], v[{ACC0 + 2 * j}:{ACC0 + 1 + 2 * j}], off nt",
-              "v_lshl_add_u64 v[60:61], %[stride], 0, v[60:61]",
+              f"global_store_dwordx2 v[{BASE}:{BASE + 1}], v[{ACC0 + 2 * j}:{ACC0 + 1 + 2 * j}], off nt",
+              f"v_lshl_add_u64 v[{BASE}:{BASE + 1}], %[stride], 0, v[{BASE}:{BASE + 1}]",
               "s_add_i32 s36, s36, 1"]
     o.append("9:")
     return o
@@ -293,7 +298,7 @@ def main():
            lit("TL_ASM_STORE", store()),
            lit("TL_ASM_ZERO", zero()),
            f"#define TL_CLOB_SGPR {clob('s', 36, 95)}\n",
-           f"#define TL_CLOB_TMP {clob('v', 24, 61)}\n",
+           f"#define TL_CLOB_TMP {clob('v', BASE, JUNK - 1)}\n",
            f"#define TL_CLOB_ACC {clob('v', JUNK, ACC0 + 2 * ROWS - 1)}\n"]
     p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "sparse_amd", "csrc", "spmm_tiled_asm.inc")
     with open(p, "w") as f:
