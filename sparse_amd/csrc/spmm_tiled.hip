@@ -83,6 +83,7 @@ struct TlFmt<double> {
     b[7 + 2 * slot] = (int)(bits >> 32);
   }
 };
+typedef int tl_srd_t __attribute__((ext_vector_type(4)));   // buffer descriptor of B (four SGPRs)
 constexpr int TL_TILE = TL_KB * 512;
 constexpr int TL_LDS = TL_NBUF * TL_TILE;
 constexpr int TL_DMA_PER_TILE = TL_TILE / 16 / (TL_WAVES * 64);  // LDS-DMA instructions per wave per tile
@@ -241,15 +242,15 @@ __device__ __forceinline__ void tl_dma16(unsigned lds_base, const void* src) {
 template <int MODE>
 __device__ __forceinline__ void tl_phases(const int* stream, int t0, int te, int o0, int o1, int o2, int offreg, int obase,
                                           int ntiles, int nfull, int toff, int mask, unsigned m0wave,
-                                          int64_t row_step, uint64_t& dptr) {
+                                          unsigned row_step, int voff, tl_srd_t srd, unsigned& soff) {
   const int lane = threadIdx.x & 63;
   const unsigned blo = (unsigned)((uintptr_t)stream & 0xffffffffu), bhi = (unsigned)((uintptr_t)stream >> 32);
   const int lane8 = lane * 8;
 #define TL_PHASES_OPERANDS                                                                                        \
-  [dptr] "+v"(dptr)                                                                                               \
+  [soff] "+s"(soff)                                                                                               \
   : [blo] "s"(blo), [bhi] "s"(bhi), [t0] "s"(t0), [te] "s"(te), [o0] "s"(o0), [o1] "s"(o1), [o2] "s"(o2),         \
     [obase] "s"(obase), [ntiles] "s"(ntiles), [nfull] "s"(nfull), [m0wave] "s"(m0wave), [step] "s"(row_step),      \
-    [toff] "v"(toff), [lane8] "v"(lane8), [mask] "v"(mask), [offreg] "v"(offreg)                                  \
+    [toff] "v"(toff), [lane8] "v"(lane8), [mask] "v"(mask), [offreg] "v"(offreg), [voff] "v"(voff), [srd] "s"(srd)  \
   : "memory", "m0", "scc", "vcc", TL_CLOB_SGPR, TL_CLOB_TMP, TL_CLOB_ACC
   if (MODE == 4)
     asm volatile(TL_ASM_PHASES_F64 : TL_PHASES_OPERANDS);
@@ -290,12 +291,20 @@ spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, int touch_lines, const int* 
   // the last, partial tile goes through `issue_partial`, rows past K clamped to row K-1 (no entry
   // refers to them).
   const int nfull = DBG == 2 ? 0 : (int)(K / TL_KB);
-  const int64_t row_step = (2 * TL_WAVES) * ldb * (int64_t)sizeof(T);  // rows covered by one round of DMA instructions
+  const unsigned row_step = (unsigned)((2 * TL_WAVES) * ldb * (int64_t)sizeof(T));  // bytes of B covered by one round of DMA instructions
   const unsigned m0wave = (unsigned)wv * 2048u;  // LDS offset of this wave's first row pair (buffer 0)
-  // walking source pointer of this thread's share of the tile DMA: an in/out operand of the asm blocks, so that it
-  // lives in registers the compiler knows about (state parked in "clobbered" registers between asm blocks is only safe
-  // while the compiler happens not to need them)
-  uint64_t dptr = (uint64_t)(uintptr_t)(b + (int64_t)(tid >> 5) * ldb + (tid & 31) * (16 / (int)sizeof(T)));
+  // source of the tile DMA: a buffer descriptor of this column panel of B (wave-uniform: SGPRs), the lane's fixed byte
+  // offset inside a round of rows, and a walking scalar offset that is an in/out operand of the asm blocks (state parked
+  // in "clobbered" registers between asm blocks is only safe while the compiler happens not to need them).  32-bit offsets:
+  // the launcher checks that a panel of B spans less than 4 GB.
+  const uint64_t bbase = (uint64_t)(uintptr_t)b;
+  tl_srd_t srd;
+  srd[0] = (int)(bbase & 0xffffffffu);
+  srd[1] = (int)((bbase >> 32) & 0xffffu);          // stride 0
+  srd[2] = (int)0xffffffffu;                         // num_records: byte range (the entries never refer past K)
+  srd[3] = 0x00020000;                               // raw buffer, 32-bit data format
+  const int voff = (int)((int64_t)(tid >> 5) * ldb * (int64_t)sizeof(T)) + (tid & 31) * 16;
+  unsigned soff = 0;
   auto issue_partial = [&](int t) {
 #pragma unroll
     for (int i = 0; i < TL_DMA_PER_TILE; ++i) {
@@ -309,7 +318,7 @@ spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, int touch_lines, const int* 
   const bool has_partial = DBG != 2 && (int64_t)nfull * TL_KB < K;  // tile `nfull` is the partial one
 
   if (nfull > 0)
-    asm volatile(TL_ASM_TILE0 : [dptr] "+v"(dptr) : [m0wave] "s"(m0wave), [step] "s"(row_step) : "memory", "m0", "scc", "vcc", "s89");
+    asm volatile(TL_ASM_TILE0 : [soff] "+s"(soff) : [m0wave] "s"(m0wave), [step] "s"(row_step), [voff] "v"(voff), [srd] "s"(srd) : "memory", "m0", "scc", "vcc", "s89");
   else if (has_partial)
     issue_partial(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -345,7 +354,7 @@ spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, int touch_lines, const int* 
       asm volatile("global_load_dword v23, %0, off" ::"v"(reinterpret_cast<const char*>(stream + (int64_t)o0 * 16) + l * 64)
                    : "memory", "v23");
     }
-    tl_phases<MODE>(stream, t, te, o0, o1, o2, offreg, obase, ntiles, nfull, toff, (int)0xfffffe00, m0wave, row_step, dptr);
+    tl_phases<MODE>(stream, t, te, o0, o1, o2, offreg, obase, ntiles, nfull, toff, (int)0xfffffe00, m0wave, row_step, voff, srd, soff);
     t = te;
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -517,6 +526,7 @@ extern "C" int spamd_spmm_tiled(int val_dtype, int64_t M, int64_t K, int64_t N, 
   if (M == 0) return 0;
   if (((uintptr_t)b % 16) || ((ldb * esz) % 16) || ((uintptr_t)out % 8) || ((ldo * esz) % 8) || ((uintptr_t)blocks % 64))
     return SPAMD_EINVAL;
+  if ((K + 2 * TL_KB) * ldb * esz >= ((int64_t)1 << 32)) return SPAMD_EINVAL;  // the tile DMA walks B with 32-bit byte offsets
   hipStream_t s = (hipStream_t)stream;
   const bool exact = (flags & SPAMD_EXACT_MULADD) != 0;
   // lines of a list that are pulled into L2 two phases ahead (flags bits 8..15; 0 = default): the launcher derives

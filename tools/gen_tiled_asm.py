@@ -109,14 +109,15 @@ def p2_exact(buf, dset):
 
 
 def dma_body():
-    """one tile-DMA instruction of the NEXT tile: from the walking source pointer %[dptr] (a compiler-owned in/out register pair, advanced one round of B rows)
-    to LDS address s89 (advanced by 16 row pairs = 32 KB of the interleaved buffers; the s_add also is the wait state
-    M0 needs before an LDS-DMA), and one
-    bit less in the pending mask (VCC)"""
+    """one tile-DMA instruction of the NEXT tile, in the buffer form: source = the B descriptor %[srd] (SGPRs) + the lane's
+    fixed byte offset %[voff] + the walking scalar offset %[soff] (a compiler-owned in/out SGPR, advanced one round of B
+    rows by a SALU add: the flat form needed a 64-bit VALU add on a per-lane pointer pair and twice the address registers);
+    LDS address s89 (advanced by 16 row pairs = 32 KB of the interleaved buffers; the s_add also is the wait state
+    M0 needs before an LDS-DMA), and one bit less in the pending mask (VCC)"""
     return ["s_mov_b32 m0, s89",
             f"s_add_u32 s89, s89, {hex(WAVES * 2048)}",
-            "global_load_lds_dwordx4 %[dptr], off",
-            "v_lshl_add_u64 %[dptr], %[step], 0, %[dptr]",
+            "buffer_load_dwordx4 %[voff], %[srd], %[soff] offen lds",
+            "s_add_u32 %[soff], %[soff], %[step]",
             "s_lshr_b64 vcc, vcc, 1"]
 
 
