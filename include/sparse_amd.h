@@ -106,6 +106,11 @@ int spamd_spmm_tiled_count(int val_dtype, int idx_dtype, int64_t M, int64_t K, c
 int spamd_spmm_tiled_fill(int val_dtype, int idx_dtype, int64_t M, int64_t K, const void* a_data, const void* a_indices,
                           const void* a_indptr, const int64_t* blk_off, int64_t total_blocks, int* blocks,
                           void* stream);
+/* one-pass form of count + scan + fill (decoupled look-back over the row groups): blk_off int32[lists + 1]; `blocks` has
+ * room for ceil(nnz / entries_per_block) + lists + slack_blocks blocks; state = groups + 2 64-bit words of workspace;
+ * state[groups + 1] != 0 afterwards: unsorted column indices, outputs invalid (use the key-sort recipe) */
+int spamd_spmm_tiled_inspect(int val_dtype, int idx_dtype, int64_t M, int64_t K, const void* a_data, const void* a_indices,
+                             const void* a_indptr, void* state, int* blk_off, int* blocks, void* stream);
 int spamd_spmm_tiled_keys(int64_t nnz, const int64_t* rowcol_keys, int64_t K, int64_t* tiled_keys, void* stream);
 int spamd_spmm_tiled_lists(int val_dtype, int64_t nnz, const int64_t* tiled_keys_sorted, int64_t M, int64_t K,
                            int64_t* seg_start, int64_t* nblk, void* stream);

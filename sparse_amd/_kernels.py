@@ -812,12 +812,26 @@ TILED_DTYPES = (torch.float32, torch.float64)
 _TOUCH_OVERRIDE = int(__import__("os").environ.get("SPARSE_AMD_TILED_TOUCH", "0"))   # tuning hook: lines prefetched per list
 
 
+TILED_ONE_PASS_INSPECTOR = True   # False: the two-pass builder (count, scan, fill) - kept for cross-checks
+
+
+class TiledLayout(tuple):
+    """(blocks, blk_off, value dtype) + `mean_blocks` = mean 64-byte blocks per (row group, tile) list, which the
+    launcher turns into the executor's prefetch width without reading anything back from the device"""
+
+    def __new__(cls, blocks, blk_off, dtype, mean_blocks):
+        self = super().__new__(cls, (blocks, blk_off, dtype))
+        self.mean_blocks = mean_blocks
+        return self
+
+
 def csr_tiled_layout(a_data, a_indices, a_indptr, M, Kd, force_sort=False, dtype=None):
     """Inspector: the K-tiled block stream of a CSR matrix used by `dot_csr_ndarray_tiled`, for float32 or float64
     values (`dtype`, default: a_data's if it is one of them, else float32).
     Returns (blocks int32[(total_blocks + slack) * 16], blk_off int32[nseg + 1], value dtype).
-    Sorted column indices and a moderate K take the direct two-pass builder (count, scan, fill); anything
-    else the general key-sort recipe."""
+    Sorted column indices and a moderate K take the direct one-pass builder (count + look-back scan + fill in one
+    launch; the stream is then allocated for its upper bound and `blocks` is longer than `blk_off[-1] + slack` blocks);
+    anything else the general key-sort recipe."""
     dev = require_hip(a_data, a_indices, a_indptr)
     if dtype is None:
         dtype = a_data.dtype if a_data.dtype in TILED_DTYPES else torch.float32
@@ -841,7 +855,21 @@ def csr_tiled_layout(a_data, a_indices, a_indptr, M, Kd, force_sort=False, dtype
         fill(blk_off, total, blocks)
         return blocks, convert(blk_off, torch.int32), dtype
 
-    if ntiles <= direct_max and not force_sort:
+    if ntiles <= direct_max and not force_sort and TILED_ONE_PASS_INSPECTOR:
+        # one pass over A (csrc/spmm_tiled.hip `tl_inspect_kernel`): count, scan (decoupled look-back over the row groups),
+        # fill and padding in a single launch; the stream is allocated for its upper bound, so nothing waits for a total
+        ic = code_of(a_indices.dtype)
+        ind, ptr_ = a_indices.contiguous(), a_indptr.contiguous()
+        upper = -(-nnz // epb) + nseg
+        if upper < 2 ** 31:
+            blocks = torch.empty((upper + slack) * 16, dtype=torch.int32, device=dev)
+            blk_off = torch.empty(nseg + 1, dtype=torch.int32, device=dev)
+            state = torch.empty(groups + 2, dtype=torch.int64, device=dev)
+            _ffi.call("spamd_spmm_tiled_inspect", vc, ic, M, Kd, ptr(vals), ptr(ind), ptr(ptr_), ptr(state), ptr(blk_off),
+                      ptr(blocks), s)
+            if int(state[groups + 1]) == 0:      # (sorted column indices everywhere)
+                return TiledLayout(blocks, blk_off, dtype, nnz / epb / max(nseg, 1) + 0.5)
+    elif ntiles <= direct_max and not force_sort:
         nblk = torch.empty(nseg + 1, dtype=torch.int64, device=dev)
         flags = torch.empty(1, dtype=torch.int32, device=dev)
         ic = code_of(a_indices.dtype)
@@ -876,7 +904,8 @@ def dot_csr_ndarray_tiled(layout, out_shape, Kd, b, out=None, exact=False):
         out = torch.empty((M, N), dtype=dtype, device=dev)
     # prefetch hint: ~1.5 x the mean number of 64-byte blocks per (row group, tile) list
     lists = max(int(blk_off.numel()) - 1, 1)
-    hint = min(64, max(6, int(1.5 * (int(blocks.numel()) // 16) / lists) + 3))
+    mean_blocks = getattr(layout, "mean_blocks", None) or (int(blocks.numel()) // 16) / lists
+    hint = min(64, max(6, int(1.5 * mean_blocks) + 3))
     if _TOUCH_OVERRIDE:
         hint = _TOUCH_OVERRIDE
     _ffi.call("spamd_spmm_tiled", code_of(dtype), M, Kd, N, ptr(blocks), ptr(blk_off), ptr(b), N, ptr(out), N,

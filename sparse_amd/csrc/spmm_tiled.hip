@@ -79,6 +79,7 @@ struct TlFmt<double> {
     const int slot = (int)(entry % EPB);
     const long long bits = __builtin_bit_cast(long long, v);
     b[slot] = d0;
+    if (slot == 0) b[5] = 0;   // (the unused dword of the block: written so that the stream is the same bytes whoever builds it)
     b[6 + 2 * slot] = (int)(bits & 0xffffffffLL);
     b[7 + 2 * slot] = (int)(bits >> 32);
   }
@@ -141,6 +142,8 @@ __global__ void __launch_bounds__(256) tl_pack_kernel(const int64_t* __restrict_
 // so no sort is needed: one workgroup per group counts (row, tile) runs in LDS, and an element's slot is
 //   8 * blk_off[g, t] + (elements of tile t in earlier rows of the group) + (position inside its row's run).
 // Two passes over A (count, fill) = ~2 GB of traffic at config 2 instead of a 64-bit radix sort of 10^8 pairs.
+constexpr int TL_INFO = 8192;             // elements of a row group whose (row, tile) the one-pass inspector keeps in LDS (16 KB)
+static_assert(TL_RG <= 256, "row in group packed into 8 bits next to the tile");
 constexpr int TL_DIRECT_MAX_TILES = 256;  // LDS: 2 * TL_RG * tiles * 4 B (+ tiles * 4) <= 73 KB (35-row groups)
 
 template <typename I>
@@ -223,6 +226,114 @@ __global__ void __launch_bounds__(256) tl_fill_kernel(int64_t M, int ntiles, con
     const int lr = tl_row_of<I>(rs, e);
     const int64_t dst = goff[t] * TlFmt<T>::EPB + before[lr * ntiles + t] + ((int)(e - e0) - runstart[lr * ntiles + t]);
     TlFmt<T>::put(stream, dst, tl_d0(lc, lr), vals[e]);
+  }
+}
+
+// ---- fused inspector: count + scan + fill in ONE pass over A ------------------------------------------------------------
+// The two-pass builder reads the indices twice, scans the 1.8 M list sizes in a separate launch, clears the 0.87 GB stream
+// with a memset and needs the host to read the total before it can allocate.  Here one workgroup per row group counts its
+// (row, tile) runs in LDS, scans its tiles' block counts locally, obtains its first block from its predecessors by
+// decoupled look-back (groups are taken in ticket order, so a group only ever waits for groups that are already running),
+// writes its slice of blk_off, fills its lists and zeroes their padding entries itself.  The stream is allocated for the
+// upper bound ceil(nnz / EPB) + lists (every list wastes less than one block).  state[groups] = ticket counter,
+// state[groups + 1] = "a row has unsorted column indices" (the caller then takes the key-sort recipe).
+template <typename I, typename T>
+__global__ void __launch_bounds__(256) tl_inspect_kernel(int64_t M, int ntiles, int64_t groups, const T* __restrict__ vals,
+                                                         const I* __restrict__ indices, const I* __restrict__ indptr,
+                                                         unsigned long long* __restrict__ state, int* __restrict__ blk_off,
+                                                         int* __restrict__ stream) {
+  extern __shared__ int tl_fill_lds[];  // before[RG][ntiles], runstart[RG][ntiles] (relative to e0), loff[ntiles + 1], info[]
+  __shared__ int64_t rs[TL_RG + 1];
+  __shared__ int64_t ticket_s, goff_s;
+  __shared__ int wtot[5];
+  constexpr int EPB = TlFmt<T>::EPB;
+  int* const before = tl_fill_lds;
+  int* const runstart = before + TL_RG * ntiles;
+  int* const loff = runstart + TL_RG * ntiles;
+  // (row in group, tile) of the group's first TL_INFO elements, kept from the counting pass for the fill pass: the
+  // bisection over the row starts and the division by the tile height are then done once per element
+  unsigned short* const info = reinterpret_cast<unsigned short*>(loff + ntiles + 1);
+  const int tid = threadIdx.x;
+  if (tid == 0) ticket_s = (int64_t)atomicAdd(&state[groups], 1ull);
+  __syncthreads();
+  const int64_t g = ticket_s;
+  const int64_t r0 = g * TL_RG;
+  if (tid <= TL_RG) {
+    const int64_t r = r0 + tid;
+    rs[tid] = (int64_t)indptr[r < M ? r : M];
+  }
+  for (int i = tid; i < TL_RG * ntiles; i += 256) before[i] = 0;
+  __syncthreads();
+  const int64_t e0 = rs[0], e1 = rs[TL_RG];
+  bool bad = false;
+  for (int64_t e = e0 + tid; e < e1; e += 256) {
+    const unsigned c = (unsigned)indices[e];          // (K <= 256 tiles x 160 columns: 32-bit arithmetic)
+    const int t = (int)(c / (unsigned)TL_KB);
+    const int lr = tl_row_of<I>(rs, e);
+    atomicAdd(&before[lr * ntiles + t], 1);
+    const bool row_start = e == rs[lr];
+    const unsigned cp = row_start ? 0u : (unsigned)indices[e - 1];
+    if (!row_start && cp > c) bad = true;
+    if (row_start || (int)(cp / (unsigned)TL_KB) != t) runstart[lr * ntiles + t] = (int)(e - e0);
+    if (e - e0 < TL_INFO) info[e - e0] = (unsigned short)((lr << 8) | t);
+  }
+  if (bad) atomicOr(&state[groups + 1], 1ull);
+  __syncthreads();
+  // per tile: elements of the tile in earlier rows of the group; blocks of the list
+  int nb = 0, cnt_t = 0;
+  for (int t = tid; t < ntiles; t += 256) {   // (ntiles <= 256: one tile per thread)
+    int run = 0;
+    for (int lr = 0; lr < TL_RG; ++lr) {
+      const int c = before[lr * ntiles + t];
+      before[lr * ntiles + t] = run;
+      run += c;
+    }
+    cnt_t = run;
+    nb = (run + EPB - 1) / EPB;
+  }
+  // exclusive scan of nb over the tiles (thread = tile)
+  const int lane = tid & 63, wid = tid >> 6;
+  int x = nb;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) wtot[wid] = x;
+  __syncthreads();
+  int woff = 0;
+  for (int w = 0; w < wid; ++w) woff += wtot[w];
+  const int gtotal = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+  const int my_off = woff + x - nb;
+  if (tid < 64) {   // wave 0 looks back
+    const unsigned long long excl = lookback_exclusive(state, g, (unsigned long long)gtotal, tid);
+    if (tid == 0) goff_s = (int64_t)excl;
+  }
+  if (tid < ntiles) loff[tid] = my_off;
+  __syncthreads();
+  const int64_t goff = goff_s;
+  if (tid < ntiles) blk_off[g * ntiles + tid] = (int)(goff + my_off);
+  if (g == groups - 1 && tid == 0) blk_off[groups * ntiles] = (int)(goff + gtotal);
+  // fill
+  for (int64_t e = e0 + tid; e < e1; e += 256) {
+    const unsigned c = (unsigned)indices[e];
+    int t, lr;
+    if (e - e0 < TL_INFO) {
+      const unsigned pk = info[e - e0];
+      t = (int)(pk & 255u);
+      lr = (int)(pk >> 8);
+    } else {
+      t = (int)(c / (unsigned)TL_KB);
+      lr = tl_row_of<I>(rs, e);
+    }
+    const int lc = (int)(c - (unsigned)t * (unsigned)TL_KB);
+    const int64_t dst = (goff + loff[t]) * EPB + before[lr * ntiles + t] + ((int)(e - e0) - runstart[lr * ntiles + t]);
+    TlFmt<T>::put(stream, dst, tl_d0(lc, lr), vals[e]);
+  }
+  // padding entries of my list (zero d0 and value: they accumulate into the junk register pair)
+  if (tid < ntiles) {
+    const int64_t first = (goff + my_off) * EPB;
+    for (int i = cnt_t; i < nb * EPB; ++i) TlFmt<T>::put(stream, first + i, 0, T(0));
   }
 }
 
@@ -491,6 +602,46 @@ extern "C" int spamd_spmm_tiled_fill(int val_dtype, int idx_dtype, int64_t M, in
                                       blocks, (hipStream_t)stream);
     return tl_launch_fill<I, double>(M, ntiles, (const double*)a_data, (const I*)a_indices, (const I*)a_indptr, blk_off,
                                      blocks, (hipStream_t)stream);
+  })
+  return SPAMD_ETYPE;
+}
+
+template <typename I, typename T>
+static int tl_launch_inspect(int64_t M, int64_t ntiles, const T* a_data, const I* a_indices, const I* a_indptr,
+                             unsigned long long* state, int* blk_off, int* blocks, hipStream_t s) {
+  const int64_t groups = tl_grid_groups(M);
+  const int lds = (int)((2 * TL_RG * ntiles + ntiles + 1) * sizeof(int)) + TL_INFO * (int)sizeof(unsigned short);
+  auto kern = &tl_inspect_kernel<I, T>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(256), lds, s, M, (int)ntiles, groups, a_data, a_indices, a_indptr,
+                     state, blk_off, blocks);
+  return launch_status();
+}
+
+// One-pass inspector for CSR with sorted column indices and at most `direct_max_tiles` tiles: fills blk_off[lists + 1]
+// (int32) and the block stream, which must have room for ceil(nnz / entries_per_block) + lists + slack blocks;
+// state = (groups + 2) zero-initialised 64-bit words of workspace (zeroed here); on return state[groups + 1] != 0 means a
+// row with unsorted column indices was met: the outputs are then garbage and the caller takes the key-sort recipe.
+extern "C" int spamd_spmm_tiled_inspect(int val_dtype, int idx_dtype, int64_t M, int64_t K, const void* a_data,
+                                        const void* a_indices, const void* a_indptr, void* state, int* blk_off, int* blocks,
+                                        void* stream) {
+  if (M < 0 || K <= 0) return SPAMD_EINVAL;
+  if (!tl_epb(val_dtype)) return SPAMD_ETYPE;
+  const int64_t ntiles = ceil_div(K, (int64_t)TL_KB);
+  if (ntiles > TL_DIRECT_MAX_TILES) return SPAMD_EINVAL;
+  const int64_t groups = tl_grid_groups(M);
+  hipError_t e = hipMemsetAsync(state, 0, (size_t)(groups + 2) * sizeof(unsigned long long), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  if (groups == 0) return (int)hipMemsetAsync(blk_off, 0, sizeof(int), (hipStream_t)stream);
+  SPAMD_DISPATCH_IDX(idx_dtype, I, {
+    if (val_dtype == SPAMD_F32)
+      return tl_launch_inspect<I, float>(M, ntiles, (const float*)a_data, (const I*)a_indices, (const I*)a_indptr,
+                                         (unsigned long long*)state, blk_off, blocks, (hipStream_t)stream);
+    return tl_launch_inspect<I, double>(M, ntiles, (const double*)a_data, (const I*)a_indices, (const I*)a_indptr,
+                                        (unsigned long long*)state, blk_off, blocks, (hipStream_t)stream);
   })
   return SPAMD_ETYPE;
 }

@@ -40,7 +40,7 @@ def test_tiled_bit_identical_to_rowgroup_fma(orc, idt, M, K, density):
     assert_within_fma_bound(got.cpu().numpy(), want, data, idx, ptr, b)   # the executor itself, 1e-6 * sum|a_k b_k|
     blocks, blk_off, _ = layout
     rg, kb, gpb, epb, slack, _, _ = Kn_params()
-    assert bool((blk_off[1:] >= blk_off[:-1]).all()) and blocks.numel() == (int(blk_off[-1]) + slack) * epb * 2
+    assert bool((blk_off[1:] >= blk_off[:-1]).all()) and blocks.numel() >= (int(blk_off[-1]) + slack) * epb * 2
     ent = blocks.view(-1, 2)[: int(blk_off[-1]) * epb].cpu().numpy()
     real = ent[ent[:, 0] != 0]                                         # padding entries are all-zero
     assert len(real) == len(data)
@@ -189,7 +189,14 @@ def test_direct_inspector_equals_the_key_sort_recipe(idt, M, K, density):
     td, ti, tp = (torch.from_numpy(x).to(d) for x in (data, idx, ptr))
     b1, o1, _ = Kn.csr_tiled_layout(td, ti, tp, M, K)
     b2, o2, _ = Kn.csr_tiled_layout(td, ti, tp, M, K, force_sort=True)
-    assert torch.equal(o1, o2) and torch.equal(b1, b2)
+    used = int(o1[-1]) * 16     # (the one-pass inspector allocates the stream for its upper bound: compare what is used)
+    assert torch.equal(o1, o2) and torch.equal(b1[:used], b2[:used])
+    Kn.TILED_ONE_PASS_INSPECTOR = False
+    try:
+        b3, o3, _ = Kn.csr_tiled_layout(td, ti, tp, M, K)       # the two-pass builder (count, scan, fill)
+    finally:
+        Kn.TILED_ONE_PASS_INSPECTOR = True
+    assert torch.equal(o1, o3) and torch.equal(b1[:used], b3[:used])
 
 
 def test_unsorted_rows_fall_back_to_the_key_sort_recipe(orc):
@@ -231,7 +238,8 @@ def test_tiled_f64_bit_identical_to_rowgroup_and_reference(orc, M, K, density, N
     assert np.array_equal(got.cpu().numpy().view(np.uint64), want.view(np.uint64))   # exact mode = reference bits
     b1, o1, _ = layout
     b2, o2, _ = Kn.csr_tiled_layout(td, ti, tp, M, K, force_sort=True)
-    assert torch.equal(o1, o2) and torch.equal(b1, b2)
+    used = int(o1[-1]) * 16
+    assert torch.equal(o1, o2) and torch.equal(b1[:used], b2[:used])
 
 
 def test_product_path_float64_and_mixed_precision(orc, monkeypatch):

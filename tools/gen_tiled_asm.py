@@ -51,6 +51,7 @@ DMA_AT_START = int(os.environ.get("TL_DMA_AT_START", "2"))  # tile-DMA instructi
 KB = int(os.environ.get("TL_KB", "160"))                    # B rows per LDS tile (multiple of 32; 2 x KB x 512 B <= 160 KB)
 DMA_PER_TILE = KB // (2 * WAVES)                             # LDS-DMA instructions per wave per tile
 PENDING = (1 << DMA_PER_TILE) - 1                            # VCC mask of a full tile's pending DMA instructions
+HOOK_BEFORE_WAIT = int(os.environ.get("TL_HOOK_BEFORE_WAIT", "0"))  # the list loop's DMA hook ahead of the block's wait (the issue stall overlaps the wait)
 TAIL_HOOKS = int(os.environ.get("TL_TAIL_HOOKS", "0"))      # DMA hooks inside the three-block tails (the rest waits for the list end)
 
 
@@ -154,8 +155,11 @@ def list_loop(lds=True, fma=True, exact=False):
         # more than three blocks left -> block r+1 exists and block r+3 is fetched
         o += ["s_sub_u32 s38, s38, 1", f"s_cbranch_scc1 3{k}f"]
         o += P1(nxt, dn) + P2(cur, dc)
+        if HOOK_BEFORE_WAIT:
+            o += dma_hook()
         o += ["s_waitcnt lgkmcnt(0)", f"s_load_dwordx16 s[{cur}:{cur + 15}], s[36:37], {hex(off)}"]
-        o += dma_hook()
+        if not HOOK_BEFORE_WAIT:
+            o += dma_hook()
     o += ["s_add_u32 s36, s36, 0x180", "s_addc_u32 s37, s37, 0", "s_branch 11b"]
     for k in range(6):   # exactly three blocks left, all in the ring: straight line
         cur, nxt, nx2 = RING[k % 3], RING[(k + 1) % 3], RING[(k + 2) % 3]
