@@ -245,7 +245,7 @@ def phases(lds=True, fma=True, exact=False):
           f"global_load_dword v{TOUCH}, %[toff], s[94:95]"]
     o += ["s_mov_b32 s93, s88",
           "s_waitcnt vmcnt(1)",      # tile t+1 (this wave's share) has landed; the touch may still fly
-          "s_barrier",
+          "s_nop 0" if os.environ.get("TL_NO_BARRIER") else "s_barrier",
           "s_add_u32 s90, s90, 1", "s_cmp_lt_u32 s90, %[te]", "s_cbranch_scc1 1b",
           "s_waitcnt lgkmcnt(0)", "s_branch 29f"]
     o += request_stub(20, 22) + request_stub(21, 23) + ["29:"]
