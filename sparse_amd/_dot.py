@@ -50,7 +50,11 @@ class _DenseIO:
 
 
 def tensordot_plan(a_shape, b_shape, axes=2):
-    """Pure shape logic of tensordot (reference _common.py:133-198; NumPy's own algorithm).
+    """Pure shape logic of tensordot (reference _common.py:133-198).
+
+    The axes normalisation below is NumPy's own `numpy.tensordot` algorithm, as the reference notes at `_common.py:125`
+    (NumPy is BSD-3-Clause, Copyright (c) 2005-2025 NumPy Developers); it is restated here because the shapes, the order
+    of the transposed axes and the `ValueError("shape-mismatch for sum")` must be the same for the product to be a drop-in.
 
     Returns (newaxes_a, newshape_a, newaxes_b, newshape_b, olda, oldb) or raises the same
     ValueErrors as the reference.

@@ -6,7 +6,7 @@ sys.path.insert(0, "/root/repo")
 from bench import make_csr_device
 from sparse_amd import _kernels as K
 N = 128
-for M, Kd, dens in ((500_000, 128, 0.5), (1_000_000, 10_000, 0.01)):
+for M, Kd, dens in ((1_000_000, 10_000, 0.01),):
     data, idx, ptr = make_csr_device(M, Kd, dens, seed=1)
     b = torch.rand((Kd, N), device="cuda")
     layout = K.csr_tiled_layout(data, idx, ptr, M, Kd)
