@@ -186,3 +186,66 @@ def test_spgemm_mostly_heavy_falls_back():
     assert Kn._spgemm_rows(n, n, a.data, a.indices, a.indptr, b.data, b.indices, b.indptr) is None
     c = a @ b
     assert np.allclose(c.todense(), dense_a @ dense_b, rtol=1e-12, atol=1e-14)
+
+
+def _spgemm_both_ways(a, b):
+    import sparse_amd as sp  # noqa: F401
+    from sparse_amd import _kernels as Kn
+
+    old = Kn.SPGEMM_ROW_LOCAL
+    try:
+        Kn.SPGEMM_ROW_LOCAL = True
+        c1 = a @ b
+        stats = dict(Kn.SPGEMM_STATS)
+        Kn.SPGEMM_ROW_LOCAL = False
+        c2 = a @ b
+    finally:
+        Kn.SPGEMM_ROW_LOCAL = old
+    assert torch.equal(c1.indptr.long(), c2.indptr.long()) and torch.equal(c1.indices.long(), c2.indices.long())
+    assert torch.equal(c1.data, c2.data)
+    return c1, stats
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_spgemm_row_kernel_with_64_bit_keys(dtype):
+    """(column, A-element index) does not fit 32 bits when B is very wide: the row kernel's 64-bit key classes (bucket
+    mapping by a 64-bit multiply) must give the same bits as the global form."""
+    import sparse_amd as sp
+
+    rng = np.random.default_rng(8)
+    n, wide = 900, 1 << 27
+    ar = np.repeat(np.arange(n), 70)
+    ac = rng.integers(0, n, size=ar.size)
+    keep = np.unique(ar * n + ac)
+    a = sp.COO(np.stack([keep // n, keep % n]), (rng.random(keep.size) - 0.5).astype(dtype), shape=(n, n)).asformat("gcxs", compressed_axes=(0,))
+    br = np.repeat(np.arange(n), 40)
+    bc = rng.integers(0, wide, size=br.size)
+    bc[::7] = bc[::7] % 1000      # some columns collide across rows: runs of equal columns inside output rows
+    keep = np.unique(br.astype(np.int64) * wide + bc)
+    b = sp.COO(np.stack([keep // wide, keep % wide]), (rng.random(keep.size) - 0.5).astype(dtype), shape=(n, wide)).asformat("gcxs", compressed_axes=(0,))
+    c, stats = _spgemm_both_ways(a, b)
+    assert stats["rows"] == n
+    ref = a.to_scipy_sparse() @ b.to_scipy_sparse()
+    assert c.nnz == ref.nnz
+    cc = c.tocoo()
+    rc = ref.tocoo()
+    order = np.lexsort((rc.col, rc.row))
+    assert np.array_equal(cc.coords[1].cpu().numpy(), rc.col[order]) and np.allclose(cc.data.cpu().numpy(), rc.data[order], rtol=1e-5, atol=1e-6)
+
+
+def test_spgemm_rows_with_a_crowded_column_are_declined_and_merged():
+    """A dense column of B collects one product per A element in EVERY output row: buckets overflow their 16 slots, the row
+    kernel declines those rows (nnz = -1) and the global form supplies them - same bits as the global form throughout."""
+    import sparse_amd as sp
+
+    rng = np.random.default_rng(9)
+    n = 3000
+    da = np.where(rng.random((n, n)) < 0.02, rng.random((n, n)) - 0.5, 0.0)          # ~60 elements per A row
+    db = np.where(rng.random((n, n)) < 0.01, rng.random((n, n)) - 0.5, 0.0)
+    db[:, 17] = rng.random(n) - 0.5                                                  # the crowded column
+    db[: n // 2, 2999] = 0.25                                                        # and one that crowds half the rows' products
+    a = sp.COO.from_numpy(da).asformat("gcxs", compressed_axes=(0,))
+    b = sp.COO.from_numpy(db).asformat("gcxs", compressed_axes=(0,))
+    c, stats = _spgemm_both_ways(a, b)
+    assert stats["heavy_or_declined"] > n // 2, stats       # the row kernel really declined them
+    assert np.allclose(c.todense(), da @ db, rtol=1e-12, atol=1e-14)

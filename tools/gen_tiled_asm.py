@@ -115,11 +115,13 @@ def dma_body():
     rows by a SALU add: the flat form needed a 64-bit VALU add on a per-lane pointer pair and twice the address registers);
     LDS address s89 (advanced by 16 row pairs = 32 KB of the interleaved buffers; the s_add also is the wait state
     M0 needs before an LDS-DMA), and one bit less in the pending mask (VCC)"""
-    return ["s_mov_b32 m0, s89",
+    prio = int(os.environ.get("TL_DMA_PRIO", "0"))
+    return (["s_setprio %d" % prio] if prio else []) + [
+            "s_mov_b32 m0, s89",
             f"s_add_u32 s89, s89, {hex(WAVES * 2048)}",
             "buffer_load_dwordx4 %[voff], %[srd], %[soff] offen lds",
             "s_add_u32 %[soff], %[soff], %[step]",
-            "s_lshr_b64 vcc, vcc, 1"]
+            "s_lshr_b64 vcc, vcc, 1"] + (["s_setprio 0"] if prio else [])
 
 
 def dma_hook():
