@@ -301,7 +301,7 @@ def _tiled_eligible(data, bt, out_shape, Kd):
     return M >= 65536 and (per_list >= 12 or (per_list >= 6 and Kd * N * bt.element_size() >= (16 << 20)))
 
 
-DERIVED_CACHES = ("_csr_view", "_csr_twin", "_tiled_layouts", "_spmm_uses", "_nan_memo", "_derived_stamp", "_sddmm_plan")
+DERIVED_CACHES = ("_csr_view", "_csr_twin", "_tiled_layouts", "_spmm_uses", "_nan_memo", "_derived_stamp", "_sddmm_plan", "_t_view")
 
 
 def drop_derived(a):
@@ -459,14 +459,15 @@ def _dot(a, b, return_type=None):
     if _is_dense(a) and isinstance(b, GCXS):
         # dense @ sparse == (sparse.T @ dense.T).T ; sparse.T is free for 2-D GCXS
         at = dev.to_device(a, b.device).t()
-        bt = b.T
+        # the transposed view shares b's buffers; it is kept on b (and dropped with b's other derived layouts) so that
+        # what it caches - the CSR twin of a csc operand, the K-tiled block streams of the executor - survives the call
+        bt = b.__dict__.get("_t_view")
+        if bt is None or bt.data is not b.data or bt.indices is not b.indices:
+            bt = b.T
+            b.__dict__["_t_view"] = bt
         if rk in (None, "ndarray"):
-            if bt.compressed_axes == (0,):
-                res = K.dot_csr_ndarray(out_shape[::-1], bt.data, bt.indices, bt.indptr, at,
-                                        exact=_settings.EXACT_MULADD)
-            else:
-                res = K.dot_csc_ndarray(bt.shape, tuple(at.shape), bt.data, bt.indices, bt.indptr, at,
-                                        exact=_settings.EXACT_MULADD)
+            # same kernels and the same inspector/executor policy as sparse @ dense (A1): (b^T a^T)^T
+            res = _gcxs_times_dense(bt, at.contiguous(), out_shape[::-1])
             return io.out(res.t())
         if bt.compressed_axes == (0,):
             data, indices, indptr = K.dot_csr_ndarray_sparse(out_shape[::-1], bt.data, bt.indices,

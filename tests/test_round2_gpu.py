@@ -269,3 +269,23 @@ def test_sharded_spmm_and_sddmm_on_rccl_world_size_1(orc, sp, rccl_group):
     c = _dist.sharded_spgemm(g, g)
     ref = g @ g
     assert torch.equal(c.indptr.long(), ref.indptr.long()) and torch.equal(c.indices.long(), ref.indices.long()) and torch.equal(c.data, ref.data)
+
+
+# ---- dense @ GCXS takes the same inspector/executor path as GCXS @ dense -----------------------
+def test_dense_times_gcxs_uses_the_cached_executor(sp):
+    from sparse_amd import _kernels as K
+
+    rng = np.random.default_rng(31)
+    Kd, N, M = 3000, 70_000, 128
+    b = sp.random((Kd, N), density=0.01, random_state=5, dtype=np.float32, idx_dtype=np.int32, format="gcxs", compressed_axes=(1,))
+    a = torch.from_numpy(rng.random((M, Kd), dtype=np.float32)).cuda()
+    r1 = a @ b if False else sp.matmul(a, b)
+    view = b.__dict__.get("_t_view")
+    assert view is not None and getattr(view, "_tiled_layouts", None), "dense @ GCXS did not build the block stream"
+    r2 = sp.matmul(a, b)                      # second product: cached layouts, same bits
+    assert torch.equal(r1, r2) and tuple(r1.shape) == (M, N)
+    bt = b.T                                   # (N, Kd) compressed by rows
+    ref = K.dot_csr_ndarray((N, M), bt.data, bt.indices, bt.indptr, a.t().contiguous()).t()
+    assert torch.equal(r1, ref), "executor and row-group kernel differ"
+    b.data.mul_(2)                             # in-place edit of b: the view's cached stream must not survive it
+    assert torch.equal(sp.matmul(a, b), ref * 2)
