@@ -142,8 +142,6 @@ __global__ void __launch_bounds__(256) tl_pack_kernel(const int64_t* __restrict_
 // so no sort is needed: one workgroup per group counts (row, tile) runs in LDS, and an element's slot is
 //   8 * blk_off[g, t] + (elements of tile t in earlier rows of the group) + (position inside its row's run).
 // Two passes over A (count, fill) = ~2 GB of traffic at config 2 instead of a 64-bit radix sort of 10^8 pairs.
-constexpr int TL_INFO = 8192;             // elements of a row group whose (row, tile) the one-pass inspector keeps in LDS (16 KB)
-static_assert(TL_RG <= 256, "row in group packed into 8 bits next to the tile");
 constexpr int TL_DIRECT_MAX_TILES = 256;  // LDS: 2 * TL_RG * tiles * 4 B (+ tiles * 4) <= 73 KB (35-row groups)
 
 template <typename I>
@@ -242,7 +240,7 @@ __global__ void __launch_bounds__(256) tl_inspect_kernel(int64_t M, int ntiles, 
                                                          const I* __restrict__ indices, const I* __restrict__ indptr,
                                                          unsigned long long* __restrict__ state, int* __restrict__ blk_off,
                                                          int* __restrict__ stream) {
-  extern __shared__ int tl_fill_lds[];  // before[RG][ntiles], runstart[RG][ntiles] (relative to e0), loff[ntiles + 1], info[]
+  extern __shared__ int tl_fill_lds[];  // before[RG][ntiles], runstart[RG][ntiles] (relative to e0), loff[ntiles + 1]
   __shared__ int64_t rs[TL_RG + 1];
   __shared__ int64_t ticket_s, goff_s;
   __shared__ int wtot[5];
@@ -250,9 +248,6 @@ __global__ void __launch_bounds__(256) tl_inspect_kernel(int64_t M, int ntiles, 
   int* const before = tl_fill_lds;
   int* const runstart = before + TL_RG * ntiles;
   int* const loff = runstart + TL_RG * ntiles;
-  // (row in group, tile) of the group's first TL_INFO elements, kept from the counting pass for the fill pass: the
-  // bisection over the row starts and the division by the tile height are then done once per element
-  unsigned short* const info = reinterpret_cast<unsigned short*>(loff + ntiles + 1);
   const int tid = threadIdx.x;
   if (tid == 0) ticket_s = (int64_t)atomicAdd(&state[groups], 1ull);
   __syncthreads();
@@ -266,27 +261,32 @@ __global__ void __launch_bounds__(256) tl_inspect_kernel(int64_t M, int ntiles, 
   __syncthreads();
   const int64_t e0 = rs[0], e1 = rs[TL_RG];
   bool bad = false;
-  for (int64_t e = e0 + tid; e < e1; e += 256) {
-    const unsigned c = (unsigned)indices[e];          // (K <= 256 tiles x 160 columns: 32-bit arithmetic)
-    const int t = (int)(c / (unsigned)TL_KB);
-    const int lr = tl_row_of<I>(rs, e);
-    atomicAdd(&before[lr * ntiles + t], 1);
-    const bool row_start = e == rs[lr];
-    const unsigned cp = row_start ? 0u : (unsigned)indices[e - 1];
-    if (!row_start && cp > c) bad = true;
-    if (row_start || (int)(cp / (unsigned)TL_KB) != t) runstart[lr * ntiles + t] = (int)(e - e0);
-    if (e - e0 < TL_INFO) info[e - e0] = (unsigned short)((lr << 8) | t);
+  // a wave per row (rows lane-strided): the row in the group is known without a bisection over the row starts
+  for (int lr = tid >> 6; lr < TL_RG; lr += 4) {
+    const int64_t ra = rs[lr], rb = rs[lr + 1];
+    for (int64_t e = ra + (tid & 63); e < rb; e += 64) {
+      const unsigned c = (unsigned)indices[e];          // (K <= 256 tiles x 160 columns: 32-bit arithmetic)
+      const int t = (int)(c / (unsigned)TL_KB);
+      atomicAdd(&before[lr * ntiles + t], 1);
+      const bool row_start = e == ra;
+      const unsigned cp = row_start ? 0u : (unsigned)indices[e - 1];
+      if (!row_start && cp > c) bad = true;
+      if (row_start || (int)(cp / (unsigned)TL_KB) != t) runstart[lr * ntiles + t] = (int)(e - e0);
+    }
   }
   if (bad) atomicOr(&state[groups + 1], 1ull);
   __syncthreads();
   // per tile: elements of the tile in earlier rows of the group; blocks of the list
   int nb = 0, cnt_t = 0;
   for (int t = tid; t < ntiles; t += 256) {   // (ntiles <= 256: one tile per thread)
+    int c[TL_RG];   // all reads first: one LDS latency instead of one per row
+#pragma unroll
+    for (int lr = 0; lr < TL_RG; ++lr) c[lr] = before[lr * ntiles + t];
     int run = 0;
+#pragma unroll
     for (int lr = 0; lr < TL_RG; ++lr) {
-      const int c = before[lr * ntiles + t];
       before[lr * ntiles + t] = run;
-      run += c;
+      run += c[lr];
     }
     cnt_t = run;
     nb = (run + EPB - 1) / EPB;
@@ -314,21 +314,16 @@ __global__ void __launch_bounds__(256) tl_inspect_kernel(int64_t M, int ntiles, 
   const int64_t goff = goff_s;
   if (tid < ntiles) blk_off[g * ntiles + tid] = (int)(goff + my_off);
   if (g == groups - 1 && tid == 0) blk_off[groups * ntiles] = (int)(goff + gtotal);
-  // fill
-  for (int64_t e = e0 + tid; e < e1; e += 256) {
-    const unsigned c = (unsigned)indices[e];
-    int t, lr;
-    if (e - e0 < TL_INFO) {
-      const unsigned pk = info[e - e0];
-      t = (int)(pk & 255u);
-      lr = (int)(pk >> 8);
-    } else {
-      t = (int)(c / (unsigned)TL_KB);
-      lr = tl_row_of<I>(rs, e);
+  // fill (a wave per row again)
+  for (int lr = tid >> 6; lr < TL_RG; lr += 4) {
+    const int64_t ra = rs[lr], rb = rs[lr + 1];
+    for (int64_t e = ra + (tid & 63); e < rb; e += 64) {
+      const unsigned c = (unsigned)indices[e];
+      const int t = (int)(c / (unsigned)TL_KB);
+      const int lc = (int)(c - (unsigned)t * (unsigned)TL_KB);
+      const int64_t dst = (goff + loff[t]) * EPB + before[lr * ntiles + t] + ((int)(e - e0) - runstart[lr * ntiles + t]);
+      TlFmt<T>::put(stream, dst, tl_d0(lc, lr), vals[e]);
     }
-    const int lc = (int)(c - (unsigned)t * (unsigned)TL_KB);
-    const int64_t dst = (goff + loff[t]) * EPB + before[lr * ntiles + t] + ((int)(e - e0) - runstart[lr * ntiles + t]);
-    TlFmt<T>::put(stream, dst, tl_d0(lc, lr), vals[e]);
   }
   // padding entries of my list (zero d0 and value: they accumulate into the junk register pair)
   if (tid < ntiles) {
@@ -610,7 +605,7 @@ template <typename I, typename T>
 static int tl_launch_inspect(int64_t M, int64_t ntiles, const T* a_data, const I* a_indices, const I* a_indptr,
                              unsigned long long* state, int* blk_off, int* blocks, hipStream_t s) {
   const int64_t groups = tl_grid_groups(M);
-  const int lds = (int)((2 * TL_RG * ntiles + ntiles + 1) * sizeof(int)) + TL_INFO * (int)sizeof(unsigned short);
+  const int lds = (int)((2 * TL_RG * ntiles + ntiles + 1) * sizeof(int));
   auto kern = &tl_inspect_kernel<I, T>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
