@@ -143,7 +143,9 @@ struct RowRankLayout {
   // (uniform columns: +- sqrt(N) / 2), so it has room for 9/8 of its share before the row is declined
   static constexpr int CAPP = PASSES == 1 ? N : (N / PASSES) * 9 / 8;
   static constexpr int pow2_at_least(int x) { int p = 1; while (p < x) p <<= 1; return p; }
-  static constexpr int NBP = pow2_at_least(CAPP / 2 > BLOCK ? CAPP / 2 : BLOCK);   // buckets per pass: a power of two, a multiple of BLOCK
+  // buckets per pass: a power of two, a multiple of BLOCK; with several passes one bucket per product slot (the buckets
+  // then hold ~0.7 products: the 5-exchange network instead of the 19-exchange one nearly always)
+  static constexpr int NBP = pow2_at_least(PASSES > 2 ? (CAPP > BLOCK ? CAPP : BLOCK) : (CAPP / 2 > BLOCK ? CAPP / 2 : BLOCK));
   static constexpr int STAGE = CAPP < 2048 ? CAPP : 2048;    // A elements staged per chunk
   static constexpr size_t prefix_bytes = ((size_t)STAGE + 2) * sizeof(int) + (size_t)STAGE * (sizeof(int64_t) + sizeof(V)) + 16;
   static constexpr size_t items_bytes = (size_t)CAPP * (sizeof(KEY) + sizeof(V));
@@ -343,7 +345,7 @@ spgemm_rowrank_kernel(int64_t n_col, int col_bits, int ebits, const I* __restric
       V v[SPG_BUCKET_MAX];
 #pragma unroll
       for (int i = 0; i < SPG_BUCKET_MAX; ++i) {
-        const bool on = i < c && (i < 8 || c > 8);
+        const bool on = i < c && (i < 4 || c > 4) && (i < 8 || c > 8);
         k[i] = on ? lkey[s0 + i] : kmax;
         v[i] = on ? lval[s0 + i] : V(0);
       }
@@ -372,7 +374,7 @@ spgemm_rowrank_kernel(int64_t n_col, int col_bits, int ebits, const I* __restric
             }
           }
         }
-      } else if (c > 1) {
+      } else if (c > 4) {
         // 8 keys: the 19-exchange network
         SPG_CE(0, 1) SPG_CE(2, 3) SPG_CE(4, 5) SPG_CE(6, 7)
         SPG_CE(0, 2) SPG_CE(1, 3) SPG_CE(4, 6) SPG_CE(5, 7)
@@ -381,25 +383,34 @@ spgemm_rowrank_kernel(int64_t n_col, int col_bits, int ebits, const I* __restric
         SPG_CE(1, 4) SPG_CE(3, 6)
         SPG_CE(2, 4) SPG_CE(3, 5)
         SPG_CE(3, 4)
+      } else if (c > 1) {
+        // 4 keys: five exchanges (the common case: buckets hold less than one product on average)
+        SPG_CE(0, 1) SPG_CE(2, 3) SPG_CE(0, 2) SPG_CE(1, 3) SPG_CE(1, 2)
       }
 #undef SPG_CE
       // runs of equal columns, summed in increasing A-element order; a run ends where the next column differs
       int h = 0;
       V acc = V(0);
-#pragma unroll
-      for (int i = 0; i < SPG_BUCKET_MAX; ++i) {
-        if (i < c) {
-          const KEY col = k[i] >> ebits;
-          const bool first = i == 0 || (k[i ? i - 1 : 0] >> ebits) != col;
-          acc = first ? v[i] : acc + v[i];
-          const bool last = i + 1 == c || (k[i + 1 < SPG_BUCKET_MAX ? i + 1 : i] >> ebits) != col;
-          if (last) {
-            lkey[s0 + h] = col;
-            lval[s0 + h] = acc;
-            ++h;
-          }
+#define SPG_RUN(i)                                                                                         \
+  if ((i) < c) {                                                                                           \
+    const KEY col = k[(i)] >> ebits;                                                                       \
+    const bool first = (i) == 0 || (k[(i) ? (i)-1 : 0] >> ebits) != col;                                   \
+    acc = first ? v[(i)] : acc + v[(i)];                                                                   \
+    const bool last = (i) + 1 == c || (k[(i) + 1 < SPG_BUCKET_MAX ? (i) + 1 : (i)] >> ebits) != col;       \
+    if (last) {                                                                                            \
+      lkey[s0 + h] = col;                                                                                  \
+      lval[s0 + h] = acc;                                                                                  \
+      ++h;                                                                                                 \
+    }                                                                                                      \
+  }
+      SPG_RUN(0) SPG_RUN(1) SPG_RUN(2) SPG_RUN(3)
+      if (c > 4) {
+        SPG_RUN(4) SPG_RUN(5) SPG_RUN(6) SPG_RUN(7)
+        if (c > 8) {
+          SPG_RUN(8) SPG_RUN(9) SPG_RUN(10) SPG_RUN(11) SPG_RUN(12) SPG_RUN(13) SPG_RUN(14) SPG_RUN(15)
         }
       }
+#undef SPG_RUN
       hc[bb] = h;
       mine += h;
     }
@@ -491,7 +502,7 @@ struct RowClasses {
   static constexpr int64_t c0 = 256 * 4, c1 = 512 * 8, c2 = 512 * MID;
   static constexpr int TOP = sizeof(KEY) + sizeof(V) <= 8 ? 24 : MID;  // (more products per thread spill: 512 x 30 -> 182 registers)
   static constexpr int64_t c3 = 512 * TOP;
-  static constexpr int64_t c4 = 1024 * TOP;   // 1024 threads, four passes: the same LDS per pass, one workgroup per CU (rare rows)
+  static constexpr int64_t c4 = 1024 * TOP;   // 1024 threads, eight passes: the same LDS per pass, one workgroup per CU (rare rows)
 };
 
 static int spg_bits(int64_t n) {   // smallest b with 2^b > n
@@ -515,7 +526,7 @@ static int rowrank_all(int64_t n_row, int64_t n_col, int col_bits, int ebits, co
   if (max_prod > C::c0) SPG_CLASS(512, 8, 1, C::c0, C::c1)
   if (max_prod > C::c1) SPG_CLASS(512, C::MID, 2, C::c1, C::c2)
   if (max_prod > C::c2 && C::c3 > C::c2) SPG_CLASS(512, C::TOP, 2, C::c2, C::c3)
-  if (max_prod > C::c3) SPG_CLASS(1024, C::TOP, 4, C::c3, C::c4)
+  if (max_prod > C::c3) SPG_CLASS(1024, C::TOP, 8, C::c3, C::c4)
 #undef SPG_CLASS
   return 0;
 }
