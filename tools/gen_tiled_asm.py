@@ -51,6 +51,9 @@ DMA_AT_START = int(os.environ.get("TL_DMA_AT_START", "2"))  # tile-DMA instructi
 KB = int(os.environ.get("TL_KB", "160"))                    # B rows per LDS tile (multiple of 32; 2 x KB x 512 B <= 160 KB)
 DMA_PER_TILE = KB // (2 * WAVES)                             # LDS-DMA instructions per wave per tile
 PENDING = (1 << DMA_PER_TILE) - 1                            # VCC mask of a full tile's pending DMA instructions
+STAGE = int(os.environ.get("TL_STAGE", "0"))   # 1: B tiles by global loads into four staging registers + ds_write_b128 instead of LDS-DMA
+STG = 18                                        # v18..v21 staging (an even-aligned tuple), v17 LDS write address (clobbers: the compiler keeps nothing there across the asm)
+WADDR = 17
 HOOK_BEFORE_WAIT = int(os.environ.get("TL_HOOK_BEFORE_WAIT", "0"))  # the list loop's DMA hook ahead of the block's wait (the issue stall overlaps the wait)
 TAIL_HOOKS = int(os.environ.get("TL_TAIL_HOOKS", "0"))      # DMA hooks inside the three-block tails (the rest waits for the list end)
 
@@ -124,10 +127,48 @@ def dma_body():
             "s_lshr_b64 vcc, vcc, 1"] + (["s_setprio 0"] if prio else [])
 
 
+def stage_flush():
+    """the staged 1 KB piece (v17..v20, loaded by an earlier hook) goes to LDS at s89 + 16 * lane"""
+    return ["s_waitcnt vmcnt(0)",
+            f"v_lshl_add_u32 v{WADDR}, %[lane8], 1, s89",
+            f"ds_write_b128 v{WADDR}, v[{STG}:{STG + 3}]",
+            f"s_add_u32 s89, s89, {hex(WAVES * 2048)}",
+            "s_mov_b32 s39, 0"]
+
+
+def stage_issue(q=STG):
+    return [f"buffer_load_dwordx4 v[{q}:{q + 3}], %[voff], %[srd], %[soff] offen",
+            "s_add_u32 %[soff], %[soff], %[step]"]
+
+
 def dma_hook():
     """Issue one more tile-DMA instruction if any are left.  The pending count lives in VCC as a mask of ones so
-    that the test is a single s_cbranch_vccz (SCC is clobbered when an instruction is issued)."""
-    return ["s_cbranch_vccz 6f"] + dma_body() + ["6:"]
+    that the test is a single s_cbranch_vccz (SCC is clobbered when an instruction is issued).
+    Staged form: the piece loaded by the PREVIOUS hook (a block ago: an L2 round trip has passed) is written to LDS,
+    then the next piece is requested; s39 = a piece is staged."""
+    if not STAGE:
+        return ["s_cbranch_vccz 6f"] + dma_body() + ["6:"]
+    return (["s_cmp_eq_u32 s39, 0", "s_cbranch_scc1 5f"] + stage_flush() + ["5:", "s_cbranch_vccz 6f"] + stage_issue() +
+            ["s_lshr_b64 vcc, vcc, 1", "s_mov_b32 s39, 1", "6:"])
+
+
+def dma_rest():
+    """what is left of the wave's share at the end of its list.  Staged form: the staged piece is flushed, then ALL
+    remaining pieces are requested into the (now idle) data-set registers, waited for once and written."""
+    if not STAGE:
+        return ["13:", "s_cbranch_vccz 14f"] + dma_body() + ["s_branch 13b", "14:"]
+    o = ["s_cmp_eq_u32 s39, 0", "s_cbranch_scc1 5f"] + stage_flush() + ["5:", "s_cbranch_vccz 14f", "s_bcnt1_i32_b64 s38, vcc"]
+    n = KB // (2 * WAVES)
+    for i in range(n):
+        o += [f"s_cmp_le_u32 s38, {i}", "s_cbranch_scc1 13f"] + stage_issue(DATASET[1] + 4 * i)
+    o += ["13:", "s_waitcnt vmcnt(0)"]
+    for i in range(n):
+        q = DATASET[1] + 4 * i
+        o += [f"s_cmp_le_u32 s38, {i}", "s_cbranch_scc1 14f",
+              f"v_lshl_add_u32 v{WADDR}, %[lane8], 1, s89", f"ds_write_b128 v{WADDR}, v[{q}:{q + 3}]",
+              f"s_add_u32 s89, s89, {hex(WAVES * 2048)}"]
+    o += ["14:", "s_mov_b64 vcc, 0"]
+    return o
 
 
 def list_loop(lds=True, fma=True, exact=False):
@@ -142,7 +183,7 @@ def list_loop(lds=True, fma=True, exact=False):
     P1 = p1 if lds else (lambda buf, dset: [])
     P2 = (p2_exact if exact else p2) if fma else (lambda buf, dset: [])
     o = []
-    for _ in range(DMA_AT_START):
+    for _ in range(1 if STAGE else DMA_AT_START):
         o += dma_hook()
     o += ["s_waitcnt lgkmcnt(0)"]
     o += P1(RING[0], 0)
@@ -220,7 +261,8 @@ def phases(lds=True, fma=True, exact=False):
     ~1000 cycles).  s90 = t, s91/s92/s93 = first block of lists t, t+1, t+2; s[36:37] = pointer of list t on
     entry to a phase (left there by the request of its first blocks).  v22 (LDS base of the tile being read)
     and s89 (LDS destination of the tile being loaded) toggle between the two buffers once per phase."""
-    o = ["s_mov_b32 s90, %[t0]", "s_mov_b32 s91, %[o0]", "s_mov_b32 s92, %[o1]", "s_mov_b32 s93, %[o2]",
+    o = ["s_mov_b32 s39, 0",   # (staged form: no piece is staged)
+         "s_mov_b32 s90, %[t0]", "s_mov_b32 s91, %[o0]", "s_mov_b32 s92, %[o1]", "s_mov_b32 s93, %[o2]",
          "s_add_u32 s88, s90, 1", "s_and_b32 s88, s88, 1", "s_lshl_b32 s88, s88, 10", "s_add_u32 s89, s88, %[m0wave]",
          "s_and_b32 s88, s90, 1", "s_lshl_b32 s88, s88, 10", f"v_or_b32 v{BASE}, s88, %[lane8]"]
     o += request_first_blocks(91, 92, 20, 22)
@@ -230,7 +272,9 @@ def phases(lds=True, fma=True, exact=False):
           "s_cmp_lt_u32 s88, %[nfull]", f"s_cselect_b64 vcc, {PENDING}, 0",
           "s_cmp_eq_u32 s38, 0", "s_cbranch_scc1 12f"]
     o += list_loop(lds, fma, exact)
-    o += ["12:", "13:", "s_cbranch_vccz 14f"] + dma_body() + ["s_branch 13b", "14:"]   # the rest of the DMA share
+    o += ["12:"] + dma_rest()   # the rest of the DMA share
+    if STAGE:
+        o += ["s_waitcnt lgkmcnt(0)"]   # the tile's pieces are in LDS before the wave arrives at the barrier
     # first blocks of the next list (not at the end of the chunk: the ring must be idle when the asm ends)
     o += ["s_add_u32 s88, s90, 1", "s_cmp_lt_u32 s88, %[te]", "s_cbranch_scc0 21f"]
     o += request_first_blocks(92, 93, 21, 23)
@@ -245,8 +289,8 @@ def phases(lds=True, fma=True, exact=False):
           # touch the first lines of list t+2 (lane i -> line min(i, L-1), L chosen by the launcher from the mean
           # list length): always ONE instruction; lists are consecutive, so lines past a short list are the next one's
           f"global_load_dword v{TOUCH}, %[toff], s[94:95]"]
-    o += ["s_mov_b32 s93, s88",
-          "s_waitcnt vmcnt(1)",      # tile t+1 (this wave's share) has landed; the touch may still fly
+    o += ["s_mov_b32 s93, s88"] + ([] if STAGE else [
+          "s_waitcnt vmcnt(1)"]) + [  # tile t+1 (this wave's share) has landed; the touch may still fly
           "s_nop 0" if os.environ.get("TL_NO_BARRIER") else "s_barrier",
           "s_add_u32 s90, s90, 1", "s_cmp_lt_u32 s90, %[te]", "s_cbranch_scc1 1b",
           "s_waitcnt lgkmcnt(0)", "s_branch 29f"]
@@ -305,7 +349,7 @@ def main():
            lit("TL_ASM_STORE", store()),
            lit("TL_ASM_ZERO", zero()),
            f"#define TL_CLOB_SGPR {clob('s', 36, 95)}\n",
-           f"#define TL_CLOB_TMP {clob('v', BASE, JUNK - 1)}\n",
+           f"#define TL_CLOB_TMP {clob('v', WADDR if STAGE else BASE, JUNK - 1)}\n",
            f"#define TL_CLOB_ACC {clob('v', JUNK, ACC0 + 2 * ROWS - 1)}\n"]
     p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "sparse_amd", "csrc", "spmm_tiled_asm.inc")
     with open(p, "w") as f:
