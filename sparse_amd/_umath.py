@@ -337,6 +337,61 @@ def _elemwise_general(func, proc, kwargs, dtype_kw, finish):
     return finish(keys, torch.from_numpy(res).to(devi), full_shape, np.asarray(fill)[()], devi)
 
 
+def _broadcast_matched(name, func, a, b, shape, out_np, comp_np, finish):
+    """`func(a, b)` where ONE operand (call it x) already has the broadcast `shape` and the other one (y) broadcasts into
+    it, without materialising y's replicas: valid when the positions where x stores nothing can only produce the result's
+    fill value, i.e. func(fill_x, v) is bit-equal to the result fill for EVERY stored v of y and for fill_y (multiply with
+    zero-fill operands is the common case; checked on the device in one pass over y's nnz values).  Then the stored
+    positions of the result are a subset of x's: every stored element of x looks up y at its coordinates PROJECTED onto
+    y's axes (binary search in y's sorted keys; y's fill value where y stores nothing), func is applied and the result
+    pruned - the reference's reduced-coordinate matching (`_get_matching_coords`, _umath.py:310-341) as a gather.
+    Returns None when the condition does not hold (the caller then broadcasts by materialisation)."""
+    x_is_a = tuple(a.shape) == tuple(shape)
+    x, y = (a, b) if x_is_a else (b, a)
+    devi = x.device
+    comp_t = torch_dtype(comp_np)
+    if comp_np not in (np.dtype("f4"), np.dtype("f8"), np.dtype("i4"), np.dtype("i8")) or np.dtype(out_np) != np.dtype(comp_np):
+        return None
+    fx, fy = np.asarray(x.fill_value).astype(comp_np), np.asarray(y.fill_value).astype(comp_np)
+    fill = np.asarray(_np_result(func, *((fx, fy) if x_is_a else (fy, fx)))).astype(out_np)[()]
+
+    def scalar_t(v):
+        return torch.tensor([v.item() if hasattr(v, "item") else v], dtype=comp_t, device=devi)
+
+    yd = K.convert(y.data, comp_t)
+    if y.nnz:
+        # func(fill_x, every stored y) must be the fill value, bit for bit
+        probe = binary_arrays(name, scalar_t(fx), yd, a_scalar=True) if x_is_a else binary_arrays(name, yd, scalar_t(fx), b_scalar=True)
+        if K.count_eq_bits(probe, fill) != y.nnz:
+            return None
+    if x.nnz == 0:
+        return finish(x.linear_loc(), K.convert(x.data, comp_t), shape, fill, devi)
+    # project x's coordinates onto y's axes (y's shape left-padded with ones; broadcast axes drop out)
+    ys = (1,) * (len(shape) - y.ndim) + tuple(y.shape)
+    keep = [d for d in range(len(shape)) if ys[d] != 1]
+    if keep:
+        ykeys = K.linearize(x.coords[keep].contiguous(), tuple(ys[d] for d in keep))
+    else:
+        ykeys = torch.zeros(x.nnz, dtype=torch.int64, device=devi)
+    yk = y.linear_loc()      # y's own C-order keys: its size-1 axes contribute nothing, so they equal the reduced keys
+    n = int(ykeys.numel())
+    pos = torch.empty(n, dtype=torch.int64, device=devi)
+    match = torch.empty(n + 1, dtype=torch.int64, device=devi)
+    _ffi.call("spamd_lower_bound_match", n, ptr(ykeys), int(yk.numel()), ptr(yk), ptr(pos), ptr(match), stream_ptr(devi))
+    yvals = _full(n, fy, comp_t, devi)
+    if y.nnz:
+        offs = K.exclusive_scan(match)
+        cnt = int(offs[-1])
+        if cnt:
+            iota = torch.empty(n, dtype=torch.int64, device=devi)
+            _ffi.call("spamd_iota", n, ptr(iota), stream_ptr(devi))
+            hit = K.compact(iota, match, offs, cnt)                 # positions of x's elements that found a stored y
+            K.scatter_into(_as_u8(yvals), hit, _as_u8(K.gather(yd, K.gather(pos, hit))))
+    xd = K.convert(x.data, comp_t)
+    res = binary_arrays(name, xd, yvals) if x_is_a else binary_arrays(name, yvals, xd)
+    return finish(x.linear_loc(), res, shape, fill, devi)
+
+
 def _func_name(func):
     if func is np.ndarray.astype:
         return "astype"
@@ -540,8 +595,15 @@ def elemwise(func, *args, **kwargs):
 
     # ---- sparse (x) sparse, same shape: one sorted-key union -------------------------------------
     if a.shape != b.shape:
-        from ._broadcast import broadcast_pair
+        from ._broadcast import broadcast_pair, broadcast_shapes
 
+        full = broadcast_shapes(a.shape, b.shape)
+        if code not in _TO_BOOL_BIN and dtype_kw is None and (tuple(a.shape) == tuple(full)) != (tuple(b.shape) == tuple(full)):
+            # one operand has the broadcast shape already, the other one broadcasts into it: reduced-coordinate matching
+            # (reference `_get_matching_coords`, _umath.py:310) instead of materialising its replicas
+            res = _broadcast_matched(name, func, a, b, full, out_np, comp_np, finish)
+            if res is not None:
+                return res
         a, b = broadcast_pair(a, b)
         shape = a.shape
     fill = np.asarray(_np_result(func, np.asarray(a.fill_value), np.asarray(b.fill_value))).astype(out_np)[()]
