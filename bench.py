@@ -210,6 +210,10 @@ def main():
     from sparse_amd import _dist, _dot, _kernels, _settings
 
     _settings.NAN_CHECK = not args.no_nan_check  # package default: on (the reference's `matmul` scans both operands)
+    # the scans run in every product of the timed region; their verdicts are polled without blocking the host and drained
+    # before the closing synchronize (package default "sync" makes the host wait for the scan kernels of every product,
+    # which bounds the launch rate once a product takes 0.1 ms: a rank's share at 8 GPUs)
+    _settings.NAN_WARNING = "deferred"
     _settings.EXACT_MULADD = bool(args.exact)
     if args.no_tiled:
         _settings.TILED_SPMM = "never"
@@ -272,6 +276,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    sparse_amd.flush_warnings()      # every NaN verdict of the timed products is read inside the timed region
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -332,6 +337,7 @@ def main():
                 "parallelism": f"row-block x{world}" + (" + RCCL all-gather(B) per step" if sharded_b else ""),
                 "mul_add": "separate (bit-exact)" if args.exact else "fma",
                 "nan_check_in_timed_region": bool(_settings.NAN_CHECK), "nan_check_ms_per_product": nan_check_ms,
+                "nan_warning": _settings.NAN_WARNING,
                 "kernel": "spmm_tiled (cached block stream)" if tiled else "spmm_csr_rowgroup",
                 "first_call_ms": first_call_ms, "first_call_cold_ms": first_call_cold_ms,
                 "first_call_gflops": flops_local / (first_call_ms * 1e-3) / 1e9 if first_call_ms else None,

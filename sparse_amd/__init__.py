@@ -15,7 +15,7 @@ from numpy import (  # noqa: F401  (the reference re-exports NumPy's ufuncs, __i
 from ._sparse_array import SparseArray
 from ._coo import COO, as_coo
 from ._gcxs import GCXS
-from ._dot import dot, matmul, tensordot
+from ._dot import dot, flush_warnings, matmul, tensordot
 from ._umath import elemwise
 from ._einsum import einsum
 from ._batched import concatenate, stack

@@ -180,12 +180,26 @@ def check_class_nan(x, deferred=False):
 
         if deferred:
             probe = K.has_nan_async(data)
-            return probe if isinstance(probe, bool) else (lambda: remember(probe.result()))
+            return probe if isinstance(probe, bool) else _Verdict(probe, remember)
         return remember(K.has_nan(data))
     if deferred:
         probe = K.has_nan_async(data)
-        return probe if isinstance(probe, bool) else probe.result
+        return probe if isinstance(probe, bool) else _Verdict(probe, None)
     return K.has_nan(data)
+
+
+class _Verdict:
+    """zero-argument callable yielding the verdict of a NaN scan in flight; `ready()` tells whether it would block"""
+
+    def __init__(self, probe, remember):
+        self.probe, self.remember = probe, remember
+
+    def ready(self):
+        return self.probe.ready()
+
+    def __call__(self):
+        res = self.probe.result()
+        return self.remember(res) if self.remember is not None else res
 
 
 def matmul(a, b):
@@ -200,9 +214,31 @@ def matmul(a, b):
     # host waits for the scan kernels only, never for the product)
     probes = [check_class_nan(a, deferred=True), check_class_nan(b, deferred=True)]
     res = _matmul(a, b)
+    if _settings.NAN_WARNING == "deferred":
+        _PENDING_NAN.extend(p for p in probes if p is not False)
+        flush_warnings(block=False)
+        return res
     if builtins.any(p if isinstance(p, bool) else p() for p in probes):
         warnings.warn("Nan will not be propagated in matrix multiplication", RuntimeWarning, stacklevel=1)
     return res
+
+
+_PENDING_NAN = []   # verdicts not read yet (`_settings.NAN_WARNING == "deferred"`): True, or a callable of a scan in flight
+
+
+def flush_warnings(block=True):
+    """Raise the NaN warnings of products whose scans have finished (`block=True`: wait for all of them)."""
+    found, keep = False, []
+    for p in _PENDING_NAN:
+        if isinstance(p, bool):
+            found = found or p
+        elif block or getattr(p, "ready", lambda: True)():
+            found = bool(p()) or found
+        else:
+            keep.append(p)
+    _PENDING_NAN[:] = keep
+    if found:
+        warnings.warn("Nan will not be propagated in matrix multiplication", RuntimeWarning, stacklevel=2)
 
 
 def _matmul(a, b):

@@ -84,6 +84,10 @@ class NanProbe:
         self.event.record(torch.cuda.current_stream(dev))
         self._keep = data  # the scanned buffer must outlive the kernel
 
+    def ready(self):
+        """True once the scan has finished (never blocks)"""
+        return self.flag is None or self.event.query()
+
     def result(self):
         self.event.synchronize()
         res = bool(int(self.flag[0]))

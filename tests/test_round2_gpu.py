@@ -289,3 +289,36 @@ def test_dense_times_gcxs_uses_the_cached_executor(sp):
     assert torch.equal(r1, ref), "executor and row-group kernel differ"
     b.data.mul_(2)                             # in-place edit of b: the view's cached stream must not survive it
     assert torch.equal(sp.matmul(a, b), ref * 2)
+
+
+def test_deferred_nan_warning_is_raised_later_not_lost(sp):
+    """`_settings.NAN_WARNING = "deferred"`: matmul does not wait for its NaN scans; the warning comes from a later call or
+    from flush_warnings() - never silently dropped, never duplicated."""
+    import warnings
+
+    from sparse_amd import _settings
+
+    rng = np.random.default_rng(3)
+    a = sp.random((300, 200), density=0.05, random_state=1, format="gcxs", compressed_axes=(0,))
+    b = torch.from_numpy(rng.random((200, 64))).cuda()
+    bad = b.clone()
+    bad[3, 5] = float("nan")
+    old = _settings.NAN_WARNING
+    try:
+        _settings.NAN_WARNING = "deferred"
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            sp.matmul(a, bad)
+            sp.matmul(a, b)
+            torch.cuda.synchronize()
+            sp.flush_warnings()
+        assert sum("Nan will not be propagated" in str(x.message) for x in w) == 1
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            sp.matmul(a, b)
+            sp.flush_warnings()
+        assert not w
+    finally:
+        _settings.NAN_WARNING = old
+    with pytest.warns(RuntimeWarning, match="Nan will not be propagated"):   # the default: before matmul returns
+        sp.matmul(a, bad)
