@@ -285,6 +285,11 @@ def dot(a, b):
         if isinstance(b, SparseArray):
             b = as_coo(b)
         return (a * b).sum()
+    if a.ndim == 2 and b.ndim == 2 and not _is_scipy_sparse(a) and not _is_scipy_sparse(b) \
+            and a.shape[1] == b.shape[0] and a.shape[0] and a.shape[1] and b.shape[1]:
+        # matrix x matrix: tensordot's axis normalisation, transposes and reshapes are all the identity here (the common
+        # case, and the one whose host cost bounds loops of short products)
+        return _dot(a, b, None)
     a_axis, b_axis = -1, -2
     if b.ndim == 1:
         b_axis = -1

@@ -73,15 +73,19 @@ class NanProbe:
     """A NaN scan in flight: the kernel writes its verdict into a pinned host int; `result()` waits for the event
     recorded right behind the scan — NOT for whatever was queued after it — and reads the int."""
 
-    _pool = []
+    _pool = []   # (pinned int32[1], its NumPy view, a reusable event)
 
     def __init__(self, data):
         dev = require_hip(data)
-        self.flag = NanProbe._pool.pop() if NanProbe._pool else torch.zeros(1, dtype=torch.int32).pin_memory()
-        self.flag[0] = 0
-        self.event = torch.cuda.Event()
+        if NanProbe._pool:
+            self.flag, self.view, self.event = NanProbe._pool.pop()
+        else:
+            self.flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self.view = self.flag.numpy()          # host-side reads / writes of the verdict without a tensor op
+            self.event = torch.cuda.Event()
+        self.view[0] = 0
         _ffi.call("spamd_has_nan_async", code_of(data.dtype), data.numel(), ptr(data), self.flag.data_ptr(), stream_ptr(dev))
-        self.event.record(torch.cuda.current_stream(dev))
+        self.event.record()
         self._keep = data  # the scanned buffer must outlive the kernel
 
     def ready(self):
@@ -90,9 +94,9 @@ class NanProbe:
 
     def result(self):
         self.event.synchronize()
-        res = bool(int(self.flag[0]))
-        NanProbe._pool.append(self.flag)
-        self._keep = self.flag = None
+        res = bool(int(self.view[0]))
+        NanProbe._pool.append((self.flag, self.view, self.event))
+        self._keep = self.flag = self.view = self.event = None
         return res
 
 
