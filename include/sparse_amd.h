@@ -174,6 +174,12 @@ int spamd_compact(int elem_bytes, int64_t n, const void* src, const int64_t* fla
                   void* dst, void* stream);
 /* dst[i] = src[perm[i]] ; dst[keys[i]] = src[i] */
 int spamd_gather(int elem_bytes, int64_t n, const void* src, const int64_t* perm, void* dst, void* stream);
+/* the same for every row of a [rows, n] matrix in one launch (the [ndim, nnz] coordinate matrix of a COO,
+ * `coords[:, order]` / `coords[:, mask]` in the reference's `_sort_indices` / `_sum_duplicates`, _coo/core.py:1294-1353) */
+int spamd_compact_rows(int elem_bytes, int rows, int64_t n, const void* src, int64_t ld_src, const int64_t* flags,
+                       const int64_t* offsets, void* dst, int64_t ld_dst, void* stream);
+int spamd_gather_rows(int elem_bytes, int rows, int64_t n, const void* src, int64_t ld_src, const int64_t* perm, void* dst,
+                      int64_t ld_dst, void* stream);
 int spamd_scatter(int elem_bytes, int64_t n, const void* src, const int64_t* keys, void* dst, void* stream);
 /* sorted keys (row*C + col) -> indptr[R+1], indices[nnz]          (`_from_coo`, compressed.py:64-76) */
 int spamd_keys_to_csr(int idx_dtype, int64_t nnz, const int64_t* keys, int64_t R, int64_t C, void* indptr,

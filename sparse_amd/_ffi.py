@@ -59,6 +59,8 @@ SIGNATURES = {
     "spamd_compact": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _vp]),
     "spamd_gather": (_int, [_int, _i64, _vp, _vp, _vp, _vp]),
     "spamd_scatter": (_int, [_int, _i64, _vp, _vp, _vp, _vp]),
+    "spamd_compact_rows": (_int, [_int, _int, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "spamd_gather_rows": (_int, [_int, _int, _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
     "spamd_keys_to_csr": (_int, [_int, _i64, _vp, _i64, _i64, _vp, _vp, _vp]),
     "spamd_csr_to_keys": (_int, [_int, _i64, _i64, _vp, _vp, _i64, _vp, _vp]),
     "spamd_rows_to_indptr": (_int, [_int, _i64, _vp, _i64, _vp, _vp]),

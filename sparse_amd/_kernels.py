@@ -312,9 +312,8 @@ def compact(src, flags, offsets, count):
         return dst
     src = src.contiguous()
     dst = torch.empty((src.shape[0], count), dtype=src.dtype, device=dev)
-    for r in range(src.shape[0]):
-        _ffi.call("spamd_compact", src.element_size(), n, ptr(src[r]), ptr(flags), ptr(offsets), ptr(dst[r]),
-                  stream_ptr(dev))
+    _ffi.call("spamd_compact_rows", src.element_size(), int(src.shape[0]), n, ptr(src), n, ptr(flags), ptr(offsets), ptr(dst),
+              count, stream_ptr(dev))   # all rows of the [k, n] matrix in one launch
     return dst
 
 
@@ -328,8 +327,8 @@ def gather(src, perm):
         return dst
     src = src.contiguous()
     dst = torch.empty((src.shape[0], n), dtype=src.dtype, device=dev)
-    for r in range(src.shape[0]):
-        _ffi.call("spamd_gather", src.element_size(), n, ptr(src[r]), ptr(perm), ptr(dst[r]), stream_ptr(dev))
+    _ffi.call("spamd_gather_rows", src.element_size(), int(src.shape[0]), n, ptr(src), int(src.shape[1]), ptr(perm), ptr(dst), n,
+              stream_ptr(dev))
     return dst
 
 

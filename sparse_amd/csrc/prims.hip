@@ -185,6 +185,26 @@ __global__ void __launch_bounds__(256) gather_kernel(const U* __restrict__ src, 
   GRID_STRIDE(i, n) dst[i] = src[perm[i]];
 }
 
+// every row of a [rows, n] matrix (row pitch ld_src / ld_dst elements) at once: blockIdx.y = row
+template <typename U>
+__global__ void __launch_bounds__(256) compact_rows_kernel(const U* __restrict__ src, int64_t ld_src, int64_t n,
+                                                           const int64_t* __restrict__ flags,
+                                                           const int64_t* __restrict__ offs, U* __restrict__ dst,
+                                                           int64_t ld_dst) {
+  src += (int64_t)blockIdx.y * ld_src;
+  dst += (int64_t)blockIdx.y * ld_dst;
+  GRID_STRIDE(i, n) if (flags[i]) dst[offs[i]] = src[i];
+}
+
+template <typename U>
+__global__ void __launch_bounds__(256) gather_rows_kernel(const U* __restrict__ src, int64_t ld_src,
+                                                          const int64_t* __restrict__ perm, int64_t n, U* __restrict__ dst,
+                                                          int64_t ld_dst) {
+  src += (int64_t)blockIdx.y * ld_src;
+  dst += (int64_t)blockIdx.y * ld_dst;
+  GRID_STRIDE(i, n) dst[i] = src[perm[i]];
+}
+
 template <typename U>
 __global__ void __launch_bounds__(256) scatter_kernel(const U* __restrict__ src, const int64_t* __restrict__ keys,
                                                       int64_t n, U* __restrict__ dst) {
@@ -428,6 +448,25 @@ extern "C" int spamd_gather(int elem_bytes, int64_t n, const void* src, const in
   if (n == 0) return 0;
   SPAMD_BYTES_SWITCH(elem_bytes, U, hipLaunchKernelGGL(gather_kernel<U>, dim3(grid_for(n)), dim3(256), 0,
                                                        (hipStream_t)stream, (const U*)src, perm, n, (U*)dst))
+  return launch_status();
+}
+
+extern "C" int spamd_compact_rows(int elem_bytes, int rows, int64_t n, const void* src, int64_t ld_src, const int64_t* flags,
+                                  const int64_t* offsets, void* dst, int64_t ld_dst, void* stream) {
+  if (n < 0 || rows < 0 || rows > 65535) return SPAMD_EINVAL;
+  if (n == 0 || rows == 0) return 0;
+  SPAMD_BYTES_SWITCH(elem_bytes, U, hipLaunchKernelGGL(compact_rows_kernel<U>, dim3(grid_for(n), (unsigned)rows), dim3(256), 0,
+                                                       (hipStream_t)stream, (const U*)src, ld_src, n, flags, offsets, (U*)dst,
+                                                       ld_dst))
+  return launch_status();
+}
+
+extern "C" int spamd_gather_rows(int elem_bytes, int rows, int64_t n, const void* src, int64_t ld_src, const int64_t* perm,
+                                 void* dst, int64_t ld_dst, void* stream) {
+  if (n < 0 || rows < 0 || rows > 65535) return SPAMD_EINVAL;
+  if (n == 0 || rows == 0) return 0;
+  SPAMD_BYTES_SWITCH(elem_bytes, U, hipLaunchKernelGGL(gather_rows_kernel<U>, dim3(grid_for(n), (unsigned)rows), dim3(256), 0,
+                                                       (hipStream_t)stream, (const U*)src, ld_src, perm, n, (U*)dst, ld_dst))
   return launch_status();
 }
 
