@@ -88,7 +88,7 @@ typedef int tl_srd_t __attribute__((ext_vector_type(4)));   // buffer descriptor
 constexpr int TL_TILE = TL_KB * 512;
 constexpr int TL_LDS = TL_NBUF * TL_TILE;
 constexpr int TL_DMA_PER_TILE = TL_TILE / 16 / (TL_WAVES * 64);  // LDS-DMA instructions per wave per tile
-static_assert(TL_LDS <= 160 * 1024 && TL_KB % 32 == 0 && TL_DMA_PER_TILE == TL_ASM_DMA_PER_TILE,
+static_assert(TL_LDS <= 160 * 1024 && TL_KB % (2 * TL_WAVES) == 0 && TL_DMA_PER_TILE == TL_ASM_DMA_PER_TILE,
               "tile geometry is baked into gen_tiled_asm.py");
 constexpr int TL_SLACK_BLOCKS = 68;  // readable blocks past the end of the stream: the fixed-width line touch (<= 64 lines) + ring over-read
 

@@ -27,7 +27,8 @@ F64 = False
 RING = (40, 56, 72)
 ROWS = int(os.environ.get("TL_RG", "35"))     # rows per wave: 2 accumulator registers each, v[128 - 2*ROWS : 128)
 WAVES = int(os.environ.get("TL_WAVES", "16"))  # waves per workgroup (ROWS * WAVES rows share one B tile)
-ACC0 = 128 - 2 * ROWS
+VB = int(os.environ.get("TL_VGPRS", "128"))    # registers of a wave (128: four waves per SIMD; 168: three)
+ACC0 = VB - 2 * ROWS
 JUNK = ACC0 - 2                               # junk accumulator pair (padding entries), just below the accumulators
 BASE = 22                                     # LDS base of the current tile + 8*lane
 TOUCH = 23                                    # destination of the line touches
@@ -285,7 +286,7 @@ def phases(lds=True, fma=True, exact=False):
           "v_readlane_b32 s88, %[offreg], s38",
           "s_mov_b32 s91, s92", "s_mov_b32 s92, s93",
           f"v_xor_b32 v{BASE}, 0x400, v{BASE}",
-          "s_and_b32 s89, s89, 0x7fff", "s_xor_b32 s89, s89, 0x400",   # back to the wave's first row pair, other buffer
+          f"s_sub_u32 s89, s89, {hex(KB * 1024)}", "s_xor_b32 s89, s89, 0x400",   # back to the wave's first row pair, other buffer
           # touch the first lines of list t+2 (lane i -> line min(i, L-1), L chosen by the launcher from the mean
           # list length): always ONE instruction; lists are consecutive, so lines past a short list are the next one's
           f"global_load_dword v{TOUCH}, %[toff], s[94:95]"]
