@@ -328,9 +328,9 @@ def _tiled_dtype(data, bt):
 
 def _tiled_eligible(data, bt, out_shape, Kd):
     """The inspector/executor kernel covers float32 (N % 128 == 0) and float64 (N % 64 == 0) products.  Thresholds
-    measured on MI355X (tools/tiled_crossover.py): it needs >= 128 workgroups of 512 rows to beat the row-group
-    kernel, and its (32-row x 128-column) lists must hold ~12 stored elements on average — 6 when B is too large for
-    the row-group kernel's gathers to stay in cache (>= 16 MB).  The inspector costs about one row-group product, so
+    measured on MI355X (tools/tiled_crossover.py): it needs >= 117 workgroups of 560 rows to beat the row-group
+    kernel, and a density of >= 0.3 % (12 stored elements per 32 x 128 cells: ~16 per (35-row x 160-column) list) — half
+    that when B is too large for the row-group kernel's gathers to stay in cache (>= 16 MB).  The inspector costs about one row-group product, so
     a single product breaks even and every further one is 2-3x faster."""
     M, N = out_shape
     if _settings.TILED_SPMM == "never" or bt.dim() != 2:
@@ -428,7 +428,7 @@ def _gcxs_times_dense(a, bt, out_shape):
         a._spmm_uses = getattr(a, "_spmm_uses", 0) + 1
         use_tiled = a._spmm_uses >= 2
     if use_tiled:
-        # the inspector costs about one product (1.5 ms at config 2 against 1.2 ms per tiled and 2.6 ms per
+        # the inspector costs about one product (1.25 ms at config 2 against 0.85 ms per tiled and 2.8 ms per
         # row-group product), so it runs at the first eligible product and is cached on the array
         dt = _tiled_dtype(data, bt)
         prepare_spmm(a, dt)
