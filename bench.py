@@ -267,6 +267,13 @@ def main():
         inspector_ms = dev_time(lambda: _kernels.csr_tiled_layout(data, idx, ptr, Mloc, K), 3)
         tiled = _dot.prepare_spmm(a)
 
+    # the value is a STEADY-STATE rate: the first ~30 products after the set-up above (host-timed first products, the
+    # inspector timing, idle gaps between them) run 5-8 % slower than the ones after them (steps 20: warm-up 3 -> 0.918 ms,
+    # 10 -> 0.887, 30 -> 0.849; the kernel alone 0.83-0.85 throughout), so the device is brought to its sustained state
+    # before the W warm-up steps the command line asks for (reported as `prewarm_products`)
+    PREWARM = 40
+    for _ in range(PREWARM):
+        out = step()
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
@@ -337,7 +344,7 @@ def main():
                 "parallelism": f"row-block x{world}" + (" + RCCL all-gather(B) per step" if sharded_b else ""),
                 "mul_add": "separate (bit-exact)" if args.exact else "fma",
                 "nan_check_in_timed_region": bool(_settings.NAN_CHECK), "nan_check_ms_per_product": nan_check_ms,
-                "nan_warning": _settings.NAN_WARNING,
+                "nan_warning": _settings.NAN_WARNING, "prewarm_products": PREWARM,
                 "kernel": "spmm_tiled (cached block stream)" if tiled else "spmm_csr_rowgroup",
                 "first_call_ms": first_call_ms, "first_call_cold_ms": first_call_cold_ms,
                 "first_call_gflops": flops_local / (first_call_ms * 1e-3) / 1e9 if first_call_ms else None,

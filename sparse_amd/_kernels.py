@@ -73,31 +73,53 @@ class NanProbe:
     """A NaN scan in flight: the kernel writes its verdict into a pinned host int; `result()` waits for the event
     recorded right behind the scan — NOT for whatever was queued after it — and reads the int."""
 
-    _pool = []   # (pinned int32[1], its NumPy view, a reusable event)
+    # verdict slots: ONE pinned int32 slab, handed out by index (a pinned allocation per probe costs ~0.1 ms of host time,
+    # which a loop that runs many products ahead of the device would pay once per product in flight)
+    _SLOTS = 1024
+    _slab = None      # pinned int32[_SLOTS]
+    _view = None      # its NumPy view: host-side reads / writes of a verdict without a tensor op
+    _free = []        # free slot indices
+    _events = []      # reusable events
+
+    @classmethod
+    def _take(cls):
+        if cls._slab is None:
+            cls._slab = torch.zeros(cls._SLOTS, dtype=torch.int32).pin_memory()
+            cls._view = cls._slab.numpy()
+            cls._free = list(range(cls._SLOTS))
+        if not cls._free:
+            return None
+        return cls._free.pop()
 
     def __init__(self, data):
         dev = require_hip(data)
-        if NanProbe._pool:
-            self.flag, self.view, self.event = NanProbe._pool.pop()
+        self.slot = NanProbe._take()
+        if self.slot is None:            # more than _SLOTS scans in flight: a private pinned word
+            self.own = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self.view, self.at, addr = self.own.numpy(), 0, self.own.data_ptr()
         else:
-            self.flag = torch.zeros(1, dtype=torch.int32).pin_memory()
-            self.view = self.flag.numpy()          # host-side reads / writes of the verdict without a tensor op
-            self.event = torch.cuda.Event()
-        self.view[0] = 0
-        _ffi.call("spamd_has_nan_async", code_of(data.dtype), data.numel(), ptr(data), self.flag.data_ptr(), stream_ptr(dev))
+            self.own = None
+            self.view, self.at, addr = NanProbe._view, self.slot, NanProbe._slab.data_ptr() + 4 * self.slot
+        self.event = NanProbe._events.pop() if NanProbe._events else torch.cuda.Event()
+        self.view[self.at] = 0
+        _ffi.call("spamd_has_nan_async", code_of(data.dtype), data.numel(), ptr(data), addr, stream_ptr(dev))
         self.event.record()
         self._keep = data  # the scanned buffer must outlive the kernel
+        self.done = None
 
     def ready(self):
         """True once the scan has finished (never blocks)"""
-        return self.flag is None or self.event.query()
+        return self.done is not None or self.event.query()
 
     def result(self):
-        self.event.synchronize()
-        res = bool(int(self.view[0]))
-        NanProbe._pool.append((self.flag, self.view, self.event))
-        self._keep = self.flag = self.view = self.event = None
-        return res
+        if self.done is None:
+            self.event.synchronize()
+            self.done = bool(int(self.view[self.at]))
+            if self.slot is not None:
+                NanProbe._free.append(self.slot)
+            NanProbe._events.append(self.event)
+            self._keep = self.view = self.event = self.own = None
+        return self.done
 
 
 def has_nan_async(data):
