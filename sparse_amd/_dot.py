@@ -338,6 +338,8 @@ def _tiled_eligible(data, bt, out_shape, Kd):
     dt = _tiled_dtype(data, bt)
     if dt is None or N < (64 if dt == torch.float32 else 32):   # narrower results: the row-group kernel
         return False
+    if (Kd + 512) * N * bt.element_size() >= (1 << 32):   # the executor walks B with 32-bit byte offsets (buffer-form tile DMA)
+        return False
     per_list = int(data.numel()) * 4096 / max(M * Kd, 1)
     return M >= 65536 and (per_list >= 12 or (per_list >= 6 and Kd * N * bt.element_size() >= (16 << 20)))
 
