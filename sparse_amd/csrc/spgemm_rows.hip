@@ -81,6 +81,9 @@ __global__ void __launch_bounds__(256) spgemm_row_products_kernel(int64_t n_row,
 // The scans are hand-written (wave shuffles + one LDS hop); nothing here comes from a library.
 // A bucket with more than 16 products (in the end: a column of B that collects many products of one row) makes the
 // kernel decline the row (nnz_row = -1): the caller routes it through the global form like the rows above the capacity.
+#ifndef SPG_WPE
+#define SPG_WPE 4
+#endif
 constexpr int SPG_BUCKET_MAX = 16;      // products one bucket may hold (registers of the thread that ranks it)
 
 template <int BLOCK>
@@ -159,7 +162,7 @@ struct RowRankLayout {
 // a CU - the global-load latencies of one row's expansion then overlap the other row's ranking (one 1024-thread
 // workgroup per CU measured 31 ms at 10^9 products, exposed latency throughout).
 template <int BLOCK, int ITEMS, int PASSES, typename KEY, typename V, typename I>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 512 ? 4 : 1, 8)))
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK >= 512 ? SPG_WPE : 1, 8)))
 spgemm_rowrank_kernel(int64_t n_col, int col_bits, int ebits, const I* __restrict__ a_ptr, const I* __restrict__ a_idx,
                       const V* __restrict__ a_val, const I* __restrict__ b_ptr, const I* __restrict__ b_idx,
                       const V* __restrict__ b_val, const int64_t* __restrict__ prod_off, int64_t lo, int64_t hi,
