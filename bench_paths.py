@@ -196,7 +196,15 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
         for dtn, tdt, esz in (("bf16", torch.bfloat16, 2), ("f32", torch.float32, 4)):
             a = torch.rand((Ms, 256), device=dev).to(tdt)
             bt = torch.rand((Ms, 256), device=dev).to(tdt)
-            ms, r = timed(lambda: K.sddmm_coo(s.coords, s.data, a, bt))
+            ms_rm, r_rm = timed(lambda: K.sddmm_coo(s.coords, s.data, a, bt))
+            width = K.sddmm_panel_width(bt)
+            t0 = time.perf_counter()
+            panels = K.sddmm_panels(s.coords, s.shape, width) if width else None
+            torch.cuda.synchronize()
+            plan_ms = (time.perf_counter() - t0) * 1e3
+            ms, r = timed(lambda: K.sddmm_coo(s.coords, s.data, a, bt, panels=panels))
+            same = bool(torch.equal(r, r_rm))
+            ms_api, _ = timed(lambda: sp.sddmm(s, a, bt=bt))
             b = nnz4 * (2 * 4 + 4) + 2 * Ms * 256 * esz + nnz4 * 4
             ha, hb = a[hrow].to(torch.float64).cpu().numpy(), bt[hcol].to(torch.float64).cpu().numpy()
             wv, leg = cpu_leg(lambda: hs * np.einsum("ik,ik->i", ha, hb),
@@ -204,8 +212,11 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
             terms = np.abs(hs) * np.einsum("ik,ik->i", np.abs(ha), np.abs(hb))
             leg["max_err_over_sum_abs_terms"] = float(np.max(np.abs(r[pick].cpu().numpy().astype(np.float64) - wv) / terms))
             emit(f"A9_sddmm_{dtn}", row(f"config 4: mask COO({Ms}x{Ms}, {nnz4} nnz) (.) A({Ms}x256) Bt({Ms}x256), {dtn} in / fp32 acc, "
-                                        "sampled kernel", ms, b, flops=2.0 * 256 * nnz4, gather_bytes=nnz4 * 2 * 256 * esz,
-                                        gather_TBps=nnz4 * 2 * 256 * esz / ms / 1e9, cpu_baseline=leg))
+                                        f"sampled kernel in column-panel order ({width} Bt rows per panel; plan cached on the mask)",
+                                        ms, b, flops=2.0 * 256 * nnz4, row_major_ms=ms_rm, plan_ms=plan_ms,
+                                        identical_to_row_major=same, api_ms=ms_api,
+                                        api_note="sparse_amd.sddmm: kernel + zero pruning + result container",
+                                        gather_bytes=nnz4 * 2 * 256 * esz, cpu_baseline=leg))
         if want("A9_mfma"):
             _sddmm_mfma_rows(sp, K, s, Ms, emit)
         del s, a, bt, r
@@ -321,10 +332,16 @@ def _sddmm_mfma_rows(sp, K, s, Ms, emit):
     clustered = sp.COO(np.stack([lin // Ms, lin % Ms]).astype(np.int32), rng.random(lin.size).astype(np.float32), shape=(Ms, Ms))
     for tag, mask in (("uniform", s), ("clustered", clustered)):
         plan = K.sddmm_plan(mask.coords, mask.shape)
-        f = lambda: (K.sddmm_coo_mfma(plan, mask.coords, mask.shape, mask.data, a, bt)
-                     if plan.n_dense_samples >= K.SDDMM_MFMA_MIN_SHARE * plan.nnz else K.sddmm_coo(mask.coords, mask.data, a, bt))
+        width = K.sddmm_panel_width(bt)
+        allp = K.sddmm_panels(mask.coords, mask.shape, width) if width else None
+        restp = (K.sddmm_panels(mask.coords, mask.shape, width, subset=plan.rest)
+                 if width and int(plan.rest.numel()) >= K.SDDMM_PANEL_MIN_NNZ else None)
+        f = lambda: (K.sddmm_coo_mfma(plan, mask.coords, mask.shape, mask.data, a, bt, rest_panels=restp)
+                     if plan.n_dense_samples >= K.SDDMM_MFMA_MIN_SHARE * plan.nnz
+                     else K.sddmm_coo(mask.coords, mask.data, a, bt, panels=allp))
         ms, got = timed(f)
-        ms_s, _ = timed(lambda: K.sddmm_coo(mask.coords, mask.data, a, bt))
+        ms_s, _ = timed(lambda: K.sddmm_coo(mask.coords, mask.data, a, bt, panels=allp))
+        ms_rm, _ = timed(lambda: K.sddmm_coo(mask.coords, mask.data, a, bt))
         pick = np.sort(rng.choice(mask.nnz, size=min(20000, mask.nnz), replace=False))
         hrow, hcol = mask.coords[0][pick].cpu().numpy(), mask.coords[1][pick].cpu().numpy()
         hs = mask.data[pick].cpu().numpy().astype(np.float64)
@@ -337,6 +354,7 @@ def _sddmm_mfma_rows(sp, K, s, Ms, emit):
             f"SDDMM, per-tile dispatch, {tag} mask COO({Ms}x{Ms}, {mask.nnz} nnz), bf16 K=256: {ntile} tiles "
             f"({plan.n_dense_samples} samples) on v_mfma_f32_32x32x16_bf16, the rest sampled", ms,
             mask.nnz * 16 + 4 * Ms * 256, flops=2.0 * 256 * mask.nnz, sampled_kernel_ms=ms_s, speedup_vs_sampled=ms_s / ms,
+            sampled_row_major_ms=ms_rm,
             dense_tiles=ntile, tile_product_TFLOPs=2.0 * ntile * 32 * 32 * 256 / ms / 1e9 if ntile else 0.0,
             max_err_over_sum_abs_terms=err))
 

@@ -337,6 +337,19 @@ int spamd_sddmm(int in_dtype, int s_dtype, int idx_dtype, int64_t nnz, const voi
                 const void* s_data, const void* A, int64_t lda, const void* Bt, int64_t ldb, int64_t K, void* out,
                 void* stream);
 
+/* A9 in column-panel order (same result, element for element, as spamd_sddmm; same reference formulation,
+ * examples/sddmm_example.py:51-52).  When Bt does not fit an XCD's L2, a mask walked in row-major order fetches every
+ * Bt row from the Infinity Cache.  spamd_sddmm_panel_keys gives keys[n] = cols[n] / width; the caller sorts them
+ * stably (spamd_sort_pairs) into `perm`, gathers rows/cols/values by it (rows_p, cols_p, s_p), and spamd_sddmm_panels
+ * walks the mask one panel of `width` Bt rows at a time, lane groups taking `chunk` elements per turn (<= 0: default):
+ * out[perm[n]] = s_p[n] * <A[rows_p[n]], Bt[cols_p[n]]>, i.e. out keeps the mask's own order.  perm/rows_p/cols_p
+ * depend on the coordinates only.  SPAMD_EINVAL when K has no row-cached kernel (call spamd_sddmm). */
+int spamd_sddmm_has_panels(int in_dtype, int64_t K); /* 1: spamd_sddmm_panels has a kernel for this K */
+int spamd_sddmm_panel_keys(int idx_dtype, int64_t nnz, const void* cols, int64_t width, void* keys, void* stream);
+int spamd_sddmm_panels(int in_dtype, int s_dtype, int idx_dtype, int64_t nnz, const void* rows_p, const void* cols_p,
+                       const int64_t* perm, const void* s_p, const void* A, int64_t lda, const void* Bt, int64_t ldb,
+                       int64_t K, int64_t chunk, void* out, void* stream);
+
 /* A9, dense-tile form (north_star: "MFMA used only on the dense tile of SDDMM"): the 32 x 32 tiles of the mask that
  * hold at least `threshold` samples are computed as one 32 x 32 x K bf16 product on the matrix cores
  * (v_mfma_f32_32x32x16_bf16, fp32 accumulate) and sampled from LDS; every other sample goes to spamd_sddmm.

@@ -37,30 +37,50 @@ def sddmm(s, a, b=None, *, bt=None):
     whole dense product first).  Pass `b` (K x N) or its transpose `bt` (N x K, K-contiguous:
     avoids a device transpose).  Dense operands may be bfloat16/float32/float64 torch tensors
     (bf16/fp32 accumulate in fp32) or float ndarrays.  Result has the format of `s`, zeros pruned."""
+    from ._dot import _validate_derived
     from ._utils import check_zero_fill_value
 
     check_zero_fill_value(s)
     if s.ndim != 2:
         raise ValueError("sddmm needs a 2-D sparse mask")
     out_gcxs = isinstance(s, GCXS)
-    sc = s if isinstance(s, COO) else s.tocoo()
+    if isinstance(s, COO):
+        sc = s
+    else:  # the COO view of a GCXS mask is kept on it, and the plans on the view
+        _validate_derived(s)
+        sc = s.__dict__.get("_coo_view")
+        if sc is None:
+            sc = s.__dict__["_coo_view"] = s.tocoo()
     at = dev.to_device(a, sc.device)
     if (b is None) == (bt is None):
         raise ValueError("pass exactly one of b / bt")
     btt = dev.to_device(bt, sc.device) if bt is not None else dev.to_device(b, sc.device).t().contiguous()
     if at.shape[0] != s.shape[0] or btt.shape[0] != s.shape[1] or at.shape[1] != btt.shape[1]:
         raise ValueError("shape-mismatch for sum")
+    _validate_derived(sc)
+    # plans depend on the pattern only and are kept on the mask (dropped with its other derived layouts when the
+    # coordinates change): the populated 32 x 32 tiles that go to the matrix cores, and - when Bt is larger than an
+    # XCD's L2 - the column-panel order of whatever the sampled kernel takes
+    width = K.sddmm_panel_width(btt) if sc.nnz >= K.SDDMM_PANEL_MIN_NNZ else 0
+    plans = sc.__dict__.setdefault("_sddmm_plan", {})
+
+    def panels_of(subset, tag):
+        key = ("panels", tag, width)
+        if key not in plans:
+            plans[key] = K.sddmm_panels(sc.coords, sc.shape, width, subset=subset)
+        return plans[key]
+
     vals = None
     if at.dtype == torch.bfloat16 and btt.dtype == torch.bfloat16 and sc.nnz >= K.SDDMM_TILE_THRESHOLD and at.shape[1] % 16 == 0:
-        # populated 32 x 32 tiles of the mask go to the matrix cores; the plan depends on the pattern only and is kept
-        # on the mask (dropped with its other derived layouts when the coordinates change)
-        plan = getattr(sc, "_sddmm_plan", None)
-        if plan is None or plan.nnz != sc.nnz or plan.threshold != K.SDDMM_TILE_THRESHOLD:
-            plan = K.sddmm_plan(sc.coords, sc.shape)
-            sc._sddmm_plan = plan
-        vals = K.sddmm_coo_mfma(plan, sc.coords, sc.shape, sc.data, at, btt)
+        key = ("tiles", K.SDDMM_TILE_THRESHOLD)
+        if key not in plans:
+            plans[key] = K.sddmm_plan(sc.coords, sc.shape)
+        plan = plans[key]
+        if plan.n_dense_samples >= K.SDDMM_MFMA_MIN_SHARE * plan.nnz:
+            rest = panels_of(plan.rest, "rest") if width and int(plan.rest.numel()) >= K.SDDMM_PANEL_MIN_NNZ else None
+            vals = K.sddmm_coo_mfma(plan, sc.coords, sc.shape, sc.data, at, btt, rest_panels=rest)
     if vals is None:
-        vals = K.sddmm_coo(sc.coords, sc.data, at, btt)
+        vals = K.sddmm_coo(sc.coords, sc.data, at, btt, panels=panels_of(None, "all") if width else None)
     out = COO(sc.coords, vals, shape=s.shape, has_duplicates=False, sorted=True, prune=True)
     return out.asformat("gcxs", compressed_axes=s.compressed_axes) if out_gcxs else out
 

@@ -344,7 +344,7 @@ def _tiled_eligible(data, bt, out_shape, Kd):
     return M >= 65536 and (per_list >= 12 or (per_list >= 6 and Kd * N * bt.element_size() >= (16 << 20)))
 
 
-DERIVED_CACHES = ("_csr_view", "_csr_twin", "_tiled_layouts", "_spmm_uses", "_nan_memo", "_derived_stamp", "_sddmm_plan", "_t_view")
+DERIVED_CACHES = ("_csr_view", "_csr_twin", "_tiled_layouts", "_spmm_uses", "_nan_memo", "_derived_stamp", "_sddmm_plan", "_t_view", "_coo_view")
 
 
 def drop_derived(a):

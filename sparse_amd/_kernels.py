@@ -716,9 +716,68 @@ def dot_coo_coo(out_shape, a_coords, b_coords, a_data, b_data, n_inner):
     return delinearize(keys, (n_row, n_col), torch.int64), data
 
 
-def sddmm_coo(coords, s_data, a, bt):
+SDDMM_PANEL_BYTES = 3 << 20     # Bt rows of one column panel: what stays in a 4 MiB L2 next to the streamed operands
+SDDMM_PANEL_MIN_NNZ = 1 << 20   # below this the sort of the plan and the scattered output cost more than they save
+
+
+class SddmmPanels:
+    """Column-panel order of a mask, or of a subset of its stored elements (csrc/sddmm.hip, spamd_sddmm_panels):
+    `pos` = the elements' positions in the mask, stably sorted by column panel; `rows`/`cols` = their coordinates in
+    that order.  Depends on the coordinates and the panel width only: cached on the mask by `sparse_amd.sddmm`."""
+
+    __slots__ = ("pos", "rows", "cols", "width", "count", "nnz", "chunk", "_vals", "_vals_key")
+
+    def values(self, s_orig, s_data):
+        """`s_data` (= `s_orig` in the accumulation dtype) in panel order; kept for as long as the same, unmodified
+        `s_orig` is passed."""
+        key = (s_orig.data_ptr(), s_orig._version, s_orig.dtype, s_data.dtype)
+        if self._vals_key != key:
+            self._vals, self._vals_key = gather(s_data, self.pos), key
+        return self._vals
+
+
+def sddmm_panel_width(bt):
+    """Bt rows per panel, or 0 when Bt fits the L2 as a whole or its K has no row-cached kernel (no panel order)."""
+    row_bytes = int(bt.shape[1]) * bt.element_size()
+    if row_bytes == 0 or int(bt.shape[0]) * row_bytes <= SDDMM_PANEL_BYTES:
+        return 0
+    if bt.dtype not in (torch.bfloat16, torch.float32, torch.float64) or \
+            not _ffi.lib().spamd_sddmm_has_panels(code_of(bt.dtype), int(bt.shape[1])):
+        return 0
+    return max(SDDMM_PANEL_BYTES // row_bytes, 64)
+
+
+def sddmm_panels(coords, shape, width, subset=None):
+    """Panel order of the mask's stored elements, or of those listed in `subset` (int64 positions, ascending)."""
+    dev = require_hip(coords)
+    rows, cols = coords[0].contiguous(), coords[1].contiguous()
+    if not index_dtype_ok(rows):
+        rows, cols = rows.to(torch.int64), cols.to(torch.int64)
+    p = SddmmPanels()
+    p.nnz = int(rows.numel())
+    if subset is not None:
+        rows, cols = gather(rows, subset), gather(cols, subset)
+    n = int(rows.numel())
+    keys = torch.empty(n, dtype=torch.int64, device=dev)
+    _ffi.call("spamd_sddmm_panel_keys", code_of(cols.dtype), n, ptr(cols), int(width), ptr(keys), stream_ptr(dev))
+    _, perm = sort_keys(keys, max((int(shape[1]) - 1) // int(width), 1))
+    p.pos = perm if subset is None else gather(subset, perm)
+    p.rows, p.cols, p.width, p.count, p.chunk = gather(rows, perm), gather(cols, perm), int(width), n, 0
+    p._vals = p._vals_key = None
+    return p
+
+
+def _sddmm_panels_into(panels, s_orig, s_data, a, bt, out):
+    """The elements of `panels` (all of the mask or a subset), written to their positions in `out`."""
+    _ffi.call("spamd_sddmm_panels", code_of(a.dtype), code_of(out.dtype), code_of(panels.rows.dtype), panels.count,
+              ptr(panels.rows), ptr(panels.cols), ptr(panels.pos), ptr(panels.values(s_orig, s_data)), ptr(a), a.stride(0),
+              ptr(bt), bt.stride(0), int(a.shape[1]), int(panels.chunk), ptr(out), stream_ptr(out.device))
+
+
+def sddmm_coo(coords, s_data, a, bt, panels=None):
     """out[n] = s[n] * <a[i_n, :], bt[j_n, :]> for a 2-D COO mask — the sampled product the
-    reference writes as `s * (a @ b)` (examples/sddmm_example.py:51-52)."""
+    reference writes as `s * (a @ b)` (examples/sddmm_example.py:51-52).  `panels` (SddmmPanels of the same
+    mask) selects the column-panel order."""
     dev = require_hip(coords, s_data, a, bt)
     nnz = int(s_data.numel())
     if a.dtype != bt.dtype:
@@ -729,7 +788,7 @@ def sddmm_coo(coords, s_data, a, bt):
         sdt = torch.float64
     else:
         raise TypeError(f"sddmm supports bfloat16/float32/float64 dense operands, got {a.dtype}")
-    s_data = s_data.to(sdt).contiguous()
+    s_orig, s_data = s_data, s_data.to(sdt).contiguous()
     a, bt = a.contiguous(), bt.contiguous()
     if a.shape[1] != bt.shape[1]:
         raise ValueError("shape-mismatch for sum")
@@ -742,6 +801,10 @@ def sddmm_coo(coords, s_data, a, bt):
     if not index_dtype_ok(rows):
         rows, cols = rows.to(torch.int64), cols.to(torch.int64)
     out = torch.empty(nnz, dtype=sdt, device=dev)
+    if panels is not None and nnz and panels.nnz == nnz and panels.count == nnz and \
+            _ffi.lib().spamd_sddmm_has_panels(code_of(a.dtype), int(a.shape[1])):
+        _sddmm_panels_into(panels, s_orig, s_data, a, bt, out)
+        return out
     _ffi.call("spamd_sddmm", code_of(a.dtype), code_of(sdt), code_of(rows.dtype), nnz, ptr(rows), ptr(cols),
               ptr(s_data), ptr(a), a.stride(0), ptr(bt), bt.stride(0), int(a.shape[1]), ptr(out), stream_ptr(dev))
     return out
@@ -794,9 +857,10 @@ def sddmm_plan(coords, shape, threshold=None):
     return p
 
 
-def sddmm_coo_mfma(plan, coords, shape, s_data, a, bt, out=None, force=False):
+def sddmm_coo_mfma(plan, coords, shape, s_data, a, bt, out=None, force=False, rest_panels=None):
     """SDDMM with per-tile dispatch (bf16 operands): dense tiles on the matrix cores, the rest through the sampled
-    kernel.  Returns None when the plan leaves (almost) everything to the sampled kernel and `force` is not set."""
+    kernel (in column-panel order when `rest_panels` = sddmm_panels(..., subset=plan.rest) is given).  Returns None
+    when the plan leaves (almost) everything to the sampled kernel and `force` is not set."""
     dev = require_hip(coords, s_data, a, bt)
     if a.dtype != torch.bfloat16 or bt.dtype != torch.bfloat16:
         raise TypeError("the matrix-core SDDMM path takes bfloat16 operands")
@@ -806,7 +870,7 @@ def sddmm_coo_mfma(plan, coords, shape, s_data, a, bt, out=None, force=False):
     if not force and plan.n_dense_samples < SDDMM_MFMA_MIN_SHARE * plan.nnz:
         return None
     a, bt = a.contiguous(), bt.contiguous()
-    s_data = s_data.to(torch.float32).contiguous()
+    s_orig, s_data = s_data, s_data.to(torch.float32).contiguous()
     rows, cols = coords[0].contiguous(), coords[1].contiguous()
     if not index_dtype_ok(rows):
         rows, cols = rows.to(torch.int64), cols.to(torch.int64)
@@ -817,7 +881,10 @@ def sddmm_coo_mfma(plan, coords, shape, s_data, a, bt, out=None, force=False):
               ptr(plan.keys), ptr(plan.perm), plan.tile_cols, int(shape[0]), int(shape[1]), ptr(rows), ptr(cols), ptr(s_data),
               ptr(a), a.stride(0), ptr(bt), bt.stride(0), Kd, ptr(out), s)
     nrest = int(plan.rest.numel())
-    if nrest:
+    if nrest and rest_panels is not None and rest_panels.count == nrest and rest_panels.nnz == plan.nnz and \
+            _ffi.lib().spamd_sddmm_has_panels(code_of(a.dtype), Kd):
+        _sddmm_panels_into(rest_panels, s_orig, s_data, a, bt, out)
+    elif nrest:
         sub = torch.empty(nrest, dtype=torch.float32, device=dev)
         rr, cc, ss = gather(rows, plan.rest), gather(cols, plan.rest), gather(s_data, plan.rest)
         _ffi.call("spamd_sddmm", code_of(a.dtype), code_of(torch.float32), code_of(rr.dtype), nrest, ptr(rr), ptr(cc), ptr(ss),

@@ -10,6 +10,7 @@
 #include "common.h"
 #include <hip/hip_bf16.h>
 #include <stdlib.h>
+#include <algorithm>
 
 namespace spamd {
 
@@ -76,87 +77,174 @@ sddmm_kernel(int64_t nnz, const I* __restrict__ rows, const I* __restrict__ cols
   }
 }
 
-// Row-cached form for masks stored in row-major order (canonical COO / CSR order): a lane group walks a
-// CONTIGUOUS chunk of stored elements, so the A row of consecutive elements is usually the same one and stays
-// in registers (KS vectors per lane); only the Bt rows are gathered — half the L1 traffic of the kernel above,
-// which is what bounds it (2 * K * sizeof(in) bytes per element through a 64 B/clk/CU path).
-// K == LPN * KS * EPL exactly.  UNR elements are in flight; a batch that straddles a row change takes the
-// per-element path.  Any element order is correct; only row-major order is fast.
-template <typename TIN, typename TS, typename I, int LPN, int KS, int UNR>
-__global__ void __launch_bounds__(256)
-sddmm_rowcache_kernel(int64_t nnz, int64_t chunk, const I* __restrict__ rows, const I* __restrict__ cols,
-                      const TS* __restrict__ s_data, const TIN* __restrict__ A, int64_t lda,
-                      const TIN* __restrict__ Bt, int64_t ldb, TS* __restrict__ out) {
+typedef __bf16 sd_bf2 __attribute__((ext_vector_type(2)));
+
+// <a, b> over KS 16-byte vectors per lane.  bf16: v_dot2c_f32_bf16 (two products and the add per instruction, fp32
+// accumulate; no bf16 -> fp32 conversions); fp32/fp64: fused multiply-adds.
+template <typename TIN, typename VT, int KS>
+__device__ __forceinline__ typename Acc<TIN>::type sd_dot(const VT (&av)[KS], const VT (&bv)[KS]) {
   using ACC = typename Acc<TIN>::type;
   constexpr int EPL = 16 / (int)sizeof(TIN);
-  using VT = Vec<TIN, EPL>;
-  const int sub = (threadIdx.x & 63) % LPN;
-  const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPN;
-  const int64_t nbeg = group * chunk;
-  const int64_t nend = nbeg + chunk < nnz ? nbeg + chunk : nnz;
-  const int koff = sub * EPL;
-  int64_t cur = -1;
-  VT av[KS];
-  auto load_a = [&](int64_t r) {
-    const TIN* ar = A + r * lda + koff;
+  ACC acc = 0;
+  if constexpr (std::is_same<TIN, __hip_bfloat16>::value) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) av[s] = *reinterpret_cast<const VT*>(ar + s * LPN * EPL);
-  };
-  auto dot = [&](const VT (&bv)[KS]) {
-    ACC acc = 0;
+    for (int s = 0; s < KS; ++s) {
+      sd_bf2 a2[4], b2[4];
+      __builtin_memcpy(a2, &av[s], 16);
+      __builtin_memcpy(b2, &bv[s], 16);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_fdot2_f32_bf16(a2[e], b2[e], acc, false);
+    }
+  } else {
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
       for (int e = 0; e < EPL; ++e) acc = __builtin_fma(to_acc(av[s].v[e]), to_acc(bv[s].v[e]), acc);
-    return acc;
-  };
-  auto finish = [&](ACC acc, int64_t n) {
+  }
+  return acc;
+}
+
+template <int CTRL>
+__device__ __forceinline__ float sd_dpp(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+
+// Sum over the LPN (>= 16) lanes of a group, left in every lane.  fp32: the first 16 lanes in four DPP adds
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror), wider groups finish with shuffles.
+template <int LPN, typename ACC>
+__device__ __forceinline__ ACC sd_group_sum(ACC acc) {
+  static_assert(LPN >= 16, "a DPP row is 16 lanes");
+  if constexpr (sizeof(ACC) == 4) {
+    acc += sd_dpp<0xB1>(acc);
+    acc += sd_dpp<0x4E>(acc);
+    acc += sd_dpp<0x141>(acc);
+    acc += sd_dpp<0x140>(acc);
+#pragma unroll
+    for (int off = 16; off < LPN; off <<= 1) acc += __shfl_xor(acc, off, 64);
+  } else {
 #pragma unroll
     for (int off = LPN / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if (sub == 0) out[n] = (TS)((ACC)s_data[n] * acc);
-  };
-  // (all lane groups of a wave run the same number of iterations: __shfl_xor needs every lane of a group,
-  // and groups only differ in whether they have work left, which is uniform inside a group)
-  for (int64_t n0 = nbeg; n0 < nend; n0 += UNR) {
-    int64_t r[UNR];
-    const TIN* br[UNR];
-    bool same = true;
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const int64_t n = n0 + u < nend ? n0 + u : nend - 1;
-      r[u] = (int64_t)rows[n];
-      br[u] = Bt + (int64_t)cols[n] * ldb + koff;
-      same = same && r[u] == r[0];
-    }
-    VT bv[UNR][KS];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u)
-#pragma unroll
-      for (int s = 0; s < KS; ++s) bv[u][s] = *reinterpret_cast<const VT*>(br[u] + s * LPN * EPL);
-    if (same) {
-      if (r[0] != cur) {
-        cur = r[0];
-        load_a(cur);
-      }
-#pragma unroll
-      for (int u = 0; u < UNR; ++u)
-        if (n0 + u < nend) finish(dot(bv[u]), n0 + u);
+  }
+  return acc;
+}
+
+// Lane `U` of every 16-lane row -> all lanes of that row (v_mov_b32_dpp row_newbcast:U); wider groups go through a
+// shuffle.  4- and 8-byte values.
+template <int LPN, int U, typename T>
+__device__ __forceinline__ T sd_bcast(T x) {
+  static_assert(sizeof(T) == 4 || sizeof(T) == 8, "4- or 8-byte values");
+  if constexpr (LPN == 16) {
+    if constexpr (sizeof(T) == 4) {
+      return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x150 + U, 0xf, 0xf, false));
     } else {
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        if (r[u] != cur) {
-          cur = r[u];
-          load_a(cur);
-        }
-        if (n0 + u < nend) finish(dot(bv[u]), n0 + u);
-      }
+      const uint64_t b = __builtin_bit_cast(uint64_t, x);
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, 0x150 + U, 0xf, 0xf, false);
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), 0x150 + U, 0xf, 0xf, false);
+      return __builtin_bit_cast(T, ((uint64_t)hi << 32) | lo);
+    }
+  } else {
+    return __shfl(x, U, LPN);
+  }
+}
+
+// Elements U0 .. U0+3 of a step (see sddmm_rowcache_kernel): the four Bt rows are requested first, then each element
+// is finished in turn; the A row is (re)loaded only when the element's row differs from the one in registers.
+template <typename TIN, typename I, int LPN, int KS, int U0>
+__device__ __forceinline__ void sd_batch4(int cnt, int sub, I myrow, I mycol, const char* Ab, const char* Bb,
+                                          int64_t lda_b, int64_t ldb_b, int64_t koff_b, I& cur,
+                                          Vec<TIN, 16 / (int)sizeof(TIN)> (&av)[KS], typename Acc<TIN>::type& res) {
+  using ACC = typename Acc<TIN>::type;
+  using VT = Vec<TIN, 16 / (int)sizeof(TIN)>;
+  constexpr int64_t step_b = (int64_t)LPN * 16;
+  VT bv[4][KS];
+  I r[4];
+#define SD_LOAD(k)                                                                                            \
+  {                                                                                                           \
+    const I c = sd_bcast<LPN, U0 + k>(mycol);                                                                 \
+    r[k] = sd_bcast<LPN, U0 + k>(myrow);                                                                      \
+    const char* bp = Bb + ((int64_t)c * ldb_b + koff_b);                                                      \
+    _Pragma("unroll") for (int s = 0; s < KS; ++s) bv[k][s] = *reinterpret_cast<const VT*>(bp + s * step_b); \
+  }
+  SD_LOAD(0) SD_LOAD(1) SD_LOAD(2) SD_LOAD(3)
+#undef SD_LOAD
+#define SD_DOT(k)                                                                                             \
+  if (U0 + k < cnt) {                                                                                         \
+    if (r[k] != cur) {                                                                                        \
+      cur = r[k];                                                                                             \
+      const char* ap = Ab + ((int64_t)cur * lda_b + koff_b);                                                  \
+      _Pragma("unroll") for (int s = 0; s < KS; ++s) av[s] = *reinterpret_cast<const VT*>(ap + s * step_b);  \
+    }                                                                                                         \
+    const ACC t = sd_group_sum<LPN>(sd_dot<TIN, VT, KS>(av, bv[k]));                                          \
+    res = sub == U0 + k ? t : res;                                                                            \
+  }
+  SD_DOT(0) SD_DOT(1) SD_DOT(2) SD_DOT(3)
+#undef SD_DOT
+}
+
+template <typename TIN, typename I, int LPN, int KS, int U0>
+struct SdStep {
+  template <typename... Args>
+  static __device__ __forceinline__ void run(int cnt, Args&... args) {
+    if constexpr (U0 < LPN) {
+      if (U0 < cnt) sd_batch4<TIN, I, LPN, KS, U0>(cnt, args...);
+      SdStep<TIN, I, LPN, KS, U0 + 4>::run(cnt, args...);
+    }
+  }
+};
+
+// Row-cached form for masks stored in row-major order (canonical COO / CSR order): a lane group walks a
+// CONTIGUOUS chunk of stored elements LPN at a time.  Lane u of the group loads element u's row, column, mask value
+// (and output position) - one coalesced load per array and step - and the group then takes the elements one after the
+// other: row/column are broadcast across the group (DPP), the A row of consecutive elements is usually the same one
+// and stays in registers (KS vectors per lane), so only the Bt rows are gathered (UNR of them in flight); the group's
+// sum lands in lane u, and ONE store per step writes the LPN results.  K == LPN * KS * EPL exactly.  Any element
+// order is correct; only row-major order is fast.
+//
+// PERM (column-panel order, see spamd_sddmm_panels): rows/cols/s_data are given in an order that walks the mask one
+// panel of Bt rows at a time (row-major inside a panel), `perm[n]` is the element's position in out, and every lane
+// group takes ONE short chunk: the workgroups resident at any moment - handed out in order - then cover one contiguous
+// window of that order, so the panel's Bt rows (a few MB) stay in every XCD's L2 instead of being fetched from the
+// Infinity Cache for each element.
+template <typename TIN, typename TS, typename I, int LPN, int KS, int UNR, bool PERM>
+__global__ void __launch_bounds__(256)
+sddmm_rowcache_kernel(int64_t nnz, int64_t chunk, const I* __restrict__ rows, const I* __restrict__ cols,
+                      const TS* __restrict__ s_data, const TIN* __restrict__ A, int64_t lda,
+                      const TIN* __restrict__ Bt, int64_t ldb, TS* __restrict__ out, const int64_t* __restrict__ perm) {
+  using ACC = typename Acc<TIN>::type;
+  constexpr int EPL = 16 / (int)sizeof(TIN);
+  using VT = Vec<TIN, EPL>;
+  static_assert(UNR == 4 && LPN % UNR == 0, "whole batches of four per step");
+  const int sub = (threadIdx.x & 63) % LPN;
+  const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPN;
+  const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / LPN;
+  const char* const Ab = reinterpret_cast<const char*>(A);
+  const char* const Bb = reinterpret_cast<const char*>(Bt);
+  const int64_t lda_b = lda * (int64_t)sizeof(TIN), ldb_b = ldb * (int64_t)sizeof(TIN);
+  const int64_t koff_b = (int64_t)sub * 16;
+  I cur = (I)-1;
+  VT av[KS];
+  for (int64_t cbeg = group * chunk; cbeg < nnz; cbeg += ngroups * chunk) {
+    const int64_t cend = cbeg + chunk < nnz ? cbeg + chunk : nnz;
+    for (int64_t nbeg = cbeg; nbeg < cend; nbeg += LPN) {
+      const int cnt = (int)(cend - nbeg < LPN ? cend - nbeg : LPN);  // uniform inside the group
+      const bool mine = sub < cnt;
+      const int64_t nl = nbeg + (mine ? sub : 0);
+      const I myrow = rows[nl], mycol = cols[nl];
+      const TS mys = s_data[nl];
+      int64_t mypos = nl;
+      if constexpr (PERM) mypos = perm[nl];
+      ACC res = 0;
+      int lane_in_group = sub;
+      SdStep<TIN, I, LPN, KS, 0>::run(cnt, lane_in_group, myrow, mycol, Ab, Bb, lda_b, ldb_b, koff_b, cur, av, res);
+      if (mine) out[mypos] = (TS)((ACC)mys * res);
     }
   }
 }
 
 template <typename TIN, typename TS, typename I>
 static int launch_sddmm(int64_t nnz, const I* rows, const I* cols, const TS* s, const TIN* A, int64_t lda,
-                        const TIN* Bt, int64_t ldb, int64_t K, TS* out, hipStream_t st) {
+                        const TIN* Bt, int64_t ldb, int64_t K, TS* out, hipStream_t st, const int64_t* perm = nullptr,
+                        int64_t perm_chunk = 0) {
   constexpr int EPL = 16 / (int)sizeof(TIN);
   const int64_t vecs = K / EPL;
   int lpn = 4;
@@ -165,8 +253,12 @@ static int launch_sddmm(int64_t nnz, const I* rows, const I* cols, const TS* s, 
   // in flight (0.86 ms), fp32/fp64 rows with four (1.44 ms vs 1.54 ms)
   {
     // row-cached kernel: K must be LPN * KS vectors exactly (KS <= 4); try 16 lanes per element first
-    const char* v = getenv("SPAMD_SDDMM_VARIANT");  // tuning hook: "0" = gather kernel only
+#ifdef SPAMD_TUNING
+    const char* v = getenv("SPAMD_SDDMM_VARIANT");  // tuning hook (-DSPAMD_TUNING builds only): "0" = gather kernel only
     const bool allow = !(v && v[0] == '0');
+#else
+    constexpr bool allow = true;
+#endif
     for (int L = 16; allow && L <= 64; L <<= 1) {
       if (vecs % L) continue;
       const int ks = (int)(vecs / L);
@@ -174,19 +266,30 @@ static int launch_sddmm(int64_t nnz, const I* rows, const I* cols, const TS* s, 
       constexpr int U = 4;
       const int64_t groups_wanted = 256 * 16 * (256 / L);  // 16 workgroups per CU
       int64_t chunk = ceil_div(nnz, groups_wanted);
-      chunk = ceil_div(chunk, (int64_t)U) * U;
-      const int64_t groups = ceil_div(nnz, chunk);
+      chunk = ceil_div(chunk, (int64_t)L) * L;  // whole steps of L elements
+      if (perm) {
+        const int64_t want = perm_chunk > 0 ? ceil_div(perm_chunk, (int64_t)L) * L : (int64_t)L;
+        if (chunk > want) chunk = want;
+      }
+      // (column-panel order: one chunk per lane group, so that the workgroups resident at any moment - handed out in
+      // order - cover one contiguous window of the element order, however unevenly they progress)
+      const int64_t groups = perm ? ceil_div(nnz, chunk) : std::min(ceil_div(nnz, chunk), groups_wanted);
       const int64_t blocks = ceil_div(groups * L, (int64_t)256);
+#define SDL(LL, KK, PP)                                                                                       \
+  hipLaunchKernelGGL((sddmm_rowcache_kernel<TIN, TS, I, LL, KK, U, PP>), dim3((unsigned)blocks), dim3(256), 0, st, \
+                     nnz, chunk, rows, cols, s, A, lda, Bt, ldb, out, perm)
 #define SDR(LL, KK)                                                                                           \
   if (L == LL && ks == KK) {                                                                                  \
-    hipLaunchKernelGGL((sddmm_rowcache_kernel<TIN, TS, I, LL, KK, U>), dim3((unsigned)blocks), dim3(256), 0, st, \
-                       nnz, chunk, rows, cols, s, A, lda, Bt, ldb, out);                                      \
+    if (perm) SDL(LL, KK, true);                                                                              \
+    else SDL(LL, KK, false);                                                                                  \
     return launch_status();                                                                                   \
   }
       SDR(16, 1) SDR(16, 2) SDR(16, 4) SDR(32, 1) SDR(32, 2) SDR(32, 4) SDR(64, 1) SDR(64, 2) SDR(64, 4)
 #undef SDR
+#undef SDL
     }
   }
+  if (perm) return SPAMD_EINVAL;  // the panel order exists for the row-cached kernel only
   constexpr int UNR = sizeof(TIN) >= 4 ? 4 : 1;
   int64_t blocks = ceil_div(ceil_div(nnz, UNR) * lpn, 256);
   if (blocks > 256 * 16) blocks = 256 * 16;
@@ -206,9 +309,63 @@ static int launch_sddmm(int64_t nnz, const I* rows, const I* cols, const TS* s, 
 
 using namespace spamd;
 
+template <typename I>
+__global__ void sddmm_panel_keys_kernel(int64_t nnz, const I* __restrict__ cols, int64_t width, int64_t* __restrict__ keys) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < nnz) keys[n] = (int64_t)cols[n] / width;
+}
+
+// keys[n] = cols[n] / width: the column panel of each stored element (stable sort by it = panel order).
+extern "C" int spamd_sddmm_panel_keys(int idx_dtype, int64_t nnz, const void* cols, int64_t width, void* keys,
+                                      void* stream) {
+  if (nnz < 0 || width < 1) return SPAMD_EINVAL;
+  if (nnz == 0) return 0;
+  SPAMD_DISPATCH_IDX(idx_dtype, I, {
+    hipLaunchKernelGGL((sddmm_panel_keys_kernel<I>), dim3((unsigned)ceil_div(nnz, (int64_t)256)), dim3(256), 0,
+                       (hipStream_t)stream, nnz, (const I*)cols, width, (int64_t*)keys);
+    return launch_status();
+  })
+  return SPAMD_ETYPE;
+}
+
+static int sddmm_entry(int in_dtype, int s_dtype, int idx_dtype, int64_t nnz, const void* rows, const void* cols,
+                       const void* s_data, const void* A, int64_t lda, const void* Bt, int64_t ldb, int64_t K,
+                       void* out, void* stream, const int64_t* perm, int64_t perm_chunk);
+
 extern "C" int spamd_sddmm(int in_dtype, int s_dtype, int idx_dtype, int64_t nnz, const void* rows, const void* cols,
                            const void* s_data, const void* A, int64_t lda, const void* Bt, int64_t ldb, int64_t K,
                            void* out, void* stream) {
+  return sddmm_entry(in_dtype, s_dtype, idx_dtype, nnz, rows, cols, s_data, A, lda, Bt, ldb, K, out, stream, nullptr, 0);
+}
+
+// 1 when K elements of in_dtype have a row-cached kernel (what spamd_sddmm_panels needs), else 0.
+extern "C" int spamd_sddmm_has_panels(int in_dtype, int64_t K) {
+  const int esz = in_dtype == SPAMD_BF16 ? 2 : (in_dtype == SPAMD_F32 ? 4 : (in_dtype == SPAMD_F64 ? 8 : 0));
+  if (!esz || K <= 0 || (K * esz) % 16) return 0;
+  const int64_t vecs = K * esz / 16;
+  for (int L = 16; L <= 64; L <<= 1) {
+    if (vecs % L) continue;
+    const int64_t ks = vecs / L;
+    if (ks == 1 || ks == 2 || ks == 4) return 1;
+  }
+  return 0;
+}
+
+// Column-panel order: rows_p/cols_p/s_p are the mask's coordinates and values gathered by `perm` (the stable sort of
+// spamd_sddmm_panel_keys); out stays in the mask's own order: out[perm[n]] = s_p[n] * <A[rows_p[n]], Bt[cols_p[n]]>.
+// `chunk` = elements a lane group takes at a time (<= 0: the default).  SPAMD_EINVAL when K has no row-cached kernel
+// (use spamd_sddmm).
+extern "C" int spamd_sddmm_panels(int in_dtype, int s_dtype, int idx_dtype, int64_t nnz, const void* rows_p,
+                                  const void* cols_p, const int64_t* perm, const void* s_p, const void* A, int64_t lda,
+                                  const void* Bt, int64_t ldb, int64_t K, int64_t chunk, void* out, void* stream) {
+  if (!perm) return SPAMD_EINVAL;
+  return sddmm_entry(in_dtype, s_dtype, idx_dtype, nnz, rows_p, cols_p, s_p, A, lda, Bt, ldb, K, out, stream, perm,
+                     chunk);
+}
+
+static int sddmm_entry(int in_dtype, int s_dtype, int idx_dtype, int64_t nnz, const void* rows, const void* cols,
+                       const void* s_data, const void* A, int64_t lda, const void* Bt, int64_t ldb, int64_t K,
+                       void* out, void* stream, const int64_t* perm, int64_t perm_chunk) {
   if (nnz < 0 || K < 0) return SPAMD_EINVAL;
   if (nnz == 0) return 0;
   if (((uintptr_t)A % 16) || ((uintptr_t)Bt % 16)) return SPAMD_EINVAL;
@@ -220,13 +377,13 @@ extern "C" int spamd_sddmm(int in_dtype, int s_dtype, int idx_dtype, int64_t nnz
     const I* c = (const I*)cols;
     if (in_dtype == SPAMD_BF16 && s_dtype == SPAMD_F32)
       return launch_sddmm<__hip_bfloat16, float, I>(nnz, r, c, (const float*)s_data, (const __hip_bfloat16*)A, lda,
-                                                    (const __hip_bfloat16*)Bt, ldb, K, (float*)out, st);
+                                                    (const __hip_bfloat16*)Bt, ldb, K, (float*)out, st, perm, perm_chunk);
     if (in_dtype == SPAMD_F32 && s_dtype == SPAMD_F32)
       return launch_sddmm<float, float, I>(nnz, r, c, (const float*)s_data, (const float*)A, lda, (const float*)Bt,
-                                           ldb, K, (float*)out, st);
+                                           ldb, K, (float*)out, st, perm, perm_chunk);
     if (in_dtype == SPAMD_F64 && s_dtype == SPAMD_F64)
       return launch_sddmm<double, double, I>(nnz, r, c, (const double*)s_data, (const double*)A, lda,
-                                             (const double*)Bt, ldb, K, (double*)out, st);
+                                             (const double*)Bt, ldb, K, (double*)out, st, perm, perm_chunk);
   })
   return SPAMD_ETYPE;
 }

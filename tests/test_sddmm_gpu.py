@@ -119,3 +119,122 @@ def test_sddmm_uniform_mask_stays_on_the_sampled_kernel():
     assert K.sddmm_coo_mfma(plan, s.coords, s.shape, s.data, at, bt) is None
     r = sp.sddmm(s, at, bt=bt)
     assert torch.equal(r.data, K.sddmm_coo(s.coords, s.data, at, bt))
+
+
+def _mask(rng, M, N, nnz, idx=np.int32):
+    lin = np.sort(rng.choice(M * N, nnz, replace=False))
+    return np.stack([lin // N, lin % N]).astype(idx), lin
+
+
+@pytest.mark.parametrize("dt,Kd", [("bf16", 128), ("bf16", 256), ("bf16", 512), ("f32", 64), ("f32", 256), ("f64", 64), ("f64", 256)])
+@pytest.mark.parametrize("idx", [np.int32, np.int64])
+def test_sddmm_column_panel_order_is_bit_identical(dt, Kd, idx):
+    """spamd_sddmm_panels walks the mask one panel of Bt rows at a time; every stored element is computed by the same
+    lanes in the same order as in the mask's own order, so the two results are equal bit for bit - for ragged sizes
+    (nnz not a multiple of the step), several panel widths and chunk lengths, and for a subset of the elements."""
+    from sparse_amd import _kernels as K
+
+    rng = np.random.default_rng(Kd)
+    M, N, nnz = 700, 5000, 60_013
+    coords_h, _ = _mask(rng, M, N, nnz, idx)
+    tdt = {"bf16": torch.bfloat16, "f32": torch.float32, "f64": torch.float64}[dt]
+    at = (torch.rand((M, Kd), device="cuda", dtype=torch.float64) - 0.5).to(tdt)
+    bt = (torch.rand((N, Kd), device="cuda", dtype=torch.float64) - 0.5).to(tdt)
+    coords = torch.from_numpy(coords_h).cuda()
+    sval = (torch.rand(nnz, device="cuda", dtype=torch.float64) - 0.5).to(torch.float64 if dt == "f64" else torch.float32)
+    ref = K.sddmm_coo(coords, sval, at, bt)
+    for width in (64, 1000, 4999, 5000):
+        plan = K.sddmm_panels(coords, (M, N), width)
+        # the order really is panel-major, row-major inside a panel, and `pos` is a permutation
+        pc = plan.cols.cpu().numpy().astype(np.int64) // width
+        assert np.all(np.diff(pc) >= 0)
+        pos = plan.pos.cpu().numpy()
+        assert np.array_equal(np.sort(pos), np.arange(nnz))
+        inside = np.diff(pc) == 0
+        assert np.all(np.diff(pos)[inside] > 0)
+        for chunk in (0, 16, 48, 1000):
+            plan.chunk = chunk
+            assert torch.equal(K.sddmm_coo(coords, sval, at, bt, panels=plan), ref), (width, chunk)
+    # a subset of the elements, written into a caller-provided result
+    subset = torch.from_numpy(np.sort(rng.choice(nnz, 20_001, replace=False))).cuda()
+    plan = K.sddmm_panels(coords, (M, N), 300, subset=subset)
+    out = torch.full((nnz,), -7.0, dtype=ref.dtype, device="cuda")
+    K._sddmm_panels_into(plan, sval, sval, at, bt, out)
+    keep = torch.zeros(nnz, dtype=torch.bool, device="cuda")
+    keep[subset] = True
+    assert torch.equal(out[keep], ref[keep]) and bool((out[~keep] == -7.0).all())
+
+
+def test_sddmm_product_path_uses_panels_and_follows_the_mask(monkeypatch):
+    """`sparse_amd.sddmm` builds the panel plan once per mask (COO, or the kept COO view of a GCXS mask), re-gathers the
+    mask values when they change in place, drops the plan when the coordinates' container is replaced, and its result
+    matches the float64 evaluation of the reference's formulation."""
+    import sparse_amd as sp
+    from sparse_amd import _kernels as K
+
+    monkeypatch.setattr(K, "SDDMM_PANEL_MIN_NNZ", 1000)
+    monkeypatch.setattr(K, "SDDMM_PANEL_BYTES", 64 * 256 * 2)   # 64 Bt rows per panel
+    rng = np.random.default_rng(11)
+    M, N, Kd, nnz = 500, 3000, 256, 40_000
+    coords_h, _ = _mask(rng, M, N, nnz)
+    sval = (rng.random(nnz) - 0.5).astype(np.float32)
+    at = (torch.rand((M, Kd), device="cuda") - 0.5).to(torch.bfloat16)
+    bt = (torch.rand((N, Kd), device="cuda") - 0.5).to(torch.bfloat16)
+    a64, b64 = at.double().cpu().numpy(), bt.double().cpu().numpy()
+    dots = np.einsum("ik,ik->i", a64[coords_h[0]], b64[coords_h[1]])
+    absd = np.einsum("ik,ik->i", np.abs(a64[coords_h[0]]), np.abs(b64[coords_h[1]]))
+
+    def check(r, values):
+        got = r.todense()[coords_h[0], coords_h[1]]
+        assert np.all(np.abs(got - values.astype(np.float64) * dots) <= 2e-6 * np.abs(values) * absd + 1e-300)
+
+    s = sp.COO(coords_h, sval, shape=(M, N))
+    check(sp.sddmm(s, at, bt=bt), sval)
+    plans = s._sddmm_plan
+    key = ("panels", "all", 64)
+    assert key in plans and plans[key].count == nnz
+    first = plans[key]
+    check(sp.sddmm(s, at, bt=bt), sval)
+    assert s._sddmm_plan[key] is first            # built once
+    s.data.mul_(2.0)                               # in-place change of the mask values: new result, no stale values
+    check(sp.sddmm(s, at, bt=bt), 2 * sval)
+    g = sp.GCXS.from_numpy(s.todense(), compressed_axes=(0,)) if False else s.asformat("gcxs", compressed_axes=(0,))
+    r = sp.sddmm(g, at, bt=bt)
+    assert isinstance(r, sp.GCXS)
+    check(r, 2 * sval)
+    view = g._coo_view
+    sp.sddmm(g, at, bt=bt)
+    assert g._coo_view is view and key in view._sddmm_plan
+
+
+def test_sddmm_mfma_rest_in_panel_order(monkeypatch):
+    """Per-tile dispatch with the left-over samples taken in column-panel order: equal, element for element, to the
+    dispatch with the left-over samples in the mask's own order."""
+    import sparse_amd as sp
+    from sparse_amd import _kernels as K
+
+    rng = np.random.default_rng(3)
+    M = N = 2048
+    Kd = 128
+    tiles = rng.choice((M // 32) * (N // 32), 300, replace=False)
+    pos = np.argsort(rng.random((300, 1024)), axis=1)[:, :600]
+    r = (tiles // (N // 32))[:, None] * 32 + pos // 32
+    c = (tiles % (N // 32))[:, None] * 32 + pos % 32
+    lin = np.unique(np.concatenate([(r.astype(np.int64) * N + c).ravel(), rng.choice(M * N, 50_000, replace=False)]))
+    coords_h = np.stack([lin // N, lin % N]).astype(np.int32)
+    s = sp.COO(coords_h, (rng.random(lin.size) - 0.5).astype(np.float32), shape=(M, N))
+    at = (torch.rand((M, Kd), device="cuda") - 0.5).to(torch.bfloat16)
+    bt = (torch.rand((N, Kd), device="cuda") - 0.5).to(torch.bfloat16)
+    plan = K.sddmm_plan(s.coords, s.shape)
+    assert plan.tiles.numel() > 0 and plan.rest.numel() > 1000
+    plain = K.sddmm_coo_mfma(plan, s.coords, s.shape, s.data, at, bt, force=True)
+    restp = K.sddmm_panels(s.coords, s.shape, 100, subset=plan.rest)
+    paneled = K.sddmm_coo_mfma(plan, s.coords, s.shape, s.data, at, bt, force=True, rest_panels=restp)
+    assert torch.equal(plain, paneled)
+    # and through the product entry point with the thresholds lowered so that both plans are used
+    monkeypatch.setattr(K, "SDDMM_PANEL_MIN_NNZ", 1000)
+    monkeypatch.setattr(K, "SDDMM_PANEL_BYTES", 100 * Kd * 2)
+    out = sp.sddmm(s, at, bt=bt)
+    assert ("panels", "rest", 100) in s._sddmm_plan
+    want = np.where(plain.cpu().numpy() == 0, 0, plain.cpu().numpy())
+    assert np.array_equal(out.todense()[coords_h[0], coords_h[1]], want)

@@ -48,7 +48,7 @@ s4 = sp.random((M4, N4), nnz=10_000_000, random_state=1, dtype=np.float32, idx_d
 a4 = (torch.rand((M4, Kd), device=dev) - 0.5).to(torch.bfloat16)
 b4 = (torch.rand((N4, Kd), device=dev) - 0.5).to(torch.bfloat16)
 t0 = time.time(); sp.sddmm(s4, a4, bt=b4); torch.cuda.synchronize(); first = (time.time() - t0) * 1e3
-p = s4._sddmm_plan
+p = s4._sddmm_plan[("tiles", K.SDDMM_TILE_THRESHOLD)]
 t_auto = timeit(lambda: K.sddmm_coo_mfma(p, s4.coords, s4.shape, s4.data, a4, b4) or K.sddmm_coo(s4.coords, s4.data, a4, b4))
 t_samp = timeit(lambda: K.sddmm_coo(s4.coords, s4.data, a4, b4))
 print(f"config 4 (uniform 0.1 %): dense tiles {p.tiles.numel()}, samples in them {p.n_dense_samples}; dispatcher {t_auto:.3f} ms, "
@@ -62,7 +62,7 @@ c = (tiles % (N4 // 32))[:, None] * 32 + pos % 32
 lin = np.unique(np.concatenate([(r.astype(np.int64) * N4 + c).ravel(), rng.choice(M4 * N4, 3_000_000, replace=False)]))
 sc = sp.COO(np.stack([lin // N4, lin % N4]).astype(np.int32), rng.random(lin.size).astype(np.float32), shape=(M4, N4))
 sp.sddmm(sc, a4, bt=b4)
-p = sc._sddmm_plan
+p = sc._sddmm_plan[("tiles", K.SDDMM_TILE_THRESHOLD)]
 t_auto = timeit(lambda: K.sddmm_coo_mfma(p, sc.coords, sc.shape, sc.data, a4, b4))
 t_samp = timeit(lambda: K.sddmm_coo(sc.coords, sc.data, a4, b4))
 flops_dense = 2.0 * p.tiles.numel() * 32 * 32 * Kd
