@@ -199,12 +199,12 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
             ms_rm, r_rm = timed(lambda: K.sddmm_coo(s.coords, s.data, a, bt))
             width = K.sddmm_panel_width(bt)
             t0 = time.perf_counter()
-            panels = K.sddmm_panels(s.coords, s.shape, width) if width else None
+            panels = K.sddmm_panels(s.coords, s.shape, width) if K.sddmm_panels_pay(nnz4, a, bt, width) else None
             torch.cuda.synchronize()
             plan_ms = (time.perf_counter() - t0) * 1e3
             ms, r = timed(lambda: K.sddmm_coo(s.coords, s.data, a, bt, panels=panels))
             same = bool(torch.equal(r, r_rm))
-            ms_api, _ = timed(lambda: sp.sddmm(s, a, bt=bt))
+            ms_api, _ = timed(lambda: sp.sddmm(s, a, bt=bt), reps=10, warm=10)  # (a one-off ~40 ms host stall shows up within the first calls of a process)
             b = nnz4 * (2 * 4 + 4) + 2 * Ms * 256 * esz + nnz4 * 4
             ha, hb = a[hrow].to(torch.float64).cpu().numpy(), bt[hcol].to(torch.float64).cpu().numpy()
             wv, leg = cpu_leg(lambda: hs * np.einsum("ik,ik->i", ha, hb),
@@ -316,8 +316,9 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
 
 def _sddmm_mfma_rows(sp, K, s, Ms, emit):
     """A9 with per-tile dispatch between the sampled kernel and the bf16 matrix-core tile kernel (csrc/sddmm_mfma.hip):
-    config 4's uniform mask (no tile qualifies: the dispatcher must cost nothing) and a block-clustered mask of the
-    same size (70 % of the samples in 32 x 32 tiles filled at 50 %), each checked on 20000 samples in float64."""
+    config 4's uniform mask (no tile qualifies: the dispatcher must cost nothing), a block-clustered mask of the
+    same size (70 % of the samples in 32 x 32 tiles filled at 50 %) and a block-sparse mask (all samples in full
+    32 x 32 tiles), each checked on 20000 samples in float64.  The sampled kernel beside it runs in its best order."""
     dev = s.device
     a = (torch.rand((Ms, 256), device=dev) - 0.5).to(torch.bfloat16)
     bt = (torch.rand((Ms, 256), device=dev) - 0.5).to(torch.bfloat16)
@@ -330,15 +331,22 @@ def _sddmm_mfma_rows(sp, K, s, Ms, emit):
     c = (tiles % (Ms // 32))[:, None] * 32 + pos % 32
     lin = np.unique(np.concatenate([(r.astype(np.int64) * Ms + c).ravel(), rng.choice(Ms * Ms, nnz - nt * 512, replace=False)]))
     clustered = sp.COO(np.stack([lin // Ms, lin % Ms]).astype(np.int32), rng.random(lin.size).astype(np.float32), shape=(Ms, Ms))
-    for tag, mask in (("uniform", s), ("clustered", clustered)):
+    nb = nnz // 1024
+    btiles = rng.choice((Ms // 32) ** 2, nb, replace=False)
+    full = np.arange(1024)
+    lin_b = np.sort((((btiles // (Ms // 32))[:, None] * 32 + full // 32).astype(np.int64) * Ms
+                     + (btiles % (Ms // 32))[:, None] * 32 + full % 32).ravel())
+    blocks = sp.COO(np.stack([lin_b // Ms, lin_b % Ms]).astype(np.int32), rng.random(lin_b.size).astype(np.float32), shape=(Ms, Ms))
+    for tag, mask in (("uniform", s), ("clustered", clustered), ("blocks", blocks)):
         plan = K.sddmm_plan(mask.coords, mask.shape)
         width = K.sddmm_panel_width(bt)
-        allp = K.sddmm_panels(mask.coords, mask.shape, width) if width else None
-        restp = (K.sddmm_panels(mask.coords, mask.shape, width, subset=plan.rest)
-                 if width and int(plan.rest.numel()) >= K.SDDMM_PANEL_MIN_NNZ else None)
-        f = lambda: (K.sddmm_coo_mfma(plan, mask.coords, mask.shape, mask.data, a, bt, rest_panels=restp)
-                     if plan.n_dense_samples >= K.SDDMM_MFMA_MIN_SHARE * plan.nnz
-                     else K.sddmm_coo(mask.coords, mask.data, a, bt, panels=allp))
+        allp = K.sddmm_panels(mask.coords, mask.shape, width) if K.sddmm_panels_pay(mask.nnz, a, bt, width) else None
+        nrest = int(plan.rest.numel())
+        rw = width if K.sddmm_panels_pay(nrest, a, bt, width) else Ms   # one panel = the mask's own order
+        restp = K.sddmm_panels(mask.coords, mask.shape, rw, subset=plan.rest) if nrest else None
+        tiles_pay = K.sddmm_tiles_pay(plan, a, bt, width)
+        f = lambda: (K.sddmm_coo_mfma(plan, mask.coords, mask.shape, mask.data, a, bt, force=True, rest_panels=restp)
+                     if tiles_pay else K.sddmm_coo(mask.coords, mask.data, a, bt, panels=allp))
         ms, got = timed(f)
         ms_s, _ = timed(lambda: K.sddmm_coo(mask.coords, mask.data, a, bt, panels=allp))
         ms_rm, _ = timed(lambda: K.sddmm_coo(mask.coords, mask.data, a, bt))
@@ -354,7 +362,7 @@ def _sddmm_mfma_rows(sp, K, s, Ms, emit):
             f"SDDMM, per-tile dispatch, {tag} mask COO({Ms}x{Ms}, {mask.nnz} nnz), bf16 K=256: {ntile} tiles "
             f"({plan.n_dense_samples} samples) on v_mfma_f32_32x32x16_bf16, the rest sampled", ms,
             mask.nnz * 16 + 4 * Ms * 256, flops=2.0 * 256 * mask.nnz, sampled_kernel_ms=ms_s, speedup_vs_sampled=ms_s / ms,
-            sampled_row_major_ms=ms_rm,
+            sampled_row_major_ms=ms_rm, dispatcher_chose="tiles + sampled rest" if tiles_pay else "sampled only",
             dense_tiles=ntile, tile_product_TFLOPs=2.0 * ntile * 32 * 32 * 256 / ms / 1e9 if ntile else 0.0,
             max_err_over_sum_abs_terms=err))
 

@@ -61,7 +61,7 @@ def sddmm(s, a, b=None, *, bt=None):
     # plans depend on the pattern only and are kept on the mask (dropped with its other derived layouts when the
     # coordinates change): the populated 32 x 32 tiles that go to the matrix cores, and - when Bt is larger than an
     # XCD's L2 - the column-panel order of whatever the sampled kernel takes
-    width = K.sddmm_panel_width(btt) if sc.nnz >= K.SDDMM_PANEL_MIN_NNZ else 0
+    width = K.sddmm_panel_width(btt)
     plans = sc.__dict__.setdefault("_sddmm_plan", {})
 
     def panels_of(subset, tag):
@@ -76,11 +76,21 @@ def sddmm(s, a, b=None, *, bt=None):
         if key not in plans:
             plans[key] = K.sddmm_plan(sc.coords, sc.shape)
         plan = plans[key]
-        if plan.n_dense_samples >= K.SDDMM_MFMA_MIN_SHARE * plan.nnz:
-            rest = panels_of(plan.rest, "rest") if width and int(plan.rest.numel()) >= K.SDDMM_PANEL_MIN_NNZ else None
-            vals = K.sddmm_coo_mfma(plan, sc.coords, sc.shape, sc.data, at, btt, rest_panels=rest)
+        if K.sddmm_tiles_pay(plan, at, btt, width):
+            # the left-over samples: in panel order if that pays for so many, else as ONE panel (= the mask's own order;
+            # either way their coordinates are gathered once, here, and the kernel writes to their positions)
+            nrest = int(plan.rest.numel())
+            rest = None
+            if nrest and K.sddmm_has_panels(at.dtype, at.shape[1]):
+                rw = width if K.sddmm_panels_pay(nrest, at, btt, width) else builtins.max(int(sc.shape[1]), 1)
+                key = ("panels", "rest", rw)
+                if key not in plans:
+                    plans[key] = K.sddmm_panels(sc.coords, sc.shape, rw, subset=plan.rest)
+                rest = plans[key]
+            vals = K.sddmm_coo_mfma(plan, sc.coords, sc.shape, sc.data, at, btt, force=True, rest_panels=rest)
     if vals is None:
-        vals = K.sddmm_coo(sc.coords, sc.data, at, btt, panels=panels_of(None, "all") if width else None)
+        vals = K.sddmm_coo(sc.coords, sc.data, at, btt,
+                           panels=panels_of(None, "all") if K.sddmm_panels_pay(sc.nnz, at, btt, width) else None)
     out = COO(sc.coords, vals, shape=s.shape, has_duplicates=False, sorted=True, prune=True)
     return out.asformat("gcxs", compressed_axes=s.compressed_axes) if out_gcxs else out
 

@@ -717,7 +717,8 @@ def dot_coo_coo(out_shape, a_coords, b_coords, a_data, b_data, n_inner):
 
 
 SDDMM_PANEL_BYTES = 3 << 20     # Bt rows of one column panel: what stays in a 4 MiB L2 next to the streamed operands
-SDDMM_PANEL_MIN_NNZ = 1 << 20   # below this the sort of the plan and the scattered output cost more than they save
+SDDMM_PANEL_MIN_NNZ = 1 << 18   # below this the kernel is launch-bound either way
+SDDMM_PANEL_GAIN = 0.75         # share of a gathered Bt row that the panel order saves (the rest: scattered output, streams)
 
 
 class SddmmPanels:
@@ -736,15 +737,52 @@ class SddmmPanels:
         return self._vals
 
 
+def sddmm_has_panels(dtype, Kd):
+    """Does spamd_sddmm_panels have a kernel for rows of `Kd` elements of `dtype`?"""
+    return dtype in (torch.bfloat16, torch.float32, torch.float64) and bool(_ffi.lib().spamd_sddmm_has_panels(code_of(dtype), int(Kd)))
+
+
 def sddmm_panel_width(bt):
     """Bt rows per panel, or 0 when Bt fits the L2 as a whole or its K has no row-cached kernel (no panel order)."""
     row_bytes = int(bt.shape[1]) * bt.element_size()
     if row_bytes == 0 or int(bt.shape[0]) * row_bytes <= SDDMM_PANEL_BYTES:
         return 0
-    if bt.dtype not in (torch.bfloat16, torch.float32, torch.float64) or \
-            not _ffi.lib().spamd_sddmm_has_panels(code_of(bt.dtype), int(bt.shape[1])):
+    if not sddmm_has_panels(bt.dtype, bt.shape[1]):
         return 0
     return max(SDDMM_PANEL_BYTES // row_bytes, 64)
+
+
+def sddmm_panels_pay(n, a, bt, width):
+    """Column-panel order or the mask's own order for `n` stored elements?  In the mask's order every element fetches
+    its Bt row (K * itemsize bytes) through the fabric; in panel order the Bt rows come from the L2, but A is streamed
+    once per panel and Bt once per XCD, whatever n is (measured at config 4's shapes: 10^7 elements 0.40 vs 0.70 ms,
+    3 * 10^6 elements 0.33 vs 0.21 ms)."""
+    if not width or n < SDDMM_PANEL_MIN_NNZ:
+        return False
+    row_bytes = int(bt.shape[1]) * bt.element_size()
+    panels = -(-int(bt.shape[0]) // int(width))
+    fixed = panels * int(a.shape[0]) * row_bytes + 8 * int(bt.shape[0]) * row_bytes
+    return n * row_bytes * SDDMM_PANEL_GAIN > fixed
+
+
+SDDMM_TILE_EQUIV = 410      # a 32 x 32 tile product costs what the sampled kernel spends on this many samples INSIDE a dense tile
+SDDMM_REST_PENALTY = 2.5    # left-over samples per sample gained that the split may cost (they leave the panel order)
+
+
+def sddmm_tiles_pay(plan, a, bt, width):
+    """Dense tiles on the matrix cores + the rest sampled, or everything sampled?  Measured at K = 256 bf16
+    (tools/sddmm_crossover.py, bench_paths A9_mfma_*): a tile product takes ~9 ns whatever the tile holds, the sampled
+    kernel ~0.022 ns per sample inside a dense tile (A and Bt rows are shared), so the tiles gain
+    n_dense - 410 * ntiles samples' worth of time; the left-over samples, run on their own, cost ~0.10 instead of
+    ~0.045 ns each when the whole mask would have taken the panel order (both scale with the row length alike)."""
+    ntiles = int(plan.tiles.numel())
+    gain = plan.n_dense_samples - SDDMM_TILE_EQUIV * ntiles
+    if ntiles == 0 or gain <= 0:
+        return False
+    nrest = int(plan.rest.numel())
+    if sddmm_panels_pay(plan.nnz, a, bt, width) and not sddmm_panels_pay(nrest, a, bt, width):
+        return gain > SDDMM_REST_PENALTY * nrest
+    return True
 
 
 def sddmm_panels(coords, shape, width, subset=None):
@@ -801,8 +839,7 @@ def sddmm_coo(coords, s_data, a, bt, panels=None):
     if not index_dtype_ok(rows):
         rows, cols = rows.to(torch.int64), cols.to(torch.int64)
     out = torch.empty(nnz, dtype=sdt, device=dev)
-    if panels is not None and nnz and panels.nnz == nnz and panels.count == nnz and \
-            _ffi.lib().spamd_sddmm_has_panels(code_of(a.dtype), int(a.shape[1])):
+    if panels is not None and nnz and panels.nnz == nnz and panels.count == nnz and sddmm_has_panels(a.dtype, a.shape[1]):
         _sddmm_panels_into(panels, s_orig, s_data, a, bt, out)
         return out
     _ffi.call("spamd_sddmm", code_of(a.dtype), code_of(sdt), code_of(rows.dtype), nnz, ptr(rows), ptr(cols),
@@ -810,8 +847,8 @@ def sddmm_coo(coords, s_data, a, bt, panels=None):
     return out
 
 
-SDDMM_TILE_THRESHOLD = 48      # samples per 32 x 32 mask tile from which the matrix-core tile product is the cheaper one (measured crossover ~40: tools/sddmm_crossover.py, profiles/r02_sddmm_crossover.txt)
-SDDMM_MFMA_MIN_SHARE = 0.05    # below this share of samples in dense tiles the plain sampled kernel takes everything
+SDDMM_TILE_THRESHOLD = 512     # samples per 32 x 32 mask tile from which the matrix-core tile product is clearly the cheaper one (tools/sddmm_crossover.py, profiles/r02_sddmm_crossover.txt: 1.5x at 512, 2.3x at 1024, break-even ~150 against the panel-order sampled kernel but ~400 against the sampled kernel on a dense tile)
+SDDMM_MFMA_MIN_SHARE = 0.05    # (sddmm_coo_mfma without `force`) below this share of samples in dense tiles it declines
 
 
 class SddmmPlan:
@@ -882,7 +919,7 @@ def sddmm_coo_mfma(plan, coords, shape, s_data, a, bt, out=None, force=False, re
               ptr(a), a.stride(0), ptr(bt), bt.stride(0), Kd, ptr(out), s)
     nrest = int(plan.rest.numel())
     if nrest and rest_panels is not None and rest_panels.count == nrest and rest_panels.nnz == plan.nnz and \
-            _ffi.lib().spamd_sddmm_has_panels(code_of(a.dtype), Kd):
+            sddmm_has_panels(a.dtype, Kd):
         _sddmm_panels_into(rest_panels, s_orig, s_data, a, bt, out)
     elif nrest:
         sub = torch.empty(nrest, dtype=torch.float32, device=dev)

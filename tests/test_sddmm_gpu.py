@@ -58,7 +58,7 @@ def _clustered_mask(rng, M, N, n_blocks, block_density, sprinkle):
 
 @pytest.mark.parametrize("shape_k", [((2048, 2048), 256), ((1000, 777), 48), ((70, 3000), 16), ((513, 515), 400)])
 @pytest.mark.parametrize("idx", ["int32", "int64"])
-def test_sddmm_dense_tiles_on_the_matrix_cores(shape_k, idx):
+def test_sddmm_dense_tiles_on_the_matrix_cores(shape_k, idx, monkeypatch):
     """Populated tiles run as bf16 MFMA tile products, the rest through the sampled kernel; both against the fp64
     evaluation of the reference formulation `s * (a @ b)` within 4e-6 * sum |terms| (fp32 accumulation of exact bf16
     products; the matrix core adds 16 products at a time), and against each other within the same bound."""
@@ -95,7 +95,9 @@ def test_sddmm_dense_tiles_on_the_matrix_cores(shape_k, idx):
     # the samples left to the sampled kernel are bit-identical to the all-sampled result
     rest = plan.rest.cpu().numpy()
     assert np.array_equal(got.cpu().numpy()[rest], sampled.cpu().numpy()[rest])
-    # product entry point: same values, plan cached on the mask
+    # product entry point (told that the tiles pay: at these sizes its traffic model says they do not): same values,
+    # plan cached on the mask
+    monkeypatch.setattr(K, "sddmm_tiles_pay", lambda plan, a, bt, width: True)
     r = sp.sddmm(s, at, bt=bt)
     assert getattr(s, "_sddmm_plan", None) is not None
     assert np.array_equal(r.todense()[coords[0], coords[1]], np.where(g == 0, 0, got.cpu().numpy()))
@@ -172,7 +174,7 @@ def test_sddmm_product_path_uses_panels_and_follows_the_mask(monkeypatch):
     import sparse_amd as sp
     from sparse_amd import _kernels as K
 
-    monkeypatch.setattr(K, "SDDMM_PANEL_MIN_NNZ", 1000)
+    monkeypatch.setattr(K, "sddmm_panels_pay", lambda n, a, bt, width: bool(width))   # (the traffic model would keep so small a mask in its own order)
     monkeypatch.setattr(K, "SDDMM_PANEL_BYTES", 64 * 256 * 2)   # 64 Bt rows per panel
     rng = np.random.default_rng(11)
     M, N, Kd, nnz = 500, 3000, 256, 40_000
@@ -232,9 +234,50 @@ def test_sddmm_mfma_rest_in_panel_order(monkeypatch):
     paneled = K.sddmm_coo_mfma(plan, s.coords, s.shape, s.data, at, bt, force=True, rest_panels=restp)
     assert torch.equal(plain, paneled)
     # and through the product entry point with the thresholds lowered so that both plans are used
-    monkeypatch.setattr(K, "SDDMM_PANEL_MIN_NNZ", 1000)
+    monkeypatch.setattr(K, "sddmm_panels_pay", lambda n, a, bt, width: bool(width))
+    monkeypatch.setattr(K, "sddmm_tiles_pay", lambda plan, a, bt, width: True)
     monkeypatch.setattr(K, "SDDMM_PANEL_BYTES", 100 * Kd * 2)
     out = sp.sddmm(s, at, bt=bt)
     assert ("panels", "rest", 100) in s._sddmm_plan
     want = np.where(plain.cpu().numpy() == 0, 0, plain.cpu().numpy())
     assert np.array_equal(out.todense()[coords_h[0], coords_h[1]], want)
+
+
+def test_sddmm_panel_order_traffic_model():
+    """The choice between the two element orders follows the traffic model: config 4's 10^7 samples take the panel
+    order, 3 * 10^6 samples of the same shapes (what the dense-tile dispatch leaves over on a clustered mask) and any
+    operand that fits the L2 keep the mask's own order."""
+    from sparse_amd import _kernels as K
+
+    a = torch.empty((100_000, 256), dtype=torch.bfloat16, device="cuda")
+    bt = torch.empty((100_000, 256), dtype=torch.bfloat16, device="cuda")
+    w = K.sddmm_panel_width(bt)
+    assert w == (3 << 20) // 512
+    assert K.sddmm_panels_pay(10_000_000, a, bt, w)
+    assert not K.sddmm_panels_pay(3_000_000, a, bt, w)
+    small = torch.empty((4096, 256), dtype=torch.bfloat16, device="cuda")
+    assert K.sddmm_panel_width(small) == 0 and not K.sddmm_panels_pay(10_000_000, a, small, 0)
+    odd = torch.empty((100_000, 200), dtype=torch.bfloat16, device="cuda")   # no row-cached kernel for K = 200
+    assert K.sddmm_panel_width(odd) == 0
+
+
+def test_sddmm_tile_dispatch_traffic_model():
+    """Dense tiles + sampled rest vs everything sampled, by the traffic model: a block-sparse mask (full tiles) takes
+    the matrix cores, a uniform mask does not."""
+    from sparse_amd import _kernels as K
+
+    rng = np.random.default_rng(0)
+    M = N = 16384
+    a = torch.empty((M, 256), dtype=torch.bfloat16, device="cuda")
+    bt = torch.empty((N, 256), dtype=torch.bfloat16, device="cuda")
+    tiles = rng.choice((M // 32) * (N // 32), 2000, replace=False)
+    full = np.arange(1024)
+    lin = np.sort((((tiles // (N // 32))[:, None] * 32 + full // 32).astype(np.int64) * N + (tiles % (N // 32))[:, None] * 32 + full % 32).ravel())
+    coords = torch.from_numpy(np.stack([lin // N, lin % N]).astype(np.int32)).cuda()
+    plan = K.sddmm_plan(coords, (M, N))
+    assert plan.tiles.numel() == 2000 and plan.rest.numel() == 0
+    assert K.sddmm_tiles_pay(plan, a, bt, K.sddmm_panel_width(bt))
+    lin = np.sort(rng.choice(M * N, 2_000_000, replace=False))
+    coords = torch.from_numpy(np.stack([lin // N, lin % N]).astype(np.int32)).cuda()
+    plan = K.sddmm_plan(coords, (M, N))
+    assert plan.tiles.numel() == 0 and not K.sddmm_tiles_pay(plan, a, bt, K.sddmm_panel_width(bt))

@@ -19,7 +19,12 @@ c = (tiles % (Ms // 32))[:, None] * 32 + pos % 32
 lin = np.unique(np.concatenate([(r.astype(np.int64) * Ms + c).ravel(), rng.choice(Ms * Ms, nnz - nt * 512, replace=False)]))
 mask = sp.COO(np.stack([lin // Ms, lin % Ms]).astype(np.int32), rng.random(lin.size).astype(np.float32), shape=(Ms, Ms))
 plan = K.sddmm_plan(mask.coords, mask.shape)
+w = K.sddmm_panel_width(bt)
+restp = K.sddmm_panels(mask.coords, mask.shape, w, subset=plan.rest)
+allp = K.sddmm_panels(mask.coords, mask.shape, w)
 for _ in range(5):
-    K.sddmm_coo_mfma(plan, mask.coords, mask.shape, mask.data, a, bt)
+    K.sddmm_coo_mfma(plan, mask.coords, mask.shape, mask.data, a, bt, force=True, rest_panels=restp)
+for _ in range(5):
+    K.sddmm_coo(mask.coords, mask.data, a, bt, panels=allp)
 torch.cuda.synchronize()
 print("dense tiles", int(plan.tiles.numel()), "samples in them", plan.n_dense_samples)
