@@ -236,7 +236,11 @@ sddmm_rowcache_kernel(int64_t nnz, int64_t chunk, const I* __restrict__ rows, co
       ACC res = 0;
       int lane_in_group = sub;
       SdStep<TIN, I, LPN, KS, 0>::run(cnt, lane_in_group, myrow, mycol, Ab, Bb, lda_b, ldb_b, koff_b, cur, av, res);
-      if (mine) out[mypos] = (TS)((ACC)mys * res);
+      if (mine) {
+        const TS v = (TS)((ACC)mys * res);
+        if constexpr (PERM) __builtin_nontemporal_store(v, out + mypos);  // scattered: keep these lines from displacing the Bt panel in L2
+        else out[mypos] = v;
+      }
     }
   }
 }

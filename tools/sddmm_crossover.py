@@ -74,5 +74,6 @@ allp = K.sddmm_panels(sc.coords, sc.shape, w4)
 t_auto = timeit(lambda: K.sddmm_coo_mfma(p, sc.coords, sc.shape, sc.data, a4, b4, force=True, rest_panels=restp))
 t_samp = timeit(lambda: K.sddmm_coo(sc.coords, sc.data, a4, b4, panels=allp))
 flops_dense = 2.0 * p.tiles.numel() * 32 * 32 * Kd
-print(f"clustered mask ({lin.size} samples, {p.tiles.numel()} dense tiles holding {p.n_dense_samples}): dispatcher {t_auto:.3f} ms "
+print(f"clustered mask ({lin.size} samples, {p.tiles.numel()} dense tiles holding {p.n_dense_samples}; sddmm_tiles_pay says "
+      f"{K.sddmm_tiles_pay(p, a4, b4, w4)}): tiles forced + sampled rest {t_auto:.3f} ms "
       f"({flops_dense / t_auto * 1e-9:.1f} TFLOP/s of tile products), sampled kernel alone (panel order) {t_samp:.3f} ms -> {t_samp / t_auto:.2f}x")
