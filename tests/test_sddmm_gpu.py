@@ -128,7 +128,8 @@ def _mask(rng, M, N, nnz, idx=np.int32):
     return np.stack([lin // N, lin % N]).astype(idx), lin
 
 
-@pytest.mark.parametrize("dt,Kd", [("bf16", 128), ("bf16", 256), ("bf16", 512), ("f32", 64), ("f32", 256), ("f64", 64), ("f64", 256)])
+@pytest.mark.parametrize("dt,Kd", [("bf16", 128), ("bf16", 256), ("bf16", 512), ("bf16", 2048), ("f32", 64), ("f32", 256), ("f32", 512),
+                                   ("f64", 64), ("f64", 256), ("f64", 512)])   # 16-, 32- and 64-lane groups, 1 / 2 / 4 vectors per lane
 @pytest.mark.parametrize("idx", [np.int32, np.int64])
 def test_sddmm_column_panel_order_is_bit_identical(dt, Kd, idx):
     """spamd_sddmm_panels walks the mask one panel of Bt rows at a time; every stored element is computed by the same
@@ -145,6 +146,12 @@ def test_sddmm_column_panel_order_is_bit_identical(dt, Kd, idx):
     coords = torch.from_numpy(coords_h).cuda()
     sval = (torch.rand(nnz, device="cuda", dtype=torch.float64) - 0.5).to(torch.float64 if dt == "f64" else torch.float32)
     ref = K.sddmm_coo(coords, sval, at, bt)
+    # (the row-cached kernel itself against the float64 evaluation, for every group width)
+    a64, b64 = at.double().cpu().numpy(), bt.double().cpu().numpy()
+    ch = coords_h.astype(np.int64)
+    want = sval.double().cpu().numpy() * np.einsum("ik,ik->i", a64[ch[0]], b64[ch[1]])
+    absum = np.abs(sval.double().cpu().numpy()) * np.einsum("ik,ik->i", np.abs(a64[ch[0]]), np.abs(b64[ch[1]]))
+    assert np.all(np.abs(ref.double().cpu().numpy() - want) <= (1e-14 if dt == "f64" else 2e-6) * absum + 1e-300)
     for width in (64, 1000, 4999, 5000):
         plan = K.sddmm_panels(coords, (M, N), width)
         # the order really is panel-major, row-major inside a panel, and `pos` is a permutation
