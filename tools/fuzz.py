@@ -1,6 +1,7 @@
 """Randomised cross-checks of kernels that exist in two forms (run on the GPU box):
    tiled vs row-group SpMM (bit-identical, both arithmetic modes, fp32/fp64), single-pass vs two-pass merge,
-   row-local vs global SpGEMM, grouped reduce vs a float64 scatter-add.   python tools/fuzz.py [seconds]"""
+   row-local vs global SpGEMM, grouped reduce vs a float64 scatter-add, SDDMM in column-panel order vs the mask's own
+   order (and vs float64).   python tools/fuzz.py [seconds]"""
 import sys, time, numpy as np, torch
 sys.path.insert(0, "/root/repo")
 import sparse_amd as sp
@@ -11,7 +12,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 ONLY_SPMM = len(sys.argv) > 2 and sys.argv[2] == "spmm"   # with PYTORCH_NO_CUDA_MEMORY_CACHING=1: catches reads past a buffer
 rng = np.random.default_rng(int(time.time()))
 t_end = time.time() + budget
-n = {"spmm": 0, "merge": 0, "spgemm": 0, "reduce": 0}
+n = {"spmm": 0, "merge": 0, "spgemm": 0, "reduce": 0, "sddmm": 0}
 while time.time() < t_end:
     # ---- SpMM
     M = int(rng.choice([1, 31, 513, 5000, 70001, 200000]))
@@ -69,5 +70,32 @@ while time.time() < t_end:
     assert torch.equal(c1.indptr.long(), c2.indptr.long()) and torch.equal(c1.indices.long(), c2.indices.long()) \
         and torch.equal(c1.data, c2.data), ("spgemm", ng, dg)
     n["spgemm"] += 1
+    # ---- SDDMM: column-panel order (also of a subset) vs the mask's own order, bit for bit; both vs float64
+    Ms, Ns = int(rng.integers(1, 3000)), int(rng.integers(1, 6000))
+    Ks = int(rng.choice([16, 64, 128, 200, 256, 512]))
+    sdt = [torch.bfloat16, torch.float32, torch.float64][int(rng.integers(0, 3))]
+    ns = int(min(Ms * Ns, rng.integers(0, 400_000)))
+    m = sp.random((Ms, Ns), nnz=ns, random_state=int(rng.integers(1 << 30)), dtype=np.float64 if sdt == torch.float64 else np.float32,
+                  idx_dtype=np.int32 if rng.random() < 0.5 else np.int64)
+    at = (torch.rand((Ms, Ks), device="cuda", dtype=torch.float64) - 0.5).to(sdt)
+    btt = (torch.rand((Ns, Ks), device="cuda", dtype=torch.float64) - 0.5).to(sdt)
+    ref = K.sddmm_coo(m.coords, m.data, at, btt)
+    if ns:
+        cl = m.coords.long()
+        want = m.data.double() * (at.double()[cl[0]] * btt.double()[cl[1]]).sum(dim=1)
+        bound = m.data.double().abs() * (at.double()[cl[0]].abs() * btt.double()[cl[1]].abs()).sum(dim=1)
+        assert bool(((ref.double() - want).abs() <= (1e-14 if sdt == torch.float64 else 2e-6) * bound + 1e-300).all()), ("sddmm", Ms, Ns, Ks, sdt)
+    if ns and K.sddmm_has_panels(sdt, Ks):
+        width = int(rng.integers(1, Ns + 1))
+        pl = K.sddmm_panels(m.coords, m.shape, width)
+        pl.chunk = int(rng.choice([0, 16, 100]))
+        assert torch.equal(K.sddmm_coo(m.coords, m.data, at, btt, panels=pl), ref), ("sddmm panels", Ms, Ns, Ks, sdt, width)
+        sub = torch.nonzero(torch.rand(ns, device="cuda") < 0.3).reshape(-1)
+        if sub.numel():
+            pl = K.sddmm_panels(m.coords, m.shape, width, subset=sub)
+            out = torch.zeros_like(ref)
+            K._sddmm_panels_into(pl, m.data, m.data.to(ref.dtype), at, btt, out)
+            assert torch.equal(out[sub], ref[sub]), ("sddmm subset", Ms, Ns, Ks, sdt, width)
+    n["sddmm"] += 1
 torch.cuda.synchronize()
 print("fuzz ok:", n)
