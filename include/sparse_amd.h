@@ -42,6 +42,7 @@ extern "C" {
 #define SPAMD_EWS (-3)     /* workspace too small */
 
 /* flags */
+#define SPAMD_TILED_GROUP_ENDS 2u /* spamd_spmm_tiled: blk_off has tiles + 1 entries per row group (spamd_spmm_tiled_inspect) */
 #define SPAMD_EXACT_MULADD 1u /* separate IEEE mul + add (bit-exact vs the reference's
                                  non-contracted loop) instead of fused multiply-add */
 
@@ -106,9 +107,12 @@ int spamd_spmm_tiled_count(int val_dtype, int idx_dtype, int64_t M, int64_t K, c
 int spamd_spmm_tiled_fill(int val_dtype, int idx_dtype, int64_t M, int64_t K, const void* a_data, const void* a_indices,
                           const void* a_indptr, const int64_t* blk_off, int64_t total_blocks, int* blocks,
                           void* stream);
-/* one-pass form of count + scan + fill (decoupled look-back over the row groups): blk_off int32[lists + 1]; `blocks` has
- * room for ceil(nnz / entries_per_block) + lists + slack_blocks blocks; state = groups + 2 64-bit words of workspace;
- * state[groups + 1] != 0 afterwards: unsorted column indices, outputs invalid (use the key-sort recipe) */
+/* one-pass form of count + fill: every row group's first block follows from the row pointers alone (an upper bound of what
+ * the groups before it need: no scan, no dependence between groups), so blk_off is int32[groups * (tiles + 1)] — per group
+ * the first block of each of its lists and the end of the last one; pass SPAMD_TILED_GROUP_ENDS to spamd_spmm_tiled with
+ * it.  `blocks` has room for ceil(nnz / entries_per_block) + lists + slack_blocks blocks (the blocks between groups are
+ * zeroed); state = one 64-bit word; state[0] != 0 afterwards: unsorted column indices, outputs invalid (use the key-sort
+ * recipe) */
 int spamd_spmm_tiled_inspect(int val_dtype, int idx_dtype, int64_t M, int64_t K, const void* a_data, const void* a_indices,
                              const void* a_indptr, void* state, int* blk_off, int* blocks, void* stream);
 int spamd_spmm_tiled_keys(int64_t nnz, const int64_t* rowcol_keys, int64_t K, int64_t* tiled_keys, void* stream);

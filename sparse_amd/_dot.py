@@ -375,7 +375,7 @@ def _validate_derived(a):
         a.__dict__["_derived_stamp"] = st
 
 
-def prepare_spmm(a, dtype=None):
+def prepare_spmm(a, dtype=None, force_sort=False):
     """Build (and cache on `a`) the tiled block stream used by `a @ dense` for value type `dtype` (default: a's own
     if float32/float64); returns True if `a` now has one.  The counterpart of the reference's memoised conversions
     (`COO(cache=True)`, _coo/core.py:317-338)."""
@@ -391,8 +391,22 @@ def prepare_spmm(a, dtype=None):
     layouts = a.__dict__.setdefault("_tiled_layouts", {})
     if dtype not in layouts:
         d, i, p = _csr_triplet(a)
-        layouts[dtype] = K.csr_tiled_layout(d, i, p, int(a.shape[0]), int(a.shape[1]), dtype=dtype)
+        layouts[dtype] = K.csr_tiled_layout(d, i, p, int(a.shape[0]), int(a.shape[1]), dtype=dtype, force_sort=force_sort,
+                                            defer_check=True)
     return True
+
+
+def _tiled_product(a, dt, out_shape, Kd, b):
+    """Executor product from `a`'s cached layout.  The one-pass inspector's "unsorted column indices" verdict is read
+    behind the first product's launch (no host wait between inspector and executor); if it says unsorted — rows whose
+    column indices do not ascend, which no constructor of this package produces — the layout is rebuilt by the key-sort
+    recipe and the product repeated."""
+    try:
+        return K.dot_csr_ndarray_tiled(a._tiled_layouts[dt], out_shape, Kd, b, exact=_settings.EXACT_MULADD)
+    except K.UnsortedColumns:
+        del a._tiled_layouts[dt]
+        prepare_spmm(a, dt, force_sort=True)
+        return K.dot_csr_ndarray_tiled(a._tiled_layouts[dt], out_shape, Kd, b, exact=_settings.EXACT_MULADD)
 
 
 def _csr_triplet(a):
@@ -443,9 +457,9 @@ def _gcxs_times_dense(a, bt, out_shape):
             npad = -(-N // panel) * panel
             bp = torch.zeros((Kd, npad), dtype=dt, device=bt.device)
             bp[:, :N] = bt
-            res = K.dot_csr_ndarray_tiled(a._tiled_layouts[dt], (M, npad), Kd, bp, exact=_settings.EXACT_MULADD)
+            res = _tiled_product(a, dt, (M, npad), Kd, bp)
             return res[:, :N].contiguous()
-        return K.dot_csr_ndarray_tiled(a._tiled_layouts[dt], out_shape, Kd, bt, exact=_settings.EXACT_MULADD)
+        return _tiled_product(a, dt, out_shape, Kd, bt)
     return K.dot_csr_ndarray(out_shape, data, indices, indptr, bt, exact=_settings.EXACT_MULADD)
 
 

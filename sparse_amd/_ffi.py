@@ -16,6 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sparse_amd.h")
 F32, F64, I32, I64, BF16, U8 = 0, 1, 2, 3, 4, 5
 MAX_NDIM = 16
 EXACT_MULADD = 1
+TILED_GROUP_ENDS = 2
 
 _lib = None
 

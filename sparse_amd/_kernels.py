@@ -950,21 +950,32 @@ TILED_ONE_PASS_INSPECTOR = True   # False: the two-pass builder (count, scan, fi
 
 class TiledLayout(tuple):
     """(blocks, blk_off, value dtype) + `mean_blocks` = mean 64-byte blocks per (row group, tile) list, which the
-    launcher turns into the executor's prefetch width without reading anything back from the device"""
+    launcher turns into the executor's prefetch width without reading anything back from the device, + `group_ends`:
+    blk_off holds tiles + 1 entries per row group (the one-pass inspector's form) instead of one running array"""
 
-    def __new__(cls, blocks, blk_off, dtype, mean_blocks):
+    def __new__(cls, blocks, blk_off, dtype, mean_blocks, group_ends=False, pending=None):
         self = super().__new__(cls, (blocks, blk_off, dtype))
         self.mean_blocks = mean_blocks
+        self.group_ends = group_ends
+        self.pending = pending   # device word of a one-pass layout whose "unsorted column indices" verdict was not read yet
         return self
 
 
-def csr_tiled_layout(a_data, a_indices, a_indptr, M, Kd, force_sort=False, dtype=None):
+class UnsortedColumns(ValueError):
+    """A one-pass tiled layout built with `defer_check=True` turned out to come from rows with unsorted column indices:
+    the layout (and the product just computed from it) is invalid; rebuild with `force_sort=True`."""
+
+
+def csr_tiled_layout(a_data, a_indices, a_indptr, M, Kd, force_sort=False, dtype=None, defer_check=False):
     """Inspector: the K-tiled block stream of a CSR matrix used by `dot_csr_ndarray_tiled`, for float32 or float64
     values (`dtype`, default: a_data's if it is one of them, else float32).
     Returns (blocks int32[(total_blocks + slack) * 16], blk_off int32[nseg + 1], value dtype).
-    Sorted column indices and a moderate K take the direct one-pass builder (count + look-back scan + fill in one
-    launch; the stream is then allocated for its upper bound and `blocks` is longer than `blk_off[-1] + slack` blocks);
-    anything else the general key-sort recipe."""
+    Sorted column indices and a moderate K take the direct one-pass builder (count + fill in one launch, row groups
+    independent of each other; the stream is then allocated for its upper bound, groups start at closed-form offsets
+    with zeroed blocks between them, and blk_off is int32[groups * (tiles + 1)]: `TiledLayout.group_ends`);
+    anything else the general key-sort recipe.  The one-pass builder reports unsorted column indices in a device word;
+    with `defer_check` that word is not read here (no host wait between the inspector and the first product):
+    `dot_csr_ndarray_tiled` reads it after enqueueing its first product and raises `UnsortedColumns`."""
     dev = require_hip(a_data, a_indices, a_indptr)
     if dtype is None:
         dtype = a_data.dtype if a_data.dtype in TILED_DTYPES else torch.float32
@@ -986,22 +997,25 @@ def csr_tiled_layout(a_data, a_indices, a_indptr, M, Kd, force_sort=False, dtype
             raise ValueError("tiled SpMM layout: more than 2^31 blocks")
         blocks = torch.empty((total + slack) * 16, dtype=torch.int32, device=dev)
         fill(blk_off, total, blocks)
-        return blocks, convert(blk_off, torch.int32), dtype
+        return TiledLayout(blocks, convert(blk_off, torch.int32), dtype, total / max(nseg, 1))
 
     if ntiles <= direct_max and not force_sort and TILED_ONE_PASS_INSPECTOR:
-        # one pass over A (csrc/spmm_tiled.hip `tl_inspect_kernel`): count, scan (decoupled look-back over the row groups),
-        # fill and padding in a single launch; the stream is allocated for its upper bound, so nothing waits for a total
+        # one pass over A (csrc/spmm_tiled.hip `tl_inspect_kernel`): count, fill and padding in a single launch with no
+        # dependence between row groups (a group's first block is a closed-form upper bound from the row pointers); the
+        # stream is allocated for its upper bound, so nothing waits for a total
         ic = code_of(a_indices.dtype)
         ind, ptr_ = a_indices.contiguous(), a_indptr.contiguous()
         upper = -(-nnz // epb) + nseg
         if upper < 2 ** 31:
             blocks = torch.empty((upper + slack) * 16, dtype=torch.int32, device=dev)
-            blk_off = torch.empty(nseg + 1, dtype=torch.int32, device=dev)
-            state = torch.empty(groups + 2, dtype=torch.int64, device=dev)
+            blk_off = torch.empty(groups * (ntiles + 1), dtype=torch.int32, device=dev)
+            state = torch.empty(1, dtype=torch.int64, device=dev)
             _ffi.call("spamd_spmm_tiled_inspect", vc, ic, M, Kd, ptr(vals), ptr(ind), ptr(ptr_), ptr(state), ptr(blk_off),
                       ptr(blocks), s)
-            if int(state[groups + 1]) == 0:      # (sorted column indices everywhere)
-                return TiledLayout(blocks, blk_off, dtype, nnz / epb / max(nseg, 1) + 0.5)
+            if defer_check:
+                return TiledLayout(blocks, blk_off, dtype, nnz / epb / max(nseg, 1) + 0.5, group_ends=True, pending=state)
+            if int(state[0]) == 0:      # (sorted column indices everywhere)
+                return TiledLayout(blocks, blk_off, dtype, nnz / epb / max(nseg, 1) + 0.5, group_ends=True)
     elif ntiles <= direct_max and not force_sort:
         nblk = torch.empty(nseg + 1, dtype=torch.int64, device=dev)
         flags = torch.empty(1, dtype=torch.int32, device=dev)
@@ -1041,6 +1055,12 @@ def dot_csr_ndarray_tiled(layout, out_shape, Kd, b, out=None, exact=False):
     hint = min(64, max(6, int(1.5 * mean_blocks) + 3))
     if _TOUCH_OVERRIDE:
         hint = _TOUCH_OVERRIDE
+    ends = _ffi.TILED_GROUP_ENDS if getattr(layout, "group_ends", False) else 0
     _ffi.call("spamd_spmm_tiled", code_of(dtype), M, Kd, N, ptr(blocks), ptr(blk_off), ptr(b), N, ptr(out), N,
-              (_ffi.EXACT_MULADD if exact else 0) | (hint << 8), stream_ptr(dev))
+              (_ffi.EXACT_MULADD if exact else 0) | ends | (hint << 8), stream_ptr(dev))
+    pending = getattr(layout, "pending", None)
+    if pending is not None:   # first product of a layout built with defer_check: the verdict is read now, behind the launch
+        layout.pending = None
+        if int(pending[0]) != 0:
+            raise UnsortedColumns("tiled layout built from rows with unsorted column indices")
     return out

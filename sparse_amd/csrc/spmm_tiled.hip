@@ -67,8 +67,11 @@ struct TlFmt<float> {
   static constexpr int EPB = 8, PANEL = 128;
   __device__ static void put(int* stream, int64_t entry, int d0, float v) {
     int* b = stream + (entry / EPB) * TL_BLOCK_INTS + (entry % EPB) * 2;
-    b[0] = d0;
-    b[1] = __builtin_bit_cast(int, v);
+    typedef int int2v __attribute__((ext_vector_type(2)));
+    int2v e;
+    e.x = d0;
+    e.y = __builtin_bit_cast(int, v);
+    *reinterpret_cast<int2v*>(b) = e;   // (entries are 8-byte aligned: one store instead of two)
   }
 };
 template <>
@@ -80,8 +83,7 @@ struct TlFmt<double> {
     const long long bits = __builtin_bit_cast(long long, v);
     b[slot] = d0;
     if (slot == 0) b[5] = 0;   // (the unused dword of the block: written so that the stream is the same bytes whoever builds it)
-    b[6 + 2 * slot] = (int)(bits & 0xffffffffLL);
-    b[7 + 2 * slot] = (int)(bits >> 32);
+    *reinterpret_cast<long long*>(b + 6 + 2 * slot) = bits;   // (8-byte aligned: block + 24 + 8 * slot bytes)
   }
 };
 typedef int tl_srd_t __attribute__((ext_vector_type(4)));   // buffer descriptor of B (four SGPRs)
@@ -235,6 +237,10 @@ __global__ void __launch_bounds__(256) tl_fill_kernel(int64_t M, int ntiles, con
 // writes its slice of blk_off, fills its lists and zeroes their padding entries itself.  The stream is allocated for the
 // upper bound ceil(nnz / EPB) + lists (every list wastes less than one block).  state[groups] = ticket counter,
 // state[groups + 1] = "a row has unsorted column indices" (the caller then takes the key-sort recipe).
+__host__ __device__ inline int64_t tl_group_first_block(int64_t e0, int64_t g, int64_t ntiles, int64_t epb) {
+  return (e0 + g * ntiles * (epb - 1) + epb - 1) / epb;
+}
+
 template <typename I, typename T>
 __global__ void __launch_bounds__(256) tl_inspect_kernel(int64_t M, int ntiles, int64_t groups, const T* __restrict__ vals,
                                                          const I* __restrict__ indices, const I* __restrict__ indptr,
@@ -242,16 +248,13 @@ __global__ void __launch_bounds__(256) tl_inspect_kernel(int64_t M, int ntiles, 
                                                          int* __restrict__ stream) {
   extern __shared__ int tl_fill_lds[];  // before[RG][ntiles], runstart[RG][ntiles] (relative to e0), loff[ntiles + 1]
   __shared__ int64_t rs[TL_RG + 1];
-  __shared__ int64_t ticket_s, goff_s;
   __shared__ int wtot[5];
   constexpr int EPB = TlFmt<T>::EPB;
   int* const before = tl_fill_lds;
   int* const runstart = before + TL_RG * ntiles;
   int* const loff = runstart + TL_RG * ntiles;
   const int tid = threadIdx.x;
-  if (tid == 0) ticket_s = (int64_t)atomicAdd(&state[groups], 1ull);
-  __syncthreads();
-  const int64_t g = ticket_s;
+  const int64_t g = blockIdx.x;
   const int64_t r0 = g * TL_RG;
   if (tid <= TL_RG) {
     const int64_t r = r0 + tid;
@@ -261,20 +264,53 @@ __global__ void __launch_bounds__(256) tl_inspect_kernel(int64_t M, int ntiles, 
   __syncthreads();
   const int64_t e0 = rs[0], e1 = rs[TL_RG];
   bool bad = false;
-  // a wave per row (rows lane-strided): the row in the group is known without a bisection over the row starts
-  for (int lr = tid >> 6; lr < TL_RG; lr += 4) {
-    const int64_t ra = rs[lr], rb = rs[lr + 1];
-    for (int64_t e = ra + (tid & 63); e < rb; e += 64) {
-      const unsigned c = (unsigned)indices[e];          // (K <= 256 tiles x 160 columns: 32-bit arithmetic)
-      const int t = (int)(c / (unsigned)TL_KB);
-      atomicAdd(&before[lr * ntiles + t], 1);
-      const bool row_start = e == ra;
-      const unsigned cp = row_start ? 0u : (unsigned)indices[e - 1];
-      if (!row_start && cp > c) bad = true;
-      if (row_start || (int)(cp / (unsigned)TL_KB) != t) runstart[lr * ntiles + t] = (int)(e - e0);
+  // A wave per row (rows wave-strided: the row in the group is known without a bisection over the row starts).  The first
+  // TL_PRE * 64 elements of each of the wave's rows (column and value) are requested up front and stay in registers for
+  // the count AND the fill phase: one memory latency per workgroup instead of one per row and phase (a workgroup lives
+  // ~90 us when every row waits for its own loads: 1.26 -> see DESIGN.md).  Longer rows continue from memory.
+  constexpr int RPW = (TL_RG + 3) / 4;   // rows per wave
+  constexpr int TL_PRE = 2;
+  const int wv = tid >> 6, lane = tid & 63;
+  unsigned cpre[RPW][TL_PRE];
+  T vpre[RPW][TL_PRE];
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) {
+    const int lr = wv + 4 * i;
+    const int64_t ra = lr < TL_RG ? rs[lr] : 0, rb = lr < TL_RG ? rs[lr + 1] : 0;
+#pragma unroll
+    for (int p = 0; p < TL_PRE; ++p) {
+      const int64_t e = ra + lane + 64 * p;
+      cpre[i][p] = e < rb ? (unsigned)indices[e] : 0xffffffffu;
+      vpre[i][p] = e < rb ? vals[e] : T(0);
     }
   }
-  if (bad) atomicOr(&state[groups + 1], 1ull);
+  auto count_one = [&](int lr, int64_t ra, int64_t e, unsigned c, unsigned cp, bool row_start) {
+    const int t = (int)(c / (unsigned)TL_KB);
+    atomicAdd(&before[lr * ntiles + t], 1);
+    if (!row_start && cp > c) bad = true;
+    if (row_start || (int)(cp / (unsigned)TL_KB) != t) runstart[lr * ntiles + t] = (int)(e - e0);
+  };
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) {
+    const int lr = wv + 4 * i;
+    if (lr >= TL_RG) break;
+    const int64_t ra = rs[lr], rb = rs[lr + 1];
+#pragma unroll
+    for (int p = 0; p < TL_PRE; ++p) {
+      const int64_t e = ra + lane + 64 * p;
+      const unsigned c = cpre[i][p];
+      // the previous element's column: the lane below, or the last lane of the previous chunk
+      unsigned cp = (unsigned)__shfl_up((int)c, 1, 64);
+      if (p > 0) {
+        const unsigned last = (unsigned)__builtin_amdgcn_readlane((int)cpre[i][p > 0 ? p - 1 : 0], 63);
+        if (lane == 0) cp = last;
+      }
+      if (e < rb) count_one(lr, ra, e, c, cp, p == 0 && lane == 0);
+    }
+    for (int64_t e = ra + lane + 64 * TL_PRE; e < rb; e += 64)
+      count_one(lr, ra, e, (unsigned)indices[e], (unsigned)indices[e - 1], false);
+  }
+  if (bad) atomicOr(&state[0], 1ull);
   __syncthreads();
   // per tile: elements of the tile in earlier rows of the group; blocks of the list
   int nb = 0, cnt_t = 0;
@@ -292,7 +328,7 @@ __global__ void __launch_bounds__(256) tl_inspect_kernel(int64_t M, int ntiles, 
     nb = (run + EPB - 1) / EPB;
   }
   // exclusive scan of nb over the tiles (thread = tile)
-  const int lane = tid & 63, wid = tid >> 6;
+  const int wid = wv;
   int x = nb;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -305,25 +341,36 @@ __global__ void __launch_bounds__(256) tl_inspect_kernel(int64_t M, int ntiles, 
   for (int w = 0; w < wid; ++w) woff += wtot[w];
   const int gtotal = wtot[0] + wtot[1] + wtot[2] + wtot[3];
   const int my_off = woff + x - nb;
-  if (tid < 64) {   // wave 0 looks back
-    const unsigned long long excl = lookback_exclusive(state, g, (unsigned long long)gtotal, tid);
-    if (tid == 0) goff_s = (int64_t)excl;
-  }
+  // First block of this group, in closed form from the row pointers alone (no scan over the groups, no look-back): the
+  // groups before this one hold e0 elements in g * ntiles lists, and a list of c elements takes ceil(c / EPB) <=
+  // (c + EPB - 1) / EPB blocks, so they take at most (e0 + g * ntiles * (EPB - 1)) / EPB blocks.  Starting every group at
+  // that bound leaves a gap (zero-filled below) of less than one block per list in front of the next group; the lists of
+  // a group stay contiguous, and blk_off carries ntiles + 1 entries per group (the last one = end of its last list).
+  const int64_t goff = tl_group_first_block(e0, g, ntiles, EPB);
+  const int64_t gnext = tl_group_first_block(e1, g + 1, ntiles, EPB);
   if (tid < ntiles) loff[tid] = my_off;
   __syncthreads();
-  const int64_t goff = goff_s;
-  if (tid < ntiles) blk_off[g * ntiles + tid] = (int)(goff + my_off);
-  if (g == groups - 1 && tid == 0) blk_off[groups * ntiles] = (int)(goff + gtotal);
-  // fill (a wave per row again)
-  for (int lr = tid >> 6; lr < TL_RG; lr += 4) {
+  if (tid < ntiles) blk_off[g * (ntiles + 1) + tid] = (int)(goff + my_off);
+  if (tid == 0) blk_off[g * (ntiles + 1) + ntiles] = (int)(goff + gtotal);
+  for (int64_t i = (goff + gtotal) * TL_BLOCK_INTS + tid; i < gnext * TL_BLOCK_INTS; i += 256) stream[i] = 0;
+  // fill (a wave per row again; the preloaded elements come from registers)
+  auto fill_one = [&](int lr, int64_t e, unsigned c, T v) {
+    const int t = (int)(c / (unsigned)TL_KB);
+    const int lc = (int)(c - (unsigned)t * (unsigned)TL_KB);
+    const int64_t dst = (goff + loff[t]) * EPB + before[lr * ntiles + t] + ((int)(e - e0) - runstart[lr * ntiles + t]);
+    TlFmt<T>::put(stream, dst, tl_d0(lc, lr), v);
+  };
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) {
+    const int lr = wv + 4 * i;
+    if (lr >= TL_RG) break;
     const int64_t ra = rs[lr], rb = rs[lr + 1];
-    for (int64_t e = ra + (tid & 63); e < rb; e += 64) {
-      const unsigned c = (unsigned)indices[e];
-      const int t = (int)(c / (unsigned)TL_KB);
-      const int lc = (int)(c - (unsigned)t * (unsigned)TL_KB);
-      const int64_t dst = (goff + loff[t]) * EPB + before[lr * ntiles + t] + ((int)(e - e0) - runstart[lr * ntiles + t]);
-      TlFmt<T>::put(stream, dst, tl_d0(lc, lr), vals[e]);
+#pragma unroll
+    for (int p = 0; p < TL_PRE; ++p) {
+      const int64_t e = ra + lane + 64 * p;
+      if (e < rb) fill_one(lr, e, cpre[i][p], vpre[i][p]);
     }
+    for (int64_t e = ra + lane + 64 * TL_PRE; e < rb; e += 64) fill_one(lr, e, (unsigned)indices[e], vals[e]);
   }
   // padding entries of my list (zero d0 and value: they accumulate into the junk register pair)
   if (tid < ntiles) {
@@ -442,7 +489,10 @@ spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, int touch_lines, const int* 
   // (A further scalar-cache prefetch stage — dummy s_load_dword of the next list's lines — was measured
   // 9 % SLOWER: the scalar memory path takes ~20 cycles per 64-byte request and ~5 per dword request per
   // CU whether it hits or not (tools/micro/smem_lat.hip), so extra requests cost more than the latency they save.)
-  const int* const myoff = blk_off + g * (int64_t)ntiles;
+  // (bits 16.. of `touch_lines`: 1 = blk_off holds ntiles + 1 entries per group — each group's own end — instead of
+  // one running array in which a group ends where the next one starts: the one-pass inspector's layout)
+  const int* const myoff = blk_off + g * (int64_t)(ntiles + (touch_lines >> 16));
+  touch_lines &= 0xffff;
   const int toff = (lane < touch_lines ? lane : touch_lines - 1) * 64;  // byte offset of the line this lane touches
   int t = 0;
   while (t < ntiles) {
@@ -616,10 +666,11 @@ static int tl_launch_inspect(int64_t M, int64_t ntiles, const T* a_data, const I
   return launch_status();
 }
 
-// One-pass inspector for CSR with sorted column indices and at most `direct_max_tiles` tiles: fills blk_off[lists + 1]
-// (int32) and the block stream, which must have room for ceil(nnz / entries_per_block) + lists + slack blocks;
-// state = (groups + 2) zero-initialised 64-bit words of workspace (zeroed here); on return state[groups + 1] != 0 means a
-// row with unsorted column indices was met: the outputs are then garbage and the caller takes the key-sort recipe.
+// One-pass inspector for CSR with sorted column indices and at most `direct_max_tiles` tiles: fills
+// blk_off[groups * (tiles + 1)] (int32: per row group its tiles' first blocks and the end of its last list — pass
+// SPAMD_TILED_GROUP_ENDS to spamd_spmm_tiled) and the block stream, which must have room for
+// ceil(nnz / entries_per_block) + lists + slack blocks; state = one 64-bit word (zeroed here); on return state[0] != 0
+// means a row with unsorted column indices was met: the outputs are then garbage and the caller takes the key-sort recipe.
 extern "C" int spamd_spmm_tiled_inspect(int val_dtype, int idx_dtype, int64_t M, int64_t K, const void* a_data,
                                         const void* a_indices, const void* a_indptr, void* state, int* blk_off, int* blocks,
                                         void* stream) {
@@ -628,9 +679,9 @@ extern "C" int spamd_spmm_tiled_inspect(int val_dtype, int idx_dtype, int64_t M,
   const int64_t ntiles = ceil_div(K, (int64_t)TL_KB);
   if (ntiles > TL_DIRECT_MAX_TILES) return SPAMD_EINVAL;
   const int64_t groups = tl_grid_groups(M);
-  hipError_t e = hipMemsetAsync(state, 0, (size_t)(groups + 2) * sizeof(unsigned long long), (hipStream_t)stream);
+  hipError_t e = hipMemsetAsync(state, 0, sizeof(unsigned long long), (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
-  if (groups == 0) return (int)hipMemsetAsync(blk_off, 0, sizeof(int), (hipStream_t)stream);
+  if (groups == 0) return 0;
   SPAMD_DISPATCH_IDX(idx_dtype, I, {
     if (val_dtype == SPAMD_F32)
       return tl_launch_inspect<I, float>(M, ntiles, (const float*)a_data, (const I*)a_indices, (const I*)a_indptr,
@@ -654,12 +705,12 @@ static int tl_set_lds_once(const void* kern) {
 
 template <typename T, typename KERN>
 static int tl_launch(KERN kern, int64_t M, int64_t K, int64_t N, const int* blocks, const int* blk_off, const T* b,
-                     int64_t ldb, T* out, int64_t ldo, int touch_lines, hipStream_t s) {
+                     int64_t ldb, T* out, int64_t ldo, int touch_lines, bool group_ends, hipStream_t s) {
   // the 160 KB dynamic-LDS opt-in is a per-function attribute: set once per kernel, not on every multiply
   if (int rc = tl_set_lds_once(reinterpret_cast<const void*>(kern))) return rc;
   const int64_t blocks_n = tl_grid_groups(M) / TL_WAVES;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks_n, (unsigned)(N / TlFmt<T>::PANEL)), dim3(TL_WAVES * 64), TL_LDS, s, M, K,
-                     (int)ceil_div(K, (int64_t)TL_KB), touch_lines, blocks, blk_off, b, ldb, out, ldo);
+                     (int)ceil_div(K, (int64_t)TL_KB), touch_lines | (group_ends ? 1 << 16 : 0), blocks, blk_off, b, ldb, out, ldo);
   return launch_status();
 }
 
@@ -675,6 +726,7 @@ extern "C" int spamd_spmm_tiled(int val_dtype, int64_t M, int64_t K, int64_t N, 
   if ((K + 2 * TL_KB) * ldb * esz >= ((int64_t)1 << 32)) return SPAMD_EINVAL;  // the tile DMA walks B with 32-bit byte offsets
   hipStream_t s = (hipStream_t)stream;
   const bool exact = (flags & SPAMD_EXACT_MULADD) != 0;
+  const bool ends = (flags & SPAMD_TILED_GROUP_ENDS) != 0;
   // lines of a list that are pulled into L2 two phases ahead (flags bits 8..15; 0 = default): the launcher derives
   // it from the mean list length, longer lists pay the HBM latency on their remaining blocks
   int touch = (int)((flags >> 8) & 0xffu);
@@ -683,8 +735,8 @@ extern "C" int spamd_spmm_tiled(int val_dtype, int64_t M, int64_t K, int64_t N, 
   if (val_dtype == SPAMD_F64) {
     const double* bb = (const double*)b;
     double* oo = (double*)out;
-    return exact ? tl_launch<double>(&spmm_tiled_kernel<0, 5, double>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, s)
-                 : tl_launch<double>(&spmm_tiled_kernel<0, 4, double>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, s);
+    return exact ? tl_launch<double>(&spmm_tiled_kernel<0, 5, double>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, s)
+                 : tl_launch<double>(&spmm_tiled_kernel<0, 4, double>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, s);
   }
   const float* bb = (const float*)b;
   float* oo = (float*)out;
@@ -693,11 +745,11 @@ extern "C" int spamd_spmm_tiled(int val_dtype, int64_t M, int64_t K, int64_t N, 
   // reads/fma, 7 = neither DMA nor LDS reads nor fma.  The shipped library never reads the environment.
   const char* dbg_env = getenv("SPAMD_TILED_DBG");
   const int dbg = dbg_env ? atoi(dbg_env) : 0;
-  if (dbg == 2) return tl_launch<float>(&spmm_tiled_kernel<2, 0, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, s);
-  if (dbg == 5) return tl_launch<float>(&spmm_tiled_kernel<0, 1, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, s);
-  if (dbg == 6) return tl_launch<float>(&spmm_tiled_kernel<0, 2, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, s);
-  if (dbg == 7) return tl_launch<float>(&spmm_tiled_kernel<2, 2, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, s);
+  if (dbg == 2) return tl_launch<float>(&spmm_tiled_kernel<2, 0, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, s);
+  if (dbg == 5) return tl_launch<float>(&spmm_tiled_kernel<0, 1, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, s);
+  if (dbg == 6) return tl_launch<float>(&spmm_tiled_kernel<0, 2, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, s);
+  if (dbg == 7) return tl_launch<float>(&spmm_tiled_kernel<2, 2, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, s);
 #endif
-  return exact ? tl_launch<float>(&spmm_tiled_kernel<0, 3, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, s)
-               : tl_launch<float>(&spmm_tiled_kernel<0, 0, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, s);
+  return exact ? tl_launch<float>(&spmm_tiled_kernel<0, 3, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, s)
+               : tl_launch<float>(&spmm_tiled_kernel<0, 0, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, s);
 }

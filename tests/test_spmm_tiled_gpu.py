@@ -42,7 +42,7 @@ def test_tiled_bit_identical_to_rowgroup_fma(orc, idt, M, K, density):
     rg, kb, gpb, epb, slack, _, _ = Kn_params()
     assert bool((blk_off[1:] >= blk_off[:-1]).all()) and blocks.numel() >= (int(blk_off[-1]) + slack) * epb * 2
     ent = blocks.view(-1, 2)[: int(blk_off[-1]) * epb].cpu().numpy()
-    real = ent[ent[:, 0] != 0]                                         # padding entries are all-zero
+    real = ent[ent[:, 0] != 0]                                         # padding entries (and the blocks between row groups) are all-zero
     assert len(real) == len(data)
     assert sorted(real[:, 1].view(np.float32).tolist()) == sorted(data.tolist())  # a permutation of A's values
 
@@ -187,16 +187,38 @@ def test_direct_inspector_equals_the_key_sort_recipe(idt, M, K, density):
     data, idx, ptr = random_csr(M, K, density, 21, np.float32, idt, empty_rows=(0, 7), long_row=3)
     d = torch.device("cuda")
     td, ti, tp = (torch.from_numpy(x).to(d) for x in (data, idx, ptr))
-    b1, o1, _ = Kn.csr_tiled_layout(td, ti, tp, M, K)
+    l1 = Kn.csr_tiled_layout(td, ti, tp, M, K)
+    b1, o1, _ = l1
     b2, o2, _ = Kn.csr_tiled_layout(td, ti, tp, M, K, force_sort=True)
-    used = int(o1[-1]) * 16     # (the one-pass inspector allocates the stream for its upper bound: compare what is used)
-    assert torch.equal(o1, o2) and torch.equal(b1[:used], b2[:used])
     Kn.TILED_ONE_PASS_INSPECTOR = False
     try:
         b3, o3, _ = Kn.csr_tiled_layout(td, ti, tp, M, K)       # the two-pass builder (count, scan, fill)
     finally:
         Kn.TILED_ONE_PASS_INSPECTOR = True
-    assert torch.equal(o1, o3) and torch.equal(b1[:used], b3[:used])
+    assert torch.equal(o2, o3) and torch.equal(b2[: int(o2[-1]) * 16], b3[: int(o2[-1]) * 16])
+    _assert_same_lists(l1, (b2, o2), K)
+
+
+def _assert_same_lists(one_pass, recipe, K):
+    """The one-pass inspector starts every row group at a closed-form upper bound (zeroed blocks in between) and gives
+    each group its own end: list by list its blocks must be those of the key-sort recipe, bit for bit."""
+    from sparse_amd import _kernels as Kn
+
+    assert one_pass.group_ends
+    (b1, o1, dt), (b2, o2) = one_pass, recipe
+    kb = Kn.tiled_params(dt)[1]
+    ntiles = -(-K // kb)
+    o1h = o1.cpu().numpy().reshape(-1, ntiles + 1)
+    o2h = o2.cpu().numpy()
+    b1h, b2h = b1.cpu().numpy().reshape(-1, 16), b2.cpu().numpy().reshape(-1, 16)
+    assert o1h.shape[0] * ntiles == o2h.size - 1
+    assert np.all(np.diff(o1h, axis=1) >= 0) and np.all(o1h[1:, 0] >= o1h[:-1, -1])     # lists in order, groups do not overlap
+    for g in range(o1h.shape[0]):
+        assert np.array_equal(np.diff(o1h[g]), np.diff(o2h[g * ntiles:(g + 1) * ntiles + 1])), g
+        assert np.array_equal(b1h[o1h[g, 0]:o1h[g, -1]], b2h[o2h[g * ntiles]:o2h[(g + 1) * ntiles]]), g
+        nxt = o1h[g + 1, 0] if g + 1 < o1h.shape[0] else o1h[g, -1]
+        assert not b1h[o1h[g, -1]:nxt].any(), g                                           # the gap is zeroed
+        assert nxt - o1h[g, -1] <= ntiles                                                  # < one block per list
 
 
 def test_unsorted_rows_fall_back_to_the_key_sort_recipe(orc):
@@ -215,6 +237,43 @@ def test_unsorted_rows_fall_back_to_the_key_sort_recipe(orc):
     got = Kn.dot_csr_ndarray_tiled(layout, (M, 128), K, tb)
     want = orc.dot_csr_ndarray((M, 128), data, idx, ptr, b)
     assert_within_fma_bound(got.cpu().numpy(), want, data, idx, ptr, b)
+
+
+def test_product_path_defers_the_sortedness_verdict(orc, monkeypatch):
+    """`a @ dense` does not wait for the one-pass inspector's verdict before launching the executor: the layout is built
+    with `defer_check`, the verdict is read behind the first product.  Rows with descending column indices (which no
+    constructor here produces, but a user-supplied triplet may hold) are caught there: the layout is rebuilt by the
+    key-sort recipe and the product repeated — same result as for the sorted matrix, order of accumulation aside."""
+    import sparse_amd as sp
+    from sparse_amd import _settings, _kernels as Kn
+
+    monkeypatch.setattr(_settings, "TILED_SPMM", "auto")
+    monkeypatch.setattr(_settings, "EXACT_MULADD", False)
+    M, K, N = 70000, 1500, 128
+    data, idx, ptr = random_csr(M, K, 0.01, 33, np.float32, np.int32)
+    b = random_dense(K, N, 34, np.float32)
+    d = torch.device("cuda")
+    tb = torch.from_numpy(b).to(d)
+    a = sp.GCXS(tuple(torch.from_numpy(x).to(d) for x in (data, idx, ptr)), shape=(M, K), compressed_axes=(0,))
+    got = a @ tb
+    lay = a._tiled_layouts[torch.float32]
+    assert lay.group_ends and lay.pending is None          # one-pass layout, verdict consumed by the first product
+    ridx, rdata = idx.copy(), data.copy()
+    for r in range(M):                                      # reverse every row: same matrix, descending column order
+        ridx[ptr[r]:ptr[r + 1]] = idx[ptr[r]:ptr[r + 1]][::-1]
+        rdata[ptr[r]:ptr[r + 1]] = data[ptr[r]:ptr[r + 1]][::-1]
+    ar = sp.GCXS(tuple(torch.from_numpy(x).to(d) for x in (rdata, ridx, ptr)), shape=(M, K), compressed_axes=(0,))
+    lay_r = Kn.csr_tiled_layout(ar.data, ar.indices, ar.indptr, M, K, defer_check=True)
+    assert lay_r.pending is not None
+    with pytest.raises(Kn.UnsortedColumns):
+        Kn.dot_csr_ndarray_tiled(lay_r, (M, N), K, tb)
+    got_r = ar @ tb
+    lay2 = ar._tiled_layouts[torch.float32]
+    assert not lay2.group_ends and lay2.pending is None    # rebuilt by the key-sort recipe
+    want = orc.dot_csr_ndarray((M, N), data, idx, ptr, b)
+    assert_within_fma_bound(got.cpu().numpy(), want, data, idx, ptr, b)
+    assert_within_fma_bound(got_r.cpu().numpy(), want, data, idx, ptr, b)
+    assert torch.equal(ar @ tb, got_r)
 
 
 # ---- float64 (the reference's default dtype): one column per lane, 64-column panels, 5-entry blocks ------------
@@ -236,10 +295,8 @@ def test_tiled_f64_bit_identical_to_rowgroup_and_reference(orc, M, K, density, N
         assert torch.equal(got, ref), exact
     want = orc.dot_csr_ndarray((M, N), data, idx, ptr, b)
     assert np.array_equal(got.cpu().numpy().view(np.uint64), want.view(np.uint64))   # exact mode = reference bits
-    b1, o1, _ = layout
     b2, o2, _ = Kn.csr_tiled_layout(td, ti, tp, M, K, force_sort=True)
-    used = int(o1[-1]) * 16
-    assert torch.equal(o1, o2) and torch.equal(b1[:used], b2[:used])
+    _assert_same_lists(layout, (b2, o2), K)
 
 
 def test_product_path_float64_and_mixed_precision(orc, monkeypatch):
