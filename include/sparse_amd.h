@@ -193,6 +193,15 @@ int spamd_csr_to_keys(int idx_dtype, int64_t R, int64_t nnz, const void* indptr,
                       int64_t* keys, void* stream);
 /* sorted row ids -> int64 indptr[R+1]        (`cumsum(bincount(coords[0]))`, _common.py:452-458) */
 int spamd_rows_to_indptr(int idx_dtype, int64_t nnz, const void* rows, int64_t R, int64_t* indptr, void* stream);
+/* CSR <-> CSC of a 2-D compressed matrix with 4-byte values in one call: `GCXS.change_compressed_axes` / `_transpose`
+ * (compressed.py:388-423, convert.py:210-273: uncompress, re-linearise, stable argsort, bincount + cumsum).  The input is
+ * in (major, minor) order, so a stable sort on the minor index alone gives (minor, major) order.  data: nnz 4-byte values
+ * (moved bit-wise), indices[nnz], indptr[n_major + 1] of idx_dtype; outputs of the same dtypes: out_data[nnz],
+ * out_indices[nnz] (the major ids), out_indptr[n_minor + 1].  n_major, n_minor < 2^32; ws of spamd_csx_swap_ws_bytes(nnz). */
+int64_t spamd_csx_swap_ws_bytes(int64_t nnz);
+int spamd_csx_swap(int idx_dtype, int64_t n_major, int64_t n_minor, int64_t nnz, const void* data, const void* indices,
+                   const void* indptr, void* out_data, void* out_indices, void* out_indptr, void* ws, int64_t ws_bytes,
+                   void* stream);
 /* Stable radix sort of (key, value) int64 pairs on key bits [0, end_bit); keys must be >= 0.
  * Replaces `np.argsort(linear, kind="mergesort")` (core.py:1315).  Workspace from *_ws_bytes. */
 int64_t spamd_sort_pairs_ws_bytes(int64_t n);

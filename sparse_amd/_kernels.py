@@ -422,6 +422,18 @@ def csx_swap_2d(data, indices, indptr, n_major, n_minor):
     it = indices.dtype if index_dtype_ok(indices) else torch.int64
     if nnz == 0:
         return data, indices.to(it), torch.zeros(n_minor + 1, dtype=it, device=dev)
+    if data.element_size() == 4 and n_major < 2 ** 31 and n_minor < 2 ** 31 and index_dtype_ok(indices) \
+            and indices.dtype == indptr.dtype:
+        # one library call: pack (32-bit minor key, major id | value bits), stable sort on the key, unpack + pointers
+        ws_bytes = int(_ffi.lib().spamd_csx_swap_ws_bytes(nnz))
+        if ws_bytes < 0:
+            raise _ffi.HipBackendError(f"spamd_csx_swap_ws_bytes failed: {ws_bytes}")
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        new_data, new_indices = torch.empty_like(data.contiguous()), torch.empty(nnz, dtype=it, device=dev)
+        new_indptr = torch.empty(n_minor + 1, dtype=it, device=dev)
+        _ffi.call("spamd_csx_swap", code_of(it), int(n_major), int(n_minor), nnz, ptr(data.contiguous()), ptr(indices.contiguous()),
+                  ptr(indptr.contiguous()), ptr(new_data), ptr(new_indices), ptr(new_indptr), ptr(ws), ws_bytes, stream_ptr(dev))
+        return new_data, new_indices, new_indptr
     major = csr_to_keys(indptr, torch.zeros_like(indices), n_major, 1)     # major id of every stored element
     keys = convert(indices.contiguous(), torch.int64)
     if data.element_size() == 4 and n_major < 2 ** 31:
