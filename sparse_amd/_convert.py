@@ -56,6 +56,14 @@ def coo_to_gcxs_arrays(x, compressed_axes=None, idx_dtype=None):
         raise ValueError(f"cannot store array with the compressed shape {(R, C)} and nnz {x.nnz} with dtype {idx_dtype}.")
     base = x.coords.dtype if not idx_dtype else (torch.int32 if np.dtype(idx_dtype).itemsize <= 4 else torch.int64)
     it = _pick_index_dtype(base, bound)
+    if x.ndim == 2 and tuple(compressed_axes) == (1,) and x.data.element_size() == 4 and x.data.dtype != torch.bool \
+            and max(x.shape) < 2 ** 31 and x.nnz < 2 ** 31 and x.coords.dtype in (torch.int32, torch.int64):
+        # canonical 2-D COO is CSR order already: row pointers + the one-call CSR -> CSC swap (a stable sort on the
+        # column alone) instead of re-linearising and sorting the full (column, row) keys
+        ct = x.coords.dtype
+        rows_ptr = K.rows_to_indptr(x.coords[0], int(x.shape[0])).to(ct)
+        data, indices, indptr = K.csx_swap_2d(x.data, x.coords[1].contiguous(), rows_ptr, int(x.shape[0]), int(x.shape[1]))
+        return ((data, indices.to(it), indptr.to(it)), x.shape, tuple(compressed_axes), x.fill_value)
     keys = x.linear_loc()
     data = x.data
     if order != list(range(x.ndim)):

@@ -258,6 +258,20 @@ __global__ void __launch_bounds__(256) csr_to_keys_kernel(const I* __restrict__ 
   }
 }
 
+// the same for rows that hold at least a few elements each: a wave per row, the row id is known without a search
+// (the per-element search above costs ~20 dependent L2 loads per element: 154 us for 10^7 elements, this form 30 us)
+template <typename I>
+__global__ void __launch_bounds__(256) csr_to_keys_rows_kernel(const I* __restrict__ indptr, const I* __restrict__ indices,
+                                                               int64_t R, int64_t C, int64_t* __restrict__ keys) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); row < R; row += nwaves) {
+    const int64_t a = (int64_t)indptr[row], b = (int64_t)indptr[row + 1];
+    const int64_t base = row * C;
+    for (int64_t e = a + lane; e < b; e += 64) keys[e] = base + (int64_t)indices[e];
+  }
+}
+
 // sorted row ids -> indptr (A5 / COO operands: `bincount + cumsum`, _common.py:452-458)
 template <typename I>
 __global__ void __launch_bounds__(256) rows_to_indptr_kernel(const I* __restrict__ rows, int64_t nnz, int64_t R,
@@ -499,6 +513,12 @@ extern "C" int spamd_csr_to_keys(int idx_dtype, int64_t R, int64_t nnz, const vo
                                  int64_t C, int64_t* keys, void* stream) {
   if (nnz < 0 || R < 0) return SPAMD_EINVAL;
   if (nnz == 0) return 0;
+  if (nnz >= 8 * R) {   // rows of at least eight elements on average: a wave per row
+    const unsigned blocks = (unsigned)std::min<int64_t>((R + 3) / 4, (int64_t)256 * 64);
+    SPAMD_IDX_SWITCH(idx_dtype, I, hipLaunchKernelGGL(csr_to_keys_rows_kernel<I>, dim3(blocks), dim3(256), 0,
+                                                      (hipStream_t)stream, (const I*)indptr, (const I*)indices, R, C, keys))
+    return launch_status();
+  }
   SPAMD_IDX_SWITCH(idx_dtype, I, hipLaunchKernelGGL(csr_to_keys_kernel<I>, dim3(grid_for(nnz)), dim3(256), 0,
                                                     (hipStream_t)stream, (const I*)indptr, (const I*)indices, R, nnz,
                                                     C, keys))
