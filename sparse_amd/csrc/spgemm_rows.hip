@@ -229,20 +229,13 @@ spgemm_rowrank_kernel(int64_t n_col, int col_bits, int ebits, const I* __restric
       before += len[j];
     }
     __syncthreads();
-    // my products p0 .. p0+ITEMS-1 of the ROW are products (p - done) of this chunk when they fall into it
+    // Product p of the ROW belongs to thread p % BLOCK (item p / BLOCK): for one item index, consecutive lanes read
+    // consecutive entries of a B row — a wave-load touches two or three lines instead of 64 (with p / ITEMS = thread, every
+    // lane sat in its own line: the expansion alone took 9.7 of the kernel's 18 ms, ablation of 2026-09).  A thread's
+    // products are BLOCK apart, so its A element advances by a few steps from one item to the next.
     const int done = chunk_done;  // products of earlier chunks (block-uniform register)
-    const int p0 = tid * ITEMS - done;
-    if (p0 + ITEMS > 0 && p0 < chunk_total) {
+    {
       int e = 0;
-      {
-        const int pp = p0 < 0 ? 0 : p0;
-        int l = 0, h = cn - 1;
-        while (l < h) {
-          const int mid = (l + h + 1) >> 1;
-          if (prefix[mid] <= pp) l = mid; else h = mid - 1;
-        }
-        e = l;
-      }
       constexpr int G = 8;   // loads in flight per thread (a register budget, not a latency one: 512 threads x 8 x 2)
 #pragma unroll
       for (int j0 = 0; j0 < ITEMS; j0 += G) {
@@ -252,7 +245,7 @@ spgemm_rowrank_kernel(int64_t n_col, int col_bits, int ebits, const I* __restric
         bool on[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-          const int p = p0 + j0 + g;
+          const int p = (j0 + g) * BLOCK + tid - done;
           on[g] = j0 + g < ITEMS && p >= 0 && p < chunk_total;
           q[g] = 0;
           av[g] = V(0);
@@ -277,6 +270,16 @@ spgemm_rowrank_kernel(int64_t n_col, int col_bits, int ebits, const I* __restric
     __syncthreads();
   }
 
+#if defined(SPG_ABL) && SPG_ABL == 1   // timing ablation (wrong results): expansion only
+  {
+    KEY x = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) x ^= keys[j] + (KEY)__builtin_bit_cast(unsigned, (float)vals[j]);
+    if (x == (KEY)0x12345) nnz_row[row] = 1;
+    if (tid == 0) nnz_row[row] = 0;
+    return;
+  }
+#endif
   KEY* const lkey = reinterpret_cast<KEY*>(raw);
   V* const lval = reinterpret_cast<V*>(raw + (size_t)CAPP * sizeof(KEY));
   int* const cnt = reinterpret_cast<int*>(raw + L::region);
@@ -315,6 +318,11 @@ spgemm_rowrank_kernel(int64_t n_col, int col_bits, int ebits, const I* __restric
       if (tid == 0) nnz_row[row] = -1;
       return;
     }
+#if defined(SPG_ABL) && SPG_ABL == 2   // timing ablation: expansion + bucket counts + scan
+    if (pass == PASSES - 1) { if (tid == 0) nnz_row[row] = 0; return; }
+    __syncthreads();
+    continue;
+#endif
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
       const unsigned sl = (slots[j / 6] >> (5 * (j % 6))) & 31u;
@@ -331,14 +339,16 @@ spgemm_rowrank_kernel(int64_t n_col, int col_bits, int ebits, const I* __restric
     // with a compare-exchange network, and its runs of equal columns are summed left to right; the heads (column, sum)
     // go back into the bucket's own LDS slots.  No dependent LDS round trips, no divergence beyond the 8 / 16 split.
     constexpr int BPT = NBP / BLOCK;   // consecutive buckets per thread
-    int hc[BPT];
+    // The heads of a thread's buckets are written back COMPACTLY from the thread's first slot on (tb + number of heads so
+    // far <= the bucket's own first slot, and the bucket being ranked sits in registers already), so that a thread's
+    // heads are one contiguous LDS run [tb, tb + mine): the emission below can then map output slots to LDS slots.
+    const int tb = cnt[tid * BPT];
     int mine = 0;
 #pragma unroll
     for (int bb = 0; bb < BPT; ++bb) {
       const int b = tid * BPT + bb;
       const int s0 = cnt[b];
       const int c = cnt[b + 1] - s0;
-      hc[bb] = 0;
       if (c > SPG_BUCKET_MAX) {
         declined = 1;
         continue;
@@ -401,8 +411,8 @@ spgemm_rowrank_kernel(int64_t n_col, int col_bits, int ebits, const I* __restric
     acc = first ? v[(i)] : acc + v[(i)];                                                                   \
     const bool last = (i) + 1 == c || (k[(i) + 1 < SPG_BUCKET_MAX ? (i) + 1 : (i)] >> ebits) != col;       \
     if (last) {                                                                                            \
-      lkey[s0 + h] = col;                                                                                  \
-      lval[s0 + h] = acc;                                                                                  \
+      lkey[tb + mine + h] = col;                                                                           \
+      lval[tb + mine + h] = acc;                                                                           \
       ++h;                                                                                                 \
     }                                                                                                      \
   }
@@ -414,7 +424,6 @@ spgemm_rowrank_kernel(int64_t n_col, int col_bits, int ebits, const I* __restric
         }
       }
 #undef SPG_RUN
-      hc[bb] = h;
       mine += h;
     }
     // ---- 3. emit: the thread's buckets are consecutive, so one scan of the per-thread head counts places them
@@ -424,14 +433,26 @@ spgemm_rowrank_kernel(int64_t n_col, int col_bits, int ebits, const I* __restric
       if (tid == 0) nnz_row[row] = -1;
       return;
     }
-    int64_t o = base + row_total + at;
-#pragma unroll
-    for (int bb = 0; bb < BPT; ++bb) {
-      const int s0 = cnt[tid * BPT + bb];
-      for (int i = 0; i < hc[bb]; ++i) {
-        tmp_cols[o] = (int)lkey[s0 + i];
-        tmp_vals[o] = lval[s0 + i];
-        ++o;
+#if defined(SPG_ABL) && SPG_ABL == 3   // timing ablation: everything but the emission
+    row_total += pass_total;
+    if (PASSES > 1) __syncthreads();
+    continue;
+#endif
+    // Output slot r of this pass lives in LDS slot map[r] (thread t: slots at .. at + mine -> tb .. tb + mine).  The map
+    // (16-bit entries) takes the place of the bucket offsets, which are dead now; with it the heads leave in output order,
+    // consecutive lanes writing consecutive elements (a thread writing its own ~9 heads one after the other put 64 lanes
+    // into 64 different lines per store: 3.3 of the kernel's 18 ms).
+    static_assert((size_t)CAPP * sizeof(unsigned short) <= (size_t)(NBP + 1) * sizeof(int) && CAPP <= 65535, "slot map");
+    unsigned short* const map = reinterpret_cast<unsigned short*>(cnt);
+    // (every thread has read its bucket offsets: the scan above has barriers behind the rank phase)
+    for (int i = 0; i < mine; ++i) map[at + i] = (unsigned short)(tb + i);
+    __syncthreads();
+    {
+      const int64_t o = base + row_total;
+      for (int r = tid; r < pass_total; r += BLOCK) {
+        const int src = map[r];
+        tmp_cols[o + r] = (int)lkey[src];
+        tmp_vals[o + r] = lval[src];
       }
     }
     row_total += pass_total;
