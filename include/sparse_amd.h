@@ -319,7 +319,9 @@ int spamd_spgemm_expand(int val_dtype, int idx_dtype, int64_t p0, int64_t np, co
  *   caller: prod_off = spamd_exclusive_scan(prod), scratch tmp_cols/tmp_vals of prod_off[n_row] entries;
  *   spamd_spgemm_rows: rows of C into the scratch at prod_off[row], their lengths into nnz_row[n_row + 1];
  *   caller: out_indptr = spamd_exclusive_scan(nnz_row);
- *   spamd_spgemm_pack: scratch -> (out_indices int64, out_data), columns ascending inside every row. */
+ *   spamd_spgemm_pack: scratch -> (out_indices int64, out_data), columns ascending inside every row; zero_count
+ *     (optional, one device word, zeroed here) receives the number of all-zero-bits values written: what the
+ *     `GCXS(..., prune=True)` of reference _common.py:374-379 then need not count in a pass of its own. */
 int spamd_spgemm_row_products(int idx_dtype, int64_t n_row, const void* a_indptr, const void* a_indices,
                               const void* b_indptr, int64_t* prod, int64_t* maxes, void* stream);
 int64_t spamd_spgemm_rows_capacity(int val_dtype, int64_t n_col, int64_t max_arow);
@@ -337,7 +339,8 @@ int spamd_spgemm_unpack(int val_dtype, int64_t n_heavy, const int64_t* heavy_row
                         const int64_t* src_indices, const void* src_data, const int64_t* prod_off, int* tmp_cols,
                         void* tmp_vals, int64_t* nnz_row, void* stream);
 int spamd_spgemm_pack(int val_dtype, int64_t n_row, const int64_t* prod_off, const int64_t* out_indptr,
-                      const int* tmp_cols, const void* tmp_vals, int64_t* out_indices, void* out_data, void* stream);
+                      const int* tmp_cols, const void* tmp_vals, int64_t* out_indices, void* out_data,
+                      int64_t* zero_count, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * A9  SDDMM      out[n] = s[n] * sum_k A[rows[n], k] * Bt[cols[n], k]

@@ -102,7 +102,7 @@ SIGNATURES = {
     "spamd_spgemm_rows": (_int, [_int, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "spamd_spgemm_classify_rows": (_int, [_int, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "spamd_spgemm_unpack": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "spamd_spgemm_pack": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "spamd_spgemm_pack": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spamd_reduce_fill": (_int, [_int, _int, _i64, _vp, _vp, _i64, _C.c_double, _i64, _vp]),
     "spamd_group_reduce_ws_bytes": (_i64, [_int, _i64]),
     "spamd_group_reduce": (_int, [_int, _int, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),

@@ -307,6 +307,13 @@ def flag_ne_bits(data, fill_value):
     return f
 
 
+def note_zero_bits_count(data, count):
+    """Remember (on the tensor, for as long as it is not written to) how many of its elements have all-zero bits — a
+    producer that has just written `data` knows it for free (the SpGEMM pack kernel), and `count_eq_bits(data, 0)`, i.e.
+    the prune of a zero-fill container built from it, then costs one device word instead of a pass over the data."""
+    data._zero_bits_count = (count, data._version)
+
+
 def count_eq_bits(data, fill_value):
     """Number of stored elements bit-identical to fill_value (one read-only pass)."""
     dev = require_hip(data)
@@ -314,6 +321,9 @@ def count_eq_bits(data, fill_value):
         return 0
     npdt = np_dtype(data.dtype)
     bits = int(np.asarray(fill_value, dtype=npdt).reshape(1).view(f"u{npdt.itemsize}")[0])
+    known = getattr(data, "_zero_bits_count", None)
+    if bits == 0 and known is not None and known[1] == data._version:
+        return int(known[0])
     c = torch.empty(1, dtype=torch.int64, device=dev)
     _ffi.call("spamd_count_eq_bits", data.element_size(), data.numel(), ptr(data.contiguous()), bits, ptr(c),
               stream_ptr(dev))
@@ -692,8 +702,10 @@ def _spgemm_rows(n_row, n_col, a_data, a_indices, a_indptr, b_data, b_indices, b
     nnz = int(out_ptr[-1])
     out_idx = torch.empty(nnz, dtype=torch.int64, device=dev)
     out_val = torch.empty(nnz, dtype=dtr, device=dev)
+    zeros = torch.empty(1, dtype=torch.int64, device=dev)
     _ffi.call("spamd_spgemm_pack", vcode, n_row, ptr(prod_off), ptr(out_ptr), ptr(tmp_cols), ptr(tmp_vals), ptr(out_idx),
-              ptr(out_val), s)
+              ptr(out_val), ptr(zeros), s)
+    note_zero_bits_count(out_val, zeros)
     return out_val, out_idx, out_ptr
 
 

@@ -466,13 +466,23 @@ template <typename V>
 __global__ void __launch_bounds__(256) spgemm_pack_kernel(const int64_t* __restrict__ prod_off,
                                                           const int64_t* __restrict__ out_ptr, const int* __restrict__ tmp_cols,
                                                           const V* __restrict__ tmp_vals, int64_t* __restrict__ out_idx,
-                                                          V* __restrict__ out_val) {
+                                                          V* __restrict__ out_val, unsigned long long* __restrict__ zeros) {
   const int64_t row = blockIdx.x;
   const int64_t src = prod_off[row], dst = out_ptr[row];
   const int64_t n = out_ptr[row + 1] - dst;
+  int nz = 0;   // values whose bits are all zero (+0.0 / 0): what the container's prune would otherwise count in a pass of its own
   for (int64_t i = threadIdx.x; i < n; i += 256) {
     out_idx[dst + i] = (int64_t)tmp_cols[src + i];
-    out_val[dst + i] = tmp_vals[src + i];
+    const V v = tmp_vals[src + i];
+    out_val[dst + i] = v;
+    if constexpr (sizeof(V) == 8) nz += __builtin_bit_cast(uint64_t, v) == 0;
+    else if constexpr (sizeof(V) == 4) nz += __builtin_bit_cast(uint32_t, v) == 0;
+    else nz += v == V(0);
+  }
+  if (zeros) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) nz += __shfl_xor(nz, d, 64);
+    if ((threadIdx.x & 63) == 0 && nz) atomicAdd(zeros, (unsigned long long)nz);
   }
 }
 
@@ -685,11 +695,14 @@ extern "C" int spamd_spgemm_unpack(int val_dtype, int64_t n_heavy, const int64_t
 
 extern "C" int spamd_spgemm_pack(int val_dtype, int64_t n_row, const int64_t* prod_off, const int64_t* out_indptr,
                                  const int* tmp_cols, const void* tmp_vals, int64_t* out_indices, void* out_data,
-                                 void* stream) {
+                                 int64_t* zero_count, void* stream) {
   if (n_row < 0) return SPAMD_EINVAL;
-  if (n_row == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
+  if (zero_count)
+    if (hipError_t e = hipMemsetAsync(zero_count, 0, sizeof(int64_t), s); e != hipSuccess) return (int)e;
+  if (n_row == 0) return 0;
   SPAMD_DISPATCH_VAL(val_dtype, V, hipLaunchKernelGGL(spgemm_pack_kernel<V>, dim3((unsigned)n_row), dim3(256), 0, s, prod_off,
-                                                      out_indptr, tmp_cols, (const V*)tmp_vals, out_indices, (V*)out_data))
+                                                      out_indptr, tmp_cols, (const V*)tmp_vals, out_indices, (V*)out_data,
+                                                      (unsigned long long*)zero_count))
   return launch_status();
 }

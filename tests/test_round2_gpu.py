@@ -322,3 +322,45 @@ def test_deferred_nan_warning_is_raised_later_not_lost(sp):
         _settings.NAN_WARNING = old
     with pytest.warns(RuntimeWarning, match="Nan will not be propagated"):   # the default: before matmul returns
         sp.matmul(a, bad)
+
+
+def test_spgemm_prune_uses_the_pack_kernels_zero_count():
+    """`GCXS @ GCXS` prunes exact zeros like the reference (`GCXS(..., prune=True)`, _common.py:374-379).  Above
+    PRUNE_COUNT_FIRST elements the prune first counts the zeros; for a row-local product the pack kernel has counted them
+    already (no pass over the result).  Cancelling products (+1 * 1 + 1 * -1) must still disappear, and the remembered
+    count must not outlive a write to the data."""
+    import sparse_amd as sp
+    from sparse_amd import _kernels as K
+
+    rng = np.random.default_rng(4)
+    n = 3000
+    dense_a = np.zeros((n, n), dtype=np.float32)
+    dense_b = np.zeros((n, n), dtype=np.float32)
+    rows = rng.integers(0, n, 60000)
+    dense_a[rows, rng.integers(0, n, 60000)] = rng.integers(1, 4, 60000).astype(np.float32)
+    dense_b[rng.integers(0, n, 60000), rng.integers(0, n, 60000)] = rng.integers(1, 4, 60000).astype(np.float32)
+    # make exact cancellations: rows 0..99 of A hold (+1 at column 0, +1 at column 1), rows 0/1 of B are negatives of each other
+    dense_a[:100, :] = 0
+    dense_a[:100, 0] = 1
+    dense_a[:100, 1] = 1
+    dense_b[0, :] = 0
+    dense_b[1, :] = 0
+    dense_b[0, :50] = 2
+    dense_b[1, :50] = -2
+    a = sp.GCXS.from_numpy(dense_a, compressed_axes=(0,))
+    b = sp.GCXS.from_numpy(dense_b, compressed_axes=(0,))
+    old = K.PRUNE_COUNT_FIRST
+    K.PRUNE_COUNT_FIRST = 1
+    try:
+        c = a @ b
+    finally:
+        K.PRUNE_COUNT_FIRST = old
+    want = dense_a.astype(np.float64) @ dense_b.astype(np.float64)
+    assert np.array_equal(c.todense(), want.astype(np.float32))
+    assert c.nnz == np.count_nonzero(want)
+    # the remembered count is tied to the tensor's version
+    t = torch.zeros(8, device="cuda")
+    K.note_zero_bits_count(t, torch.tensor([8], device="cuda"))
+    assert K.count_eq_bits(t, 0.0) == 8
+    t[0] = 1.0
+    assert K.count_eq_bits(t, 0.0) == 7
