@@ -220,3 +220,51 @@ def test_basic_index_normalisation():
     for fancy in ([0, 1], np.array([0, 1])):
         with pytest.raises(NotImplementedError):
             _normalise((fancy,), 2)
+
+
+def test_sddmm_dispatch_models(hiplib):
+    """The host-side choices of `sparse_amd.sddmm` are pure arithmetic on shapes (no GPU needed): which lane-group
+    widths have a row-cached kernel (asked of the library), the panel width, and the traffic models that pick the
+    element order and the tile dispatch (measured at config 4's shapes)."""
+    import torch
+    from types import SimpleNamespace
+    from sparse_amd import _kernels as K
+
+    assert K.sddmm_has_panels(torch.bfloat16, 256) and K.sddmm_has_panels(torch.float32, 256) and K.sddmm_has_panels(torch.float64, 512)
+    assert not K.sddmm_has_panels(torch.bfloat16, 200) and not K.sddmm_has_panels(torch.float32, 7)
+    assert not K.sddmm_has_panels(torch.int32, 256)
+    a = torch.empty((100_000, 256), dtype=torch.bfloat16, device="meta")
+    bt = torch.empty((100_000, 256), dtype=torch.bfloat16, device="meta")
+    w = K.sddmm_panel_width(bt)
+    assert w == (3 << 20) // 512
+    assert K.sddmm_panels_pay(10_000_000, a, bt, w) and not K.sddmm_panels_pay(3_000_000, a, bt, w)
+    assert not K.sddmm_panels_pay(10_000_000, a, bt, 0) and not K.sddmm_panels_pay(1000, a, bt, w)
+    small = torch.empty((4096, 256), dtype=torch.bfloat16, device="meta")
+    assert K.sddmm_panel_width(small) == 0
+    # tiles: a block-sparse plan pays, a half-filled clustered one (its left-over samples would leave the panel order) does not
+    plan = lambda ntiles, dense, rest: SimpleNamespace(tiles=torch.empty(ntiles, device="meta"), n_dense_samples=dense,
+                                                       rest=torch.empty(rest, device="meta"), nnz=dense + rest)
+    assert K.sddmm_tiles_pay(plan(9765, 9_999_360, 0), a, bt, w)
+    assert not K.sddmm_tiles_pay(plan(13671, 7_001_614, 2_996_267), a, bt, w)
+    assert not K.sddmm_tiles_pay(plan(0, 0, 10_000_000), a, bt, w)
+    assert not K.sddmm_tiles_pay(plan(1000, 300_000, 0), a, bt, w)      # 300 samples per tile: below what a tile product costs
+
+
+def test_one_pass_inspector_group_offsets_never_overlap():
+    """The tiled-SpMM inspector starts row group g at ceil((e0 + g * tiles * (EPB - 1)) / EPB) blocks (csrc/spmm_tiled.hip
+    `tl_group_first_block`): for any split of the elements into lists, a group's lists (each padded to whole blocks) end
+    before the next group starts, the gap is less than one block per list, and the total stays inside the allocation
+    ceil(nnz / EPB) + lists."""
+    rng = np.random.default_rng(0)
+    for epb in (8, 5):
+        for _ in range(200):
+            tiles = int(rng.integers(1, 70))
+            groups = int(rng.integers(1, 40))
+            counts = rng.integers(0, 40, size=(groups, tiles)) * (rng.random((groups, tiles)) < 0.8)
+            e0 = np.concatenate([[0], np.cumsum(counts.sum(axis=1))])
+            first = lambda e, g: (int(e) + g * tiles * (epb - 1) + epb - 1) // epb
+            for g in range(groups):
+                used = int(np.sum(-(-counts[g] // epb)))
+                assert first(e0[g], g) + used <= first(e0[g + 1], g + 1)
+                assert first(e0[g + 1], g + 1) - (first(e0[g], g) + used) <= tiles
+            assert first(e0[-1], groups) <= -(-int(e0[-1]) // epb) + groups * tiles
