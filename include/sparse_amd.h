@@ -359,12 +359,17 @@ int spamd_sddmm(int in_dtype, int s_dtype, int idx_dtype, int64_t nnz, const voi
  * stably (spamd_sort_pairs) into `perm`, gathers rows/cols/values by it (rows_p, cols_p, s_p), and spamd_sddmm_panels
  * walks the mask one panel of `width` Bt rows at a time, lane groups taking `chunk` elements per turn (<= 0: default):
  * out[perm[n]] = s_p[n] * <A[rows_p[n]], Bt[cols_p[n]]>, i.e. out keeps the mask's own order.  perm/rows_p/cols_p
- * depend on the coordinates only.  SPAMD_EINVAL when K has no row-cached kernel (call spamd_sddmm). */
+ * depend on the coordinates only.  SPAMD_EINVAL when K has no row-cached kernel (call spamd_sddmm).
+ * XCD-private panels (optional): with per_xcd = ceil(panels / 8) the keys are XCD-major, (panel % 8) * per_xcd + panel / 8,
+ * xcd_first = int64[9] (device) holds the first element of each XCD's range in the sorted order (and the total) and
+ * xcd_max the longest range; workgroup b then takes piece b / 8 of the range of XCD b % 8 (the observed placement: for
+ * speed only), so that a panel's Bt rows are fetched into one L2 instead of eight.  NULL = all XCDs share every panel. */
 int spamd_sddmm_has_panels(int in_dtype, int64_t K); /* 1: spamd_sddmm_panels has a kernel for this K */
-int spamd_sddmm_panel_keys(int idx_dtype, int64_t nnz, const void* cols, int64_t width, void* keys, void* stream);
+int spamd_sddmm_panel_keys(int idx_dtype, int64_t nnz, const void* cols, int64_t width, int64_t per_xcd, void* keys,
+                           void* stream);
 int spamd_sddmm_panels(int in_dtype, int s_dtype, int idx_dtype, int64_t nnz, const void* rows_p, const void* cols_p,
                        const int64_t* perm, const void* s_p, const void* A, int64_t lda, const void* Bt, int64_t ldb,
-                       int64_t K, int64_t chunk, void* out, void* stream);
+                       int64_t K, int64_t chunk, const int64_t* xcd_first, int64_t xcd_max, void* out, void* stream);
 
 /* A9, dense-tile form (north_star: "MFMA used only on the dense tile of SDDMM"): the 32 x 32 tiles of the mask that
  * hold at least `threshold` samples are computed as one 32 x 32 x K bf16 product on the matrix cores

@@ -750,7 +750,7 @@ class SddmmPanels:
     `pos` = the elements' positions in the mask, stably sorted by column panel; `rows`/`cols` = their coordinates in
     that order.  Depends on the coordinates and the panel width only: cached on the mask by `sparse_amd.sddmm`."""
 
-    __slots__ = ("pos", "rows", "cols", "width", "count", "nnz", "chunk", "_vals", "_vals_key")
+    __slots__ = ("pos", "rows", "cols", "width", "count", "nnz", "chunk", "xstate", "xmax", "_vals", "_vals_key")
 
     def values(self, s_orig, s_data):
         """`s_data` (= `s_orig` in the accumulation dtype) in panel order; kept for as long as the same, unmodified
@@ -773,6 +773,11 @@ def sddmm_panel_width(bt):
         return 0
     if not sddmm_has_panels(bt.dtype, bt.shape[1]):
         return 0
+    if SDDMM_XCD_PANELS and int(bt.shape[0]) * row_bytes >= 8 * SDDMM_PANEL_BYTES:
+        # XCD-private panels: a multiple of eight panels of at most 7/6 of the panel size (3.5 MiB), so that every XCD owns the same number
+        # (measured at config 4: 16 panels of 6250 rows 0.357 ms private vs 0.390 shared; 17 panels of 6144 rows 0.402 vs 0.396)
+        per_xcd = -(-int(bt.shape[0]) * row_bytes // (8 * (SDDMM_PANEL_BYTES * 7 // 6)))
+        return max(-(-int(bt.shape[0]) // (8 * per_xcd)), 64)
     return max(SDDMM_PANEL_BYTES // row_bytes, 64)
 
 
@@ -809,8 +814,13 @@ def sddmm_tiles_pay(plan, a, bt, width):
     return True
 
 
-def sddmm_panels(coords, shape, width, subset=None):
-    """Panel order of the mask's stored elements, or of those listed in `subset` (int64 positions, ascending)."""
+SDDMM_XCD_PANELS = True   # panels are private to an XCD (the kernel reads the XCC id it runs on); False: every XCD walks every panel
+
+
+def sddmm_panels(coords, shape, width, subset=None, xcd=None):
+    """Panel order of the mask's stored elements, or of those listed in `subset` (int64 positions, ascending).  With `xcd`
+    (default SDDMM_XCD_PANELS, and only when there are at least 8 panels) the order is XCD-major: panel p belongs to XCD
+    p % 8, and `xstate` holds where each XCD's elements start."""
     dev = require_hip(coords)
     rows, cols = coords[0].contiguous(), coords[1].contiguous()
     if not index_dtype_ok(rows):
@@ -821,10 +831,19 @@ def sddmm_panels(coords, shape, width, subset=None):
         rows, cols = gather(rows, subset), gather(cols, subset)
     n = int(rows.numel())
     keys = torch.empty(n, dtype=torch.int64, device=dev)
-    _ffi.call("spamd_sddmm_panel_keys", code_of(cols.dtype), n, ptr(cols), int(width), ptr(keys), stream_ptr(dev))
-    _, perm = sort_keys(keys, max((int(shape[1]) - 1) // int(width), 1))
+    npanels = (int(shape[1]) - 1) // int(width) + 1
+    xcd = SDDMM_XCD_PANELS if xcd is None else xcd
+    per_xcd = -(-npanels // 8) if xcd and npanels >= 8 else 0
+    _ffi.call("spamd_sddmm_panel_keys", code_of(cols.dtype), n, ptr(cols), int(width), per_xcd, ptr(keys), stream_ptr(dev))
+    skeys, perm = sort_keys(keys, max(8 * per_xcd - 1 if per_xcd else npanels - 1, 1))
     p.pos = perm if subset is None else gather(subset, perm)
     p.rows, p.cols, p.width, p.count, p.chunk = gather(rows, perm), gather(cols, perm), int(width), n, 0
+    p.xstate, p.xmax = None, 0
+    if per_xcd:
+        # first element of every (XCD, panel) key in the sorted order -> the nine boundaries of the XCDs' ranges
+        first = rows_to_indptr(skeys, 8 * per_xcd)[::per_xcd].contiguous()
+        host = first.cpu().numpy()                       # (plan time: one small read-back for the launch grid)
+        p.xstate, p.xmax = first, int(np.max(np.diff(host)))
     p._vals = p._vals_key = None
     return p
 
@@ -833,7 +852,8 @@ def _sddmm_panels_into(panels, s_orig, s_data, a, bt, out):
     """The elements of `panels` (all of the mask or a subset), written to their positions in `out`."""
     _ffi.call("spamd_sddmm_panels", code_of(a.dtype), code_of(out.dtype), code_of(panels.rows.dtype), panels.count,
               ptr(panels.rows), ptr(panels.cols), ptr(panels.pos), ptr(panels.values(s_orig, s_data)), ptr(a), a.stride(0),
-              ptr(bt), bt.stride(0), int(a.shape[1]), int(panels.chunk), ptr(out), stream_ptr(out.device))
+              ptr(bt), bt.stride(0), int(a.shape[1]), int(panels.chunk), ptr(panels.xstate) if panels.xstate is not None else None,
+              int(panels.xmax), ptr(out), stream_ptr(out.device))
 
 
 def sddmm_coo(coords, s_data, a, bt, panels=None):

@@ -209,22 +209,47 @@ template <typename TIN, typename TS, typename I, int LPN, int KS, int UNR, bool 
 __global__ void __launch_bounds__(256)
 sddmm_rowcache_kernel(int64_t nnz, int64_t chunk, const I* __restrict__ rows, const I* __restrict__ cols,
                       const TS* __restrict__ s_data, const TIN* __restrict__ A, int64_t lda,
-                      const TIN* __restrict__ Bt, int64_t ldb, TS* __restrict__ out, const int64_t* __restrict__ perm) {
+                      const TIN* __restrict__ Bt, int64_t ldb, TS* __restrict__ out, const int64_t* __restrict__ perm,
+                      const int64_t* __restrict__ xstate) {
   using ACC = typename Acc<TIN>::type;
   constexpr int EPL = 16 / (int)sizeof(TIN);
   using VT = Vec<TIN, EPL>;
   static_assert(UNR == 4 && LPN % UNR == 0, "whole batches of four per step");
   const int sub = (threadIdx.x & 63) % LPN;
-  const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPN;
-  const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / LPN;
+  // elements [cbeg0, cbeg0 + chunk), then every `cstride`-th chunk after it, below nnz_end
+  int64_t cbeg0 = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPN) * chunk;
+  int64_t cstride = ((int64_t)gridDim.x * blockDim.x / LPN) * chunk;
+  int64_t nnz_end = nnz;
+  if constexpr (PERM) {
+    // XCD-private panels (xstate = first[9]): the element order is XCD-major — the elements of the panels that belong
+    // to XCD x are [first[x], first[x + 1]) — and workgroup b takes piece b / 8 of the range of XCD b % 8, the XCD it is
+    // observed to run on (MI355X_MICROARCH.md: for speed only, nothing depends on it), so that a panel's Bt rows are
+    // fetched into ONE L2 instead of eight.  (Reading HW_REG_XCC_ID and taking a ticket per piece instead was built and
+    // is slower, 0.51 vs 0.36 ms at config 4: every short-lived workgroup then starts with an atomic's round trip.)
+    if (xstate) {
+      __shared__ int64_t piece_s[2];
+      const int64_t piece = (int64_t)(blockDim.x / LPN) * chunk;
+      const int x = (int)(blockIdx.x & 7u);
+      const int64_t lo = (int64_t)xstate[x], hi = (int64_t)xstate[x + 1];
+      const int64_t b = lo + (int64_t)(blockIdx.x >> 3) * piece;
+      if (threadIdx.x == 0) {
+        piece_s[0] = b < hi ? b : 0;
+        piece_s[1] = b < hi ? (b + piece < hi ? b + piece : hi) : 0;
+      }
+      __syncthreads();
+      cbeg0 = piece_s[0] + (int64_t)(threadIdx.x / LPN) * chunk;
+      cstride = (int64_t)1 << 40;   // one chunk per lane group
+      nnz_end = piece_s[1];
+    }
+  }
   const char* const Ab = reinterpret_cast<const char*>(A);
   const char* const Bb = reinterpret_cast<const char*>(Bt);
   const int64_t lda_b = lda * (int64_t)sizeof(TIN), ldb_b = ldb * (int64_t)sizeof(TIN);
   const int64_t koff_b = (int64_t)sub * 16;
   I cur = (I)-1;
   VT av[KS];
-  for (int64_t cbeg = group * chunk; cbeg < nnz; cbeg += ngroups * chunk) {
-    const int64_t cend = cbeg + chunk < nnz ? cbeg + chunk : nnz;
+  for (int64_t cbeg = cbeg0; cbeg < nnz_end; cbeg += cstride) {
+    const int64_t cend = cbeg + chunk < nnz_end ? cbeg + chunk : nnz_end;
     for (int64_t nbeg = cbeg; nbeg < cend; nbeg += LPN) {
       const int cnt = (int)(cend - nbeg < LPN ? cend - nbeg : LPN);  // uniform inside the group
       const bool mine = sub < cnt;
@@ -248,7 +273,7 @@ sddmm_rowcache_kernel(int64_t nnz, int64_t chunk, const I* __restrict__ rows, co
 template <typename TIN, typename TS, typename I>
 static int launch_sddmm(int64_t nnz, const I* rows, const I* cols, const TS* s, const TIN* A, int64_t lda,
                         const TIN* Bt, int64_t ldb, int64_t K, TS* out, hipStream_t st, const int64_t* perm = nullptr,
-                        int64_t perm_chunk = 0) {
+                        int64_t perm_chunk = 0, const int64_t* xstate = nullptr, int64_t xmax = 0) {
   constexpr int EPL = 16 / (int)sizeof(TIN);
   const int64_t vecs = K / EPL;
   int lpn = 4;
@@ -278,10 +303,12 @@ static int launch_sddmm(int64_t nnz, const I* rows, const I* cols, const TS* s, 
       // (column-panel order: one chunk per lane group, so that the workgroups resident at any moment - handed out in
       // order - cover one contiguous window of the element order, however unevenly they progress)
       const int64_t groups = perm ? ceil_div(nnz, chunk) : std::min(ceil_div(nnz, chunk), groups_wanted);
-      const int64_t blocks = ceil_div(groups * L, (int64_t)256);
+      int64_t blocks = ceil_div(groups * L, (int64_t)256);
+      if (perm && xstate)   // a piece per workgroup, eight workgroups (one per XCD) per piece index
+        blocks = 8 * std::max<int64_t>(ceil_div(xmax, (int64_t)(256 / L) * chunk), 1);
 #define SDL(LL, KK, PP)                                                                                       \
   hipLaunchKernelGGL((sddmm_rowcache_kernel<TIN, TS, I, LL, KK, U, PP>), dim3((unsigned)blocks), dim3(256), 0, st, \
-                     nnz, chunk, rows, cols, s, A, lda, Bt, ldb, out, perm)
+                     nnz, chunk, rows, cols, s, A, lda, Bt, ldb, out, perm, xstate)
 #define SDR(LL, KK)                                                                                           \
   if (L == LL && ks == KK) {                                                                                  \
     if (perm) SDL(LL, KK, true);                                                                              \
@@ -314,19 +341,25 @@ static int launch_sddmm(int64_t nnz, const I* rows, const I* cols, const TS* s, 
 using namespace spamd;
 
 template <typename I>
-__global__ void sddmm_panel_keys_kernel(int64_t nnz, const I* __restrict__ cols, int64_t width, int64_t* __restrict__ keys) {
+__global__ void sddmm_panel_keys_kernel(int64_t nnz, const I* __restrict__ cols, int64_t width, int64_t per_xcd,
+                                        int64_t* __restrict__ keys) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (n < nnz) keys[n] = (int64_t)cols[n] / width;
+  if (n < nnz) {
+    const int64_t p = (int64_t)cols[n] / width;
+    keys[n] = per_xcd > 0 ? (p % 8) * per_xcd + p / 8 : p;
+  }
 }
 
-// keys[n] = cols[n] / width: the column panel of each stored element (stable sort by it = panel order).
-extern "C" int spamd_sddmm_panel_keys(int idx_dtype, int64_t nnz, const void* cols, int64_t width, void* keys,
-                                      void* stream) {
-  if (nnz < 0 || width < 1) return SPAMD_EINVAL;
+// keys[n] = cols[n] / width: the column panel of each stored element (stable sort by it = panel order).  With
+// per_xcd > 0 (= ceil(panels / 8)) the key is XCD-major instead: panel p belongs to XCD p % 8 and is that XCD's
+// (p / 8)-th panel, key = (p % 8) * per_xcd + p / 8, so that the elements of one XCD's panels are contiguous.
+extern "C" int spamd_sddmm_panel_keys(int idx_dtype, int64_t nnz, const void* cols, int64_t width, int64_t per_xcd,
+                                      void* keys, void* stream) {
+  if (nnz < 0 || width < 1 || per_xcd < 0) return SPAMD_EINVAL;
   if (nnz == 0) return 0;
   SPAMD_DISPATCH_IDX(idx_dtype, I, {
     hipLaunchKernelGGL((sddmm_panel_keys_kernel<I>), dim3((unsigned)ceil_div(nnz, (int64_t)256)), dim3(256), 0,
-                       (hipStream_t)stream, nnz, (const I*)cols, width, (int64_t*)keys);
+                       (hipStream_t)stream, nnz, (const I*)cols, width, per_xcd, (int64_t*)keys);
     return launch_status();
   })
   return SPAMD_ETYPE;
@@ -334,12 +367,14 @@ extern "C" int spamd_sddmm_panel_keys(int idx_dtype, int64_t nnz, const void* co
 
 static int sddmm_entry(int in_dtype, int s_dtype, int idx_dtype, int64_t nnz, const void* rows, const void* cols,
                        const void* s_data, const void* A, int64_t lda, const void* Bt, int64_t ldb, int64_t K,
-                       void* out, void* stream, const int64_t* perm, int64_t perm_chunk);
+                       void* out, void* stream, const int64_t* perm, int64_t perm_chunk, const int64_t* xstate,
+                       int64_t xmax);
 
 extern "C" int spamd_sddmm(int in_dtype, int s_dtype, int idx_dtype, int64_t nnz, const void* rows, const void* cols,
                            const void* s_data, const void* A, int64_t lda, const void* Bt, int64_t ldb, int64_t K,
                            void* out, void* stream) {
-  return sddmm_entry(in_dtype, s_dtype, idx_dtype, nnz, rows, cols, s_data, A, lda, Bt, ldb, K, out, stream, nullptr, 0);
+  return sddmm_entry(in_dtype, s_dtype, idx_dtype, nnz, rows, cols, s_data, A, lda, Bt, ldb, K, out, stream, nullptr, 0,
+                     nullptr, 0);
 }
 
 // 1 when K elements of in_dtype have a row-cached kernel (what spamd_sddmm_panels needs), else 0.
@@ -361,15 +396,17 @@ extern "C" int spamd_sddmm_has_panels(int in_dtype, int64_t K) {
 // (use spamd_sddmm).
 extern "C" int spamd_sddmm_panels(int in_dtype, int s_dtype, int idx_dtype, int64_t nnz, const void* rows_p,
                                   const void* cols_p, const int64_t* perm, const void* s_p, const void* A, int64_t lda,
-                                  const void* Bt, int64_t ldb, int64_t K, int64_t chunk, void* out, void* stream) {
-  if (!perm) return SPAMD_EINVAL;
+                                  const void* Bt, int64_t ldb, int64_t K, int64_t chunk, const int64_t* xcd_first,
+                                  int64_t xcd_max, void* out, void* stream) {
+  if (!perm || (xcd_first && xcd_max < 0)) return SPAMD_EINVAL;
   return sddmm_entry(in_dtype, s_dtype, idx_dtype, nnz, rows_p, cols_p, s_p, A, lda, Bt, ldb, K, out, stream, perm,
-                     chunk);
+                     chunk, xcd_first, xcd_max);
 }
 
 static int sddmm_entry(int in_dtype, int s_dtype, int idx_dtype, int64_t nnz, const void* rows, const void* cols,
                        const void* s_data, const void* A, int64_t lda, const void* Bt, int64_t ldb, int64_t K,
-                       void* out, void* stream, const int64_t* perm, int64_t perm_chunk) {
+                       void* out, void* stream, const int64_t* perm, int64_t perm_chunk, const int64_t* xstate,
+                       int64_t xmax) {
   if (nnz < 0 || K < 0) return SPAMD_EINVAL;
   if (nnz == 0) return 0;
   if (((uintptr_t)A % 16) || ((uintptr_t)Bt % 16)) return SPAMD_EINVAL;
@@ -381,13 +418,13 @@ static int sddmm_entry(int in_dtype, int s_dtype, int idx_dtype, int64_t nnz, co
     const I* c = (const I*)cols;
     if (in_dtype == SPAMD_BF16 && s_dtype == SPAMD_F32)
       return launch_sddmm<__hip_bfloat16, float, I>(nnz, r, c, (const float*)s_data, (const __hip_bfloat16*)A, lda,
-                                                    (const __hip_bfloat16*)Bt, ldb, K, (float*)out, st, perm, perm_chunk);
+                                                    (const __hip_bfloat16*)Bt, ldb, K, (float*)out, st, perm, perm_chunk, xstate, xmax);
     if (in_dtype == SPAMD_F32 && s_dtype == SPAMD_F32)
       return launch_sddmm<float, float, I>(nnz, r, c, (const float*)s_data, (const float*)A, lda, (const float*)Bt,
-                                           ldb, K, (float*)out, st, perm, perm_chunk);
+                                           ldb, K, (float*)out, st, perm, perm_chunk, xstate, xmax);
     if (in_dtype == SPAMD_F64 && s_dtype == SPAMD_F64)
       return launch_sddmm<double, double, I>(nnz, r, c, (const double*)s_data, (const double*)A, lda,
-                                             (const double*)Bt, ldb, K, (double*)out, st, perm, perm_chunk);
+                                             (const double*)Bt, ldb, K, (double*)out, st, perm, perm_chunk, xstate, xmax);
   })
   return SPAMD_ETYPE;
 }

@@ -236,7 +236,7 @@ def test_sddmm_dispatch_models(hiplib):
     a = torch.empty((100_000, 256), dtype=torch.bfloat16, device="meta")
     bt = torch.empty((100_000, 256), dtype=torch.bfloat16, device="meta")
     w = K.sddmm_panel_width(bt)
-    assert w == (3 << 20) // 512
+    assert w == 6250          # 16 panels (two per XCD) of 3.05 MiB; (3 << 20) // 512 = 6144 with shared panels
     assert K.sddmm_panels_pay(10_000_000, a, bt, w) and not K.sddmm_panels_pay(3_000_000, a, bt, w)
     assert not K.sddmm_panels_pay(10_000_000, a, bt, 0) and not K.sddmm_panels_pay(1000, a, bt, w)
     small = torch.empty((4096, 256), dtype=torch.bfloat16, device="meta")

@@ -152,10 +152,22 @@ def test_sddmm_column_panel_order_is_bit_identical(dt, Kd, idx):
     want = sval.double().cpu().numpy() * np.einsum("ik,ik->i", a64[ch[0]], b64[ch[1]])
     absum = np.abs(sval.double().cpu().numpy()) * np.einsum("ik,ik->i", np.abs(a64[ch[0]]), np.abs(b64[ch[1]]))
     assert np.all(np.abs(ref.double().cpu().numpy() - want) <= (1e-14 if dt == "f64" else 2e-6) * absum + 1e-300)
-    for width in (64, 1000, 4999, 5000):
-        plan = K.sddmm_panels(coords, (M, N), width)
-        # the order really is panel-major, row-major inside a panel, and `pos` is a permutation
+    for width, xcd in ((64, False), (64, True), (300, True), (1000, False), (4999, False), (5000, True)):
+        plan = K.sddmm_panels(coords, (M, N), width, xcd=xcd)
+        # the order really is panel-major (XCD-major: panel p of XCD p % 8 is that XCD's (p / 8)-th), row-major inside a
+        # panel, and `pos` is a permutation
         pc = plan.cols.cpu().numpy().astype(np.int64) // width
+        npanels = (N - 1) // width + 1
+        if xcd and npanels >= 8:
+            per = -(-npanels // 8)
+            assert plan.xstate is not None
+            first = plan.xstate.cpu().numpy()
+            assert first[0] == 0 and first[8] == nnz and plan.xmax == int(np.max(np.diff(first)))
+            pc = (pc % 8) * per + pc // 8
+            for x in range(8):
+                assert np.all(pc[first[x]:first[x + 1]] // per == x)
+        else:
+            assert plan.xstate is None
         assert np.all(np.diff(pc) >= 0)
         pos = plan.pos.cpu().numpy()
         assert np.array_equal(np.sort(pos), np.arange(nnz))
@@ -200,7 +212,7 @@ def test_sddmm_product_path_uses_panels_and_follows_the_mask(monkeypatch):
     s = sp.COO(coords_h, sval, shape=(M, N))
     check(sp.sddmm(s, at, bt=bt), sval)
     plans = s._sddmm_plan
-    key = ("panels", "all", 64)
+    key = ("panels", "all", K.sddmm_panel_width(bt))
     assert key in plans and plans[key].count == nnz
     first = plans[key]
     check(sp.sddmm(s, at, bt=bt), sval)
@@ -245,7 +257,7 @@ def test_sddmm_mfma_rest_in_panel_order(monkeypatch):
     monkeypatch.setattr(K, "sddmm_tiles_pay", lambda plan, a, bt, width: True)
     monkeypatch.setattr(K, "SDDMM_PANEL_BYTES", 100 * Kd * 2)
     out = sp.sddmm(s, at, bt=bt)
-    assert ("panels", "rest", 100) in s._sddmm_plan
+    assert ("panels", "rest", K.sddmm_panel_width(bt)) in s._sddmm_plan
     want = np.where(plain.cpu().numpy() == 0, 0, plain.cpu().numpy())
     assert np.array_equal(out.todense()[coords_h[0], coords_h[1]], want)
 
@@ -259,7 +271,7 @@ def test_sddmm_panel_order_traffic_model():
     a = torch.empty((100_000, 256), dtype=torch.bfloat16, device="cuda")
     bt = torch.empty((100_000, 256), dtype=torch.bfloat16, device="cuda")
     w = K.sddmm_panel_width(bt)
-    assert w == (3 << 20) // 512
+    assert w == 6250          # 16 panels (two per XCD) of 3.05 MiB; (3 << 20) // 512 = 6144 with shared panels
     assert K.sddmm_panels_pay(10_000_000, a, bt, w)
     assert not K.sddmm_panels_pay(3_000_000, a, bt, w)
     small = torch.empty((4096, 256), dtype=torch.bfloat16, device="cuda")

@@ -33,11 +33,10 @@ for dt in (torch.bfloat16, torch.float32):
     bt = torch.rand(N, Kd, device=dev, generator=g).to(dt)
     t0, ref = timeit(lambda: K.sddmm_coo(coords, s, a, bt))
     print(f"{dt} K={Kd} row-major order: {t0:.3f} ms", flush=True)
-    for width in (2048, 3072, 4096, 6144, 8192):
-        plan = K.sddmm_panels(coords, (M, N), width); torch.cuda.synchronize()
+    for width in (3072, 4096, 6144, 6250, 8192, 12500):
         line = f"   panels of {width:6d} Bt rows ({width * Kd * a.element_size() / 2**20:5.2f} MiB):"
-        for chunk in (4, 8, 16, 64):
-            plan.chunk = chunk
+        for xcd in (False, True):
+            plan = K.sddmm_panels(coords, (M, N), width, xcd=xcd); torch.cuda.synchronize()
             t1, out = timeit(lambda: K.sddmm_coo(coords, s, a, bt, panels=plan))
-            line += f"  chunk {chunk}: {t1:.3f} ms{'' if torch.equal(ref, out) else ' DIFFERS'}"
+            line += f"  {'XCD-private' if xcd else 'shared'}: {t1:.3f} ms{'' if torch.equal(ref, out) else ' DIFFERS'}"
         print(line, flush=True)
