@@ -80,6 +80,19 @@ def test_config4_sddmm_properties(sp):
     ones = torch.ones((M, 256), device="cuda", dtype=torch.bfloat16)
     r3 = sp.sddmm(s, ones, bt=ones)
     assert torch.equal(r3.data, s.data * 256)
+    # this size takes the column-panel order (XCD-private panels), plan kept on the mask; same bits as the mask's own order;
+    # 20000 samples against the float64 evaluation of the reference's formulation
+    from sparse_amd import _kernels as K
+
+    w = K.sddmm_panel_width(bt)
+    plan = s._sddmm_plan[("panels", "all", w)]
+    assert plan.count == s.nnz and plan.xstate is not None and w * 16 >= M
+    assert torch.equal(r.data, K.sddmm_coo(s.coords, s.data, a, bt))
+    pick = torch.randperm(s.nnz, generator=g, device="cuda")[:20000]
+    rows, cols = s.coords[0][pick].long(), s.coords[1][pick].long()
+    want = s.data[pick].double() * (a[rows].double() * bt[cols].double()).sum(dim=1)
+    bound = s.data[pick].double().abs() * (a[rows].double().abs() * bt[cols].double().abs()).sum(dim=1)
+    assert bool(((r.data[pick].double() - want).abs() <= 2e-6 * bound).all())
 
 
 def test_spgemm_identity_and_transpose(sp):
