@@ -278,10 +278,11 @@ static int launch_sddmm(int64_t nnz, const I* rows, const I* cols, const TS* s, 
   const int64_t vecs = K / EPL;
   int lpn = 4;
   while (lpn < 64 && vecs > lpn * 2) lpn <<= 1;  // ~2 vector loads per lane per operand
-  // measured on MI355X (config 4): bf16 rows (512 B) are fastest with one element per lane group
-  // in flight (0.86 ms), fp32/fp64 rows with four (1.44 ms vs 1.54 ms)
+  // (the gather kernel at the bottom — any K — measured on MI355X at config 4 in round 1: bf16 rows are fastest with one
+  // element per lane group in flight, fp32/fp64 rows with four)
   {
-    // row-cached kernel: K must be LPN * KS vectors exactly (KS <= 4); try 16 lanes per element first
+    // row-cached kernel (config 4: 0.70 ms in the mask's own order, 0.36 ms in XCD-private panel order): K must be
+    // LPN * KS vectors exactly (KS in 1, 2, 4); try 16 lanes per element first
 #ifdef SPAMD_TUNING
     const char* v = getenv("SPAMD_SDDMM_VARIANT");  // tuning hook (-DSPAMD_TUNING builds only): "0" = gather kernel only
     const bool allow = !(v && v[0] == '0');
