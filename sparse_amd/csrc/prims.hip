@@ -286,6 +286,20 @@ __global__ void __launch_bounds__(256) rows_to_indptr_kernel(const I* __restrict
   }
 }
 
+// The same from the elements' side: element e opens every row in (rows[e-1], rows[e]] (and the last element closes the
+// rest): one coalesced pass over the row ids instead of R + 1 binary searches of ~log2(nnz) dependent loads each.
+template <typename I>
+__global__ void __launch_bounds__(256) rows_to_indptr_fill_kernel(const I* __restrict__ rows, int64_t nnz, int64_t R,
+                                                                  int64_t* __restrict__ indptr) {
+  GRID_STRIDE(e, nnz) {
+    const int64_t r = (int64_t)rows[e];
+    const int64_t rp = e > 0 ? (int64_t)rows[e - 1] : -1;
+    for (int64_t j = rp + 1; j <= r; ++j) indptr[j] = e;
+    if (e == nnz - 1)
+      for (int64_t j = r + 1; j <= R; ++j) indptr[j] = nnz;
+  }
+}
+
 // U8 is the backend's bool: converting TO it is NumPy's astype(bool), i.e. x != 0 (NaN -> True)
 template <typename A, typename B>
 __global__ void __launch_bounds__(256) convert_kernel(const A* __restrict__ in, int64_t n, B* __restrict__ out) {
@@ -528,6 +542,11 @@ extern "C" int spamd_csr_to_keys(int idx_dtype, int64_t R, int64_t nnz, const vo
 extern "C" int spamd_rows_to_indptr(int idx_dtype, int64_t nnz, const void* rows, int64_t R, int64_t* indptr,
                                     void* stream) {
   if (nnz < 0 || R < 0) return SPAMD_EINVAL;
+  if (nnz > 0 && R <= 8 * nnz) {   // (not hypersparse: the element-side form; empty stretches are short)
+    SPAMD_IDX_SWITCH(idx_dtype, I, hipLaunchKernelGGL(rows_to_indptr_fill_kernel<I>, dim3(grid_for(nnz)), dim3(256), 0,
+                                                      (hipStream_t)stream, (const I*)rows, nnz, R, indptr))
+    return launch_status();
+  }
   SPAMD_IDX_SWITCH(idx_dtype, I, hipLaunchKernelGGL(rows_to_indptr_kernel<I>, dim3(grid_for(R + 1)), dim3(256), 0,
                                                     (hipStream_t)stream, (const I*)rows, nnz, R, indptr))
   return launch_status();
