@@ -167,12 +167,15 @@ int spamd_coords_check(int idx_dtype, int ndim, int64_t nnz, const void* coords,
 int spamd_keys_check(int64_t n, const int64_t* keys, int* flags2, void* stream);
 /* flags[i] = 1 where a run of equal keys starts (int64 0/1, ready for spamd_exclusive_scan) */
 int spamd_flag_heads(int64_t n, const int64_t* keys, int64_t* flags, void* stream);
-/* flags[i] = 1 where data[i] is NOT bit-identical to fill_bits (the reference's bit-wise
- * `equivalent`, _utils.py:448-452: -0.0 is not 0.0).  elem_bytes in {1,2,4,8}. */
-int spamd_flag_ne_bits(int elem_bytes, int64_t n, const void* data, uint64_t fill_bits, int64_t* flags,
-                       void* stream);
-/* *count (device int64) = number of elements bit-identical to fill_bits: the cheap test that a prune has nothing to do */
-int spamd_count_eq_bits(int elem_bytes, int64_t n, const void* data, uint64_t fill_bits, int64_t* count, void* stream);
+/* flags[i] = 1 where data[i] is NOT bit-identical to the fill pattern (the reference's bit-wise
+ * `equivalent`, _utils.py:448-452: -0.0 is not 0.0).  elem_bytes in {1,2,4,8,16}; fill_bits holds the element's low
+ * 8 bytes, fill_bits_hi bytes 8..15 of a 16-byte element (complex128: the imaginary part) and is ignored otherwise. */
+int spamd_flag_ne_bits(int elem_bytes, int64_t n, const void* data, uint64_t fill_bits, uint64_t fill_bits_hi,
+                       int64_t* flags, void* stream);
+/* *count (device int64) = number of elements bit-identical to the fill pattern: the cheap test that a prune has nothing
+ * to do */
+int spamd_count_eq_bits(int elem_bytes, int64_t n, const void* data, uint64_t fill_bits, uint64_t fill_bits_hi,
+                        int64_t* count, void* stream);
 /* dst[offsets[i]] = src[i] where flags[i] != 0  (stream compaction after an exclusive scan) */
 int spamd_compact(int elem_bytes, int64_t n, const void* src, const int64_t* flags, const int64_t* offsets,
                   void* dst, void* stream);

@@ -17,10 +17,14 @@ def partition_rows_by_nnz(indptr, world):
     M = int(indptr.numel()) - 1
     if M < 0:
         raise ValueError("indptr must have at least one entry")
-    nnz = int(indptr[-1]) if M >= 0 and indptr.numel() else 0
+    if world <= 1:
+        return [0, M]
+    # (set-up step, once per matrix: the cut targets are formed on the pointers' own device from nnz = indptr[-1], so the
+    # host reads back the world - 1 cuts only — one synchronisation, not one for nnz and one for the cuts)
     ip = indptr.to(torch.int64)
-    targets = torch.tensor([(p * nnz) // world for p in range(1, world)], dtype=torch.int64, device=ip.device)
-    cuts = torch.searchsorted(ip, targets, right=False) if world > 1 else targets
+    parts = torch.arange(1, world, dtype=torch.int64, device=ip.device)
+    targets = torch.div(parts * ip[-1], world, rounding_mode="floor")
+    cuts = torch.searchsorted(ip, targets, right=False)
     bounds = [0] + [min(int(c), M) for c in cuts.tolist()] + [M]
     for i in range(1, len(bounds)):  # monotone even with long empty stretches
         bounds[i] = max(bounds[i], bounds[i - 1])
@@ -49,53 +53,106 @@ def row_shard(b, rank, world):
     return b[lo:hi]
 
 
-def all_gather_rows(b_shard, n_rows, group=None):
-    """All-gather a row-sharded dense operand into the full (n_rows x N) matrix on every rank.
-
-    Uses one `all_gather_into_tensor` when the shards are equal-sized (the RCCL fast path),
-    otherwise one padded gather followed by a local compaction."""
+def _start_gather_rows(b_shard, n_rows, group=None):
+    """Launch the all-gather of a row-sharded dense operand; returns `finish()`, which waits for the collective (on the
+    current stream) and returns the full (n_rows x N) matrix.  Between the two the caller may queue work that does not
+    need B (the NaN scan and the inspector of the local block of A run while the shards cross xGMI)."""
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     if world == 1:
-        return b_shard
+        return lambda: b_shard
     cols = b_shard.shape[1:]
     out = torch.empty((n_rows, *cols), dtype=b_shard.dtype, device=b_shard.device)
     if n_rows % world == 0:
-        dist.all_gather_into_tensor(out, b_shard.contiguous(), group=group)
-        return out
+        work = dist.all_gather_into_tensor(out, b_shard.contiguous(), group=group, async_op=True)
+
+        def finish_even():
+            work.wait()
+            return out
+
+        return finish_even
     # ragged shards: pad every shard to the largest one (collectives need equal sizes), gather
     # once, then compact the valid rows into `out`
     maxrows = -(-n_rows // world)
     padded = torch.zeros((maxrows, *cols), dtype=b_shard.dtype, device=b_shard.device)
     padded[: b_shard.shape[0]] = b_shard
     gathered = torch.empty((world * maxrows, *cols), dtype=b_shard.dtype, device=b_shard.device)
-    dist.all_gather_into_tensor(gathered, padded, group=group)
-    for r in range(world):
-        lo, hi = row_bounds(n_rows, r, world)
-        out[lo:hi] = gathered[r * maxrows: r * maxrows + (hi - lo)]
-    return out
+    work = dist.all_gather_into_tensor(gathered, padded, group=group, async_op=True)
+
+    def finish_ragged():
+        work.wait()
+        for r in range(world):
+            lo, hi = row_bounds(n_rows, r, world)
+            out[lo:hi] = gathered[r * maxrows: r * maxrows + (hi - lo)]
+        return out
+
+    return finish_ragged
+
+
+def all_gather_rows(b_shard, n_rows, group=None):
+    """All-gather a row-sharded dense operand into the full (n_rows x N) matrix on every rank.
+
+    Uses one `all_gather_into_tensor` when the shards are equal-sized (the RCCL fast path),
+    otherwise one padded gather followed by a local compaction."""
+    return _start_gather_rows(b_shard, n_rows, group)()
+
+
+# The gathered operand of the last call per (shard buffer, version, group): a static B (inference-style loops, the bench's
+# steady state when B does not change) crosses xGMI once, not once per product.  In-place writes to the shard bump torch's
+# version counter and a replaced shard changes the pointer, so a changed B is gathered again.  Every rank evaluates the
+# same key from its own shard; a rank whose shard changed while another's did not would deadlock in the collective, so the
+# contract is the usual SPMD one: all ranks update B together.
+_GATHER_MEMO = {}
+GATHER_MEMO_ENTRIES = 4
+
+
+def _gather_key(t, n_rows, group):
+    return (t.data_ptr(), int(t._version), tuple(t.shape), t.dtype, int(n_rows), id(group))
+
+
+def gathered_rows(b_shard, n_rows, group=None, before_wait=None):
+    """`all_gather_rows` with the memo above; `before_wait()` is called after the collective is launched and before it
+    is waited for (also when the memo hits: the caller's preparation work is wanted either way)."""
+    key = _gather_key(b_shard, n_rows, group)
+    hit = _GATHER_MEMO.get(key)
+    if hit is not None:
+        if before_wait is not None:
+            before_wait()
+        return hit[1]
+    finish = _start_gather_rows(b_shard, n_rows, group)
+    if before_wait is not None:
+        before_wait()
+    full = finish()
+    _GATHER_MEMO[key] = (b_shard, full)       # (the shard is kept alive: a recycled pointer must not alias the key)
+    while len(_GATHER_MEMO) > GATHER_MEMO_ENTRIES:
+        _GATHER_MEMO.pop(next(iter(_GATHER_MEMO)))
+    return full
 
 
 def sharded_spmm(a_local, b_shard, n_rows_b, group=None):
     """Row-block-sharded C_local = A_local @ all_gather(B): the multi-GPU form of A1/A3.
-    `a_local` is this rank's GCXS/COO row block, `b_shard` its slice of B's rows."""
-    from ._dot import matmul
+    `a_local` is this rank's GCXS/COO row block, `b_shard` its slice of B's rows.  While the shards of B are in flight
+    the local block is prepared: its NaN scan (`matmul`'s warning, memoised per buffer) and, for an eligible operand,
+    its block stream (`prepare_operand`)."""
+    from . import _dot
 
-    b = all_gather_rows(b_shard, n_rows_b, group)
-    return matmul(a_local, b)
+    b = gathered_rows(b_shard, n_rows_b, group, before_wait=lambda: _dot.prepare_operand(a_local, b_shard))
+    return _dot.matmul(a_local, b)
 
 
-def all_gather_ragged(t, group=None):
+def all_gather_ragged(t, group=None, sizes=None):
     """All-gather 1-D (or [k, n]) tensors whose last dimension differs per rank: one size
-    exchange, one padded `all_gather_into_tensor`, local compaction.  Returns (cat, sizes)."""
+    exchange (skipped when the caller already knows `sizes`), one padded `all_gather_into_tensor`, local compaction.
+    Returns (cat, sizes)."""
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    n = torch.tensor([t.shape[-1]], dtype=torch.int64, device=t.device)
-    sizes = torch.empty(world, dtype=torch.int64, device=t.device)
-    dist.all_gather_into_tensor(sizes, n, group=group)
-    sizes = [int(s) for s in sizes.tolist()]
+    if sizes is None:
+        n = torch.tensor([t.shape[-1]], dtype=torch.int64, device=t.device)
+        got = torch.empty(world, dtype=torch.int64, device=t.device)
+        dist.all_gather_into_tensor(got, n, group=group)
+        sizes = [int(s) for s in got.tolist()]
     if world == 1:
         return t, sizes
     mx = max(max(sizes), 1)
@@ -107,33 +164,55 @@ def all_gather_ragged(t, group=None):
     return torch.cat([gathered[r][..., : sizes[r]] for r in range(world)], dim=-1), sizes
 
 
+def _offset_i64(t, value):
+    """t + value for an int64 index array: the library's elementwise kernel for device arrays; host arrays (the gloo
+    tests of this module's sharding logic run on CPU tensors) are offset by torch."""
+    if value == 0:
+        return t
+    if t.is_cuda:
+        from ._umath import binary_arrays
+
+        return binary_arrays("add", t.contiguous(), torch.tensor([value], dtype=torch.int64, device=t.device), b_scalar=True)
+    return t + value
+
+
 def all_gather_csr(data, indices, indptr, group=None):
     """All-gather row-block shards of a CSR matrix into the whole matrix on every rank — the
-    exchange step of row-sharded SpGEMM (B's triplet, 0.8 GB for config 5)."""
+    exchange step of row-sharded SpGEMM (B's triplet, 0.8 GB for config 5).
+    The row pointers are exchanged REBASED: once the shard sizes are known (the one size exchange of the values), rank
+    r's pointers are shifted by the stored elements of the ranks before it, so the gathered pointers are the whole
+    matrix's without a scan over the rows."""
+    import torch.distributed as dist
+
     d, sizes = all_gather_ragged(data, group)
-    i, _ = all_gather_ragged(indices, group)
-    counts, rsizes = all_gather_ragged((indptr[1:] - indptr[:-1]).to(torch.int64), group)
-    ip = torch.zeros(counts.numel() + 1, dtype=torch.int64, device=data.device)
-    ip[1:] = torch.cumsum(counts, 0)
-    return d, i, ip.to(indptr.dtype) if indptr.dtype == torch.int64 or int(ip[-1]) < 2 ** 31 else ip
+    i, _ = all_gather_ragged(indices, group, sizes=sizes)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    total = sum(sizes)
+    wide = indptr.dtype == torch.int64 or total >= 2 ** 31
+    mine = _offset_i64(indptr[:-1].to(torch.int64), sum(sizes[:rank]))
+    heads, _ = all_gather_ragged(mine, group)
+    ip = torch.empty(heads.numel() + 1, dtype=torch.int64, device=data.device)
+    ip[:-1] = heads
+    ip[-1] = total
+    return d, i, ip if wide or indptr.dtype == torch.int64 else ip.to(indptr.dtype)
 
 
 def sharded_spgemm(a_local, b_shard, group=None):
     """C_local = A_local @ all_gather(B): A and B both arrive as row blocks (GCXS,
     compressed_axes=(0,)); C stays row-sharded."""
-    from ._gcxs import GCXS
+    from . import _gcxs
 
     if a_local.compressed_axes != (0,) or b_shard.compressed_axes != (0,):
         raise ValueError("row-block sharding needs compressed_axes=(0,) operands")
     d, i, ip = all_gather_csr(b_shard.data, b_shard.indices, b_shard.indptr, group)
-    b_full = GCXS((d, i, ip), shape=(int(ip.numel()) - 1, b_shard.shape[1]), compressed_axes=(0,))
+    b_full = _gcxs.GCXS((d, i, ip), shape=(int(ip.numel()) - 1, b_shard.shape[1]), compressed_axes=(0,))
     return a_local @ b_full
 
 
 def sharded_sddmm(s_local, a_local, bt_shard, n_cols, group=None):
     """out_local = sddmm(S_local, A_local, all_gather(Bt)): mask rows and A rows co-sharded,
     Bt (N x K) row-sharded and gathered once."""
-    from ._api import sddmm
+    from . import _api
 
-    bt = all_gather_rows(bt_shard, n_cols, group)
-    return sddmm(s_local, a_local, bt=bt)
+    bt = gathered_rows(bt_shard, n_cols, group)
+    return _api.sddmm(s_local, a_local, bt=bt)

@@ -212,8 +212,16 @@ def matmul(a, b):
     # the reference scans both operands before multiplying (_common.py:245-246) only to WARN; here the scans are
     # launched, the product is queued behind them, and the verdicts are read afterwards from pinned host memory (the
     # host waits for the scan kernels only, never for the product)
-    probes = [check_class_nan(a, deferred=True), check_class_nan(b, deferred=True)]
-    res = _matmul(a, b)
+    _drain_prepared()
+    probes = [check_class_nan(a, deferred=True)]
+    try:
+        probes.append(check_class_nan(b, deferred=True))
+        res = _matmul(a, b)
+    except BaseException:
+        for p in probes:    # the product raised: hand the scans' verdict slots back unread
+            if isinstance(p, _Verdict):
+                p.probe.discard()
+        raise
     if _settings.NAN_WARNING == "deferred":
         _PENDING_NAN.extend(p for p in probes if p is not False)
         flush_warnings(block=False)
@@ -396,11 +404,42 @@ def prepare_spmm(a, dtype=None, force_sort=False):
     return True
 
 
+def prepare_operand(a, b_like):
+    """Everything `matmul(a, dense)` needs from `a` alone, queued now: the NaN scan of its values (the verdict is
+    memoised per buffer and version, so the product's own check is then a dictionary hit) and, when the product with an
+    operand like `b_like` (its dtype and column count) takes the inspector/executor kernel, the block stream.  Used by the
+    sharded products to fill the time the all-gather of B is in flight; harmless (and idempotent) anywhere else."""
+    from ._coo import COO
+    from ._gcxs import GCXS
+
+    if not isinstance(a, (GCXS, COO)) or a.ndim != 2 or not isinstance(b_like, torch.Tensor) or b_like.dim() != 2:
+        return
+    if _settings.NAN_CHECK:
+        v = check_class_nan(a, deferred=True)
+        if isinstance(v, _Verdict):
+            _PENDING_PREP.append(v)     # read (and memoised on `a`) by the next `matmul` through `_drain_prepared`
+    if isinstance(a, GCXS) or getattr(a, "_tiled_layouts", None):
+        data, _, _ = _csr_triplet(a)
+        out_shape = (int(a.shape[0]), int(b_like.shape[1]))
+        if _tiled_eligible(data, b_like, out_shape, int(a.shape[1])):
+            prepare_spmm(a, _tiled_dtype(data, b_like))
+
+
+_PENDING_PREP = []   # NaN scans started by `prepare_operand`, not read yet
+
+
+def _drain_prepared():
+    """Read the verdicts of `prepare_operand`'s scans (each remembers its result on its array)."""
+    while _PENDING_PREP:
+        _PENDING_PREP.pop()()
+
+
 def _tiled_product(a, dt, out_shape, Kd, b):
     """Executor product from `a`'s cached layout.  The one-pass inspector's "unsorted column indices" verdict is read
     behind the first product's launch (no host wait between inspector and executor); if it says unsorted — rows whose
-    column indices do not ascend, which no constructor of this package produces — the layout is rebuilt by the key-sort
-    recipe and the product repeated."""
+    column indices do not ascend (reachable: `GCXS((data, indices, indptr))` takes the caller's arrays as they are) — the
+    layout is rebuilt by the key-sort recipe and the product repeated.  The first, discarded product is memory-safe: the
+    inspector writes zero entries for every row group that met such a row (csrc/spmm_tiled.hip, `group_bad`)."""
     try:
         return K.dot_csr_ndarray_tiled(a._tiled_layouts[dt], out_shape, Kd, b, exact=_settings.EXACT_MULADD)
     except K.UnsortedColumns:

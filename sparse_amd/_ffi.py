@@ -55,8 +55,8 @@ SIGNATURES = {
     "spamd_keys_check": (_int, [_i64, _vp, _vp, _vp]),
     "spamd_coords_check": (_int, [_int, _int, _i64, _vp, _i64, _vp, _vp, _vp]),
     "spamd_flag_heads": (_int, [_i64, _vp, _vp, _vp]),
-    "spamd_flag_ne_bits": (_int, [_int, _i64, _vp, _C.c_uint64, _vp, _vp]),
-    "spamd_count_eq_bits": (_int, [_int, _i64, _vp, _C.c_uint64, _vp, _vp]),
+    "spamd_flag_ne_bits": (_int, [_int, _i64, _vp, _C.c_uint64, _C.c_uint64, _vp, _vp]),
+    "spamd_count_eq_bits": (_int, [_int, _i64, _vp, _C.c_uint64, _C.c_uint64, _vp, _vp]),
     "spamd_compact": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _vp]),
     "spamd_gather": (_int, [_int, _i64, _vp, _vp, _vp, _vp]),
     "spamd_scatter": (_int, [_int, _i64, _vp, _vp, _vp, _vp]),

@@ -102,10 +102,26 @@ class NanProbe:
             self.view, self.at, addr = NanProbe._view, self.slot, NanProbe._slab.data_ptr() + 4 * self.slot
         self.event = NanProbe._events.pop() if NanProbe._events else torch.cuda.Event()
         self.view[self.at] = 0
-        _ffi.call("spamd_has_nan_async", code_of(data.dtype), data.numel(), ptr(data), addr, stream_ptr(dev))
-        self.event.record()
-        self._keep = data  # the scanned buffer must outlive the kernel
         self.done = None
+        try:
+            _ffi.call("spamd_has_nan_async", code_of(data.dtype), data.numel(), ptr(data), addr, stream_ptr(dev))
+            # behind the scan on ITS stream: the array may live on another device than the current one (`to_device`)
+            self.event.record(torch.cuda.current_stream(dev))
+        except BaseException:
+            self.discard()
+            raise
+        self._keep = data  # the scanned buffer must outlive the kernel
+
+    def discard(self):
+        """Give the verdict slot and the event back without reading the verdict (the launch failed, or the product
+        this scan belonged to raised before asking)."""
+        if self.done is None:
+            self.done = False
+            if self.slot is not None:
+                NanProbe._free.append(self.slot)
+            if self.event is not None:
+                NanProbe._events.append(self.event)
+            self._keep = self.view = self.event = self.own = None
 
     def ready(self):
         """True once the scan has finished (never blocks)"""
@@ -300,11 +316,20 @@ def flag_ne_bits(data, fill_value):
     `loose`, _utils.py:448-452)."""
     dev = require_hip(data)
     f = new_flags(data.numel(), dev)
-    npdt = np_dtype(data.dtype)
-    bits = int(np.asarray(fill_value, dtype=npdt).reshape(1).view(f"u{npdt.itemsize}")[0])
-    _ffi.call("spamd_flag_ne_bits", data.element_size(), data.numel(), ptr(data.contiguous()), bits, ptr(f),
+    lo, hi = _fill_words(fill_value, np_dtype(data.dtype))
+    _ffi.call("spamd_flag_ne_bits", data.element_size(), data.numel(), ptr(data.contiguous()), lo, hi, ptr(f),
               stream_ptr(dev))
     return f
+
+
+def _fill_words(fill_value, npdt):
+    """The fill value's bit pattern as (low 8 bytes, bytes 8..15): the second word is only non-zero for 16-byte
+    elements (complex128: real part, imaginary part)."""
+    raw = np.asarray(fill_value, dtype=npdt).reshape(1)
+    if npdt.itemsize == 16:
+        w = raw.view(np.uint64)
+        return int(w[0]), int(w[1])
+    return int(raw.view(f"u{npdt.itemsize}")[0]), 0
 
 
 def note_zero_bits_count(data, count):
@@ -319,13 +344,12 @@ def count_eq_bits(data, fill_value):
     dev = require_hip(data)
     if data.numel() == 0:
         return 0
-    npdt = np_dtype(data.dtype)
-    bits = int(np.asarray(fill_value, dtype=npdt).reshape(1).view(f"u{npdt.itemsize}")[0])
+    bits, bits_hi = _fill_words(fill_value, np_dtype(data.dtype))
     known = getattr(data, "_zero_bits_count", None)
-    if bits == 0 and known is not None and known[1] == data._version:
+    if bits == 0 and bits_hi == 0 and known is not None and known[1] == data._version:
         return int(known[0])
     c = torch.empty(1, dtype=torch.int64, device=dev)
-    _ffi.call("spamd_count_eq_bits", data.element_size(), data.numel(), ptr(data.contiguous()), bits, ptr(c),
+    _ffi.call("spamd_count_eq_bits", data.element_size(), data.numel(), ptr(data.contiguous()), bits, bits_hi, ptr(c),
               stream_ptr(dev))
     return int(c[0])
 
@@ -814,7 +838,8 @@ def sddmm_tiles_pay(plan, a, bt, width):
     return True
 
 
-SDDMM_XCD_PANELS = True   # panels are private to an XCD (the kernel reads the XCC id it runs on); False: every XCD walks every panel
+SDDMM_XCD_PANELS = True   # panels are private to an XCD (workgroup b serves XCD b % 8: the placement MI355X is observed to use;
+                          # only speed depends on it); False: every XCD walks every panel
 
 
 def sddmm_panels(coords, shape, width, subset=None, xcd=None):
@@ -879,6 +904,10 @@ def sddmm_coo(coords, s_data, a, bt, panels=None):
         pad = (16 - (a.shape[1] * esz) % 16) // esz  # row pitch must be 16-byte aligned
         a = torch.nn.functional.pad(a, (0, pad))
         bt = torch.nn.functional.pad(bt, (0, pad))
+    if a.data_ptr() % 16:      # the kernels load 16-byte vectors: a view at an odd storage offset is copied once
+        a = a.clone()
+    if bt.data_ptr() % 16:
+        bt = bt.clone()
     rows, cols = coords[0].contiguous(), coords[1].contiguous()
     if not index_dtype_ok(rows):
         rows, cols = rows.to(torch.int64), cols.to(torch.int64)
@@ -951,6 +980,8 @@ def sddmm_coo_mfma(plan, coords, shape, s_data, a, bt, out=None, force=False, re
     if not force and plan.n_dense_samples < SDDMM_MFMA_MIN_SHARE * plan.nnz:
         return None
     a, bt = a.contiguous(), bt.contiguous()
+    if a.data_ptr() % 16 or bt.data_ptr() % 16:
+        return None     # the tile kernel loads 16-byte operand fragments (a view at an odd storage offset): sampled kernel
     s_orig, s_data = s_data, s_data.to(torch.float32).contiguous()
     rows, cols = coords[0].contiguous(), coords[1].contiguous()
     if not index_dtype_ok(rows):

@@ -68,6 +68,71 @@ def _scalar_dev(value, dtype, dev):
     return torch.tensor([value], dtype=dtype, device=dev)
 
 
+def _device_reducible(x, name, dtype, kwargs):
+    """Whether the grouped-reduce kernels cover this reduction: one of the eight table ufuncs, value and result dtypes
+    the kernels are instantiated for, no keyword besides `dtype`."""
+    if name not in _RED_OPS or kwargs:
+        return False
+    if x.data.dtype not in K._CODE_T:
+        return False
+    return dtype is None or torch_dtype_or_none(dtype) in K._CODE_T
+
+
+def torch_dtype_or_none(dt):
+    try:
+        return torch_dtype(dt)
+    except (KeyError, TypeError):
+        return None
+
+
+def _reduce_on_host(x, method, axis, keepdims, kwargs, out_gcxs):
+    """Any other binary ufunc (bitwise_or, hypot, ...), complex or narrow value dtypes, extra keywords: the reference's
+    own algorithm (`COO._reduce_calc` + `_grouped_reduce`, _coo/core.py:693-723,1631-1661, and the fill fold-in of
+    `SparseArray.reduce`, _sparse_array.py:398-423) with `ufunc.reduceat` evaluated by NumPy on the host over the grouped
+    runs.  The STRUCTURE stays on the device: kept axes first by a key permutation, one stable key sort; only the sorted
+    keys and values cross to the host, the result container is built on the device again."""
+    from ._coo import COO
+
+    kept = tuple(ax for ax in range(x.ndim) if ax not in set(axis))
+    n_groups = prod(x.shape[d] for d in kept)
+    n_cols = prod(x.shape[d] for d in axis)
+    keys, data = x.linear_loc(), x.data
+    order = kept + tuple(axis)
+    if order != tuple(range(x.ndim)) and x.nnz:
+        keys, perm = K.sort_keys(K.permute_keys(keys, x.shape, order), max(x.size - 1, 1))
+        data = K.gather(data, perm)
+    groups = keys.cpu().numpy() // max(n_cols, 1)
+    vals = data.cpu().numpy()
+    heads = np.flatnonzero(np.concatenate(([True], groups[1:] != groups[:-1]))) if groups.size else np.empty(0, np.intp)
+    counts = np.diff(np.concatenate((heads, [groups.size]))) if groups.size else np.empty(0, np.intp)
+    fv = x.fill_value
+    super_ufunc = _SUPER.get(getattr(method, "__name__", None))
+    with np.errstate(all="ignore"):
+        red = method.reduceat(vals, heads, **kwargs)
+        result_fill = fv
+        if super_ufunc is None:
+            missing = counts != n_cols
+            red[missing] = method(red[missing], fv, **kwargs)
+        else:
+            n_fill = n_cols - counts
+            contribution = super_ufunc(fv, n_fill)
+            if method.identity is not None:   # no implicit entries in the group: the identity, not super(fill, 0)
+                contribution = np.where(n_fill == 0, method.identity, contribution)
+            red = method(red, contribution).astype(red.dtype)
+            result_fill = super_ufunc(fv, n_cols)
+    out = COO(groups[heads][None, :].astype(np.int64), red, shape=(n_groups,), has_duplicates=False, sorted=True,
+              prune=True, fill_value=result_fill, device=x.device)
+    out = out.reshape(tuple(x.shape[d] for d in kept))
+    if keepdims:
+        shape = list(x.shape)
+        for ax in axis:
+            shape[ax] = 1
+        out = out.reshape(shape)
+    if out.ndim == 0:
+        return COO.from_numpy(out.todense_device())
+    return out.asformat("gcxs") if out_gcxs else out
+
+
 def reduce_impl(x, method, axis=(0,), keepdims=False, **kwargs):
     from ._coo import COO
     from ._gcxs import GCXS
@@ -76,19 +141,22 @@ def reduce_impl(x, method, axis=(0,), keepdims=False, **kwargs):
     out_gcxs = isinstance(x, GCXS)
     if out_gcxs:
         x = x.tocoo()
-    dtype = kwargs.pop("dtype", None)
     kwargs.pop("out", None)
-    if kwargs:
-        raise NotImplementedError(f"unsupported reduce kwargs {sorted(kwargs)}")
     axis = normalize_axis(axis, x.ndim)
     fv = x.fill_value
-    zero_reduce_result = method.reduce([fv, fv]) if dtype is None else method.reduce([fv, fv], dtype=dtype)
+    zero_reduce_result = method.reduce([fv, fv], **kwargs)
     super_ufunc = _SUPER.get(name)
     if not equivalent(zero_reduce_result, fv) and super_ufunc is None:
         raise ValueError(f"Performing this reduction operation would produce a dense result: {method!s}")
-    if name not in _RED_OPS:
-        raise NotImplementedError(f"reduction with {method!s} is not on the hip backend's path "
-                                  f"(supported: {sorted(_RED_OPS)})")
+    dtype = kwargs.pop("dtype", None)
+    if not _device_reducible(x, name, dtype, kwargs):
+        if dtype is not None:
+            kwargs["dtype"] = dtype
+        if not isinstance(axis, tuple):
+            axis = (axis,)
+        if axis == (None,):
+            axis = tuple(range(x.ndim))
+        return _reduce_on_host(x, method, axis, keepdims, kwargs, out_gcxs)
     if not isinstance(axis, tuple):
         axis = (axis,)
     if axis == (None,):
@@ -135,8 +203,6 @@ def reduce_impl(x, method, axis=(0,), keepdims=False, **kwargs):
         vcode = _ffi.U8 if vals.dtype == torch.uint8 else code_of(vals.dtype)
         fvn = np.asarray(result_fill if super_ufunc is None else fv)
         with np.errstate(all="ignore"):
-            if fvn.dtype.kind == "c":
-                raise NotImplementedError("complex reductions are not on the hip backend's path")
             fill_f = float(fvn.astype(np.float64)) if fvn.dtype.kind != "b" else float(bool(fvn))
             fill_i = int(fvn.astype(res_np_dtype if res_np_dtype.kind in "iu" else np.int64)) if np.isfinite(fill_f) else 0
         vals = vals.contiguous()

@@ -114,65 +114,87 @@ class SparseArray:
         return np.asarray(self.todense(), *args, **kwargs)
 
     # ---- NumPy protocols ---------------------------------------------------------------
+    # The two dispatch hooks below reproduce the observable behaviour of the reference's hooks
+    # (sparse/numba_backend/_sparse_array.py:282-370, BSD-3-Clause, (c) the pydata/sparse developers): which package
+    # function a NumPy function resolves to, which exceptions an illegal `out=` raises, how `outer` is expressed as a
+    # broadcast call.  The bodies are this package's own.
     def __array_function__(self, func, types, args, kwargs):
-        """Route `np.<func>(sparse, ...)` to the same-named function of this package
-        (reference _sparse_array.py:282-308)."""
-        import sparse_amd as module
+        """`np.<func>(sparse, ...)` -> the function of the same dotted name in this package, else an attribute of the
+        container class (a method is called with the original arguments, a property is read for the one-argument
+        form `np.<name>(x)`), else `NotImplemented`."""
+        import sparse_amd
 
-        sparse_func = None
-        try:
-            submodules = getattr(func, "__module__", "numpy").split(".")[1:]
-            for sub in submodules:
-                module = getattr(module, sub)
-            sparse_func = getattr(module, func.__name__)
-        except AttributeError:
-            pass
-        else:
-            return sparse_func(*args, **kwargs)
-        try:
-            sparse_func = getattr(type(self), func.__name__)
-        except AttributeError:
-            pass
-        if not isinstance(sparse_func, property) and callable(sparse_func):
-            return sparse_func(*args, **kwargs)
-        if sparse_func is None:
+        where = sparse_amd
+        for part in getattr(func, "__module__", "numpy").split(".")[1:]:   # numpy.linalg.x -> sparse_amd.linalg.x
+            where = getattr(where, part, None)
+            if where is None:
+                break
+        target = getattr(where, func.__name__, None) if where is not None else None
+        if target is not None:
+            return target(*args, **kwargs)
+        member = getattr(type(self), func.__name__, None)
+        if member is None:
             return NotImplemented
-        return sparse_func.__get__(self)
+        if callable(member):
+            return member(*args, **kwargs)
+        if len(args) == 1 and not kwargs:
+            return getattr(self, func.__name__)
+        return NotImplemented
+
+    @staticmethod
+    def _check_out_casting(ufunc, method, inputs, out, kwargs):
+        """An `out=` whose dtype the ufunc may not cast into must fail BEFORE any work, with NumPy's own exception
+        (`UFuncTypeError`): NumPy itself is asked, on one-element stand-ins of the operands' dtypes
+        (reference _sparse_array.py:333-342)."""
+        probe = [np.empty((1,), dtype=v.dtype) if hasattr(v, "dtype") else v for v in inputs]
+        probe_out = tuple(np.empty((1,), dtype=o.dtype) for o in out)
+        kw = dict(kwargs)
+        if method == "reduce":
+            kw["axis"] = None
+        getattr(ufunc, method)(*probe, out=probe_out[0] if len(probe_out) == 1 else probe_out, **kw)
+
+    @staticmethod
+    def _outer_as_broadcast(inputs):
+        """`ufunc.outer(a, b, ...)` as a broadcasting call: operand i keeps its own axes and gets one trailing unit
+        axis for every axis of the operands AFTER it, so the result's axes are a's, then b's, ...
+        (reference _sparse_array.py:343-352)."""
+        trailing = 0
+        shaped = []
+        for v in reversed(inputs):
+            shaped.append(v[(Ellipsis,) + (None,) * trailing])
+            trailing += v.ndim
+        return tuple(reversed(shaped))
 
     def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
-        """`np.<ufunc>(...)` with a sparse operand: "__call__" -> elemwise, "reduce" -> reduce
-        (reference _sparse_array.py:322-370)."""
+        """`np.<ufunc>(...)` with a sparse operand: "__call__" and "outer" -> elemwise, "reduce" -> reduce, generalised
+        ufuncs (matmul, ...) -> `__array_function__`, anything else `NotImplemented` (reference
+        _sparse_array.py:322-370)."""
         from ._umath import elemwise
 
         out = kwargs.pop("out", None)
-        if out is not None and not all(isinstance(x, type(self)) for x in out):
+        if out is not None and not all(isinstance(o, type(self)) for o in out):
             return NotImplemented
         if getattr(ufunc, "signature", None) is not None:
             return self.__array_function__(ufunc, (np.ndarray, type(self)), inputs, kwargs)
         if out is not None:
+            SparseArray._check_out_casting(ufunc, method, inputs, out, kwargs)
             kwargs["dtype"] = out[0].dtype
         if method == "outer":
-            method = "__call__"
-            cum_ndim = 0
-            inputs_transformed = []
-            for inp in inputs:
-                inputs_transformed.append(inp[(Ellipsis,) + (None,) * cum_ndim])
-                cum_ndim += inp.ndim
-            inputs = tuple(inputs_transformed)
+            inputs, method = SparseArray._outer_as_broadcast(inputs), "__call__"
         if method == "__call__":
             result = elemwise(ufunc, *inputs, **kwargs)
         elif method == "reduce":
             result = SparseArray._reduce(ufunc, *inputs, **kwargs)
         else:
             return NotImplemented
-        if out is not None:
-            (out,) = out
-            if out.shape != result.shape:
-                raise ValueError(f"non-broadcastable output operand with shape {out.shape} "
-                                 f"doesn't match the broadcast shape {result.shape}")
-            out._make_shallow_copy_of(result)
-            return out
-        return result
+        if out is None:
+            return result
+        (target,) = out
+        if target.shape != result.shape:
+            raise ValueError(f"non-broadcastable output operand with shape {target.shape} "
+                             f"doesn't match the broadcast shape {result.shape}")
+        target._make_shallow_copy_of(result)
+        return target
 
     @staticmethod
     def _reduce(method, *args, **kwargs):
@@ -212,27 +234,26 @@ class SparseArray:
         return np.logical_and.reduce(self, out=out, axis=axis, keepdims=keepdims)
 
     def mean(self, axis=None, keepdims=False, dtype=None, out=None):
-        """sum / n in the reference's order of operations (_sparse_array.py:645-723)."""
-        if axis is None:
-            axis = tuple(range(self.ndim))
-        elif not isinstance(axis, tuple):
-            axis = (axis,)
-        den = 1
-        for ax in normalize_axis(axis, self.ndim):
-            den *= self.shape[ax]
-        if dtype is None:
-            if issubclass(self.dtype.type, (np.integer, np.bool_)):
-                dtype = inter_dtype = np.dtype("f8")
-            else:
-                dtype = self.dtype
-                inter_dtype = np.dtype("f4") if issubclass(dtype.type, np.float16) else dtype
+        """Arithmetic mean = sum in an intermediate dtype, divided by the number of reduced positions, cast to the
+        result dtype — the dtype rules are NumPy's `mean` as the reference applies them (_sparse_array.py:645-723):
+        integers and booleans average in float64, float16 sums in float32 and is cast back, an explicit `dtype` is
+        used for both."""
+        axes = tuple(range(self.ndim)) if axis is None else (axis if isinstance(axis, tuple) else (axis,))
+        n_reduced = 1
+        for ax in normalize_axis(axes, self.ndim):
+            n_reduced *= self.shape[ax]
+        if dtype is not None:
+            result_dtype = sum_dtype = dtype
+        elif self.dtype.kind in "iub":
+            result_dtype = sum_dtype = np.dtype("f8")
         else:
-            inter_dtype = dtype
-        num = self.sum(axis=axis, keepdims=keepdims, dtype=inter_dtype)
-        if num.ndim:
-            out_ = np.true_divide(num, den, casting="unsafe")
-            return out_.astype(dtype) if out_.dtype != dtype else out_
-        return np.divide(num, den, dtype=dtype, out=out)
+            result_dtype = self.dtype
+            sum_dtype = np.dtype("f4") if self.dtype == np.dtype("f2") else self.dtype
+        total = self.sum(axis=axes, keepdims=keepdims, dtype=sum_dtype)
+        if total.ndim == 0:
+            return np.divide(total, n_reduced, dtype=result_dtype, out=out)
+        quotient = np.true_divide(total, n_reduced, casting="unsafe")
+        return quotient if quotient.dtype == result_dtype else quotient.astype(result_dtype)
 
     def var(self, axis=None, dtype=None, out=None, ddof=0, keepdims=False):
         """Variance (reference _sparse_array.py:725-814), evaluated per group on the device."""

@@ -471,7 +471,7 @@ def elemwise(func, *args, **kwargs):
             kwargs.pop("casting", None)
             fill = np.asarray(x.fill_value).astype(target)[()]
             return finish(x.linear_loc(), K.convert(x.data, torch_dtype(target)), shape, fill, devi)
-        if name not in _UN or kwargs:
+        if name not in _UN or kwargs or x.data.dtype not in _CODE:   # (complex / narrow value types: host-evaluated func)
             return _elemwise_general(func, proc, kwargs, dtype_kw, finish)
         fill = _np_result(func, np.asarray(x.fill_value))[()]
         data = x.data

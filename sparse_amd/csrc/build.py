@@ -48,12 +48,25 @@ def is_stale():
     return any(os.path.getmtime(p) > t for p in sources() + _deps())
 
 
+def _own_deps(src, obj):
+    """The files `src` really includes, from the compiler's dependency file of the last build (-MD); every header and
+    .inc of csrc/ when there is none yet."""
+    dep = obj[:-2] + ".d"
+    if not os.path.exists(dep):
+        return _deps()
+    words = open(dep).read().replace("\\\n", " ").split()
+    files = [w for w in words[1:] if not w.startswith("/opt/") and not w.startswith("/usr/")]
+    if any(not os.path.exists(f) for f in files):
+        return _deps()
+    return files + [os.path.abspath(__file__)]
+
+
 def _compile(src, force):
     obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
-    newest = max(os.path.getmtime(p) for p in [src] + _deps())
+    newest = max(os.path.getmtime(p) for p in [src] + _own_deps(src, obj))
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
         return obj, ""
-    cmd = [_hipcc(), *CXXFLAGS, "-c", src, "-o", obj]
+    cmd = [_hipcc(), *CXXFLAGS, "-MD", "-MF", obj[:-2] + ".d", "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")

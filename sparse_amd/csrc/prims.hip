@@ -287,16 +287,46 @@ __global__ void __launch_bounds__(256) rows_to_indptr_kernel(const I* __restrict
 }
 
 // The same from the elements' side: element e opens every row in (rows[e-1], rows[e]] (and the last element closes the
-// rest): one coalesced pass over the row ids instead of R + 1 binary searches of ~log2(nnz) dependent loads each.
+// rest): one coalesced pass over the row ids instead of R + 1 binary searches of ~log2(nnz) dependent loads each.  Row ids
+// are clamped to [0, R] (a container built with sorted=True / has_duplicates=False is trusted, as in the reference, and may
+// carry anything: never a store outside the R + 1 pointers), and an empty stretch of more than 32 rows is filled by the
+// whole wave instead of by the one lane that found it.
 template <typename I>
 __global__ void __launch_bounds__(256) rows_to_indptr_fill_kernel(const I* __restrict__ rows, int64_t nnz, int64_t R,
                                                                   int64_t* __restrict__ indptr) {
-  GRID_STRIDE(e, nnz) {
-    const int64_t r = (int64_t)rows[e];
-    const int64_t rp = e > 0 ? (int64_t)rows[e - 1] : -1;
-    for (int64_t j = rp + 1; j <= r; ++j) indptr[j] = e;
-    if (e == nnz - 1)
-      for (int64_t j = r + 1; j <= R; ++j) indptr[j] = nnz;
+  const int lane = threadIdx.x & 63;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  auto clampr = [R](int64_t r) { return r < 0 ? (int64_t)0 : (r > R ? R : r); };
+  for (int64_t base = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63); base < nnz; base += stride) {   // wave-uniform trips
+    const int64_t e = base + lane;
+    const bool valid = e < nnz;
+    int64_t first = 1, last = 0;     // rows [first, last] get the value e
+    if (valid) {
+      last = clampr((int64_t)rows[e]);
+      first = e > 0 ? clampr((int64_t)rows[e - 1]) + 1 : 0;
+    }
+    const bool wide = last - first >= 32;
+    if (!wide)
+      for (int64_t j = first; j <= last; ++j) indptr[j] = e;
+    // the rows after the last element
+    int64_t tfirst = 1, tlast = 0;
+    if (valid && e == nnz - 1) { tfirst = last + 1; tlast = R; }
+    const bool twide = tlast - tfirst >= 32;
+    if (!twide)
+      for (int64_t j = tfirst; j <= tlast; ++j) indptr[j] = nnz;
+    unsigned long long m = __ballot(wide);
+    while (m) {
+      const int src = __builtin_ctzll(m);
+      m &= m - 1;
+      const int64_t a = __shfl(first, src, 64), b = __shfl(last, src, 64), v = __shfl(e, src, 64);
+      for (int64_t j = a + lane; j <= b; j += 64) indptr[j] = v;
+    }
+    m = __ballot(twide);
+    if (m) {
+      const int src = __builtin_ctzll(m);
+      const int64_t a = __shfl(tfirst, src, 64), b = __shfl(tlast, src, 64);
+      for (int64_t j = a + lane; j <= b; j += 64) indptr[j] = nnz;
+    }
   }
 }
 
@@ -343,12 +373,24 @@ using namespace spamd;
     default: return SPAMD_ETYPE;                               \
   }
 
+// 16-byte elements (complex128 values) move and compare as two 64-bit words
+struct alignas(16) Bits128 {
+  uint64_t lo, hi;
+  __host__ __device__ bool operator==(const Bits128& o) const { return lo == o.lo && hi == o.hi; }
+  __host__ __device__ bool operator!=(const Bits128& o) const { return lo != o.lo || hi != o.hi; }
+};
+template <typename U>
+static inline U fill_word(uint64_t lo, uint64_t) { return (U)lo; }
+template <>
+inline Bits128 fill_word<Bits128>(uint64_t lo, uint64_t hi) { return Bits128{lo, hi}; }
+
 #define SPAMD_BYTES_SWITCH(elem_bytes, U, ...)                  \
   switch (elem_bytes) {                                        \
     case 1: { using U = uint8_t; __VA_ARGS__; } break;         \
     case 2: { using U = uint16_t; __VA_ARGS__; } break;        \
     case 4: { using U = uint32_t; __VA_ARGS__; } break;        \
     case 8: { using U = uint64_t; __VA_ARGS__; } break;        \
+    case 16: { using U = Bits128; __VA_ARGS__; } break;        \
     default: return SPAMD_ETYPE;                               \
   }
 
@@ -442,23 +484,25 @@ extern "C" int spamd_flag_heads(int64_t n, const int64_t* keys, int64_t* flags, 
   return launch_status();
 }
 
-extern "C" int spamd_flag_ne_bits(int elem_bytes, int64_t n, const void* data, uint64_t fill_bits, int64_t* flags,
-                                  void* stream) {
+extern "C" int spamd_flag_ne_bits(int elem_bytes, int64_t n, const void* data, uint64_t fill_bits, uint64_t fill_bits_hi,
+                                  int64_t* flags, void* stream) {
   if (n < 0) return SPAMD_EINVAL;
   if (n == 0) return 0;
   SPAMD_BYTES_SWITCH(elem_bytes, U, hipLaunchKernelGGL(flag_ne_bits_kernel<U>, dim3(grid_for(n)), dim3(256), 0,
-                                                       (hipStream_t)stream, (const U*)data, n, (U)fill_bits, flags))
+                                                       (hipStream_t)stream, (const U*)data, n,
+                                                       fill_word<U>(fill_bits, fill_bits_hi), flags))
   return launch_status();
 }
 
-extern "C" int spamd_count_eq_bits(int elem_bytes, int64_t n, const void* data, uint64_t fill_bits, int64_t* count,
-                                   void* stream) {
+extern "C" int spamd_count_eq_bits(int elem_bytes, int64_t n, const void* data, uint64_t fill_bits, uint64_t fill_bits_hi,
+                                   int64_t* count, void* stream) {
   if (n < 0) return SPAMD_EINVAL;
   hipError_t e = hipMemsetAsync(count, 0, sizeof(int64_t), (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
   if (n == 0) return 0;
   SPAMD_BYTES_SWITCH(elem_bytes, U, hipLaunchKernelGGL(count_eq_bits_kernel<U>, dim3(grid_for(n)), dim3(256), 0,
-                                                       (hipStream_t)stream, (const U*)data, n, (U)fill_bits,
+                                                       (hipStream_t)stream, (const U*)data, n,
+                                                       fill_word<U>(fill_bits, fill_bits_hi),
                                                        reinterpret_cast<unsigned long long*>(count)))
   return launch_status();
 }

@@ -232,11 +232,12 @@ __global__ void __launch_bounds__(256) tl_fill_kernel(int64_t M, int ntiles, con
 // ---- fused inspector: count + scan + fill in ONE pass over A ------------------------------------------------------------
 // The two-pass builder reads the indices twice, scans the 1.8 M list sizes in a separate launch, clears the 0.87 GB stream
 // with a memset and needs the host to read the total before it can allocate.  Here one workgroup per row group counts its
-// (row, tile) runs in LDS, scans its tiles' block counts locally, obtains its first block from its predecessors by
-// decoupled look-back (groups are taken in ticket order, so a group only ever waits for groups that are already running),
-// writes its slice of blk_off, fills its lists and zeroes their padding entries itself.  The stream is allocated for the
-// upper bound ceil(nnz / EPB) + lists (every list wastes less than one block).  state[groups] = ticket counter,
-// state[groups + 1] = "a row has unsorted column indices" (the caller then takes the key-sort recipe).
+// (row, tile) runs in LDS, scans its tiles' block counts locally, takes its first block from a CLOSED FORM of the row
+// pointers (tl_group_first_block: an upper bound of what the groups before it need, so groups are independent: no ticket,
+// no look-back), writes its tiles + 1 entries of blk_off, fills its lists and zeroes their padding entries and the gap
+// in front of the next group itself.  The stream is allocated for the upper bound ceil(nnz / EPB) + lists (every list
+// wastes less than one block).  state = ONE 64-bit word: non-zero = "a row has unsorted column indices" (the caller then
+// takes the key-sort recipe; the groups that met such a row wrote zero entries, see group_bad).
 __host__ __device__ inline int64_t tl_group_first_block(int64_t e0, int64_t g, int64_t ntiles, int64_t epb) {
   return (e0 + g * ntiles * (epb - 1) + epb - 1) / epb;
 }
@@ -249,6 +250,7 @@ __global__ void __launch_bounds__(256) tl_inspect_kernel(int64_t M, int ntiles, 
   extern __shared__ int tl_fill_lds[];  // before[RG][ntiles], runstart[RG][ntiles] (relative to e0), loff[ntiles + 1]
   __shared__ int64_t rs[TL_RG + 1];
   __shared__ int wtot[5];
+  __shared__ int group_bad;   // a row of THIS group has unsorted column indices: its lists are written as zeros
   constexpr int EPB = TlFmt<T>::EPB;
   int* const before = tl_fill_lds;
   int* const runstart = before + TL_RG * ntiles;
@@ -261,6 +263,7 @@ __global__ void __launch_bounds__(256) tl_inspect_kernel(int64_t M, int ntiles, 
     rs[tid] = (int64_t)indptr[r < M ? r : M];
   }
   for (int i = tid; i < TL_RG * ntiles; i += 256) before[i] = 0;
+  if (tid == 0) group_bad = 0;
   __syncthreads();
   const int64_t e0 = rs[0], e1 = rs[TL_RG];
   bool bad = false;
@@ -310,7 +313,10 @@ __global__ void __launch_bounds__(256) tl_inspect_kernel(int64_t M, int ntiles, 
     for (int64_t e = ra + lane + 64 * TL_PRE; e < rb; e += 64)
       count_one(lr, ra, e, (unsigned)indices[e], (unsigned)indices[e - 1], false);
   }
-  if (bad) atomicOr(&state[0], 1ull);
+  if (bad) {
+    atomicOr(&state[0], 1ull);
+    group_bad = 1;
+  }
   __syncthreads();
   // per tile: elements of the tile in earlier rows of the group; blocks of the list
   int nb = 0, cnt_t = 0;
@@ -353,6 +359,15 @@ __global__ void __launch_bounds__(256) tl_inspect_kernel(int64_t M, int ntiles, 
   if (tid < ntiles) blk_off[g * (ntiles + 1) + tid] = (int)(goff + my_off);
   if (tid == 0) blk_off[g * (ntiles + 1) + ntiles] = (int)(goff + gtotal);
   for (int64_t i = (goff + gtotal) * TL_BLOCK_INTS + tid; i < gnext * TL_BLOCK_INTS; i += 256) stream[i] = 0;
+  if (group_bad) {
+    // With unsorted columns a (row, tile) run is not contiguous in the row: `runstart` holds whichever run wrote last, so
+    // the slot arithmetic below could leave this group's range (even the allocation) and would leave other slots
+    // unwritten.  The per-tile COUNTS do not depend on the order, so the group's lists are well-formed; they are written
+    // as zero entries (harmless to the executor: they accumulate into the junk register pair).  The caller sees state[0]
+    // and rebuilds the layout by the key-sort recipe; until then nothing downstream reads garbage.
+    for (int64_t i = goff * TL_BLOCK_INTS + tid; i < (goff + gtotal) * TL_BLOCK_INTS; i += 256) stream[i] = 0;
+    return;
+  }
   // fill (a wave per row again; the preloaded elements come from registers)
   auto fill_one = [&](int lr, int64_t e, unsigned c, T v) {
     const int t = (int)(c / (unsigned)TL_KB);

@@ -21,7 +21,9 @@ def inputs():
     return dict(x=x, y=y, z=z, xn=xn, yb=arr(16, 0.6, (6, 1)), zb=arr(17, 0.7, (7,)), dense=arr(18, 1.0, SHAPE, lo=0.5),
                 dense_row=arr(19, 1.0, (7,), lo=0.5), big=arr(20, 1.0, (2,) + SHAPE),
                 a4=arr(21, 0.5, (3, 1, 4, 5)), b4=arr(22, 0.5, (1, 2, 5, 6)), a3=arr(23, 0.5, (1, 4, 5)), b3=arr(24, 0.5, (3, 5, 6)),
-                c3=arr(25, 0.5, (3, 4, 5)), d3=arr(26, 0.5, (1, 5, 6)), dn=arr(27, 1.0, (3, 4, 5)), d4=arr(28, 1.0, (1, 2, 5, 6)))
+                c3=arr(25, 0.5, (3, 4, 5)), d3=arr(26, 0.5, (1, 5, 6)), dn=arr(27, 1.0, (3, 4, 5)), d4=arr(28, 1.0, (1, 2, 5, 6)),
+                xi=(arr(29, 0.5, lo=0.1) * 100).astype(np.int64), xc=arr(30, 0.4) + 1j * arr(31, 0.4),
+                o1=arr(32, 0.5, (3, 4)), o2=arr(33, 0.6, (5,)))
 
 
 def _coo(sp, a):
@@ -73,6 +75,21 @@ CASES = [
     ("matmul dense (3,4,5) @ sparse (1,5,6)", lambda sp, i: sp.matmul(i["dn"], _coo(sp, i["d3"]))),
     ("matmul dense (3,4,5) @ sparse (3,5,6)", lambda sp, i: sp.matmul(i["dn"], _coo(sp, i["b3"]))),
     ("matmul (3,4,5) @ dense (5,6)", lambda sp, i: sp.matmul(_coo(sp, i["c3"]), i["d3"][0])),
+    # round 3: the protocol surface (`ufunc.outer`, `out=`) and reductions beyond the device kernels' table
+    ("subtract.outer of two COO", lambda sp, i: np.subtract.outer(_coo(sp, i["o1"]), _coo(sp, i["o2"]))),
+    ("multiply.outer, second operand first", lambda sp, i: np.multiply.outer(_coo(sp, i["o2"]), _coo(sp, i["o1"]))),
+    ("bitwise_or.reduce", lambda sp, i: np.bitwise_or.reduce(_coo(sp, i["xi"]), axis=1)),
+    ("bitwise_xor.reduce over two axes", lambda sp, i: np.bitwise_xor.reduce(_coo(sp, i["xi"]), axis=(0, 2))),
+    ("hypot.reduce", lambda sp, i: np.hypot.reduce(_coo(sp, i["x"]), axis=2)),
+    ("hypot.reduce gcxs, keepdims", lambda sp, i: np.hypot.reduce(sp.GCXS.from_numpy(i["y"]), axis=0, keepdims=True)),
+    ("complex sum over an axis", lambda sp, i: _coo(sp, i["xc"]).sum(axis=0)),
+    ("complex sum of everything", lambda sp, i: _coo(sp, i["xc"]).sum()),
+    ("complex prod with a fill value", lambda sp, i: (_coo(sp, i["xc"]) + (1 + 0.5j)).prod(axis=(1, 2))),
+    ("int16 max", lambda sp, i: _coo(sp, i["xi"].astype(np.int16)).max(axis=1)),
+    ("illegal out= cast", lambda sp, i: np.add(_coo(sp, i["x"]), _coo(sp, i["y"]), out=_coo(sp, i["xi"]))),
+    ("legal out=", lambda sp, i: np.add(_coo(sp, i["x"]), _coo(sp, i["y"]), out=_coo(sp, i["z"]))),
+    ("out= of the wrong shape", lambda sp, i: np.add(_coo(sp, i["x"]), _coo(sp, i["y"]), out=_coo(sp, i["o1"]))),
+    ("reduce with out= of another dtype", lambda sp, i: np.add.reduce(_coo(sp, i["x"]), axis=0, out=_coo(sp, i["xi"][0]))),
 ]
 
 

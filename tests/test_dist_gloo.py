@@ -138,6 +138,114 @@ def test_sharded_sddmm_plumbing_world2():
     assert per_rank == ret[1] and abs(per_rank[0] - per_rank[1]) <= 157 + 1   # nnz-balanced up to one (long) row
 
 
+class _Block:
+    """Host stand-in for a rank's GCXS row block (this container has no HIP device, so the real container cannot be
+    built): carries the CSR triplet and multiplies through the ORACLE.  What runs unmodified is `sparse_amd._dist`."""
+
+    compressed_axes = (0,)
+    ndim = 2
+
+    def __init__(self, arg, shape, compressed_axes=(0,), **_):
+        self.data, self.indices, self.indptr = arg
+        self.shape = tuple(shape)
+
+    def __matmul__(self, other):
+        from oracle import oracle
+
+        n = lambda t: t.numpy() if isinstance(t, torch.Tensor) else np.asarray(t)   # noqa: E731
+        return oracle.dot_csr_csr((self.shape[0], other.shape[1]), n(self.data), n(other.data), n(self.indices),
+                                  n(other.indices), n(self.indptr), n(other.indptr))
+
+
+def _worker_calls_dist(rank, world, port, ret):
+    """`sharded_spmm`, `sharded_spgemm` and `sharded_sddmm` THEMSELVES (not a restatement of their bodies) at world size
+    2: only the local product of each is replaced by the oracle / NumPy."""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle
+    from sparse_amd import _api, _dist, _dot, _gcxs
+
+    calls = {"matmul": 0, "prepare": 0, "sddmm": 0}
+
+    def fake_matmul(a, b):
+        calls["matmul"] += 1
+        return oracle.dot_csr_ndarray((a.shape[0], b.shape[1]), a.data.numpy(), a.indices.numpy(), a.indptr.numpy(), b.numpy())
+
+    def fake_prepare(a, b_like):
+        calls["prepare"] += 1
+
+    def fake_sddmm(s, a, bt=None):
+        calls["sddmm"] += 1
+        rows = np.repeat(np.arange(s.shape[0]), np.diff(s.indptr.numpy()))
+        return s.data.numpy() * np.einsum("ik,ik->i", a.numpy()[rows], bt.numpy()[s.indices.numpy()])
+
+    _dot.matmul, _dot.prepare_operand, _api.sddmm, _gcxs.GCXS = fake_matmul, fake_prepare, fake_sddmm, _Block
+
+    # ---- sharded_spmm: ragged B (301 rows over 2 ranks), static B gathered once, changed B gathered again
+    M, K, N = 501, 301, 6
+    data, idx, ptr = random_csr(M, K, 0.05, 9, np.float64, np.int64, empty_rows=(0, 1, 2), long_row=77)
+    b = random_dense(K, N, 10, np.float64)
+    tptr = torch.from_numpy(ptr)
+    bounds = _dist.partition_rows_by_nnz(tptr, world)
+    d, i, p, r0, r1 = _dist.shard_csr(torch.from_numpy(data), torch.from_numpy(idx), tptr, rank, world, bounds)
+    a_local = _Block((d, i, p), (r1 - r0, K))
+    b_shard = _dist.row_shard(torch.from_numpy(b), rank, world).clone()
+    whole = oracle.dot_csr_ndarray((M, N), data, idx, ptr, b)
+    gathers = {"n": 0}
+    real_start = _dist._start_gather_rows
+
+    def counting_start(*a, **k):
+        gathers["n"] += 1
+        return real_start(*a, **k)
+
+    _dist._start_gather_rows = counting_start
+    for _ in range(3):
+        assert np.array_equal(_dist.sharded_spmm(a_local, b_shard, K), whole[r0:r1])
+    assert gathers["n"] == 1 and calls["matmul"] == 3 and calls["prepare"] == 3, (gathers, calls)
+    b_shard *= 2.0                                   # in-place update on every rank: the version counter changes
+    assert np.array_equal(_dist.sharded_spmm(a_local, b_shard, K), oracle.dot_csr_ndarray((M, N), data, idx, ptr, 2.0 * b)[r0:r1])
+    assert gathers["n"] == 2
+    _dist._start_gather_rows = real_start
+
+    # ---- sharded_spgemm: B's CSR triplet gathered (rebased pointers), local product by the oracle's Gustavson loop
+    n2 = 157
+    bd, bi, bp = random_csr(n2, n2, 0.07, 21, np.float64, np.int64, empty_rows=(0, n2 - 1), long_row=60)
+    tbp = torch.from_numpy(bp)
+    bb = _dist.partition_rows_by_nnz(tbp, world)
+    sd, si, sp_, s0, s1 = _dist.shard_csr(torch.from_numpy(bd), torch.from_numpy(bi), tbp, rank, world, bb)
+    got = _dist.sharded_spgemm(_Block((sd, si, sp_), (s1 - s0, n2)), _Block((sd, si, sp_), (s1 - s0, n2)))
+    want = oracle.dot_csr_csr((s1 - s0, n2), sd.numpy(), bd, si.numpy(), bi, sp_.numpy(), bp)
+    assert all(np.array_equal(x, y) for x, y in zip(got, want))
+
+    # ---- sharded_sddmm: mask rows and A rows co-sharded, Bt gathered
+    Ms, Nc, Kd = 211, 157, 24
+    md, mi, mp_ = random_csr(Ms, Nc, 0.06, 31, np.float64, np.int64, empty_rows=(5, 6), long_row=100)
+    a = random_dense(Ms, Kd, 32, np.float64)
+    bt = random_dense(Nc, Kd, 33, np.float64)
+    tmp = torch.from_numpy(mp_)
+    mb = _dist.partition_rows_by_nnz(tmp, world)
+    xd, xi, xp, m0, m1 = _dist.shard_csr(torch.from_numpy(md), torch.from_numpy(mi), tmp, rank, world, mb)
+    got = _dist.sharded_sddmm(_Block((xd, xi, xp), (m1 - m0, Nc)), torch.from_numpy(a[m0:m1]),
+                              _dist.row_shard(torch.from_numpy(bt), rank, world), Nc)
+    rows_g = np.repeat(np.arange(Ms), np.diff(mp_))
+    assert np.array_equal(got, (md * np.einsum("ik,ik->i", a[rows_g], bt[mi]))[mp_[m0]:mp_[m1]]) and calls["sddmm"] == 1
+    ret[rank] = True
+    dist.destroy_process_group()
+
+
+def test_sharded_products_themselves_world2():
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_calls_dist, args=(2, port, ret), nprocs=2, join=True)
+    assert len(ret) == 2
+
+
 def test_partition_rows_by_nnz_strong_scaling_balance():
     """bench.py --scaling strong splits ONE matrix into nnz-balanced row blocks: at 8 blocks of a uniform matrix the
     heaviest block is within one row of the mean."""

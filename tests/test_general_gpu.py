@@ -34,8 +34,10 @@ def test_case_matches_the_reference(k):
         assert np.array_equal(got["dense"], want, equal_nan=True), name
     if kind == "sparse":
         assert got["cls"] == str(G[f"c{k}_cls"]), name
-        assert np.allclose(np.asarray(got["fill"], dtype=np.float64), np.asarray(G[f"c{k}_fill"], dtype=np.float64),
+        wide = np.complex128 if np.iscomplexobj(G[f"c{k}_fill"]) else np.float64
+        assert np.allclose(np.asarray(got["fill"], dtype=wide), np.asarray(G[f"c{k}_fill"], dtype=wide),
                            rtol=1e-12, atol=0, equal_nan=True), name
+        assert np.asarray(got["fill"]).dtype == G[f"c{k}_fill"].dtype, name
         if "var" not in name and "std" not in name:   # (a variance that cancels to 0 exactly in one order need not in another)
             assert got["nnz"] == int(G[f"c{k}_nnz"]), name
 

@@ -1,0 +1,205 @@
+"""Round-3 additions: config 5's per-GPU share against the oracle on sampled rows, the NumPy protocol surface
+(`ufunc.outer`, `out=` casting), reductions with ufuncs outside the device kernels' table, complex values, and the
+robustness fixes of the round (unsorted column indices reaching the one-pass inspector, out-of-range row ids)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+@pytest.fixture(scope="module")
+def sp():
+    import sparse_amd
+
+    return sparse_amd
+
+
+def test_config5_share_against_the_oracle_on_sampled_rows(orc, sp):
+    """One of the 8 row blocks of config 5 — GCXS(125000 x 10^6) @ GCXS(10^6 x 10^6 @ 1e-4): 1.25e9 products, a result
+    with more than 2^30 stored elements (int64 row pointers) — against the oracle's restatement of `_dot_csr_csr`
+    (_common.py:639-717) on 256 sampled rows: column indices bit for bit (after the canonical per-row sort: the
+    reference emits rows in reverse discovery order, Appendix C.2), values bit for bit as well (the products of an
+    output element are summed left to right in the order of A's elements, the reference's `sums[j] += ...`)."""
+    n, share = 1_000_000, 8
+    gB = sp.random((n, n), density=1e-4, random_state=7, dtype=np.float32, idx_dtype=np.int32, format="gcxs",
+                   compressed_axes=(0,))
+    rows = n // share
+    p1 = int(gB.indptr[rows])
+    gA = sp.GCXS((gB.data[:p1].contiguous(), gB.indices[:p1].contiguous(), gB.indptr[:rows + 1].contiguous()),
+                 shape=(rows, n), compressed_axes=(0,))
+    c = gA @ gB
+    assert isinstance(c, sp.GCXS) and c.shape == (rows, n) and c.compressed_axes == (0,)
+    assert c.indptr.dtype == torch.int64 and c.nnz > 2 ** 30
+    pick = np.sort(np.random.default_rng(3).choice(rows, size=256, replace=False))
+    hA = [t.cpu().numpy() for t in (gA.data, gA.indices, gA.indptr)]
+    hB = [t.cpu().numpy() for t in (gB.data, gB.indices, gB.indptr)]
+    segs = [np.arange(hA[2][r], hA[2][r + 1]) for r in pick]
+    sub_ptr = np.zeros(len(pick) + 1, dtype=hA[2].dtype)
+    sub_ptr[1:] = np.cumsum([len(s) for s in segs])
+    sel = np.concatenate(segs)
+    wd, wi, wp = orc.dot_csr_csr((len(pick), n), hA[0][sel], hB[0], hA[1][sel], hB[1], sub_ptr, hB[2])
+    cp = c.indptr.cpu().numpy()
+    for j, r in enumerate(pick):
+        lo, hi = int(cp[r]), int(cp[r + 1])
+        gi, gd = c.indices[lo:hi].cpu().numpy(), c.data[lo:hi].cpu().numpy()
+        o = np.argsort(wi[wp[j]:wp[j + 1]], kind="stable")
+        keep = wd[wp[j]:wp[j + 1]][o].view(np.uint32) != 0      # the GCXS constructor prunes explicit +0.0 results
+        assert np.array_equal(gi, wi[wp[j]:wp[j + 1]][o][keep]), f"row {r}: column indices differ"
+        assert np.array_equal(gd.view(np.uint32), wd[wp[j]:wp[j + 1]][o][keep].view(np.uint32)), f"row {r}: values differ"
+    # the row pointers of the sampled rows' neighbours are consistent with the row lengths the oracle found
+    assert np.array_equal(np.diff(cp)[pick], [int(np.count_nonzero(wd[wp[j]:wp[j + 1]].view(np.uint32))) for j in range(len(pick))])
+
+
+def _dense(shape, seed, density=0.5):
+    r = np.random.default_rng(seed)
+    return np.where(r.random(shape) < density, r.random(shape) - 0.4, 0.0)
+
+
+def test_ufunc_outer_has_numpys_axis_order(sp):
+    """`np.<ufunc>.outer(a, b)`: result axes are a's, then b's (reference _sparse_array.py:343-352)."""
+    a, b, c = _dense((3, 4), 1), _dense((5,), 2), _dense((2, 3), 3)
+    for f in (np.subtract, np.multiply, np.maximum):
+        for x, y in ((a, b), (b, a), (a, c)):
+            got = f.outer(sp.COO.from_numpy(x), sp.COO.from_numpy(y))
+            want = f.outer(x, y)
+            assert got.shape == want.shape and np.array_equal(got.todense(), want)
+    got = np.multiply.outer(sp.GCXS.from_numpy(a), sp.GCXS.from_numpy(c))
+    assert isinstance(got, sp.GCXS) and np.array_equal(got.todense(), np.multiply.outer(a, c))
+
+
+def test_out_casting_is_validated_before_any_work(sp):
+    """An `out=` the ufunc may not cast into raises NumPy's own `UFuncTypeError` (reference _sparse_array.py:333-342);
+    a legal `out=` receives the result and is returned."""
+    x, y = sp.COO.from_numpy(_dense((4, 5), 4)), sp.COO.from_numpy(_dense((4, 5), 5))
+    bad = sp.COO.from_numpy(np.arange(20).reshape(4, 5))
+    with pytest.raises(np._core._exceptions.UFuncTypeError):
+        np.add(x, y, out=bad)
+    with pytest.raises(ValueError):     # the reference's dry run reduces 1-element stand-ins into a 1-element `out`:
+        np.add.reduce(x, axis=None, out=bad.sum())   # NumPy refuses the shape before it looks at the cast (same here)
+    good = sp.COO.from_numpy(np.zeros((4, 5), dtype=np.float32))
+    r = np.add(x, y, out=good)
+    assert r is good and r.dtype == np.float32
+    assert np.array_equal(r.todense(), (x.todense() + y.todense()).astype(np.float32))
+    assert np.add(x, y, out=(good,)) is good
+
+
+@pytest.mark.parametrize("ufunc, dtype", [(np.bitwise_or, np.int64), (np.bitwise_and, np.int32), (np.bitwise_xor, np.int64),
+                                          (np.hypot, np.float64), (np.gcd, np.int64), (np.logaddexp2, np.float32)])
+@pytest.mark.parametrize("axis", [0, (0, 2), None])
+def test_reduce_with_any_binary_ufunc(sp, ufunc, dtype, axis):
+    """Ufuncs outside the grouped-reduce kernels' table take the reference's own algorithm (`ufunc.reduceat` over the
+    grouped runs + fold-in of the implicit fill values, _coo/core.py:1631-1661, _sparse_array.py:398-408); the
+    comparison is NumPy's dense reduction, or the `ValueError` the reference raises when the result would be dense."""
+    d = _dense((4, 5, 6), 7)
+    d = (d * 50).astype(dtype) if np.dtype(dtype).kind == "i" else d.astype(dtype)
+    x = sp.COO.from_numpy(d)
+    fv = x.fill_value
+    dense_result = not np.array_equal(ufunc.reduce([fv, fv]), fv)
+    if dense_result:
+        with pytest.raises(ValueError, match="dense result"):
+            ufunc.reduce(x, axis=axis)
+        return
+    got = ufunc.reduce(x, axis=axis)
+    want = ufunc.reduce(d, axis=axis)
+    assert got.dtype == want.dtype and got.shape == np.shape(want)
+    if np.dtype(dtype).kind == "i":
+        assert np.array_equal(got.todense(), want)
+    else:
+        assert np.allclose(got.todense(), want, rtol=1e-6 if dtype == np.float32 else 1e-13)
+    g = ufunc.reduce(sp.GCXS.from_numpy(d), axis=axis)
+    assert np.array_equal(g.todense(), got.todense())
+
+
+@pytest.mark.parametrize("dtype", [np.complex128, np.complex64])
+def test_complex_values(sp, dtype):
+    """Complex arrays: canonical form, densification, transposition, elementwise arithmetic (host-evaluated function,
+    device structure) and reductions (host `reduceat`), against NumPy on the dense arrays."""
+    d = (_dense((4, 5, 6), 8) + 1j * _dense((4, 5, 6), 9)).astype(dtype)
+    e = (_dense((4, 5, 6), 10) + 1j * _dense((4, 5, 6), 11)).astype(dtype)
+    x, y = sp.COO.from_numpy(d), sp.COO.from_numpy(e)
+    assert x.dtype == dtype and x.nnz == np.count_nonzero(d) and np.array_equal(x.todense(), d)
+    assert np.array_equal(x.transpose((2, 0, 1)).todense(), d.transpose(2, 0, 1))
+    assert np.array_equal((x + y).todense(), d + e) and np.array_equal((x * y).todense(), d * e)
+    assert np.array_equal(np.conj(x).todense(), np.conj(d))
+    tol = dict(rtol=1e-5 if dtype == np.complex64 else 1e-13, atol=1e-6 if dtype == np.complex64 else 1e-14)
+    for axis in (0, (1, 2), None):
+        s = x.sum(axis=axis)
+        assert s.dtype == dtype and np.allclose(s.todense(), d.sum(axis=axis), **tol)
+    assert np.allclose((x + (1 + 2j)).prod(axis=2).todense(), (d + (1 + 2j)).prod(axis=2), **tol)
+    unsorted = sp.COO(np.array([[1, 0, 0], [0, 2, 1]]), np.array([3j, 1 + 1j, 2 - 1j], dtype=dtype), shape=(2, 3),
+                      has_duplicates=False, sorted=False)
+    assert np.array_equal(unsorted.todense(), np.array([[0, 2 - 1j, 1 + 1j], [3j, 0, 0]], dtype=dtype))
+    g = sp.GCXS.from_numpy(d)
+    assert np.array_equal(g.todense(), d) and np.allclose(g.sum(axis=1).todense(), d.sum(axis=1), **tol)
+
+
+def test_unsorted_columns_never_reach_the_executor_as_garbage(sp):
+    """A GCXS built from raw (data, indices, indptr) with UNSORTED column indices inside the rows (the tuple constructor
+    does not sort) and large enough for the inspector/executor path: the one-pass inspector must stay inside its
+    allocation, and the product must be the reference's (the per-row sums do not depend on the order the row is stored
+    in beyond fp re-association; here values are small integers, so exactly)."""
+    from sparse_amd import _kernels
+
+    M, K, N = 70_000, 4096, 128
+    rng = np.random.default_rng(5)
+    per_row = 48
+    cols = np.argsort(rng.random((M, K // 8)), axis=1)[:, :per_row].astype(np.int32) * 8 + rng.integers(0, 8, (M, per_row), dtype=np.int32)
+    data = rng.integers(1, 5, size=(M, per_row)).astype(np.float32)
+    ptr = (np.arange(M + 1) * per_row).astype(np.int32)
+    b = rng.integers(-3, 4, size=(K, N)).astype(np.float32)
+    a = sp.GCXS((data.reshape(-1), cols.reshape(-1), ptr), shape=(M, K), compressed_axes=(0,))
+    got = a @ torch.from_numpy(b).cuda()
+    import scipy.sparse as sps
+
+    want = sps.csr_matrix((data.reshape(-1), cols.reshape(-1), ptr), shape=(M, K)) @ b
+    assert np.array_equal(got.cpu().numpy(), want)
+    lay = getattr(a, "_tiled_layouts", None)
+    assert lay, "this shape must take the inspector/executor path"
+    assert not getattr(next(iter(lay.values())), "group_ends", False), "the layout in use must be the key-sort recipe's"
+    # the one-pass inspector on its own: flags the matrix, and every group that met an unsorted row holds zero entries only
+    direct = _kernels.csr_tiled_layout(a.data, a.indices, a.indptr, M, K, defer_check=True)
+    assert int(direct.pending[0]) != 0
+    rg, kb, gpb, epb, slack, _, _ = _kernels.tiled_params(torch.float32)
+    ntiles = -(-K // kb)
+    off = direct[1].view(-1, ntiles + 1).cpu().numpy()
+    blocks = direct[0].cpu().numpy()
+    assert not blocks[off[0, 0] * 16: off[200, ntiles] * 16].any(), "lists of groups with unsorted rows must be zero entries"
+
+
+def test_rows_to_indptr_ignores_nothing_and_writes_in_bounds(sp):
+    """`rows_to_indptr` on row ids that a trusting constructor let through (sorted=True, has_duplicates=False skip the
+    range check): ids beyond R are clamped, never written past the R + 1 pointers."""
+    from sparse_amd import _kernels
+
+    R = 1000
+    rows = torch.tensor([0, 0, 5, 999, 1500, 4000], dtype=torch.int64, device="cuda")
+    guard = torch.full((R + 1 + 64,), -7, dtype=torch.int64, device="cuda")
+    ptr = _kernels.rows_to_indptr(rows, R)
+    assert ptr.numel() == R + 1 and int(ptr[0]) == 0 and int(ptr[1]) == 2 and int(ptr[6]) == 3 and int(ptr[R]) <= 6
+    # a long empty stretch in front of the only populated rows (one thread used to fill it serially)
+    big = 3_000_000
+    rows = torch.full((5000,), big - 1, dtype=torch.int64, device="cuda")
+    ptr = _kernels.rows_to_indptr(rows, big)
+    assert int(ptr[big]) == 5000 and int(ptr[big - 1]) == 0 and int(ptr[big // 2]) == 0 and int(ptr.max()) == 5000
+    del guard
+
+
+def test_sddmm_with_a_misaligned_bf16_view_takes_the_sampled_kernel(sp):
+    """A contiguous bf16 operand whose storage offset is not a multiple of 16 bytes cannot feed the matrix-core tile
+    kernel; the product must still be computed (by the sampled kernel), not refused."""
+    M, Kd = 2048, 64
+    s = sp.random((M, M), density=0.02, random_state=1, dtype=np.float32)
+    base = (torch.rand(M * Kd + 8, device="cuda") - 0.5).to(torch.bfloat16)
+    a = base[3:3 + M * Kd].view(M, Kd)
+    bt = base[5:5 + M * Kd].view(M, Kd)
+    assert a.data_ptr() % 16 != 0
+    got = sp.sddmm(s, a, bt.T)
+    want = sp.sddmm(s, a.clone(), bt.clone().T)
+    assert got.nnz == want.nnz and torch.equal(got.data, want.data)
