@@ -266,6 +266,17 @@ int spamd_merge_union(int fill, int op, int val_dtype, int64_t na, const int64_t
                       const int64_t* kb, const void* vb, uint64_t fill_a_bits, uint64_t fill_b_bits,
                       uint64_t fill_out_bits, const int64_t* part, int64_t* counts, const int64_t* offsets,
                       int64_t* out_keys, void* out_vals, void* stream);
+/* The same union in ONE launch and without a copy-back (csrc/merge.hip, MODE 3): every tile finds its own merge-path
+ * diagonals, the tiles chain their output offsets by look-back, and the kernel leaves its workspace zeroed for the next
+ * call.  ws = int64[3 + capacity], capacity >= spamd_merge_num_blocks(na, nb), all zero before the first use; calls that
+ * share a workspace must be ordered on one stream.  *total_dev (device) receives the number of outputs; total_host, if not
+ * null, is pinned host memory mapped to the device that receives it too (system-scope release store) - the host may spin on
+ * it.  out_keys / out_vals hold na + nb elements.  Replaces `_match_arrays` + the mask loop of `_Elemwise`,
+ * _umath.py:53-92,576-654, for canonical same-shape operands. */
+int spamd_merge_union_fused(int op, int val_dtype, int64_t na, const int64_t* ka, const void* va, int64_t nb,
+                            const int64_t* kb, const void* vb, uint64_t fill_a_bits, uint64_t fill_b_bits,
+                            uint64_t fill_out_bits, int64_t* ws, int64_t* total_dev, int64_t* total_host, int64_t* out_keys,
+                            void* out_vals, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * A8  Grouped reduce     replaces `_calc_counts_invidx` + `_grouped_reduce` / `ufunc.reduceat`
@@ -286,6 +297,13 @@ int spamd_segment_reduce(int op, int val_dtype, int64_t n, const void* data, con
  * in the work dtype (float64 for floating results), the other ops fold fv in once where counts[i] != n_cols. */
 int spamd_reduce_fill(int op, int val_dtype, int64_t n, void* vals, const int64_t* counts, int64_t n_cols, double fill_f,
                       int64_t fill_i, void* stream);
+/* The same fold-in with the number of groups still on the device (*n_dev, as spamd_group_reduce leaves it; the grid is
+ * sized for n_max), plus *n_eq (device int64, zeroed here) = how many folded results are bit-identical to
+ * result_fill_bits: the host reads both numbers in one copy, and the result container's prune (`COO(..., prune=True)`,
+ * _coo/core.py:705-716) has nothing to do when *n_eq == 0. */
+int spamd_reduce_fill_count(int op, int val_dtype, int64_t n_max, const int64_t* n_dev, void* vals, const int64_t* counts,
+                            int64_t n_cols, double fill_f, int64_t fill_i, uint64_t result_fill_bits, int64_t* n_eq,
+                            void* stream);
 /* A8 in one pass: runs of equal (keys[i] / divisor) over SORTED keys are reduced together with their lengths
  * (two streaming passes, csrc/group_reduce.hip; fp sums in a fixed, reproducible order).  Outputs hold up to n entries;
  * *n_groups (device int64) receives the number of runs.  op as for spamd_segment_reduce;

@@ -97,6 +97,8 @@ SIGNATURES = {
     "spamd_merge_partition": (_int, [_i64, _vp, _i64, _vp, _vp, _vp]),
     "spamd_merge_union": (_int, [_int, _int, _int, _i64, _vp, _vp, _i64, _vp, _vp, _C.c_uint64, _C.c_uint64,
                                  _C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "spamd_merge_union_fused": (_int, [_int, _int, _i64, _vp, _vp, _i64, _vp, _vp, _C.c_uint64, _C.c_uint64, _C.c_uint64,
+                                       _vp, _vp, _vp, _vp, _vp, _vp]),
     "spamd_spgemm_row_products": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spamd_spgemm_rows_capacity": (_i64, [_int, _i64, _i64]),
     "spamd_spgemm_rows": (_int, [_int, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
@@ -104,6 +106,7 @@ SIGNATURES = {
     "spamd_spgemm_unpack": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spamd_spgemm_pack": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spamd_reduce_fill": (_int, [_int, _int, _i64, _vp, _vp, _i64, _C.c_double, _i64, _vp]),
+    "spamd_reduce_fill_count": (_int, [_int, _int, _i64, _vp, _vp, _vp, _i64, _C.c_double, _i64, _C.c_uint64, _vp, _vp]),
     "spamd_group_reduce_ws_bytes": (_i64, [_int, _i64]),
     "spamd_group_reduce": (_int, [_int, _int, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "spamd_spmm_tiled_params": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

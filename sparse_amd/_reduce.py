@@ -41,9 +41,10 @@ def segment_reduce(data, heads, offs, count, op, want_counts=False, sequential=F
     return (out, counts) if want_counts else out
 
 
-def group_reduce(keys, divisor, data, op, key_bound=0):
+def group_reduce(keys, divisor, data, op, key_bound=0, sync=True):
     """One pass over SORTED keys: runs of equal `keys // divisor` -> (group ids, reduced values, run lengths).
-    C ABI `spamd_group_reduce` (reference `_reduce_calc`, _coo/core.py:1601-1661)."""
+    C ABI `spamd_group_reduce` (reference `_reduce_calc`, _coo/core.py:1601-1661).  `sync=False`: nothing is read back -
+    returns the n-sized output buffers and a device int64[2] whose first word is the number of groups."""
     dev = require_hip(keys, data)
     n = int(keys.numel())
     if data.dtype == torch.bool:
@@ -52,7 +53,7 @@ def group_reduce(keys, divisor, data, op, key_bound=0):
     gids = torch.empty(n, dtype=torch.int64, device=dev)
     vals = torch.empty(n, dtype=data.dtype, device=dev)
     counts = torch.empty(n, dtype=torch.int64, device=dev)
-    ng = torch.empty(1, dtype=torch.int64, device=dev)
+    ng = torch.empty(2, dtype=torch.int64, device=dev)
     ws_bytes = int(_ffi.lib().spamd_group_reduce_ws_bytes(code, n))
     if ws_bytes < 0:
         raise _ffi.HipBackendError(f"spamd_group_reduce_ws_bytes failed: {ws_bytes}")
@@ -60,6 +61,8 @@ def group_reduce(keys, divisor, data, op, key_bound=0):
     _ffi.call("spamd_group_reduce", _RED_OPS[op], code, n, ptr(keys.contiguous()), int(divisor), int(key_bound),
               ptr(data.contiguous()),
               ptr(gids), ptr(vals), ptr(counts), ptr(ng), ptr(ws), ws_bytes, stream_ptr(dev))
+    if not sync:
+        return gids, vals, counts, ng
     count = int(ng[0])
     return gids[:count], vals[:count], counts[:count], count
 
@@ -189,33 +192,41 @@ def reduce_impl(x, method, axis=(0,), keepdims=False, **kwargs):
         else:
             keys, perm = K.sort_keys(keys, max(x.size - 1, 1))
             data = K.gather(data, perm)
-    if x.nnz:
-        gids, vals, counts, count = group_reduce(keys, max(n_cols, 1), data, name, key_bound=max(int(x.size), 1))
-    else:
-        count = 0
-        vals = data[:0]
-        counts = torch.empty(0, dtype=torch.int64, device=dev)
-        gids = torch.empty(0, dtype=torch.int64, device=dev)
-
     result_fill = np.asarray(fv).astype(res_np_dtype)[()] if name not in ("logical_or", "logical_and") else np.bool_(fv)
-    if count:
-        # fold the implicit fill entries of every group in (reference :405-422): one launch
+    if super_ufunc is not None:
+        with np.errstate(all="ignore"):
+            final_fill = np.asarray(super_ufunc(fv, n_cols)).astype(res_np_dtype)[()]
+    else:
+        final_fill = result_fill
+    if x.nnz:
+        # ONE host read for the whole reduction: the grouped reduce leaves the number of groups on the device, the fold-in
+        # of the implicit fill entries (reference :405-422) reads it from there and counts the results that equal the
+        # result's fill value, and both numbers come back in a single copy (each `.item()` is a stream synchronisation,
+        # which at config-1 sizes costs as much as the kernels)
+        n = int(keys.numel())
+        gids, vals, counts, ng = group_reduce(keys, max(n_cols, 1), data, name, key_bound=max(int(x.size), 1), sync=False)
         vcode = _ffi.U8 if vals.dtype == torch.uint8 else code_of(vals.dtype)
         fvn = np.asarray(result_fill if super_ufunc is None else fv)
         with np.errstate(all="ignore"):
             fill_f = float(fvn.astype(np.float64)) if fvn.dtype.kind != "b" else float(bool(fvn))
             fill_i = int(fvn.astype(res_np_dtype if res_np_dtype.kind in "iu" else np.int64)) if np.isfinite(fill_f) else 0
-        vals = vals.contiguous()
-        _ffi.call("spamd_reduce_fill", _RED_OPS[name], vcode, count, ptr(vals), ptr(counts.contiguous()), int(n_cols),
-                  fill_f, fill_i, stream_ptr(dev))
-    if super_ufunc is not None:
-        with np.errstate(all="ignore"):
-            result_fill = np.asarray(super_ufunc(fv, n_cols)).astype(res_np_dtype)[()]
-
+        eq_np = np.dtype("uint8") if res_np_dtype == np.dtype(bool) else res_np_dtype
+        eq_bits = int(np.asarray(final_fill).astype(eq_np).reshape(1).view(f"u{eq_np.itemsize}")[0])
+        _ffi.call("spamd_reduce_fill_count", _RED_OPS[name], vcode, n, ptr(ng), ptr(vals), ptr(counts), int(n_cols),
+                  fill_f, fill_i, eq_bits, ptr(ng) + 8, stream_ptr(dev))
+        count, n_eq = (int(v) for v in ng.tolist())
+        gids, vals = gids[:count], vals[:count]
+        if n_eq:    # results equal to the fill value are not stored (rare: a sum that cancels exactly, a max of zeros)
+            flags = K.flag_ne_bits(vals, final_fill if vals.dtype != torch.uint8 else np.uint8(bool(final_fill)))
+            offs = K.exclusive_scan(flags)
+            gids, vals = K.compact(gids, flags, offs, count - n_eq), K.compact(vals, flags, offs, count - n_eq)
+    else:
+        vals = data[:0]
+        gids = torch.empty(0, dtype=torch.int64, device=dev)
     if vals.dtype == torch.uint8 and res_np_dtype == np.dtype(bool):
         vals = vals.view(torch.bool)
-    out = COO(gids[None, :], vals, shape=(n_groups,), has_duplicates=False, sorted=True, prune=True,
-              fill_value=result_fill)
+    # the group ids ARE the sorted linear keys of the 1-D result: no coordinate matrix, no re-linearisation on the reshape
+    out = COO._from_sorted_keys(gids, vals, (n_groups,), final_fill, x._index_dtype)
     out = out.reshape(tuple(x.shape[d] for d in kept))
     if keepdims:
         shape = list(x.shape)

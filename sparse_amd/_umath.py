@@ -122,6 +122,47 @@ def _bits(value, np_dtype):
 
 
 MERGE_SINGLE_PASS = True   # tuning hook: False = count pass + scan + fill pass
+MERGE_FUSED = True         # one launch (partition inside the kernel, self-cleaning workspace, total through pinned memory)
+
+
+class _MergeWorkspace:
+    """Per (device, stream): the fused merge kernel's look-back workspace - zero before the first call, left zero by every
+    call - plus one device word and one pinned host word for the number of outputs.  The host does not copy the count
+    back: the kernel stores it into the pinned word as soon as the last tile knows it and the host spins on that word
+    (a `.item()` costs a blocking stream synchronisation plus a copy, ~20 us; config-1-sized merges take ~35 us)."""
+
+    _pool = {}
+    SENTINEL = -1
+
+    def __init__(self, devi):
+        self.cap = 0
+        self.ws = None
+        self.total_dev = torch.zeros(1, dtype=torch.int64, device=devi)
+        self.pinned = torch.full((1,), self.SENTINEL, dtype=torch.int64).pin_memory()
+        self.view = self.pinned.numpy()
+        self.devi = devi
+
+    @classmethod
+    def get(cls, devi, stream, nblocks):
+        key = (devi.index, stream)
+        w = cls._pool.get(key)
+        if w is None:
+            w = cls._pool[key] = cls(devi)
+        if nblocks > w.cap:
+            w.cap = max(2 * nblocks, 4096)
+            w.ws = torch.zeros(3 + w.cap, dtype=torch.int64, device=devi)
+        return w
+
+    def wait_total(self):
+        """Spin on the pinned word (bounded: ~50 ms), then fall back to the device word behind a synchronisation."""
+        view = self.view
+        for _ in range(2_000_000):
+            t = int(view[0])
+            if t != self.SENTINEL:
+                return t
+        torch.cuda.current_stream(self.devi).synchronize()
+        t = int(view[0])
+        return t if t != self.SENTINEL else int(self.total_dev[0])
 
 
 def merge_union(name, ka, va, kb, vb, fill_a, fill_b, fill_out):
@@ -139,11 +180,24 @@ def merge_union(name, ka, va, kb, vb, fill_a, fill_b, fill_out):
         e = torch.empty(0, dtype=out_t, device=devi)
         return torch.empty(0, dtype=torch.int64, device=devi), (e.view(torch.bool) if code in _TO_BOOL_BIN else e)
     s = stream_ptr(devi)
+    fa, fb = _bits(fill_a, comp_np), _bits(fill_b, comp_np)
+    fo = _bits(fill_out, np.dtype("uint8") if code in _TO_BOOL_BIN else comp_np)
+    if MERGE_FUSED and MERGE_SINGLE_PASS:
+        w = _MergeWorkspace.get(devi, s, nblocks)
+        keys = torch.empty(na + nb, dtype=torch.int64, device=devi)
+        vals = torch.empty(na + nb, dtype=out_t, device=devi)
+        w.view[0] = w.SENTINEL
+        _ffi.call("spamd_merge_union_fused", code, _CODE[va.dtype], na, ptr(ka), ptr(va), nb, ptr(kb), ptr(vb), fa, fb, fo,
+                  ptr(w.ws), ptr(w.total_dev), w.pinned.data_ptr(), ptr(keys), ptr(vals), s)
+        total = w.wait_total()
+        if total * 2 < na + nb:   # a sparse result should not pin the worst-case buffers
+            keys, vals = keys[:total].clone(), vals[:total].clone()
+        else:
+            keys, vals = keys[:total], vals[:total]
+        return keys, (vals.view(torch.bool) if code in _TO_BOOL_BIN else vals)
     part = torch.empty(nblocks + 1, dtype=torch.int64, device=devi)
     _ffi.call("spamd_merge_partition", na, ptr(ka), nb, ptr(kb), ptr(part), s)
     counts = torch.empty(nblocks + 2, dtype=torch.int64, device=devi)
-    fa, fb = _bits(fill_a, comp_np), _bits(fill_b, comp_np)
-    fo = _bits(fill_out, np.dtype("uint8") if code in _TO_BOOL_BIN else comp_np)
     args = (code, _CODE[va.dtype], na, ptr(ka), ptr(va), nb, ptr(kb), ptr(vb), fa, fb, fo, ptr(part))
     if MERGE_SINGLE_PASS:
         # one pass: tiles chain their output offsets by look-back; room for the worst case, trimmed afterwards

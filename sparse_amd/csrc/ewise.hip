@@ -443,6 +443,65 @@ __global__ void __launch_bounds__(256) reduce_fill_kernel(int op, int64_t n, T* 
   }
 }
 
+// The same with the number of groups still on the device (*n_dev, written by spamd_group_reduce on the same stream), plus
+// the count of results that are bit-identical to the result's fill value (the prune of the result container then costs
+// nothing when there are none - the usual case - and the host reads both numbers in ONE copy after this launch).
+template <typename T>
+__global__ void __launch_bounds__(256) reduce_fill_count_kernel(int op, const int64_t* __restrict__ n_dev, T* __restrict__ vals,
+                                                                const int64_t* __restrict__ counts, int64_t n_cols, double fv_f,
+                                                                int64_t fv_i, uint64_t eq_bits,
+                                                                unsigned long long* __restrict__ n_eq) {
+#pragma clang fp contract(off)
+  const int64_t n = *n_dev;
+  unsigned long long same = 0;
+  GRID_STRIDE(i, n) {
+    const int64_t n_fill = n_cols - counts[i];
+    T v = vals[i];
+    if (op == R_ADD || op == R_MUL) {
+      if constexpr (std::is_floating_point<T>::value) {
+        double contrib;
+        if (n_fill == 0) contrib = op == R_ADD ? 0.0 : 1.0;
+        else contrib = op == R_ADD ? fv_f * (double)n_fill : pow(fv_f, (double)n_fill);
+        v = (T)(op == R_ADD ? (double)v + contrib : (double)v * contrib);
+      } else {
+        T contrib;
+        if (n_fill == 0) contrib = op == R_ADD ? T(0) : T(1);
+        else contrib = op == R_ADD ? (T)((T)fv_i * (T)n_fill) : bin_tt<T>(B_POW, (T)fv_i, (T)n_fill);
+        v = op == R_ADD ? (T)(v + contrib) : (T)(v * contrib);
+      }
+    } else if (n_fill != 0) {
+      T fv;
+      if constexpr (std::is_floating_point<T>::value) fv = (T)fv_f;
+      else fv = (T)fv_i;
+      v = red<T>(op, v, fv);
+    }
+    vals[i] = v;
+    uint64_t b;
+    if constexpr (sizeof(T) == 8) b = __builtin_bit_cast(uint64_t, v);
+    else if constexpr (sizeof(T) == 4) b = __builtin_bit_cast(uint32_t, v);
+    else b = (uint64_t)(uint8_t)v;
+    same += b == eq_bits ? 1 : 0;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) same += __shfl_xor(same, d, 64);
+  if ((threadIdx.x & 63) == 0 && same) atomicAdd(n_eq, same);
+}
+
+extern "C" int spamd_reduce_fill_count(int op, int val_dtype, int64_t n_max, const int64_t* n_dev, void* vals,
+                                       const int64_t* counts, int64_t n_cols, double fill_f, int64_t fill_i,
+                                       uint64_t result_fill_bits, int64_t* n_eq, void* stream) {
+  if (n_max < 0 || op < R_ADD || op > R_FMIN || !n_dev || !n_eq) return SPAMD_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(n_eq, 0, sizeof(int64_t), s);
+  if (e != hipSuccess) return (int)e;
+  if (n_max == 0) return 0;
+  VAL_SWITCH5(val_dtype, T, {
+    hipLaunchKernelGGL(reduce_fill_count_kernel<T>, dim3(grid_for(n_max)), dim3(256), 0, s, op, n_dev, (T*)vals, counts,
+                       n_cols, fill_f, fill_i, result_fill_bits, reinterpret_cast<unsigned long long*>(n_eq));
+  })
+  return launch_status();
+}
+
 extern "C" int spamd_reduce_fill(int op, int val_dtype, int64_t n, void* vals, const int64_t* counts, int64_t n_cols,
                                  double fill_f, int64_t fill_i, void* stream) {
   if (n < 0 || op < R_ADD || op > R_FMIN) return SPAMD_EINVAL;

@@ -99,17 +99,41 @@ __global__ void __launch_bounds__(256) mp_partition_kernel(const int64_t* __rest
   part[p] = lo;
 }
 
+// The same search by the 64 lanes of one wave, 64 probes per round: 4 rounds of two dependent loads for 10^7 keys
+// instead of ~23 (the fused single-launch form below runs it at the start of every tile).
+__device__ __forceinline__ int64_t mp_diag_wave(const int64_t* __restrict__ a, int64_t na, const int64_t* __restrict__ b,
+                                                int64_t nb, int64_t d, int lane) {
+  int64_t lo = d > nb ? d - nb : 0, hi = d < na ? d : na;
+  while (lo < hi) {   // invariant: the answer (number of i with a[i] <= b[d-1-i], a prefix-true predicate) lies in [lo, hi]
+    const int64_t step = (hi - lo + 63) / 64;
+    const int64_t p = lo + lane * step;
+    bool t = false;
+    if (p < hi) t = a[p] <= b[d - 1 - p];
+    const int c = __popcll(__ballot(t));   // probes 0 .. c-1 hold, probe c does not (or lies past the range)
+    const int64_t nlo = c > 0 ? lo + (c - 1) * step + 1 : lo;
+    const int64_t nhi = lo + c * step < hi ? lo + c * step : hi;
+    lo = nlo;
+    hi = nhi;
+  }
+  return lo;
+}
+
 // MODE 0: counts[block] = number of outputs.  MODE 1: write them at offs[block] + local rank.
 // MODE 2: single pass — tiles are taken in ticket order and every tile obtains its output offset by looking back
 // at its predecessors' published totals (`counts` then holds nblocks state words, zero-initialised, + the ticket
 // counter + the grand total): the count pass (a full extra read of both operands) disappears; the outputs must
 // have room for na + nb elements.
+// MODE 3: MODE 2 in ONE launch with nothing to prepare: every tile finds its own two diagonals (mp_diag_wave: no partition
+// kernel), and the workspace `counts` = [ticket, done, unused, state words ...] is left ZERO by the kernel itself (the
+// last tile to finish its look-back clears it: no memset before the next call).  The number of outputs goes to
+// offs[0] (device) and, when given, to *out_total_host - pinned host memory the caller spins on instead of copying back.
 template <typename T, typename O, int MODE>
 __global__ void __launch_bounds__(MP_THREADS)
 mp_union_kernel(int op, const int64_t* __restrict__ ka, const T* __restrict__ va, int64_t na,
                 const int64_t* __restrict__ kb, const T* __restrict__ vb, int64_t nb, T fill_a, T fill_b,
                 O fill_out, const int64_t* __restrict__ part, int64_t* __restrict__ counts,
-                const int64_t* __restrict__ offs, int64_t* __restrict__ out_keys, O* __restrict__ out_vals) {
+                int64_t* __restrict__ offs, int64_t* __restrict__ out_keys, O* __restrict__ out_vals,
+                int64_t* __restrict__ out_total_host) {
   __shared__ int64_t sk[MP_TILE + 4];
   __shared__ T sv[MP_TILE + 4];
   __shared__ int wave_tot[MP_THREADS / 64];
@@ -117,15 +141,30 @@ mp_union_kernel(int op, const int64_t* __restrict__ ka, const T* __restrict__ va
   const int tid = threadIdx.x;
   int64_t blk = blockIdx.x;
   const int64_t nblocks = gridDim.x;
-  if constexpr (MODE == 2) {  // ticket order = start order: a tile only ever waits for tiles that are already running
+  unsigned long long* const states =
+      reinterpret_cast<unsigned long long*>(MODE == 3 ? counts + 3 : counts);   // look-back state words
+  if constexpr (MODE == 2 || MODE == 3) {  // ticket order = start order: a tile only ever waits for tiles that are already running
     __shared__ int64_t ticket;
-    if (tid == 0) ticket = (int64_t)atomicAdd(reinterpret_cast<unsigned long long*>(counts + nblocks), 1ull);
+    if (tid == 0) ticket = (int64_t)atomicAdd(reinterpret_cast<unsigned long long*>(MODE == 3 ? counts : counts + nblocks), 1ull);
     __syncthreads();
     blk = ticket;
   }
-  const int64_t a0 = part[blk], a1 = part[blk + 1];
   int64_t d0 = blk * MP_TILE, d1 = (blk + 1) * MP_TILE;
   if (d1 > na + nb) d1 = na + nb;
+  int64_t a0, a1;
+  if constexpr (MODE == 3) {
+    __shared__ int64_t diag_s[2];
+    if (tid < 128) {   // wave 0: this tile's first diagonal, wave 1: its last
+      const int64_t r = mp_diag_wave(ka, na, kb, nb, tid < 64 ? d0 : d1, tid & 63);
+      if ((tid & 63) == 0) diag_s[tid >> 6] = r;
+    }
+    __syncthreads();
+    a0 = diag_s[0];
+    a1 = diag_s[1];
+  } else {
+    a0 = part[blk];
+    a1 = part[blk + 1];
+  }
   const int64_t b0 = d0 - a0, b1 = d1 - a1;
   const int la = (int)(a1 - a0), lb = (int)(b1 - b0);
   // LDS layout: [0] = a[a0-1] | A segment [1 .. la] | B segment [la+1 .. la+lb] | [la+lb+1] = b[b1]
@@ -211,15 +250,36 @@ mp_union_kernel(int op, const int64_t* __restrict__ ka, const T* __restrict__ va
     } else {
       __shared__ int64_t excl_s;
       if (tid < 64) {  // wave 0 looks back 64 predecessors at a time
-        const unsigned long long excl = lookback_exclusive(reinterpret_cast<unsigned long long*>(counts), blk,
-                                                           (unsigned long long)tot, tid);
+        const unsigned long long excl = lookback_exclusive(states, blk, (unsigned long long)tot, tid);
         if (tid == 0) {
-          if (blk == nblocks - 1) counts[nblocks + 1] = (int64_t)(excl + (unsigned long long)tot);
+          if (blk == nblocks - 1) {
+            const int64_t total = (int64_t)(excl + (unsigned long long)tot);
+            if constexpr (MODE == 3) {
+              offs[0] = total;
+              if (out_total_host) __hip_atomic_store(out_total_host, total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else {
+              counts[nblocks + 1] = total;
+            }
+          }
           excl_s = (int64_t)excl;
         }
       }
       __syncthreads();
       o = excl_s;
+      if constexpr (MODE == 3) {
+        // every tile reports once its look-back is over; the last one to report knows that nobody reads the state words
+        // any more and leaves the workspace zeroed for the next call
+        __shared__ int last_s;
+        if (tid == 0) {
+          __threadfence();
+          last_s = atomicAdd(reinterpret_cast<unsigned long long*>(counts + 1), 1ull) == (unsigned long long)(nblocks - 1);
+        }
+        __syncthreads();
+        if (last_s) {
+          for (int64_t t = tid; t < nblocks; t += MP_THREADS) states[t] = 0;
+          if (tid == 0) counts[0] = counts[1] = 0;
+        }
+      }
     }
     if (tot * 4 >= MP_TILE) {
       __syncthreads();  // everyone is done reading sk / sv
@@ -298,18 +358,18 @@ extern "C" int spamd_merge_union(int fill, int op, int val_dtype, int64_t na, co
     if (fill == 2)                                                                                            \
       hipLaunchKernelGGL((mp_union_kernel<T, O, 2>), dim3((unsigned)nblocks), dim3(MP_THREADS), 0, s, op, ka,    \
                          (const T*)va, na, kb, (const T*)vb, nb, from_bits<T>(fill_a_bits),                   \
-                         from_bits<T>(fill_b_bits), from_bits<O>(fill_out_bits), part, counts, offsets,       \
-                         out_keys, (O*)out_vals);                                                             \
+                         from_bits<T>(fill_b_bits), from_bits<O>(fill_out_bits), part, counts,                \
+                         const_cast<int64_t*>(offsets), out_keys, (O*)out_vals, (int64_t*)nullptr);           \
     else if (fill)                                                                                            \
       hipLaunchKernelGGL((mp_union_kernel<T, O, 1>), dim3((unsigned)nblocks), dim3(MP_THREADS), 0, s, op, ka,    \
                          (const T*)va, na, kb, (const T*)vb, nb, from_bits<T>(fill_a_bits),                   \
-                         from_bits<T>(fill_b_bits), from_bits<O>(fill_out_bits), part, counts, offsets,       \
-                         out_keys, (O*)out_vals);                                                             \
+                         from_bits<T>(fill_b_bits), from_bits<O>(fill_out_bits), part, counts,                \
+                         const_cast<int64_t*>(offsets), out_keys, (O*)out_vals, (int64_t*)nullptr);           \
     else                                                                                                      \
       hipLaunchKernelGGL((mp_union_kernel<T, O, 0>), dim3((unsigned)nblocks), dim3(MP_THREADS), 0, s, op, ka,    \
                          (const T*)va, na, kb, (const T*)vb, nb, from_bits<T>(fill_a_bits),                   \
-                         from_bits<T>(fill_b_bits), from_bits<O>(fill_out_bits), part, counts, offsets,       \
-                         out_keys, (O*)out_vals);                                                             \
+                         from_bits<T>(fill_b_bits), from_bits<O>(fill_out_bits), part, counts,                \
+                         const_cast<int64_t*>(offsets), out_keys, (O*)out_vals, (int64_t*)nullptr);           \
   } while (0)
   switch (val_dtype) {
     case SPAMD_F32: if (to_bool) MP_LAUNCH(float, uint8_t); else MP_LAUNCH(float, float); break;
@@ -320,5 +380,41 @@ extern "C" int spamd_merge_union(int fill, int op, int val_dtype, int64_t na, co
     default: return SPAMD_ETYPE;
   }
 #undef MP_LAUNCH
+  return launch_status();
+}
+
+// The fused single-launch form (mp_union_kernel MODE 3): no partition kernel, no memset, no copy-back.
+//   ws         : int64[3 + capacity] device workspace, capacity >= spamd_merge_num_blocks(na, nb); all ZERO before the
+//                first use; every call leaves it zero again (calls sharing a workspace must be stream-ordered)
+//   total_dev  : device int64 that receives the number of outputs
+//   total_host : null, or pinned host memory mapped to the device (hipHostMalloc / torch pin_memory): receives the same
+//                number with a system-scope release store as soon as it is known, so the host may spin on it instead
+//                of synchronising the stream
+//   out_keys / out_vals hold na + nb elements.
+extern "C" int spamd_merge_union_fused(int op, int val_dtype, int64_t na, const int64_t* ka, const void* va, int64_t nb,
+                                       const int64_t* kb, const void* vb, uint64_t fill_a_bits, uint64_t fill_b_bits,
+                                       uint64_t fill_out_bits, int64_t* ws, int64_t* total_dev, int64_t* total_host,
+                                       int64_t* out_keys, void* out_vals, void* stream) {
+  if (na < 0 || nb < 0 || !ws || !total_dev) return SPAMD_EINVAL;
+  const int64_t nblocks = spamd_merge_num_blocks(na, nb);
+  if (nblocks == 0) return SPAMD_EINVAL;   // (nothing to merge: the caller returns an empty result without a launch)
+  hipStream_t s = (hipStream_t)stream;
+  const bool to_bool = op >= 32 && op < 64;
+  if (op >= 64 && (val_dtype == SPAMD_F32 || val_dtype == SPAMD_F64)) return SPAMD_ETYPE;
+  if (op == 6) return SPAMD_ETYPE;  // power: use the aligned-array path
+#define MP_FUSED(T, O)                                                                                          \
+  hipLaunchKernelGGL((mp_union_kernel<T, O, 3>), dim3((unsigned)nblocks), dim3(MP_THREADS), 0, s, op, ka,        \
+                     (const T*)va, na, kb, (const T*)vb, nb, from_bits<T>(fill_a_bits), from_bits<T>(fill_b_bits), \
+                     from_bits<O>(fill_out_bits), (const int64_t*)nullptr, ws, total_dev, out_keys, (O*)out_vals,  \
+                     total_host)
+  switch (val_dtype) {
+    case SPAMD_F32: if (to_bool) MP_FUSED(float, uint8_t); else MP_FUSED(float, float); break;
+    case SPAMD_F64: if (to_bool) MP_FUSED(double, uint8_t); else MP_FUSED(double, double); break;
+    case SPAMD_I32: if (to_bool) MP_FUSED(int32_t, uint8_t); else MP_FUSED(int32_t, int32_t); break;
+    case SPAMD_I64: if (to_bool) MP_FUSED(int64_t, uint8_t); else MP_FUSED(int64_t, int64_t); break;
+    case SPAMD_U8: MP_FUSED(uint8_t, uint8_t); break;
+    default: return SPAMD_ETYPE;
+  }
+#undef MP_FUSED
   return launch_status();
 }

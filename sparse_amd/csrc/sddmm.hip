@@ -7,23 +7,11 @@
 // K-long rows with 16-byte loads (B is taken K-major, i.e. as Bt = B^T row-major, so both rows
 // are contiguous), multiply-accumulate in fp32 (bf16/fp32 inputs) or fp64, and reduce across
 // the LPN lanes with wave shuffles.  Gather-bound (L2): 2*K*sizeof(in) bytes per element.
-#include "common.h"
-#include <hip/hip_bf16.h>
+#include "sddmm_common.h"
 #include <stdlib.h>
 #include <algorithm>
 
 namespace spamd {
-
-template <typename TIN>
-struct Acc { using type = float; };
-template <>
-struct Acc<double> { using type = double; };
-
-template <typename TIN>
-__device__ __forceinline__ typename Acc<TIN>::type to_acc(TIN x) {
-  if constexpr (std::is_same<TIN, __hip_bfloat16>::value) return __bfloat162float(x);
-  else return (typename Acc<TIN>::type)x;
-}
 
 // TIN: element type of A/Bt; TS: type of the mask values and of the output; LPN lanes per element;
 // UNR stored elements per lane group in flight (all their row loads are issued before any FMA).
@@ -77,79 +65,16 @@ sddmm_kernel(int64_t nnz, const I* __restrict__ rows, const I* __restrict__ cols
   }
 }
 
-typedef __bf16 sd_bf2 __attribute__((ext_vector_type(2)));
+#ifndef SD_NT_A
+#define SD_NT_A 0
+#endif
+#ifndef SD_NT_MASK
+#define SD_NT_MASK 1
+#endif
 
-// <a, b> over KS 16-byte vectors per lane.  bf16: v_dot2c_f32_bf16 (two products and the add per instruction, fp32
-// accumulate; no bf16 -> fp32 conversions); fp32/fp64: fused multiply-adds.
-template <typename TIN, typename VT, int KS>
-__device__ __forceinline__ typename Acc<TIN>::type sd_dot(const VT (&av)[KS], const VT (&bv)[KS]) {
-  using ACC = typename Acc<TIN>::type;
-  constexpr int EPL = 16 / (int)sizeof(TIN);
-  ACC acc = 0;
-  if constexpr (std::is_same<TIN, __hip_bfloat16>::value) {
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      sd_bf2 a2[4], b2[4];
-      __builtin_memcpy(a2, &av[s], 16);
-      __builtin_memcpy(b2, &bv[s], 16);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_fdot2_f32_bf16(a2[e], b2[e], acc, false);
-    }
-  } else {
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) acc = __builtin_fma(to_acc(av[s].v[e]), to_acc(bv[s].v[e]), acc);
-  }
-  return acc;
-}
-
-template <int CTRL>
-__device__ __forceinline__ float sd_dpp(float x) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
-}
-
-// Sum over the LPN (>= 16) lanes of a group, left in every lane.  fp32: the first 16 lanes in four DPP adds
-// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror), wider groups finish with shuffles.
-template <int LPN, typename ACC>
-__device__ __forceinline__ ACC sd_group_sum(ACC acc) {
-  static_assert(LPN >= 16, "a DPP row is 16 lanes");
-  if constexpr (sizeof(ACC) == 4) {
-    acc += sd_dpp<0xB1>(acc);
-    acc += sd_dpp<0x4E>(acc);
-    acc += sd_dpp<0x141>(acc);
-    acc += sd_dpp<0x140>(acc);
-#pragma unroll
-    for (int off = 16; off < LPN; off <<= 1) acc += __shfl_xor(acc, off, 64);
-  } else {
-#pragma unroll
-    for (int off = LPN / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-  }
-  return acc;
-}
-
-// Lane `U` of every 16-lane row -> all lanes of that row (v_mov_b32_dpp row_newbcast:U); wider groups go through a
-// shuffle.  4- and 8-byte values.
-template <int LPN, int U, typename T>
-__device__ __forceinline__ T sd_bcast(T x) {
-  static_assert(sizeof(T) == 4 || sizeof(T) == 8, "4- or 8-byte values");
-  if constexpr (LPN == 16) {
-    if constexpr (sizeof(T) == 4) {
-      return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x150 + U, 0xf, 0xf, false));
-    } else {
-      const uint64_t b = __builtin_bit_cast(uint64_t, x);
-      const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, 0x150 + U, 0xf, 0xf, false);
-      const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), 0x150 + U, 0xf, 0xf, false);
-      return __builtin_bit_cast(T, ((uint64_t)hi << 32) | lo);
-    }
-  } else {
-    return __shfl(x, U, LPN);
-  }
-}
-
-// Elements U0 .. U0+3 of a step (see sddmm_rowcache_kernel): the four Bt rows are requested first, then each element
-// is finished in turn; the A row is (re)loaded only when the element's row differs from the one in registers.
-template <typename TIN, typename I, int LPN, int KS, int U0>
+// STREAM_A: the A rows are read with the non-temporal hint (panel order: a row of A is used by ONE lane group once per
+// panel and the panel's Bt rows are what must stay in L2; in row-major order A rows are left to the default policy).
+template <typename TIN, typename I, int LPN, int KS, int U0, bool STREAM_A>
 __device__ __forceinline__ void sd_batch4(int cnt, int sub, I myrow, I mycol, const char* Ab, const char* Bb,
                                           int64_t lda_b, int64_t ldb_b, int64_t koff_b, I& cur,
                                           Vec<TIN, 16 / (int)sizeof(TIN)> (&av)[KS], typename Acc<TIN>::type& res) {
@@ -172,7 +97,8 @@ __device__ __forceinline__ void sd_batch4(int cnt, int sub, I myrow, I mycol, co
     if (r[k] != cur) {                                                                                        \
       cur = r[k];                                                                                             \
       const char* ap = Ab + ((int64_t)cur * lda_b + koff_b);                                                  \
-      _Pragma("unroll") for (int s = 0; s < KS; ++s) av[s] = *reinterpret_cast<const VT*>(ap + s * step_b);  \
+      _Pragma("unroll") for (int s = 0; s < KS; ++s)                                                          \
+        av[s] = STREAM_A ? sd_load_nt<VT>(ap + s * step_b) : *reinterpret_cast<const VT*>(ap + s * step_b);  \
     }                                                                                                         \
     const ACC t = sd_group_sum<LPN>(sd_dot<TIN, VT, KS>(av, bv[k]));                                          \
     res = sub == U0 + k ? t : res;                                                                            \
@@ -181,13 +107,13 @@ __device__ __forceinline__ void sd_batch4(int cnt, int sub, I myrow, I mycol, co
 #undef SD_DOT
 }
 
-template <typename TIN, typename I, int LPN, int KS, int U0>
+template <typename TIN, typename I, int LPN, int KS, int U0, bool STREAM_A>
 struct SdStep {
   template <typename... Args>
   static __device__ __forceinline__ void run(int cnt, Args&... args) {
     if constexpr (U0 < LPN) {
-      if (U0 < cnt) sd_batch4<TIN, I, LPN, KS, U0>(cnt, args...);
-      SdStep<TIN, I, LPN, KS, U0 + 4>::run(cnt, args...);
+      if (U0 < cnt) sd_batch4<TIN, I, LPN, KS, U0, STREAM_A>(cnt, args...);
+      SdStep<TIN, I, LPN, KS, U0 + 4, STREAM_A>::run(cnt, args...);
     }
   }
 };
@@ -254,13 +180,16 @@ sddmm_rowcache_kernel(int64_t nnz, int64_t chunk, const I* __restrict__ rows, co
       const int cnt = (int)(cend - nbeg < LPN ? cend - nbeg : LPN);  // uniform inside the group
       const bool mine = sub < cnt;
       const int64_t nl = nbeg + (mine ? sub : 0);
-      const I myrow = rows[nl], mycol = cols[nl];
-      const TS mys = s_data[nl];
+      // (panel order: the mask's arrays are a once-through stream as well)
+      constexpr bool NTM = PERM && SD_NT_MASK;
+      const I myrow = NTM ? __builtin_nontemporal_load(rows + nl) : rows[nl];
+      const I mycol = NTM ? __builtin_nontemporal_load(cols + nl) : cols[nl];
+      const TS mys = NTM ? __builtin_nontemporal_load(s_data + nl) : s_data[nl];
       int64_t mypos = nl;
-      if constexpr (PERM) mypos = perm[nl];
+      if constexpr (PERM) mypos = NTM ? __builtin_nontemporal_load(perm + nl) : perm[nl];
       ACC res = 0;
       int lane_in_group = sub;
-      SdStep<TIN, I, LPN, KS, 0>::run(cnt, lane_in_group, myrow, mycol, Ab, Bb, lda_b, ldb_b, koff_b, cur, av, res);
+      SdStep<TIN, I, LPN, KS, 0, PERM && SD_NT_A>::run(cnt, lane_in_group, myrow, mycol, Ab, Bb, lda_b, ldb_b, koff_b, cur, av, res);
       if (mine) {
         const TS v = (TS)((ACC)mys * res);
         if constexpr (PERM) __builtin_nontemporal_store(v, out + mypos);  // scattered: keep these lines from displacing the Bt panel in L2
@@ -312,8 +241,13 @@ static int launch_sddmm(int64_t nnz, const I* rows, const I* cols, const TS* s, 
                      nnz, chunk, rows, cols, s, A, lda, Bt, ldb, out, perm, xstate)
 #define SDR(LL, KK)                                                                                           \
   if (L == LL && ks == KK) {                                                                                  \
-    if (perm) SDL(LL, KK, true);                                                                              \
-    else SDL(LL, KK, false);                                                                                  \
+    if constexpr (LL * KK * 16 >= 1024) {   /* (panel order for shorter rows: sddmm_panel.hip) */            \
+      if (perm) SDL(LL, KK, true);                                                                            \
+      else SDL(LL, KK, false);                                                                                \
+    } else {                                                                                                  \
+      if (perm) return SPAMD_EINVAL;                                                                          \
+      SDL(LL, KK, false);                                                                                     \
+    }                                                                                                         \
     return launch_status();                                                                                   \
   }
       SDR(16, 1) SDR(16, 2) SDR(16, 4) SDR(32, 1) SDR(32, 2) SDR(32, 4) SDR(64, 1) SDR(64, 2) SDR(64, 4)
@@ -391,17 +325,12 @@ extern "C" int spamd_sddmm_has_panels(int in_dtype, int64_t K) {
   return 0;
 }
 
-// Column-panel order: rows_p/cols_p/s_p are the mask's coordinates and values gathered by `perm` (the stable sort of
-// spamd_sddmm_panel_keys); out stays in the mask's own order: out[perm[n]] = s_p[n] * <A[rows_p[n]], Bt[cols_p[n]]>.
-// `chunk` = elements a lane group takes at a time (<= 0: the default).  SPAMD_EINVAL when K has no row-cached kernel
-// (use spamd_sddmm).
-extern "C" int spamd_sddmm_panels(int in_dtype, int s_dtype, int idx_dtype, int64_t nnz, const void* rows_p,
-                                  const void* cols_p, const int64_t* perm, const void* s_p, const void* A, int64_t lda,
-                                  const void* Bt, int64_t ldb, int64_t K, int64_t chunk, const int64_t* xcd_first,
-                                  int64_t xcd_max, void* out, void* stream) {
-  if (!perm || (xcd_first && xcd_max < 0)) return SPAMD_EINVAL;
-  return sddmm_entry(in_dtype, s_dtype, idx_dtype, nnz, rows_p, cols_p, s_p, A, lda, Bt, ldb, K, out, stream, perm,
-                     chunk, xcd_first, xcd_max);
+// the column-panel order for rows of 1 KB and more (called by spamd_sddmm_panels, sddmm_panel.hip)
+int sddmm_rowcache_panels(int in_dtype, int s_dtype, int idx_dtype, int64_t nnz, const void* rows, const void* cols,
+                          const void* s_data, const void* A, int64_t lda, const void* Bt, int64_t ldb, int64_t K, void* out,
+                          void* stream, const int64_t* perm, int64_t perm_chunk, const int64_t* xstate, int64_t xmax) {
+  return sddmm_entry(in_dtype, s_dtype, idx_dtype, nnz, rows, cols, s_data, A, lda, Bt, ldb, K, out, stream, perm, perm_chunk,
+                     xstate, xmax);
 }
 
 static int sddmm_entry(int in_dtype, int s_dtype, int idx_dtype, int64_t nnz, const void* rows, const void* cols,

@@ -148,10 +148,10 @@ constexpr int TL_DIRECT_MAX_TILES = 256;  // LDS: 2 * TL_RG * tiles * 4 B (+ til
 
 template <typename I>
 __device__ __forceinline__ int tl_row_of(const int64_t* rs, int64_t e) {  // largest lr in [0, TL_RG) with rs[lr] <= e
-  static_assert(TL_RG <= 64, "six bisection steps");
+  static_assert(TL_RG <= 128, "seven bisection steps");
   int lo = 0, hi = TL_RG;   // invariant: rs[lo] <= e < rs[hi] (rs[TL_RG] = end of the group)
 #pragma unroll
-  for (int it = 0; it < 6; ++it) {
+  for (int it = 0; it < (TL_RG <= 64 ? 6 : 7); ++it) {
     const int mid = (lo + hi) >> 1;
     if (hi - lo > 1) {
       if (rs[mid] <= e) lo = mid; else hi = mid;
@@ -437,7 +437,7 @@ __device__ __forceinline__ void tl_phases(const int* stream, int t0, int te, int
 
 // DBG (timing ablation): 2 = no tile DMA.  MODE: see tl_phases.
 template <int DBG, int MODE, typename T>
-__global__ void __launch_bounds__(TL_WAVES * 64) __attribute__((amdgpu_num_vgpr(22)))
+__global__ void __launch_bounds__(TL_WAVES * 64) __attribute__((amdgpu_num_vgpr(TL_ASM_COMP)))
 spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, int touch_lines, const int* __restrict__ stream,
                   const int* __restrict__ blk_off, const T* __restrict__ b, int64_t ldb,
                   T* __restrict__ out, int64_t ldo) {
@@ -522,8 +522,8 @@ spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, int touch_lines, const int* 
     const int o0 = o(t), o1 = o(t + 1), o2 = o(t + 2);
     if (t == 0) {  // lists 0 and 1 have not been touched by an earlier phase
       const int n = o2 - o0, l = lane < n ? lane : 0;
-      asm volatile("global_load_dword v23, %0, off" ::"v"(reinterpret_cast<const char*>(stream + (int64_t)o0 * 16) + l * 64)
-                   : "memory", "v23");
+      asm volatile("global_load_dword " TL_ASM_TOUCH ", %0, off" ::"v"(reinterpret_cast<const char*>(stream + (int64_t)o0 * 16) + l * 64)
+                   : "memory", TL_ASM_TOUCH);
     }
     tl_phases<MODE>(stream, t, te, o0, o1, o2, offreg, obase, ntiles, nfull, toff, (int)0xfffffe00, m0wave, row_step, voff, srd, soff);
     t = te;
@@ -540,7 +540,7 @@ spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, int touch_lines, const int* 
                :
                : [lo] "v"((unsigned)((uintptr_t)obase_p & 0xffffffffu)), [hi] "v"((unsigned)((uintptr_t)obase_p >> 32)),
                  [stride] "s"(stride_bytes), [n] "s"(nvalid)
-               : "memory", "scc", "s36", "v22", "v23", TL_CLOB_ACC);
+               : "memory", "scc", "s36", TL_ASM_BASE, TL_ASM_TOUCH, TL_CLOB_ACC);
 }
 
 static int64_t tl_grid_groups(int64_t M) { return ceil_div(ceil_div(M, (int64_t)TL_RG), (int64_t)TL_WAVES) * TL_WAVES; }

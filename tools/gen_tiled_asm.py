@@ -30,11 +30,12 @@ WAVES = int(os.environ.get("TL_WAVES", "16"))  # waves per workgroup (ROWS * WAV
 VB = int(os.environ.get("TL_VGPRS", "128"))    # registers of a wave (128: four waves per SIMD; 168: three)
 ACC0 = VB - 2 * ROWS
 JUNK = ACC0 - 2                               # junk accumulator pair (padding entries), just below the accumulators
-BASE = 22                                     # LDS base of the current tile + 8*lane
-TOUCH = 23                                    # destination of the line touches
+COMP = int(os.environ.get("TL_COMP", "22"))   # v0 .. v(COMP-1) belong to the compiler (amdgpu_num_vgpr)
+BASE = COMP                                   # LDS base of the current tile + 8*lane
+TOUCH = COMP + 1                              # destination of the line touches
 
 
-DATASET = (40, 24)
+DATASET = (COMP + 18, COMP + 2)
 assert JUNK >= DATASET[0] + 16, "accumulators collide with the data sets"
 
 
@@ -149,6 +150,8 @@ def dma_hook():
     then the next piece is requested; s39 = a piece is staged."""
     if not STAGE:
         return ["s_cbranch_vccz 6f"] + dma_body() + ["6:"]
+    if STAGE == 2:   # every piece of the next tile is requested, waited for and written at the END of the list (dma_rest)
+        return []
     return (["s_cmp_eq_u32 s39, 0", "s_cbranch_scc1 5f"] + stage_flush() + ["5:", "s_cbranch_vccz 6f"] + stage_issue() +
             ["s_lshr_b64 vcc, vcc, 1", "s_mov_b32 s39, 1", "6:"])
 
@@ -184,7 +187,7 @@ def list_loop(lds=True, fma=True, exact=False):
     P1 = p1 if lds else (lambda buf, dset: [])
     P2 = (p2_exact if exact else p2) if fma else (lambda buf, dset: [])
     o = []
-    for _ in range(1 if STAGE else DMA_AT_START):
+    for _ in range((1 if STAGE == 1 else 0) if STAGE else DMA_AT_START):
         o += dma_hook()
     o += ["s_waitcnt lgkmcnt(0)"]
     o += P1(RING[0], 0)
@@ -340,7 +343,8 @@ def f64_variants():
 
 def main():
     out = ["// GENERATED by tools/gen_tiled_asm.py - do not edit.\n",
-           f"#define TL_ASM_KB {KB}\n#define TL_ASM_DMA_PER_TILE {DMA_PER_TILE}\n#define TL_ASM_RG {ROWS}\n#define TL_ASM_WAVES {WAVES}\n",
+           f"#define TL_ASM_KB {KB}\n#define TL_ASM_DMA_PER_TILE {DMA_PER_TILE}\n#define TL_ASM_RG {ROWS}\n#define TL_ASM_WAVES {WAVES}\n"
+           f"#define TL_ASM_COMP {COMP}\n#define TL_ASM_TOUCH \"v{TOUCH}\"\n#define TL_ASM_BASE \"v{BASE}\"\n",
            lit("TL_ASM_PHASES", phases()),
            lit("TL_ASM_PHASES_EXACT", phases(True, True, True)),
            lit("TL_ASM_PHASES_NOFMA", phases(True, False)),
