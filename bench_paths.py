@@ -43,6 +43,26 @@ def timed(fn, reps=5, warm=1):
     return e0.elapsed_time(e1) / reps, r
 
 
+def overheads(fn):
+    """What one call costs besides its kernels: C-ABI calls (each is one to a few launches) and host<->device
+    synchronisations that torch can see (`.item()`, `.tolist()`, `.cpu()`: counted with torch's sync debug mode; the
+    spin on a pinned word the fused merge uses instead of a copy-back is not one of them)."""
+    import warnings
+
+    from sparse_amd import _ffi
+
+    fn()
+    c0 = _ffi.CALLS
+    torch.cuda.set_sync_debug_mode("warn")
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            fn()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    return {"c_abi_calls": _ffi.CALLS - c0, "host_syncs": sum("synchroniz" in str(x.message).lower() for x in w)}
+
+
 def row(workload, ms, bytes_alg, flops=None, **extra):
     d = {"workload": workload, "ms": ms, "algorithmic_bytes": int(bytes_alg),
          "GBps": bytes_alg / ms / 1e6, "frac": bytes_alg / ms / 1e6 / HBM}
@@ -124,7 +144,7 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
             leg["keys_bit_exact"] = bool(np.array_equal(z.linear_loc().cpu().numpy(), wk))
             leg["max_rel_err"] = rel_err(z.data.cpu().numpy(), wv) if leg["keys_bit_exact"] else None
             emit(f"A7_{name}_config1", row(f"config 1: COO(1000^3, {nnz} nnz, f64/int64) {name} COO", ms, b, out_nnz=z.nnz,
-                                           cpu_baseline=leg))
+                                           cpu_baseline=leg, **overheads(f)))
         if want("A8"):
             z = x + y
             hk, hv = z.linear_loc().cpu().numpy(), z.data.cpu().numpy()
@@ -146,7 +166,8 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
                 leg["max_rel_err"] = rel_err(s.data.cpu().numpy(), wv) if leg["keys_bit_exact"] else None
                 emit(f"A8_sum_axis{ax}_config1", row(f"config 1: COO(1000^3, {z.nnz} nnz).sum(axis={ax})"
                                                      + (" (needs a key sort)" if ax == 0 else ""), ms,
-                                                     z.nnz * 16 + s.nnz * 16, groups=s.nnz, cpu_baseline=leg))
+                                                     z.nnz * 16 + s.nnz * 16, groups=s.nnz, cpu_baseline=leg,
+                                                     **overheads(lambda: z.sum(axis=ax))))
         del x, y
         if not quick and want("A7_1e8"):
             nb = 100_000_000
@@ -278,7 +299,10 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
         p1 = int(gB.indptr[rows])
         gA = sp.GCXS((gB.data[:p1].contiguous(), gB.indices[:p1].contiguous(), gB.indptr[:rows + 1].contiguous()),
                      shape=(rows, n5), compressed_axes=(0,))
-        ms, c = timed(lambda: gA @ gB, reps=3, warm=1)
+        # (two warm-up products: the result of product i is still alive while product i + 1 is formed, so the allocator
+        # needs two sets of the ~25 GB of result and scratch buffers before it stops going to the driver for memory -
+        # a first-time hipMalloc of that size costs more than the product)
+        ms, c = timed(lambda: gA @ gB, reps=3, warm=2)
         prods = float((gB.indptr[1:] - gB.indptr[:-1]).double()[gA.indices.long()].sum())
         # sampled check: 200 rows of the block against the oracle's Gustavson restatement on the host
         rng = np.random.default_rng(1)

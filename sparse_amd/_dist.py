@@ -111,11 +111,12 @@ def _gather_key(t, n_rows, group):
     return (t.data_ptr(), int(t._version), tuple(t.shape), t.dtype, int(n_rows), id(group))
 
 
-def gathered_rows(b_shard, n_rows, group=None, before_wait=None):
-    """`all_gather_rows` with the memo above; `before_wait()` is called after the collective is launched and before it
-    is waited for (also when the memo hits: the caller's preparation work is wanted either way)."""
+def gathered_rows(b_shard, n_rows, group=None, before_wait=None, memo=True):
+    """`all_gather_rows` with the memo above (`memo=False`: always gather); `before_wait()` is called after the collective
+    is launched and before it is waited for (also when the memo hits: the caller's preparation work is wanted either
+    way)."""
     key = _gather_key(b_shard, n_rows, group)
-    hit = _GATHER_MEMO.get(key)
+    hit = _GATHER_MEMO.get(key) if memo else None
     if hit is not None:
         if before_wait is not None:
             before_wait()
@@ -124,20 +125,22 @@ def gathered_rows(b_shard, n_rows, group=None, before_wait=None):
     if before_wait is not None:
         before_wait()
     full = finish()
+    if not memo:
+        return full
     _GATHER_MEMO[key] = (b_shard, full)       # (the shard is kept alive: a recycled pointer must not alias the key)
     while len(_GATHER_MEMO) > GATHER_MEMO_ENTRIES:
         _GATHER_MEMO.pop(next(iter(_GATHER_MEMO)))
     return full
 
 
-def sharded_spmm(a_local, b_shard, n_rows_b, group=None):
+def sharded_spmm(a_local, b_shard, n_rows_b, group=None, memo=True):
     """Row-block-sharded C_local = A_local @ all_gather(B): the multi-GPU form of A1/A3.
     `a_local` is this rank's GCXS/COO row block, `b_shard` its slice of B's rows.  While the shards of B are in flight
     the local block is prepared: its NaN scan (`matmul`'s warning, memoised per buffer) and, for an eligible operand,
-    its block stream (`prepare_operand`)."""
+    its block stream (`prepare_operand`).  `memo=False` gathers B at every call even when the shard has not changed."""
     from . import _dot
 
-    b = gathered_rows(b_shard, n_rows_b, group, before_wait=lambda: _dot.prepare_operand(a_local, b_shard))
+    b = gathered_rows(b_shard, n_rows_b, group, before_wait=lambda: _dot.prepare_operand(a_local, b_shard), memo=memo)
     return _dot.matmul(a_local, b)
 
 

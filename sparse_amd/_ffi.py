@@ -144,5 +144,10 @@ def check(code, what):
         raise HipBackendError(f"{what} failed: {kind}")
 
 
+CALLS = 0   # C-ABI calls made so far (a cheap counter: the benches report calls per operation from its differences)
+
+
 def call(name, *args):
+    global CALLS
+    CALLS += 1
     check(getattr(lib(), name)(*args), name)
