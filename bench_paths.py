@@ -136,7 +136,7 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
         for name, f, uf in (("add", lambda: x + y, np.add), ("multiply", lambda: x * y, np.multiply)):
             if not want("A7"):
                 break
-            ms, z = timed(f)
+            ms, z = timed(f, reps=100, warm=10)   # (sub-0.1-ms operations: a 5-call average is mostly first-call effects)
             b = 2 * nnz * (3 * 8 + 8) + z.nnz * (3 * 8 + 8)
             (wk, wv, _, _), leg = cpu_leg(lambda: oracle.elemwise_zero_fill(uf, hx[0], hx[1], hy[0], hy[1]),
                                           "whole workload once (oracle.elemwise_zero_fill: NumPy sorted-key union of the "
@@ -149,7 +149,7 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
             z = x + y
             hk, hv = z.linear_loc().cpu().numpy(), z.data.cpu().numpy()
             for ax in (2, 0):
-                ms, s = timed(lambda: z.sum(axis=ax))
+                ms, s = timed(lambda: z.sum(axis=ax), reps=100, warm=10)
 
                 def cpu_sum():
                     if ax == 2:

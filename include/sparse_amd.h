@@ -268,11 +268,13 @@ int spamd_merge_union(int fill, int op, int val_dtype, int64_t na, const int64_t
                       int64_t* out_keys, void* out_vals, void* stream);
 /* The same union in ONE launch and without a copy-back (csrc/merge.hip, MODE 3): every tile finds its own merge-path
  * diagonals, the tiles chain their output offsets by look-back, and the kernel leaves its workspace zeroed for the next
- * call.  ws = int64[3 + capacity], capacity >= spamd_merge_num_blocks(na, nb), all zero before the first use; calls that
+ * call.  ws = int64[3 + capacity], capacity >= spamd_merge_fused_blocks(na, nb), all zero before the first use; calls that
  * share a workspace must be ordered on one stream.  *total_dev (device) receives the number of outputs; total_host, if not
  * null, is pinned host memory mapped to the device that receives it too (system-scope release store) - the host may spin on
  * it.  out_keys / out_vals hold na + nb elements.  Replaces `_match_arrays` + the mask loop of `_Elemwise`,
  * _umath.py:53-92,576-654, for canonical same-shape operands. */
+/* tiles the fused form below runs (its workspace holds 3 + that many int64) */
+int64_t spamd_merge_fused_blocks(int64_t na, int64_t nb);
 int spamd_merge_union_fused(int op, int val_dtype, int64_t na, const int64_t* ka, const void* va, int64_t nb,
                             const int64_t* kb, const void* vb, uint64_t fill_a_bits, uint64_t fill_b_bits,
                             uint64_t fill_out_bits, int64_t* ws, int64_t* total_dev, int64_t* total_host, int64_t* out_keys,

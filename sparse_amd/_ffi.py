@@ -97,6 +97,7 @@ SIGNATURES = {
     "spamd_merge_partition": (_int, [_i64, _vp, _i64, _vp, _vp, _vp]),
     "spamd_merge_union": (_int, [_int, _int, _int, _i64, _vp, _vp, _i64, _vp, _vp, _C.c_uint64, _C.c_uint64,
                                  _C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "spamd_merge_fused_blocks": (_i64, [_i64, _i64]),
     "spamd_merge_union_fused": (_int, [_int, _int, _i64, _vp, _vp, _i64, _vp, _vp, _C.c_uint64, _C.c_uint64, _C.c_uint64,
                                        _vp, _vp, _vp, _vp, _vp, _vp]),
     "spamd_spgemm_row_products": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -123,6 +123,11 @@ def _bits(value, np_dtype):
 
 MERGE_SINGLE_PASS = True   # tuning hook: False = count pass + scan + fill pass
 MERGE_FUSED = True         # one launch (partition inside the kernel, self-cleaning workspace, total through pinned memory)
+# ... up to this many items: every tile of the fused form searches its own two merge-path diagonals with 64 probes per round
+# (latency: 4 rounds instead of ~23), which touches ~0.5 K cache lines per tile.  At config 1 (2 x 10^6 items, everything
+# resident in the Infinity Cache) that is the cheaper trade: 0.109 -> 0.062 ms per `x + y`; at 2 x 10^8 items the probes
+# are HBM traffic of the size of the operands themselves (2.4 -> 4.5 ms), so large merges keep the partition kernel.
+MERGE_FUSED_MAX_ITEMS = 1 << 23
 
 
 class _MergeWorkspace:
@@ -182,8 +187,8 @@ def merge_union(name, ka, va, kb, vb, fill_a, fill_b, fill_out):
     s = stream_ptr(devi)
     fa, fb = _bits(fill_a, comp_np), _bits(fill_b, comp_np)
     fo = _bits(fill_out, np.dtype("uint8") if code in _TO_BOOL_BIN else comp_np)
-    if MERGE_FUSED and MERGE_SINGLE_PASS:
-        w = _MergeWorkspace.get(devi, s, nblocks)
+    if MERGE_FUSED and MERGE_SINGLE_PASS and na + nb <= MERGE_FUSED_MAX_ITEMS:
+        w = _MergeWorkspace.get(devi, s, int(_ffi.lib().spamd_merge_fused_blocks(na, nb)))
         keys = torch.empty(na + nb, dtype=torch.int64, device=devi)
         vals = torch.empty(na + nb, dtype=out_t, device=devi)
         w.view[0] = w.SENTINEL
@@ -446,6 +451,9 @@ def _broadcast_matched(name, func, a, b, shape, out_np, comp_np, finish):
     return finish(x.linear_loc(), res, shape, fill, devi)
 
 
+_SAME_SHAPE_PLANS = {}   # (ufunc name, dtypes, fill bytes) -> what the fused merge needs (see `elemwise`)
+
+
 def _func_name(func):
     if func is np.ndarray.astype:
         return "astype"
@@ -547,6 +555,22 @@ def elemwise(func, *args, **kwargs):
         return _elemwise_general(func, proc, kwargs, dtype_kw, finish)
     a, b = proc
     a_sp, b_sp = isinstance(a, COO), isinstance(b, COO)
+    if a_sp and b_sp and a.shape == b.shape and dtype_kw is None and a.size:
+        # two canonical COO of one shape (config 1): everything the host has to decide - result dtype, compute dtype,
+        # kernel op, fill values - depends only on the ufunc, the dtypes and the fills, and is decided once per combination
+        # (the NumPy dtype arithmetic below costs more host time than the launch it prepares)
+        fka, fkb = a.fill_value, b.fill_value
+        pkey = (name, a.data.dtype, b.data.dtype, fka.tobytes() if hasattr(fka, "tobytes") else fka,
+                fkb.tobytes() if hasattr(fkb, "tobytes") else fkb)
+        plan = _SAME_SHAPE_PLANS.get(pkey)
+        if plan is not None:
+            mname, comp_t, fa, fb, fill_in_kernel, fill = plan
+            keys, res = merge_union(mname, a.linear_loc(), K.convert(a.data, comp_t), b.linear_loc(), K.convert(b.data, comp_t),
+                                    fa, fb, fill_in_kernel)
+            out = COO._from_sorted_keys(keys, res, shape, fill, a._index_dtype)
+            return out.asformat(out_type, **out_kwargs) if out_type != "coo" else out
+    else:
+        pkey = None
 
     def fill_of(v):
         if isinstance(v, COO):
@@ -668,6 +692,8 @@ def elemwise(func, *args, **kwargs):
     if code != 6 and (torch_dtype(out_np) == comp_t or code in _TO_BOOL_BIN):
         # default: one fused merge-path pass (function + prune inside the kernel)
         fill_in_kernel = fill if code not in _TO_BOOL_BIN else np.uint8(bool(fill))
+        if pkey is not None:
+            _SAME_SHAPE_PLANS[pkey] = (name, comp_t, fa, fb, fill_in_kernel, fill)
         keys, res = merge_union(name, a.linear_loc(), ad, b.linear_loc(), bd, fa, fb, fill_in_kernel)
         out = COO._from_sorted_keys(keys, res, shape, fill, a._index_dtype)
         return out.asformat(out_type, **out_kwargs) if out_type != "coo" else out

@@ -172,6 +172,44 @@ __device__ __forceinline__ unsigned long long lookback_exclusive(unsigned long l
 }
 #endif
 
+// Exclusive scan of a SHORT int64 array by one workgroup of 1024 threads (out[i] = in[0] + .. + in[i-1], i < n; in == out
+// allowed): a device-wide scan primitive costs ~30 us whatever the length (several launches, look-back state), which at
+// config-1 sizes (a few hundred tile counts) is as much as the kernel it serves.
+constexpr int SMALL_SCAN_MAX = 16384;
+#ifdef __HIPCC__
+static __global__ void __launch_bounds__(1024) small_exclusive_scan_kernel(const int64_t* in, int64_t* out, int n) {
+  constexpr int PER = SMALL_SCAN_MAX / 1024;
+  __shared__ int64_t wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int64_t v[PER];
+  int64_t mine = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int i = tid * PER + j;
+    v[j] = i < n ? in[i] : 0;
+    mine += v[j];
+  }
+  int64_t incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int64_t y = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += y;
+  }
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  int64_t run = incl - mine;
+#pragma unroll
+  for (int w = 0; w < 16; ++w)
+    if (w < wv) run += wsum[w];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int i = tid * PER + j;
+    if (i < n) out[i] = run;
+    run += v[j];
+  }
+}
+#endif
+
 }  // namespace spamd
 
 // Dispatch helpers: call F<T,I>(...) for runtime dtype codes.

@@ -384,9 +384,13 @@ static int group_reduce_t(int op, int64_t n, const int64_t* keys, int64_t diviso
     hipLaunchKernelGGL(gr_count_kernel<GroupOfD>, dim3((unsigned)nt), dim3(GR_THREADS), 0, s, keys, n, gofd, tile_heads);
   else
     hipLaunchKernelGGL(gr_count_kernel<GroupOf>, dim3((unsigned)nt), dim3(GR_THREADS), 0, s, keys, n, gof, tile_heads);
-  hipError_t e = rocprim::exclusive_scan(scan_ws, scan_bytes, tile_heads, tile_first, (int64_t)0, (size_t)(nt + 1),
-                                         rocprim::plus<int64_t>(), s);
-  if (e != hipSuccess) return (int)e;
+  if (nt + 1 <= SMALL_SCAN_MAX) {
+    hipLaunchKernelGGL(small_exclusive_scan_kernel, dim3(1), dim3(1024), 0, s, tile_heads, tile_first, (int)(nt + 1));
+  } else {
+    hipError_t e = rocprim::exclusive_scan(scan_ws, scan_bytes, tile_heads, tile_first, (int64_t)0, (size_t)(nt + 1),
+                                           rocprim::plus<int64_t>(), s);
+    if (e != hipSuccess) return (int)e;
+  }
   if (small)
     hipLaunchKernelGGL((gr_reduce_kernel<T, GroupOfD>), dim3((unsigned)nt), dim3(GR_THREADS), 0, s, op, keys, data, n, gofd,
                        tile_first, gids, vals, counts, open_head, open_tail);

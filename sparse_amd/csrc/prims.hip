@@ -671,6 +671,10 @@ extern "C" int64_t spamd_scan_ws_bytes(int64_t n) {
 extern "C" int spamd_exclusive_scan(int64_t n, const int64_t* in, int64_t* out, void* ws, int64_t ws_bytes,
                                     void* stream) {
   if (n < 0) return SPAMD_EINVAL;
+  if (n + 1 <= SMALL_SCAN_MAX) {   // short arrays: one workgroup (the device-wide primitive costs ~30 us at any length)
+    hipLaunchKernelGGL(small_exclusive_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, in, out, (int)(n + 1));
+    return launch_status();
+  }
   size_t bytes = (size_t)ws_bytes;
   hipError_t e = rocprim::exclusive_scan(ws, bytes, in, out, (int64_t)0, (size_t)(n + 1), rocprim::plus<int64_t>(),
                                          (hipStream_t)stream);
