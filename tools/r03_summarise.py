@@ -1,0 +1,36 @@
+"""Summarise the round-3 evidence run: per kernel (name prefix) the rocprofv3 average duration and, from the PMC passes over
+bench_paths.py, the fabric-side bytes per launch (reads = 2 * FETCH_SIZE * 1024 on gfx950, writes = WRITE_SIZE * 1024:
+MI355X_MICROARCH.md, HBM section), the L2 hit rate and the LDS / wave-cycle counters.  -> JSON on stdout."""
+import csv, glob, json, os, re, sys
+root = sys.argv[1]
+def short(n):
+    n = re.sub(r"\(.*", "", n)           # drop the argument list
+    n = re.sub(r"^void\s+", "", n)
+    return n[:140]
+stats = {}
+for p in glob.glob(os.path.join(root, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    for r in csv.DictReader(open(p)):
+        stats[short(r["Name"])] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6, "total_ms": float(r["TotalDurationNs"]) / 1e6}
+pmc = {}
+for p in glob.glob(os.path.join(root, "pmc_paths", "*", "**", "*counter_collection.csv"), recursive=True):
+    acc = {}
+    for r in csv.DictReader(open(p)):
+        k = (short(r["Kernel_Name"]), r["Counter_Name"])
+        d = acc.setdefault(k, {})
+        d[r["Dispatch_Id"]] = d.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+    for (kern, ctr), per in acc.items():
+        pmc.setdefault(kern, {})[ctr] = sum(per.values()) / len(per)
+        pmc[kern]["dispatches"] = len(per)
+out = {}
+for kern, c in pmc.items():
+    if "spamd" not in kern and "reduce_fill" not in kern:
+        continue
+    e = dict(c)
+    if "FETCH_SIZE" in c: e["fabric_read_bytes_per_launch"] = 2 * c["FETCH_SIZE"] * 1024
+    if "WRITE_SIZE" in c: e["fabric_write_bytes_per_launch"] = c["WRITE_SIZE"] * 1024
+    if "TCC_HIT_sum" in c and c.get("TCC_REQ_sum"): e["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+    if c.get("SQ_LDS_IDX_ACTIVE"): e["lds_conflict_share_of_lds_cycles"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]
+    if kern in stats: e["rocprof_avg_ms"] = stats[kern]["avg_ms"]; e["rocprof_calls"] = stats[kern]["calls"]
+    out[kern] = e
+print(json.dumps({"what": "tools/run_r03_profiles.sh", "kernels": out,
+                  "kernel_stats_top": dict(sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"])[:40])}, indent=1))
