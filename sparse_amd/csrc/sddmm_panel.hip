@@ -13,7 +13,6 @@
 //   * the DISTINCT A rows of those elements (~41 at config 4: runs of equal rows are found with one block scan) are staged
 //     in LDS by ONE burst of loads issued by all 256 threads - no A latency is left on any element's critical path,
 //     a row is fetched once per workgroup instead of once per lane group that meets it;
-//   * UNR Bt rows per lane group are in flight (8 for 512-byte rows) instead of 4;
 //   * the arithmetic is the row-cached kernel's: the same lanes hold the same K positions, the products are added in
 //     the same order, the 16-lane sum is the same DPP tree - results are bit-identical to spamd_sddmm's
 //     (tests/test_sddmm_gpu.py::test_sddmm_column_panel_order_is_bit_identical).
@@ -23,6 +22,9 @@
 
 namespace spamd {
 
+#ifndef SDP_UNR
+#define SDP_UNR 4   // Bt rows per lane group in flight (8: 100 registers, four waves per SIMD, 0.323 ms at config 4; 4: 0.313; 2: 0.316)
+#endif
 #ifndef SDP_NT_A
 #define SDP_NT_A 0   // 1: A rows with the non-temporal hint (they then come from HBM instead of the Infinity Cache)
 #endif
@@ -239,7 +241,7 @@ static int launch_panel(int64_t nnz, const I* rows, const I* cols, const TS* s, 
                        ldb, out, perm, xstate);                                                                \
     return launch_status();                                                                                    \
   }
-    SDP(16, 1, 8) SDP(16, 2, 8) SDP(32, 1, 8)   // (rows below 1 KB: see spamd_sddmm_panels)
+    SDP(16, 1, SDP_UNR) SDP(16, 2, SDP_UNR) SDP(32, 1, SDP_UNR)   // (rows below 1 KB: see spamd_sddmm_panels)
 #undef SDP
   }
   return SPAMD_EINVAL;

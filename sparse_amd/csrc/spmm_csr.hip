@@ -133,7 +133,16 @@ spmm_csr_rowgroup_kernel(int64_t M, int64_t N, const T* __restrict__ a_data,
       }
 #pragma unroll
       for (int h = 0; h < CH; ++h)
+#ifdef SPMM_PLAIN_STORE
+        if (row_ok && col_ok[h]) {
+          V o;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) o.v[e] = acc[h][e];
+          *reinterpret_cast<V*>(out + row * ldo + col[h]) = o;
+        }
+#else
         if (row_ok && col_ok[h]) nt_store<T, VEC>(out + row * ldo + col[h], acc[h]);
+#endif
     }
   }
 }
