@@ -25,6 +25,9 @@ namespace spamd {
 #ifndef SDP_UNR
 #define SDP_UNR 4   // Bt rows per lane group in flight (8: 100 registers, four waves per SIMD, 0.323 ms at config 4; 4: 0.313; 2: 0.316)
 #endif
+#ifndef SDP_BLK
+#define SDP_BLK 256   // elements (= threads) per workgroup
+#endif
 #ifndef SDP_NT_A
 #define SDP_NT_A 0   // 1: A rows with the non-temporal hint (they then come from HBM instead of the Infinity Cache)
 #endif
@@ -222,7 +225,7 @@ static int launch_panel(int64_t nnz, const I* rows, const I* cols, const TS* s, 
     // LDS slots for A rows: 24 KB by default (six workgroups per CU), at least 16 rows, never more than a workgroup
     // has elements
     int cap = cap_rows > 0 ? (int)cap_rows : std::max(16, (24 << 10) / rowb);
-    const int blk = 256;
+    const int blk = SDP_BLK;
     if (cap > blk) cap = blk;
     int64_t blocks = ceil_div(nnz, (int64_t)blk);
     if (xstate) blocks = 8 * std::max<int64_t>(ceil_div(xmax, (int64_t)blk), 1);
@@ -230,7 +233,7 @@ static int launch_panel(int64_t nnz, const I* rows, const I* cols, const TS* s, 
     const size_t lds = (size_t)cap * rowb + 1024 + 2 * blk * sizeof(I) + 16;
 #define SDP(LL, KK, UU)                                                                                        \
   if (L == LL && ks == KK) {                                                                                   \
-    constexpr int BLK = 256;                                                                                   \
+    constexpr int BLK = SDP_BLK;                                                                               \
     auto kern = &sddmm_panel_kernel<TIN, TS, I, LL, KK, UU, BLK>;                                              \
     if (lds > 48 * 1024) {                                                                                     \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                  \

@@ -31,7 +31,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "chunks":
         plan = K.sddmm_panels(coords, (M, N), K.sddmm_panel_width(bt))
         ref0 = K.sddmm_coo(coords, s, a, bt)
         line = []
-        for ch in (0, 32, 40, 48, 64, 80):
+        for ch in (0, 16, 20, 24, 28, 32, 48):
             plan.chunk = ch
             t1, got = timeit(lambda: K.sddmm_coo(coords, s, a, bt, panels=plan))
             line.append(f"cap {ch}: {t1:.3f}{'' if torch.equal(got, ref0) else ' WRONG'}")
