@@ -203,3 +203,52 @@ def test_sddmm_with_a_misaligned_bf16_view_takes_the_sampled_kernel(sp):
     got = sp.sddmm(s, a, bt.T)
     want = sp.sddmm(s, a.clone(), bt.clone().T)
     assert got.nnz == want.nnz and torch.equal(got.data, want.data)
+
+
+def test_fused_merge_equals_the_two_launch_form(sp):
+    """`x (op) y` through the one-launch merge (in-kernel partition, self-cleaning workspace, pinned output count) and
+    through the partition kernel + merge kernel: keys and values bit for bit, for sizes that change the tile count between
+    calls (the workspace is shared and must come back zeroed) and for every result density (union, intersection, empty)."""
+    from sparse_amd import _umath
+
+    rng = np.random.default_rng(11)
+    shape = (300, 400, 50)
+    size = int(np.prod(shape))
+    for na, nb in ((5000, 7000), (200_000, 150_000), (1, 1), (3000, 0), (600_000, 900_000), (10, 40_000)):
+        ka = np.sort(rng.choice(size, na, replace=False)) if na else np.zeros(0, np.int64)
+        kb = np.sort(rng.choice(size, nb, replace=False)) if nb else np.zeros(0, np.int64)
+        if na and nb:
+            kb = np.unique(np.concatenate([kb, ka[::3][:1000]]))   # positions stored in both operands
+        x = sp.COO(np.stack(np.unravel_index(ka, shape)), rng.random(len(ka)) - 0.5, shape=shape, has_duplicates=False, sorted=True)
+        y = sp.COO(np.stack(np.unravel_index(kb, shape)), rng.random(len(kb)) - 0.5, shape=shape, has_duplicates=False, sorted=True)
+        for f in (np.add, np.multiply, np.maximum, np.greater):
+            _umath.MERGE_FUSED = True
+            a = f(x, y)
+            _umath.MERGE_FUSED = False
+            try:
+                b = f(x, y)
+            finally:
+                _umath.MERGE_FUSED = True
+            assert a.nnz == b.nnz and torch.equal(a.linear_loc(), b.linear_loc()) and torch.equal(a.data, b.data), (na, nb, f)
+            assert np.array_equal(a.fill_value, b.fill_value)
+    ws = next(iter(_umath._MergeWorkspace._pool.values()))
+    assert int(ws.ws.abs().sum()) == 0, "the fused merge must leave its workspace zeroed"
+
+
+def test_reduction_drops_results_equal_to_the_fill_value_in_one_read(sp):
+    """Sums that cancel to exactly 0.0, maxima of negative numbers against a zero fill, products with a stored zero: results
+    bit-equal to the result's fill value are not stored (the count comes back with the group count in one host read)."""
+    d = np.zeros((6, 8))
+    d[0, :2] = (1.5, -1.5)          # cancels exactly
+    d[1, 3] = 2.0
+    d[2, :] = -1.0                  # max over a full row of negatives stays stored; over a partial row it is the fill 0
+    d[3, 1] = -4.0
+    d[4, 2:4] = (3.0, 0.25)
+    x = sp.COO.from_numpy(d)
+    for name, f in (("sum", np.add), ("max", np.maximum), ("min", np.minimum), ("prod", np.multiply)):
+        got = f.reduce(x, axis=1)
+        want = f.reduce(d, axis=1)
+        assert np.array_equal(got.todense(), want), name
+        assert got.nnz == np.count_nonzero(want.view(np.uint64) != np.asarray(got.fill_value).view(np.uint64)), name
+    s = x.sum(axis=1)
+    assert s.nnz == 4 and 0 not in s.coords[0].tolist()
