@@ -126,6 +126,36 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
         del a64, i64, p64, r
         torch.cuda.empty_cache()
 
+    # ---- shapes outside the executor's round-2 policy, on the same matrix ------------------------
+    if int64_of is not None and want("A1_shapes"):
+        data, idx, ptr, b, M, Kd, N = int64_of
+        nnz = int(data.numel())
+        a32 = sp.GCXS((data, idx, ptr), shape=(M, Kd), compressed_axes=(0,))
+        b32 = b[:, :32].contiguous()
+        ms_rg, _ = timed(lambda: K.dot_csr_ndarray((M, 32), data, idx, ptr, b32), reps=5)
+        a32 @ b32
+        ms, r = timed(lambda: a32 @ b32, reps=10)
+        emit("A1_shapes_n32", row(f"config-2 matrix x dense {Kd}x32 fp32 (narrow result: B zero-padded to one 128-column panel, C written "
+                                  f"unpadded by the executor)", ms, nnz * 8 + (M + 1) * 4 + Kd * 32 * 4 + M * 32 * 4,
+                                  flops=2.0 * nnz * 32, rowgroup_ms=ms_rg, speedup_vs_rowgroup=ms_rg / ms))
+        m5 = 50_000
+        p5 = int(ptr[m5])
+        d5, i5, q5 = data[:p5].contiguous(), idx[:p5].contiguous(), ptr[:m5 + 1].contiguous()
+        ms_rg, _ = timed(lambda: K.dot_csr_ndarray((m5, N), d5, i5, q5, b), reps=10)
+        lay = K.csr_tiled_layout(d5, i5, q5, m5, Kd)
+        ms_tl, _ = timed(lambda: K.dot_csr_ndarray_tiled(lay, (m5, N), Kd, b), reps=10)
+        emit("A1_shapes_m50k", row(f"first {m5} rows of the config-2 matrix ({p5} nnz) x dense {Kd}x{N} fp32: the row-group kernel "
+                                   f"(policy below 65536 rows: 90 workgroups of 560 rows do not fill 256 CUs)", ms_rg,
+                                   p5 * 8 + (m5 + 1) * 4 + Kd * N * 4 + m5 * N * 4, flops=2.0 * p5 * N, tiled_forced_ms=ms_tl))
+        di = (data * 100).to(torch.int32)
+        bi = (b * 10).to(torch.int32)
+        ms_i, _ = timed(lambda: K.dot_csr_ndarray((M, N), di, idx, ptr, bi), reps=5)
+        emit("A1_shapes_int32_values", row(f"config-2 matrix with int32 values x dense {Kd}x{N} int32 (exact integer products: the "
+                                           f"row-group kernel, no executor variant)", ms_i, nnz * 8 + (M + 1) * 4 + Kd * N * 4 + M * N * 4,
+                                           flops=2.0 * nnz * N))
+        del a32, b32, r, d5, i5, q5, lay, di, bi
+        torch.cuda.empty_cache()
+
     # ---- config 1: COO + COO, (1000,1000,1000), 1e6 nnz each, f64 / int64 ---------------------------------------------
     if want("A7") or want("A8"):
         nnz = 1_000_000 // q

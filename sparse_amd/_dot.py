@@ -335,7 +335,9 @@ def _tiled_dtype(data, bt):
 
 
 def _tiled_eligible(data, bt, out_shape, Kd):
-    """The inspector/executor kernel covers float32 (N % 128 == 0) and float64 (N % 64 == 0) products.  Thresholds
+    """The inspector/executor kernel covers float32 and float64 products whose B is (padded to) whole 128- / 64-column
+    panels; from N = 32 (float32) / 16 (float64) on the padded product beats the row-group kernel (round 3, config-2 operand:
+    N = 32 fp32 0.80 vs 1.18 ms, N = 16 fp64 1.03 vs 1.32 ms; tools/rowgroup_shapes.py).  Thresholds
     measured on MI355X (tools/tiled_crossover.py): it needs >= 117 workgroups of 560 rows to beat the row-group
     kernel, and a density of >= 0.3 % (12 stored elements per 32 x 128 cells: ~16 per (35-row x 160-column) list) — half
     that when B is too large for the row-group kernel's gathers to stay in cache (>= 16 MB).  The inspector costs about one row-group product, so
@@ -344,7 +346,7 @@ def _tiled_eligible(data, bt, out_shape, Kd):
     if _settings.TILED_SPMM == "never" or bt.dim() != 2:
         return False
     dt = _tiled_dtype(data, bt)
-    if dt is None or N < (64 if dt == torch.float32 else 32):   # narrower results: the row-group kernel
+    if dt is None or N < (32 if dt == torch.float32 else 16):   # narrower results: the row-group kernel
         return False
     if (Kd + 512) * N * bt.element_size() >= (1 << 32):   # the executor walks B with 32-bit byte offsets (buffer-form tile DMA)
         return False
@@ -491,13 +493,15 @@ def _gcxs_times_dense(a, bt, out_shape):
         panel = 128 if dt == torch.float32 else 64
         bt = bt.to(dt)
         if N % panel:
-            # a workgroup covers whole 512-byte column panels: zero-pad B (small) to the next panel and slice the
-            # result (one extra pass over C; still 3-5x faster than the row-group kernel for wide results)
+            # a workgroup covers whole 512-byte column panels: B (small) is zero-padded to the next panel; the result is
+            # NOT - the last panel stores its leading columns only (float32: a lane stores two columns, so an odd N
+            # still takes the padded result + slice)
             npad = -(-N // panel) * panel
             bp = torch.zeros((Kd, npad), dtype=dt, device=bt.device)
             bp[:, :N] = bt
-            res = _tiled_product(a, dt, (M, npad), Kd, bp)
-            return res[:, :N].contiguous()
+            if dt == torch.float32 and N % 2:
+                return _tiled_product(a, dt, (M, npad), Kd, bp)[:, :N].contiguous()
+            return _tiled_product(a, dt, (M, N), Kd, bp)
         return _tiled_product(a, dt, out_shape, Kd, bt)
     return K.dot_csr_ndarray(out_shape, data, indices, indptr, bt, exact=_settings.EXACT_MULADD)
 

@@ -1114,16 +1114,23 @@ def csr_tiled_layout(a_data, a_indices, a_indptr, M, Kd, force_sort=False, dtype
 
 
 def dot_csr_ndarray_tiled(layout, out_shape, Kd, b, out=None, exact=False):
-    """Executor: C = A @ B from the tiled layout (float32: N % 128 == 0, float64: N % 64 == 0); `exact` = separate
-    multiply and add (the reference's arithmetic) instead of one FMA per term."""
+    """Executor: C = A @ B from the tiled layout; `exact` = separate multiply and add (the reference's arithmetic) instead
+    of one FMA per term.  B provides whole column panels (float32: 128 columns, float64: 64; `b.shape[1]` a multiple of
+    that, zero-padded by the caller); `out_shape[1]` may be narrower than B (even for float32): the last panel then stores
+    its leading columns only - no padded result, no slice afterwards."""
     blocks, blk_off, dtype = layout
-    M, N = int(out_shape[0]), int(out_shape[1])
+    M, N = int(out_shape[0]), int(b.shape[1])
+    Nout = int(out_shape[1])
+    panel = 128 if dtype == torch.float32 else 64
+    if N % panel or not (N - panel < Nout <= N) or (dtype == torch.float32 and Nout % 2):
+        raise ValueError(f"tiled executor: B has {N} columns (whole {panel}-column panels expected), result {Nout}")
+    last_cols = (Nout - (N - panel)) % panel    # 0 = the whole last panel
     dev = require_hip(blocks, blk_off, b)
     if b.dtype != dtype:
         raise TypeError(f"tiled layout holds {dtype} values, B is {b.dtype}")
     b = b.contiguous()
     if out is None:
-        out = torch.empty((M, N), dtype=dtype, device=dev)
+        out = torch.empty((M, Nout), dtype=dtype, device=dev)
     # prefetch hint: ~1.5 x the mean number of 64-byte blocks per (row group, tile) list
     lists = max(int(blk_off.numel()) - 1, 1)
     mean_blocks = getattr(layout, "mean_blocks", None) or (int(blocks.numel()) // 16) / lists
@@ -1131,8 +1138,8 @@ def dot_csr_ndarray_tiled(layout, out_shape, Kd, b, out=None, exact=False):
     if _TOUCH_OVERRIDE:
         hint = _TOUCH_OVERRIDE
     ends = _ffi.TILED_GROUP_ENDS if getattr(layout, "group_ends", False) else 0
-    _ffi.call("spamd_spmm_tiled", code_of(dtype), M, Kd, N, ptr(blocks), ptr(blk_off), ptr(b), N, ptr(out), N,
-              (_ffi.EXACT_MULADD if exact else 0) | ends | (hint << 8), stream_ptr(dev))
+    _ffi.call("spamd_spmm_tiled", code_of(dtype), M, Kd, N, ptr(blocks), ptr(blk_off), ptr(b), N, ptr(out), Nout,
+              (_ffi.EXACT_MULADD if exact else 0) | ends | (hint << 8) | (last_cols << 16), stream_ptr(dev))
     pending = getattr(layout, "pending", None)
     if pending is not None:   # first product of a layout built with defer_check: the verdict is read now, behind the launch
         layout.pending = None

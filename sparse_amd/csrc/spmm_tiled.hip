@@ -440,7 +440,7 @@ template <int DBG, int MODE, typename T>
 __global__ void __launch_bounds__(TL_WAVES * 64) __attribute__((amdgpu_num_vgpr(TL_ASM_COMP)))
 spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, int touch_lines, const int* __restrict__ stream,
                   const int* __restrict__ blk_off, const T* __restrict__ b, int64_t ldb,
-                  T* __restrict__ out, int64_t ldo) {
+                  T* __restrict__ out, int64_t ldo, int last_cols) {
   constexpr int PANEL = TlFmt<T>::PANEL;            // columns per workgroup: 512 bytes of every B row
   constexpr int CPL = PANEL / 64;                   // columns per lane
   extern __shared__ __attribute__((aligned(16))) char lds[];  // the only LDS object: starts at LDS byte 0
@@ -536,11 +536,16 @@ spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, int touch_lines, const int* 
   const int nvalid = left <= 0 ? 0 : (left < TL_RG ? (int)left : TL_RG);
   T* const obase_p = out + row0 * ldo + lane * CPL;
   const int64_t stride_bytes = ldo * (int64_t)sizeof(T);
-  asm volatile(TL_ASM_STORE
-               :
-               : [lo] "v"((unsigned)((uintptr_t)obase_p & 0xffffffffu)), [hi] "v"((unsigned)((uintptr_t)obase_p >> 32)),
-                 [stride] "s"(stride_bytes), [n] "s"(nvalid)
-               : "memory", "scc", "s36", TL_ASM_BASE, TL_ASM_TOUCH, TL_CLOB_ACC);
+  // a result narrower than a whole number of panels: the last panel stores its first `last_cols` columns only (B is
+  // zero-padded to whole panels by the caller, C is not: no padded result, no slice pass afterwards); the store block
+  // runs under the branch's exec mask
+  const int ncols = (last_cols > 0 && blockIdx.y == gridDim.y - 1) ? last_cols : PANEL;
+  if (lane * CPL < ncols)
+    asm volatile(TL_ASM_STORE
+                 :
+                 : [lo] "v"((unsigned)((uintptr_t)obase_p & 0xffffffffu)), [hi] "v"((unsigned)((uintptr_t)obase_p >> 32)),
+                   [stride] "s"(stride_bytes), [n] "s"(nvalid)
+                 : "memory", "scc", "s36", TL_ASM_BASE, TL_ASM_TOUCH, TL_CLOB_ACC);
 }
 
 static int64_t tl_grid_groups(int64_t M) { return ceil_div(ceil_div(M, (int64_t)TL_RG), (int64_t)TL_WAVES) * TL_WAVES; }
@@ -720,12 +725,13 @@ static int tl_set_lds_once(const void* kern) {
 
 template <typename T, typename KERN>
 static int tl_launch(KERN kern, int64_t M, int64_t K, int64_t N, const int* blocks, const int* blk_off, const T* b,
-                     int64_t ldb, T* out, int64_t ldo, int touch_lines, bool group_ends, hipStream_t s) {
+                     int64_t ldb, T* out, int64_t ldo, int touch_lines, bool group_ends, int last_cols, hipStream_t s) {
   // the 160 KB dynamic-LDS opt-in is a per-function attribute: set once per kernel, not on every multiply
   if (int rc = tl_set_lds_once(reinterpret_cast<const void*>(kern))) return rc;
   const int64_t blocks_n = tl_grid_groups(M) / TL_WAVES;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks_n, (unsigned)(N / TlFmt<T>::PANEL)), dim3(TL_WAVES * 64), TL_LDS, s, M, K,
-                     (int)ceil_div(K, (int64_t)TL_KB), touch_lines | (group_ends ? 1 << 16 : 0), blocks, blk_off, b, ldb, out, ldo);
+                     (int)ceil_div(K, (int64_t)TL_KB), touch_lines | (group_ends ? 1 << 16 : 0), blocks, blk_off, b, ldb, out, ldo,
+                     last_cols);
   return launch_status();
 }
 
@@ -742,6 +748,11 @@ extern "C" int spamd_spmm_tiled(int val_dtype, int64_t M, int64_t K, int64_t N, 
   hipStream_t s = (hipStream_t)stream;
   const bool exact = (flags & SPAMD_EXACT_MULADD) != 0;
   const bool ends = (flags & SPAMD_TILED_GROUP_ENDS) != 0;
+  // flags bits 16..23: columns of the LAST panel that are stored (0 = the whole panel).  N stays the padded width (whole
+  // panels, which is what B must provide: the tile DMA reads 512 bytes of every row of B per panel); `out` then needs room for
+  // N - panel + that many columns per row only.  Even for float32 (a lane stores two columns).
+  const int last_cols = (int)((flags >> 16) & 0xffu);
+  if (last_cols > panel || (val_dtype == SPAMD_F32 && (last_cols & 1))) return SPAMD_EINVAL;
   // lines of a list that are pulled into L2 two phases ahead (flags bits 8..15; 0 = default): the launcher derives
   // it from the mean list length, longer lists pay the HBM latency on their remaining blocks
   int touch = (int)((flags >> 8) & 0xffu);
@@ -750,8 +761,8 @@ extern "C" int spamd_spmm_tiled(int val_dtype, int64_t M, int64_t K, int64_t N, 
   if (val_dtype == SPAMD_F64) {
     const double* bb = (const double*)b;
     double* oo = (double*)out;
-    return exact ? tl_launch<double>(&spmm_tiled_kernel<0, 5, double>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, s)
-                 : tl_launch<double>(&spmm_tiled_kernel<0, 4, double>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, s);
+    return exact ? tl_launch<double>(&spmm_tiled_kernel<0, 5, double>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s)
+                 : tl_launch<double>(&spmm_tiled_kernel<0, 4, double>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s);
   }
   const float* bb = (const float*)b;
   float* oo = (float*)out;
@@ -760,11 +771,11 @@ extern "C" int spamd_spmm_tiled(int val_dtype, int64_t M, int64_t K, int64_t N, 
   // reads/fma, 7 = neither DMA nor LDS reads nor fma.  The shipped library never reads the environment.
   const char* dbg_env = getenv("SPAMD_TILED_DBG");
   const int dbg = dbg_env ? atoi(dbg_env) : 0;
-  if (dbg == 2) return tl_launch<float>(&spmm_tiled_kernel<2, 0, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, s);
-  if (dbg == 5) return tl_launch<float>(&spmm_tiled_kernel<0, 1, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, s);
-  if (dbg == 6) return tl_launch<float>(&spmm_tiled_kernel<0, 2, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, s);
-  if (dbg == 7) return tl_launch<float>(&spmm_tiled_kernel<2, 2, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, s);
+  if (dbg == 2) return tl_launch<float>(&spmm_tiled_kernel<2, 0, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s);
+  if (dbg == 5) return tl_launch<float>(&spmm_tiled_kernel<0, 1, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s);
+  if (dbg == 6) return tl_launch<float>(&spmm_tiled_kernel<0, 2, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s);
+  if (dbg == 7) return tl_launch<float>(&spmm_tiled_kernel<2, 2, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s);
 #endif
-  return exact ? tl_launch<float>(&spmm_tiled_kernel<0, 3, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, s)
-               : tl_launch<float>(&spmm_tiled_kernel<0, 0, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, s);
+  return exact ? tl_launch<float>(&spmm_tiled_kernel<0, 3, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s)
+               : tl_launch<float>(&spmm_tiled_kernel<0, 0, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s);
 }
