@@ -9,6 +9,7 @@ mkdir -p gpurun_out/r03
 timeout 300 python bench.py --steps 20 --warmup 5 2>&1 | tail -1 > gpurun_out/r03/bench_line.json
 ( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/r03/stats -o b -- python /root/repo/bench.py --steps 20 --warmup 5 --no-cpu > /root/repo/gpurun_out/r03/stats.log 2>&1 )
 bash tools/tools_pmc.sh r03 spmm_tiled fetch write tcc sq sq3 > gpurun_out/r03/pmc_headline.json 2>&1
+BENCH_ARGS=--no-tiled bash tools/tools_pmc.sh r03rg spmm_csr_rowgroup fetch write tcc > gpurun_out/r03/pmc_rowgroup.json 2>&1
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo
 mkdir -p $R/gpurun_out/r03/pmc_paths

@@ -1,12 +1,12 @@
 #!/bin/bash
 # rocprofv3 PMC passes for the bench's dominant kernel (each counter group in its own run,
 # with --kernel-trace only, as gpurun requires).  Output CSVs under gpurun_out/pmc_<tag>/.
-# usage: tools_pmc.sh <tag> <kernel-name-substring> [pass ...]   (passes: fetch write tcc sq grbm)
+# usage: [BENCH_ARGS=--no-tiled] tools_pmc.sh <tag> <kernel-name-substring> [pass ...]   (passes: fetch write tcc sq grbm)
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo
 tag=${1:-r01}; needle=${2:-spmm_csr}; shift; shift
 passes=${@:-fetch write}
-run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_$tag/$name -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu --no-paths > $R/gpurun_out/pmc_$tag/$name.log 2>&1; }
+run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_$tag/$name -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu --no-paths $BENCH_ARGS > $R/gpurun_out/pmc_$tag/$name.log 2>&1; }
 mkdir -p $R/gpurun_out/pmc_$tag
 for p in $passes; do
   case $p in
