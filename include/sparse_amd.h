@@ -255,6 +255,10 @@ int spamd_ewise_binary(int op, int val_dtype, int64_t n, const void* a, int a_is
  *   21 reciprocal 22 positive 23 log2 24 log10 25 exp2 26 arcsinh 27 arctanh 28 cbrt 29 deg2rad
  *   30 rad2deg (out dtype = val_dtype); 64 isnan 65 isinf 66 isfinite 67 logical_not 68 signbit (out U8) */
 int spamd_ewise_unary(int op, int val_dtype, int64_t n, const void* a, void* out, void* stream);
+/* out[i] = mask[i] ? a[i] : b[i] (`np.where` on aligned arrays of 1-, 4- or 8-byte elements, moved bit-wise; mask = 0/1 bytes;
+ * *_is_scalar broadcasts a 1-element device array) */
+int spamd_ewise_select(int elem_bytes, int64_t n, const void* mask_u8, const void* a, int a_is_scalar, const void* b,
+                       int b_is_scalar, void* out, void* stream);
 
 /* Merge-path form of the same union, fused with the function and the prune (the default path):
  *   nblocks = spamd_merge_num_blocks(na, nb);  part[nblocks+1] <- spamd_merge_partition;

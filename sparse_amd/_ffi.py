@@ -81,6 +81,7 @@ SIGNATURES = {
     "spamd_fill": (_int, [_int, _i64, _vp, _C.c_uint64, _vp]),
     "spamd_ewise_binary": (_int, [_int, _int, _i64, _vp, _int, _vp, _int, _vp, _vp]),
     "spamd_ewise_unary": (_int, [_int, _int, _i64, _vp, _vp, _vp]),
+    "spamd_ewise_select": (_int, [_int, _i64, _vp, _vp, _int, _vp, _int, _vp, _vp]),
     "spamd_segment_reduce": (_int, [_int, _int, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "spamd_spgemm_count": (_int, [_int, _i64, _i64, _vp, _vp, _vp, _vp]),
     "spamd_spgemm_expand": (_int, [_int, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),

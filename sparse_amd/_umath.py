@@ -323,6 +323,49 @@ def _loose_all_equal(value, array):
         return bool(np.all(eq))
 
 
+ELEMWISE_ON_DEVICE = True   # plain callables whose operations are exactly reproducible run on the device (`_trace`)
+
+
+def _on_device(func, ops, slots, keys, n, full_shape, out_dtype, devi):
+    """`func` over the union positions WITHOUT the nnz-sized host round trip: the callable is traced once into a graph of
+    exactly-rounded elementwise operations (`_trace.build`) and replayed on device arrays (stored value or fill value per
+    operand and union position; dense operands gathered at the union's positions).  None when `func` is not traceable -
+    the caller then evaluates it with NumPy on the host, as the reference does."""
+    from . import _trace
+    from ._coo import COO
+
+    spec = []
+    for v in ops:
+        if isinstance(v, COO):
+            spec.append(("array", v.dtype))
+        elif isinstance(v, np.ndarray) and v.ndim:
+            spec.append(("array", v.dtype))
+        else:
+            spec.append(("scalar", v[()] if isinstance(v, np.ndarray) else v))
+    root = _trace.build(func, spec)
+    if root is None:
+        return None
+    arrays = []
+    for v, slot in zip(ops, slots):
+        if isinstance(v, COO):
+            t = _full(n, np.asarray(v.fill_value)[()], v.data.dtype, devi)
+            if v.nnz:
+                K.scatter_into(_as_u8(t), slot, _as_u8(v.data))
+            arrays.append(t)
+        elif isinstance(v, np.ndarray) and v.ndim:
+            flat = dev.to_device(np.ascontiguousarray(np.broadcast_to(v, full_shape)).reshape(-1), devi)
+            arrays.append(K.gather(_as_u8(flat), keys).view(flat.dtype) if flat.dtype == torch.bool else K.gather(flat, keys))
+        else:
+            arrays.append(None)
+    try:
+        res = _trace.run(root, arrays, n, devi)
+    except _trace.Untraceable:
+        return None
+    if res.dtype != torch_dtype(out_dtype):
+        res = K.convert(res, torch_dtype(out_dtype))
+    return res
+
+
 def _elemwise_general(func, proc, kwargs, dtype_kw, finish):
     """The reference's `_Elemwise` for everything the fused kernels do not cover (_umath.py:392-751): ANY callable, any
     number of operands, dense operands, keyword arguments, non-zero fill values, broadcasting.
@@ -375,6 +418,10 @@ def _elemwise_general(func, proc, kwargs, dtype_kw, finish):
     ops = [broadcast_to(v, full_shape) if isinstance(v, COO) and tuple(v.shape) != tuple(full_shape) else v for v in host]
     keys, slots = _union_slots(ops, devi)
     n = int(keys.numel())
+    if ELEMWISE_ON_DEVICE and dtype_kw is None and not kwargs and not isinstance(func, np.ufunc) and n:
+        res = _on_device(func, ops, slots, keys, n, full_shape, out_dtype, devi)
+        if res is not None:
+            return finish(keys, res, full_shape, np.asarray(fill)[()], devi)
     hkeys = dev.to_numpy(keys)
     vals = []
     for v, slot in zip(ops, slots):

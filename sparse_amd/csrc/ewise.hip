@@ -395,6 +395,29 @@ extern "C" int spamd_ewise_binary(int op, int val_dtype, int64_t n, const void* 
   return launch_status();
 }
 
+// out[i] = mask[i] ? a[i] : b[i]  (np.where on aligned arrays; a / b may be one-element arrays broadcast as scalars);
+// values are moved bit-wise
+template <typename U>
+__global__ void __launch_bounds__(256) select_kernel(const uint8_t* __restrict__ mask, const U* __restrict__ a, int as,
+                                                     const U* __restrict__ b, int bs, int64_t n, U* __restrict__ out) {
+  GRID_STRIDE(i, n) out[i] = mask[i] ? a[i * as] : b[i * bs];
+}
+
+extern "C" int spamd_ewise_select(int elem_bytes, int64_t n, const void* mask_u8, const void* a, int a_is_scalar,
+                                  const void* b, int b_is_scalar, void* out, void* stream) {
+  if (n < 0) return SPAMD_EINVAL;
+  if (n == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int as = a_is_scalar ? 0 : 1, bs = b_is_scalar ? 0 : 1;
+  switch (elem_bytes) {
+    case 1: hipLaunchKernelGGL(select_kernel<uint8_t>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)mask_u8, (const uint8_t*)a, as, (const uint8_t*)b, bs, n, (uint8_t*)out); break;
+    case 4: hipLaunchKernelGGL(select_kernel<uint32_t>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)mask_u8, (const uint32_t*)a, as, (const uint32_t*)b, bs, n, (uint32_t*)out); break;
+    case 8: hipLaunchKernelGGL(select_kernel<uint64_t>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)mask_u8, (const uint64_t*)a, as, (const uint64_t*)b, bs, n, (uint64_t*)out); break;
+    default: return SPAMD_ETYPE;
+  }
+  return launch_status();
+}
+
 extern "C" int spamd_ewise_unary(int op, int val_dtype, int64_t n, const void* a, void* out, void* stream) {
   if (n < 0) return SPAMD_EINVAL;
   if (n == 0) return 0;

@@ -268,3 +268,37 @@ def test_one_pass_inspector_group_offsets_never_overlap():
                 assert first(e0[g], g) + used <= first(e0[g + 1], g + 1)
                 assert first(e0[g + 1], g + 1) - (first(e0[g], g) + used) <= tiles
             assert first(e0[-1], groups) <= -(-int(e0[-1]) // epb) + groups * tiles
+
+
+def test_elemwise_tracer_records_numpys_own_dtypes_and_refuses_what_is_not_exact():
+    """`_trace.build`: a plain callable over exactly-rounded operations becomes a graph whose every node carries the dtype
+    NumPy itself gives that step; anything else (transcendental functions, keywords, data-dependent control flow, other
+    dtypes) is refused, so that the caller evaluates it on the host as the reference does."""
+    import numpy as np
+
+    from sparse_amd import _trace
+
+    f32, f64, i32, i64 = (np.dtype(x) for x in ("f4", "f8", "i4", "i8"))
+
+    def dt(func, *spec):
+        root = _trace.build(func, list(spec))
+        return None if root is None else root.dtype
+
+    A = lambda d: ("array", d)   # noqa: E731
+    S = lambda v: ("scalar", v)  # noqa: E731
+    assert dt(lambda a, b, c: a * b + c, A(f64), A(f64), A(f64)) == f64
+    assert dt(lambda a, b: a * b + 3, A(f32), A(f32)) == f32                      # Python scalars are weak (NEP 50)
+    assert dt(lambda a, b: a * b + np.float64(3), A(f32), A(f32)) == f64
+    assert dt(lambda a, b: a / b, A(i32), A(i64)) == f64
+    assert dt(lambda a, b: (a > b) & (a != 0), A(f64), A(f32)) == np.dtype(bool)
+    assert dt(lambda a, b, c, d: np.maximum(a, b) - c * d, A(f64), A(f64), A(f64), S(2.0)) == f64
+    assert dt(lambda a, b: np.where(a > 0, a, b), A(f32), A(f64)) == f64
+    assert dt(lambda a: abs(a) ** 2 - (-a), A(i32)) == i32
+    assert dt(lambda a: a.astype(np.float32) * 2, A(i64)) == f32
+    assert dt(lambda a: np.sin(a) ** 2, A(f64)) is None                          # not bit-identical on the device
+    assert dt(lambda a: a ** 3, A(f64)) is None
+    assert dt(lambda a: a // 2, A(i64)) is None
+    assert dt(lambda a: np.clip(a, 0, 1), A(f64)) is None
+    assert dt(lambda a: a if a > 0 else -a, A(f64)) is None                       # data-dependent control flow
+    assert dt(lambda a: a + 1, A(np.dtype("f2"))) is None and dt(lambda a: a + 1j, A(f64)) is None
+    assert dt(lambda a: 5.0, A(f64)) is None                                      # a constant is not a graph

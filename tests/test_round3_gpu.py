@@ -282,3 +282,65 @@ def test_narrow_results_through_the_executor(sp, dtype, N):
         buf = torch.full((M * N + 4096,), 7.0, device="cuda", dtype=tdt)
         _kernels.dot_csr_ndarray_tiled(a._tiled_layouts[tdt], (M, N), K, bp, out=buf[: M * N].view(M, N))
         assert torch.equal(buf[: M * N].view(M, N), want) and bool((buf[M * N:] == 7.0).all())
+
+
+def test_common_lambdas_run_on_the_device_and_equal_numpy_bit_for_bit(sp):
+    """`elemwise` with plain callables over exactly-rounded operations: evaluated on the device from a traced graph (no
+    nnz-sized host round trip - the host evaluation is made to fail loudly here), results bit-identical to NumPy on the
+    dense arrays, fill values and pruning included; callables outside that set still take the host path."""
+    from sparse_amd import _umath
+
+    rng = np.random.default_rng(5)
+    shape = (40, 50, 6)
+
+    def arr(density, lo=-0.5, dtype=np.float64):
+        d = np.where(rng.random(shape) < density, rng.random(shape) + lo, 0.0)
+        return (d * 20).astype(dtype) if np.dtype(dtype).kind == "i" else d.astype(dtype)
+
+    x, y, z = arr(0.3), arr(0.4), arr(0.2)
+    xf, yi = arr(0.3, dtype=np.float32), arr(0.5, dtype=np.int32)
+    dense = rng.random(shape) + 0.5
+    cases = [
+        (lambda a, b, c: a * b + c, (x, y, z)),
+        (lambda a, b: a * b + 3, (x + 1, y - 2)),
+        (lambda a, b, c, d: np.maximum(a, b) - c * d, (x, y, z, 2.0)),
+        (lambda a, b: (a > b) & (a != 0), (x, y)),
+        (lambda a, b: np.where(a > b, a, b * 2) - 1, (x, y)),
+        (lambda a, b: abs(a) ** 2 / (b + 4), (x, yi)),
+        (lambda a, b: (a.astype(np.float64) - b) * 0.5, (xf, yi)),
+        (lambda a, b, c: a * b * c, (x, dense, y)),
+        (lambda a, b: -a + (b < 0), (xf, y)),
+        (lambda a: a * 2 + 1, (yi,)),
+    ]
+    called = []
+    orig = _umath._on_device
+
+    def spy(func, *a, **k):
+        r = orig(func, *a, **k)
+        called.append(r is not None)
+        return r
+
+    _umath._on_device = spy
+    try:
+        for k, (f, operands) in enumerate(cases):
+            args = [sp.COO.from_numpy(o) if isinstance(o, np.ndarray) and o is not dense else o for o in operands]
+            got = sp.elemwise(f, *args)
+            with np.errstate(all="ignore"):
+                want = f(*operands)
+            assert called[-1] is True, f"case {k} did not take the device path"
+            gd = got.todense()
+            assert gd.dtype == want.dtype and np.array_equal(gd.view(np.uint8), np.ascontiguousarray(want).view(np.uint8)), k
+            assert got.nnz == int(np.count_nonzero(~_same_bits(want, got.fill_value))), k
+        got = sp.elemwise(lambda a: np.sin(a) ** 2, sp.COO.from_numpy(x))       # not exactly reproducible: host path
+        assert called[-1] is False and np.array_equal(got.todense(), np.sin(x) ** 2)
+    finally:
+        _umath._on_device = orig
+
+
+def _same_bits(a, fill):
+    a = np.ascontiguousarray(a)
+    f = np.asarray(fill).astype(a.dtype)
+    if a.dtype == np.dtype(bool):
+        return a == f
+    u = {1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[a.dtype.itemsize]
+    return a.view(u) == f.reshape(1).view(u)[0]
