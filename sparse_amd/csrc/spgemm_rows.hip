@@ -291,6 +291,7 @@ spgemm_rowrank_kernel(int64_t n_col, int col_bits, int ebits, const I* __restric
   auto bucket_of = [&](KEY key) { return (int)(((uint64_t)(key >> ebits) * scale) >> 32); };
   int row_total = 0;
 
+#pragma unroll 1
   for (int pass = 0; pass < PASSES; ++pass) {
     const int b_lo = pass * NBP;   // this pass ranks the buckets [b_lo, b_lo + NBP)
     // ---- 1. bucket ---------------------------------------------------------------------------------------------------
@@ -344,7 +345,9 @@ spgemm_rowrank_kernel(int64_t n_col, int col_bits, int ebits, const I* __restric
     // heads are one contiguous LDS run [tb, tb + mine): the emission below can then map output slots to LDS slots.
     const int tb = cnt[tid * BPT];
     int mine = 0;
-#pragma unroll
+    // (a REAL loop: unrolled eight times with three sorting networks each, the kernel was 400 KB of code - six times the
+    // instruction cache two CUs share; nothing in the body is indexed by bb but LDS)
+#pragma unroll 1
     for (int bb = 0; bb < BPT; ++bb) {
       const int b = tid * BPT + bb;
       const int s0 = cnt[b];
