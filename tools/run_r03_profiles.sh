@@ -1,12 +1,16 @@
 # Round-3 evidence run (one gpurun call).  Everything lands under gpurun_out/r03/:
 #   bench_line.json     the driver's command (python bench.py), full line with `paths`
-#   stats/              rocprofv3 --kernel-trace --stats of the SAME command without the CPU leg: kernel averages of the
-#                       headline kernel and of every `paths` row's kernels
+#   stats_headline/     rocprofv3 --kernel-trace --stats of the driver's command without the CPU leg and without `paths`: the
+#                       headline kernel's average
+#   stats/              the same with `paths`: kernel averages of every other row's kernels
 #   pmc_headline.json   FETCH/WRITE/TCC/SQ counters of the headline kernel (one counter group per run, --kernel-trace only)
 #   pmc_paths/          FETCH_SIZE / WRITE_SIZE / TCC passes over bench_paths.py (every other section-8 row)
 cd /root/repo
 mkdir -p gpurun_out/r03
 timeout 300 python bench.py --steps 20 --warmup 5 2>&1 | tail -1 > gpurun_out/r03/bench_line.json
+# (two runs: the headline kernel also serves smaller shapes in `paths` - A2, the narrow and forced rows - so its average
+#  is only the headline's in a run without them)
+( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/r03/stats_headline -o b -- python /root/repo/bench.py --steps 20 --warmup 5 --no-cpu --no-paths > /root/repo/gpurun_out/r03/stats_headline.log 2>&1 )
 ( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/r03/stats -o b -- python /root/repo/bench.py --steps 20 --warmup 5 --no-cpu > /root/repo/gpurun_out/r03/stats.log 2>&1 )
 bash tools/tools_pmc.sh r03 spmm_tiled fetch write tcc sq sq3 > gpurun_out/r03/pmc_headline.json 2>&1
 BENCH_ARGS=--no-tiled bash tools/tools_pmc.sh r03rg spmm_csr_rowgroup fetch write tcc > gpurun_out/r03/pmc_rowgroup.json 2>&1
