@@ -91,6 +91,68 @@ def p2(buf, dset):
     return o
 
 
+HALF_SKIP = int(os.environ.get("TL_HALF_SKIP", "1"))   # the last block of a list skips its upper half when that is all padding
+
+
+def _with_half_skip(lines_lo, lines_hi, buf, label):
+    """`lines_lo` (entries below ENTRIES // 2) always, `lines_hi` only if the block's entry ENTRIES // 2 is a real one: padding
+    entries have d0 = 0 (a real d0 carries an accumulator index >= 2), and a list's entries are packed from the front, so
+    d0[ENTRIES // 2] == 0 means the whole upper half is padding."""
+    if not HALF_SKIP:
+        return lines_lo + lines_hi
+    return lines_lo + [f"s_cmp_eq_u32 s{d0_reg(buf, ENTRIES // 2)}, 0", f"s_cbranch_scc1 {label}f"] + lines_hi + [f"{label}:"]
+
+
+def p1_last(buf, dset, label):
+    """p1 for the LAST block of a list"""
+    half = ENTRIES // 2
+    lo, hi = [], []
+    for part, rng in ((lo, range(0, half)), (hi, range(half, ENTRIES))):
+        for i in rng:
+            d = DATASET[dset] + 2 * i
+            part.append(f"v_and_or_b32 v{d}, s{d0_reg(buf, i)}, %[mask], v{BASE}")
+        for i in rng:
+            d = DATASET[dset] + 2 * i
+            part.append(f"ds_read_b64 v[{d}:{d + 1}], v{d}")
+    return _with_half_skip(lo, hi, buf, label)
+
+
+def p2_last(buf, dset, label, exact=False):
+    """p2 / p2_exact for the LAST block of a list.  Exact mode: the products (no index mode) and the adds (under the index
+    mode) are two separate runs over the entries, each with its own skip of the upper half."""
+    half = ENTRIES // 2
+    lo_r, hi_r = list(range(0, half)), list(range(half, ENTRIES))
+
+    def muls(rng):
+        o = []
+        for i in rng:
+            d = DATASET[dset] + 2 * i
+            lo_, hi_ = val_pair(buf, i)
+            o.append(f"v_mul_f64 v[{d}:{d + 1}], v[{d}:{d + 1}], s[{lo_}:{hi_}]" if F64 else
+                     f"v_pk_mul_f32 v[{d}:{d + 1}], v[{d}:{d + 1}], s[{lo_}:{hi_}] op_sel:[0,1] op_sel_hi:[1,1]")
+        return o
+
+    def accs(rng, first):
+        o = []
+        for i in rng:
+            d = DATASET[dset] + 2 * i
+            lo_, hi_ = val_pair(buf, i)
+            mode = "gpr_idx(SRC1,DST)" if exact else "gpr_idx(SRC2,DST)"
+            o.append(f"s_set_gpr_idx_on s{d0_reg(buf, i)}, {mode}" if (first and i == rng[0]) else f"s_set_gpr_idx_idx s{d0_reg(buf, i)}")
+            if exact:
+                o.append(f"v_add_f64 v[{JUNK}:{JUNK + 1}], v[{d}:{d + 1}], v[{JUNK}:{JUNK + 1}]" if F64 else
+                         f"v_pk_add_f32 v[{JUNK}:{JUNK + 1}], v[{d}:{d + 1}], v[{JUNK}:{JUNK + 1}]")
+            elif F64:
+                o.append(f"v_fma_f64 v[{JUNK}:{JUNK + 1}], s[{lo_}:{hi_}], v[{d}:{d + 1}], v[{JUNK}:{JUNK + 1}]")
+            else:
+                o.append(f"v_pk_fma_f32 v[{JUNK}:{JUNK + 1}], v[{d}:{d + 1}], s[{lo_}:{hi_}], "
+                         f"v[{JUNK}:{JUNK + 1}] op_sel:[0,1,0] op_sel_hi:[1,1,1]")
+        return o
+
+    o = _with_half_skip(muls(lo_r), muls(hi_r), buf, label) if exact else []
+    return o + _with_half_skip(accs(lo_r, True), accs(hi_r, False), buf, label) + ["s_set_gpr_idx_off"]
+
+
 def p2_exact(buf, dset):
     """reference arithmetic (`out[i, j] += data * b[k, j]`, _common.py:752): a rounded product, then a rounded
     add - the products overwrite the B rows in place, only the adds run under the gpr-index mode"""
@@ -186,6 +248,9 @@ def list_loop(lds=True, fma=True, exact=False):
     line): lists are short (~5 blocks), so per-block loop bookkeeping is a large share of the issue slots."""
     P1 = p1 if lds else (lambda buf, dset: [])
     P2 = (p2_exact if exact else p2) if fma else (lambda buf, dset: [])
+    # the same for the LAST block of a list of four or more blocks: its upper half is skipped when it is all padding
+    P1L = (lambda buf, dset: p1_last(buf, dset, 8)) if lds else (lambda buf, dset: [])
+    P2L = (lambda buf, dset: p2_last(buf, dset, 8, exact)) if fma else (lambda buf, dset: [])
     o = []
     for _ in range((1 if STAGE == 1 else 0) if STAGE else DMA_AT_START):
         o += dma_hook()
@@ -213,8 +278,8 @@ def list_loop(lds=True, fma=True, exact=False):
         dc, dn = k % 2, (k + 1) % 2
         th = [dma_hook() if j < TAIL_HOOKS else [] for j in range(3)]
         o += [f"3{k}:"] + P1(nxt, dn) + P2(cur, dc) + ["s_waitcnt lgkmcnt(0)"] + th[0]
-        o += P1(nx2, dc) + P2(nxt, dn) + ["s_waitcnt lgkmcnt(0)"] + th[1]
-        o += P2(nx2, dc) + th[2] + ["s_branch 12f"]
+        o += P1L(nx2, dc) + P2(nxt, dn) + ["s_waitcnt lgkmcnt(0)"] + th[1]
+        o += P2L(nx2, dc) + th[2] + ["s_branch 12f"]
     # a list of one to three blocks (ring position 0)
     cur, nxt, nx2 = RING
     o += ["40:", "s_cmp_lt_u32 s38, 2", "s_cbranch_scc1 7f"]
