@@ -309,14 +309,16 @@ int spamd_reduce_fill(int op, int val_dtype, int64_t n, void* vals, const int64_
                       int64_t fill_i, void* stream);
 /* The same fold-in with the number of groups still on the device (*n_dev, as spamd_group_reduce leaves it; the grid is
  * sized for n_max), plus *n_eq (device int64, zeroed here) = how many folded results are bit-identical to
- * result_fill_bits: the host reads both numbers in one copy, and the result container's prune (`COO(..., prune=True)`,
+ * result_fill_bits (n_eq == n_dev + 1, the second word of spamd_group_reduce's n_groups, is already zero and not cleared
+ * again): the host reads both numbers in one copy, and the result container's prune (`COO(..., prune=True)`,
  * _coo/core.py:705-716) has nothing to do when *n_eq == 0. */
 int spamd_reduce_fill_count(int op, int val_dtype, int64_t n_max, const int64_t* n_dev, void* vals, const int64_t* counts,
                             int64_t n_cols, double fill_f, int64_t fill_i, uint64_t result_fill_bits, int64_t* n_eq,
                             void* stream);
 /* A8 in one pass: runs of equal (keys[i] / divisor) over SORTED keys are reduced together with their lengths
  * (two streaming passes, csrc/group_reduce.hip; fp sums in a fixed, reproducible order).  Outputs hold up to n entries;
- * *n_groups (device int64) receives the number of runs.  op as for spamd_segment_reduce;
+ * n_groups = device int64[2]: [0] receives the number of runs, [1] is cleared (the counter spamd_reduce_fill_count then
+ * accumulates into, so that the caller reads both numbers with one copy).  op as for spamd_segment_reduce;
  * val_dtype F32 | F64 | I32 | I64 | U8.  keys < key_bound (0 = unknown; below 2^53 the ids are computed in
  * double precision).  keys and data 16-byte aligned.  Workspace from spamd_group_reduce_ws_bytes. */
 int64_t spamd_group_reduce_ws_bytes(int val_dtype, int64_t n);

@@ -515,8 +515,10 @@ extern "C" int spamd_reduce_fill_count(int op, int val_dtype, int64_t n_max, con
                                        uint64_t result_fill_bits, int64_t* n_eq, void* stream) {
   if (n_max < 0 || op < R_ADD || op > R_FMIN || !n_dev || !n_eq) return SPAMD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(n_eq, 0, sizeof(int64_t), s);
-  if (e != hipSuccess) return (int)e;
+  if (n_eq != n_dev + 1) {   // (n_eq = n_dev + 1: the second word of spamd_group_reduce's n_groups, which that call has zeroed)
+    hipError_t e = hipMemsetAsync(n_eq, 0, sizeof(int64_t), s);
+    if (e != hipSuccess) return (int)e;
+  }
   if (n_max == 0) return 0;
   VAL_SWITCH5(val_dtype, T, {
     hipLaunchKernelGGL(reduce_fill_count_kernel<T>, dim3(grid_for(n_max)), dim3(256), 0, s, op, n_dev, (T*)vals, counts,
