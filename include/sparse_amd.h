@@ -45,6 +45,7 @@ extern "C" {
 #define SPAMD_TILED_GROUP_ENDS 2u /* spamd_spmm_tiled: blk_off has tiles + 1 entries per row group (spamd_spmm_tiled_inspect) */
 #define SPAMD_EXACT_MULADD 1u /* separate IEEE mul + add (bit-exact vs the reference's
                                  non-contracted loop) instead of fused multiply-add */
+#define SPAMD_SPMM_ROWGROUP 4u /* spamd_spmm_csr: keep the k-ascending row-group kernel for results of 1..4 columns too */
 
 /* Library/ABI version: major*10000 + minor*100 + patch. */
 int spamd_version(void);
@@ -63,6 +64,10 @@ const char* spamd_target_arch(void);
  *   `dtr = dt1*dt2`; the host layer promotes mixed inputs), strictly in storage order
  *   per output element, so with SPAMD_EXACT_MULADD the result is bit-identical to the
  *   reference loop; without it each step is one fused multiply-add.
+ *   Results of at most 4 columns (N = 1: the matrix-vector product) without SPAMD_EXACT_MULADD take the row-vector
+ *   kernel instead: the lanes of a wave run along a row and a butterfly adds their partial sums, i.e. a fixed TREE
+ *   order per row (deterministic; floating point within rounding of the k-ascending sum, integers identical).
+ *   SPAMD_SPMM_ROWGROUP keeps the k-ascending kernel for those widths as well.
  *   val_dtype: F32 | F64 | I32 | I64.   idx_dtype: I32 | I64 (a_indices and a_indptr).
  * ------------------------------------------------------------------------------------- */
 int spamd_spmm_csr(int val_dtype, int idx_dtype, int64_t M, int64_t K, int64_t N,

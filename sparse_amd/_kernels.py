@@ -25,10 +25,11 @@ def _unify_index(*idx):
     return [i if i.dtype == want else i.to(want) for i in idx], want
 
 
-def dot_csr_ndarray(out_shape, a_data, a_indices, a_indptr, b, *, exact=False, out=None):
+def dot_csr_ndarray(out_shape, a_data, a_indices, a_indptr, b, *, exact=False, out=None, keep_order=False):
     """C = A @ B, A in CSR, B dense row-major, C dense — `_dot_csr_ndarray`
     (reference _common.py:720-755).  `exact=True` reproduces the reference's separate
-    multiply/add bit-for-bit; the default uses one FMA per term (same k-ascending order)."""
+    multiply/add bit-for-bit; the default uses one FMA per term (same k-ascending order; results of at most 4 columns
+    are summed in a per-row tree order by the row-vector kernel unless `keep_order`)."""
     M, N = int(out_shape[0]), int(out_shape[1])
     dev = require_hip(a_data, a_indices, a_indptr, b)
     dtr = torch_dtype(dot_dtype(a_data.dtype, b.dtype))
@@ -51,7 +52,7 @@ def dot_csr_ndarray(out_shape, a_data, a_indices, a_indptr, b, *, exact=False, o
         raise ValueError("out buffer has wrong shape/dtype/layout")
     _ffi.call("spamd_spmm_csr", vcode, code_of(it), M, K, N, ptr(a_data), ptr(a_indices),
               ptr(a_indptr), ptr(b), max(N, 1), ptr(out), max(N, 1),
-              _ffi.EXACT_MULADD if exact else 0, stream_ptr(dev))
+              (_ffi.EXACT_MULADD if exact else 0) | (_ffi.SPMM_ROWGROUP if keep_order else 0), stream_ptr(dev))
     return out
 
 

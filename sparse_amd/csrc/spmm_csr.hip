@@ -147,6 +147,218 @@ spmm_csr_rowgroup_kernel(int64_t M, int64_t N, const T* __restrict__ a_data,
   }
 }
 
+// ---- "row-vector" kernel: results at most 4 columns wide (N = 1 is the matrix-vector product) ----------------------
+// With so few columns the row-group mapping above leaves 15 of 16 lanes idle.  Here the lanes run ALONG a row instead:
+// L lanes (a power of two chosen per matrix, inside the kernel, from nnz / M = indptr[M] / M) share one compressed row;
+// each lane takes the stored elements p, p + L, p + 2L, ... of it with coalesced loads of (index, value), gathers the NV
+// entries of B's row and accumulates privately; a butterfly over the L lanes then forms the row's sums.  The products
+// of one row are therefore added in a fixed TREE order, not k-ascending: results are deterministic and - for floating
+// point - within rounding of the reference's (integers wrap identically), which is why the exact mode keeps the
+// row-group kernel.  The pass is the CSR triplet's stream (12 or 8 B per stored element), once.
+template <typename T, int NV>
+__device__ __forceinline__ void rv_load(const T* p, bool aligned, T (&o)[NV]) {
+  constexpr int BYTES = (int)sizeof(T) * NV;
+  if constexpr (NV == 1) {
+    o[0] = p[0];
+  } else if constexpr (BYTES == 8 || BYTES == 16) {
+    if (aligned) {
+      const Vec<T, NV> v = *reinterpret_cast<const Vec<T, NV>*>(p);
+#pragma unroll
+      for (int e = 0; e < NV; ++e) o[e] = v.v[e];
+      return;
+    }
+#pragma unroll
+    for (int e = 0; e < NV; ++e) o[e] = p[e];
+  } else if constexpr (BYTES == 32) {
+    if (aligned) {
+      const Vec<T, 2> v0 = *reinterpret_cast<const Vec<T, 2>*>(p);
+      const Vec<T, 2> v1 = *reinterpret_cast<const Vec<T, 2>*>(p + 2);
+      o[0] = v0.v[0]; o[1] = v0.v[1]; o[2] = v1.v[0]; o[3] = v1.v[1];
+      return;
+    }
+#pragma unroll
+    for (int e = 0; e < NV; ++e) o[e] = p[e];
+  } else {
+#pragma unroll
+    for (int e = 0; e < NV; ++e) o[e] = p[e];
+  }
+}
+
+template <typename T, typename I, int NV, int L>
+__device__ __forceinline__ void rowvec_body(int64_t M, const T* __restrict__ a_data, const I* __restrict__ a_idx,
+                                            const I* __restrict__ a_ptr, const T* __restrict__ b, int64_t ldb,
+                                            T* __restrict__ out, int64_t ldo, bool aligned) {
+  constexpr int RPW = SPAMD_WAVE / L;
+  const int lane = threadIdx.x & (SPAMD_WAVE - 1);
+  const int gl = lane & (L - 1);
+  const int sub = lane / L;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / SPAMD_WAVE) + (threadIdx.x / SPAMD_WAVE);
+  const int64_t stride = (int64_t)gridDim.x * (blockDim.x / SPAMD_WAVE) * RPW;
+  // A wave's chain  row pointers -> (index, value) -> gather -> butterfly  is three memory latencies long whatever the
+  // row holds, and the CU's vector-memory queue is in order, so the chain is software-pipelined over the wave's row
+  // slots: while slot t is being summed, the elements of slot t + 1 and the pointers of slot t + 2 are in flight.
+  struct Elems {
+    I i0, i1;
+    T v0, v1;
+  };
+  auto ptrs = [&](int64_t rbase, int64_t& s, int64_t& e) {
+    const int64_t r = rbase + sub;
+    s = 0;
+    e = 0;
+    if (r < M) {
+      s = (int64_t)a_ptr[r];
+      e = (int64_t)a_ptr[r + 1];
+    }
+  };
+  auto elems = [&](int64_t s, int64_t e, Elems& x) {
+    const int64_t p = s + gl;
+    x.i0 = 0; x.i1 = 0; x.v0 = T(0); x.v1 = T(0);
+    if (p < e) {
+      x.i0 = a_idx[p];
+      x.v0 = a_data[p];
+    }
+    if (p + L < e) {
+      x.i1 = a_idx[p + L];
+      x.v1 = a_data[p + L];
+    }
+  };
+  int64_t base = wave * RPW;
+  int64_t s0, e0, s1, e1, s2, e2;
+  Elems c, n;
+  ptrs(base, s0, e0);
+  ptrs(base + stride, s1, e1);
+  elems(s0, e0, c);
+  for (; base < M; base += stride) {
+    ptrs(base + 2 * stride, s2, e2);
+    elems(s1, e1, n);
+    T acc[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) acc[e] = T(0);
+    {
+      const int64_t p = s0 + gl;
+      T g0[NV], g1[NV];
+      if (p < e0) rv_load<T, NV>(b + (int64_t)c.i0 * ldb, aligned, g0);
+      if (p + L < e0) rv_load<T, NV>(b + (int64_t)c.i1 * ldb, aligned, g1);
+      if (p < e0) {
+#pragma unroll
+        for (int e = 0; e < NV; ++e) acc[e] = mul_add<false>(c.v0, g0[e], acc[e]);
+      }
+      if (p + L < e0) {
+#pragma unroll
+        for (int e = 0; e < NV; ++e) acc[e] = mul_add<false>(c.v1, g1[e], acc[e]);
+      }
+    }
+    // rows longer than 2 L (L is sized so that an average row is not)
+    for (int64_t p = s0 + gl + 2 * L; p < e0; p += 2 * L) {
+      const bool two = p + L < e0;
+      const I j0 = a_idx[p];
+      const T w0 = a_data[p];
+      I j1 = 0;
+      T w1 = T(0);
+      if (two) {
+        j1 = a_idx[p + L];
+        w1 = a_data[p + L];
+      }
+      T r0[NV], r1[NV];
+      rv_load<T, NV>(b + (int64_t)j0 * ldb, aligned, r0);
+      if (two) rv_load<T, NV>(b + (int64_t)j1 * ldb, aligned, r1);
+#pragma unroll
+      for (int e = 0; e < NV; ++e) acc[e] = mul_add<false>(w0, r0[e], acc[e]);
+      if (two) {
+#pragma unroll
+        for (int e = 0; e < NV; ++e) acc[e] = mul_add<false>(w1, r1[e], acc[e]);
+      }
+    }
+    // every lane of the wave is back here: butterfly over the row's L lanes
+#pragma unroll
+    for (int off = L / 2; off >= 1; off >>= 1) {
+#pragma unroll
+      for (int e = 0; e < NV; ++e) acc[e] = (T)(acc[e] + lane_shfl(acc[e], lane ^ off));
+    }
+    if (base + sub < M && gl == 0) {
+#pragma unroll
+      for (int e = 0; e < NV; ++e) out[(base + sub) * ldo + e] = acc[e];
+    }
+    s0 = s1; e0 = e1; s1 = s2; e1 = e2;
+    c = n;
+  }
+}
+
+// lanes per row: the power of two with 2 L >= nnz / M (one trip covers an average row), 4..64
+#define SPAMD_ROWVEC_PICK(B, LDB, AL)                                                                      \
+  const int64_t avg = uniform((int64_t)a_ptr[M]) / M;                                                      \
+  if (avg > 64) rowvec_body<T, I, NV, 64>(M, a_data, a_idx, a_ptr, B, LDB, out, ldo, AL);                  \
+  else if (avg > 32) rowvec_body<T, I, NV, 32>(M, a_data, a_idx, a_ptr, B, LDB, out, ldo, AL);             \
+  else if (avg > 16) rowvec_body<T, I, NV, 16>(M, a_data, a_idx, a_ptr, B, LDB, out, ldo, AL);             \
+  else if (avg > 8) rowvec_body<T, I, NV, 8>(M, a_data, a_idx, a_ptr, B, LDB, out, ldo, AL);               \
+  else rowvec_body<T, I, NV, 4>(M, a_data, a_idx, a_ptr, B, LDB, out, ldo, AL);
+
+template <typename T, typename I, int NV>
+__global__ void __launch_bounds__(256)
+spmm_csr_rowvec_kernel(int64_t M, const T* __restrict__ a_data, const I* __restrict__ a_idx,
+                       const I* __restrict__ a_ptr, const T* __restrict__ b, int64_t ldb, T* __restrict__ out,
+                       int64_t ldo, int aligned) {
+  SPAMD_ROWVEC_PICK(b, ldb, aligned != 0)
+}
+
+// The same with B resident in LDS (K * NV values, at most ROWVEC_LDS_BYTES): gathers of 4..32 bytes at random rows cost the
+// CU's vector-memory pipe one cache line per lane (measured: 0.50 ms with them, 0.30 ms with coalesced stand-ins, config 2's
+// matrix times a vector), the LDS serves them at bank rate.  Persistent blocks, as many per CU as the size of B allows
+// (512 threads, up to four; one of 1024 threads above 80 KB); each copies B once.
+constexpr int ROWVEC_LDS_BYTES = 144 * 1024;   // of the CU's 160 KB
+
+template <typename T, typename I, int NV>
+__global__ void __launch_bounds__(1024)
+spmm_csr_rowvec_lds_kernel(int64_t M, int64_t K, const T* __restrict__ a_data, const I* __restrict__ a_idx,
+                           const I* __restrict__ a_ptr, const T* __restrict__ b, int64_t ldb, T* __restrict__ out,
+                           int64_t ldo) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rv_smem[];
+  T* bl = reinterpret_cast<T*>(rv_smem);
+  for (int64_t i = threadIdx.x; i < K * NV; i += blockDim.x) bl[i] = b[(i / NV) * ldb + (i % NV)];
+  __syncthreads();
+  SPAMD_ROWVEC_PICK(bl, (int64_t)NV, true)
+}
+#undef SPAMD_ROWVEC_PICK
+
+constexpr int ROWVEC_MAX_N = 4;
+
+template <typename T, typename I>
+static int launch_rowvec(int64_t M, int64_t K, int64_t N, const T* a_data, const I* a_idx, const I* a_ptr, const T* b,
+                         int64_t ldb, T* out, int64_t ldo, hipStream_t s) {
+  // (the lanes-per-row choice is the kernel's, so the grid is sized for the widest one - one row per wave - and
+  // strides over the rows)
+  const size_t rowbytes = sizeof(T) * (size_t)N;
+  const size_t ldsbytes = rowbytes * (size_t)K;
+  const bool lds = ldsbytes <= (size_t)ROWVEC_LDS_BYTES && M >= 32768;
+  const bool big = ldsbytes > 80 * 1024;
+  int64_t blocks = ceil_div(M, 4);
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  const size_t al = rowbytes > 16 ? 16 : rowbytes;
+  const int aligned = (rowbytes == 8 || rowbytes == 16 || rowbytes == 32) && (uintptr_t)b % al == 0 && (ldb * sizeof(T)) % al == 0;
+#define SPAMD_RV(NV)                                                                                              \
+  case NV:                                                                                                        \
+    if (lds) {                                                                                                    \
+      auto kern = spmm_csr_rowvec_lds_kernel<T, I, NV>;                                                           \
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ROWVEC_LDS_BYTES) != \
+          hipSuccess)                                                                                             \
+        return SPAMD_EINVAL;                                                                                      \
+      hipLaunchKernelGGL(kern, dim3(big ? 256 : 1024), dim3(big ? 1024 : 512), ldsbytes, s, M, K, a_data, a_idx, a_ptr, b, ldb, out, ldo); \
+    } else {                                                                                                      \
+      hipLaunchKernelGGL((spmm_csr_rowvec_kernel<T, I, NV>), dim3((unsigned)blocks), dim3(256), 0, s, M, a_data,  \
+                         a_idx, a_ptr, b, ldb, out, ldo, aligned);                                                \
+    }                                                                                                             \
+    break;
+  switch (N) {
+    SPAMD_RV(1)
+    SPAMD_RV(2)
+    SPAMD_RV(3)
+    SPAMD_RV(4)
+    default: return SPAMD_EINVAL;
+  }
+#undef SPAMD_RV
+  return launch_status();
+}
+
 struct SpmmVariant {
   int g = 0, vec = 0, unroll = 0;
   int64_t panel = 0;  // 0 = whole N in one pass
@@ -283,6 +495,7 @@ extern "C" int spamd_spmm_csr(int val_dtype, int idx_dtype, int64_t M, int64_t K
       if constexpr (std::is_floating_point<T>::value) {
         if (exact) return dispatch_shape<T, I, true>(M, K, N, ad, ai, ap, bb, ldb, oo, ldo, s);
       }
+      if (N <= ROWVEC_MAX_N && !(flags & SPAMD_SPMM_ROWGROUP)) return launch_rowvec<T, I>(M, K, N, ad, ai, ap, bb, ldb, oo, ldo, s);
       return dispatch_shape<T, I, false>(M, K, N, ad, ai, ap, bb, ldb, oo, ldo, s);
     })
   })

@@ -146,3 +146,120 @@ def test_kernel_variants_all_rows_empty(monkeypatch, variant):
     monkeypatch.setenv("SPAMD_SPMM_VARIANT", variant)
     (_, _, _, _), got = _run(300, 50, 128, 0.0, np.float32, np.int32, exact=False)
     assert got.shape == (300, 128) and not got.any()
+
+
+# ---- results of 1..4 columns: the row-vector kernel (lanes along the row, tree order per row) ------------------------
+
+def _fast_csr(M, K, nnz, seed, dtype, idt, empty_rows=(), long_row=None):
+    """CSR with ~nnz stored elements (duplicates of the random draw dropped): sizes `util.random_csr`'s
+    choice-without-replacement cannot reach."""
+    rng = np.random.default_rng(seed)
+    lin = np.unique(rng.integers(0, M * K, size=nnz))
+    rows, cols = lin // K, lin % K
+    if len(empty_rows):
+        keep = ~np.isin(rows, np.asarray(empty_rows))
+        rows, cols = rows[keep], cols[keep]
+    if long_row is not None:
+        keep = rows != long_row
+        rows = np.concatenate([rows[keep], np.full(K, long_row)])
+        cols = np.concatenate([cols[keep], np.arange(K)])
+        o = np.lexsort((cols, rows))
+        rows, cols = rows[o], cols[o]
+    data = (rng.random(len(rows)) - 0.3).astype(dtype) if np.dtype(dtype).kind == "f" else \
+        rng.integers(-50, 50, size=len(rows)).astype(dtype)
+    ptr = np.zeros(M + 1, dtype=idt)
+    np.cumsum(np.bincount(rows, minlength=M), out=ptr[1:])
+    return data, cols.astype(idt), ptr
+
+
+def _rowvec_check(orc, M, K, N, nnz, dtype, idt, seed=0, **kw):
+    from sparse_amd import _kernels as Kn
+    from util import assert_within_fma_bound
+
+    data, idx, ptr = _fast_csr(M, K, nnz, seed, dtype, idt, **kw)
+    b = random_dense(K, N, seed + 1, dtype)
+    d = torch.device("cuda")
+    args = [torch.from_numpy(x).to(d) for x in (data, idx, ptr, b)]
+    got = Kn.dot_csr_ndarray((M, N), *args).cpu().numpy()
+    kept = Kn.dot_csr_ndarray((M, N), *args, keep_order=True).cpu().numpy()
+    want = orc.dot_csr_ndarray((M, N), data, idx, ptr, b)
+    if np.dtype(dtype).kind == "f":
+        assert_within_fma_bound(got, want, data, idx, ptr, b)
+        assert_within_fma_bound(kept, want, data, idx, ptr, b)
+    else:
+        assert np.array_equal(got, want) and np.array_equal(kept, want)
+    return got
+
+
+@pytest.mark.parametrize("dtype,idt", [(np.float32, np.int32), (np.float64, np.int64), (np.int64, np.int32)])
+@pytest.mark.parametrize("N", [1, 2, 3, 4])
+@pytest.mark.parametrize("avg", [3, 12, 24, 48, 120])       # one per lanes-per-row choice (4, 8, 16, 32, 64)
+def test_rowvec_dense_operand_in_lds(orc, dtype, idt, N, avg):
+    """M >= 32768 and K * N values within the LDS budget: B is staged per block."""
+    M, K = 33000, 600
+    _rowvec_check(orc, M, K, N, M * avg, dtype, idt, seed=avg + N, empty_rows=(0, 5, 6, M - 1), long_row=777)
+
+
+@pytest.mark.parametrize("dtype,idt", [(np.float32, np.int64), (np.float64, np.int32), (np.int32, np.int32)])
+@pytest.mark.parametrize("N", [1, 2, 3, 4])
+@pytest.mark.parametrize("M,K,avg", [(3000, 5000, 5), (3000, 5000, 20), (2500, 5000, 100), (33000, 40000, 30)])
+def test_rowvec_dense_operand_gathered(orc, dtype, idt, N, M, K, avg):
+    """Few rows, or a B beyond the LDS budget (40000 x N): gathers from global memory."""
+    _rowvec_check(orc, M, K, N, M * avg, dtype, idt, seed=avg + N, empty_rows=(1, M - 1), long_row=M // 2)
+
+
+@pytest.mark.parametrize("N", [1, 2, 4])
+@pytest.mark.parametrize("M", [1000, 40000])
+def test_rowvec_leading_dimensions_and_misaligned_operand(orc, N, M):
+    """Through the C ABI with ldb > N, ldo > N and a dense operand that starts 4 bytes off a 16-byte boundary."""
+    from sparse_amd import _ffi
+    from sparse_amd._device import ptr as p_, stream_ptr
+
+    K, ldb, ldo = 700, 7, 6
+    data, idx, ptr = _fast_csr(M, K, M * 40, 11, np.float32, np.int32)
+    rng = np.random.default_rng(12)
+    bbuf = rng.random(K * ldb + 1).astype(np.float32)
+    d = torch.device("cuda")
+    tb = torch.from_numpy(bbuf).to(d)
+    b_view = tb[1:]
+    out = torch.full((M, ldo), 7.0, dtype=torch.float32, device=d)
+    td, ti, tp = (torch.from_numpy(x).to(d) for x in (data, idx, ptr))
+    _ffi.call("spamd_spmm_csr", _ffi.F32, _ffi.I32, M, K, N, p_(td), p_(ti), p_(tp), p_(b_view), ldb, p_(out), ldo, 0,
+              stream_ptr(d))
+    torch.cuda.synchronize()
+    b = bbuf[1:].reshape(K, ldb)[:, :N].copy()
+    want = orc.dot_csr_ndarray((M, N), data, idx, ptr, b)
+    got = out.cpu().numpy()
+    from util import assert_within_fma_bound
+
+    assert_within_fma_bound(got[:, :N].copy(), want, data, idx, ptr, b)
+    assert np.all(got[:, N:] == 7.0)          # nothing beyond the result's columns is written
+
+
+def test_rowvec_nan_inf_only_touch_referenced_rows(orc):
+    data, idx, ptr = _fast_csr(40000, 300, 40000 * 3, 3, np.float32, np.int32)
+    b = random_dense(300, 1, 4, np.float32)
+    b[5, 0] = np.inf
+    b[0, 0] = np.nan        # B's row 0 is what a masked-off lane would gather if it were not masked
+    data[idx == 0] = 0.0    # ... and where row 0 IS referenced the stored value is a zero: 0 * nan must appear
+    d = torch.device("cuda")
+    from sparse_amd import _kernels as Kn
+
+    got = Kn.dot_csr_ndarray((40000, 1), *(torch.from_numpy(x).to(d) for x in (data, idx, ptr, b))).cpu().numpy()
+    want = orc.dot_csr_ndarray((40000, 1), data, idx, ptr, b)
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.isinf(got), np.isinf(want))
+    ok = np.isfinite(want)
+    assert np.allclose(got[ok], want[ok], rtol=1e-5, atol=1e-6)
+
+
+def test_container_matrix_vector_product(orc):
+    """`GCXS @ 1-D ndarray` and `COO @ 1-D ndarray` (numpy.dot's contraction over the last axis)."""
+    import sparse_amd
+
+    data, idx, ptr = _fast_csr(35000, 500, 35000 * 20, 21, np.float64, np.int64)
+    v = random_dense(500, 1, 22, np.float64)[:, 0].copy()
+    a = sparse_amd.GCXS((data, idx, ptr), shape=(35000, 500), compressed_axes=(0,))
+    want = orc.dot_csr_ndarray((35000, 1), data, idx, ptr, v[:, None])[:, 0]
+    for got in (a @ v, sparse_amd.dot(a, v), a.tocoo() @ v):
+        assert isinstance(got, np.ndarray) and got.shape == (35000,) and got.dtype == np.float64
+        assert np.allclose(got, want, rtol=1e-12, atol=1e-13)
