@@ -2,6 +2,7 @@
 imported in place from /root/reference under the no-op numba stub, see ref_loader.py).
 
     python oracle/gen_golden.py            # rewrites every fixture (deterministic seeds)
+    python oracle/gen_golden.py array_api  # only tests/golden/array_api.npz
 
 TEST INFRASTRUCTURE.  Runs only in the build container (the GPU box has no /root/reference);
 the fixtures it writes are committed, travel to the GPU box, and pin both the CPU oracle
@@ -483,12 +484,15 @@ def gen_einsum(sp):
     _save("einsum", **cases)
 
 
-def gen_general(sp):
+def gen_general(sp, module="general_cases", out_name="general"):
     """N2/N3: arbitrary callables, N operands, keywords, dense operands, non-zero-fill var/std, broadcast N-D matmul -
     the cases of tests/general_cases.py evaluated by the reference (`_Elemwise`, _umath.py:392-751; `_matmul_recurser`,
-    _common.py:278-293; `var/std`, _sparse_array.py:704-876)."""
+    _common.py:278-293; `var/std`, _sparse_array.py:704-876).  With `module="array_api_cases"`: the array-namespace
+    functions of `_coo/common.py` / `_common.py` (tests/array_api_cases.py -> array_api.npz)."""
+    import importlib
+
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import general_cases as gc
+    gc = importlib.import_module(module)
 
     inp = gc.inputs()
     out = {f"in_{k}": v for k, v in inp.items()}
@@ -504,12 +508,19 @@ def gen_general(sp):
         if r["kind"] == "sparse":
             out[f"c{k}_nnz"], out[f"c{k}_fill"], out[f"c{k}_cls"] = np.array(r["nnz"]), r["fill"], np.array(r["cls"])
     out["n_cases"] = np.array(len(gc.CASES))
-    _save("general", **out)
+    if out_name == "array_api":   # the public names of the backend (`__all__`, numba_backend/__init__.py:179-350)
+        import sparse.numba_backend as nb
+
+        out["reference_all"] = np.array(sorted(nb.__all__))
+    _save(out_name, **out)
 
 
 def main():
     sp = ref_loader.load()
     print("reference:", sp.__file__)
+    if sys.argv[1:] == ["array_api"]:      # only the array-namespace cases
+        gen_general(sp, "array_api_cases", "array_api")
+        return
     gen_dot(sp)
     gen_convert(sp)
     gen_elemwise(sp)
@@ -519,6 +530,7 @@ def main():
     gen_select(sp)
     gen_einsum(sp)
     gen_general(sp)
+    gen_general(sp, "array_api_cases", "array_api")
 
 
 if __name__ == "__main__":

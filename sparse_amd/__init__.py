@@ -5,12 +5,26 @@ Drop-in for the `sparse.numba_backend` names on that path: `COO`, `GCXS`, `tenso
 PyTorch-ROCm tensors; all arithmetic is done by hand-written HIP kernels behind the C ABI of
 `libsparse_amd.so` (include/sparse_amd.h).  There is no CPU fallback.
 """
-from numpy import (  # noqa: F401  (the reference re-exports NumPy's ufuncs, __init__.py:1-83)
-    abs, add, bitwise_and, bitwise_or, bitwise_xor, ceil, cos, cosh, divide, equal, exp, expm1, floor, greater,
-    greater_equal, isfinite, isinf, isnan, less, less_equal, log, log1p, log2, log10, logical_and, logical_not,
-    logical_or, logical_xor, maximum, minimum, multiply, negative, not_equal, positive, sign, sin, sinh, sqrt, square,
-    subtract, tan, tanh, trunc,
+from numpy import (  # noqa: F401  (the reference re-exports NumPy's ufuncs, dtypes and constants, __init__.py:1-83)
+    add, bitwise_and, bitwise_not, bitwise_or, bitwise_xor, ceil, complex64, complex128, conj, copysign, cos, cosh, divide, e,
+    exp, expm1, finfo, float16, float32, float64, floor, floor_divide, greater, greater_equal, hypot, iinfo, inf, int8, int16,
+    int32, int64, isfinite, less, less_equal, log, log1p, log2, log10, logaddexp, logical_and, logical_not, logical_or,
+    logical_xor, maximum, minimum, multiply, nan, negative, newaxis, nextafter, not_equal, pi, positive, reciprocal, remainder,
+    sign, signbit, sin, sinh, sqrt, square, subtract, tan, tanh, trunc, uint8, uint16, uint32, uint64,
 )
+from numpy import arccos as acos  # noqa: F401  (array-API spellings, __init__.py:71-83)
+from numpy import arccosh as acosh  # noqa: F401
+from numpy import arcsin as asin  # noqa: F401
+from numpy import arcsinh as asinh  # noqa: F401
+from numpy import arctan as atan  # noqa: F401
+from numpy import arctan2 as atan2  # noqa: F401
+from numpy import arctanh as atanh  # noqa: F401
+from numpy import bool_ as bool  # noqa: F401, A004
+from numpy import invert as bitwise_invert  # noqa: F401
+from numpy import isdtype  # noqa: F401
+from numpy import left_shift as bitwise_left_shift  # noqa: F401
+from numpy import power as pow  # noqa: F401, A004
+from numpy import right_shift as bitwise_right_shift  # noqa: F401
 
 from ._sparse_array import SparseArray
 from ._coo import COO, as_coo
@@ -25,9 +39,22 @@ from ._api import (all, any, argwhere, asarray, astype, empty, empty_like, expan
                    matrix_transpose, max, mean, min, moveaxis, nanmax, nanmean, nanmin, nanprod, nanreduce, nansum, nonzero,
                    ones, ones_like, permute_dims, prod, random, reshape, sddmm, squeeze, std, sum, var, vecdot, where, zeros,
                    zeros_like)
+from ._array_api import (abs, argmax, argmin, asCOO, asnumpy, broadcast_arrays, broadcast_shapes, can_cast, clip, concat, diagonal, diagonalize,
+                         diff, equal, flip, imag, interp, isinf, isnan, isneginf, isposinf, kron, outer, pad, real, repeat,
+                         result_type, roll, round, sort, take, tile, tril, triu, unique_counts, unique_values, unstack)
 from ._ffi import HipBackendError
 
-__all__ = ["COO", "GCXS", "SparseArray", "HipBackendError", "all", "any", "argwhere", "as_coo", "asarray", "astype", "broadcast_to",
+__all__ = ["COO", "GCXS", "SparseArray", "HipBackendError", "abs", "acos", "acosh", "add", "all", "any", "argmax", "argmin", "argwhere", "asCOO", "as_coo",
+           "asarray", "asin", "asinh", "asnumpy", "astype", "atan", "atan2", "atanh", "bitwise_and", "bitwise_invert",
+           "bitwise_left_shift", "bitwise_not", "bitwise_or", "bitwise_right_shift", "bitwise_xor", "bool", "broadcast_arrays",
+           "broadcast_shapes", "broadcast_to", "can_cast", "ceil", "clip", "complex128", "complex64", "concat", "conj", "copysign",
+           "cos", "cosh", "diagonal", "diagonalize", "diff", "divide", "e", "equal", "exp", "expm1", "finfo", "flip", "float16",
+           "float32", "float64", "floor", "floor_divide", "greater", "greater_equal", "hypot", "iinfo", "imag", "inf", "int16",
+           "int32", "int64", "int8", "interp", "isdtype", "isfinite", "isinf", "isnan", "isneginf", "isposinf", "kron", "less", "less_equal",
+           "log", "log10", "log1p", "log2", "logaddexp", "logical_and", "logical_not", "logical_or", "logical_xor", "maximum",
+           "minimum", "multiply", "nan", "negative", "newaxis", "nextafter", "not_equal", "outer", "pad", "pi", "positive", "pow",
+           "real", "reciprocal", "remainder", "repeat", "result_type", "roll", "round", "sign", "signbit", "sin", "sinh", "sqrt",
+           "square", "subtract", "tan", "tanh", "sort", "take", "tile", "tril", "triu", "trunc", "unique_counts", "unique_values", "uint16", "uint32", "uint64", "uint8", "unstack",
            "concatenate", "dot", "einsum", "elemwise", "empty", "empty_like", "expand_dims", "eye", "full", "full_like", "load_npz", "matmul",
            "matrix_transpose", "max", "mean", "min", "moveaxis", "nanmax", "nanmean", "nanmin", "nanprod", "nanreduce", "nansum",
            "nonzero", "ones", "ones_like", "permute_dims", "prod", "random", "reshape", "save_npz", "sddmm", "squeeze", "stack", "std",

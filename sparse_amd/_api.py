@@ -386,6 +386,10 @@ def moveaxis(a, source, destination):
 
 
 def expand_dims(x, /, *, axis=0):
+    """`_coo/common.py:1362-1400`: always a COO (the reference converts its input first)."""
+    from ._array_api import _validate_coo_input
+
+    x = _validate_coo_input(x)
     axes = (axis,) if isinstance(axis, int) else tuple(axis)
     nd = x.ndim + len(axes)
     axes = sorted(a % nd for a in axes)

@@ -54,8 +54,16 @@ def take_leading(x, i):
     return out.asformat("gcxs") if is_gcxs and out.ndim >= 1 else out
 
 
-def concatenate(arrays, axis=0):
-    """Join sparse arrays along an existing axis (reference _coo/common.py:132-192)."""
+def _gcxs_result(out, nd_in, axis, compressed_axes):
+    """What the reference's all-GCXS branch returns (`_compressed/common.py:6-96`): 1-D inputs give a COO, otherwise a
+    GCXS compressed along `compressed_axes` (default: the joined axis)."""
+    if nd_in == 1:
+        return out
+    return out.asformat("gcxs", compressed_axes=(axis,) if compressed_axes is None else compressed_axes)
+
+
+def concatenate(arrays, axis=0, compressed_axes=None):
+    """Join sparse arrays along an existing axis (reference _common.py:1518-1558, _coo/common.py:132-192)."""
     from ._coo import COO, as_coo
     from ._gcxs import GCXS
     from ._umath import binary_arrays
@@ -92,11 +100,11 @@ def concatenate(arrays, axis=0):
         off += c.shape[axis]
     out = COO(torch.cat(parts_c, dim=1), torch.cat(parts_d), shape=shape, has_duplicates=False, sorted=(axis == 0),
               fill_value=fv)
-    return out.asformat("gcxs") if all_gcxs else out
+    return _gcxs_result(out, len(ref_shape), axis, compressed_axes) if all_gcxs else out
 
 
-def stack(arrays, axis=0):
-    """Join sparse arrays along a NEW axis (reference _coo/common.py:195-249)."""
+def stack(arrays, axis=0, compressed_axes=None):
+    """Join sparse arrays along a NEW axis (reference _common.py:1479-1515, _coo/common.py:195-249)."""
     from ._coo import COO, as_coo
     from ._gcxs import GCXS
 
@@ -116,7 +124,7 @@ def stack(arrays, axis=0):
         perm = list(range(1, nd + 1))
         perm.insert(axis, 0)
         out = out.transpose(perm)
-    return out.asformat("gcxs") if all_gcxs else out
+    return _gcxs_result(out, nd, axis, compressed_axes) if all_gcxs else out
 
 
 def block_diagonal_csr(a):

@@ -217,9 +217,15 @@ def test_basic_index_normalisation():
     for bad in ((0, 0, 0), (Ellipsis, Ellipsis), ("a",), (1.5,)):
         with pytest.raises(IndexError):
             _normalise(bad, 2)
-    for fancy in ([0, 1], np.array([0, 1])):
+    # one 1-D integer (or boolean) array index is on the path; several of them, or N-D ones, are not
+    got = _normalise(([0, 1], Ellipsis), 2)
+    assert isinstance(got[0], np.ndarray) and got[0].dtype == np.int64 and got[1] == full
+    assert _normalise((np.array([True, False]),), 1)[0].dtype == bool
+    for fancy in (([0, 1], [1, 0]), (np.zeros((2, 2), dtype=np.int64),)):
         with pytest.raises(NotImplementedError):
-            _normalise((fancy,), 2)
+            _normalise(fancy, 2)
+    with pytest.raises(IndexError):
+        _normalise((np.array([0.5, 1.0]),), 2)
 
 
 def test_sddmm_dispatch_models(hiplib):

@@ -280,8 +280,9 @@ def test_basic_indexing_matches_numpy():
     for bad in (s_[6], s_[0, 0, 0, 0], s_[..., ...]):
         with pytest.raises(IndexError):
             x[bad]
+    assert np.array_equal(x[[0, 1]].todense(), d[[0, 1]])          # one integer array: the join of tests/array_api_cases.py
     with pytest.raises(NotImplementedError):
-        x[[0, 1]]
+        x[[0, 1], [1, 0]]
 
 
 @pytest.mark.gpu
