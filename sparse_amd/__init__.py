@@ -29,6 +29,7 @@ from numpy import right_shift as bitwise_right_shift  # noqa: F401
 from ._sparse_array import SparseArray
 from ._coo import COO, as_coo
 from ._gcxs import GCXS
+from ._dok import DOK
 from ._dot import dot, flush_warnings, matmul, tensordot
 from ._umath import elemwise
 from ._einsum import einsum
@@ -44,7 +45,7 @@ from ._array_api import (abs, argmax, argmin, asCOO, asnumpy, broadcast_arrays, 
                          result_type, roll, round, sort, take, tile, tril, triu, unique_counts, unique_values, unstack)
 from ._ffi import HipBackendError
 
-__all__ = ["COO", "GCXS", "SparseArray", "HipBackendError", "abs", "acos", "acosh", "add", "all", "any", "argmax", "argmin", "argwhere", "asCOO", "as_coo",
+__all__ = ["COO", "DOK", "GCXS", "SparseArray", "HipBackendError", "abs", "acos", "acosh", "add", "all", "any", "argmax", "argmin", "argwhere", "asCOO", "as_coo",
            "asarray", "asin", "asinh", "asnumpy", "astype", "atan", "atan2", "atanh", "bitwise_and", "bitwise_invert",
            "bitwise_left_shift", "bitwise_not", "bitwise_or", "bitwise_right_shift", "bitwise_xor", "bool", "broadcast_arrays",
            "broadcast_shapes", "broadcast_to", "can_cast", "ceil", "clip", "complex128", "complex64", "concat", "conj", "copysign",

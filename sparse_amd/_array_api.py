@@ -497,7 +497,9 @@ def interp(x, xp, fp, left=None, right=None, period=None):
               prune=True, has_duplicates=False, sorted=True)
     if isinstance(x, GCXS):
         return out.asformat("gcxs", compressed_axes=x.compressed_axes)
-    return out
+    from ._dok import DOK
+
+    return out.asformat("dok") if isinstance(x, DOK) else out
 
 
 UniqueCountsResult = namedtuple("UniqueCountsResult", ["values", "counts"])
