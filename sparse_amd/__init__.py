@@ -44,6 +44,9 @@ from ._array_api import (abs, argmax, argmin, asCOO, asnumpy, broadcast_arrays, 
                          diff, equal, flip, imag, interp, isinf, isnan, isneginf, isposinf, kron, outer, pad, real, repeat,
                          result_type, roll, round, sort, take, tile, tril, triu, unique_counts, unique_values, unstack)
 from ._ffi import HipBackendError
+from ._settings import __array_namespace_info__  # noqa: F401
+
+__array_api_version__ = "2025.12"   # as the reference declares (sparse/__init__.py:7)
 
 __all__ = ["COO", "DOK", "GCXS", "SparseArray", "HipBackendError", "abs", "acos", "acosh", "add", "all", "any", "argmax", "argmin", "argwhere", "asCOO", "as_coo",
            "asarray", "asin", "asinh", "asnumpy", "astype", "atan", "atan2", "atanh", "bitwise_and", "bitwise_invert",

@@ -239,6 +239,12 @@ class GCXS(SparseArray, NDArrayOperatorsMixin):
             return self.tocoo().asformat("dok", **kwargs)
         raise NotImplementedError(f"format {format!r} is not available in the hip backend")
 
+    def todok(self):
+        """`compressed.py:490-493`"""
+        from ._dok import DOK
+
+        return DOK.from_coo(self.tocoo())
+
     def maybe_densify(self, max_size=1000, min_density=0.25):
         if self.size <= max_size or self.density >= min_density:
             return self.todense()

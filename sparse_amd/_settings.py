@@ -16,3 +16,36 @@ EXACT_MULADD = bool(int(os.environ.get("SPARSE_AMD_EXACT", "0")))  # bit-exact m
 # eligible product (fp32, N % 128 == 0, FMA mode, large enough) and caches it on the array; "never" keeps the
 # row-group kernel
 TILED_SPMM = os.environ.get("SPARSE_AMD_TILED_SPMM", "auto")
+
+
+class ArrayNamespaceInfo:
+    """Array-API inspection object (reference `_settings.py:24-46`): NumPy's dtypes; the devices are the HIP devices the
+    arrays live on, not "cpu"."""
+
+    def __init__(self):
+        import numpy as np
+
+        self.np_info = np.__array_namespace_info__()
+
+    def capabilities(self):
+        return {"boolean indexing": False, "data-dependent shapes": True, "max dimensions": 16}      # MAX_NDIM of the C ABI
+
+    def default_device(self):
+        from ._device import default_device
+
+        return default_device()
+
+    def default_dtypes(self, *, device=None):
+        return self.np_info.default_dtypes(device=None)
+
+    def devices(self):
+        import torch
+
+        return tuple(torch.device("cuda", i) for i in range(torch.cuda.device_count()))
+
+    def dtypes(self, *, device=None, kind=None):
+        return self.np_info.dtypes(device=None, kind=kind)
+
+
+def __array_namespace_info__():
+    return ArrayNamespaceInfo()

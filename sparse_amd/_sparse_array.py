@@ -291,6 +291,8 @@ class SparseArray:
             out = (out,)
         return self.__array_ufunc__(np.round, "__call__", self, decimals=decimals, out=out)
 
+    round_ = round
+
     def clip(self, min=None, max=None, out=None):
         if min is None and max is None:
             raise ValueError("One of max or min must be given.")
