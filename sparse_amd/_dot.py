@@ -336,8 +336,9 @@ def _tiled_dtype(data, bt):
 
 def _tiled_eligible(data, bt, out_shape, Kd):
     """The inspector/executor kernel covers float32 and float64 products whose B is (padded to) whole 128- / 64-column
-    panels; from N = 32 (float32) / 16 (float64) on the padded product beats the row-group kernel (round 3, config-2 operand:
-    N = 32 fp32 0.80 vs 1.18 ms, N = 16 fp64 1.03 vs 1.32 ms; tools/rowgroup_shapes.py).  Thresholds
+    panels; from N = 8 (float32) / 5 (float64) on the padded product beats the row-group kernel (round 3, config-2 operand:
+    fp32 N = 8 / 16 / 32: 0.80 vs 1.14 / 1.17 / 1.18 ms, fp64 N = 5 / 8 / 16: 1.02 vs 1.17 / 1.33 / 1.32 ms;
+    `NARROW=1 tools/rowgroup_shapes.py`; results of at most 4 columns have the row-vector kernel).  Thresholds
     measured on MI355X (tools/tiled_crossover.py): it needs >= 117 workgroups of 560 rows to beat the row-group
     kernel, and a density of >= 0.3 % (12 stored elements per 32 x 128 cells: ~16 per (35-row x 160-column) list) — half
     that when B is too large for the row-group kernel's gathers to stay in cache (>= 16 MB).  The inspector costs about one row-group product, so
@@ -346,7 +347,7 @@ def _tiled_eligible(data, bt, out_shape, Kd):
     if _settings.TILED_SPMM == "never" or bt.dim() != 2:
         return False
     dt = _tiled_dtype(data, bt)
-    if dt is None or N < (32 if dt == torch.float32 else 16):   # narrower results: the row-group kernel
+    if dt is None or N < (8 if dt == torch.float32 else 5):   # narrower results: the row-group / row-vector kernels
         return False
     if (Kd + 512) * N * bt.element_size() >= (1 << 32):   # the executor walks B with 32-bit byte offsets (buffer-form tile DMA)
         return False

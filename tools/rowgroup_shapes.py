@@ -14,8 +14,12 @@ def t(f, reps=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 
-for M, Kd, N, dt in ((1_000_000, 10_000, 32, torch.float32), (1_000_000, 10_000, 64, torch.float32), (50_000, 10_000, 128, torch.float32),
-                     (20_000, 10_000, 128, torch.float32), (1_000_000, 10_000, 128, torch.int32), (1_000_000, 10_000, 16, torch.float64)):
+import os
+SHAPES = ((1_000_000, 10_000, 32, torch.float32), (1_000_000, 10_000, 64, torch.float32), (50_000, 10_000, 128, torch.float32),
+          (20_000, 10_000, 128, torch.float32), (1_000_000, 10_000, 128, torch.int32), (1_000_000, 10_000, 16, torch.float64))
+if os.environ.get("NARROW"):     # widths between the row-vector kernel (<= 4) and the round-3 executor policy
+    SHAPES = tuple((1_000_000, 10_000, n, torch.float32) for n in (5, 8, 16, 24)) + tuple((1_000_000, 10_000, n, torch.float64) for n in (5, 8, 12))
+for M, Kd, N, dt in SHAPES:
     data, idx, ptr = make_csr_device(M, Kd, 0.01, seed=7)
     if dt in (torch.int32,):
         data = (data * 100).to(dt)
