@@ -45,7 +45,7 @@ extern "C" {
 #define SPAMD_TILED_GROUP_ENDS 2u /* spamd_spmm_tiled: blk_off has tiles + 1 entries per row group (spamd_spmm_tiled_inspect) */
 #define SPAMD_EXACT_MULADD 1u /* separate IEEE mul + add (bit-exact vs the reference's
                                  non-contracted loop) instead of fused multiply-add */
-#define SPAMD_SPMM_ROWGROUP 4u /* spamd_spmm_csr: keep the k-ascending row-group kernel for results of 1..4 columns too */
+#define SPAMD_SPMM_ROWGROUP 4u /* spamd_spmm_csr: the k-ascending row-group kernel whatever the shape (no row-vector, no LDS-resident-B path) */
 
 /* Library/ABI version: major*10000 + minor*100 + patch. */
 int spamd_version(void);
@@ -74,6 +74,21 @@ int spamd_spmm_csr(int val_dtype, int idx_dtype, int64_t M, int64_t K, int64_t N
                    const void* a_data, const void* a_indices, const void* a_indptr,
                    const void* b, int64_t ldb, void* out, int64_t ldo,
                    unsigned flags, void* stream);
+
+/* The same product with B RESIDENT IN LDS, for a short contracted axis (`_dot_csr_ndarray` / `_dot_coo_ndarray` as
+ * tensordot uses them, `_common.py:720-755, 979-1014`; BASELINE config 3: K = 512): a 256-byte column panel of B —
+ * (K + 1) * 256 bytes <= 144 KB, i.e. K <= 575 — is copied into LDS once per workgroup, 16 lanes own a row of A and read a
+ * row of B per stored element from LDS instead of through the vector-memory path.  Sums run in storage order per output
+ * element (bit-identical to spamd_spmm_csr's row-group kernel in both arithmetic modes; SPAMD_EXACT_MULADD as there).
+ * spamd_spmm_csr itself takes this path when `spamd_spmm_csr_ldsb_fits` says 1, M >= 8192 and N * itemsize >= 128, unless
+ * SPAMD_SPMM_ROWGROUP is set.  `..._fits`: K within the LDS budget, N / ldb / ldo multiples of 16 / itemsize, b and out
+ * 16-byte aligned. */
+int spamd_spmm_csr_ldsb_fits(int val_dtype, int64_t M, int64_t K, int64_t N, const void* b, int64_t ldb,
+                             const void* out, int64_t ldo);
+int spamd_spmm_csr_ldsb(int val_dtype, int idx_dtype, int64_t M, int64_t K, int64_t N,
+                        const void* a_data, const void* a_indices, const void* a_indptr,
+                        const void* b, int64_t ldb, void* out, int64_t ldo,
+                        unsigned flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * A1 (inspector/executor form)   same product as spamd_spmm_csr for F32 (N % 128 == 0) and F64 (N % 64 == 0),

@@ -334,6 +334,9 @@ def _tiled_dtype(data, bt):
     return None
 
 
+LDSB_MAX_K = 575      # (K + 1) rows of 256 bytes within 144 KB of LDS: `spamd_spmm_csr_ldsb_fits`
+
+
 def _tiled_eligible(data, bt, out_shape, Kd):
     """The inspector/executor kernel covers float32 and float64 products whose B is (padded to) whole 128- / 64-column
     panels; from N = 8 (float32) / 5 (float64) on the padded product beats the row-group kernel (round 3, config-2 operand:
@@ -350,6 +353,10 @@ def _tiled_eligible(data, bt, out_shape, Kd):
     if dt is None or N < (8 if dt == torch.float32 else 5):   # narrower results: the row-group / row-vector kernels
         return False
     if (Kd + 512) * N * bt.element_size() >= (1 << 32):   # the executor walks B with 32-bit byte offsets (buffer-form tile DMA)
+        return False
+    if Kd <= LDSB_MAX_K and N * bt.element_size() >= 128:
+        # a short contracted axis: `spamd_spmm_csr` keeps a column panel of B in LDS by itself (spmm_ldsb.hip) - as fast as
+        # the executor on these shapes (config 3: 0.13-0.15 ms against 0.143 ms) without an inspector or a second copy of A
         return False
     per_list = int(data.numel()) * 4096 / max(M * Kd, 1)
     return M >= 65536 and (per_list >= 12 or (per_list >= 6 and Kd * N * bt.element_size() >= (16 << 20)))

@@ -475,6 +475,12 @@ static int dispatch_shape(int64_t M, int64_t K, int64_t N, const T* a_data, cons
 
 }  // namespace spamd
 
+extern "C" int spamd_spmm_csr_ldsb_fits(int val_dtype, int64_t M, int64_t K, int64_t N, const void* b, int64_t ldb,
+                                        const void* out, int64_t ldo);
+extern "C" int spamd_spmm_csr_ldsb(int val_dtype, int idx_dtype, int64_t M, int64_t K, int64_t N, const void* a_data,
+                                   const void* a_indices, const void* a_indptr, const void* b, int64_t ldb, void* out,
+                                   int64_t ldo, unsigned flags, void* stream);
+
 extern "C" int spamd_spmm_csr(int val_dtype, int idx_dtype, int64_t M, int64_t K, int64_t N,
                               const void* a_data, const void* a_indices, const void* a_indptr,
                               const void* b, int64_t ldb, void* out, int64_t ldo, unsigned flags,
@@ -485,6 +491,11 @@ extern "C" int spamd_spmm_csr(int val_dtype, int idx_dtype, int64_t M, int64_t K
   if (!a_indptr || !out || ldo < N || (K > 0 && (!b || ldb < N))) return SPAMD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const bool exact = (flags & SPAMD_EXACT_MULADD) != 0;
+  // a short contracted axis and a result of at least half a 256-byte panel: B resident in LDS (spmm_ldsb.hip; same
+  // k-ascending sums, so both arithmetic modes)
+  if (!(flags & SPAMD_SPMM_ROWGROUP) && M >= 8192 && N * ((val_dtype == SPAMD_F64 || val_dtype == SPAMD_I64) ? 8 : 4) >= 128 &&
+      spamd_spmm_csr_ldsb_fits(val_dtype, M, K, N, b, ldb, out, ldo))
+    return spamd_spmm_csr_ldsb(val_dtype, idx_dtype, M, K, N, a_data, a_indices, a_indptr, b, ldb, out, ldo, flags, stream);
   SPAMD_DISPATCH_VAL(val_dtype, T, {
     SPAMD_DISPATCH_IDX(idx_dtype, I, {
       const T* ad = (const T*)a_data;

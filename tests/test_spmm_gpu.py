@@ -263,3 +263,87 @@ def test_container_matrix_vector_product(orc):
     for got in (a @ v, sparse_amd.dot(a, v), a.tocoo() @ v):
         assert isinstance(got, np.ndarray) and got.shape == (35000,) and got.dtype == np.float64
         assert np.allclose(got, want, rtol=1e-12, atol=1e-13)
+
+
+# ---- short contracted axis: the dense operand resident in LDS (spmm_ldsb.hip) ----------------------------------------
+
+def _ldsb_case(M, K, N, nnz, dtype, idt, seed, exact, **kw):
+    from sparse_amd import _kernels as Kn
+
+    data, idx, ptr = _fast_csr(M, K, nnz, seed, dtype, idt, **kw)
+    b = random_dense(K, N, seed + 1, dtype)
+    d = torch.device("cuda")
+    args = [torch.from_numpy(x).to(d) for x in (data, idx, ptr, b)]
+    got = Kn.dot_csr_ndarray((M, N), *args, exact=exact).cpu().numpy()
+    kept = Kn.dot_csr_ndarray((M, N), *args, exact=exact, keep_order=True).cpu().numpy()      # the row-group kernel
+    return (data, idx, ptr, b), got, kept
+
+
+@pytest.mark.parametrize("dtype,idt", [(np.float32, np.int32), (np.float64, np.int64), (np.float32, np.int64)])
+@pytest.mark.parametrize("K,N", [(512, 512), (575, 68), (64, 32), (300, 130 * 2), (1, 64)])
+@pytest.mark.parametrize("avg", [0.5, 5, 40])
+def test_ldsb_exact_mode_is_bit_identical(orc, dtype, idt, K, N, avg):
+    """M >= 8192, (K + 1) rows of 256 bytes within the LDS budget, N * itemsize >= 128: rows shorter and longer than the
+    16-pair chunk (and than two of them), empty rows, a dense row, partial last panels."""
+    M = 9000
+    if np.dtype(dtype).itemsize * N < 128:
+        pytest.skip("narrower than half a panel: not this kernel's shape")
+    (data, idx, ptr, b), got, kept = _ldsb_case(M, K, N, int(M * min(avg, K * 0.8)), dtype, idt, int(avg * 10) + K + N, True,
+                                                empty_rows=(0, 3, M - 1), long_row=4000)
+    want = orc.dot_csr_ndarray((M, N), data, idx, ptr, b)
+    u = np.uint32 if dtype == np.float32 else np.uint64
+    assert np.array_equal(got.view(u), want.view(u))
+    assert np.array_equal(kept.view(u), want.view(u))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int32, np.int64])
+def test_ldsb_default_mode_equals_the_rowgroup_kernel(orc, dtype):
+    (data, idx, ptr, b), got, kept = _ldsb_case(20000, 200, 96, 20000 * 12, dtype, np.int32, 77, False, empty_rows=(5,), long_row=9)
+    want = orc.dot_csr_ndarray((20000, 96), data, idx, ptr, b)
+    assert np.array_equal(got, kept)                     # same k-ascending FMA chain per output element
+    if np.dtype(dtype).kind == "f":
+        from util import assert_within_fma_bound
+
+        assert_within_fma_bound(got, want, data, idx, ptr, b)
+    else:
+        assert np.array_equal(got, want)
+
+
+def test_ldsb_signed_zeros_nan_and_inf(orc):
+    """The lanes beyond a row's end multiply +0 by the neutral row of -0.0: the sign of every zero result must be the
+    reference's (products of -0.0 included), rows of B that no stored element refers to may hold NaN / inf without
+    leaking, and referenced ones must propagate."""
+    M, K, N = 8200, 40, 64
+    data, idx, ptr = _fast_csr(M, K, M * 3, 9, np.float32, np.int32, empty_rows=(7,))
+    b = random_dense(K, N, 10, np.float32)
+    b[0, :] = np.nan                 # row 0 of B: what a clamped / padded lane must never touch ...
+    data[idx == 0] = 0.0             # ... and where it IS referenced, 0 * NaN = NaN must appear
+    b[1, :8] = np.inf
+    b[2, :] = 0.0
+    data[idx == 2] = -np.abs(data[idx == 2])     # (-x) * 0.0 = -0.0 products
+    d = torch.device("cuda")
+    from sparse_amd import _kernels as Kn
+
+    args = [torch.from_numpy(x).to(d) for x in (data, idx, ptr, b)]
+    got = Kn.dot_csr_ndarray((M, N), *args, exact=True).cpu().numpy()
+    want = orc.dot_csr_ndarray((M, N), data, idx, ptr, b)
+    assert np.array_equal(got.view(np.uint32) | (np.isnan(got) * np.uint32(0x7fffffff)),
+                          want.view(np.uint32) | (np.isnan(want) * np.uint32(0x7fffffff)))      # NaN payloads aside
+    assert np.isnan(got).any() and np.isinf(got).any() and (got == 0).any()          # the cases are exercised
+
+
+def test_ldsb_all_rows_empty_and_boundaries_of_the_policy(orc):
+    from sparse_amd import _kernels as Kn
+
+    d = torch.device("cuda")
+    ptr = torch.zeros(8193, dtype=torch.int32, device=d)
+    e_i = torch.zeros(0, dtype=torch.int32, device=d)
+    e_v = torch.zeros(0, dtype=torch.float32, device=d)
+    b = torch.rand((100, 64), device=d)
+    out = torch.full((8192, 64), 3.0, device=d)
+    Kn.dot_csr_ndarray((8192, 64), e_v, e_i, ptr, b, out=out)
+    assert not out.any()
+    # K = 576 does not fit the LDS budget (577 rows of 256 bytes), M = 8191 is below the policy: both take the row-group kernel
+    for M, K in ((8192, 576), (8191, 512)):
+        (data, idx, ptr_, bb), got, kept = _ldsb_case(M, K, 128, M * 4, np.float32, np.int32, K, True)
+        assert np.array_equal(got, orc.dot_csr_ndarray((M, 128), data, idx, ptr_, bb))

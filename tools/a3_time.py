@@ -9,6 +9,18 @@ for dt in (np.float32, np.float64):
     x2 = x.reshape((n * n, n))
     d = torch.rand((n, n), device="cuda", dtype=torch.float32 if dt == np.float32 else torch.float64)
     ptr = K.rows_to_indptr(x2.coords[0], n * n); idx = x2.coords[1].contiguous(); out = torch.empty((n * n, n), device="cuda", dtype=d.dtype)
+    ref = torch.empty_like(out)
+    K.dot_csr_ndarray((n * n, n), x2.data, idx, ptr, d, out=ref, keep_order=True)      # the row-group kernel
+    K.dot_csr_ndarray((n * n, n), x2.data, idx, ptr, d, out=out)
+    print("identical to the row-group kernel:", bool(torch.equal(out, ref)))
+    g = lambda: K.dot_csr_ndarray((n * n, n), x2.data, idx, ptr, d, out=ref, keep_order=True)
+    for _ in range(10): g()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): g()
+    e1.record(); torch.cuda.synchronize()
+    print(f"row-group kernel {e0.elapsed_time(e1) / 20:.4f} ms")
     f = lambda: K.dot_csr_ndarray((n * n, n), x2.data, idx, ptr, d, out=out)
     for _ in range(20): f()
     torch.cuda.synchronize()
