@@ -32,6 +32,36 @@ while time.time() < t_end:
         ref = K.dot_csr_ndarray((M, N), data, idx, ptr, b, exact=exact)
         assert torch.equal(got, ref), ("spmm", M, Kd, dens, dt, N, exact)
     n["spmm"] += 1
+    # ---- the dispatcher's other kernels against the k-ascending row-group kernel: B resident in LDS for a short contracted
+    #      axis (bit-identical, both modes, any value type) and the row-vector kernel for results of 1..4 columns (tree order:
+    #      within rounding for floats, identical for integers)
+    M2 = int(rng.choice([8192, 9001, 40000, 150000]))
+    K2 = int(rng.choice([1, 2, 17, 64, 300, 575, 576]))
+    dens2 = float(rng.choice([0.0, 0.004, 0.03, 0.2, 0.9]))
+    dt2 = [torch.float32, torch.float64, torch.int32, torch.int64][int(rng.integers(4))]
+    vec = 16 // torch.empty(0, dtype=dt2).element_size()
+    N2 = vec * int(rng.integers(32 // vec, 80))
+    d2, i2, p2 = make_csr_device(M2, K2, dens2, seed=int(rng.integers(1 << 30)), dtype=torch.float32,
+                                 idx_dtype=torch.int32 if rng.random() < 0.7 else torch.int64)
+    d2 = d2.to(dt2) if dt2.is_floating_point else ((d2 - 0.5) * 40).to(dt2)
+    b2 = torch.randn((K2, N2), device="cuda", dtype=torch.float64)
+    b2 = b2.to(dt2) if dt2.is_floating_point else (b2 * 9).to(dt2)
+    for exact in ((False, True) if dt2.is_floating_point else (False,)):
+        got = K.dot_csr_ndarray((M2, N2), d2, i2, p2, b2, exact=exact)
+        ref = K.dot_csr_ndarray((M2, N2), d2, i2, p2, b2, exact=exact, keep_order=True)
+        assert torch.equal(got, ref), ("ldsb", M2, K2, dens2, dt2, N2, exact)
+    nv = int(rng.integers(1, 5))
+    bv = b2[:, :nv].contiguous()
+    got = K.dot_csr_ndarray((M2, nv), d2, i2, p2, bv)
+    ref = K.dot_csr_ndarray((M2, nv), d2, i2, p2, bv, keep_order=True)
+    if dt2.is_floating_point:
+        bound = K.dot_csr_ndarray((M2, nv), d2.abs(), i2, p2, bv.abs(), keep_order=True)
+        tol = 1e-6 if dt2 == torch.float32 else 1e-14
+        assert bool(((got - ref).abs() <= tol * bound + 1e-300).all()), ("rowvec", M2, K2, dens2, dt2, nv)
+    else:
+        assert torch.equal(got, ref), ("rowvec", M2, K2, dens2, dt2, nv)
+    n["narrow"] = n.get("narrow", 0) + 1
+    del d2, i2, p2, b2, bv
     if ONLY_SPMM:
         del data, idx, ptr, b, layout, got, ref
         continue
