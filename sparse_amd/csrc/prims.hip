@@ -597,12 +597,42 @@ extern "C" int spamd_rows_to_indptr(int idx_dtype, int64_t nnz, const void* rows
 }
 
 // ---- rocPRIM-backed primitives (stable radix sort, exclusive scan) ---------------------------
-extern "C" int64_t spamd_sort_pairs_ws_bytes(int64_t n) {
-  size_t bytes = 0;
-  int64_t* k = nullptr;
-  hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, k, k, k, k, (size_t)(n > 0 ? n : 1), 0, 64, (hipStream_t)0);
+// rocPRIM's radix sort runs a MERGE sort below `merge_sort_limit` items (default 2^20) whatever the key width.  Measured on
+// MI355X for (8-byte key, 8-byte payload) pairs (tools/micro/sort_limit.hip, ms): n = 10^6: merge 0.19, radix (onesweep)
+// 0.093 / 0.121 / 0.150 for 20 / 30 / 40 key bits; n = 3*10^5: 0.13 against 0.080 / 0.105 / 0.128; n = 10^5: 0.057 against
+// 0.073 / 0.096 / 0.119.  BASELINE config 1 (10^6 stored elements) sits right under the default limit, so the limit is moved to
+// the measured crossover: 128 K pairs for keys of at most 24 bits, 256 K above.
+namespace spamd {
+using SortNarrowKeys = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 128 * 1024>;
+using SortWideKeys = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 256 * 1024>;
+
+template <typename K, typename V>
+static hipError_t sort_pairs_tuned(void* ws, size_t& bytes, const K* kin, K* kout, const V* vin, V* vout, size_t n, unsigned end_bit,
+                                   hipStream_t s) {
+  if (end_bit <= 24) return rocprim::radix_sort_pairs<SortNarrowKeys>(ws, bytes, kin, kout, vin, vout, n, 0, end_bit, s);
+  return rocprim::radix_sort_pairs<SortWideKeys>(ws, bytes, kin, kout, vin, vout, n, 0, end_bit, s);
+}
+
+// workspace that serves either configuration (the key width is not known when the caller allocates)
+template <typename K, typename V>
+static int64_t sort_pairs_tuned_ws(int64_t n, unsigned max_bits) {
+  size_t a = 0, b = 0;
+  K* k = nullptr;
+  V* v = nullptr;
+  const size_t m = (size_t)(n > 0 ? n : 1);
+  hipError_t e = sort_pairs_tuned<K, V>(nullptr, a, k, k, v, v, m, max_bits < 24 ? max_bits : 24, (hipStream_t)0);
   if (e != hipSuccess) return -(int64_t)e;
-  return (int64_t)bytes + 16;
+  if (max_bits > 24) {
+    e = sort_pairs_tuned<K, V>(nullptr, b, k, k, v, v, m, max_bits, (hipStream_t)0);
+    if (e != hipSuccess) return -(int64_t)e;
+  }
+  return (int64_t)(a > b ? a : b);
+}
+}  // namespace spamd
+
+extern "C" int64_t spamd_sort_pairs_ws_bytes(int64_t n) {
+  const int64_t bytes = spamd::sort_pairs_tuned_ws<int64_t, int64_t>(n, 64);
+  return bytes < 0 ? bytes : bytes + 16;
 }
 
 // Stable LSD radix sort of (key, value) pairs on bits [0, end_bit) of the int64 keys (keys >= 0).
@@ -611,26 +641,17 @@ extern "C" int spamd_sort_pairs(int64_t n, const int64_t* keys_in, int64_t* keys
   if (n < 0 || end_bit < 1 || end_bit > 64) return SPAMD_EINVAL;
   if (n == 0) return 0;
   size_t bytes = (size_t)ws_bytes;
-  hipError_t e = rocprim::radix_sort_pairs(ws, bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0,
-                                           (unsigned)end_bit, (hipStream_t)stream);
+  hipError_t e = spamd::sort_pairs_tuned(ws, bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, (unsigned)end_bit,
+                                         (hipStream_t)stream);
   return (int)e;
 }
 
 // Same sort with the VALUE as payload (4- or 8-byte values moved bit-wise): SpGEMM sorts its
 // (key, product) pairs directly instead of sorting a permutation and gathering through it.
 extern "C" int64_t spamd_sort_kv_ws_bytes(int val_bytes, int64_t n) {
-  size_t bytes = 0;
-  int64_t* k = nullptr;
-  hipError_t e;
-  if (val_bytes == 8) {
-    uint64_t* v = nullptr;
-    e = rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)(n > 0 ? n : 1), 0, 64, (hipStream_t)0);
-  } else {
-    uint32_t* v = nullptr;
-    e = rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)(n > 0 ? n : 1), 0, 64, (hipStream_t)0);
-  }
-  if (e != hipSuccess) return -(int64_t)e;
-  return (int64_t)bytes + 16;
+  const int64_t bytes = val_bytes == 8 ? spamd::sort_pairs_tuned_ws<int64_t, uint64_t>(n, 64)
+                                       : spamd::sort_pairs_tuned_ws<int64_t, uint32_t>(n, 64);
+  return bytes < 0 ? bytes : bytes + 16;
 }
 
 extern "C" int spamd_sort_kv(int val_bytes, int64_t n, const int64_t* keys_in, int64_t* keys_out, const void* vals_in,
@@ -640,11 +661,11 @@ extern "C" int spamd_sort_kv(int val_bytes, int64_t n, const int64_t* keys_in, i
   size_t bytes = (size_t)ws_bytes;
   hipError_t e;
   if (val_bytes == 8)
-    e = rocprim::radix_sort_pairs(ws, bytes, keys_in, keys_out, (const uint64_t*)vals_in, (uint64_t*)vals_out,
-                                  (size_t)n, 0, (unsigned)end_bit, (hipStream_t)stream);
+    e = spamd::sort_pairs_tuned(ws, bytes, keys_in, keys_out, (const uint64_t*)vals_in, (uint64_t*)vals_out, (size_t)n,
+                                (unsigned)end_bit, (hipStream_t)stream);
   else if (val_bytes == 4)
-    e = rocprim::radix_sort_pairs(ws, bytes, keys_in, keys_out, (const uint32_t*)vals_in, (uint32_t*)vals_out,
-                                  (size_t)n, 0, (unsigned)end_bit, (hipStream_t)stream);
+    e = spamd::sort_pairs_tuned(ws, bytes, keys_in, keys_out, (const uint32_t*)vals_in, (uint32_t*)vals_out, (size_t)n,
+                                (unsigned)end_bit, (hipStream_t)stream);
   else
     return SPAMD_ETYPE;
   return (int)e;
@@ -754,11 +775,9 @@ static size_t csx_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 extern "C" int64_t spamd_csx_swap_ws_bytes(int64_t nnz) {
   if (nnz < 0) return -1;
-  size_t sort_bytes = 0;
-  uint32_t* k = nullptr;
-  uint64_t* v = nullptr;
-  hipError_t e = rocprim::radix_sort_pairs(nullptr, sort_bytes, k, k, v, v, (size_t)(nnz > 0 ? nnz : 1), 0, 32, (hipStream_t)0);
-  if (e != hipSuccess) return -(int64_t)e;
+  const int64_t sb = spamd::sort_pairs_tuned_ws<uint32_t, uint64_t>(nnz, 32);
+  if (sb < 0) return sb;
+  const size_t sort_bytes = (size_t)sb;
   const size_t n = (size_t)(nnz > 0 ? nnz : 1);
   return (int64_t)(2 * csx_align(4 * n) + 2 * csx_align(8 * n) + csx_align(sort_bytes) + 256);
 }
@@ -789,7 +808,7 @@ extern "C" int spamd_csx_swap(int idx_dtype, int64_t n_major, int64_t n_minor, i
     hipLaunchKernelGGL(csx_pack_kernel<I>, dim3(pack_blocks ? pack_blocks : 1), dim3(256), 0, s, n_major, (const I*)indptr,
                        (const I*)indices, (const uint32_t*)data, k0, v0);
     if (int rc = launch_status()) return rc;
-    hipError_t e = rocprim::radix_sort_pairs(p, sort_bytes, k0, k1, v0, v1, (size_t)nnz, 0, (unsigned)bits, s);
+    hipError_t e = spamd::sort_pairs_tuned(p, sort_bytes, k0, k1, v0, v1, (size_t)nnz, (unsigned)bits, s);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(csx_unpack_kernel<I>, dim3(grid_for(nnz)), dim3(256), 0, s, nnz, n_minor, k1, v1, (I*)out_indices,
                        (uint32_t*)out_data, (I*)out_indptr);
