@@ -14,6 +14,7 @@
 // The row chain (pointers -> elements -> LDS -> store) is software-pipelined over the wave's row slots as in the row-vector
 // kernel of spmm_csr.hip.  A is re-read once per panel (N / 64 times for fp32): it is the small operand here.
 #include "common.h"
+#include <mutex>
 
 namespace spamd {
 
@@ -192,8 +193,16 @@ static int launch_ldsb(int64_t M, int64_t K, int64_t N, const T* a_data, const I
   if (per_panel > slots) per_panel = slots;
   if (per_panel < 1) per_panel = 1;
   auto kern = spmm_csr_ldsb_kernel<T, I, EXACT>;
-  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS_BYTES) != hipSuccess)
-    return SPAMD_EINVAL;
+  {
+    static std::mutex mu;
+    static bool done = false;   // (one flag per template instantiation: the attribute is set once per process)
+    std::lock_guard<std::mutex> lock(mu);
+    if (!done) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS_BYTES) != hipSuccess)
+        return SPAMD_EINVAL;
+      done = true;
+    }
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)per_panel, panels), dim3(1024), ldsbytes, s, M, K, N, a_data, a_idx, a_ptr, b, ldb,
                      out, ldo);
   return launch_status();
