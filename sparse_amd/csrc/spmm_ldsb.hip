@@ -98,33 +98,39 @@ spmm_csr_ldsb_kernel(int64_t M, int64_t K, int64_t N, const T* __restrict__ a_da
     I ci;
     T vi;
   };
-  auto ptrs = [&](int64_t rbase, I& s, I& e) {
-    int64_t r = rbase + sub;
-    r = r < M ? r : M - 1;
+  // Row numbers and element positions are computed in the index type's own width: with 32-bit indices nnz and M are below
+  // 2^31, so unsigned 32-bit arithmetic (one instruction per step instead of the carry chains and paired selects of 64-bit
+  // values) is exact; only the final address is 64 bits wide.
+  using U = typename std::conditional<sizeof(I) == 4, unsigned, int64_t>::type;
+  const U m_rows = (U)M, n_el = (U)nnz;
+  const U ustride = (U)stride;
+  auto ptrs = [&](U rbase, I& s, I& e) {
+    U r = rbase + (U)sub;
+    r = r < m_rows ? r : m_rows - 1;
     s = a_ptr[r];
     e = a_ptr[r + 1];
   };
-  auto head = [&](int64_t s, Raw& h) {
-    int64_t p = s + gl;
-    p = p < nnz ? p : nnz - 1;
+  auto head = [&](U s, Raw& h) {
+    U p = s + (U)gl;
+    p = p < n_el ? p : n_el - 1;
     h.ci = a_idx[p];
     h.vi = a_data[p];
   };
-  int64_t base = wave * RPW;
+  U base = (U)(wave * RPW);
   I ps0, pe0, ps1, pe1, ps2, pe2;
   Raw cur, nxt;
   ptrs(base, ps0, pe0);
-  ptrs(base + stride, ps1, pe1);
-  head((int64_t)ps0, cur);
-  for (; base < M; base += stride) {
-    ptrs(base + 2 * stride, ps2, pe2);
-    head((int64_t)ps1, nxt);
+  ptrs(base + ustride, ps1, pe1);
+  head((U)ps0, cur);
+  for (; base < m_rows; base += ustride) {
+    ptrs(base + 2 * ustride, ps2, pe2);
+    head((U)ps1, nxt);
     T acc[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) acc[e] = T(0);
-    const bool row_ok = base + sub < M;
-    const int64_t s0 = (int64_t)ps0;
-    const int64_t len = row_ok ? (int64_t)pe0 - s0 : 0;
+    const bool row_ok = base + (U)sub < m_rows;
+    const U s0 = (U)ps0;
+    const U len = row_ok ? (U)pe0 - s0 : (U)0;
 #define SPAMD_LB_STEP4(J)                                                                                     \
   {                                                                                                           \
     const int a0 = row_bcast<J>(ca) + lane_off, a1 = row_bcast<J + 1>(ca) + lane_off;                         \
@@ -139,8 +145,9 @@ spmm_csr_ldsb_kernel(int64_t M, int64_t K, int64_t N, const T* __restrict__ a_da
     _Pragma("unroll") for (int e = 0; e < VEC; ++e) acc[e] = mul_add<EXACT>(v3, b3.v[e], acc[e]);             \
   }
     // one chunk of up to 16 pairs per row: `h` holds this lane's pair, `done` pairs of the row came before
-    auto chunk = [&](const Raw& h, int64_t done) {
-      const int cnt = (int)((len - done) < (int64_t)LB_LANES ? (len - done) : (int64_t)LB_LANES);
+    auto chunk = [&](const Raw& h, U done) {
+      const U left = len > done ? len - done : (U)0;      // (U may be unsigned: no negative remainders)
+      const int cnt = (int)(left < (U)LB_LANES ? left : (U)LB_LANES);
       const bool mine = gl < cnt;
       const int ca = mine ? (int)h.ci * LB_ROW_BYTES : pad_row;   // LDS byte address of the B row of this lane's element
       const T va = mine ? h.vi : T(0);
@@ -158,11 +165,11 @@ spmm_csr_ldsb_kernel(int64_t M, int64_t K, int64_t N, const T* __restrict__ a_da
     };
     // the first chunk stands outside the loop over longer rows: a loop header here would merge "pair from the prefetch"
     // with "pair just loaded" and make the compiler wait for every outstanding load, the prefetches of this trip included
-    chunk(cur, 0);
-    if (__any(len > LB_LANES ? 1 : 0)) {
+    chunk(cur, (U)0);
+    if (__any(len > (U)LB_LANES ? 1 : 0)) {
       // rows longer than 16 (every lane of the wave takes part in the DPP moves, so the loop runs while ANY of the four
       // rows has pairs left)
-      for (int64_t done = LB_LANES; __any(done < len ? 1 : 0); done += LB_LANES) {
+      for (U done = LB_LANES; __any(done < len ? 1 : 0); done += LB_LANES) {
         Raw h;
         head(s0 + done, h);
         chunk(h, done);
@@ -170,9 +177,9 @@ spmm_csr_ldsb_kernel(int64_t M, int64_t K, int64_t N, const T* __restrict__ a_da
     }
 #undef SPAMD_LB_STEP4
 #if defined(LB_ABL) && LB_ABL == 2
-    if (row_ok && col_ok && acc[0] == T(12345.678)) nt_store<T, VEC>(out + (base + sub) * ldo + col, acc);
+    if (row_ok && col_ok && acc[0] == T(12345.678)) nt_store<T, VEC>(out + (int64_t)(base + (U)sub) * ldo + col, acc);
 #else
-    if (row_ok && col_ok) nt_store<T, VEC>(out + (base + sub) * ldo + col, acc);
+    if (row_ok && col_ok) nt_store<T, VEC>(out + (int64_t)(base + (U)sub) * ldo + col, acc);
 #endif
     ps0 = ps1; pe0 = pe1; ps1 = ps2; pe1 = pe2;
     cur = nxt;
