@@ -386,7 +386,7 @@ def moveaxis(a, source, destination):
 
 
 def expand_dims(x, /, *, axis=0):
-    """`_coo/common.py:1362-1400`: always a COO (the reference converts its input first)."""
+    """`_coo/common.py:1074-1133`: always a COO (the reference converts its input first)."""
     from ._array_api import _validate_coo_input
 
     x = _validate_coo_input(x)

@@ -57,7 +57,7 @@ def _keep(mask_u8, coords, data):
 # ---- conversions and dtype helpers --------------------------------------------------------------------------------
 
 def asCOO(x, name="asCOO", check=True):
-    """`_coo/common.py:27-55`: any sparse array as COO; a dense input is refused unless `check=False`."""
+    """`_coo/common.py:21-53`: any sparse array as COO; a dense input is refused unless `check=False`."""
     from ._coo import COO
 
     if check and not _is_sparse(x):
@@ -68,7 +68,7 @@ def asCOO(x, name="asCOO", check=True):
 
 
 def _validate_coo_input(x):
-    """`_coo/common.py:1462-1473`"""
+    """`_coo/common.py:1386-1397`"""
     from ._coo import COO, _is_scipy_sparse
 
     if _is_scipy_sparse(x):
@@ -79,7 +79,7 @@ def _validate_coo_input(x):
 
 
 def asnumpy(a, dtype=None, order=None):
-    """`_common.py:1928-1951`: the dense host array"""
+    """`_common.py:1928-1948`: the dense host array"""
     if isinstance(a, SparseArray):
         a = a.todense()
     if isinstance(a, torch.Tensor):
@@ -93,7 +93,7 @@ def can_cast(from_, to, /, *, casting="safe"):
 
 
 def result_type(*arrays_and_dtypes):
-    """`_coo/common.py:1186-1197`: sparse arrays count by dtype (0-d ones by value)."""
+    """`_coo/common.py:991-1008`: sparse arrays count by dtype (0-d ones by value)."""
     def arg(x):
         if not isinstance(x, SparseArray):
             return x
@@ -170,7 +170,7 @@ def imag(x, /):
 
 
 def clip(a, min=None, max=None, out=None):  # noqa: A002
-    """`_coo/common.py:1200-1252`"""
+    """`_coo/common.py:1028-1071`"""
     return asCOO(a, name="clip").clip(min, max)
 
 
@@ -189,14 +189,14 @@ def _same_sign_inf(x, positive):
 
 
 def isposinf(x, out=None):
-    """`_coo/common.py:1113-1147`"""
+    """`_coo/common.py:937-961`"""
     if out is not None:
         raise NotImplementedError("`out=` is not supported here")
     return _same_sign_inf(x, True)
 
 
 def isneginf(x, out=None):
-    """`_coo/common.py:1150-1183`"""
+    """`_coo/common.py:964-988`"""
     if out is not None:
         raise NotImplementedError("`out=` is not supported here")
     return _same_sign_inf(x, False)
@@ -205,7 +205,7 @@ def isneginf(x, out=None):
 # ---- coordinate shuffles --------------------------------------------------------------------------------------------
 
 def flip(x, /, *, axis=None):
-    """`_coo/common.py:1403-1437`: coordinate c of a flipped axis becomes n - 1 - c."""
+    """`_coo/common.py:1136-1178`: coordinate c of a flipped axis becomes n - 1 - c."""
     from ._coo import COO
 
     x = _validate_coo_input(x)
@@ -222,7 +222,7 @@ def flip(x, /, *, axis=None):
 
 
 def roll(a, shift, axis=None):
-    """`_coo/common.py:906-980`: coordinates move by `shift` modulo the axis length."""
+    """`_coo/common.py:735-812`: coordinates move by `shift` modulo the axis length."""
     from ._coo import COO, as_coo
 
     a = as_coo(a)
@@ -298,17 +298,17 @@ def _triangle(x, k, upper):
 
 
 def triu(x, k=0):
-    """`_coo/common.py:275-313`: elements with row + k <= column of the last two axes."""
+    """`_coo/common.py:252-290`: elements with row + k <= column of the last two axes."""
     return _triangle(x, k, True)
 
 
 def tril(x, k=0):
-    """`_coo/common.py:316-354`: elements with row + k >= column of the last two axes."""
+    """`_coo/common.py:293-331`: elements with row + k >= column of the last two axes."""
     return _triangle(x, k, False)
 
 
 def diagonal(a, offset=0, axis1=0, axis2=1):
-    """`_coo/common.py:983-1050`: stored elements with coords[axis1] + offset == coords[axis2]; the result's last axis
+    """`_coo/common.py:815-878` (`_diagonal_idx` :1012-1025): stored elements with coords[axis1] + offset == coords[axis2]; the result's last axis
     carries coords[axis1] (the reference's choice, also for negative offsets)."""
     from ._coo import COO
 
@@ -327,7 +327,7 @@ def diagonal(a, offset=0, axis1=0, axis2=1):
 
 
 def diagonalize(a, axis=0):
-    """`_coo/common.py:1053-1110`: a new last axis that repeats the coordinate of `axis`."""
+    """`_coo/common.py:881-934`: a new last axis that repeats the coordinate of `axis`."""
     from ._coo import COO, as_coo
 
     a = as_coo(a)
@@ -336,7 +336,7 @@ def diagonalize(a, axis=0):
 
 
 def kron(a, b):
-    """`_coo/common.py:58-155`: every pair (stored element of a, stored element of b); coordinate = a's times b's extent
+    """`_coo/common.py:67-129`: every pair (stored element of a, stored element of b); coordinate = a's times b's extent
     plus b's, value = the product."""
     from ._coo import COO
 
@@ -475,7 +475,7 @@ def diff(x, axis=-1, n=1, prepend=None, append=None):
 
 
 def interp(x, xp, fp, left=None, right=None, period=None):
-    """`_common.py:3267-3350`: `numpy.interp` of the stored values and of the fill value (a general, host-evaluated
+    """`_common.py:3267-3349`: `numpy.interp` of the stored values and of the fill value (a general, host-evaluated
     callable for the elementwise path, as in the reference); zeros of the result are pruned."""
     from ._coo import COO, as_coo
     from ._gcxs import GCXS
@@ -555,7 +555,7 @@ ALL_KEY_BITS = 2 ** 64 - 1      # sort on all 64 bits: rocPRIM's codec then orde
 
 
 def _arg_minmax(x, axis, keepdims, max_mode):
-    """`_coo/common.py:1476-1548` and its kernel `_compute_minmax_args` (:1440-1459) per output position:
+    """`_coo/common.py:1499-1568` and its kernel `_compute_minmax_args` (:1455-1496) per output position:
     the coordinate of the first best STORED value if one beats the fill value (or nothing but stored values is there),
     otherwise the first coordinate that holds no stored value."""
     from ._coo import COO
@@ -633,17 +633,17 @@ def _arg_minmax(x, axis, keepdims, max_mode):
 
 
 def argmax(x, /, *, axis=None, keepdims=False):
-    """`_coo/common.py:1340-1359`"""
+    """`_coo/common.py:614-641`"""
     return _arg_minmax(x, axis, keepdims, True)
 
 
 def argmin(x, /, *, axis=None, keepdims=False):
-    """`_coo/common.py:1318-1337`"""
+    """`_coo/common.py:644-671`"""
     return _arg_minmax(x, axis, keepdims, False)
 
 
 def sort(x, /, *, axis=-1, descending=False, stable=False):
-    """`_coo/common.py:1255-1315` and `_sort_coo` (:1551-1598): along `axis` the stored values of every line are sorted and
+    """`_coo/common.py:1280-1346` and `_sort_coo` (:1401-1451): along `axis` the stored values of every line are sorted and
     take the leading coordinates; from the first value the fill value is smaller than (larger than, descending) onwards
     they move behind the line's fill values."""
     from ._api import moveaxis
@@ -734,7 +734,7 @@ def _unique_stored(x):
 
 
 def unique_counts(x, /):
-    """`_coo/common.py:1201-1252` (array API): distinct values with their counts, the fill value included - inserted the
+    """`_coo/common.py:1189-1236` (array API): distinct values with their counts, the fill value included - inserted the
     way the reference inserts it (its scatter through `argsort`, which is the sorted order when the fill value is the
     smallest or second smallest value)."""
     x = _validate_coo_input(x)
@@ -755,7 +755,7 @@ def unique_counts(x, /):
 
 
 def unique_values(x, /):
-    """`_coo/common.py:1255-1300`"""
+    """`_coo/common.py:1239-1277`"""
     x = _validate_coo_input(x)
     x = x.flatten()
     values, _ = _unique_stored(x)
@@ -769,7 +769,7 @@ def unique_values(x, /):
 
 
 def take(x, indices, /, *, axis=None):
-    """`_coo/common.py:1303-1315`: an integer array index along one axis (`_indexing.getitem`)."""
+    """`_coo/common.py:1349-1383`: an integer array index along one axis (`_indexing.getitem`)."""
     x = _validate_coo_input(x)
     if axis is None:
         x = x.flatten()

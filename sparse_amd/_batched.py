@@ -63,7 +63,7 @@ def _gcxs_result(out, nd_in, axis, compressed_axes):
 
 
 def concatenate(arrays, axis=0, compressed_axes=None):
-    """Join sparse arrays along an existing axis (reference _common.py:1518-1558, _coo/common.py:132-192)."""
+    """Join sparse arrays along an existing axis (reference _common.py:1518-1554, _coo/common.py:132-192)."""
     from ._coo import COO, as_coo
     from ._gcxs import GCXS
     from ._umath import binary_arrays

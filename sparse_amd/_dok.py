@@ -16,7 +16,7 @@ from ._utils import equivalent
 
 
 class DOK(SparseArray, NDArrayOperatorsMixin):
-    """N-D sparse array as `{coordinate tuple: value}` (reference `_dok.py:13-133`).
+    """N-D sparse array as `{coordinate tuple: value}` (reference `_dok.py:13-132`).
 
     `DOK(shape, data=None, dtype=None, fill_value=None)`; `shape` may also be a COO, a NumPy array or a SciPy sparse
     matrix to convert."""
@@ -214,7 +214,7 @@ class DOK(SparseArray, NDArrayOperatorsMixin):
 
     def _set_block(self, key, value):
         """`self[key] = value` for integers and (normalised) slices: the value broadcasts NumPy-style from the right over
-        the slice axes; elements equal to the fill value are removed, not stored (reference `_setitem`, :396-434)."""
+        the slice axes; elements equal to the fill value are removed, not stored (reference `_setitem`, `_dok.py:396-434`)."""
         n_slices = sum(1 for k in key if isinstance(k, slice))
         if n_slices - value.ndim < 0:
             raise ValueError("setting an array element with a sequence.")

@@ -112,7 +112,7 @@ def test_argmax_argmin_sort_unique_against_numpy():
                 if full or d.dtype.kind == "f":
                     # (with zeros in the line NumPy returns the first zero's position: so does the reference's first-gap
                     #  rule when no stored value beats the fill value; distinct values otherwise)
-                    # (the reference squeezes EVERY unit axis of the result, `_arg_minmax_common`, _coo/common.py:1547)
+                    # (the reference squeezes EVERY unit axis of the result, `_arg_minmax_common`, _coo/common.py:1568)
                     _same(sp.argmax(x, axis=ax), np.squeeze(np.argmax(d, axis=ax)))
                     _same(sp.argmin(x, axis=ax), np.squeeze(np.argmin(d, axis=ax)))
                     if d.ndim > 1:     # (a vector is lifted to a column first there: keepdims gives (1, 1))
