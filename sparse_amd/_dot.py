@@ -468,7 +468,16 @@ def _csr_triplet(a):
     if isinstance(a, COO):  # canonical 2-D COO is CSR order already: only the row pointers are missing
         view = getattr(a, "_csr_view", None)
         if view is None:
-            view = (a.data, a.coords[1].contiguous(), K.rows_to_indptr(a.coords[0], int(a.shape[0])))
+            keys = getattr(a, "_keys", None)
+            it = a._index_dtype
+            if a.__dict__.get("_coords") is None and keys is not None and it in (torch.int32, torch.int64) \
+                    and (it == torch.int64 or max(int(a.shape[1]), a.nnz) < 2 ** 31):
+                # built from linear keys (a reshape / transpose / elementwise result) and the coordinates never asked for:
+                # column indices and row pointers come from the keys in one pass, the coordinate rows are not materialised
+                indptr, indices = K.keys_to_csr(keys, int(a.shape[0]), int(a.shape[1]), it)
+                view = (a.data, indices, indptr)
+            else:
+                view = (a.data, a.coords[1].contiguous(), K.rows_to_indptr(a.coords[0], int(a.shape[0])))
             a._csr_view = view
         return view
     if a.compressed_axes == (0,):
