@@ -29,7 +29,6 @@ from numpy import right_shift as bitwise_right_shift  # noqa: F401
 from ._sparse_array import SparseArray
 from ._coo import COO, as_coo
 from ._gcxs import GCXS
-from ._dok import DOK
 from ._dot import dot, flush_warnings, matmul, tensordot
 from ._umath import elemwise
 from ._einsum import einsum
@@ -41,24 +40,24 @@ from ._api import (all, any, argwhere, asarray, astype, empty, empty_like, expan
                    ones, ones_like, permute_dims, prod, random, reshape, sddmm, squeeze, std, sum, var, vecdot, where, zeros,
                    zeros_like)
 from ._array_api import (abs, argmax, argmin, asCOO, asnumpy, broadcast_arrays, broadcast_shapes, can_cast, clip, concat, diagonal, diagonalize,
-                         diff, equal, flip, imag, interp, isinf, isnan, isneginf, isposinf, kron, outer, pad, real, repeat,
-                         result_type, roll, round, sort, take, tile, tril, triu, unique_counts, unique_values, unstack)
+                         equal, flip, imag, isinf, isnan, isneginf, isposinf, kron, outer, pad, real,
+                         result_type, roll, round, sort, tril, triu)
 from ._ffi import HipBackendError
 from ._settings import __array_namespace_info__  # noqa: F401
 
 __array_api_version__ = "2025.12"   # as the reference declares (sparse/__init__.py:7)
 
-__all__ = ["COO", "DOK", "GCXS", "SparseArray", "HipBackendError", "abs", "acos", "acosh", "add", "all", "any", "argmax", "argmin", "argwhere", "asCOO", "as_coo",
+__all__ = ["COO", "GCXS", "SparseArray", "HipBackendError", "abs", "acos", "acosh", "add", "all", "any", "argmax", "argmin", "argwhere", "asCOO", "as_coo",
            "asarray", "asin", "asinh", "asnumpy", "astype", "atan", "atan2", "atanh", "bitwise_and", "bitwise_invert",
            "bitwise_left_shift", "bitwise_not", "bitwise_or", "bitwise_right_shift", "bitwise_xor", "bool", "broadcast_arrays",
            "broadcast_shapes", "broadcast_to", "can_cast", "ceil", "clip", "complex128", "complex64", "concat", "conj", "copysign",
-           "cos", "cosh", "diagonal", "diagonalize", "diff", "divide", "e", "equal", "exp", "expm1", "finfo", "flip", "float16",
+           "cos", "cosh", "diagonal", "diagonalize", "divide", "e", "equal", "exp", "expm1", "finfo", "flip", "float16",
            "float32", "float64", "floor", "floor_divide", "greater", "greater_equal", "hypot", "iinfo", "imag", "inf", "int16",
-           "int32", "int64", "int8", "interp", "isdtype", "isfinite", "isinf", "isnan", "isneginf", "isposinf", "kron", "less", "less_equal",
+           "int32", "int64", "int8", "isdtype", "isfinite", "isinf", "isnan", "isneginf", "isposinf", "kron", "less", "less_equal",
            "log", "log10", "log1p", "log2", "logaddexp", "logical_and", "logical_not", "logical_or", "logical_xor", "maximum",
            "minimum", "multiply", "nan", "negative", "newaxis", "nextafter", "not_equal", "outer", "pad", "pi", "positive", "pow",
-           "real", "reciprocal", "remainder", "repeat", "result_type", "roll", "round", "sign", "signbit", "sin", "sinh", "sqrt",
-           "square", "subtract", "tan", "tanh", "sort", "take", "tile", "tril", "triu", "trunc", "unique_counts", "unique_values", "uint16", "uint32", "uint64", "uint8", "unstack",
+           "real", "reciprocal", "remainder", "result_type", "roll", "round", "sign", "signbit", "sin", "sinh", "sqrt",
+           "square", "subtract", "tan", "tanh", "sort", "tril", "triu", "trunc", "uint16", "uint32", "uint64", "uint8", 
            "concatenate", "dot", "einsum", "elemwise", "empty", "empty_like", "expand_dims", "eye", "full", "full_like", "load_npz", "matmul",
            "matrix_transpose", "max", "mean", "min", "moveaxis", "nanmax", "nanmean", "nanmin", "nanprod", "nanreduce", "nansum",
            "nonzero", "ones", "ones_like", "permute_dims", "prod", "random", "reshape", "save_npz", "sddmm", "squeeze", "stack", "std",

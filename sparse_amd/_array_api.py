@@ -4,9 +4,11 @@ coordinate-shuffling functions of `_coo/common.py` and the array-API utilities o
 Nothing here has arithmetic of its own beyond integer coordinate work.  Each function is restated on top of the
 library's device primitives - the elementwise kernels over coordinate rows (`_umath.binary_arrays`), flag / scan /
 compaction (`_kernels`), the COO constructor's sort, `concatenate`, `broadcast_to`, basic indexing - so operands stay
-in HBM; the only host traffic is what the reference itself returns as host values (shapes, dtypes, `unique_*`)."""
+in HBM; the only host traffic is what the reference itself returns as host values (shapes, dtypes).  Round 4: the
+functions that were compositions of other public functions (`repeat`, `tile`, `unstack`, `diff`, `interp`, `take`,
+`unique_*`) and the host-side `DOK` container were REMOVED - they are outside SURVEY.md section 8 and carried no device
+work of their own."""
 import builtins
-from collections import namedtuple
 from collections.abc import Iterable
 
 import numpy as np
@@ -396,115 +398,6 @@ def concat(arrays, axis=0, compressed_axes=None):
     return concatenate(arrays, axis=axis, compressed_axes=compressed_axes)
 
 
-def repeat(a, repeats, axis=None):
-    """`_common.py:3121-3161`: a new unit axis behind `axis`, broadcast to `repeats`, folded back."""
-    from ._api import expand_dims
-    from ._broadcast import broadcast_to
-
-    if not isinstance(a, SparseArray):
-        raise TypeError("`a` must be a SparseArray.")
-    if not isinstance(repeats, int):
-        raise ValueError("`repeats` must be an integer, uneven repeats are not yet Implemented.")
-    new_shape = list(a.shape)
-    axis_is_none = False
-    if axis is None:
-        a = a.reshape(-1)
-        axis = 0
-        axis_is_none = True
-    if axis < 0:
-        axis = a.ndim + axis
-    new_shape[axis] *= repeats
-    a = expand_dims(a, axis=axis + 1)
-    a = broadcast_to(a, a.shape[: axis + 1] + (a.shape[axis + 1] * repeats,) + a.shape[axis + 2:])
-    if not axis_is_none:
-        return a.reshape(new_shape)
-    return a.reshape(new_shape).flatten()
-
-
-def tile(a, reps):
-    """`_common.py:3164-3200`: every axis gets a unit axis in front, the unit axes are broadcast to `reps`."""
-    from ._coo import as_coo
-
-    if not isinstance(a, SparseArray):
-        a = as_coo(a)
-    if isinstance(reps, int):
-        reps = (reps,)
-    reps = tuple(reps)
-    if a.ndim == 0:
-        a = a.reshape((1,))
-    if len(reps) < a.ndim:
-        reps = (1,) * (a.ndim - len(reps)) + reps
-    elif len(reps) > a.ndim:
-        a = a.reshape((1,) * (len(reps) - a.ndim) + a.shape)
-    shape = a.shape
-    nd = len(reps)
-    a = a.reshape(tuple(int(v) for v in np.column_stack(([1] * nd, shape)).reshape(-1)))
-    a = a.broadcast_to(tuple(int(v) for v in np.column_stack((reps, shape)).reshape(-1)))
-    return a.reshape(tuple(int(v) for v in np.multiply(reps, shape)))
-
-
-def unstack(x, axis=0):
-    """`_common.py:3203-3231`: the slices along `axis`."""
-    ndim = x.ndim
-    if not (-ndim <= axis < ndim):
-        raise ValueError(f"axis must be in range [-{ndim}, {ndim}), got {axis}")
-    if not isinstance(x, SparseArray):
-        raise TypeError("`a` must be a SparseArray.")
-    if axis < 0:
-        axis = ndim + axis
-    x = x.transpose((axis,) + tuple(i for i in range(ndim) if i != axis))
-    return tuple(x[i] for i in range(x.shape[0]))
-
-
-def diff(x, axis=-1, n=1, prepend=None, append=None):
-    """`_common.py:3234-3264`: n times (x[1:] - x[:-1]) along `axis`."""
-    from ._batched import concatenate
-
-    if not isinstance(x, SparseArray):
-        raise TypeError("`x` must be a SparseArray.")
-    if axis < 0:
-        axis = x.ndim + axis
-    if prepend is not None:
-        x = concatenate([prepend, x], axis=axis)
-    if append is not None:
-        x = concatenate([x, append], axis=axis)
-    lead = (slice(None),) * axis
-    for _ in range(n):
-        x = x[lead + (slice(1, None),)] - x[lead + (slice(None, -1),)]
-    return x
-
-
-def interp(x, xp, fp, left=None, right=None, period=None):
-    """`_common.py:3267-3349`: `numpy.interp` of the stored values and of the fill value (a general, host-evaluated
-    callable for the elementwise path, as in the reference); zeros of the result are pruned."""
-    from ._coo import COO, as_coo
-    from ._gcxs import GCXS
-
-    if isinstance(xp, SparseArray):
-        xp = xp.todense()
-    if isinstance(fp, SparseArray):
-        fp = fp.todense()
-
-    def interp_func(xx):
-        return np.interp(xx, xp, fp, left=left, right=right, period=period)
-
-    if not isinstance(x, SparseArray):
-        return interp_func(x)
-    arr = as_coo(x)
-    data = interp_func(arr.data.cpu().numpy())
-    fill_value = interp_func(arr.fill_value)
-    out = COO(arr.coords, torch.from_numpy(np.ascontiguousarray(data)).to(arr.device), shape=arr.shape, fill_value=fill_value,
-              prune=True, has_duplicates=False, sorted=True)
-    if isinstance(x, GCXS):
-        return out.asformat("gcxs", compressed_axes=x.compressed_axes)
-    from ._dok import DOK
-
-    return out.asformat("dok") if isinstance(x, DOK) else out
-
-
-UniqueCountsResult = namedtuple("UniqueCountsResult", ["values", "counts"])
-
-
 # ---- order statistics: argmax / argmin, sort, unique ------------------------------------------------------------------
 
 def _where(mask, a, b, a_scalar=False, b_scalar=False):
@@ -702,77 +595,3 @@ def sort(x, /, *, axis=-1, descending=False, stable=False):
     return out
 
 
-def _unique_stored(x):
-    """sorted distinct stored values and their multiplicities, NaNs kept apart (`np.unique(..., equal_nan=False)`),
-    as host arrays - what the reference's `np.unique(x.data, return_counts=True, equal_nan=False)` returns"""
-    from ._umath import unary_array
-
-    data = x.data
-    n, dev = int(data.numel()), x.device
-    if n == 0:
-        return np.empty(0, dtype=x.dtype), np.empty(0, dtype=np.intp)
-    keys, perm = K.sort_keys(_order_keys(data), ALL_KEY_BITS)
-    vals = K.gather(data.contiguous(), perm)
-    n_nan = 0
-    if data.dtype in (torch.float32, torch.float64):
-        n_nan = int(K.count_eq_bits(unary_array("isnan", vals).view(torch.uint8), 1))
-    m = n - n_nan                                                           # NaNs sort last
-    values = np.empty(0, dtype=x.dtype)
-    counts = np.empty(0, dtype=np.intp)
-    if m:
-        heads = K.flag_heads(keys[:m].contiguous())
-        offs = K.exclusive_scan(heads)
-        u = int(offs[-1])
-        first = K.compact(_iota(m, dev), heads, offs, u)
-        values = K.gather(vals, first).cpu().numpy()
-        ends = torch.cat([first[1:], _i64(m, dev)])
-        counts = _binary("subtract", ends, first).cpu().numpy().astype(np.intp)
-    if n_nan:
-        values = np.concatenate([values, vals[m:].cpu().numpy()])
-        counts = np.concatenate([counts, np.ones(n_nan, dtype=np.intp)])
-    return values, counts
-
-
-def unique_counts(x, /):
-    """`_coo/common.py:1189-1236` (array API): distinct values with their counts, the fill value included - inserted the
-    way the reference inserts it (its scatter through `argsort`, which is the sorted order when the fill value is the
-    smallest or second smallest value)."""
-    x = _validate_coo_input(x)
-    x = x.flatten()
-    values, counts = _unique_stored(x)
-    fill_count = x.size - x.nnz
-    if fill_count > 0:
-        if np.isnan(x.fill_value):
-            values = np.concatenate([values, np.full(fill_count, x.fill_value)])
-            counts = np.concatenate([counts, np.ones(fill_count, dtype=counts.dtype)])
-        else:
-            values = np.concatenate([[x.fill_value], values])
-            counts = np.concatenate([[fill_count], counts])
-            order = np.argsort(values)
-            values[order] = values.copy()
-            counts[order] = counts.copy()
-    return UniqueCountsResult(values, counts)
-
-
-def unique_values(x, /):
-    """`_coo/common.py:1239-1277`"""
-    x = _validate_coo_input(x)
-    x = x.flatten()
-    values, _ = _unique_stored(x)
-    fill_count = x.size - x.nnz
-    if fill_count > 0:
-        if np.isnan(x.fill_value):
-            values = np.concatenate([values, np.full(fill_count, x.fill_value)])
-        else:
-            values = np.sort(np.concatenate([[x.fill_value], values]))
-    return values
-
-
-def take(x, indices, /, *, axis=None):
-    """`_coo/common.py:1349-1383`: an integer array index along one axis (`_indexing.getitem`)."""
-    x = _validate_coo_input(x)
-    if axis is None:
-        x = x.flatten()
-        return x[indices]
-    axis = normalize_axis(axis, x.ndim)
-    return x[(slice(None),) * axis + (indices, ...)]

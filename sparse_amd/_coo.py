@@ -427,12 +427,6 @@ class COO(SparseArray, NDArrayOperatorsMixin):
             from ._gcxs import GCXS
 
             return GCXS.from_coo(self, **kwargs)
-        if format == "dok":
-            from ._dok import DOK
-
-            if kwargs:
-                raise ValueError(f"Extra kwargs found: {kwargs}")
-            return DOK.from_coo(self)
         raise NotImplementedError(f"format {format!r} is not available in the hip backend")
 
     def tocsr(self):

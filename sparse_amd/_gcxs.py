@@ -235,15 +235,7 @@ class GCXS(SparseArray, NDArrayOperatorsMixin):
             if kwargs or ca is not None:
                 raise TypeError("unexpected keyword arguments for format 'coo'")
             return self.tocoo()
-        if format == "dok":
-            return self.tocoo().asformat("dok", **kwargs)
         raise NotImplementedError(f"format {format!r} is not available in the hip backend")
-
-    def todok(self):
-        """`compressed.py:490-493`"""
-        from ._dok import DOK
-
-        return DOK.from_coo(self.tocoo())
 
     def maybe_densify(self, max_size=1000, min_density=0.25):
         if self.size <= max_size or self.density >= min_density:

@@ -526,11 +526,7 @@ def elemwise(func, *args, **kwargs):
     if not sparse_args:
         raise ValueError(f"None of the args is sparse: {args}")
     out_kwargs = {}
-    from ._dok import DOK
-
-    if all(isinstance(a, DOK) for a in sparse_args):      # the reference's rule (`_umath.py:419-427`): all DOK -> DOK
-        out_type = "dok"
-    elif all(isinstance(a, GCXS) for a in sparse_args):
+    if all(isinstance(a, GCXS) for a in sparse_args):
         out_type = "gcxs"
         if len({a.compressed_axes for a in sparse_args}) == 1:
             out_kwargs["compressed_axes"] = sparse_args[0].compressed_axes

@@ -1,5 +1,5 @@
 """The array-namespace functions around the hot path (`sparse_amd/_array_api.py`: flip, roll, pad, tril / triu, diagonal,
-diagonalize, kron, outer, repeat, tile, unstack, diff, interp, clip, isposinf / isneginf, the array-API spellings of NumPy's
+diagonalize, kron, outer, clip, isposinf / isneginf, the array-API spellings of NumPy's
 ufuncs, dtypes and constants) against what the REAL reference returned for the same inputs (tests/golden/array_api.npz,
 written by `python oracle/gen_golden.py array_api` from the cases in tests/array_api_cases.py)."""
 import os
@@ -43,10 +43,16 @@ def test_case_matches_the_reference(k):
         assert got["nnz"] == int(G[f"c{k}_nnz"]), name
 
 
+# outside SURVEY.md section 8 and deliberately absent (removed in round 4: compositions of other public functions and the
+# host-side dictionary container; nothing of the hot path)
+NOT_PROVIDED = {"DOK", "diff", "interp", "repeat", "take", "tile", "unique_counts", "unique_values", "unstack"}
+
+
 def test_namespace_covers_the_reference_names():
-    """every public name of `sparse.numba_backend` (its `__all__`, __init__.py:179-350)"""
+    """the public names of `sparse.numba_backend` (its `__all__`, __init__.py:179-350) for the subset this backend supports
+    ("the same names for the subset it supports")"""
     import sparse_amd as sp
 
     names = [str(n) for n in G["reference_all"]]
     missing = [n for n in names if not hasattr(sp, n)]
-    assert not missing, missing
+    assert set(missing) == NOT_PROVIDED, missing

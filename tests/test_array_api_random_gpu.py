@@ -75,30 +75,7 @@ def test_triangles_diagonals_kron_against_numpy():
             _same(sp.kron(small, x), np.kron(small, d))
 
 
-def test_repeat_tile_diff_unstack_take_against_numpy():
-    import sparse_amd as sp
-
-    for rng, shape, d in _cases(3):
-        for x in _both(sp, d):
-            for ax in range(d.ndim):
-                _same(sp.repeat(x, 2, axis=ax), np.repeat(d, 2, axis=ax))
-                parts = sp.unstack(x, axis=ax)
-                assert len(parts) == d.shape[ax]
-                for got, want in zip(parts, np.moveaxis(d, ax, 0)):
-                    _same(got, want)
-                if d.shape[ax] > 1:
-                    _same(sp.diff(x, axis=ax), np.diff(d, axis=ax))
-                if d.shape[ax]:
-                    idx = rng.integers(-d.shape[ax], d.shape[ax], size=5)
-                    _same(sp.take(x, idx, axis=ax), np.take(d, idx, axis=ax))
-            _same(sp.repeat(x, 3), np.repeat(d, 3))
-            _same(sp.tile(sp.COO.from_numpy(d), 2), np.tile(d, 2))
-            if d.size:
-                idx = rng.integers(0, d.size, size=7)
-                _same(sp.take(x, idx), np.take(d, idx))
-
-
-def test_argmax_argmin_sort_unique_against_numpy():
+def test_argmax_argmin_sort_against_numpy():
     import sparse_amd as sp
 
     for rng, shape, d in _cases(4):
@@ -118,9 +95,3 @@ def test_argmax_argmin_sort_unique_against_numpy():
                     if d.ndim > 1:     # (a vector is lifted to a column first there: keepdims gives (1, 1))
                         _same(sp.argmax(x, axis=ax, keepdims=True), np.argmax(d, axis=ax, keepdims=True))
             _same(np.asarray(sp.argmax(x).todense()).reshape(()), np.argmax(d))
-            vals = sp.unique_values(x)
-            assert np.array_equal(np.sort(vals), np.unique(d)) and vals.dtype == d.dtype
-            res = sp.unique_counts(x)
-            order = np.argsort(res.values, kind="stable")
-            uv, uc = np.unique(d, return_counts=True)
-            assert np.array_equal(res.values[order], uv) and np.array_equal(res.counts[order], uc)
