@@ -98,24 +98,41 @@ def all_gather_rows(b_shard, n_rows, group=None):
     return _start_gather_rows(b_shard, n_rows, group)()
 
 
-# The gathered operand of the last call per (shard buffer, version, group): a static B (inference-style loops, the bench's
-# steady state when B does not change) crosses xGMI once, not once per product.  In-place writes to the shard bump torch's
-# version counter and a replaced shard changes the pointer, so a changed B is gathered again.  Every rank evaluates the
-# same key from its own shard; a rank whose shard changed while another's did not would deadlock in the collective, so the
-# contract is the usual SPMD one: all ranks update B together.
+# OPT-IN memo of the gathered operand (`memo=True`): a static B (inference-style loops) crosses xGMI once, not once per
+# product.  Off by default (round-3 advice): the key - pointer, torch version counter, shape, dtype, group - cannot see a
+# write that does not bump the version counter (a raw-pointer kernel writing an `out=` buffer, a DLPack / NumPy view), and a
+# key that changes on some ranks only sends those ranks into the collective alone.  A caller that opts in owns that
+# contract (all ranks update B together, through torch) and calls `invalidate_gather_memo()` after any other write.
 _GATHER_MEMO = {}
-GATHER_MEMO_ENTRIES = 4
+GATHER_MEMO_ENTRIES = 2
+
+
+def invalidate_gather_memo():
+    """Forget every memoised gathered operand (and release the shards and full matrices it kept alive)."""
+    _GATHER_MEMO.clear()
+
+
+def _group_key(group):
+    """A stable identity of a process group: its name when torch gives one, else the global ranks it spans (never `id()`:
+    a collected group's id can be reused by a new one)."""
+    import torch.distributed as dist
+
+    if group is None:
+        return "WORLD"
+    name = getattr(group, "group_name", None)
+    if name:
+        return str(name)
+    return tuple(dist.get_process_group_ranks(group))
 
 
 def _gather_key(t, n_rows, group):
-    return (t.data_ptr(), int(t._version), tuple(t.shape), t.dtype, int(n_rows), id(group))
+    return (t.data_ptr(), int(t._version), tuple(t.shape), t.dtype, int(n_rows), _group_key(group))
 
 
-def gathered_rows(b_shard, n_rows, group=None, before_wait=None, memo=True):
-    """`all_gather_rows` with the memo above (`memo=False`: always gather); `before_wait()` is called after the collective
-    is launched and before it is waited for (also when the memo hits: the caller's preparation work is wanted either
-    way)."""
-    key = _gather_key(b_shard, n_rows, group)
+def gathered_rows(b_shard, n_rows, group=None, before_wait=None, memo=False):
+    """`all_gather_rows`; `before_wait()` is called after the collective is launched and before it is waited for (also when
+    the opt-in memo hits: the caller's preparation work is wanted either way)."""
+    key = _gather_key(b_shard, n_rows, group) if memo else None
     hit = _GATHER_MEMO.get(key) if memo else None
     if hit is not None:
         if before_wait is not None:
@@ -133,11 +150,11 @@ def gathered_rows(b_shard, n_rows, group=None, before_wait=None, memo=True):
     return full
 
 
-def sharded_spmm(a_local, b_shard, n_rows_b, group=None, memo=True):
+def sharded_spmm(a_local, b_shard, n_rows_b, group=None, memo=False):
     """Row-block-sharded C_local = A_local @ all_gather(B): the multi-GPU form of A1/A3.
     `a_local` is this rank's GCXS/COO row block, `b_shard` its slice of B's rows.  While the shards of B are in flight
     the local block is prepared: its NaN scan (`matmul`'s warning, memoised per buffer) and, for an eligible operand,
-    its block stream (`prepare_operand`).  `memo=False` gathers B at every call even when the shard has not changed."""
+    its block stream (`prepare_operand`).  `memo=True` opts into the gathered-operand memo (see `_GATHER_MEMO`)."""
     from . import _dot
 
     b = gathered_rows(b_shard, n_rows_b, group, before_wait=lambda: _dot.prepare_operand(a_local, b_shard), memo=memo)
@@ -179,25 +196,59 @@ def _offset_i64(t, value):
     return t + value
 
 
+def _pad16(n):
+    return (n + 15) // 16 * 16
+
+
 def all_gather_csr(data, indices, indptr, group=None):
     """All-gather row-block shards of a CSR matrix into the whole matrix on every rank — the
     exchange step of row-sharded SpGEMM (B's triplet, 0.8 GB for config 5).
-    The row pointers are exchanged REBASED: once the shard sizes are known (the one size exchange of the values), rank
-    r's pointers are shifted by the stored elements of the ranks before it, so the gathered pointers are the whole
-    matrix's without a scan over the rows."""
+    ONE size exchange ((stored elements, rows) per rank) and ONE collective: every rank packs its values, column indices
+    and row-pointer heads (relative to its own first pointer, so a shard may be a row-slice view of a larger CSR) into one
+    byte buffer, 16-byte aligned sections, padded to the largest rank's; the receiver slices the three sections per rank and
+    shifts rank r's heads by the stored elements of the ranks before it - the gathered pointers are the whole matrix's
+    without a scan over the rows."""
     import torch.distributed as dist
 
-    d, sizes = all_gather_ragged(data, group)
-    i, _ = all_gather_ragged(indices, group, sizes=sizes)
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
-    total = sum(sizes)
-    wide = indptr.dtype == torch.int64 or total >= 2 ** 31
-    mine = _offset_i64(indptr[:-1].to(torch.int64), sum(sizes[:rank]))
-    heads, _ = all_gather_ragged(mine, group)
-    ip = torch.empty(heads.numel() + 1, dtype=torch.int64, device=data.device)
-    ip[:-1] = heads
+    world = dist.get_world_size(group)
+    dev = data.device
+    nnz, rows = int(data.numel()), int(indptr.numel()) - 1
+    if int(indices.numel()) != nnz:
+        raise ValueError("data and indices differ in length")
+    got = torch.empty(2 * world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(got, torch.tensor([nnz, rows], dtype=torch.int64, device=dev), group=group)
+    got = got.tolist()
+    nnzs, nrows = [int(v) for v in got[0::2]], [int(v) for v in got[1::2]]
+    total = sum(nnzs)
+    heads = indptr[:-1].to(torch.int64) - indptr[:1].to(torch.int64)        # rebased to the shard's own first element
+    ds, isz = data.element_size(), indices.element_size()
+    sect = lambda n, r: (_pad16(n * ds), _pad16(n * isz), _pad16(r * 8))
+    width = max(max(sum(sect(n, r)) for n, r in zip(nnzs, nrows)), 16)
+    mine = torch.zeros(width, dtype=torch.uint8, device=dev)
+    o_d, o_i, o_h = sect(nnz, rows)
+    mine[:nnz * ds] = data.contiguous().view(torch.uint8).reshape(-1)
+    mine[o_d:o_d + nnz * isz] = indices.contiguous().view(torch.uint8).reshape(-1)
+    mine[o_d + o_i:o_d + o_i + rows * 8] = heads.contiguous().view(torch.uint8).reshape(-1)
+    if world == 1:
+        packed = mine.reshape(1, width)
+    else:
+        packed = torch.empty((world, width), dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(packed.view(-1), mine, group=group)
+    d = torch.empty(total, dtype=data.dtype, device=dev)
+    i = torch.empty(total, dtype=indices.dtype, device=dev)
+    ip = torch.empty(sum(nrows) + 1, dtype=torch.int64, device=dev)
+    e0 = r0 = 0
+    for r in range(world):
+        n, m = nnzs[r], nrows[r]
+        s_d, s_i, _ = sect(n, m)
+        row = packed[r]
+        d[e0:e0 + n] = row[:n * ds].view(data.dtype)
+        i[e0:e0 + n] = row[s_d:s_d + n * isz].view(indices.dtype)
+        ip[r0:r0 + m] = _offset_i64(row[s_d + s_i:s_d + s_i + m * 8].view(torch.int64), e0)
+        e0, r0 = e0 + n, r0 + m
     ip[-1] = total
-    return d, i, ip if wide or indptr.dtype == torch.int64 else ip.to(indptr.dtype)
+    wide = indptr.dtype == torch.int64 or total >= 2 ** 31
+    return d, i, ip if wide else ip.to(indptr.dtype)
 
 
 def sharded_spgemm(a_local, b_shard, group=None):

@@ -104,20 +104,30 @@ class NanProbe:
         self.event = NanProbe._events.pop() if NanProbe._events else torch.cuda.Event()
         self.view[self.at] = 0
         self.done = None
+        self.launched = False
+        self._keep = data  # the scanned buffer must outlive the kernel
         try:
             _ffi.call("spamd_has_nan_async", code_of(data.dtype), data.numel(), ptr(data), addr, stream_ptr(dev))
+            self.launched = True
             # behind the scan on ITS stream: the array may live on another device than the current one (`to_device`)
             self.event.record(torch.cuda.current_stream(dev))
+            self.recorded = True
         except BaseException:
             self.discard()
             raise
-        self._keep = data  # the scanned buffer must outlive the kernel
 
     def discard(self):
         """Give the verdict slot and the event back without reading the verdict (the launch failed, or the product
         this scan belonged to raised before asking)."""
         if self.done is None:
             self.done = False
+            if self.launched:
+                # the scan may still be running and will write its verdict word: the slot (and the scanned buffer) go back
+                # only once it has finished - behind the event when that was recorded, else behind the whole device
+                if getattr(self, "recorded", False):
+                    self.event.synchronize()
+                else:
+                    torch.cuda.synchronize()
             if self.slot is not None:
                 NanProbe._free.append(self.slot)
             if self.event is not None:

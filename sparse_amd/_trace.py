@@ -134,6 +134,13 @@ def build(func, args_spec):
 
 
 def _scalar_tensor(value, np_dtype, devi):
+    # A Python / NumPy integer that the compute dtype cannot hold must not wrap around on its way to the device (NumPy 2
+    # compares `int32_array < 2**40` exactly; int32(2**40) is 0): such a graph goes back to the host path.
+    dt = np.dtype(np_dtype)
+    if dt.kind in "iu" and isinstance(value, (int, np.integer)) and not isinstance(value, (bool, np.bool_)):
+        info = np.iinfo(dt)
+        if not (info.min <= int(value) <= info.max):
+            raise Untraceable(f"integer scalar {value} does not fit {dt}")
     with np.errstate(all="ignore"):
         v = np.asarray(value).astype(np_dtype)
     t = torch.from_numpy(v.reshape(1).copy())

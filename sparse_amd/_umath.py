@@ -9,6 +9,8 @@ reference's fill-value rules (result fill = func(fills); stored results bit-equa
 pruned; non-zero operand fills are honoured).  Anything else raises NotImplementedError —
 there is deliberately no host fallback.
 """
+import threading
+
 import numpy as np
 import torch
 
@@ -138,14 +140,33 @@ class _MergeWorkspace:
 
     _pool = {}
     SENTINEL = -1
+    SLOTS = 64      # pinned result words used round-robin: the late store of a call that was abandoned (an interrupt in
+    #                 the spin, a fault) lands in ITS slot, not in the word the next call is waiting on
 
     def __init__(self, devi):
         self.cap = 0
         self.ws = None
         self.total_dev = torch.zeros(1, dtype=torch.int64, device=devi)
-        self.pinned = torch.full((1,), self.SENTINEL, dtype=torch.int64).pin_memory()
+        self.pinned = torch.full((self.SLOTS,), self.SENTINEL, dtype=torch.int64).pin_memory()
         self.view = self.pinned.numpy()
         self.devi = devi
+        self.seq = 0
+        self.lock = threading.Lock()    # two host threads on one stream share the workspace: one merge at a time
+
+    def next_slot(self):
+        self.seq += 1
+        k = self.seq % self.SLOTS
+        self.view[k] = self.SENTINEL
+        return k
+
+    def recover(self):
+        """After a failed or abandoned call: wait for whatever is in flight and restore the all-zero workspace the next
+        call relies on (the kernel cleans up after itself only when it runs to completion)."""
+        try:
+            torch.cuda.current_stream(self.devi).synchronize()
+        finally:
+            if self.ws is not None:
+                self.ws.zero_()
 
     @classmethod
     def get(cls, devi, stream, nblocks):
@@ -158,15 +179,15 @@ class _MergeWorkspace:
             w.ws = torch.zeros(3 + w.cap, dtype=torch.int64, device=devi)
         return w
 
-    def wait_total(self):
-        """Spin on the pinned word (bounded: ~50 ms), then fall back to the device word behind a synchronisation."""
+    def wait_total(self, k):
+        """Spin on pinned word `k` (bounded: ~50 ms), then fall back to the device word behind a synchronisation."""
         view = self.view
         for _ in range(2_000_000):
-            t = int(view[0])
+            t = int(view[k])
             if t != self.SENTINEL:
                 return t
         torch.cuda.current_stream(self.devi).synchronize()
-        t = int(view[0])
+        t = int(view[k])
         return t if t != self.SENTINEL else int(self.total_dev[0])
 
 
@@ -191,10 +212,15 @@ def merge_union(name, ka, va, kb, vb, fill_a, fill_b, fill_out):
         w = _MergeWorkspace.get(devi, s, int(_ffi.lib().spamd_merge_fused_blocks(na, nb)))
         keys = torch.empty(na + nb, dtype=torch.int64, device=devi)
         vals = torch.empty(na + nb, dtype=out_t, device=devi)
-        w.view[0] = w.SENTINEL
-        _ffi.call("spamd_merge_union_fused", code, _CODE[va.dtype], na, ptr(ka), ptr(va), nb, ptr(kb), ptr(vb), fa, fb, fo,
-                  ptr(w.ws), ptr(w.total_dev), w.pinned.data_ptr(), ptr(keys), ptr(vals), s)
-        total = w.wait_total()
+        with w.lock:
+            k = w.next_slot()
+            try:
+                _ffi.call("spamd_merge_union_fused", code, _CODE[va.dtype], na, ptr(ka), ptr(va), nb, ptr(kb), ptr(vb), fa, fb,
+                          fo, ptr(w.ws), ptr(w.total_dev), w.pinned.data_ptr() + 8 * k, ptr(keys), ptr(vals), s)
+                total = w.wait_total(k)
+            except BaseException:      # KeyboardInterrupt in the spin included: leave the workspace as the next call needs it
+                w.recover()
+                raise
         if total * 2 < na + nb:   # a sparse result should not pin the worst-case buffers
             keys, vals = keys[:total].clone(), vals[:total].clone()
         else:
@@ -359,8 +385,8 @@ def _on_device(func, ops, slots, keys, n, full_shape, out_dtype, devi):
             arrays.append(None)
     try:
         res = _trace.run(root, arrays, n, devi)
-    except _trace.Untraceable:
-        return None
+    except (_trace.Untraceable, _ffi.HipBackendError, KeyError, TypeError, NotImplementedError):
+        return None     # (an operation / dtype pair the kernels decline is as untraceable as a data-dependent branch)
     if res.dtype != torch_dtype(out_dtype):
         res = K.convert(res, torch_dtype(out_dtype))
     return res

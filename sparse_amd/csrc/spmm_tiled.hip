@@ -753,6 +753,7 @@ extern "C" int spamd_spmm_tiled(int val_dtype, int64_t M, int64_t K, int64_t N, 
   // N - panel + that many columns per row only.  Even for float32 (a lane stores two columns).
   const int last_cols = (int)((flags >> 16) & 0xffu);
   if (last_cols > panel || (val_dtype == SPAMD_F32 && (last_cols & 1))) return SPAMD_EINVAL;
+  if (ldo < N - panel + (last_cols ? last_cols : panel)) return SPAMD_EINVAL;   // a row of `out` holds every stored column
   // lines of a list that are pulled into L2 two phases ahead (flags bits 8..15; 0 = default): the launcher derives
   // it from the mean list length, longer lists pay the HBM latency on their remaining blocks
   int touch = (int)((flags >> 8) & 0xffu);

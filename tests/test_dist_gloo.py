@@ -204,12 +204,22 @@ def _worker_calls_dist(rank, world, port, ret):
         return real_start(*a, **k)
 
     _dist._start_gather_rows = counting_start
-    for _ in range(3):
+    for _ in range(2):                               # default: B is gathered at every product (the memo is opt-in)
         assert np.array_equal(_dist.sharded_spmm(a_local, b_shard, K), whole[r0:r1])
-    assert gathers["n"] == 1 and calls["matmul"] == 3 and calls["prepare"] == 3, (gathers, calls)
+    assert gathers["n"] == 2 and calls["matmul"] == 2 and calls["prepare"] == 2, (gathers, calls)
+    for _ in range(3):                               # opt-in memo: a static B crosses once
+        assert np.array_equal(_dist.sharded_spmm(a_local, b_shard, K, memo=True), whole[r0:r1])
+    assert gathers["n"] == 3 and calls["matmul"] == 5 and calls["prepare"] == 5, (gathers, calls)
     b_shard *= 2.0                                   # in-place update on every rank: the version counter changes
-    assert np.array_equal(_dist.sharded_spmm(a_local, b_shard, K), oracle.dot_csr_ndarray((M, N), data, idx, ptr, 2.0 * b)[r0:r1])
-    assert gathers["n"] == 2
+    doubled = oracle.dot_csr_ndarray((M, N), data, idx, ptr, 2.0 * b)[r0:r1]
+    assert np.array_equal(_dist.sharded_spmm(a_local, b_shard, K, memo=True), doubled)
+    assert gathers["n"] == 4
+    b_shard.numpy()[...] *= 0.5                      # a write torch's version counter does not see ...
+    assert np.array_equal(_dist.sharded_spmm(a_local, b_shard, K, memo=True), doubled)     # ... is served stale by the memo
+    _dist.invalidate_gather_memo()                   # the documented remedy
+    assert np.array_equal(_dist.sharded_spmm(a_local, b_shard, K, memo=True), whole[r0:r1])
+    assert gathers["n"] == 5
+    _dist.invalidate_gather_memo()
     _dist._start_gather_rows = real_start
 
     # ---- sharded_spgemm: B's CSR triplet gathered (rebased pointers), local product by the oracle's Gustavson loop
@@ -221,6 +231,9 @@ def _worker_calls_dist(rank, world, port, ret):
     got = _dist.sharded_spgemm(_Block((sd, si, sp_), (s1 - s0, n2)), _Block((sd, si, sp_), (s1 - s0, n2)))
     want = oracle.dot_csr_csr((s1 - s0, n2), sd.numpy(), bd, si.numpy(), bi, sp_.numpy(), bp)
     assert all(np.array_equal(x, y) for x, y in zip(got, want))
+    # a shard whose pointers are NOT rebased (a row-slice view of the whole matrix's pointer array) gathers to the same matrix
+    gd, gi, gp = _dist.all_gather_csr(sd, si, tbp[s0:s1 + 1])
+    assert np.array_equal(gd.numpy(), bd) and np.array_equal(gi.numpy(), bi) and np.array_equal(gp.numpy(), bp)
 
     # ---- sharded_sddmm: mask rows and A rows co-sharded, Bt gathered
     Ms, Nc, Kd = 211, 157, 24

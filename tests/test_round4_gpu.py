@@ -1,0 +1,185 @@
+"""Round-4 additions: run-to-run determinism of every kernel that uses atomics or look-back ("race
+detection": the reference is single-threaded, so ANY run-to-run difference here would be a bug of this backend), and the
+hygiene fixes of the round (leading-dimension check of the tiled executor, integer scalars that do not fit the traced
+compute type, the merge workspace after an abandoned call)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+@pytest.fixture(scope="module")
+def sp():
+    import sparse_amd
+
+    return sparse_amd
+
+
+def _bits(t):
+    t = t.contiguous()
+    return t.view(torch.uint8).cpu().numpy().tobytes()
+
+
+def _same_sparse(x, y):
+    if type(x) is not type(y) or x.shape != y.shape or x.nnz != y.nnz:
+        return False
+    if hasattr(x, "indptr"):
+        return _bits(x.data) == _bits(y.data) and _bits(x.indices) == _bits(y.indices) and _bits(x.indptr) == _bits(y.indptr)
+    return _bits(x.data) == _bits(y.data) and _bits(x.linear_loc()) == _bits(y.linear_loc())
+
+
+# ---- run twice, compare bit for bit -------------------------------------------------------------------------------------
+
+def test_spgemm_is_bit_identical_run_to_run(sp):
+    """bucket slots are claimed with LDS atomics (csrc/spgemm_rows.hip): the ORDER of the claims varies from run to run,
+    the result must not.  Rows of every size class (short rows, the 24-products-per-thread class, declined rows that go
+    through the global form)."""
+    from sparse_amd import _dot
+
+    n = 40_000
+    g = sp.random((n, n), density=2.5e-3, random_state=5, dtype=np.float32, idx_dtype=np.int32, format="gcxs", compressed_axes=(0,))
+    ref = g @ g
+    for _ in range(3):
+        _dot.drop_derived(g)
+        again = g @ g
+        assert _same_sparse(ref, again)
+    # sparse x sparse with a skewed operand (one very long row: the global form merges in)
+    h = sp.random((3000, 3000), density=0.02, random_state=6, dtype=np.float64, format="gcxs", compressed_axes=(0,))
+    r1, r2 = h @ h, h @ h
+    assert _same_sparse(r1, r2)
+
+
+def test_fused_merge_is_bit_identical_run_to_run(sp):
+    """tiles chain their output offsets by decoupled look-back and take tickets with a same-address atomic
+    (csrc/merge.hip): the result must not depend on which tile wins."""
+    x = sp.random((1000, 1000, 1000), nnz=700_000, random_state=1)
+    y = sp.random((1000, 1000, 1000), nnz=500_000, random_state=2)
+    for f in (lambda: x + y, lambda: x * y, lambda: sp.maximum(x, y), lambda: x - y):
+        ref = f()
+        for _ in range(4):
+            assert _same_sparse(ref, f())
+    # the two-launch and the count / scan / fill forms give the same bits as the fused one
+    from sparse_amd import _umath
+
+    ref = x + y
+    for fused, single in ((False, True), (False, False)):
+        old = _umath.MERGE_FUSED, _umath.MERGE_SINGLE_PASS
+        _umath.MERGE_FUSED, _umath.MERGE_SINGLE_PASS = fused, single
+        try:
+            assert _same_sparse(ref, x + y)
+        finally:
+            _umath.MERGE_FUSED, _umath.MERGE_SINGLE_PASS = old
+
+
+def test_group_reduce_is_bit_identical_run_to_run(sp):
+    """runs that cross tiles are closed by a fix-up pass (csrc/group_reduce.hip); floating-point sums must come out in
+    one fixed association whatever the scheduling"""
+    x = sp.random((300, 400, 500), nnz=2_000_000, random_state=3)
+    for ax in (2, 0, (0, 1), (1, 2), None):
+        ref = x.sum(axis=ax)
+        for _ in range(3):
+            got = x.sum(axis=ax)
+            assert _same_sparse(ref, got) if hasattr(ref, "nnz") else _bits(torch.as_tensor(np.asarray(ref))) == _bits(torch.as_tensor(np.asarray(got)))
+    long_runs = sp.random((4, 3_000_000), nnz=4_000_000, random_state=4)      # runs longer than 64 K elements
+    ref = long_runs.sum(axis=1)
+    for _ in range(3):
+        assert _same_sparse(ref, long_runs.sum(axis=1))
+
+
+def test_sddmm_panel_order_is_bit_identical_run_to_run(sp):
+    """scattered non-temporal stores of the panel-ordered SDDMM (csrc/sddmm_panel.hip): every result slot has ONE writer"""
+    from sparse_amd import _kernels as K
+
+    M = 30_000
+    s = sp.random((M, M), nnz=3_000_000, random_state=8, dtype=np.float32, idx_dtype=np.int32)
+    dev = s.data.device
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    a = torch.rand((M, 256), generator=gen).to(dev).to(torch.bfloat16)
+    bt = torch.rand((M, 256), generator=gen).to(dev).to(torch.bfloat16)
+    panels = K.sddmm_panels(s.coords, (M, M), K.sddmm_panel_width(bt))
+    runs = [K.sddmm_coo(s.coords, s.data, a, bt, panels=panels) for _ in range(4)]
+    assert all(_bits(runs[0]) == _bits(r) for r in runs[1:])
+    plain = K.sddmm_coo(s.coords, s.data, a, bt)
+    assert _bits(plain) == _bits(runs[0])
+
+
+def test_tiled_executor_is_bit_identical_run_to_run(sp):
+    from sparse_amd import _kernels as K
+
+    M, Kd, N = 140_000, 4000, 128
+    g = sp.random((M, Kd), density=0.01, random_state=9, dtype=np.float32, idx_dtype=np.int32, format="gcxs", compressed_axes=(0,))
+    b = torch.rand((Kd, N), device=g.data.device, dtype=torch.float32)
+    lay = K.csr_tiled_layout(g.data, g.indices, g.indptr, M, Kd)
+    ref = K.dot_csr_ndarray_tiled(lay, (M, N), Kd, b)
+    for _ in range(3):
+        lay2 = K.csr_tiled_layout(g.data, g.indices, g.indptr, M, Kd)
+        assert _bits(ref) == _bits(K.dot_csr_ndarray_tiled(lay2, (M, N), Kd, b))
+
+
+# ---- hygiene ------------------------------------------------------------------------------------------------------------
+
+def test_tiled_executor_rejects_a_leading_dimension_below_the_stored_width(sp):
+    """`spamd_spmm_tiled` stores N - panel + last_cols columns per row: an `ldo` below that would overlap rows (round-3
+    advice)."""
+    from sparse_amd import _ffi, _kernels as K
+    from sparse_amd._device import ptr, stream_ptr
+
+    M, Kd = 70_000, 2000
+    g = sp.random((M, Kd), density=0.01, random_state=10, dtype=np.float32, idx_dtype=np.int32, format="gcxs", compressed_axes=(0,))
+    b = torch.rand((Kd, 128), device=g.data.device, dtype=torch.float32)
+    lay = K.csr_tiled_layout(g.data, g.indices, g.indptr, M, Kd)
+    out = torch.empty((M, 128), device=b.device, dtype=torch.float32)
+    lib = _ffi.lib()
+    blocks, blk_off, _ = lay
+    flags_full = _ffi.TILED_GROUP_ENDS if lay.group_ends else 0
+    EINVAL = -1     # SPAMD_EINVAL (include/sparse_amd.h)
+    args = lambda ldo, flags: (_ffi.F32, C.c_int64(M), C.c_int64(Kd), C.c_int64(128), C.c_void_p(ptr(blocks)), C.c_void_p(ptr(blk_off)),
+                               C.c_void_p(ptr(b)), C.c_int64(128), C.c_void_p(ptr(out)), C.c_int64(ldo), C.c_uint(flags),
+                               C.c_void_p(stream_ptr(b.device)))
+    assert lib.spamd_spmm_tiled(*args(126, flags_full)) == EINVAL
+    assert lib.spamd_spmm_tiled(*args(30, flags_full | (32 << 16))) == EINVAL        # 32 stored columns need ldo >= 32
+    assert lib.spamd_spmm_tiled(*args(32, flags_full | (32 << 16))) == 0
+    torch.cuda.synchronize()
+    if lay.pending is not None:
+        assert int(lay.pending[0]) == 0
+
+
+def test_integer_scalar_beyond_the_compute_type_is_not_wrapped(sp):
+    """`elemwise(lambda v: v < 2**40, int32 array)`: NumPy compares exactly; a device replay with int32(2**40) == 0 would
+    not (round-3 advice) - such a graph goes to the host path and the result matches NumPy."""
+    d = np.where(np.random.default_rng(0).random((50, 60)) < 0.3, np.random.default_rng(1).integers(-9, 9, (50, 60)), 0).astype(np.int32)
+    x = sp.COO.from_numpy(d)
+    got = sp.elemwise(lambda v: v < 2 ** 40, x)
+    assert np.array_equal(np.asarray(got.todense()), d < 2 ** 40)
+    got = sp.elemwise(lambda v: v + 3, x)          # in range: still traced on the device
+    assert np.array_equal(np.asarray(got.todense()), d + 3)
+
+
+def test_merge_workspace_survives_an_abandoned_call(sp):
+    """an exception between launch and wait must leave the look-back workspace zeroed for the next merge"""
+    from sparse_amd import _umath
+
+    x = sp.random((1000, 1000, 1000), nnz=300_000, random_state=11)
+    y = sp.random((1000, 1000, 1000), nnz=300_000, random_state=12)
+    ref = x + y
+    real = _umath._MergeWorkspace.wait_total
+
+    def boom(self, k):
+        raise KeyboardInterrupt
+
+    _umath._MergeWorkspace.wait_total = boom
+    try:
+        with pytest.raises(KeyboardInterrupt):
+            x + y
+    finally:
+        _umath._MergeWorkspace.wait_total = real
+    for _ in range(3):
+        assert _same_sparse(ref, x + y)
