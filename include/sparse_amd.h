@@ -395,6 +395,23 @@ int spamd_spgemm_pack(int val_dtype, int64_t n_row, const int64_t* prod_off, con
                       const int* tmp_cols, const void* tmp_vals, int64_t* out_indices, void* out_data,
                       int64_t* zero_count, void* stream);
 
+/* A4 / A5, row-local form for wide rows of a matrix with at most 2^20 columns (csrc/spgemm_bitmap.hip; replaces the same
+ * reference functions, sparse/numba_backend/_common.py:543-570,639-717).  A persistent workgroup per CU keeps a bitmap
+ * of the output row's columns in LDS: a column's position in the sorted row is a popcount, the row's length is known
+ * before anything is written, rows take tickets and find their offset by a look-back over one state word per row, and
+ * every row is written ONCE, in place - no scratch rows, no pack, no scan of row lengths.  Values are summed in the order
+ * of A's elements (bit-identical to the other two forms).
+ *   spamd_spgemm_bitmap_limits(val_dtype, which): 0 = products per row, 1 = A elements per row, 2 = columns,
+ *     3 = products per row that may share an output element with an earlier product (checked inside the kernel);
+ *   spamd_spgemm_bitmap: out_indptr[n_row + 1]; out_indices (int64) / out_data with room for EVERY product (the caller
+ *     trims to out_indptr[n_row]); work = n_row + 8 int64 words, zeroed here: afterwards work[1] != 0 = a row was outside
+ *     the limits (discard the result, use spamd_spgemm_rows), work[2] = values written whose bits are all zero. */
+int64_t spamd_spgemm_bitmap_limits(int val_dtype, int which);
+int spamd_spgemm_bitmap(int val_dtype, int idx_dtype, int64_t n_row, int64_t n_col, const void* a_indptr,
+                        const void* a_indices, const void* a_data, const void* b_indptr, const void* b_indices,
+                        const void* b_data, int64_t* work, int64_t* out_indptr, int64_t* out_indices, void* out_data,
+                        void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * A9  SDDMM      out[n] = s[n] * sum_k A[rows[n], k] * Bt[cols[n], k]
  *   replaces the reference's formulation `s * (a @ b)` (examples/sddmm_example.py:51-52: a dense

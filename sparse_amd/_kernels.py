@@ -669,6 +669,31 @@ SPGEMM_ROW_LOCAL = True  # tuning hook: False = always the global expand-sort-co
 
 
 SPGEMM_STATS = {}   # last row-local product: rows, rows left to the global form (diagnostics for the benches)
+SPGEMM_BITMAP = True            # wide rows of a matrix with <= 2^20 columns: csrc/spgemm_bitmap.hip (rows written in place)
+SPGEMM_BITMAP_MIN_MEAN = 1024   # mean products per row from which the per-row bitmap scan (n_col / 8 bytes of LDS) pays
+SPGEMM_BITMAP_MAX_DUPS = 120    # expected products per row that share an output element with an earlier one (list of 512)
+
+
+def _spgemm_bitmap(vcode, it, n_row, n_col, total, a_indptr, a_indices, a_data, b_indptr, b_indices, b_data, dtr, dev, s):
+    """C = A @ B by csrc/spgemm_bitmap.hip: (data, int64 indices, int64 indptr), or None when a row exceeded the kernel's
+    parked-product list (the caller then takes the bucket kernels).  The result buffers are allocated for every product
+    (an upper bound of the result's length) and trimmed: a view when at least 3/4 of them are used."""
+    out_idx = torch.empty(max(total, 1), dtype=torch.int64, device=dev)
+    out_val = torch.empty(max(total, 1), dtype=dtr, device=dev)
+    out_ptr = torch.empty(n_row + 1, dtype=torch.int64, device=dev)
+    work = torch.empty(n_row + 8, dtype=torch.int64, device=dev)
+    _ffi.call("spamd_spgemm_bitmap", vcode, code_of(it), n_row, n_col, ptr(a_indptr), ptr(a_indices), ptr(a_data),
+              ptr(b_indptr), ptr(b_indices), ptr(b_data), ptr(work), ptr(out_ptr), ptr(out_idx), ptr(out_val), s)
+    failed, zeros, nnz = (int(v) for v in torch.cat([work[1:3], out_ptr[-1:]]).tolist())   # ONE read-back
+    if failed:
+        return None
+    if nnz * 4 < total * 3:
+        out_idx, out_val = out_idx[:nnz].clone(), out_val[:nnz].clone()
+    else:
+        out_idx, out_val = out_idx[:nnz], out_val[:nnz]
+    note_zero_bits_count(out_val, zeros)
+    SPGEMM_STATS["rows"], SPGEMM_STATS["heavy_or_declined"], SPGEMM_STATS["kernel"] = n_row, 0, "bitmap"
+    return out_val, out_idx, out_ptr
 
 
 def _spgemm_rows(n_row, n_col, a_data, a_indices, a_indptr, b_data, b_indices, b_indptr):
@@ -693,6 +718,14 @@ def _spgemm_rows(n_row, n_col, a_data, a_indices, a_indptr, b_data, b_indices, b
     max_prod, max_arow = (int(v) for v in maxes.tolist())
     cap = int(_ffi.lib().spamd_spgemm_rows_capacity(vcode, n_col, max_arow))
     total = int(prod_off[-1])
+    lim = _ffi.lib().spamd_spgemm_bitmap_limits
+    if (SPGEMM_BITMAP and total and max_prod <= lim(vcode, 0) and max_arow <= lim(vcode, 1) and n_col <= lim(vcode, 2)
+            and total >= SPGEMM_BITMAP_MIN_MEAN * n_row and max_prod * max_prod <= 2 * n_col * SPGEMM_BITMAP_MAX_DUPS):
+        res = _spgemm_bitmap(vcode, it, n_row, n_col, total, a_indptr, a_indices, a_data, b_indptr, b_indices, b_data, dtr,
+                             dev, s)
+        if res is not None:
+            return res
+    SPGEMM_STATS["kernel"] = "buckets"
 
     def classify(nnz_row):
         """(flags[n_row + 1], rows, their products, rows heavy only by their A length) - csrc/spgemm_rows.hip"""

@@ -1,0 +1,183 @@
+"""csrc/spgemm_bitmap.hip (round 4: bitmap-ordered rows, written in place through a look-back over the rows) against the
+bucket kernels of csrc/spgemm_rows.hip and the global expand-sort-compress - bit for bit: row pointers, column indices and
+values (the products of an output element are added in the order of A's elements, the reference's `sums[j] += ...`,
+_common.py:690-705) - and against the oracle's restatement of `_dot_csr_csr` on small cases."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _csr(m, n, per_row, seed, dtype=np.float32, idt=np.int32, empty_every=0, hot_col=None):
+    """random CSR, ~per_row (Poisson-like spread) sorted distinct columns per row"""
+    rng = np.random.default_rng(seed)
+    width = int(per_row * 1.3) + 4
+    cols = np.sort(rng.integers(0, n, size=(m, width)), axis=1)
+    keep = np.ones((m, width), dtype=bool)
+    keep[:, 1:] = cols[:, 1:] != cols[:, :-1]
+    keep &= rng.random((m, width)) < per_row / width
+    if hot_col is not None:     # a column present in EVERY row: many products of one output element
+        keep &= cols != hot_col
+        cols[:, 0], keep[:, 0] = hot_col, True
+        o = np.argsort(cols, axis=1, kind="stable")
+        cols, keep = np.take_along_axis(cols, o, 1), np.take_along_axis(keep, o, 1)
+    if empty_every:
+        keep[::empty_every] = False
+    counts = keep.sum(axis=1)
+    indptr = np.zeros(m + 1, dtype=np.int64)
+    np.cumsum(counts, out=indptr[1:])
+    indices = cols[keep]
+    vals = rng.random(indices.size) - 0.3
+    if np.dtype(dtype).kind == "f":
+        data = vals.astype(dtype)
+    else:
+        data = (vals * 40).astype(dtype)
+        data[data == 0] = 1
+    return data, indices.astype(idt), indptr.astype(idt)
+
+
+def _dev(t):
+    return tuple(torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0") for a in t)
+
+
+def _both(shape, A, B):
+    """(bitmap result or None, bucket-kernel result) for A (m x k) @ B (k x n), host triplets"""
+    from sparse_amd import _kernels as K
+
+    (ad, ai, ap), (bd, bi, bp) = _dev(A), _dev(B)
+    old = K.SPGEMM_BITMAP, K.SPGEMM_BITMAP_MIN_MEAN, K.SPGEMM_BITMAP_MAX_DUPS
+    try:
+        K.SPGEMM_BITMAP = False
+        want = K._spgemm_rows(shape[0], shape[1], ad, ai, ap, bd, bi, bp)
+        if want is None:
+            want = K.dot_csr_csr(shape, ad, bd, ai, bi, ap, bp)
+        K.SPGEMM_BITMAP, K.SPGEMM_BITMAP_MIN_MEAN, K.SPGEMM_BITMAP_MAX_DUPS = True, 0, 10 ** 9
+        K.SPGEMM_STATS.clear()
+        got = K._spgemm_rows(shape[0], shape[1], ad, ai, ap, bd, bi, bp)
+        used = K.SPGEMM_STATS.get("kernel")
+    finally:
+        K.SPGEMM_BITMAP, K.SPGEMM_BITMAP_MIN_MEAN, K.SPGEMM_BITMAP_MAX_DUPS = old
+    return got, want, used
+
+
+def _same(got, want):
+    for g, w in zip(got, want):
+        g, w = g.cpu().numpy(), w.cpu().numpy()
+        assert g.shape == w.shape and g.dtype == w.dtype, (g.shape, w.shape, g.dtype, w.dtype)
+        assert np.array_equal(g.view(np.uint8), w.view(np.uint8))
+
+
+@pytest.mark.parametrize("dtype,idt", [(np.float32, np.int32), (np.float32, np.int64), (np.float64, np.int64),
+                                       (np.int32, np.int32), (np.int64, np.int64)])
+def test_bitmap_rows_equal_the_bucket_kernels(dtype, idt):
+    """config 5 in small: ~100 x ~100 products per row, 10^6 columns; more rows than CUs, some of them empty"""
+    m, k, n = 1500, 40_000, 1_000_000
+    A = _csr(m, k, 100, 1, dtype, idt, empty_every=97)
+    B = _csr(k, n, 100, 2, dtype, idt, empty_every=13)
+    got, want, used = _both((m, n), A, B)
+    assert used == "bitmap"
+    _same(got, want)
+    assert int(got[2][-1]) == got[0].numel() == got[1].numel()
+
+
+def test_bitmap_rows_with_many_products_per_output_element():
+    """a column of B that every row holds: ~100 products of ONE output element per row, added in the order of A's elements
+    (the parked-product list at work), plus the usual handful of pairs"""
+    m, k, n = 700, 5_000, 300_000
+    A = _csr(m, k, 100, 3, np.float32, np.int32)
+    B = _csr(k, n, 90, 4, np.float32, np.int32, hot_col=12345)
+    got, want, used = _both((m, n), A, B)
+    assert used == "bitmap"
+    _same(got, want)
+    B64 = _csr(k, n, 60, 5, np.float64, np.int64, hot_col=299_999)
+    A64 = _csr(m, k, 100, 6, np.float64, np.int64)
+    got, want, used = _both((m, n), A64, B64)
+    assert used == "bitmap"
+    _same(got, want)
+
+
+def test_bitmap_kernel_declines_what_its_list_cannot_hold_and_the_caller_falls_back():
+    """few columns: thousands of products share output elements - the kernel sets its `failed` word, the host takes the
+    bucket kernels, the result is the same"""
+    m, k, n = 300, 4_000, 20_000
+    A = _csr(m, k, 100, 7)
+    B = _csr(k, n, 100, 8)
+    got, want, used = _both((m, n), A, B)
+    assert used == "buckets"
+    _same(got, want)
+
+
+@pytest.mark.parametrize("m", [1, 2, 255, 257, 600])
+def test_bitmap_rows_few_and_odd_row_counts(m):
+    k, n = 3_000, 1_048_576
+    A = _csr(m, k, 120, 10 + m)
+    B = _csr(k, n, 110, 11)
+    got, want, used = _both((m, n), A, B)
+    assert used == "bitmap"
+    _same(got, want)
+
+
+def test_bitmap_rows_at_the_limits():
+    """A rows of exactly 256 elements, rows near 16384 products, n_col = 2^20, and a matrix one step beyond each limit
+    (which the host must not hand to the kernel)"""
+    from sparse_amd import _ffi
+
+    lim = _ffi.lib().spamd_spgemm_bitmap_limits
+    assert (lim(_ffi.F32, 0), lim(_ffi.F32, 1), lim(_ffi.F32, 2), lim(_ffi.F32, 3)) == (16384, 256, 1 << 20, 512)
+    assert lim(_ffi.F64, 0) == 12288
+    m, k, n = 300, 2_000, 1 << 20
+    rng = np.random.default_rng(0)
+    cols = np.stack([np.sort(rng.choice(k, 256, replace=False)) for _ in range(m)]).astype(np.int32)
+    A = ((rng.random(m * 256) + 0.1).astype(np.float32), cols.reshape(-1), (np.arange(m + 1) * 256).astype(np.int32))
+    B = _csr(k, n, 60, 12)
+    got, want, used = _both((m, n), A, B)
+    assert used == "bitmap"
+    _same(got, want)
+    cols = np.stack([np.sort(rng.choice(k, 257, replace=False)) for _ in range(m)]).astype(np.int32)
+    A2 = ((rng.random(m * 257) + 0.1).astype(np.float32), cols.reshape(-1), (np.arange(m + 1) * 257).astype(np.int32))
+    got, want, used = _both((m, n), A2, B)
+    assert used == "buckets"
+    _same(got, want)
+
+
+def test_bitmap_rows_against_the_oracle(orc):
+    m, k, n = 64, 500, 70_000
+    A = _csr(m, k, 40, 20, np.float64, np.int64)
+    B = _csr(k, n, 50, 21, np.float64, np.int64, hot_col=7)
+    got, want, used = _both((m, n), A, B)
+    assert used == "bitmap"
+    wd, wi, wp = orc.dot_csr_csr((m, n), A[0], B[0], A[1], B[1], A[2], B[2])
+    gd, gi, gp = (t.cpu().numpy() for t in got)
+    assert np.array_equal(gp, wp)
+    for r in range(m):
+        o = np.argsort(wi[wp[r]:wp[r + 1]], kind="stable")       # the reference emits rows in reverse discovery order
+        assert np.array_equal(gi[gp[r]:gp[r + 1]], wi[wp[r]:wp[r + 1]][o])
+        assert np.array_equal(gd[gp[r]:gp[r + 1]].view(np.uint64), wd[wp[r]:wp[r + 1]][o].view(np.uint64))
+
+
+def test_product_api_takes_the_bitmap_kernel_and_is_reproducible():
+    import sparse_amd as sp
+    from sparse_amd import _kernels as K
+
+    n = 60_000
+    g = sp.random((n, 1_000_000), density=1e-4, random_state=3, dtype=np.float32, idx_dtype=np.int32, format="gcxs",
+                  compressed_axes=(0,))
+    rows = 4000
+    p1 = int(g.indptr[rows])
+    a = sp.GCXS((g.data[:p1].contiguous(), (g.indices[:p1] % n).contiguous(), g.indptr[:rows + 1].contiguous()), shape=(rows, n),
+                compressed_axes=(0,))
+    # (column indices folded into B's row range; duplicates inside a row are possible but rare - rebuild canonically)
+    a = sp.GCXS(a.tocoo(), compressed_axes=(0,))
+    K.SPGEMM_STATS.clear()
+    c1 = a @ g
+    assert K.SPGEMM_STATS.get("kernel") == "bitmap"
+    c2 = a @ g
+    for x, y in ((c1.data, c2.data), (c1.indices, c2.indices), (c1.indptr, c2.indptr)):
+        assert torch.equal(x, y)
