@@ -404,7 +404,7 @@ int spamd_spgemm_pack(int val_dtype, int64_t n_row, const int64_t* prod_off, con
  *   spamd_spgemm_bitmap_limits(val_dtype, which): 0 = products per row, 1 = A elements per row, 2 = columns,
  *     3 = products per row that may share an output element with an earlier product (checked inside the kernel);
  *   spamd_spgemm_bitmap: out_indptr[n_row + 1]; out_indices (int64) / out_data with room for EVERY product (the caller
- *     trims to out_indptr[n_row]); work = n_row + 8 int64 words, zeroed here: afterwards work[1] != 0 = a row was outside
+ *     trims to out_indptr[n_row]); work = n_row + 32 int64 words, zeroed here: afterwards work[1] != 0 = a row was outside
  *     the limits (discard the result, use spamd_spgemm_rows), work[2] = values written whose bits are all zero. */
 int64_t spamd_spgemm_bitmap_limits(int val_dtype, int which);
 int spamd_spgemm_bitmap(int val_dtype, int idx_dtype, int64_t n_row, int64_t n_col, const void* a_indptr,

@@ -6,11 +6,13 @@ entry point of libsparse_amd.so (a few for the composite kernels) on the current
 path (products, sums, sorts, scans, merges) happens in that library; torch is used for allocation, views, dtype
 casts of operands and host<->device copies.
 """
+import os
+
+import numpy as np
 import torch
 
 from . import _ffi
 from ._device import code_of, np_dtype, ptr, require_hip, stream_ptr, torch_dtype
-import numpy as np
 
 
 def dot_dtype(dt1, dt2):
@@ -681,11 +683,14 @@ def _spgemm_bitmap(vcode, it, n_row, n_col, total, a_indptr, a_indices, a_data, 
     out_idx = torch.empty(max(total, 1), dtype=torch.int64, device=dev)
     out_val = torch.empty(max(total, 1), dtype=dtr, device=dev)
     out_ptr = torch.empty(n_row + 1, dtype=torch.int64, device=dev)
-    work = torch.empty(n_row + 8, dtype=torch.int64, device=dev)
+    work = torch.empty(n_row + 32, dtype=torch.int64, device=dev)
     _ffi.call("spamd_spgemm_bitmap", vcode, code_of(it), n_row, n_col, ptr(a_indptr), ptr(a_indices), ptr(a_data),
               ptr(b_indptr), ptr(b_indices), ptr(b_data), ptr(work), ptr(out_ptr), ptr(out_idx), ptr(out_val), s)
     failed, zeros, nnz = (int(v) for v in torch.cat([work[1:3], out_ptr[-1:]]).tolist())   # ONE read-back
+    if os.environ.get("SPAMD_BMK_PROF"):     # (-DBMK_PROF builds of csrc/spgemm_bitmap.hip: cycles per phase, thread 0 of every workgroup)
+        SPGEMM_STATS["phase_cycles"] = work[4:20].tolist()
     if failed:
+        SPGEMM_STATS["bitmap_failed"] = True
         return None
     if nnz * 4 < total * 3:
         out_idx, out_val = out_idx[:nnz].clone(), out_val[:nnz].clone()
@@ -719,6 +724,7 @@ def _spgemm_rows(n_row, n_col, a_data, a_indices, a_indptr, b_data, b_indices, b
     cap = int(_ffi.lib().spamd_spgemm_rows_capacity(vcode, n_col, max_arow))
     total = int(prod_off[-1])
     lim = _ffi.lib().spamd_spgemm_bitmap_limits
+    SPGEMM_STATS.update(max_prod=max_prod, max_arow=max_arow, products=total)
     if (SPGEMM_BITMAP and total and max_prod <= lim(vcode, 0) and max_arow <= lim(vcode, 1) and n_col <= lim(vcode, 2)
             and total >= SPGEMM_BITMAP_MIN_MEAN * n_row and max_prod * max_prod <= 2 * n_col * SPGEMM_BITMAP_MAX_DUPS):
         res = _spgemm_bitmap(vcode, it, n_row, n_col, total, a_indptr, a_indices, a_data, b_indptr, b_indices, b_data, dtr,

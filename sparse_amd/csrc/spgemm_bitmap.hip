@@ -11,10 +11,10 @@
 //     nothing is sorted and nothing is ranked against anything else;
 //   * the first product to set a bit stores (column, value) at its final position.  Products that find their bit already
 //     set (two products of one output element: ~50 of 10^4 at config 5) are parked in a small LDS list together with the
-//     first arriver of their column (which recognises itself through a 2048-bit filter); the entry with the smallest
+//     first arriver of their column (which recognises itself through a 16384-bit filter); the entry with the smallest
 //     A-element index of each column then adds the column's products left to right in A's order - the reference's
 //     `sums[j] += ...` order (`_common.py:690-705`), bit-identical to spgemm_rows.hip and to the global form;
-//   * the row length is known right after the popcount scan, BEFORE anything is emitted: rows take tickets in order, a
+//   * the row length is known right after the popcount scan, BEFORE anything is emitted: rows are dealt round-robin to the workgroups, a
 //     decoupled look-back over one state word per row (common.h) gives the row's offset in the result, and the row is
 //     written once, in place.  No scratch rows, no pack kernel, no scan over the row lengths; the exact zeros written are
 //     counted on the way (the result container's prune then has nothing to read);
@@ -35,8 +35,15 @@ constexpr int BMK_STAGE = 256;                              // A elements a row 
 constexpr int BMK_MAX_GROUPS = 4096;                        // groups of 256 columns (8 bitmap words)
 constexpr int BMK_GPT = BMK_MAX_GROUPS / BMK_THREADS;       // groups per thread = 16-bit fields of the packed scan
 constexpr int BMK_DUP = 512;                                // parked products per row
-constexpr int BMK_FILT_WORDS = 64;                          // 2048-bit filter of the columns with parked products
+constexpr int BMK_FILT_WORDS = 512;                         // 16384-bit filter of the columns with parked products
+constexpr unsigned BMK_FILT_MASK = BMK_FILT_WORDS * 32 - 1;
 constexpr unsigned BMK_NONE = 0xffffffffu;
+constexpr int BMK_HEADER = 32;                              // words of `work` before the per-row state words
+#ifdef BMK_PROF
+#define BMK_T(k) { if (tid == 0) { const unsigned long long now = __builtin_readcyclecounter(); prof[k] += now - tprev; tprev = now; } }
+#else
+#define BMK_T(k)
+#endif
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -57,19 +64,31 @@ struct BmkStage {   // one A row: prefix[e] = products of the elements before e,
 struct BmkMisc {
   unsigned long long wa[20];
   unsigned wb[20];
-  int ndup;
-  int pad;
+  int ndup[2];    // parked products of the current row ([row parity]: the other one is cleared for the next row meanwhile)
   int64_t row_off;
-  int64_t ticket[2];
 };
 
 template <typename V>
+struct BmkItems {   // products per thread: a row's (column, value) pairs must fit the front region of LDS (see BmkLayout)
+  static constexpr int value = sizeof(V) == 4 ? 16 : 8;
+};
+
+// LDS: [front region][parked list][filter][two A-row stages][misc].  The front region is the bitmap + the group
+// positions while a row's columns are ranked, and the row itself - (column, value) in output order - from then on: it is
+// copied out with coalesced stores (scattered 4- and 8-byte stores straight to HBM were measured at 107 ms per product
+// at config 5: every one becomes a partial-line write that the L2 cannot combine before it evicts the line).
+template <typename V>
 struct BmkLayout {
+  static constexpr size_t row_bytes = (size_t)BMK_THREADS * BmkItems<V>::value * (4 + sizeof(V));
   __host__ __device__ static size_t bitmap_bytes(int ngroups) { return (size_t)ngroups * 32; }
   __host__ __device__ static size_t pref_bytes(int ngroups) { return ((size_t)ngroups * 2 + 15) / 16 * 16; }
+  __host__ __device__ static size_t front_bytes(int ngroups) {
+    const size_t a = bitmap_bytes(ngroups) + pref_bytes(ngroups);
+    return a > row_bytes ? a : row_bytes;
+  }
   static size_t bytes(int ngroups) {
-    return bitmap_bytes(ngroups) + pref_bytes(ngroups) + sizeof(BmkDup<V>) * BMK_DUP + BMK_FILT_WORDS * 4 +
-           2 * sizeof(BmkStage<V>) + sizeof(BmkMisc) + 64;
+    return front_bytes(ngroups) + sizeof(BmkDup<V>) * BMK_DUP + BMK_FILT_WORDS * 4 + 2 * sizeof(BmkStage<V>) +
+           sizeof(BmkMisc) + 64;
   }
 };
 
@@ -146,6 +165,37 @@ __device__ __forceinline__ int bmk_rank(const unsigned* bm, const unsigned short
   return r + __popc(cur & ((1u << (col & 31u)) - 1u));
 }
 
+// common.h's decoupled look-back with the aggregate already published by the caller and a back-off in the spin (256
+// workgroups polling one another's state words without it take bandwidth from the rows that are still being computed)
+__device__ __forceinline__ unsigned long long bmk_lookback(unsigned long long* st, int64_t blk, unsigned long long tot, int lane) {
+  const unsigned long long mask = (1ull << 62) - 1;
+  unsigned long long excl = 0;
+  int64_t hi = blk - 1;
+  while (hi >= 0) {
+    const int64_t j = hi - lane;
+    unsigned long long v = 2ull << 62;
+    if (j >= 0) v = __hip_atomic_load(&st[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long flag = v >> 62;
+    const unsigned long long have_prefix = __ballot(flag == 2);
+    const unsigned long long missing = __ballot(flag == 0);
+    const int first_prefix = have_prefix ? __builtin_ctzll(have_prefix) : 64;
+    const unsigned long long upto = first_prefix >= 63 ? ~0ull : ((2ull << first_prefix) - 1);
+    if (missing & upto) {
+      __builtin_amdgcn_s_sleep(16);
+      continue;
+    }
+    unsigned long long part = lane <= first_prefix ? (v & mask) : 0;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+    excl += part;
+    if (first_prefix < 64) break;
+    hi -= 64;
+  }
+  if (lane == 0)
+    __hip_atomic_store(&st[blk], (2ull << 62) | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return excl;
+}
+
 template <typename V>
 __device__ __forceinline__ int bmk_is_zero_bits(V v) {
   if constexpr (sizeof(V) == 8) return __builtin_bit_cast(unsigned long long, v) == 0;
@@ -163,25 +213,38 @@ spgemm_bitmap_kernel(int64_t n_row, int ngroups, const I* __restrict__ a_ptr, co
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned* const bm = reinterpret_cast<unsigned*>(smem);
   unsigned short* const pref = reinterpret_cast<unsigned short*>(smem + BmkLayout<V>::bitmap_bytes(ngroups));
-  BmkDup<V>* const dup = reinterpret_cast<BmkDup<V>*>(reinterpret_cast<char*>(pref) + BmkLayout<V>::pref_bytes(ngroups));
+  BmkDup<V>* const dup = reinterpret_cast<BmkDup<V>*>(smem + BmkLayout<V>::front_bytes(ngroups));
+  // the finished row in output order: 4-byte values as {column, value bits} pairs, 8-byte values as two arrays
+  uint2* const row_cv = reinterpret_cast<uint2*>(smem);
+  unsigned* const row_c = reinterpret_cast<unsigned*>(smem);
+  V* const row_v = reinterpret_cast<V*>(smem + (size_t)BMK_THREADS * ITEMS * 4);
+  auto put = [&](unsigned at, unsigned c, V v) {
+    if constexpr (sizeof(V) == 4) {
+      row_cv[at] = make_uint2(c, __builtin_bit_cast(unsigned, v));
+    } else {
+      row_c[at] = c;
+      row_v[at] = v;
+    }
+  };
   unsigned* const filt = reinterpret_cast<unsigned*>(dup + BMK_DUP);
   BmkStage<V>* const stage = reinterpret_cast<BmkStage<V>*>(filt + BMK_FILT_WORDS);
   BmkMisc* const misc = reinterpret_cast<BmkMisc*>(stage + 2);
-  unsigned long long* const ticket_ctr = work;
-  unsigned long long* const state = work + 8;
+  unsigned long long* const state = work + BMK_HEADER;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   constexpr int CAP = BMK_THREADS * ITEMS;
 
   // ---- set-up: clean LDS, the first two tickets -------------------------------------------------------------------------
   for (int i = tid; i < ngroups * 2; i += BMK_THREADS) reinterpret_cast<uint4*>(bm)[i] = make_uint4(0, 0, 0, 0);
   if (tid < BMK_FILT_WORDS) filt[tid] = 0;
-  if (tid == 0) {
-    misc->ndup = 0;
-    misc->ticket[0] = (int64_t)__hip_atomic_fetch_add(ticket_ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    misc->ticket[1] = (int64_t)__hip_atomic_fetch_add(ticket_ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  if (tid == 0) misc->ndup[0] = misc->ndup[1] = 0;
   lds_barrier();
-  int64_t cur = misc->ticket[0], nxt = misc->ticket[1];
+  // Rows are dealt round-robin: workgroup w takes rows w, w + G, w + 2 G, ... (G = the grid = one workgroup per CU, all
+  // resident).  A row's look-back then only ever waits for rows that the OTHER workgroups are working on at the same time,
+  // or that are finished.  (Tickets taken from a counter were built first and measured 4x SLOWER than the bucket kernels:
+  // with a row prefetched, a workgroup holds the ticket of a row it has not started while higher rows, held by others,
+  // already wait for it in their look-back - the rows of all workgroups end up in one dependency chain.)
+  const int64_t G = gridDim.x;
+  int64_t cur = blockIdx.x, nxt = cur + G;
   bool failed = false;
 
   // the A row of `row`: element `tid` (column of A = row of B, value); rows longer than the staging area fail the call
@@ -268,13 +331,18 @@ spgemm_bitmap_kernel(int64_t n_row, int ngroups, const I* __restrict__ a_ptr, co
   }
   int buf = 0;
   int zero_count = 0;
+#ifdef BMK_PROF
+  unsigned long long prof[16] = {0};
+  unsigned long long tprev = __builtin_readcyclecounter();
+#endif
 
   while (cur < n_row) {   // (workgroup-uniform)
     const BmkStage<V>* const sc = &stage[buf];
     BmkStage<V>* const sn = &stage[buf ^ 1];
-    // ---- top: a ticket for the row after next, the B row pointers of the next row's A elements -------------------------
-    unsigned long long tk = 0;
-    if (tid == 0) tk = __hip_atomic_fetch_add(ticket_ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int* const ndup = &misc->ndup[buf];
+    // ---- top: the B row pointers of the next row's A elements ------------------------------------------------------------
+    const int64_t nn = nxt + G;
+    BMK_T(0)
     int64_t bs;
     unsigned len;
     load_brow(nA_n, ka, bs, len);
@@ -296,9 +364,9 @@ spgemm_bitmap_kernel(int64_t n_row, int ngroups, const I* __restrict__ a_ptr, co
         const unsigned bit = 1u << (c & 31u);
         const unsigned old = atomicOr(&bm[c >> 5], bit);
         if (old & bit) {   // the output element has a product already: park this one
-          const unsigned h = (c ^ (c >> 11)) & 2047u;
+          const unsigned h = (c ^ (c >> 14)) & BMK_FILT_MASK;
           atomicOr(&filt[h >> 5], 1u << (h & 31u));
-          const int slot = atomicAdd(&misc->ndup, 1);
+          const int slot = atomicAdd(ndup, 1);
           if (slot < BMK_DUP) {
             dup[slot].key = key[j];
             dup[slot].rank = BMK_NONE;
@@ -310,7 +378,9 @@ spgemm_bitmap_kernel(int64_t n_row, int ngroups, const I* __restrict__ a_ptr, co
       }
       if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);
     }
+    BMK_T(1)
     lds_barrier();
+    BMK_T(2)
     // ---- 2. popcount scan: positions of the columns; the same scan sums the next row's B-row lengths --------------------
     unsigned long long cnts = 0;
 #pragma unroll
@@ -338,31 +408,28 @@ spgemm_bitmap_kernel(int64_t n_row, int ngroups, const I* __restrict__ a_ptr, co
       sn->bstart[tid] = bs;
       sn->aval[tid] = av_n;
     }
-    if (tid == 0) misc->ticket[0] = (int64_t)tk;
+    BMK_T(3)
     lds_barrier();
-    const int64_t nn = misc->ticket[0];
+    BMK_T(4)
     // ---- 3. the row's length is known: wave 0 publishes it and looks back for the row's offset, while every first
     // arriver finds its column's position (unless products of its column are parked: then it joins them) ---------------
-    if (wid == 0) {
-      const unsigned long long before = lookback_exclusive(state, cur, (unsigned long long)row_nnz, lane);
-      if (lane == 0) {
-        misc->row_off = (int64_t)before;
-        out_ptr[cur + 1] = (int64_t)before + row_nnz;
-        if (cur == 0) out_ptr[0] = 0;
-      }
-    }
+    // (only the publication happens here: the look-back itself waits until the row is assembled - step 5 -, by which time
+    // the rows before this one have published theirs; looking back right here cost 61 k of a row's 194 k cycles)
+    if (tid == 0 && cur > 0)
+      __hip_atomic_store(&state[cur], (1ull << 62) | (unsigned long long)row_nnz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    BMK_T(5)
     // (a position has 14 bits: its low 12 replace the A-element index in key[j], the high 2 of all items share one register)
     unsigned rk_hi = 0;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
       if ((first_mask >> j) & 1u) {
         const unsigned c = key[j] >> 8;
-        const unsigned h = (c ^ (c >> 11)) & 2047u;
+        const unsigned h = (c ^ (c >> 14)) & BMK_FILT_MASK;
         const bool parked = (filt[h >> 5] >> (h & 31u)) & 1u;
         const int r = bmk_rank(bm, pref, c);
         if (parked) {
           first_mask &= ~(1u << j);
-          const int slot = atomicAdd(&misc->ndup, 1);
+          const int slot = atomicAdd(ndup, 1);
           if (slot < BMK_DUP) {
             dup[slot].key = key[j];
             dup[slot].rank = (unsigned)r;
@@ -374,71 +441,124 @@ spgemm_bitmap_kernel(int64_t n_row, int ngroups, const I* __restrict__ a_ptr, co
       }
       if (j % 2 == 1) __builtin_amdgcn_sched_barrier(0);   // (two lookups = 18 words in flight, not 16 x 9)
     }
+    BMK_T(6)
     lds_barrier();
-    const int64_t row_off = misc->row_off;
-    // ---- 4. request the next row's products (they land while this row is written), then store this row in place ---------
+    BMK_T(7)
+    // ---- 4. request the next row's products (they land while this row is assembled and written); every position is known
+    // and the bitmap has served: the front region now takes the row, (column, value) at its position ---------------------
     expand(sn, nA_n, P_n);
+    BMK_T(8)
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-      if ((first_mask >> j) & 1u) {
-        const int64_t at = row_off + (int64_t)((key[j] & 0xfffu) | (((rk_hi >> (2 * j)) & 3u) << 12));
-        out_idx[at] = (int64_t)(key[j] >> 12);
-        out_val[at] = val[j];
-        zero_count += bmk_is_zero_bits(val[j]);
-      }
+      if ((first_mask >> j) & 1u)
+        put((key[j] & 0xfffu) | (((rk_hi >> (2 * j)) & 3u) << 12), key[j] >> 12, val[j]);
       if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- 5. parked products: the entry with the smallest A-element index of a column sums the column left to right ------
+    BMK_T(9)
+    // ---- 5. parked products: a WAVE per entry scans the list (8 entries per lane at most); the entry with the smallest
+    // A-element index of its column adds the column's products left to right, in the order of A's elements ------------
     {
-      int n = misc->ndup;
+      int n = *ndup;
       if (n > BMK_DUP) {
         failed = true;
         n = BMK_DUP;
       }
-      if (tid < n) {
-        const unsigned kd = dup[tid].key;
+      constexpr int PER = BMK_DUP / 64;
+      unsigned lk[PER];
+#pragma unroll
+      for (int t = 0; t < PER; ++t) lk[t] = lane + 64 * t < n ? dup[lane + 64 * t].key : BMK_NONE;
+      for (int d = wid; d < n; d += BMK_THREADS / 64) {
+        const unsigned kd = dup[d].key;          // (wave-uniform)
         const unsigned c = kd >> 8;
-        bool leader = true;
-        unsigned rank = dup[tid].rank;
-        for (int i = 0; i < n; ++i) {
-          const unsigned k = dup[i].key;
-          if ((k >> 8) == c) {
-            leader = leader && k >= kd;
-            const unsigned r2 = dup[i].rank;
-            rank = r2 != BMK_NONE ? r2 : rank;
-          }
+        // smallest key of the column, and where the column's position is recorded (exactly one entry has it)
+        unsigned lo = BMK_NONE;
+        int cnt = 0, holder = -1;
+#pragma unroll
+        for (int t = 0; t < PER; ++t) {
+          const bool m = lk[t] != BMK_NONE && (lk[t] >> 8) == c;
+          lo = m && lk[t] < lo ? lk[t] : lo;
+          cnt += m;
         }
-        if (leader) {
-          V acc = dup[tid].val;
-          unsigned last = kd;
-          for (;;) {   // next larger A-element index of this column
-            unsigned best = BMK_NONE;
-            V bv = V(0);
-            for (int i = 0; i < n; ++i) {
-              const unsigned k = dup[i].key;
-              if ((k >> 8) == c && k > last && k < best) {
-                best = k;
-                bv = dup[i].val;
-              }
-            }
-            if (best == BMK_NONE) break;
-            acc = acc + bv;
-            last = best;
-          }
-          out_idx[row_off + rank] = (int64_t)c;
-          out_val[row_off + rank] = acc;
-          zero_count += bmk_is_zero_bits(acc);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const unsigned y = __shfl_xor(lo, o, 64);
+          lo = y < lo ? y : lo;
+          cnt += __shfl_xor(cnt, o, 64);
         }
+        if (lo != kd) continue;                  // not the first A element of this column (wave-uniform)
+        V acc = dup[d].val;
+        unsigned rank = dup[d].rank;
+        unsigned last = kd;
+        for (int step = 1; step < cnt; ++step) {   // the next larger A-element index of this column, cnt - 1 times
+          unsigned nx = BMK_NONE;
+          int at = 0;
+#pragma unroll
+          for (int t = 0; t < PER; ++t) {
+            const bool m = lk[t] != BMK_NONE && (lk[t] >> 8) == c && lk[t] > last && lk[t] < nx;
+            nx = m ? lk[t] : nx;
+            at = m ? lane + 64 * t : at;
+          }
+          unsigned best = nx;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) {
+            const unsigned y = __shfl_xor(best, o, 64);
+            best = y < best ? y : best;
+          }
+          const unsigned long long who = __ballot(nx == best && best != BMK_NONE);
+          const int src = __builtin_amdgcn_readlane(at, (int)__builtin_ctzll(who));
+          acc = acc + dup[src].val;
+          const unsigned r2 = dup[src].rank;
+          rank = r2 != BMK_NONE ? r2 : rank;
+          last = best;
+        }
+        if (lane == 0 && rank != BMK_NONE) put(rank, c, acc);   // (always a position, unless the list overflowed: failed anyway)
       }
     }
-    // the A elements of the row after next (two dependent loads: they have the rest of this row and the head of the next)
+    // the row's offset in the result: sum of the lengths of the rows before it (decoupled look-back, wave 0)
+    if (wid == 0) {
+      const unsigned long long before = bmk_lookback(state, cur, (unsigned long long)row_nnz, lane);
+      if (lane == 0) {
+        misc->row_off = (int64_t)before;
+        out_ptr[cur + 1] = (int64_t)before + row_nnz;
+        if (cur == 0) out_ptr[0] = 0;
+      }
+    }
+    BMK_T(10)
     int nA_nn;
     load_arow(nn, nA_nn, ka, av);
-    // ---- 6. leave LDS clean for the next row (nobody reads the bitmap after step 3; the list is read in step 5) ---------
-    for (int i = tid; i < ngroups * 2; i += BMK_THREADS) reinterpret_cast<uint4*>(bm)[i] = make_uint4(0, 0, 0, 0);
-    if (tid < BMK_FILT_WORDS) filt[tid] = 0;
+    // ---- 6. the row leaves with coalesced stores; the bitmap's bytes are left zeroed for the next row ---------------------
     lds_barrier();
-    if (tid == 0) misc->ndup = 0;
+    BMK_T(11)
+    const int64_t row_off = misc->row_off;
+    {
+      const int units = ngroups * 4;   // the bitmap in 8-byte units
+      if constexpr (sizeof(V) == 4) {
+        // a thread clears exactly the 8 bytes it has just read: no barrier between copying out and clearing
+        for (int u = tid; u < (units > row_nnz ? units : row_nnz); u += BMK_THREADS) {
+          if (u < row_nnz) {
+            const uint2 cv = row_cv[u];
+            out_idx[row_off + u] = (int64_t)cv.x;
+            out_val[row_off + u] = __builtin_bit_cast(V, cv.y);
+            zero_count += cv.y == 0;
+          }
+          if (u < units) row_cv[u] = make_uint2(0, 0);
+        }
+      } else {
+        for (int u = tid; u < row_nnz; u += BMK_THREADS) {
+          const V v = row_v[u];
+          out_idx[row_off + u] = (int64_t)row_c[u];
+          out_val[row_off + u] = v;
+          zero_count += bmk_is_zero_bits(v);
+        }
+        lds_barrier();
+        for (int u = tid; u < units; u += BMK_THREADS) row_cv[u] = make_uint2(0, 0);
+      }
+    }
+    if (tid < BMK_FILT_WORDS) filt[tid] = 0;
+    if (tid == 0) misc->ndup[buf ^ 1] = 0;   // (the previous row's count: read for the last time two barriers ago)
+    BMK_T(12)
+    lds_barrier();
+    BMK_T(13)
     cur = nxt;
     nxt = nn;
     nA_c = nA_n;
@@ -446,17 +566,16 @@ spgemm_bitmap_kernel(int64_t n_row, int ngroups, const I* __restrict__ a_ptr, co
     P_c = P_n;
     buf ^= 1;
   }
+#ifdef BMK_PROF
+  if (tid == 0)
+    for (int k = 0; k < 16; ++k) atomicAdd(work + 4 + k, prof[k]);
+#endif
   // ---- epilogue: exact zeros written, failure word ------------------------------------------------------------------------
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) zero_count += __shfl_xor(zero_count, d, 64);
   if (lane == 0 && zero_count) atomicAdd(work + 2, (unsigned long long)zero_count);
   if (failed && lane == 0) __hip_atomic_store(work + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-
-template <typename V>
-struct BmkItems {
-  static constexpr int value = sizeof(V) == 4 ? 16 : 12;
-};
 
 template <typename V, typename I>
 static int bmk_launch(int64_t n_row, int64_t n_col, const I* a_ptr, const I* a_idx, const V* a_val, const I* b_ptr,
@@ -504,7 +623,7 @@ extern "C" int64_t spamd_spgemm_bitmap_limits(int val_dtype, int which) {
 }
 
 // C = A @ B, rows written in place: out_indptr[n_row + 1], out_indices / out_data with room for every product (the
-// caller trims to out_indptr[n_row]).  work: n_row + 8 words, zeroed here; afterwards work[1] != 0 = failed (a row
+// caller trims to out_indptr[n_row]).  work: n_row + 32 words, zeroed here; afterwards work[1] != 0 = failed (a row
 // outside the limits, or with more parked products than the list holds: discard the result), work[2] = values written
 // whose bits are all zero.
 extern "C" int spamd_spgemm_bitmap(int val_dtype, int idx_dtype, int64_t n_row, int64_t n_col, const void* a_indptr,
@@ -513,7 +632,7 @@ extern "C" int spamd_spgemm_bitmap(int val_dtype, int idx_dtype, int64_t n_row, 
                                    void* out_data, void* stream) {
   if (n_row < 0 || n_col <= 0 || n_col > (int64_t)BMK_MAX_GROUPS * 256 || !work || !out_indptr) return SPAMD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  if (hipError_t e = hipMemsetAsync(work, 0, (size_t)(n_row + 8) * sizeof(int64_t), s); e != hipSuccess) return (int)e;
+  if (hipError_t e = hipMemsetAsync(work, 0, (size_t)(n_row + BMK_HEADER) * sizeof(int64_t), s); e != hipSuccess) return (int)e;
   if (n_row == 0) return (int)hipMemsetAsync(out_indptr, 0, sizeof(int64_t), s);
   SPAMD_DISPATCH_VAL(val_dtype, V, {
     SPAMD_DISPATCH_IDX(idx_dtype, I, {

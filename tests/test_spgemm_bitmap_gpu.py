@@ -79,7 +79,8 @@ def _same(got, want):
 def test_bitmap_rows_equal_the_bucket_kernels(dtype, idt):
     """config 5 in small: ~100 x ~100 products per row, 10^6 columns; more rows than CUs, some of them empty"""
     m, k, n = 1500, 40_000, 1_000_000
-    A = _csr(m, k, 100, 1, dtype, idt, empty_every=97)
+    per_a = 100 if np.dtype(dtype).itemsize == 4 else 60        # (8-byte values: rows of at most 8192 products)
+    A = _csr(m, k, per_a, 1, dtype, idt, empty_every=97)
     B = _csr(k, n, 100, 2, dtype, idt, empty_every=13)
     got, want, used = _both((m, n), A, B)
     assert used == "bitmap"
@@ -90,14 +91,14 @@ def test_bitmap_rows_equal_the_bucket_kernels(dtype, idt):
 def test_bitmap_rows_with_many_products_per_output_element():
     """a column of B that every row holds: ~100 products of ONE output element per row, added in the order of A's elements
     (the parked-product list at work), plus the usual handful of pairs"""
-    m, k, n = 700, 5_000, 300_000
+    m, k, n = 700, 5_000, 1_000_000
     A = _csr(m, k, 100, 3, np.float32, np.int32)
     B = _csr(k, n, 90, 4, np.float32, np.int32, hot_col=12345)
     got, want, used = _both((m, n), A, B)
     assert used == "bitmap"
     _same(got, want)
-    B64 = _csr(k, n, 60, 5, np.float64, np.int64, hot_col=299_999)
-    A64 = _csr(m, k, 100, 6, np.float64, np.int64)
+    B64 = _csr(k, n, 60, 5, np.float64, np.int64, hot_col=999_999)
+    A64 = _csr(m, k, 90, 6, np.float64, np.int64)
     got, want, used = _both((m, n), A64, B64)
     assert used == "bitmap"
     _same(got, want)
@@ -131,7 +132,7 @@ def test_bitmap_rows_at_the_limits():
 
     lim = _ffi.lib().spamd_spgemm_bitmap_limits
     assert (lim(_ffi.F32, 0), lim(_ffi.F32, 1), lim(_ffi.F32, 2), lim(_ffi.F32, 3)) == (16384, 256, 1 << 20, 512)
-    assert lim(_ffi.F64, 0) == 12288
+    assert lim(_ffi.F64, 0) == 8192
     m, k, n = 300, 2_000, 1 << 20
     rng = np.random.default_rng(0)
     cols = np.stack([np.sort(rng.choice(k, 256, replace=False)) for _ in range(m)]).astype(np.int32)
@@ -174,10 +175,11 @@ def test_product_api_takes_the_bitmap_kernel_and_is_reproducible():
     a = sp.GCXS((g.data[:p1].contiguous(), (g.indices[:p1] % n).contiguous(), g.indptr[:rows + 1].contiguous()), shape=(rows, n),
                 compressed_axes=(0,))
     # (column indices folded into B's row range; duplicates inside a row are possible but rare - rebuild canonically)
-    a = sp.GCXS(a.tocoo(), compressed_axes=(0,))
+    coo = a.tocoo()
+    a = sp.GCXS(sp.COO(coo.coords, coo.data, shape=coo.shape), compressed_axes=(0,))    # (duplicates summed, sorted)
     K.SPGEMM_STATS.clear()
     c1 = a @ g
-    assert K.SPGEMM_STATS.get("kernel") == "bitmap"
+    assert K.SPGEMM_STATS.get("kernel") == "bitmap", K.SPGEMM_STATS
     c2 = a @ g
     for x, y in ((c1.data, c2.data), (c1.indices, c2.indices), (c1.indptr, c2.indptr)):
         assert torch.equal(x, y)
