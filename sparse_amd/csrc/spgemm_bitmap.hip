@@ -3,27 +3,38 @@
 //
 // spgemm_rows.hip orders a row's products with LDS bucket counts + per-bucket sorting networks, writes the row to a
 // scratch area at its product offset and needs a pack kernel once every row length is known: ~20 barrier-separated phases
-// per row, two passes over the column range, 69 GB of traffic for 20 GB of algorithmic bytes at BASELINE config 5.
-// Here the column ORDER comes from a bitmap instead of a sort, and rows go straight to their final place:
+// per row, two passes over the column range, 69 GB of traffic for 20 GB of algorithmic bytes at BASELINE config 5
+// (28.8 ms for one GPU's share).  Here the column ORDER comes from a bitmap instead of a sort, and rows go straight to
+// their final place (13.1 ms, bit-identical):
 //   * one persistent 1024-thread workgroup per CU keeps a bitmap of the output row's columns in LDS (n_col bits: 125 KB
 //     at config 5).  Every product sets its column's bit with one returning LDS atomic; the position of a column in the
 //     sorted row is the number of set bits below it (a popcount scan over the bitmap + three LDS reads per product), so
 //     nothing is sorted and nothing is ranked against anything else;
-//   * the first product to set a bit stores (column, value) at its final position.  Products that find their bit already
-//     set (two products of one output element: ~50 of 10^4 at config 5) are parked in a small LDS list together with the
-//     first arriver of their column (which recognises itself through a 16384-bit filter); the entry with the smallest
-//     A-element index of each column then adds the column's products left to right in A's order - the reference's
+//   * once every position is known the bitmap has served, and its LDS space takes the row itself: the first product to
+//     have set a bit writes (column, value) at its position.  Products that found their bit already set (two products of
+//     one output element: ~50 of 10^4 at config 5) are parked in a small LDS list together with the first arriver of
+//     their column (which recognises itself through a 16384-bit filter); a wave per entry scans the list, and the entry with
+//     the smallest A-element index of each column adds the column's products left to right in A's order - the reference's
 //     `sums[j] += ...` order (`_common.py:690-705`), bit-identical to spgemm_rows.hip and to the global form;
-//   * the row length is known right after the popcount scan, BEFORE anything is emitted: rows are dealt round-robin to the workgroups, a
-//     decoupled look-back over one state word per row (common.h) gives the row's offset in the result, and the row is
-//     written once, in place.  No scratch rows, no pack kernel, no scan over the row lengths; the exact zeros written are
-//     counted on the way (the result container's prune then has nothing to read);
-//   * a row's products are prefetched: while row r is ranked and emitted, the loads of row r+1's products are in flight
-//     (into registers) and row r+2's A elements are being fetched, so no phase waits for HBM.  Barriers wait for LDS
-//     only (`s_waitcnt lgkmcnt(0)` + `s_barrier`): `__syncthreads()` would drain the prefetch at every phase.
+//   * the row length is known right after the popcount scan, BEFORE anything is emitted: rows are dealt round-robin to the
+//     workgroups, a decoupled look-back over one state word per row gives the row's offset in the result, and the row
+//     leaves LDS once, with coalesced stores, to its final place.  No scratch rows, no pack kernel, no scan over the row
+//     lengths; the exact zeros written are counted on the way (the result container's prune then has nothing to read);
+//   * a row's products are prefetched: while row r is finished and written, the loads of row r+1's products are in flight
+//     (into registers) and row r+2's A elements are being fetched.  Barriers wait for LDS only (`s_waitcnt lgkmcnt(0)` +
+//     `s_barrier`): `__syncthreads()` would drain the prefetch at every phase.
+// Measured on the way (config-5 share, ms per product through `a @ b`; bucket kernels 28.8): first arrivers storing
+// straight to HBM 107 (scattered 4- and 8-byte stores); rows handed out by a ticket counter 110 / 36 with the rows in LDS
+// (a workgroup that prefetches holds the ticket of a row it has not started, and higher rows wait for it: one dependency
+// chain through all workgroups); one thread per parked entry and the look-back right after the publication 36 -> 14.5;
+// one copy of the products in registers instead of two (30 -> 2 spilled registers) 13.1.  Per row then (cycles of thread
+// 0, instrumented build): bits 6 k, popcount scan + staging of the next A row 14 k, positions 8 k, row into LDS 7 k,
+// product requests 20-24 k, parked products 5 k, look-back 17-20 k, copy-out 5 k: the last two large ones are the memory
+// system absorbing every CU's product requests at once (the loaded latency of a state word is ~8 us).
 // Limits (checked by the host before the launch, spamd_spgemm_bitmap_limits): n_col <= 2^20, A rows of at most 256
-// elements, at most 1024 * ITEMS products per row, index arrays of either width.  A row whose parked products exceed the
-// list (512 entries) sets the `failed` word: the caller then discards the result and uses spgemm_rows.hip.
+// elements, at most 1024 * ITEMS products per row (ITEMS = 16 for 4-byte values, 8 for 8-byte ones: the row must fit the
+// LDS region), index arrays of either width.  A row whose parked products exceed the list (512 entries) sets the `failed`
+// word: the caller then discards the result and uses spgemm_rows.hip.
 #include <mutex>
 
 #include "common.h"
@@ -165,31 +176,49 @@ __device__ __forceinline__ int bmk_rank(const unsigned* bm, const unsigned short
   return r + __popc(cur & ((1u << (col & 31u)) - 1u));
 }
 
-// common.h's decoupled look-back with the aggregate already published by the caller and a back-off in the spin (256
-// workgroups polling one another's state words without it take bandwidth from the rows that are still being computed)
+// common.h's decoupled look-back with the aggregate already published by the caller, FOUR windows of 64 predecessors per
+// round trip (a state word written by another XCD comes from the fabric: ~2 us each; with one workgroup per CU the
+// nearest row with a known prefix is up to 255 rows back, i.e. four dependent round trips with one window at a time:
+// 17 k of a row's 91 k cycles), and a back-off in the spin.
 __device__ __forceinline__ unsigned long long bmk_lookback(unsigned long long* st, int64_t blk, unsigned long long tot, int lane) {
   const unsigned long long mask = (1ull << 62) - 1;
   unsigned long long excl = 0;
   int64_t hi = blk - 1;
   while (hi >= 0) {
-    const int64_t j = hi - lane;
-    unsigned long long v = 2ull << 62;
-    if (j >= 0) v = __hip_atomic_load(&st[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long flag = v >> 62;
-    const unsigned long long have_prefix = __ballot(flag == 2);
-    const unsigned long long missing = __ballot(flag == 0);
-    const int first_prefix = have_prefix ? __builtin_ctzll(have_prefix) : 64;
-    const unsigned long long upto = first_prefix >= 63 ? ~0ull : ((2ull << first_prefix) - 1);
-    if (missing & upto) {
-      __builtin_amdgcn_s_sleep(16);
+    unsigned long long v[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int64_t j = hi - lane - 64 * t;
+      v[t] = 2ull << 62;   // rows before row 0 behave like "prefix known, value 0"
+      if (j >= 0) v[t] = __hip_atomic_load(&st[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    bool done = false, retry = false;
+    unsigned long long part = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (!done && !retry) {   // (wave-uniform)
+        const unsigned long long flag = v[t] >> 62;
+        const unsigned long long have_prefix = __ballot(flag == 2);
+        const unsigned long long missing = __ballot(flag == 0);
+        const int first_prefix = have_prefix ? __builtin_ctzll(have_prefix) : 64;
+        const unsigned long long upto = first_prefix >= 63 ? ~0ull : ((2ull << first_prefix) - 1);
+        if (missing & upto) {
+          retry = true;
+        } else {
+          part += lane <= first_prefix ? (v[t] & mask) : 0;
+          done = first_prefix < 64;
+        }
+      }
+    }
+    if (retry) {   // (what was summed so far is dropped: the same windows are read again)
+      __builtin_amdgcn_s_sleep(8);
       continue;
     }
-    unsigned long long part = lane <= first_prefix ? (v & mask) : 0;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
     excl += part;
-    if (first_prefix < 64) break;
-    hi -= 64;
+    if (done) break;
+    hi -= 256;
   }
   if (lane == 0)
     __hip_atomic_store(&st[blk], (2ull << 62) | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -299,7 +328,7 @@ spgemm_bitmap_kernel(int64_t n_row, int ngroups, const I* __restrict__ a_ptr, co
         bvN[j] = b_val[q];
         eN[j / 4] |= (unsigned)e << (8 * (j % 4));
       }
-      if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);   // (keeps the scheduler from hoisting all 2 x ITEMS address chains)
+      if (j % 8 == 7) __builtin_amdgcn_sched_barrier(0);   // (keeps the scheduler from hoisting all 2 x ITEMS address chains)
     }
   };
 
@@ -348,35 +377,30 @@ spgemm_bitmap_kernel(int64_t n_row, int ngroups, const I* __restrict__ a_ptr, co
     load_brow(nA_n, ka, bs, len);
     const V av_n = av;
     // ---- 1. every product of the current row sets its column's bit -----------------------------------------------------
-    // key[j] = (column << 8) | A element; first arrivers are remembered in a mask, later ones parked
-    unsigned key[ITEMS];
-    V val[ITEMS];
+    // (the products stay where the prefetch put them - colN / bvN / eN - until the row is assembled in step 4: a second
+    // copy of them, as keys and values, had the kernel spill 30 registers)
     unsigned first_mask = 0;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-      key[j] = BMK_NONE;
-      val[j] = V(0);
       if (colN[j] != BMK_NONE) {
-        const unsigned e = (eN[j / 4] >> (8 * (j % 4))) & 255u;
-        val[j] = sc->aval[e] * bvN[j];
         const unsigned c = colN[j];
-        key[j] = (c << 8) | e;
         const unsigned bit = 1u << (c & 31u);
         const unsigned old = atomicOr(&bm[c >> 5], bit);
         if (old & bit) {   // the output element has a product already: park this one
+          const unsigned e = (eN[j / 4] >> (8 * (j % 4))) & 255u;
           const unsigned h = (c ^ (c >> 14)) & BMK_FILT_MASK;
           atomicOr(&filt[h >> 5], 1u << (h & 31u));
           const int slot = atomicAdd(ndup, 1);
           if (slot < BMK_DUP) {
-            dup[slot].key = key[j];
+            dup[slot].key = (c << 8) | e;
             dup[slot].rank = BMK_NONE;
-            dup[slot].val = val[j];
+            dup[slot].val = sc->aval[e] * bvN[j];
           }
         } else {
           first_mask |= 1u << j;
         }
       }
-      if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+      if (j % 8 == 7) __builtin_amdgcn_sched_barrier(0);
     }
     BMK_T(1)
     lds_barrier();
@@ -418,42 +442,45 @@ spgemm_bitmap_kernel(int64_t n_row, int ngroups, const I* __restrict__ a_ptr, co
     if (tid == 0 && cur > 0)
       __hip_atomic_store(&state[cur], (1ull << 62) | (unsigned long long)row_nnz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     BMK_T(5)
-    // (a position has 14 bits: its low 12 replace the A-element index in key[j], the high 2 of all items share one register)
-    unsigned rk_hi = 0;
+    // positions: 14 bits each, two to a register
+    unsigned rk[ITEMS / 2];
+#pragma unroll
+    for (int j = 0; j < ITEMS / 2; ++j) rk[j] = 0;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
       if ((first_mask >> j) & 1u) {
-        const unsigned c = key[j] >> 8;
+        const unsigned c = colN[j];
         const unsigned h = (c ^ (c >> 14)) & BMK_FILT_MASK;
         const bool parked = (filt[h >> 5] >> (h & 31u)) & 1u;
         const int r = bmk_rank(bm, pref, c);
+        rk[j / 2] |= (unsigned)r << (16 * (j % 2));
         if (parked) {
           first_mask &= ~(1u << j);
+          const unsigned e = (eN[j / 4] >> (8 * (j % 4))) & 255u;
           const int slot = atomicAdd(ndup, 1);
           if (slot < BMK_DUP) {
-            dup[slot].key = key[j];
+            dup[slot].key = (c << 8) | e;
             dup[slot].rank = (unsigned)r;
-            dup[slot].val = val[j];
+            dup[slot].val = sc->aval[e] * bvN[j];
           }
         }
-        key[j] = (c << 12) | ((unsigned)r & 0xfffu);
-        rk_hi |= ((unsigned)r >> 12) << (2 * j);
       }
-      if (j % 2 == 1) __builtin_amdgcn_sched_barrier(0);   // (two lookups = 18 words in flight, not 16 x 9)
+      if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);   // (four lookups = 36 words in flight, not 16 x 9)
     }
     BMK_T(6)
     lds_barrier();
     BMK_T(7)
-    // ---- 4. request the next row's products (they land while this row is assembled and written); every position is known
-    // and the bitmap has served: the front region now takes the row, (column, value) at its position ---------------------
-    expand(sn, nA_n, P_n);
-    BMK_T(8)
+    // ---- 4. every position is known and the bitmap has served: the front region now takes the row, (column, value) at its
+    // position; then the next row's products are requested (they land while this row is finished and written) -----------
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-      if ((first_mask >> j) & 1u)
-        put((key[j] & 0xfffu) | (((rk_hi >> (2 * j)) & 3u) << 12), key[j] >> 12, val[j]);
-      if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+      if ((first_mask >> j) & 1u) {
+        const unsigned e = (eN[j / 4] >> (8 * (j % 4))) & 255u;
+        put((rk[j / 2] >> (16 * (j % 2))) & 0xffffu, colN[j], sc->aval[e] * bvN[j]);
+      }
     }
+    BMK_T(8)
+    expand(sn, nA_n, P_n);
     BMK_T(9)
     // ---- 5. parked products: a WAVE per entry scans the list (8 entries per lane at most); the entry with the smallest
     // A-element index of its column adds the column's products left to right, in the order of A's elements ------------
@@ -514,7 +541,10 @@ spgemm_bitmap_kernel(int64_t n_row, int ngroups, const I* __restrict__ a_ptr, co
         if (lane == 0 && rank != BMK_NONE) put(rank, c, acc);   // (always a position, unless the list overflowed: failed anyway)
       }
     }
-    // the row's offset in the result: sum of the lengths of the rows before it (decoupled look-back, wave 0)
+    BMK_T(10)
+    // the row's offset in the result: sum of the lengths of the rows before it (decoupled look-back, wave 0).  Measured
+    // in three places - right after the publication, before the product requests, here - it takes ~17 k cycles wherever it
+    // stands: the state words travel through a memory system that every CU has just filled with its product requests.
     if (wid == 0) {
       const unsigned long long before = bmk_lookback(state, cur, (unsigned long long)row_nnz, lane);
       if (lane == 0) {
@@ -523,7 +553,7 @@ spgemm_bitmap_kernel(int64_t n_row, int ngroups, const I* __restrict__ a_ptr, co
         if (cur == 0) out_ptr[0] = 0;
       }
     }
-    BMK_T(10)
+    BMK_T(14)
     int nA_nn;
     load_arow(nn, nA_nn, ka, av);
     // ---- 6. the row leaves with coalesced stores; the bitmap's bytes are left zeroed for the next row ---------------------
