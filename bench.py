@@ -339,6 +339,21 @@ def main():
         kern = lambda: _kernels.dot_csr_ndarray((Mloc, N), data, idx, ptr, b_full, exact=bool(args.exact), out=out)
     kern()
     kernel_ms = dev_time(kern, args.steps)
+    # ---- the only scaling proxy one GPU can give: a rank's share at world size 8 (the first of 8 nnz-balanced row blocks of
+    # THIS matrix, B resident: what `--gpus 8 --scaling strong` runs per rank besides the all-gather of B), timed alone
+    shard8 = None
+    if world == 1 and tiled:
+        try:
+            b8 = _dist.partition_rows_by_nnz(ptr, 8)
+            d8, i8, p8, s0, s1 = _dist.shard_csr(data, idx, ptr, 0, 8, b8)
+            a8 = sparse_amd.GCXS((d8.contiguous(), i8.contiguous(), p8.contiguous()), shape=(s1 - s0, K), compressed_axes=(0,))
+            for _ in range(5):
+                o8 = sparse_amd.matmul(a8, b_full)
+            shard8 = {"ms": dev_time(lambda: sparse_amd.matmul(a8, b_full), args.steps), "rows": s1 - s0, "nnz": int(d8.numel())}
+            shard8["speedup_vs_whole"] = ms_per_step / shard8["ms"]
+            del a8, o8, d8, i8, p8
+        except Exception as e:   # noqa: BLE001 - the headline line must still be printed
+            shard8 = {"error": repr(e)}
     nan_check_ms = None
     if _settings.NAN_CHECK:
         _settings.NAN_CHECK = False
@@ -394,6 +409,9 @@ def main():
                 "lds_floor_ms": nnz * N * 4 / LDS_READ_PEAK_BPS * 1e3,
                 "frac_of_lds_floor": (nnz * N * 4 / LDS_READ_PEAK_BPS * 1e3) / kernel_ms,
                 "hbm_frac_at_lds_floor": (rd + wr) / (nnz * N * 4 / LDS_READ_PEAK_BPS) / 1e9 / HBM_PEAK_GBS,
+                # a rank's share at world size 8 timed alone on this GPU (B resident, no collective): ideal strong scaling
+                # would be 8x; what is missing is the fixed part of a product (launches, the per-tile phases of a shorter grid)
+                "shard_ms_at_world8": shard8,
                 "ablation_ms": TILED_ABLATION_R03 if tiled and world == 1 and (M, K, N) == (1_000_000, 10_000, 128) else None,
                 "what": "rank 0's launch: algorithmic bytes of its row block / average of `steps` back-to-back executor launches (HIP events)",
             },
@@ -415,6 +433,9 @@ def main():
                                                   if isinstance(v, dict) and "frac" in v}
                 line["roofline"]["paths_ms"] = {k: round(v["ms"], 4) for k, v in line["paths"].items()
                                                 if isinstance(v, dict) and "ms" in v}
+                line["roofline"]["paths_pmc_over_algorithmic"] = {k: round(v["pmc_over_algorithmic"], 3) for k, v in line["paths"].items()
+                                                                  if isinstance(v, dict) and "pmc_over_algorithmic" in v}
+                line["roofline"]["paths_accounting_errors"] = line["paths"].get("_accounting_errors", [])
             except Exception as e:
                 line["paths"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)

@@ -150,6 +150,52 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
         del a64, i64, p64, r
         torch.cuda.empty_cache()
 
+    # ---- what a drop-in user runs FIRST: the stateless product, the reference's default construction,
+    # a COO operand's first product - all at config 2's size, on bench.py's own matrix ---------------------------------------
+    if int64_of is not None and (want("A1_first") or want("A2_default") or want("A3_coo")):
+        data, idx, ptr, b, M, Kd, N = int64_of
+        nnz = int(data.numel())
+        a32 = sp.GCXS((data, idx, ptr), shape=(M, Kd), compressed_axes=(0,))
+        by = nnz * 8 + (M + 1) * 4 + Kd * N * 4 + M * N * 4
+
+        def first(x, bb):
+            _dot.drop_derived(x)
+            x.__dict__.pop("_spmm_uses", None)
+            return x @ bb
+
+        ms_first, _ = timed(lambda: first(a32, b), reps=5, warm=3)
+        ms_rg, _ = timed(lambda: K.dot_csr_ndarray((M, N), data, idx, ptr, b), reps=3)
+        emit("A1_first_product", row(f"config 2, the product with NO operand state: GCXS(CSR) {M}x{Kd} ({nnz} nnz) x dense {Kd}x{N} fp32, every "
+                                     "derived layout dropped before each call (inspector + executor; warm allocator)", ms_first, by,
+                                     flops=2.0 * nnz * N, cacheless_rowgroup_ms=ms_rg, target_ms=1.1))
+        # a COO operand (canonical, int32 coordinates): row pointers from the coordinates + inspector + executor at its FIRST product
+        rows_c = K.csr_to_keys(ptr, torch.zeros_like(idx), M, 1).to(idx.dtype)
+        coo = sp.COO(torch.stack([rows_c, idx]), data, shape=(M, Kd), has_duplicates=False, sorted=True)
+        del rows_c
+        ms_coo, _ = timed(lambda: first(coo, b), reps=5, warm=3)
+        emit("A3_coo_first_product", row(f"config 2's matrix as COO ({nnz} nnz, int32 coordinates) x dense {Kd}x{N} fp32: first eligible product "
+                                         "(row pointers + inspector + executor; round 3: the cache-less kernel by policy)", ms_coo,
+                                         nnz * 12 + Kd * N * 4 + M * N * 4, flops=2.0 * nnz * N, cacheless_rowgroup_ms=ms_rg))
+        del coo
+        torch.cuda.empty_cache()
+        # the reference's default construction: float64 values, int64 indices, compressed_axes = argmin(shape) = (1,): CSC
+        # (`sparse.random(..., format="gcxs")`, _compressed/compressed.py:37-39, _utils.py:221-346)
+        a64 = sp.GCXS((data.to(torch.float64), idx.to(torch.int64), ptr.to(torch.int64)), shape=(M, Kd), compressed_axes=(0,))
+        adef = a64.change_compressed_axes((1,))
+        del a64
+        torch.cuda.empty_cache()
+        b64 = b.to(torch.float64)
+        by64 = nnz * 16 + (Kd + 1) * 8 + Kd * N * 8 + M * N * 8
+        ms_dfirst, _ = timed(lambda: first(adef, b64), reps=3, warm=2)
+        ms_dsteady, r = timed(lambda: adef @ b64, reps=5)
+        emit("A2_default_gcxs_first", row(f"config 2 as the reference constructs it by default (float64, int64, compressed_axes=(1,) = CSC, {nnz} nnz) "
+                                          f"x dense {Kd}x{N} fp64: FIRST product (CSC -> CSR twin + inspector + two-panel executor)", ms_dfirst,
+                                          by64, flops=2.0 * nnz * N))
+        emit("A2_default_gcxs_steady", row("the same operand, steady state (cached CSR twin and block stream)", ms_dsteady, by64,
+                                           flops=2.0 * nnz * N))
+        del adef, b64, r, a32
+        torch.cuda.empty_cache()
+
     # ---- shapes outside the executor's round-2 policy, on the same matrix ------------------------
     if int64_of is not None and want("A1_shapes"):
         data, idx, ptr, b, M, Kd, N = int64_of
@@ -475,7 +521,17 @@ def main():
     ap.add_argument("--quick", action="store_true", help="1/10 sizes")
     ap.add_argument("--rows", default=None, help="comma-separated row-id prefixes (A7,A3,...)")
     args = ap.parse_args()
-    res = run(quick=args.quick, only=args.rows.split(",") if args.rows else None)
+    only = args.rows.split(",") if args.rows else None
+    int64_of = None
+    if not args.quick and (only is None or any(o.startswith(("A1", "A2_default", "A3_coo")) for o in only)):
+        # the rows that run on bench.py's own config-2 operands: built here when this script runs on its own
+        from bench import make_csr_device
+
+        M, Kd, N = 1_000_000, 10_000, 128
+        data, idx, ptr = make_csr_device(M, Kd, 0.01, seed=1234, idx_dtype=torch.int32, device="cuda")
+        b = torch.rand((Kd, N), generator=torch.Generator(device="cuda").manual_seed(99), device="cuda", dtype=torch.float32)
+        int64_of = (data, idx, ptr, b, M, Kd, N)
+    res = run(quick=args.quick, only=only, int64_of=int64_of)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "paths.json"), "w") as f:
         json.dump(res, f, indent=1)

@@ -477,7 +477,14 @@ def _csr_triplet(a):
                 indptr, indices = K.keys_to_csr(keys, int(a.shape[0]), int(a.shape[1]), it)
                 view = (a.data, indices, indptr)
             else:
-                view = (a.data, a.coords[1].contiguous(), K.rows_to_indptr(a.coords[0], int(a.shape[0])))
+                cols = a.coords[1].contiguous()
+                indptr = K.rows_to_indptr(a.coords[0], int(a.shape[0]))
+                if cols.dtype == torch.int32 and a.nnz < 2 ** 31:
+                    # the row pointers (R + 1 words) in the coordinates' own width: with int64 pointers every kernel that
+                    # takes the triplet would first widen the nnz column indices (`_unify_index`: 0.3 ms and 0.8 GB at
+                    # config 2's size, and an inspector that reads 8-byte indices: 0.89 instead of 0.51 ms)
+                    indptr = indptr.to(torch.int32)
+                view = (a.data, cols, indptr)
             a._csr_view = view
         return view
     if a.compressed_axes == (0,):
@@ -489,6 +496,9 @@ def _csr_triplet(a):
     return twin
 
 
+COO_TILED_FIRST_NNZ = 20_000_000
+
+
 def _gcxs_times_dense(a, bt, out_shape):
     """GCXS or canonical 2-D COO times dense."""
     from ._coo import COO
@@ -497,10 +507,14 @@ def _gcxs_times_dense(a, bt, out_shape):
     Kd = int(a.shape[1])
     use_tiled = _tiled_eligible(data, bt, out_shape, Kd)
     if use_tiled and isinstance(a, COO) and not getattr(a, "_tiled_layouts", None):
-        # COO operands of `tensordot` are usually temporaries (an N-D array reshaped to 2-D): the inspector only pays
-        # for an array that is multiplied again, so a COO gets its block stream at its SECOND eligible product
+        # COO operands of `tensordot` are usually temporaries (an N-D array reshaped to 2-D): for small ones the inspector
+        # only pays when the array is multiplied again (config 3, 1.3 x 10^6 elements: 0.33 ms with a fresh layout per call
+        # against 0.14), so such a COO gets its block stream at its SECOND eligible product.  From COO_TILED_FIRST_NNZ stored
+        # elements on the first product already takes it: the fixed part of a fresh layout (allocations, three launches,
+        # the verdict read-back: ~0.15 ms) is then below what the executor saves over the cache-less kernel (config 2's
+        # size: inspector 0.57 + executor 0.85 ms against 2.8 ms).
         a._spmm_uses = getattr(a, "_spmm_uses", 0) + 1
-        use_tiled = a._spmm_uses >= 2
+        use_tiled = a._spmm_uses >= 2 or int(data.numel()) >= COO_TILED_FIRST_NNZ
     if use_tiled:
         # the inspector costs about one product (1.25 ms at config 2 against 0.85 ms per tiled and 2.8 ms per
         # row-group product), so it runs at the first eligible product and is cached on the array

@@ -151,7 +151,11 @@ sddmm_panel_kernel(int64_t nnz, int cap, const I* __restrict__ rows, const I* __
   const bool mine = tid < nblk;
   const int64_t nl = pb + (mine ? tid : 0);
   const I myrow = __builtin_nontemporal_load(rows + nl);
+#if defined(SDP_ABL) && SDP_ABL == 2   // timing ablation (wrong results): every Bt row comes from a 16-row set (no L2 gather)
+  const I mycol = __builtin_nontemporal_load(cols + nl) & 15;
+#else
   const I mycol = __builtin_nontemporal_load(cols + nl);
+#endif
   const TS mys = __builtin_nontemporal_load(s_data + nl);
   const int64_t mypos = __builtin_nontemporal_load(perm + nl);
 
@@ -208,7 +212,11 @@ sddmm_panel_kernel(int64_t nnz, int cap, const I* __restrict__ rows, const I* __
   ACC res = 0;
   B0::template dot<0>(cnt, sub, bv0, sl0, rr0, sa, cap, Ab, lda_b, koff_b, res);
   SdpStep<TIN, I, LPN, KS, UNR, UNR>::run(cnt, sub, myrow, mycol, myslot, sa, cap, Ab, Bb, lda_b, ldb_b, koff_b, res);
+#if defined(SDP_ABL) && SDP_ABL == 1   // timing ablation (wrong order): results stored in panel order, coalesced
+  if (mine) __builtin_nontemporal_store((TS)((ACC)mys * res), out + nl + (mypos & 0));
+#else
   if (mine) __builtin_nontemporal_store((TS)((ACC)mys * res), out + mypos);  // scattered: keep these lines out of the panel's way
+#endif
 }
 
 template <typename TIN, typename TS, typename I>

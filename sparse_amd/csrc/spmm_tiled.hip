@@ -435,21 +435,42 @@ __device__ __forceinline__ void tl_phases(const int* stream, int t0, int te, int
 #undef TL_PHASES_OPERANDS
 }
 
+__device__ __forceinline__ void tl_block_map(unsigned L, int npanels, int nblocks, int& bx, int& by) {
+  const unsigned pin = npanels > 1 ? 2u : 1u;
+  const unsigned per_chunk = (unsigned)((nblocks + 7) / 8) * 8u * pin;
+  const unsigned chunk = L / per_chunk, l = L % per_chunk;
+  const unsigned seq = l >> 3;
+  // (the unsigned divisions are done on the vector unit: back to SGPRs, the asm blocks take B's descriptor as scalars)
+  by = uniform((int)(chunk * pin + seq % pin));
+  bx = uniform((int)((seq / pin) * 8u + (l & 7u)));
+}
+
 // DBG (timing ablation): 2 = no tile DMA.  MODE: see tl_phases.
 template <int DBG, int MODE, typename T>
 __global__ void __launch_bounds__(TL_WAVES * 64) __attribute__((amdgpu_num_vgpr(TL_ASM_COMP)))
 spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, int touch_lines, const int* __restrict__ stream,
                   const int* __restrict__ blk_off, const T* __restrict__ b, int64_t ldb,
-                  T* __restrict__ out, int64_t ldo, int last_cols) {
+                  T* __restrict__ out, int64_t ldo, int last_cols, int npanels, int nblocks) {
   constexpr int PANEL = TlFmt<T>::PANEL;            // columns per workgroup: 512 bytes of every B row
   constexpr int CPL = PANEL / 64;                   // columns per lane
   extern __shared__ __attribute__((aligned(16))) char lds[];  // the only LDS object: starts at LDS byte 0
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = uniform(tid >> 6);
-  const int64_t g = (int64_t)blockIdx.x * TL_WAVES + wv;  // my row group (lists exist for every wave of the grid)
-  b += (int64_t)blockIdx.y * PANEL;                        // column panel of B and of the result
-  out += (int64_t)blockIdx.y * PANEL;
+  // Workgroup -> (block of row groups, column panel), PAIRS of panels innermost on one XCD: workgroup L runs on XCD L % 8
+  // (observed; only speed depends on it).  The panels are taken two at a time (chunk = L / per_chunk); inside a chunk the
+  // L / 8-th workgroup of an XCD takes panel (L / 8) % 2 of row-group block ((L / 8) / 2) * 8 + L % 8: the two panels of one
+  // block are dispatched back to back to the same XCD, so the block stream that the first pulls from HBM is an L2 hit for
+  // the second (a (blocks, panels) grid runs ALL blocks of panel 0 first: float64 at N = 128 then read its stream twice
+  // from HBM, 4.4 GB of fabric reads against 2.2 GB algorithmic, 2.1-2.25 ms; pairs 1.95 ms).  Not more than two: every
+  // panel in flight on an XCD is another 5 MB of B competing for its 4 MiB L2 (all eight panels of N = 512 innermost: 5.5
+  // against 5.0 ms).
+  int bx, by;
+  tl_block_map(blockIdx.x, npanels, nblocks, bx, by);
+  if (bx >= nblocks || by >= npanels) return;              // (whole rounds of the eight XCDs, whole pairs of panels)
+  const int64_t g = (int64_t)bx * TL_WAVES + wv;           // my row group (lists exist for every wave of the grid)
+  b += (int64_t)by * PANEL;                                // column panel of B and of the result
+  out += (int64_t)by * PANEL;
 
   asm volatile(TL_ASM_ZERO ::: "memory", TL_CLOB_ACC);
 
@@ -539,7 +560,9 @@ spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, int touch_lines, const int* 
   // a result narrower than a whole number of panels: the last panel stores its first `last_cols` columns only (B is
   // zero-padded to whole panels by the caller, C is not: no padded result, no slice pass afterwards); the store block
   // runs under the branch's exec mask
-  const int ncols = (last_cols > 0 && blockIdx.y == gridDim.y - 1) ? last_cols : PANEL;
+  int bx2, by2;   // (recomputed from the kernel arguments: nothing of the mapping stays live across the asm blocks, whose
+  tl_block_map(blockIdx.x, npanels, nblocks, bx2, by2);   //  scalar operands leave the compiler s0..s35)
+  const int ncols = (last_cols > 0 && by2 == npanels - 1) ? last_cols : PANEL;
   if (lane * CPL < ncols)
     asm volatile(TL_ASM_STORE
                  :
@@ -729,9 +752,12 @@ static int tl_launch(KERN kern, int64_t M, int64_t K, int64_t N, const int* bloc
   // the 160 KB dynamic-LDS opt-in is a per-function attribute: set once per kernel, not on every multiply
   if (int rc = tl_set_lds_once(reinterpret_cast<const void*>(kern))) return rc;
   const int64_t blocks_n = tl_grid_groups(M) / TL_WAVES;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks_n, (unsigned)(N / TlFmt<T>::PANEL)), dim3(TL_WAVES * 64), TL_LDS, s, M, K,
+  const int64_t npanels = N / TlFmt<T>::PANEL;
+  const int64_t grid = ceil_div(blocks_n, (int64_t)8) * 8 * (npanels > 1 ? ceil_div(npanels, (int64_t)2) * 2 : 1);
+  if (grid >= ((int64_t)1 << 31) || blocks_n >= ((int64_t)1 << 31)) return SPAMD_EINVAL;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(TL_WAVES * 64), TL_LDS, s, M, K,
                      (int)ceil_div(K, (int64_t)TL_KB), touch_lines | (group_ends ? 1 << 16 : 0), blocks, blk_off, b, ldb, out, ldo,
-                     last_cols);
+                     last_cols, (int)npanels, (int)blocks_n);
   return launch_status();
 }
 
