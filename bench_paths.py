@@ -219,10 +219,14 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
                                    p5 * 8 + (m5 + 1) * 4 + Kd * N * 4 + m5 * N * 4, flops=2.0 * p5 * N, tiled_forced_ms=ms_tl))
         di = (data * 100).to(torch.int32)
         bi = (b * 10).to(torch.int32)
-        ms_i, _ = timed(lambda: K.dot_csr_ndarray((M, N), di, idx, ptr, bi), reps=5)
-        emit("A1_shapes_int32_values", row(f"config-2 matrix with int32 values x dense {Kd}x{N} int32 (exact integer products: the "
-                                           f"row-group kernel, no executor variant)", ms_i, nnz * 8 + (M + 1) * 4 + Kd * N * 4 + M * N * 4,
-                                           flops=2.0 * nnz * N))
+        ms_irg, _ = timed(lambda: K.dot_csr_ndarray((M, N), di, idx, ptr, bi), reps=5)
+        ai = sp.GCXS((di, idx, ptr), shape=(M, Kd), compressed_axes=(0,))
+        ms_i, ri = timed(lambda: ai @ bi, reps=10, warm=3)
+        emit("A1_shapes_int32_values", row(f"config-2 matrix with int32 values x dense {Kd}x{N} int32 (exact wrap-around products; round 4: the "
+                                           f"executor's int32 variant, v_mul_lo_u32 + v_add_u32 on the float32 layout)", ms_i,
+                                           nnz * 8 + (M + 1) * 4 + Kd * N * 4 + M * N * 4, flops=2.0 * nnz * N, rowgroup_ms=ms_irg,
+                                           identical_to_rowgroup=bool(torch.equal(ri, K.dot_csr_ndarray((M, N), di, idx, ptr, bi)))))
+        del ai, ri
         # matrix x vector and results of 2..4 columns: the row-vector kernel (lanes along the row; B in LDS when it fits)
         for n_v, dt_v in ((1, torch.float32), (2, torch.float32), (4, torch.float32), (1, torch.float64)):
             dv = data if dt_v == torch.float32 else data.to(dt_v)

@@ -45,6 +45,9 @@ extern "C" {
 #define SPAMD_TILED_GROUP_ENDS 2u /* spamd_spmm_tiled: blk_off has tiles + 1 entries per row group (spamd_spmm_tiled_inspect) */
 #define SPAMD_EXACT_MULADD 1u /* separate IEEE mul + add (bit-exact vs the reference's
                                  non-contracted loop) instead of fused multiply-add */
+#define SPAMD_TILED_INT32 8u /* spamd_spmm_tiled with val_dtype SPAMD_F32: the stream's values, B and the result are int32 BIT
+                             * PATTERNS (the inspector only moves value bits: build the stream from the int32 values viewed
+                             * as float32); products and sums wrap around like NumPy's int32 (`_dot_dtype`, _common.py:635) */
 #define SPAMD_SPMM_ROWGROUP 4u /* spamd_spmm_csr: the k-ascending row-group kernel whatever the shape (no row-vector, no LDS-resident-B path) */
 
 /* Library/ABI version: major*10000 + minor*100 + patch. */
@@ -142,7 +145,7 @@ int spamd_spmm_tiled_pack(int val_dtype, int64_t nnz, const int64_t* tiled_keys_
                           const int64_t* seg_start, const int64_t* blk_off, int64_t total_blocks, int* blocks,
                           void* stream);
 /* executor.  N = the PADDED width (whole panels; B provides that many columns, zero-padded).  flags: SPAMD_EXACT_MULADD,
- * SPAMD_TILED_GROUP_ENDS, bits 8..15 = lines of a list to prefetch (0: default), bits 16..23 = columns of the LAST panel
+ * SPAMD_TILED_GROUP_ENDS, SPAMD_TILED_INT32, bits 8..15 = lines of a list to prefetch (0: default), bits 16..23 = columns of the LAST panel
  * that are stored (0: all) - a narrower result is then written without padding: `out` holds N - panel + that many
  * columns per row (even for float32). */
 int spamd_spmm_tiled(int val_dtype, int64_t M, int64_t K, int64_t N, const int* blocks, const int* blk_off32,

@@ -331,6 +331,8 @@ def _tiled_dtype(data, bt):
         return torch.float32
     if {data.dtype, bt.dtype} <= {torch.float32, torch.float64}:
         return torch.float64
+    if data.dtype == torch.int32 and bt.dtype == torch.int32:
+        return torch.int32      # (round 4: exact wrap-around products, the executor's int32 variant)
     return None
 
 
@@ -350,7 +352,7 @@ def _tiled_eligible(data, bt, out_shape, Kd):
     if _settings.TILED_SPMM == "never" or bt.dim() != 2:
         return False
     dt = _tiled_dtype(data, bt)
-    if dt is None or N < (8 if dt == torch.float32 else 5):   # narrower results: the row-group / row-vector kernels
+    if dt is None or N < (5 if dt == torch.float64 else 8):   # narrower results: the row-group / row-vector kernels
         return False
     if (Kd + 512) * N * bt.element_size() >= (1 << 32):   # the executor walks B with 32-bit byte offsets (buffer-form tile DMA)
         return False
@@ -521,7 +523,7 @@ def _gcxs_times_dense(a, bt, out_shape):
         dt = _tiled_dtype(data, bt)
         prepare_spmm(a, dt)
         M, N = out_shape
-        panel = 128 if dt == torch.float32 else 64
+        panel = 64 if dt == torch.float64 else 128
         bt = bt.to(dt)
         if N % panel:
             # a workgroup covers whole 512-byte column panels: B (small) is zero-padded to the next panel; the result is
@@ -530,7 +532,7 @@ def _gcxs_times_dense(a, bt, out_shape):
             npad = -(-N // panel) * panel
             bp = torch.zeros((Kd, npad), dtype=dt, device=bt.device)
             bp[:, :N] = bt
-            if dt == torch.float32 and N % 2:
+            if dt != torch.float64 and N % 2:
                 return _tiled_product(a, dt, (M, npad), Kd, bp)[:, :N].contiguous()
             return _tiled_product(a, dt, (M, N), Kd, bp)
         return _tiled_product(a, dt, out_shape, Kd, bt)

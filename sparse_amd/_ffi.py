@@ -17,6 +17,7 @@ F32, F64, I32, I64, BF16, U8 = 0, 1, 2, 3, 4, 5
 MAX_NDIM = 16
 EXACT_MULADD = 1
 TILED_GROUP_ENDS = 2
+TILED_INT32 = 8
 SPMM_ROWGROUP = 4
 
 _lib = None

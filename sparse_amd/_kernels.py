@@ -1062,11 +1062,18 @@ def tiled_params(dtype=torch.float32):
     """(rows per group, B rows per tile, groups per workgroup, entries per block, slack blocks, max tiles of the
     direct inspector, columns per panel) for float32 / float64 values."""
     v = [_ct.c_int(0) for _ in range(7)]
-    _ffi.call("spamd_spmm_tiled_params", code_of(torch_dtype(dtype)), *[_ct.byref(x) for x in v])
+    _ffi.call("spamd_spmm_tiled_params", code_of(_tiled_layout_dtype(torch_dtype(dtype))), *[_ct.byref(x) for x in v])
     return tuple(x.value for x in v)
 
 
-TILED_DTYPES = (torch.float32, torch.float64)
+TILED_DTYPES = (torch.float32, torch.float64, torch.int32)
+
+
+def _tiled_layout_dtype(dtype):
+    """int32 values travel in the float32 layout (the inspector only moves value bits; the executor's int32 variant does
+    the arithmetic: SPAMD_TILED_INT32)"""
+    return torch.float32 if dtype == torch.int32 else dtype
+
 _TOUCH_OVERRIDE = int(__import__("os").environ.get("SPARSE_AMD_TILED_TOUCH", "0"))   # tuning hook: lines prefetched per list
 
 
@@ -1105,7 +1112,7 @@ def csr_tiled_layout(a_data, a_indices, a_indptr, M, Kd, force_sort=False, dtype
     if dtype is None:
         dtype = a_data.dtype if a_data.dtype in TILED_DTYPES else torch.float32
     dtype = torch_dtype(dtype)
-    vc = code_of(dtype)
+    vc = code_of(_tiled_layout_dtype(dtype))
     rg, kb, gpb, epb, slack, direct_max, _ = tiled_params(dtype)
     nnz = int(a_data.numel())
     ntiles = -(-Kd // kb)
@@ -1113,6 +1120,8 @@ def csr_tiled_layout(a_data, a_indices, a_indptr, M, Kd, force_sort=False, dtype
     nseg = groups * ntiles
     s = stream_ptr(dev)
     vals = a_data.to(dtype).contiguous()
+    if dtype == torch.int32:
+        vals = vals.view(torch.float32)
     if not index_dtype_ok(a_indices) or a_indices.dtype != a_indptr.dtype:
         a_indices, a_indptr = a_indices.to(torch.int64), a_indptr.to(torch.int64)
 
@@ -1171,8 +1180,8 @@ def dot_csr_ndarray_tiled(layout, out_shape, Kd, b, out=None, exact=False):
     blocks, blk_off, dtype = layout
     M, N = int(out_shape[0]), int(b.shape[1])
     Nout = int(out_shape[1])
-    panel = 128 if dtype == torch.float32 else 64
-    if N % panel or not (N - panel < Nout <= N) or (dtype == torch.float32 and Nout % 2):
+    panel = 64 if dtype == torch.float64 else 128
+    if N % panel or not (N - panel < Nout <= N) or (dtype != torch.float64 and Nout % 2):
         raise ValueError(f"tiled executor: B has {N} columns (whole {panel}-column panels expected), result {Nout}")
     last_cols = (Nout - (N - panel)) % panel    # 0 = the whole last panel
     dev = require_hip(blocks, blk_off, b)
@@ -1188,8 +1197,9 @@ def dot_csr_ndarray_tiled(layout, out_shape, Kd, b, out=None, exact=False):
     if _TOUCH_OVERRIDE:
         hint = _TOUCH_OVERRIDE
     ends = _ffi.TILED_GROUP_ENDS if getattr(layout, "group_ends", False) else 0
-    _ffi.call("spamd_spmm_tiled", code_of(dtype), M, Kd, N, ptr(blocks), ptr(blk_off), ptr(b), N, ptr(out), Nout,
-              (_ffi.EXACT_MULADD if exact else 0) | ends | (hint << 8) | (last_cols << 16), stream_ptr(dev))
+    ints = _ffi.TILED_INT32 if dtype == torch.int32 else 0
+    _ffi.call("spamd_spmm_tiled", code_of(_tiled_layout_dtype(dtype)), M, Kd, N, ptr(blocks), ptr(blk_off), ptr(b), N, ptr(out), Nout,
+              (_ffi.EXACT_MULADD if exact and not ints else 0) | ends | ints | (hint << 8) | (last_cols << 16), stream_ptr(dev))
     pending = getattr(layout, "pending", None)
     if pending is not None:   # first product of a layout built with defer_check: the verdict is read now, behind the launch
         layout.pending = None

@@ -28,6 +28,9 @@ namespace spamd {
 #ifndef SDP_BLK
 #define SDP_BLK 256   // elements (= threads) per workgroup
 #endif
+#ifndef SDP_CHUNKS
+#define SDP_CHUNKS 1   // chunks of SDP_BLK elements per workgroup (the next chunk's mask arrays are prefetched)
+#endif
 #ifndef SDP_NT_A
 #define SDP_NT_A 0   // 1: A rows with the non-temporal hint (they then come from HBM instead of the Infinity Cache)
 #endif
@@ -134,89 +137,107 @@ sddmm_panel_kernel(int64_t nnz, int cap, const I* __restrict__ rows, const I* __
   I* const drow = srow + BLK;
   int* const wtot = reinterpret_cast<int*>(drow + BLK);
   const int tid = threadIdx.x;
-  // this workgroup's BLK elements [pb, pe).  XCD-private panels (xstate = first[9]): the order is XCD-major and workgroup b
-  // takes piece b / 8 of the range of XCD b % 8 - the XCD it is observed to run on; only speed depends on that.
-  int64_t pb, pe;
+  // this workgroup's SDP_CHUNKS x BLK consecutive elements, BLK at a time.  XCD-private panels (xstate = first[9]): the order
+  // is XCD-major and workgroup b takes piece b / 8 of the range of XCD b % 8 - the XCD it is observed to run on; only speed
+  // depends on that.  The mask arrays of chunk c + 1 are requested before chunk c is computed (one HBM latency less on the
+  // chain of every chunk but the first).
+  int64_t wb, we;
   if (xstate) {
     const int x = (int)(blockIdx.x & 7u);
     const int64_t lo = xstate[x], hi = xstate[x + 1];
-    pb = lo + (int64_t)(blockIdx.x >> 3) * BLK;
-    if (pb >= hi) return;
-    pe = pb + BLK < hi ? pb + BLK : hi;
+    wb = lo + (int64_t)(blockIdx.x >> 3) * (BLK * SDP_CHUNKS);
+    we = wb + BLK * SDP_CHUNKS < hi ? wb + BLK * SDP_CHUNKS : hi;
   } else {
-    pb = (int64_t)blockIdx.x * BLK;
-    pe = pb + BLK < nnz ? pb + BLK : nnz;
+    wb = (int64_t)blockIdx.x * (BLK * SDP_CHUNKS);
+    we = wb + BLK * SDP_CHUNKS < nnz ? wb + BLK * SDP_CHUNKS : nnz;
   }
-  const int nblk = (int)(pe - pb);
-  const bool mine = tid < nblk;
-  const int64_t nl = pb + (mine ? tid : 0);
-  const I myrow = __builtin_nontemporal_load(rows + nl);
-#if defined(SDP_ABL) && SDP_ABL == 2   // timing ablation (wrong results): every Bt row comes from a 16-row set (no L2 gather)
-  const I mycol = __builtin_nontemporal_load(cols + nl) & 15;
-#else
-  const I mycol = __builtin_nontemporal_load(cols + nl);
-#endif
-  const TS mys = __builtin_nontemporal_load(s_data + nl);
-  const int64_t mypos = __builtin_nontemporal_load(perm + nl);
-
-  // distinct rows of the workgroup's elements: heads of runs of equal rows, numbered by a block scan
-  srow[tid] = myrow;
-  __syncthreads();
-  const int head = (mine && (tid == 0 || srow[tid - 1] != myrow)) ? 1 : 0;
-  const int lane = tid & 63, wv = tid >> 6;
-  int incl = head;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int n = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += n;
-  }
-  if (lane == 63) wtot[wv] = incl;
-  __syncthreads();
-  int wbase = 0, ndist = 0;
-#pragma unroll
-  for (int w = 0; w < BLK / 64; ++w) {
-    if (w < wv) wbase += wtot[w];
-    ndist += wtot[w];
-  }
-  const int myslot = wbase + incl - 1;   // slot of my element's row (>= 0 for every valid element)
-  if (head) drow[myslot] = myrow;
-  __syncthreads();
-
+  if (wb >= we) return;
   const char* const Ab = reinterpret_cast<const char*>(A);
   const char* const Bb = reinterpret_cast<const char*>(Bt);
   const int64_t lda_b = lda * (int64_t)sizeof(TIN), ldb_b = ldb * (int64_t)sizeof(TIN);
+  const int lane = tid & 63, wv = tid >> 6;
   const int sub = lane % LPN;
   const int grp = tid / LPN;
-  int cnt = nblk - grp * LPN;               // elements of my lane group (uniform inside the group)
-  cnt = cnt < 0 ? 0 : (cnt > LPN ? LPN : cnt);
   const int koff_b = sub * 16;
-  // The Bt rows of the lane group's first batch are requested first (into registers), then ONE burst of LDS-DMA brings the
-  // staged A rows straight into LDS (no staging registers: `global_load_lds_dwordx4`, a wave-instruction moves 1 KB =
-  // 64 consecutive 16-byte vectors of the staged area); both are in flight together and waited for once.
-  const int nstage = ndist < cap ? ndist : cap;
-  const int nvec = nstage * VPR;   // (>= VPR: the workgroup has at least one element)
-  using B0 = SdpBatch<TIN, I, LPN, KS, UNR, 0>;
-  VT bv0[UNR][KS];
-  int sl0[UNR];
-  I rr0[UNR];
-  B0::template load<0>(bv0, sl0, rr0, myrow, mycol, myslot, Bb, ldb_b, koff_b);
-  for (int base = uniform(wv) * 64; base < nvec; base += BLK) {   // wave-uniform trip count; lanes past the end repeat the last vector
-    int i = base + lane;
-    i = i < nvec ? i : nvec - 1;
-    const char* ap = Ab + ((int64_t)drow[i / VPR] * lda_b + (int64_t)(i % VPR) * 16);
-    sdp_dma16((unsigned)uniform(base) * 16u, ap);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  sdp_lds_barrier();
-
-  ACC res = 0;
-  B0::template dot<0>(cnt, sub, bv0, sl0, rr0, sa, cap, Ab, lda_b, koff_b, res);
-  SdpStep<TIN, I, LPN, KS, UNR, UNR>::run(cnt, sub, myrow, mycol, myslot, sa, cap, Ab, Bb, lda_b, ldb_b, koff_b, res);
-#if defined(SDP_ABL) && SDP_ABL == 1   // timing ablation (wrong order): results stored in panel order, coalesced
-  if (mine) __builtin_nontemporal_store((TS)((ACC)mys * res), out + nl + (mypos & 0));
+  auto fetch = [&](int64_t pb, I& r, I& c, TS& sv, int64_t& pos) {
+    const int64_t nl = pb + tid < we ? pb + tid : we - 1;
+    r = __builtin_nontemporal_load(rows + nl);
+#if defined(SDP_ABL) && SDP_ABL == 2   // timing ablation (wrong results): every Bt row comes from a 16-row set (no L2 gather)
+    c = __builtin_nontemporal_load(cols + nl) & 15;
 #else
-  if (mine) __builtin_nontemporal_store((TS)((ACC)mys * res), out + mypos);  // scattered: keep these lines out of the panel's way
+    c = __builtin_nontemporal_load(cols + nl);
 #endif
+    sv = __builtin_nontemporal_load(s_data + nl);
+    pos = __builtin_nontemporal_load(perm + nl);
+  };
+  I nrow, ncol;
+  TS ns;
+  int64_t npos;
+  fetch(wb, nrow, ncol, ns, npos);
+#pragma unroll 1
+  for (int64_t pb = wb; pb < we; pb += BLK) {
+    const int64_t pe = pb + BLK < we ? pb + BLK : we;
+    const int nblk = (int)(pe - pb);
+    const bool mine = tid < nblk;
+    const int64_t nl = pb + (mine ? tid : 0);
+    const I myrow = nrow, mycol = ncol;
+    const TS mys = ns;
+    const int64_t mypos = npos;
+    if (SDP_CHUNKS > 1 && pe < we) fetch(pe, nrow, ncol, ns, npos);
+
+    // distinct rows of the chunk's elements: heads of runs of equal rows, numbered by a block scan
+    srow[tid] = myrow;
+    __syncthreads();
+    const int head = (mine && (tid == 0 || srow[tid - 1] != myrow)) ? 1 : 0;
+    int incl = head;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int n = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += n;
+    }
+    if (lane == 63) wtot[wv] = incl;
+    __syncthreads();
+    int wbase = 0, ndist = 0;
+#pragma unroll
+    for (int w = 0; w < BLK / 64; ++w) {
+      if (w < wv) wbase += wtot[w];
+      ndist += wtot[w];
+    }
+    const int myslot = wbase + incl - 1;   // slot of my element's row (>= 0 for every valid element)
+    if (head) drow[myslot] = myrow;
+    __syncthreads();
+
+    int cnt = nblk - grp * LPN;               // elements of my lane group (uniform inside the group)
+    cnt = cnt < 0 ? 0 : (cnt > LPN ? LPN : cnt);
+    // The Bt rows of the lane group's first batch are requested first (into registers), then ONE burst of LDS-DMA brings the
+    // staged A rows straight into LDS (no staging registers: `global_load_lds_dwordx4`, a wave-instruction moves 1 KB =
+    // 64 consecutive 16-byte vectors of the staged area); both are in flight together and waited for once.
+    const int nstage = ndist < cap ? ndist : cap;
+    const int nvec = nstage * VPR;   // (>= VPR: the chunk has at least one element)
+    using B0 = SdpBatch<TIN, I, LPN, KS, UNR, 0>;
+    VT bv0[UNR][KS];
+    int sl0[UNR];
+    I rr0[UNR];
+    B0::template load<0>(bv0, sl0, rr0, myrow, mycol, myslot, Bb, ldb_b, koff_b);
+    for (int base = uniform(wv) * 64; base < nvec; base += BLK) {   // wave-uniform trip count; lanes past the end repeat the last vector
+      int i = base + lane;
+      i = i < nvec ? i : nvec - 1;
+      const char* ap = Ab + ((int64_t)drow[i / VPR] * lda_b + (int64_t)(i % VPR) * 16);
+      sdp_dma16((unsigned)uniform(base) * 16u, ap);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    sdp_lds_barrier();
+
+    ACC res = 0;
+    B0::template dot<0>(cnt, sub, bv0, sl0, rr0, sa, cap, Ab, lda_b, koff_b, res);
+    SdpStep<TIN, I, LPN, KS, UNR, UNR>::run(cnt, sub, myrow, mycol, myslot, sa, cap, Ab, Bb, lda_b, ldb_b, koff_b, res);
+#if defined(SDP_ABL) && SDP_ABL == 1   // timing ablation (wrong order): results stored in panel order, coalesced
+    if (mine) __builtin_nontemporal_store((TS)((ACC)mys * res), out + nl + (mypos & 0));
+#else
+    if (mine) __builtin_nontemporal_store((TS)((ACC)mys * res), out + mypos);  // scattered: keep these lines out of the panel's way
+#endif
+    if (SDP_CHUNKS > 1) __syncthreads();   // (the next chunk re-uses the staged rows' LDS)
+  }
 }
 
 template <typename TIN, typename TS, typename I>
@@ -235,8 +256,8 @@ static int launch_panel(int64_t nnz, const I* rows, const I* cols, const TS* s, 
     int cap = cap_rows > 0 ? (int)cap_rows : std::max(16, (24 << 10) / rowb);
     const int blk = SDP_BLK;
     if (cap > blk) cap = blk;
-    int64_t blocks = ceil_div(nnz, (int64_t)blk);
-    if (xstate) blocks = 8 * std::max<int64_t>(ceil_div(xmax, (int64_t)blk), 1);
+    int64_t blocks = ceil_div(nnz, (int64_t)blk * SDP_CHUNKS);
+    if (xstate) blocks = 8 * std::max<int64_t>(ceil_div(xmax, (int64_t)blk * SDP_CHUNKS), 1);
     // (+ 1 KB: the last LDS-DMA instruction of the staging burst always writes a whole KB)
     const size_t lds = (size_t)cap * rowb + 1024 + 2 * blk * sizeof(I) + 16;
 #define SDP(LL, KK, UU)                                                                                        \

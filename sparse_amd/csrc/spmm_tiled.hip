@@ -406,7 +406,8 @@ __device__ __forceinline__ void tl_dma16(unsigned lds_base, const void* src) {
 // t+1 (if t+1 < nfull), the scalar request for the first blocks of list t+1, the line touch of list t+2,
 // the DMA wait and the barrier.  o(t) = lane (min(t, ntiles) - obase) of `offreg`; o0..o2 = o(t0..t0+2).
 // MODE: 0 one fma per term, 3 separate multiply and add (the reference's arithmetic, bit for bit); 4 / 5 the same
-// for float64 (5-entry blocks, one column per lane); 1 no fma, 2 no LDS reads / fma (timing ablations).
+// for float64 (5-entry blocks, one column per lane); 6 int32 values and B in the float32 layout (v_mul_lo_u32 + v_add_u32:
+// NumPy's wrap-around int32 arithmetic); 1 no fma, 2 no LDS reads / fma (timing ablations).
 template <int MODE>
 __device__ __forceinline__ void tl_phases(const int* stream, int t0, int te, int o0, int o1, int o2, int offreg, int obase,
                                           int ntiles, int nfull, int toff, int mask, unsigned m0wave,
@@ -420,7 +421,9 @@ __device__ __forceinline__ void tl_phases(const int* stream, int t0, int te, int
     [obase] "s"(obase), [ntiles] "s"(ntiles), [nfull] "s"(nfull), [m0wave] "s"(m0wave), [step] "s"(row_step),      \
     [toff] "v"(toff), [lane8] "v"(lane8), [mask] "v"(mask), [offreg] "v"(offreg), [voff] "v"(voff), [srd] "s"(srd)  \
   : "memory", "m0", "scc", "vcc", TL_CLOB_SGPR, TL_CLOB_TMP, TL_CLOB_ACC
-  if (MODE == 4)
+  if (MODE == 6)
+    asm volatile(TL_ASM_PHASES_I32 : TL_PHASES_OPERANDS);
+  else if (MODE == 4)
     asm volatile(TL_ASM_PHASES_F64 : TL_PHASES_OPERANDS);
   else if (MODE == 5)
     asm volatile(TL_ASM_PHASES_F64_EXACT : TL_PHASES_OPERANDS);
@@ -774,6 +777,8 @@ extern "C" int spamd_spmm_tiled(int val_dtype, int64_t M, int64_t K, int64_t N, 
   hipStream_t s = (hipStream_t)stream;
   const bool exact = (flags & SPAMD_EXACT_MULADD) != 0;
   const bool ends = (flags & SPAMD_TILED_GROUP_ENDS) != 0;
+  const bool i32 = (flags & SPAMD_TILED_INT32) != 0;   // the stream's values, B and the result are int32 bit patterns
+  if (i32 && val_dtype != SPAMD_F32) return SPAMD_EINVAL;
   // flags bits 16..23: columns of the LAST panel that are stored (0 = the whole panel).  N stays the padded width (whole
   // panels, which is what B must provide: the tile DMA reads 512 bytes of every row of B per panel); `out` then needs room for
   // N - panel + that many columns per row only.  Even for float32 (a lane stores two columns).
@@ -803,6 +808,7 @@ extern "C" int spamd_spmm_tiled(int val_dtype, int64_t M, int64_t K, int64_t N, 
   if (dbg == 6) return tl_launch<float>(&spmm_tiled_kernel<0, 2, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s);
   if (dbg == 7) return tl_launch<float>(&spmm_tiled_kernel<2, 2, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s);
 #endif
+  if (i32) return tl_launch<float>(&spmm_tiled_kernel<0, 6, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s);
   return exact ? tl_launch<float>(&spmm_tiled_kernel<0, 3, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s)
                : tl_launch<float>(&spmm_tiled_kernel<0, 0, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s);
 }

@@ -183,3 +183,53 @@ def test_merge_workspace_survives_an_abandoned_call(sp):
         _umath._MergeWorkspace.wait_total = real
     for _ in range(3):
         assert _same_sparse(ref, x + y)
+
+
+# ---- int32 values through the inspector / executor (round 4) --------------------------------------------------------------
+
+def test_int32_executor_equals_the_row_group_kernel_and_numpy(sp):
+    """`_dot_dtype` makes int32 x int32 -> int32 with wrap-around (reference test_compressed_2d.py:18-47 runs integer
+    operands); the executor's int32 variant (v_mul_lo_u32 + v_add_u32 on the float32 layout) must give the row-group
+    kernel's bits - and NumPy's, overflow included."""
+    from sparse_amd import _kernels as K
+    import scipy.sparse as sps
+
+    rng = np.random.default_rng(5)
+    M, Kd = 70_000, 3000
+    for N, big in ((128, False), (40, True), (256, False), (6, False)):
+        x = sps.random(M, Kd, density=0.01, format="csr", random_state=rng, dtype=np.float64)
+        x.sort_indices()
+        hi = 2 ** 31 - 1 if big else 1000
+        data = rng.integers(-hi, hi, size=x.nnz, dtype=np.int64).astype(np.int32)
+        b = rng.integers(-hi, hi, size=(Kd, N), dtype=np.int64).astype(np.int32)
+        td, ti, tp, tb = (torch.from_numpy(v).to("cuda:0") for v in (data, x.indices.astype(np.int32), x.indptr.astype(np.int32), b))
+        want = K.dot_csr_ndarray((M, N), td, ti, tp, tb)
+        if N >= 8:
+            lay = K.csr_tiled_layout(td, ti, tp, M, Kd, dtype=torch.int32)
+            assert lay[2] == torch.int32
+            npad = -(-N // 128) * 128
+            bp = torch.zeros((Kd, npad), dtype=torch.int32, device="cuda:0")
+            bp[:, :N] = tb
+            got = K.dot_csr_ndarray_tiled(lay, (M, N), Kd, bp)
+            assert got.dtype == torch.int32 and torch.equal(got, want), N
+        a = sp.GCXS((td, ti, tp), shape=(M, Kd), compressed_axes=(0,))
+        through = a @ tb
+        assert through.dtype == torch.int32 and torch.equal(through, want), N
+        # NumPy (int64 accumulate, wrapped to int32 = two's complement arithmetic mod 2^32) on a sample of rows
+        pick = rng.choice(M, 300, replace=False)
+        ref = (sps.csr_matrix((data.astype(np.int64), x.indices, x.indptr), shape=(M, Kd))[pick] @ b.astype(np.int64))
+        ref = np.asarray(ref).astype(np.int64).astype(np.int32) if not big else None
+        if ref is not None:
+            assert np.array_equal(want.cpu().numpy()[pick], ref), N
+
+
+def test_int32_product_takes_the_executor(sp):
+    from sparse_amd import _dot
+
+    a = sp.random((131072, 4000), density=0.01, random_state=2, dtype=np.float32, idx_dtype=np.int32, format="gcxs", compressed_axes=(0,))
+    ai = sp.GCXS(((a.data * 100).to(torch.int32), a.indices, a.indptr), shape=a.shape, compressed_axes=(0,))
+    b = torch.randint(-50, 50, (4000, 128), device=a.data.device, dtype=torch.int32)
+    r1 = ai @ b
+    assert torch.int32 in ai.__dict__.get("_tiled_layouts", {})
+    from sparse_amd import _kernels as K
+    assert torch.equal(r1, K.dot_csr_ndarray((131072, 128), ai.data, ai.indices, ai.indptr, b))

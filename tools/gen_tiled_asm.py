@@ -24,6 +24,7 @@ import os
 
 ENTRIES = 8      # entries per 16-dword block: 8 x (d0, f32 value) or, for f64, 5 d0 + pad + 5 x (value lo, hi)
 F64 = False
+I32 = False      # int32 values and B (wrap-around arithmetic): the float32 layout, the "exact" structure with integer opcodes
 RING = (40, 56, 72)
 ROWS = int(os.environ.get("TL_RG", "35"))     # rows per wave: 2 accumulator registers each, v[128 - 2*ROWS : 128)
 WAVES = int(os.environ.get("TL_WAVES", "16"))  # waves per workgroup (ROWS * WAVES rows share one B tile)
@@ -128,6 +129,9 @@ def p2_last(buf, dset, label, exact=False):
         for i in rng:
             d = DATASET[dset] + 2 * i
             lo_, hi_ = val_pair(buf, i)
+            if I32:
+                o += int_muls(d, hi_)
+                continue
             o.append(f"v_mul_f64 v[{d}:{d + 1}], v[{d}:{d + 1}], s[{lo_}:{hi_}]" if F64 else
                      f"v_pk_mul_f32 v[{d}:{d + 1}], v[{d}:{d + 1}], s[{lo_}:{hi_}] op_sel:[0,1] op_sel_hi:[1,1]")
         return o
@@ -139,7 +143,9 @@ def p2_last(buf, dset, label, exact=False):
             lo_, hi_ = val_pair(buf, i)
             mode = "gpr_idx(SRC1,DST)" if exact else "gpr_idx(SRC2,DST)"
             o.append(f"s_set_gpr_idx_on s{d0_reg(buf, i)}, {mode}" if (first and i == rng[0]) else f"s_set_gpr_idx_idx s{d0_reg(buf, i)}")
-            if exact:
+            if exact and I32:
+                o += int_adds(d)
+            elif exact:
                 o.append(f"v_add_f64 v[{JUNK}:{JUNK + 1}], v[{d}:{d + 1}], v[{JUNK}:{JUNK + 1}]" if F64 else
                          f"v_pk_add_f32 v[{JUNK}:{JUNK + 1}], v[{d}:{d + 1}], v[{JUNK}:{JUNK + 1}]")
             elif F64:
@@ -162,6 +168,8 @@ def p2_exact(buf, dset):
         lo, hi = val_pair(buf, i)
         if F64:
             o.append(f"v_mul_f64 v[{d}:{d + 1}], v[{d}:{d + 1}], s[{lo}:{hi}]")
+        elif I32:
+            o += int_muls(d, hi)
         else:
             o.append(f"v_pk_mul_f32 v[{d}:{d + 1}], v[{d}:{d + 1}], s[{lo}:{hi}] op_sel:[0,1] op_sel_hi:[1,1]")
     for i in range(ENTRIES):
@@ -170,10 +178,22 @@ def p2_exact(buf, dset):
                  else f"s_set_gpr_idx_idx s{d0_reg(buf, i)}")
         if F64:
             o.append(f"v_add_f64 v[{JUNK}:{JUNK + 1}], v[{d}:{d + 1}], v[{JUNK}:{JUNK + 1}]")
+        elif I32:
+            o += int_adds(d)
         else:
             o.append(f"v_pk_add_f32 v[{JUNK}:{JUNK + 1}], v[{d}:{d + 1}], v[{JUNK}:{JUNK + 1}]")
     o.append("s_set_gpr_idx_off")
     return o
+
+
+def int_muls(d, sval):
+    """two columns per lane: the low 32 bits of column x value, in place (wrap-around: what NumPy's int32 product is)"""
+    return [f"v_mul_lo_u32 v{d}, v{d}, s{sval}", f"v_mul_lo_u32 v{d + 1}, v{d + 1}, s{sval}"]
+
+
+def int_adds(d):
+    """under gpr_idx(SRC1,DST): accumulator pair += products (the index offsets vsrc1 and vdst, not src0)"""
+    return [f"v_add_u32 v{JUNK}, v{d}, v{JUNK}", f"v_add_u32 v{JUNK + 1}, v{d + 1}, v{JUNK + 1}"]
 
 
 def dma_body():
@@ -406,6 +426,16 @@ def f64_variants():
         ENTRIES, F64 = 8, False
 
 
+def i32_variant():
+    """the float32 phases with integer opcodes (always the two-step form: a product, then an add under the index mode)"""
+    global I32
+    I32 = True
+    try:
+        return [lit("TL_ASM_PHASES_I32", phases(True, True, True))]
+    finally:
+        I32 = False
+
+
 def main():
     out = ["// GENERATED by tools/gen_tiled_asm.py - do not edit.\n",
            f"#define TL_ASM_KB {KB}\n#define TL_ASM_DMA_PER_TILE {DMA_PER_TILE}\n#define TL_ASM_RG {ROWS}\n#define TL_ASM_WAVES {WAVES}\n"
@@ -415,6 +445,7 @@ def main():
            lit("TL_ASM_PHASES_NOFMA", phases(True, False)),
            lit("TL_ASM_PHASES_NOLDS", phases(False, False)),
            *f64_variants(),
+           *i32_variant(),
            lit("TL_ASM_TILE0", tile0()),
            lit("TL_ASM_STORE", store()),
            lit("TL_ASM_ZERO", zero()),

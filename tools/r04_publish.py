@@ -1,0 +1,37 @@
+"""Copy the outputs of tools/run_r04_profiles.sh (gpurun_out/r04) into profiles/ and refresh profiles/traffic.json."""
+import csv, json, shutil
+src = 'gpurun_out/r04'
+shutil.copy(f'{src}/bench_line.json', 'profiles/r04_bench_line.json')
+shutil.copy(f'{src}/stats/b_kernel_stats.csv', 'profiles/r04_bench_kernel_stats.csv')
+shutil.copy(f'{src}/stats_headline/b_kernel_stats.csv', 'profiles/r04_headline_kernel_stats.csv')
+shutil.copy(f'{src}/summary.txt', 'profiles/r04_paths_pmc_summary.json')
+shutil.copy(f'{src}/paths_pmc.json', 'profiles/paths_pmc.json')
+line = [l for l in open(f'{src}/stats_headline.log') if l.startswith('{')][-1]
+open('profiles/r04_headline_profiled_line.json', 'w').write(line)
+h = json.load(open(f'{src}/pmc_headline.json'))
+flat = {k: v['avg_per_dispatch'] for k, v in h.items()}
+flat['dispatches'] = h['FETCH_SIZE']['dispatches']
+rd, wr = 2 * flat['FETCH_SIZE'] * 1024, flat['WRITE_SIZE'] * 1024
+flat['fabric_read_bytes_per_launch'], flat['fabric_write_bytes_per_launch'] = rd, wr
+wc = flat['SQ_WAVE_CYCLES']
+flat['wave_cycle_split'] = {'parked(s_waitcnt/barrier)': flat['SQ_WAIT_ANY'] / wc, 'issue_stall': flat['SQ_WAIT_INST_ANY'] / wc, 'issuing': flat['SQ_ACTIVE_INST_ANY'] / wc}
+flat['what'] = ("tools/run_r04_profiles.sh: tools/tools_pmc.sh r04 spmm_tiled fetch write tcc sq (rocprofv3 --kernel-trace --pmc <group> -- "
+                "python bench.py --steps 3 --warmup 1 --no-cpu --no-paths; one counter group per run); gfx950 correction: reads = 2 * FETCH_SIZE * 1024")
+json.dump(flat, open('profiles/r04_tiled_pmc_summary.json', 'w'), indent=1)
+t = json.load(open('profiles/traffic.json'))
+t['round'] = 4
+k = t['kernels']['spmm_tiled']
+k.update({'FETCH_SIZE_KB_per_launch': flat['FETCH_SIZE'], 'WRITE_SIZE_KB_per_launch': flat['WRITE_SIZE'], 'traffic_bytes_per_launch': rd + wr,
+          'TCC_HIT_sum': flat['TCC_HIT_sum'], 'TCC_MISS_sum': flat['TCC_MISS_sum'], 'TCC_REQ_sum': flat['TCC_REQ_sum'],
+          'SQ_WAVE_CYCLES': wc, 'SQ_WAIT_ANY': flat['SQ_WAIT_ANY'], 'SQ_WAIT_INST_ANY': flat['SQ_WAIT_INST_ANY'], 'SQ_ACTIVE_INST_ANY': flat['SQ_ACTIVE_INST_ANY']})
+for r in csv.DictReader(open('profiles/r04_headline_kernel_stats.csv')):
+    if 'spmm_tiled_kernel<0, 0, float>' in r['Name']:
+        k['rocprof_kernel_avg_ms'], k['rocprof_kernel_calls'] = float(r['AverageNs']) / 1e6, int(r['Calls'])
+json.dump(t, open('profiles/traffic.json', 'w'), indent=1)
+d = json.loads(open('profiles/r04_bench_line.json').read())
+p = json.loads(line)
+print('bench line: ms_per_step', d['ms_per_step'], 'kernel_ms', d['roofline']['kernel_ms'], 'frac', d['roofline']['frac'])
+print('profiled run: kernel_ms', p['roofline']['kernel_ms'], 'rocprof avg', k['rocprof_kernel_avg_ms'], 'calls', k['rocprof_kernel_calls'])
+print('wave split', flat['wave_cycle_split'])
+for a, v in d['paths'].items():
+    print(' ', a, round(v['ms'], 4), round(v['frac'], 4))

@@ -1,0 +1,65 @@
+"""Summarise the round-4 evidence run: per kernel (name prefix) the rocprofv3 average duration and, from the PMC passes over
+bench_paths.py, the fabric-side bytes per launch (reads = 2 * FETCH_SIZE * 1024 on gfx950, writes = WRITE_SIZE * 1024:
+MI355X_MICROARCH.md, HBM section), the L2 hit rate and the LDS / wave-cycle counters.  -> JSON on stdout."""
+import csv, glob, json, os, re, sys
+root = sys.argv[1]
+def short(n):
+    n = re.sub(r"\(.*", "", n)           # drop the argument list
+    n = re.sub(r"^void\s+", "", n)
+    return n[:140]
+stats = {}
+for p in glob.glob(os.path.join(root, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    for r in csv.DictReader(open(p)):
+        stats[short(r["Name"])] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6, "total_ms": float(r["TotalDurationNs"]) / 1e6}
+pmc = {}
+for p in glob.glob(os.path.join(root, "pmc_paths", "*", "**", "*counter_collection.csv"), recursive=True):
+    acc = {}
+    for r in csv.DictReader(open(p)):
+        k = (short(r["Kernel_Name"]), r["Counter_Name"])
+        d = acc.setdefault(k, {})
+        d[r["Dispatch_Id"]] = d.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+    for (kern, ctr), per in acc.items():
+        pmc.setdefault(kern, {})[ctr] = sum(per.values()) / len(per)
+        pmc[kern]["dispatches"] = len(per)
+out = {}
+for kern, c in pmc.items():
+    if "spamd" not in kern and "reduce_fill" not in kern:
+        continue
+    e = dict(c)
+    if "FETCH_SIZE" in c: e["fabric_read_bytes_per_launch"] = 2 * c["FETCH_SIZE"] * 1024
+    if "WRITE_SIZE" in c: e["fabric_write_bytes_per_launch"] = c["WRITE_SIZE"] * 1024
+    if "TCC_HIT_sum" in c and c.get("TCC_REQ_sum"): e["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+    if c.get("SQ_LDS_IDX_ACTIVE"): e["lds_conflict_share_of_lds_cycles"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]
+    if kern in stats: e["rocprof_avg_ms"] = stats[kern]["avg_ms"]; e["rocprof_calls"] = stats[kern]["calls"]
+    out[kern] = e
+# ---- rows of bench_paths.py -> the kernels that do their work (one launch each per operation unless stated): the HBM-side
+# bytes the row's operation really moved, for bench_paths.py's `pmc_bytes` (profiles/paths_pmc.json).  Only rows whose
+# kernels are not shared with rows of another size are listed (rocprofv3 averages a kernel over all its dispatches).
+ROWS = {
+    "A7_1e8_add": ["spamd::mp_partition_kernel", "spamd::mp_union_kernel<double, double, 2, 8>"],
+    "A7_1e8_multiply": ["spamd::mp_partition_kernel", "spamd::mp_union_kernel<double, double, 2, 8>"],
+    "A7_add_config1": ["spamd::mp_union_kernel<double, double, 3, 8>"],
+    "A7_multiply_config1": ["spamd::mp_union_kernel<double, double, 3, 8>"],
+    "A9_sddmm_bf16": ["spamd::sddmm_panel_kernel<__hip_bfloat16"],
+    "A9_sddmm_f32": ["spamd::sddmm_rowcache_kernel<float, float, int, 16, 4, 4, true>"],
+    "A4_spgemm_config5_share": ["spamd::spgemm_bitmap_kernel<float, int, 16>", "spamd::spgemm_row_products_kernel<int>"],
+    "A1_f64": ["spamd::spmm_tiled_kernel<0, 4, double>"],
+    "A2_default_gcxs_steady": ["spamd::spmm_tiled_kernel<0, 4, double>"],
+}
+CACHE_RESIDENT = {"A7_add_config1", "A7_multiply_config1"}   # operands + result < 256 MiB: Infinity-Cache hits are not HBM bytes
+rows = {}
+for rid, kerns in ROWS.items():
+    tot, found = 0.0, []
+    for k in kerns:
+        hit = [n for n in out if n.startswith(k)]
+        if not hit or "fabric_read_bytes_per_launch" not in out[hit[0]] or "fabric_write_bytes_per_launch" not in out[hit[0]]:
+            tot = None
+            break
+        tot += out[hit[0]]["fabric_read_bytes_per_launch"] + out[hit[0]]["fabric_write_bytes_per_launch"]
+        found.append(hit[0])
+    if tot is not None:
+        rows[rid] = {"pmc_bytes": tot, "kernels": found, "cache_resident": rid in CACHE_RESIDENT,
+                     "source": "profiles/paths_pmc.json (tools/run_r04_profiles.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench_paths.py; reads = 2 x FETCH_SIZE x 1024 on gfx950)"}
+json.dump({"rows": rows}, open(os.path.join(root, "paths_pmc.json"), "w"), indent=1)
+print(json.dumps({"what": "tools/run_r04_profiles.sh", "kernels": out,
+                  "kernel_stats_top": dict(sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"])[:40])}, indent=1))
