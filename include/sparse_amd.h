@@ -232,6 +232,11 @@ int64_t spamd_csx_swap_ws_bytes(int64_t nnz);
 int spamd_csx_swap(int idx_dtype, int64_t n_major, int64_t n_minor, int64_t nnz, const void* data, const void* indices,
                    const void* indptr, void* out_data, void* out_indices, void* out_indptr, void* ws, int64_t ws_bytes,
                    void* stream);
+/* the same for 8-byte values (float64 / int64: the reference's default value type): a 16-byte payload rides through the sort */
+int64_t spamd_csx_swap8_ws_bytes(int64_t nnz);
+int spamd_csx_swap8(int idx_dtype, int64_t n_major, int64_t n_minor, int64_t nnz, const void* data, const void* indices,
+                   const void* indptr, void* out_data, void* out_indices, void* out_indptr, void* ws, int64_t ws_bytes,
+                   void* stream);
 /* Stable radix sort of (key, value) int64 pairs on key bits [0, end_bit); keys must be >= 0.
  * Replaces `np.argsort(linear, kind="mergesort")` (core.py:1315).  Workspace from *_ws_bytes. */
 int64_t spamd_sort_pairs_ws_bytes(int64_t n);

@@ -69,6 +69,8 @@ SIGNATURES = {
     "spamd_rows_to_indptr": (_int, [_int, _i64, _vp, _i64, _vp, _vp]),
     "spamd_csx_swap_ws_bytes": (_i64, [_i64]),
     "spamd_csx_swap": (_int, [_int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "spamd_csx_swap8_ws_bytes": (_i64, [_i64]),
+    "spamd_csx_swap8": (_int, [_int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "spamd_sort_pairs_ws_bytes": (_i64, [_i64]),
     "spamd_sort_pairs": (_int, [_i64, _vp, _vp, _vp, _vp, _int, _vp, _i64, _vp]),
     "spamd_sort_kv_ws_bytes": (_i64, [_int, _i64]),

@@ -469,16 +469,19 @@ def csx_swap_2d(data, indices, indptr, n_major, n_minor):
     it = indices.dtype if index_dtype_ok(indices) else torch.int64
     if nnz == 0:
         return data, indices.to(it), torch.zeros(n_minor + 1, dtype=it, device=dev)
-    if data.element_size() == 4 and n_major < 2 ** 31 and n_minor < 2 ** 31 and index_dtype_ok(indices) \
-            and indices.dtype == indptr.dtype:
+    if data.element_size() in (4, 8) and n_major < 2 ** 31 and n_minor < 2 ** 31 and index_dtype_ok(indices) \
+            and indices.dtype == indptr.dtype and not data.is_complex():
         # one library call: pack (32-bit minor key, major id | value bits), stable sort on the key, unpack + pointers
-        ws_bytes = int(_ffi.lib().spamd_csx_swap_ws_bytes(nnz))
+        # (8-byte values - the reference's default float64 - ride in a 16-byte payload: round 4; before, they went through a
+        # 64-bit key sort with a permutation payload and two gathers: ~8 ms per 10^8 elements)
+        wide = data.element_size() == 8
+        ws_bytes = int((_ffi.lib().spamd_csx_swap8_ws_bytes if wide else _ffi.lib().spamd_csx_swap_ws_bytes)(nnz))
         if ws_bytes < 0:
             raise _ffi.HipBackendError(f"spamd_csx_swap_ws_bytes failed: {ws_bytes}")
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         new_data, new_indices = torch.empty_like(data.contiguous()), torch.empty(nnz, dtype=it, device=dev)
         new_indptr = torch.empty(n_minor + 1, dtype=it, device=dev)
-        _ffi.call("spamd_csx_swap", code_of(it), int(n_major), int(n_minor), nnz, ptr(data.contiguous()), ptr(indices.contiguous()),
+        _ffi.call("spamd_csx_swap8" if wide else "spamd_csx_swap", code_of(it), int(n_major), int(n_minor), nnz, ptr(data.contiguous()), ptr(indices.contiguous()),
                   ptr(indptr.contiguous()), ptr(new_data), ptr(new_indices), ptr(new_indptr), ptr(ws), ws_bytes, stream_ptr(dev))
         return new_data, new_indices, new_indptr
     major = csr_to_keys(indptr, torch.zeros_like(indices), n_major, 1)     # major id of every stored element

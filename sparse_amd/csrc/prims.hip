@@ -728,38 +728,61 @@ extern "C" int spamd_convert(int src_dtype, int dst_dtype, int64_t n, const void
   return SPAMD_ETYPE;
 }
 
-// ---- A6: re-compress a 2-D compressed matrix along its other axis (CSR <-> CSC), 4-byte values ---------------------
+// ---- A6: re-compress a 2-D compressed matrix along its other axis (CSR <-> CSC), 4- and 8-byte values ---------------
 // `GCXS.change_compressed_axes` / `_transpose` (reference _compressed/compressed.py:388-423, convert.py:210-273:
 // uncompress, re-linearise, stable argsort, bincount + cumsum).  The input is ordered by (major, minor), so a STABLE sort
 // on the minor index alone gives (minor, major) order: ceil(log2(n_minor)) bits of a 32-bit key, and the major id rides
-// along with the value bits in one 8-byte payload.  Three launches around the sort: pack (a wave per major row: the
-// row id is known without a search), sort, unpack + pointers.
+// along with the value bits in one payload (8 bytes for 4-byte values, 16 for 8-byte ones: everything streams, nothing is
+// gathered by a permutation).  Three launches around the sort: pack (a wave per major row: the row id is known without a
+// search), sort, unpack + pointers.
 namespace spamd {
 
-template <typename I>
+struct CsxWide {   // payload of an 8-byte value
+  uint64_t value;
+  uint64_t major;
+};
+template <int VB> struct CsxPayload;
+template <> struct CsxPayload<4> {
+  using V = uint32_t;
+  using P = uint64_t;
+  static __device__ __forceinline__ P make(uint32_t row, V v) { return ((uint64_t)row << 32) | (uint64_t)v; }
+  static __device__ __forceinline__ uint32_t major(P p) { return (uint32_t)(p >> 32); }
+  static __device__ __forceinline__ V value(P p) { return (uint32_t)p; }
+};
+template <> struct CsxPayload<8> {
+  using V = uint64_t;
+  using P = CsxWide;
+  static __device__ __forceinline__ P make(uint32_t row, V v) { return CsxWide{v, (uint64_t)row}; }
+  static __device__ __forceinline__ uint32_t major(const P& p) { return (uint32_t)p.major; }
+  static __device__ __forceinline__ V value(const P& p) { return p.value; }
+};
+
+template <typename I, int VB>
 __global__ void __launch_bounds__(256) csx_pack_kernel(int64_t n_major, const I* __restrict__ indptr,
-                                                       const I* __restrict__ indices, const uint32_t* __restrict__ data,
-                                                       uint32_t* __restrict__ keys, uint64_t* __restrict__ payload) {
+                                                       const I* __restrict__ indices,
+                                                       const typename CsxPayload<VB>::V* __restrict__ data,
+                                                       uint32_t* __restrict__ keys, typename CsxPayload<VB>::P* __restrict__ payload) {
   const int lane = threadIdx.x & 63;
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   for (int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); row < n_major; row += nwaves) {
     const int64_t a = (int64_t)indptr[row], b = (int64_t)indptr[row + 1];
     for (int64_t e = a + lane; e < b; e += 64) {
       keys[e] = (uint32_t)indices[e];
-      payload[e] = ((uint64_t)(uint32_t)row << 32) | (uint64_t)data[e];
+      payload[e] = CsxPayload<VB>::make((uint32_t)row, data[e]);
     }
   }
 }
 
-template <typename I>
+template <typename I, int VB>
 __global__ void __launch_bounds__(256) csx_unpack_kernel(int64_t nnz, int64_t n_minor, const uint32_t* __restrict__ keys,
-                                                         const uint64_t* __restrict__ payload, I* __restrict__ out_indices,
-                                                         uint32_t* __restrict__ out_data, I* __restrict__ out_indptr) {
+                                                         const typename CsxPayload<VB>::P* __restrict__ payload,
+                                                         I* __restrict__ out_indices, typename CsxPayload<VB>::V* __restrict__ out_data,
+                                                         I* __restrict__ out_indptr) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += stride) {
-    const uint64_t p = payload[e];
-    out_indices[e] = (I)(uint32_t)(p >> 32);
-    out_data[e] = (uint32_t)p;
+    const typename CsxPayload<VB>::P p = payload[e];
+    out_indices[e] = (I)CsxPayload<VB>::major(p);
+    out_data[e] = CsxPayload<VB>::value(p);
     // pointers: element e opens every minor index in (key[e-1], key[e]]; the last element closes the rest
     const int64_t k = (int64_t)keys[e];
     const int64_t kp = e > 0 ? (int64_t)keys[e - 1] : -1;
@@ -773,13 +796,58 @@ __global__ void __launch_bounds__(256) csx_unpack_kernel(int64_t nnz, int64_t n_
 
 static size_t csx_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
+template <int VB>
+static int64_t csx_ws_bytes(int64_t nnz) {
+  using P = typename spamd::CsxPayload<VB>::P;
+  const int64_t sb = spamd::sort_pairs_tuned_ws<uint32_t, P>(nnz, 32);
+  if (sb < 0) return sb;
+  const size_t n = (size_t)(nnz > 0 ? nnz : 1);
+  return (int64_t)(2 * csx_align(4 * n) + 2 * csx_align(sizeof(P) * n) + csx_align((size_t)sb) + 256);
+}
+
 extern "C" int64_t spamd_csx_swap_ws_bytes(int64_t nnz) {
   if (nnz < 0) return -1;
-  const int64_t sb = spamd::sort_pairs_tuned_ws<uint32_t, uint64_t>(nnz, 32);
-  if (sb < 0) return sb;
-  const size_t sort_bytes = (size_t)sb;
-  const size_t n = (size_t)(nnz > 0 ? nnz : 1);
-  return (int64_t)(2 * csx_align(4 * n) + 2 * csx_align(8 * n) + csx_align(sort_bytes) + 256);
+  return csx_ws_bytes<4>(nnz);
+}
+extern "C" int64_t spamd_csx_swap8_ws_bytes(int64_t nnz) {
+  if (nnz < 0) return -1;
+  return csx_ws_bytes<8>(nnz);
+}
+
+template <int VB>
+static int csx_swap(int idx_dtype, int64_t n_major, int64_t n_minor, int64_t nnz, const void* data, const void* indices,
+                    const void* indptr, void* out_data, void* out_indices, void* out_indptr, void* ws, int64_t ws_bytes,
+                    void* stream) {
+  using namespace spamd;
+  using V = typename CsxPayload<VB>::V;
+  using P = typename CsxPayload<VB>::P;
+  if (n_major < 0 || n_minor < 0 || nnz < 0 || n_major >= ((int64_t)1 << 32) || n_minor >= ((int64_t)1 << 32)) return SPAMD_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (nnz == 0) {
+    const size_t isz = idx_dtype == SPAMD_I32 ? 4 : 8;
+    return (int)hipMemsetAsync(out_indptr, 0, (size_t)(n_minor + 1) * isz, s);
+  }
+  if (ws_bytes < csx_ws_bytes<VB>(nnz)) return SPAMD_EWS;
+  char* p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
+  uint32_t* k0 = reinterpret_cast<uint32_t*>(p); p += csx_align(4 * (size_t)nnz);
+  uint32_t* k1 = reinterpret_cast<uint32_t*>(p); p += csx_align(4 * (size_t)nnz);
+  P* v0 = reinterpret_cast<P*>(p); p += csx_align(sizeof(P) * (size_t)nnz);
+  P* v1 = reinterpret_cast<P*>(p); p += csx_align(sizeof(P) * (size_t)nnz);
+  size_t sort_bytes = (size_t)(reinterpret_cast<char*>(ws) + ws_bytes - p);
+  int bits = 1;
+  while (bits < 32 && ((int64_t)1 << bits) < n_minor) ++bits;
+  const unsigned pack_blocks = (unsigned)std::min<int64_t>((n_major + 3) / 4, (int64_t)256 * 64);
+  SPAMD_IDX_SWITCH(idx_dtype, I, {
+    hipLaunchKernelGGL((csx_pack_kernel<I, VB>), dim3(pack_blocks ? pack_blocks : 1), dim3(256), 0, s, n_major, (const I*)indptr,
+                       (const I*)indices, (const V*)data, k0, v0);
+    if (int rc = launch_status()) return rc;
+    hipError_t e = spamd::sort_pairs_tuned(p, sort_bytes, k0, k1, v0, v1, (size_t)nnz, (unsigned)bits, s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((csx_unpack_kernel<I, VB>), dim3(grid_for(nnz)), dim3(256), 0, s, nnz, n_minor, k1, v1, (I*)out_indices,
+                       (V*)out_data, (I*)out_indptr);
+    return launch_status();
+  })
+  return SPAMD_ETYPE;
 }
 
 // data: nnz 4-byte values (moved bit-wise); indices/indptr of idx_dtype, n_major + 1 pointers; outputs: nnz values, nnz
@@ -787,32 +855,11 @@ extern "C" int64_t spamd_csx_swap_ws_bytes(int64_t nnz) {
 extern "C" int spamd_csx_swap(int idx_dtype, int64_t n_major, int64_t n_minor, int64_t nnz, const void* data,
                               const void* indices, const void* indptr, void* out_data, void* out_indices, void* out_indptr,
                               void* ws, int64_t ws_bytes, void* stream) {
-  using namespace spamd;
-  if (n_major < 0 || n_minor < 0 || nnz < 0 || n_major >= ((int64_t)1 << 32) || n_minor >= ((int64_t)1 << 32)) return SPAMD_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
-  if (nnz == 0) {
-    const size_t isz = idx_dtype == SPAMD_I32 ? 4 : 8;
-    return (int)hipMemsetAsync(out_indptr, 0, (size_t)(n_minor + 1) * isz, s);
-  }
-  if (ws_bytes < spamd_csx_swap_ws_bytes(nnz)) return SPAMD_EWS;
-  char* p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
-  uint32_t* k0 = reinterpret_cast<uint32_t*>(p); p += csx_align(4 * (size_t)nnz);
-  uint32_t* k1 = reinterpret_cast<uint32_t*>(p); p += csx_align(4 * (size_t)nnz);
-  uint64_t* v0 = reinterpret_cast<uint64_t*>(p); p += csx_align(8 * (size_t)nnz);
-  uint64_t* v1 = reinterpret_cast<uint64_t*>(p); p += csx_align(8 * (size_t)nnz);
-  size_t sort_bytes = (size_t)(reinterpret_cast<char*>(ws) + ws_bytes - p);
-  int bits = 1;
-  while (bits < 32 && ((int64_t)1 << bits) < n_minor) ++bits;
-  const unsigned pack_blocks = (unsigned)std::min<int64_t>((n_major + 3) / 4, (int64_t)256 * 64);
-  SPAMD_IDX_SWITCH(idx_dtype, I, {
-    hipLaunchKernelGGL(csx_pack_kernel<I>, dim3(pack_blocks ? pack_blocks : 1), dim3(256), 0, s, n_major, (const I*)indptr,
-                       (const I*)indices, (const uint32_t*)data, k0, v0);
-    if (int rc = launch_status()) return rc;
-    hipError_t e = spamd::sort_pairs_tuned(p, sort_bytes, k0, k1, v0, v1, (size_t)nnz, (unsigned)bits, s);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(csx_unpack_kernel<I>, dim3(grid_for(nnz)), dim3(256), 0, s, nnz, n_minor, k1, v1, (I*)out_indices,
-                       (uint32_t*)out_data, (I*)out_indptr);
-    return launch_status();
-  })
-  return SPAMD_ETYPE;
+  return csx_swap<4>(idx_dtype, n_major, n_minor, nnz, data, indices, indptr, out_data, out_indices, out_indptr, ws, ws_bytes, stream);
+}
+// the same for 8-byte values (float64 / int64: the reference's default value type); workspace: spamd_csx_swap8_ws_bytes
+extern "C" int spamd_csx_swap8(int idx_dtype, int64_t n_major, int64_t n_minor, int64_t nnz, const void* data,
+                               const void* indices, const void* indptr, void* out_data, void* out_indices, void* out_indptr,
+                               void* ws, int64_t ws_bytes, void* stream) {
+  return csx_swap<8>(idx_dtype, n_major, n_minor, nnz, data, indices, indptr, out_data, out_indices, out_indptr, ws, ws_bytes, stream);
 }
