@@ -342,7 +342,7 @@ def main():
     # ---- the only scaling proxy one GPU can give: a rank's share at world size 8 (the first of 8 nnz-balanced row blocks of
     # THIS matrix, B resident: what `--gpus 8 --scaling strong` runs per rank besides the all-gather of B), timed alone
     shard8 = None
-    if world == 1 and tiled:
+    if world == 1 and tiled and not args.no_paths:   # (not in the profiled headline run: its kernel average must be the headline's alone)
         try:
             b8 = _dist.partition_rows_by_nnz(ptr, 8)
             d8, i8, p8, s0, s1 = _dist.shard_csr(data, idx, ptr, 0, 8, b8)
