@@ -12,6 +12,7 @@ for p in glob.glob(os.path.join(root, "stats", "**", "*kernel_stats.csv"), recur
     for r in csv.DictReader(open(p)):
         stats[short(r["Name"])] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6, "total_ms": float(r["TotalDurationNs"]) / 1e6}
 pmc = {}
+seq = {}
 for p in glob.glob(os.path.join(root, "pmc_paths", "*", "**", "*counter_collection.csv"), recursive=True):
     acc = {}
     for r in csv.DictReader(open(p)):
@@ -21,6 +22,7 @@ for p in glob.glob(os.path.join(root, "pmc_paths", "*", "**", "*counter_collecti
     for (kern, ctr), per in acc.items():
         pmc.setdefault(kern, {})[ctr] = sum(per.values()) / len(per)
         pmc[kern]["dispatches"] = len(per)
+        seq.setdefault(kern, {})[ctr] = [per[k] for k in sorted(per, key=int)]   # per dispatch, in launch order
 out = {}
 for kern, c in pmc.items():
     if "spamd" not in kern and "reduce_fill" not in kern:
@@ -46,6 +48,9 @@ ROWS = {
     "A1_f64": ["spamd::spmm_tiled_kernel<0, 4, double>"],
     "A2_default_gcxs_steady": ["spamd::spmm_tiled_kernel<0, 4, double>"],
 }
+# rows that share their kernels with another row of a different size: (first, last) share of the kernels' dispatches, in
+# launch order (bench_paths.py runs `add` - plain and with coordinates - before `multiply`)
+SPLIT = {"A7_1e8_add": (0.0, 0.5), "A7_1e8_multiply": (0.5, 1.0), "A7_add_config1": (0.0, 0.5), "A7_multiply_config1": (0.5, 1.0)}
 CACHE_RESIDENT = {"A7_add_config1", "A7_multiply_config1"}   # operands + result < 256 MiB: Infinity-Cache hits are not HBM bytes
 rows = {}
 for rid, kerns in ROWS.items():
@@ -55,7 +60,13 @@ for rid, kerns in ROWS.items():
         if not hit or "fabric_read_bytes_per_launch" not in out[hit[0]] or "fabric_write_bytes_per_launch" not in out[hit[0]]:
             tot = None
             break
-        tot += out[hit[0]]["fabric_read_bytes_per_launch"] + out[hit[0]]["fabric_write_bytes_per_launch"]
+        if rid in SPLIT and hit[0] in seq and "FETCH_SIZE" in seq[hit[0]] and "WRITE_SIZE" in seq[hit[0]]:
+            lo, hi = SPLIT[rid]
+            f, w = seq[hit[0]]["FETCH_SIZE"], seq[hit[0]]["WRITE_SIZE"]
+            f, w = f[int(lo * len(f)):int(hi * len(f))], w[int(lo * len(w)):int(hi * len(w))]
+            tot += 2 * 1024 * sum(f) / len(f) + 1024 * sum(w) / len(w)
+        else:
+            tot += out[hit[0]]["fabric_read_bytes_per_launch"] + out[hit[0]]["fabric_write_bytes_per_launch"]
         found.append(hit[0])
     if tot is not None:
         rows[rid] = {"pmc_bytes": tot, "kernels": found, "cache_resident": rid in CACHE_RESIDENT,
