@@ -410,15 +410,20 @@ int spamd_spgemm_pack(int val_dtype, int64_t n_row, const int64_t* prod_off, con
  * every row is written ONCE, in place - no scratch rows, no pack, no scan of row lengths.  Values are summed in the order
  * of A's elements (bit-identical to the other two forms).
  *   spamd_spgemm_bitmap_limits(val_dtype, which): 0 = products per row, 1 = A elements per row, 2 = columns,
- *     3 = products per row that may share an output element with an earlier product (checked inside the kernel);
+ *     3 = products per row that may share an output element with an earlier product (checked inside the kernel),
+ *     4 / 5 / 6 = products, columns and such products per PART of a row in the split form (below);
  *   spamd_spgemm_bitmap: out_indptr[n_row + 1]; out_indices (int64) / out_data with room for EVERY product (the caller
  *     trims to out_indptr[n_row]); work = n_row + 32 int64 words, zeroed here: afterwards work[1] != 0 = a row was outside
  *     the limits (discard the result, use spamd_spgemm_rows), work[2] = values written whose bits are all zero. */
 int64_t spamd_spgemm_bitmap_limits(int val_dtype, int which);
-int spamd_spgemm_bitmap(int val_dtype, int idx_dtype, int64_t n_row, int64_t n_col, const void* a_indptr,
-                        const void* a_indices, const void* a_data, const void* b_indptr, const void* b_indices,
-                        const void* b_data, int64_t* work, int64_t* out_indptr, int64_t* out_indices, void* out_data,
-                        void* stream);
+/* parts = 1: whole rows, one 1024-thread workgroup per CU (n_col <= limit 2).  parts > 1 (4-byte values): every row in `parts`
+ * column ranges (ceil(n_col / parts) rounded up to 256 <= limit 5), 512-thread workgroups, two per CU; bsplit = n_inner *
+ * (parts - 1) words of the index type (workspace, filled here: where each B row crosses a range boundary), n_inner = rows
+ * of B; limits 4 / 6 are per part.  work = n_row * parts + 32 int64 words. */
+int spamd_spgemm_bitmap(int val_dtype, int idx_dtype, int64_t n_row, int64_t n_inner, int64_t n_col, int parts,
+                        const void* a_indptr, const void* a_indices, const void* a_data, const void* b_indptr,
+                        const void* b_indices, const void* b_data, void* bsplit, int64_t* work, int64_t* out_indptr,
+                        int64_t* out_indices, void* out_data, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * A9  SDDMM      out[n] = s[n] * sum_k A[rows[n], k] * Bt[cols[n], k]

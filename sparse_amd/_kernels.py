@@ -679,21 +679,25 @@ SPGEMM_BITMAP_MIN_MEAN = 1024   # mean products per row from which the per-row b
 SPGEMM_BITMAP_MAX_DUPS = 120    # expected products per row that share an output element with an earlier one (list of 512)
 
 
-def _spgemm_bitmap(vcode, it, n_row, n_col, total, a_indptr, a_indices, a_data, b_indptr, b_indices, b_data, dtr, dev, s):
-    """C = A @ B by csrc/spgemm_bitmap.hip: (data, int64 indices, int64 indptr), or None when a row exceeded the kernel's
-    parked-product list (the caller then takes the bucket kernels).  The result buffers are allocated for every product
-    (an upper bound of the result's length) and trimmed: a view when at least 3/4 of them are used."""
+def _spgemm_bitmap(vcode, it, n_row, n_inner, n_col, parts, total, a_indptr, a_indices, a_data, b_indptr, b_indices, b_data, dtr,
+                   dev, s):
+    """C = A @ B by csrc/spgemm_bitmap.hip: (data, int64 indices, int64 indptr), or None when a row (or part of a row)
+    exceeded the kernel's limits (the caller then tries the next form).  `parts` = 1: whole rows, one workgroup per CU;
+    > 1: column ranges, two workgroups per CU.  The result buffers are allocated for every product (an upper bound of the
+    result's length) and trimmed: a view when at least 3/4 of them are used."""
     out_idx = torch.empty(max(total, 1), dtype=torch.int64, device=dev)
     out_val = torch.empty(max(total, 1), dtype=dtr, device=dev)
     out_ptr = torch.empty(n_row + 1, dtype=torch.int64, device=dev)
-    work = torch.empty(n_row + 32, dtype=torch.int64, device=dev)
-    _ffi.call("spamd_spgemm_bitmap", vcode, code_of(it), n_row, n_col, ptr(a_indptr), ptr(a_indices), ptr(a_data),
-              ptr(b_indptr), ptr(b_indices), ptr(b_data), ptr(work), ptr(out_ptr), ptr(out_idx), ptr(out_val), s)
+    work = torch.empty(n_row * parts + 32, dtype=torch.int64, device=dev)
+    bsplit = torch.empty(max(n_inner * (parts - 1), 1), dtype=it, device=dev) if parts > 1 else None
+    _ffi.call("spamd_spgemm_bitmap", vcode, code_of(it), n_row, n_inner, n_col, parts, ptr(a_indptr), ptr(a_indices), ptr(a_data),
+              ptr(b_indptr), ptr(b_indices), ptr(b_data), ptr(bsplit) if bsplit is not None else None, ptr(work), ptr(out_ptr),
+              ptr(out_idx), ptr(out_val), s)
     failed, zeros, nnz = (int(v) for v in torch.cat([work[1:3], out_ptr[-1:]]).tolist())   # ONE read-back
     if os.environ.get("SPAMD_BMK_PROF"):     # (-DBMK_PROF builds of csrc/spgemm_bitmap.hip: cycles per phase, thread 0 of every workgroup)
         SPGEMM_STATS["phase_cycles"] = work[4:20].tolist()
     if failed:
-        SPGEMM_STATS["bitmap_failed"] = True
+        SPGEMM_STATS["bitmap_failed"] = SPGEMM_STATS.get("bitmap_failed", 0) + 1
         return None
     if nnz * 4 < total * 3:
         out_idx, out_val = out_idx[:nnz].clone(), out_val[:nnz].clone()
@@ -701,7 +705,31 @@ def _spgemm_bitmap(vcode, it, n_row, n_col, total, a_indptr, a_indices, a_data, 
         out_idx, out_val = out_idx[:nnz], out_val[:nnz]
     note_zero_bits_count(out_val, zeros)
     SPGEMM_STATS["rows"], SPGEMM_STATS["heavy_or_declined"], SPGEMM_STATS["kernel"] = n_row, 0, "bitmap"
+    SPGEMM_STATS["parts"] = parts
     return out_val, out_idx, out_ptr
+
+
+SPGEMM_BITMAP_SPLIT = True   # tuning hook: False = only the wide form (whole rows, one workgroup per CU); "first" = the split form first
+
+
+def _spgemm_bitmap_forms(vcode, n_col, max_prod):
+    """The forms of the bitmap kernel to try for this product, best first: a list of `parts` values (1 = wide).  The wide
+    form wins where both apply (config-5 share: 13.2 against 14.6 ms with two parts: every part repeats the row's staging,
+    scans and look-back with half the threads); the split form is what takes matrices of more than 2^20 columns and rows of
+    more than 16384 products."""
+    lim = _ffi.lib().spamd_spgemm_bitmap_limits
+    forms = []
+    if max_prod <= lim(vcode, 0) and n_col <= lim(vcode, 2) and max_prod * max_prod <= 2 * n_col * SPGEMM_BITMAP_MAX_DUPS:
+        forms.append(1)
+    split_prod, split_cols = int(lim(vcode, 4)), int(lim(vcode, 5))
+    if SPGEMM_BITMAP_SPLIT and split_prod and split_cols and (not forms or SPGEMM_BITMAP_SPLIT == "first"):
+        parts = max(2, -(-n_col // split_cols))
+        # a part holds ~1 / parts of a row's products (uniform columns: + a few standard deviations)
+        while parts <= 64 and max_prod / parts + 4 * (max_prod / parts) ** 0.5 + 64 > split_prod:
+            parts += 1
+        if parts <= 64 and max_prod * max_prod <= 2 * n_col * parts * (SPGEMM_BITMAP_MAX_DUPS // 2):
+            forms.insert(0, parts)
+    return forms
 
 
 def _spgemm_rows(n_row, n_col, a_data, a_indices, a_indptr, b_data, b_indices, b_indptr):
@@ -728,12 +756,14 @@ def _spgemm_rows(n_row, n_col, a_data, a_indices, a_indptr, b_data, b_indices, b
     total = int(prod_off[-1])
     lim = _ffi.lib().spamd_spgemm_bitmap_limits
     SPGEMM_STATS.update(max_prod=max_prod, max_arow=max_arow, products=total)
-    if (SPGEMM_BITMAP and total and max_prod <= lim(vcode, 0) and max_arow <= lim(vcode, 1) and n_col <= lim(vcode, 2)
-            and total >= SPGEMM_BITMAP_MIN_MEAN * n_row and max_prod * max_prod <= 2 * n_col * SPGEMM_BITMAP_MAX_DUPS):
-        res = _spgemm_bitmap(vcode, it, n_row, n_col, total, a_indptr, a_indices, a_data, b_indptr, b_indices, b_data, dtr,
-                             dev, s)
-        if res is not None:
-            return res
+    SPGEMM_STATS.pop("bitmap_failed", None)
+    if SPGEMM_BITMAP and total and max_arow <= lim(vcode, 1) and total >= SPGEMM_BITMAP_MIN_MEAN * n_row:
+        n_inner = int(b_indptr.numel()) - 1
+        for parts in _spgemm_bitmap_forms(vcode, n_col, max_prod):
+            res = _spgemm_bitmap(vcode, it, n_row, n_inner, n_col, parts, total, a_indptr, a_indices, a_data, b_indptr, b_indices,
+                                 b_data, dtr, dev, s)
+            if res is not None:
+                return res
     SPGEMM_STATS["kernel"] = "buckets"
 
     def classify(nnz_row):

