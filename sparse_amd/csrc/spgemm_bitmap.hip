@@ -233,14 +233,15 @@ __device__ __forceinline__ int bmk_is_zero_bits(V v) {
 // ("virtual row" v = r * np + h; np = 1: whole rows).  Parts of one row are emitted one behind the other, so the look-back
 // runs over the virtual rows and the result is the same CSR.  With np > 1, `bsplit[k * (np - 1) + h]` = the first element of
 // B row k whose column is >= (h + 1) * range (spgemm_bsplit_kernel): a part's products are contiguous pieces of B rows.
-template <typename V, typename I, int ITEMS, int THREADS, int DUP>
+template <typename V, typename I, int ITEMS, int THREADS, int DUP, bool SPLIT>
 __global__ void __launch_bounds__(THREADS, 4)   // (four waves per SIMD: one 1024-thread or two 512-thread workgroups per CU)
-spgemm_bitmap_kernel(int64_t n_vrow, int np, int64_t range, int ngroups, const I* __restrict__ a_ptr, const I* __restrict__ a_idx,
+spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, const I* __restrict__ a_ptr, const I* __restrict__ a_idx,
                      const V* __restrict__ a_val, const I* __restrict__ b_ptr, const I* __restrict__ bsplit,
                      const I* __restrict__ b_idx, const V* __restrict__ b_val, unsigned long long* __restrict__ work,
                      int64_t* __restrict__ out_ptr, int64_t* __restrict__ out_idx, V* __restrict__ out_val) {
 #pragma clang fp contract(off)
   using L = BmkLayout<V, THREADS, ITEMS, DUP>;
+  const int np = SPLIT ? np_arg : 1;                    // (whole rows: every `np > 1` branch below folds away)
   constexpr int FILT_WORDS = DUP;                       // 32 filter bits per list entry
   constexpr unsigned FILT_MASK = FILT_WORDS * 32 - 1;
   static_assert(BMK_GPT * THREADS * 256 >= (1 << 19), "column range of a part");
@@ -657,12 +658,12 @@ static int64_t bmk_split_max_groups() {   // groups of 256 columns whose bitmap 
   return g;
 }
 
-template <typename V, typename I, int ITEMS, int THREADS, int DUP>
+template <typename V, typename I, int ITEMS, int THREADS, int DUP, bool SPLIT>
 static int bmk_launch(int64_t n_row, int np, int64_t range, const I* a_ptr, const I* a_idx, const V* a_val, const I* b_ptr,
                       const I* bsplit, const I* b_idx, const V* b_val, unsigned long long* work, int64_t* out_ptr,
                       int64_t* out_idx, V* out_val, hipStream_t s) {
   using L = BmkLayout<V, THREADS, ITEMS, DUP>;
-  auto kern = &spgemm_bitmap_kernel<V, I, ITEMS, THREADS, DUP>;
+  auto kern = &spgemm_bitmap_kernel<V, I, ITEMS, THREADS, DUP, SPLIT>;
   const int ngroups = (int)ceil_div(range, (int64_t)256);
   if (ngroups > BMK_GPT * THREADS) return SPAMD_EINVAL;
   const size_t lds = L::bytes(ngroups);
@@ -740,19 +741,19 @@ extern "C" int spamd_spgemm_bitmap(int val_dtype, int idx_dtype, int64_t n_row, 
     if (int rc = launch_status()) return rc;
   }
   unsigned long long* const w = reinterpret_cast<unsigned long long*>(work);
-#define BMK_GO(V, I, ITEMS, THREADS, DUP)                                                                                    \
-  return (bmk_launch<V, I, ITEMS, THREADS, DUP>(n_row, parts, range, (const I*)a_indptr, (const I*)a_indices, (const V*)a_data, \
+#define BMK_GO(V, I, ITEMS, THREADS, DUP, SPLIT)                                                                                  \
+  return (bmk_launch<V, I, ITEMS, THREADS, DUP, SPLIT>(n_row, parts, range, (const I*)a_indptr, (const I*)a_indices, (const V*)a_data, \
                                                 (const I*)b_indptr, (const I*)bsplit, (const I*)b_indices, (const V*)b_data, w,  \
                                                 out_indptr, out_indices, (V*)out_data, s));
   if (parts > 1) {
     SPAMD_DISPATCH_IDX(idx_dtype, I, {
-      if (val_dtype == SPAMD_F32) BMK_GO(float, I, BMK_SPLIT_ITEMS, BMK_SPLIT_THREADS, BMK_SPLIT_DUP)
-      BMK_GO(int32_t, I, BMK_SPLIT_ITEMS, BMK_SPLIT_THREADS, BMK_SPLIT_DUP)
+      if (val_dtype == SPAMD_F32) BMK_GO(float, I, BMK_SPLIT_ITEMS, BMK_SPLIT_THREADS, BMK_SPLIT_DUP, true)
+      BMK_GO(int32_t, I, BMK_SPLIT_ITEMS, BMK_SPLIT_THREADS, BMK_SPLIT_DUP, true)
     })
     return SPAMD_ETYPE;
   }
   SPAMD_DISPATCH_VAL(val_dtype, V, {
-    SPAMD_DISPATCH_IDX(idx_dtype, I, { BMK_GO(V, I, BmkItems<V>::value, BMK_THREADS, BMK_DUP) })
+    SPAMD_DISPATCH_IDX(idx_dtype, I, { BMK_GO(V, I, BmkItems<V>::value, BMK_THREADS, BMK_DUP, false) })
   })
 #undef BMK_GO
   return SPAMD_ETYPE;
