@@ -31,6 +31,14 @@
 // 0, instrumented build): bits 6 k, popcount scan + staging of the next A row 14 k, positions 8 k, row into LDS 7 k,
 // product requests 20-24 k, parked products 5 k, look-back 17-20 k, copy-out 5 k: the last two large ones are the memory
 // system absorbing every CU's product requests at once (the loaded latency of a state word is ~8 us).
+// Tried on top of the 13.1 ms kernel and NOT kept (each bit-identical): the row in two column-range parts with two 512-thread
+// workgroups per CU 14.6 (every part repeats the staging, the scans and the look-back with half the threads); the block
+// scans on DPP row shifts instead of `__shfl_up` + the binary search with its steps outermost (0 spilled registers) 13.5; a
+// second register set so that the next row's products are requested right after its staging instead of after this row is
+// assembled 16.5 (the loads of one wave return in order: everything that waits on vmcnt in between - spill reloads, the
+// look-back - then waits for the whole burst); without the look-back (wrong offsets, timing only) 12.6: the coupling of the
+// workgroups costs 0.6 ms.  Model: per row and CU ~15 k cycles of product loads, ~15 k of result stores and ~35 k of LDS
+// phases run one after the other (64 k cycles per row); the fabric moves 30 GB per product at 2.4 TB/s.
 // Limits (checked by the host before the launch, spamd_spgemm_bitmap_limits): n_col <= 2^20, A rows of at most 256
 // elements, at most 1024 * ITEMS products per row (ITEMS = 16 for 4-byte values, 8 for 8-byte ones: the row must fit the
 // LDS region), index arrays of either width.  A row whose parked products exceed the list (512 entries) sets the `failed`
