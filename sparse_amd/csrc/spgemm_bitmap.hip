@@ -186,10 +186,16 @@ __device__ __forceinline__ int bmk_rank(const unsigned* bm, const unsigned short
 // round trip (a state word written by another XCD comes from the fabric: ~2 us each; with one workgroup per CU the
 // nearest row with a known prefix is up to 255 rows back, i.e. four dependent round trips with one window at a time:
 // 17 k of a row's 91 k cycles), and a back-off in the spin.
-__device__ __forceinline__ unsigned long long bmk_lookback(unsigned long long* st, int64_t blk, unsigned long long tot, int lane) {
+// BOUNDED: the rows this one waits for are held by workgroups that must be resident (the grid is one workgroup per CU - or
+// the occupancy query's number - so they are, unless CUs are masked away from the process or held by another stream's
+// kernels for seconds); after ~2^21 polls (seconds) the wait is given up, `gave_up` is set and the caller fails the call,
+// whose result the host then discards.
+__device__ __forceinline__ unsigned long long bmk_lookback(unsigned long long* st, int64_t blk, unsigned long long tot, int lane,
+                                                           bool& gave_up) {
   const unsigned long long mask = (1ull << 62) - 1;
   unsigned long long excl = 0;
   int64_t hi = blk - 1;
+  int polls = 0;
   while (hi >= 0) {
     unsigned long long v[4];
 #pragma unroll
@@ -217,6 +223,10 @@ __device__ __forceinline__ unsigned long long bmk_lookback(unsigned long long* s
       }
     }
     if (retry) {   // (what was summed so far is dropped: the same windows are read again)
+      if (++polls > (1 << 21)) {
+        gave_up = true;
+        break;
+      }
       __builtin_amdgcn_s_sleep(8);
       continue;
     }
@@ -573,7 +583,9 @@ spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, con
 #if defined(BMK_ABL) && BMK_ABL == 1   // timing ablation (wrong row offsets): no look-back, rows at a fixed pitch
       const unsigned long long before = (unsigned long long)cur * 9900ull;
 #else
-      const unsigned long long before = bmk_lookback(state, cur, (unsigned long long)row_nnz, lane);
+      bool gave_up = false;
+      const unsigned long long before = bmk_lookback(state, cur, (unsigned long long)row_nnz, lane, gave_up);
+      if (gave_up) failed = true;
 #endif
       if (lane == 0) {
         misc->row_off = (int64_t)before;
