@@ -289,10 +289,18 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
                 (wk, wv), leg = cpu_leg(cpu_sum, "whole workload once (oracle.grouped_reduce: stable sort + np.add.reduceat)")
                 leg["keys_bit_exact"] = bool(np.array_equal(s.linear_loc().cpu().numpy(), wk))
                 leg["max_rel_err"] = rel_err(s.data.cpu().numpy(), wv) if leg["keys_bit_exact"] else None
+                extra = {}
+                if ax == 0:
+                    # what the leading-axis reduction pays that the trailing one does not: the stable radix sort of the
+                    # (permuted key, value) pairs - timed alone on this row's own keys, so that the row's fraction is explained
+                    # in the line (one histogram + four 8-bit onesweep passes over 2 x 10^6 16-byte pairs: launch-bound)
+                    pk = z.linear_loc() % 1_000_000 * 1000 + z.linear_loc() // 1_000_000
+                    extra["key_sort_ms"], _ = timed(lambda: K.sort_key_value(pk, z.data, 10 ** 9 - 1), reps=100, warm=10)
+                    extra["sum_axis2_ms_for_comparison"] = out.get("A8_sum_axis2_config1", {}).get("ms")
                 emit(f"A8_sum_axis{ax}_config1", row(f"config 1: COO(1000^3, {z.nnz} nnz).sum(axis={ax})"
                                                      + (" (needs a key sort)" if ax == 0 else ""), ms,
                                                      z.nnz * 16 + s.nnz * 16, groups=s.nnz, cpu_baseline=leg,
-                                                     **overheads(lambda: z.sum(axis=ax))))
+                                                     **extra, **overheads(lambda: z.sum(axis=ax))))
         del x, y
         if not quick and want("A7_1e8"):
             nb = 100_000_000

@@ -119,9 +119,43 @@ struct SdpStep {
   }
 };
 
+// The same steps software-pipelined: the Bt rows of batch U0 + UNR are requested BEFORE batch U0 (whose rows arrived in `bv`)
+// is multiplied, so a lane group always has one batch of loads in flight behind the one it works on.  Two batches of
+// registers instead of one: the kernel stays below the 96 registers that its LDS-limited five waves per SIMD allow.
+template <typename TIN, typename I, int LPN, int KS, int UNR, int U0>
+struct SdpPipe {
+  using ACC = typename Acc<TIN>::type;
+  using VT = Vec<TIN, 16 / (int)sizeof(TIN)>;
+  static __device__ __forceinline__ void run(int cnt, int sub, I myrow, I mycol, int myslot, const VT (&bv)[UNR][KS],
+                                             const int (&sl)[UNR], const I (&rr)[UNR], const char* sa, int cap, const char* Ab,
+                                             const char* Bb, int64_t lda_b, int64_t ldb_b, int koff_b, ACC& res) {
+    if constexpr (U0 < LPN) {
+      VT nbv[UNR][KS];
+      int nsl[UNR];
+      I nrr[UNR];
+      if constexpr (U0 + UNR < LPN) {
+        if (U0 + UNR < cnt)
+          SdpBatch<TIN, I, LPN, KS, UNR, U0 + UNR>::template load<0>(nbv, nsl, nrr, myrow, mycol, myslot, Bb, ldb_b, koff_b);
+      }
+      if (U0 < cnt) SdpBatch<TIN, I, LPN, KS, UNR, U0>::template dot<0>(cnt, sub, bv, sl, rr, sa, cap, Ab, lda_b, koff_b, res);
+      if constexpr (U0 + UNR < LPN)
+        SdpPipe<TIN, I, LPN, KS, UNR, U0 + UNR>::run(cnt, sub, myrow, mycol, myslot, nbv, nsl, nrr, sa, cap, Ab, Bb, lda_b, ldb_b,
+                                                      koff_b, res);
+    }
+  }
+};
+
+#ifndef SDP_PIPE
+#define SDP_PIPE 0   // 1: batches software-pipelined (SdpPipe; round 4: 0.374 ms at 104 registers = four waves per SIMD, 0.565 ms
+                     // squeezed into 96 with 27 spills, against 0.348 ms for 0: one batch at a time, 60 registers, five waves)
+#endif
+
 // BLK threads = BLK consecutive elements per workgroup
+#ifndef SDP_WPE
+#define SDP_WPE 5   // waves per SIMD the register allocation aims at (five 256-thread workgroups per CU is what the LDS allows)
+#endif
 template <typename TIN, typename TS, typename I, int LPN, int KS, int UNR, int BLK>
-__global__ void __launch_bounds__(BLK)
+__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(SDP_WPE, 8)))
 sddmm_panel_kernel(int64_t nnz, int cap, const I* __restrict__ rows, const I* __restrict__ cols,
                    const TS* __restrict__ s_data, const TIN* __restrict__ A, int64_t lda, const TIN* __restrict__ Bt,
                    int64_t ldb, TS* __restrict__ out, const int64_t* __restrict__ perm, const int64_t* __restrict__ xstate) {
@@ -160,7 +194,11 @@ sddmm_panel_kernel(int64_t nnz, int cap, const I* __restrict__ rows, const I* __
   const int grp = tid / LPN;
   const int koff_b = sub * 16;
   auto fetch = [&](int64_t pb, I& r, I& c, TS& sv, int64_t& pos) {
+#if defined(SDP_ABL) && SDP_ABL == 3   // timing ablation (wrong results): the mask arrays come from a 64 K-element window (L2 hits)
+    const int64_t nl = (pb + tid < we ? pb + tid : we - 1) & 0xffff;
+#else
     const int64_t nl = pb + tid < we ? pb + tid : we - 1;
+#endif
     r = __builtin_nontemporal_load(rows + nl);
 #if defined(SDP_ABL) && SDP_ABL == 2   // timing ablation (wrong results): every Bt row comes from a 16-row set (no L2 gather)
     c = __builtin_nontemporal_load(cols + nl) & 15;
@@ -222,15 +260,23 @@ sddmm_panel_kernel(int64_t nnz, int cap, const I* __restrict__ rows, const I* __
     for (int base = uniform(wv) * 64; base < nvec; base += BLK) {   // wave-uniform trip count; lanes past the end repeat the last vector
       int i = base + lane;
       i = i < nvec ? i : nvec - 1;
+#if defined(SDP_ABL) && SDP_ABL == 4   // timing ablation (wrong results): the staged A rows come from a 1024-row set
+      const char* ap = Ab + ((int64_t)(drow[i / VPR] & 1023) * lda_b + (int64_t)(i % VPR) * 16);
+#else
       const char* ap = Ab + ((int64_t)drow[i / VPR] * lda_b + (int64_t)(i % VPR) * 16);
+#endif
       sdp_dma16((unsigned)uniform(base) * 16u, ap);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     sdp_lds_barrier();
 
     ACC res = 0;
+#if SDP_PIPE
+    SdpPipe<TIN, I, LPN, KS, UNR, 0>::run(cnt, sub, myrow, mycol, myslot, bv0, sl0, rr0, sa, cap, Ab, Bb, lda_b, ldb_b, koff_b, res);
+#else
     B0::template dot<0>(cnt, sub, bv0, sl0, rr0, sa, cap, Ab, lda_b, koff_b, res);
     SdpStep<TIN, I, LPN, KS, UNR, UNR>::run(cnt, sub, myrow, mycol, myslot, sa, cap, Ab, Bb, lda_b, ldb_b, koff_b, res);
+#endif
 #if defined(SDP_ABL) && SDP_ABL == 1   // timing ablation (wrong order): results stored in panel order, coalesced
     if (mine) __builtin_nontemporal_store((TS)((ACC)mys * res), out + nl + (mypos & 0));
 #else
