@@ -19,4 +19,7 @@ run write WRITE_SIZE
 run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 run lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 python $R/tools/r04_summarise.py $R/gpurun_out/r04 > $R/gpurun_out/r04/summary.txt 2>&1
+# only summaries travel back (gpurun merges at most 64 MiB): the raw per-dispatch counter tables stay on the box
+find $R/gpurun_out/r04 $R/gpurun_out/pmc_r04 -name '*counter_collection.csv' -delete
+find $R/gpurun_out/r04 $R/gpurun_out/pmc_r04 -name '*kernel_trace.csv' -delete
 ls $R/gpurun_out/r04
