@@ -21,6 +21,7 @@ json.dump(flat, open('profiles/r04_tiled_pmc_summary.json', 'w'), indent=1)
 t = json.load(open('profiles/traffic.json'))
 t['round'] = 4
 k = t['kernels']['spmm_tiled']
+k['round'] = 4
 k.update({'FETCH_SIZE_KB_per_launch': flat['FETCH_SIZE'], 'WRITE_SIZE_KB_per_launch': flat['WRITE_SIZE'], 'traffic_bytes_per_launch': rd + wr,
           'TCC_HIT_sum': flat['TCC_HIT_sum'], 'TCC_MISS_sum': flat['TCC_MISS_sum'], 'TCC_REQ_sum': flat['TCC_REQ_sum'],
           'SQ_WAVE_CYCLES': wc, 'SQ_WAIT_ANY': flat['SQ_WAIT_ANY'], 'SQ_WAIT_INST_ANY': flat['SQ_WAIT_INST_ANY'], 'SQ_ACTIVE_INST_ANY': flat['SQ_ACTIVE_INST_ANY']})
