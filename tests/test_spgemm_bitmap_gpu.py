@@ -191,10 +191,11 @@ def test_more_column_ranges_than_two_and_the_split_form_ran():
         K.SPGEMM_STATS.clear()
         got = K._spgemm_rows(m, n, ad, ai, ap, bd, bi, bp)
         assert K.SPGEMM_STATS.get("kernel") == "bitmap" and K.SPGEMM_STATS.get("parts", 1) >= 6, K.SPGEMM_STATS
+        SPLIT_RUNS.append(K.SPGEMM_STATS["parts"])
     finally:
         K.SPGEMM_BITMAP = old
     _same(got, want)
-    assert SPLIT_RUNS or True
+    assert SPLIT_RUNS, "the column-range form must have taken some of this module's products"
 
 
 def test_product_api_takes_the_bitmap_kernel_and_is_reproducible():
