@@ -37,7 +37,10 @@
 // second register set so that the next row's products are requested right after its staging instead of after this row is
 // assembled 16.5 (the loads of one wave return in order: everything that waits on vmcnt in between - spill reloads, the
 // look-back - then waits for the whole burst); without the look-back (wrong offsets, timing only) 12.6: the coupling of the
-// workgroups costs 0.6 ms.  Model: per row and CU ~15 k cycles of product loads, ~15 k of result stores and ~35 k of LDS
+// workgroups costs 0.6 ms; nothing stored at all 13.0 (the result stores are hidden); no product loads at all (computed
+// columns, no parked products) 8.9: the LDS phases are two thirds of the time, the exposed part of the product loads one
+// third; waiting for the products before the row's stores are issued (so that no later wait covers the stores) 13.3: no change.
+// Model: per row and CU ~15 k cycles of product loads, ~15 k of result stores and ~35 k of LDS
 // phases run one after the other (64 k cycles per row); the fabric moves 30 GB per product at 2.4 TB/s.
 // Limits (checked by the host before the launch, spamd_spgemm_bitmap_limits): n_col <= 2^20, A rows of at most 256
 // elements, at most 1024 * ITEMS products per row (ITEMS = 16 for 4-byte values, 8 for 8-byte ones: the row must fit the
