@@ -675,7 +675,9 @@ SPGEMM_ROW_LOCAL = True  # tuning hook: False = always the global expand-sort-co
 
 SPGEMM_STATS = {}   # last row-local product: rows, rows left to the global form (diagnostics for the benches)
 SPGEMM_BITMAP = True            # wide rows of a matrix with <= 2^20 columns: csrc/spgemm_bitmap.hip (rows written in place)
-SPGEMM_BITMAP_MIN_MEAN = 1024   # mean products per row from which the per-row bitmap scan (n_col / 8 bytes of LDS) pays
+SPGEMM_BITMAP_MIN_MEAN = 1536   # mean products per row from which the per-row bitmap scan (n_col / 8 bytes of LDS) pays: measured
+#                                 at n_col = 10^6, 60000 rows (tools/r04/spgemm_sweep.py; ms buckets / bitmap): 900 products per row
+#                                 1.91 / 2.55, 2025: 3.36 / 2.89, 4096: 6.47 / 3.48, 6400: 8.13 / 4.44, 10^4: 13.95 / 6.45
 SPGEMM_BITMAP_MAX_DUPS = 120    # expected products per row that share an output element with an earlier one (list of 512)
 
 
