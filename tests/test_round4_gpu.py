@@ -233,3 +233,31 @@ def test_int32_product_takes_the_executor(sp):
     assert torch.int32 in ai.__dict__.get("_tiled_layouts", {})
     from sparse_amd import _kernels as K
     assert torch.equal(r1, K.dot_csr_ndarray((131072, 128), ai.data, ai.indices, ai.indptr, b))
+
+
+def test_large_coo_operand_takes_the_inspector_at_its_first_product(sp):
+    """round-3 verdict, item 3 (iii): from COO_TILED_FIRST_NNZ stored elements a COO operand gets its block stream at the
+    FIRST eligible product (smaller ones at the second, as before); the row pointers keep the coordinates' int32 width; the
+    result is the row-group kernel's, bit for bit."""
+    from sparse_amd import _dot, _kernels as K
+
+    M, Kd, N = 400_000, 6000, 128
+    g = sp.random((M, Kd), density=0.01, random_state=12, dtype=np.float32, idx_dtype=np.int32, format="gcxs", compressed_axes=(0,))
+    rows = K.csr_to_keys(g.indptr, torch.zeros_like(g.indices), M, 1).to(torch.int32)
+    coo = sp.COO(torch.stack([rows, g.indices]), g.data, shape=(M, Kd), has_duplicates=False, sorted=True)
+    b = torch.rand((Kd, N), device=g.data.device, dtype=torch.float32)
+    assert coo.nnz >= _dot.COO_TILED_FIRST_NNZ
+    r = coo @ b
+    assert torch.float32 in coo.__dict__.get("_tiled_layouts", {}), "first product of a large COO did not build the block stream"
+    assert coo._csr_view[2].dtype == torch.int32
+    assert torch.equal(r, K.dot_csr_ndarray((M, N), g.data, g.indices, g.indptr, b))
+    old = _dot.COO_TILED_FIRST_NNZ
+    try:
+        _dot.COO_TILED_FIRST_NNZ = 10 ** 12
+        coo2 = sp.COO(torch.stack([rows, g.indices]), g.data, shape=(M, Kd), has_duplicates=False, sorted=True)
+        coo2 @ b
+        assert not coo2.__dict__.get("_tiled_layouts")          # the round-3 policy: at the second product
+        coo2 @ b
+        assert torch.float32 in coo2.__dict__.get("_tiled_layouts", {})
+    finally:
+        _dot.COO_TILED_FIRST_NNZ = old
