@@ -416,7 +416,7 @@ int spamd_spgemm_pack(int val_dtype, int64_t n_row, const int64_t* prod_off, con
  *     trims to out_indptr[n_row]); work = n_row + 32 int64 words, zeroed here: afterwards work[1] != 0 = a row was outside
  *     the limits (discard the result, use spamd_spgemm_rows), work[2] = values written whose bits are all zero. */
 int64_t spamd_spgemm_bitmap_limits(int val_dtype, int which);
-/* parts = 1: whole rows, one 1024-thread workgroup per CU (n_col <= limit 2).  parts > 1 (4-byte values): every row in `parts`
+/* parts = 1: whole rows, one 1024-thread workgroup per CU (n_col <= limit 2).  parts > 1: every row in `parts`
  * column ranges (ceil(n_col / parts) rounded up to 256 <= limit 5), 512-thread workgroups, two per CU; bsplit = n_inner *
  * (parts - 1) words of the index type (workspace, filled here: where each B row crosses a range boundary), n_inner = rows
  * of B; limits 4 / 6 are per part.  work = n_row * parts + 32 int64 words. */

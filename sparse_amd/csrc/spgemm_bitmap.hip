@@ -670,11 +670,15 @@ __global__ void __launch_bounds__(256) spgemm_bsplit_kernel(int64_t n_inner, int
 
 // the two forms: WIDE = whole rows, one 1024-thread workgroup per CU, n_col <= 2^20; SPLIT = parts of rows (column ranges),
 // 512 threads and <= 80 KB of LDS, so that TWO workgroups share a CU and fill each other's barrier and memory waits
-constexpr int BMK_SPLIT_THREADS = 512, BMK_SPLIT_ITEMS = 16, BMK_SPLIT_DUP = 256;
+constexpr int BMK_SPLIT_THREADS = 512, BMK_SPLIT_ITEMS = 16, BMK_SPLIT_DUP = 256;   // (8-byte values: 8 products per thread)
+template <typename V>
+struct BmkSplitItems {
+  static constexpr int value = sizeof(V) == 4 ? BMK_SPLIT_ITEMS : BMK_SPLIT_ITEMS / 2;
+};
 
 template <typename V>
 static int64_t bmk_split_max_groups() {   // groups of 256 columns whose bitmap + positions fit next to the rest in 80 KB
-  using L = BmkLayout<V, BMK_SPLIT_THREADS, BMK_SPLIT_ITEMS, BMK_SPLIT_DUP>;
+  using L = BmkLayout<V, BMK_SPLIT_THREADS, BmkSplitItems<V>::value, BMK_SPLIT_DUP>;
   const int64_t rest = (int64_t)L::bytes(0) - (int64_t)L::front_bytes(0);
   int64_t g = (80 * 1024 - rest) / 34;
   while (g > 0 && (int64_t)L::bytes((int)g) > 80 * 1024) --g;
@@ -730,15 +734,15 @@ extern "C" int64_t spamd_spgemm_bitmap_limits(int val_dtype, int which) {
     case 1: return BMK_STAGE;
     case 2: return (int64_t)BMK_MAX_GROUPS * 256;
     case 3: return BMK_DUP;
-    case 4: return v4 ? (int64_t)BMK_SPLIT_THREADS * BMK_SPLIT_ITEMS : 0;   // (4-byte values only)
-    case 5: return v4 ? bmk_split_max_groups<float>() * 256 : 0;
+    case 4: return (int64_t)BMK_SPLIT_THREADS * (v4 ? BmkSplitItems<float>::value : BmkSplitItems<double>::value);
+    case 5: return (v4 ? bmk_split_max_groups<float>() : bmk_split_max_groups<double>()) * 256;
     case 6: return BMK_SPLIT_DUP;
     default: return -1;
   }
 }
 
 // C = A @ B, rows written in place: out_indptr[n_row + 1], out_indices / out_data with room for every product (the
-// caller trims to out_indptr[n_row]).  parts = 1: the wide form (n_col <= limit 2).  parts > 1 (4-byte values): every row
+// caller trims to out_indptr[n_row]).  parts = 1: the wide form (n_col <= limit 2).  parts > 1: every row
 // in `parts` column ranges of ceil(n_col / parts) columns rounded up to 256 (<= limit 5), two workgroups per CU; `bsplit`
 // = n_inner * (parts - 1) words of the index type, filled here (n_inner = rows of B).  work: n_row * parts + 32 words,
 // zeroed here; afterwards work[1] != 0 = failed (a row or part outside the limits, or with more parked products than the
@@ -751,9 +755,8 @@ extern "C" int spamd_spgemm_bitmap(int val_dtype, int idx_dtype, int64_t n_row, 
   if (parts == 1 && n_col > (int64_t)BMK_MAX_GROUPS * 256) return SPAMD_EINVAL;
   if (parts > 1 && !bsplit) return SPAMD_EINVAL;
   const bool v4 = val_dtype == SPAMD_F32 || val_dtype == SPAMD_I32;
-  if (parts > 1 && !v4) return SPAMD_ETYPE;
   int64_t range = ceil_div(ceil_div(n_col, (int64_t)parts), (int64_t)256) * 256;
-  if (parts > 1 && range > bmk_split_max_groups<float>() * 256) return SPAMD_EINVAL;
+  if (parts > 1 && range > (v4 ? bmk_split_max_groups<float>() : bmk_split_max_groups<double>()) * 256) return SPAMD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (hipError_t e = hipMemsetAsync(work, 0, (size_t)(n_row * parts + BMK_HEADER) * sizeof(int64_t), s); e != hipSuccess) return (int)e;
   if (n_row == 0) return (int)hipMemsetAsync(out_indptr, 0, sizeof(int64_t), s);
@@ -769,9 +772,8 @@ extern "C" int spamd_spgemm_bitmap(int val_dtype, int idx_dtype, int64_t n_row, 
                                                 (const I*)b_indptr, (const I*)bsplit, (const I*)b_indices, (const V*)b_data, w,  \
                                                 out_indptr, out_indices, (V*)out_data, s));
   if (parts > 1) {
-    SPAMD_DISPATCH_IDX(idx_dtype, I, {
-      if (val_dtype == SPAMD_F32) BMK_GO(float, I, BMK_SPLIT_ITEMS, BMK_SPLIT_THREADS, BMK_SPLIT_DUP, true)
-      BMK_GO(int32_t, I, BMK_SPLIT_ITEMS, BMK_SPLIT_THREADS, BMK_SPLIT_DUP, true)
+    SPAMD_DISPATCH_VAL(val_dtype, V, {
+      SPAMD_DISPATCH_IDX(idx_dtype, I, { BMK_GO(V, I, BmkSplitItems<V>::value, BMK_SPLIT_THREADS, BMK_SPLIT_DUP, true) })
     })
     return SPAMD_ETYPE;
   }

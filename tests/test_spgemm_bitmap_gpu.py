@@ -198,6 +198,29 @@ def test_more_column_ranges_than_two_and_the_split_form_ran():
     assert SPLIT_RUNS, "the column-range form must have taken some of this module's products"
 
 
+@pytest.mark.parametrize("dtype,idt", [(np.float64, np.int64), (np.int64, np.int32)])
+def test_eight_byte_values_of_config5_shape_take_column_ranges(dtype, idt):
+    """the reference's default value type at config 5's row shape (100 x 100 products): beyond the whole-row form's 8192
+    products for 8-byte values, so the row goes in three or more column ranges"""
+    from sparse_amd import _kernels as K
+
+    m, k, n = 1200, 30_000, 1_000_000
+    A = _csr(m, k, 100, 50, dtype, idt, empty_every=101)
+    B = _csr(k, n, 100, 51, dtype, idt)
+    (ad, ai, ap), (bd, bi, bp) = _dev(A), _dev(B)
+    old = K.SPGEMM_BITMAP
+    try:
+        K.SPGEMM_BITMAP = False
+        want = K._spgemm_rows(m, n, ad, ai, ap, bd, bi, bp)
+        K.SPGEMM_BITMAP = True
+        K.SPGEMM_STATS.clear()
+        got = K._spgemm_rows(m, n, ad, ai, ap, bd, bi, bp)
+        assert K.SPGEMM_STATS.get("kernel") == "bitmap" and K.SPGEMM_STATS.get("parts", 1) >= 3, K.SPGEMM_STATS
+    finally:
+        K.SPGEMM_BITMAP = old
+    _same(got, want)
+
+
 def test_product_api_takes_the_bitmap_kernel_and_is_reproducible():
     import sparse_amd as sp
     from sparse_amd import _kernels as K
