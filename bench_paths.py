@@ -468,8 +468,26 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
         emit("A4_spgemm_config5_share", row(
             f"one of {share} row blocks of config 5: GCXS({rows}x{n5}, {gA.nnz} nnz) @ GCXS({n5}x{n5}, {gB.nnz} nnz), {int(prods)} products "
             f"-> {c.nnz} nnz (f32/int32)", ms, gA.nnz * 8 + prods * 8 + c.nnz * 8, flops=2.0 * prods, products=prods,
-            ns_per_product=ms * 1e6 / max(prods, 1), cpu_baseline=leg))
-        del gA, gB, c
+            ns_per_product=ms * 1e6 / max(prods, 1), cpu_baseline=leg, kernel=K.SPGEMM_STATS.get("kernel"),
+            parts=K.SPGEMM_STATS.get("parts")))
+        del c
+        if not quick:
+            # the same block in the reference's DEFAULT dtypes (`sparse.random` gives float64 values and int64 indices): the
+            # bitmap kernel in column ranges (8-byte values: 4096 products per part)
+            torch.cuda.empty_cache()
+            gB8 = sp.GCXS((gB.data.to(torch.float64), gB.indices.to(torch.int64), gB.indptr.to(torch.int64)), shape=gB.shape,
+                          compressed_axes=(0,))
+            gA8 = sp.GCXS((gA.data.to(torch.float64), gA.indices.to(torch.int64), gA.indptr.to(torch.int64)), shape=gA.shape,
+                          compressed_axes=(0,))
+            del gA, gB
+            ms8, c8 = timed(lambda: gA8 @ gB8, reps=3, warm=2)
+            emit("A4_spgemm_config5_share_f64", row(
+                f"the same block with float64 values and int64 indices (the reference's defaults): {int(prods)} products -> {c8.nnz} nnz",
+                ms8, gA8.nnz * 16 + prods * 16 + c8.nnz * 16, flops=2.0 * prods, products=prods,
+                ns_per_product=ms8 * 1e6 / max(prods, 1), kernel=K.SPGEMM_STATS.get("kernel"), parts=K.SPGEMM_STATS.get("parts")))
+            del gA8, gB8, c8
+        else:
+            del gA, gB
 
     _settings.NAN_CHECK = nan_was
     return out

@@ -44,7 +44,9 @@ ROWS = {
     "A7_multiply_config1": ["spamd::mp_union_kernel<double, double, 3, 8>"],
     "A9_sddmm_bf16": ["spamd::sddmm_panel_kernel<__hip_bfloat16"],
     "A9_sddmm_f32": ["spamd::sddmm_rowcache_kernel<float, float, int, 16, 4, 4, true>"],
-    "A4_spgemm_config5_share": ["spamd::spgemm_bitmap_kernel<float, int, 16>", "spamd::spgemm_row_products_kernel<int>"],
+    "A4_spgemm_config5_share": ["spamd::spgemm_bitmap_kernel<float, int, 16, 1024, 512, false>", "spamd::spgemm_row_products_kernel<int>"],
+    "A4_spgemm_config5_share_f64": ["spamd::spgemm_bitmap_kernel<double, long, 8, 512, 256, true>", "spamd::spgemm_row_products_kernel<long>",
+                                    "spamd::spgemm_bsplit_kernel<long>"],
     "A1_f64": ["spamd::spmm_tiled_kernel<0, 4, double>"],
     "A2_default_gcxs_steady": ["spamd::spmm_tiled_kernel<0, 4, double>"],
 }
