@@ -221,6 +221,23 @@ def test_eight_byte_values_of_config5_shape_take_column_ranges(dtype, idt):
     _same(got, want)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_bitmap_forms_on_random_shapes(seed):
+    """randomised cross-check of both forms against the bucket kernels: row counts, inner sizes, column counts up to 6 x 10^6,
+    row lengths, value and index types, empty rows; whatever form the host policy picks must give the bucket kernels' bits"""
+    rng = np.random.default_rng(1000 + seed)
+    m = int(rng.integers(1, 1500))
+    k = int(rng.integers(200, 30_000))
+    n = int(rng.choice([70_000, 300_000, 1_000_000, 1_048_576, 2_500_000, 6_000_000]))
+    per_a = int(rng.integers(5, 140))
+    per_b = int(rng.integers(5, 140))
+    dtype, idt = [(np.float32, np.int32), (np.float64, np.int64), (np.int32, np.int64), (np.float32, np.int64)][seed % 4]
+    A = _csr(m, k, min(per_a, k // 2), 2000 + seed, dtype, idt, empty_every=int(rng.integers(0, 9)))
+    B = _csr(k, n, per_b, 3000 + seed, dtype, idt, empty_every=int(rng.integers(0, 9)))
+    got, want, used = _both((m, n), A, B)
+    _same(got, want)      # (`used` may be "buckets": few columns with long rows park more products than the list holds)
+
+
 def test_product_api_takes_the_bitmap_kernel_and_is_reproducible():
     import sparse_amd as sp
     from sparse_amd import _kernels as K
