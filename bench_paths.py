@@ -204,7 +204,7 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
         b32 = b[:, :32].contiguous()
         ms_rg, _ = timed(lambda: K.dot_csr_ndarray((M, 32), data, idx, ptr, b32), reps=5)
         a32 @ b32
-        ms, r = timed(lambda: a32 @ b32, reps=10)
+        ms, r = timed(lambda: a32 @ b32, reps=10, warm=4)   # (fresh 128 MB results: the first calls pay the allocator)
         emit("A1_shapes_n32", row(f"config-2 matrix x dense {Kd}x32 fp32 (narrow result: B zero-padded to one 128-column panel, C written "
                                   f"unpadded by the executor)", ms, nnz * 8 + (M + 1) * 4 + Kd * 32 * 4 + M * 32 * 4,
                                   flops=2.0 * nnz * 32, rowgroup_ms=ms_rg, speedup_vs_rowgroup=ms_rg / ms))
@@ -214,9 +214,27 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
         ms_rg, _ = timed(lambda: K.dot_csr_ndarray((m5, N), d5, i5, q5, b), reps=10)
         lay = K.csr_tiled_layout(d5, i5, q5, m5, Kd)
         ms_tl, _ = timed(lambda: K.dot_csr_ndarray_tiled(lay, (m5, N), Kd, b), reps=10)
-        emit("A1_shapes_m50k", row(f"first {m5} rows of the config-2 matrix ({p5} nnz) x dense {Kd}x{N} fp32: the row-group kernel "
-                                   f"(policy below 65536 rows: 90 workgroups of 560 rows do not fill 256 CUs)", ms_rg,
-                                   p5 * 8 + (m5 + 1) * 4 + Kd * N * 4 + m5 * N * 4, flops=2.0 * p5 * N, tiled_forced_ms=ms_tl))
+        emit("A1_shapes_m50k", row(f"first {m5} rows of the config-2 matrix ({p5} nnz) x dense {Kd}x{N} fp32 (round 4: one full column "
+                                   f"panel takes the executor from 45056 rows; every workgroup walks all of K, so its time has a 0.108 ms floor)",
+                                   ms_tl, p5 * 8 + (m5 + 1) * 4 + Kd * N * 4 + m5 * N * 4, flops=2.0 * p5 * N, rowgroup_ms=ms_rg,
+                                   policy_takes_executor=bool(_dot._tiled_eligible(d5, b, (m5, N), Kd))))
+        m6, n6 = 16_384, 512
+        p6 = int(ptr[m6])
+        d6, i6, q6 = data[:p6].contiguous(), idx[:p6].contiguous(), ptr[:m6 + 1].contiguous()
+        b6 = torch.rand((Kd, n6), device="cuda", dtype=torch.float32)
+        ms_rg, _ = timed(lambda: K.dot_csr_ndarray((m6, n6), d6, i6, q6, b6), reps=10)
+        def first6():
+            a6 = sp.GCXS((d6, i6, q6), shape=(m6, Kd), compressed_axes=(0,))
+            return a6 @ b6
+        ms_f6, _ = timed(first6, reps=10, warm=3)
+        a6 = sp.GCXS((d6, i6, q6), shape=(m6, Kd), compressed_axes=(0,))
+        ms6, r6 = timed(lambda: a6 @ b6, reps=10, warm=3)
+        emit("A1_shapes_m16k_n512", row(f"first {m6} rows of the config-2 matrix ({p6} nnz) x dense {Kd}x{n6} fp32 through a @ b (round 4: "
+                                        f"results of 4 column panels take the executor from 10240 rows)", ms6,
+                                        p6 * 8 + (m6 + 1) * 4 + Kd * n6 * 4 + m6 * n6 * 4, flops=2.0 * p6 * n6, rowgroup_ms=ms_rg,
+                                        first_product_ms=ms_f6, took_executor=bool(getattr(a6, "_tiled_layouts", None)),
+                                        identical_to_rowgroup=bool(torch.equal(r6, K.dot_csr_ndarray((m6, n6), d6, i6, q6, b6)))))
+        del a6, r6, b6
         di = (data * 100).to(torch.int32)
         bi = (b * 10).to(torch.int32)
         ms_irg, _ = timed(lambda: K.dot_csr_ndarray((M, N), di, idx, ptr, bi), reps=5)

@@ -344,8 +344,8 @@ def _tiled_eligible(data, bt, out_shape, Kd):
     panels; from N = 8 (float32) / 5 (float64) on the padded product beats the row-group kernel (round 3, config-2 operand:
     fp32 N = 8 / 16 / 32: 0.80 vs 1.14 / 1.17 / 1.18 ms, fp64 N = 5 / 8 / 16: 1.02 vs 1.17 / 1.33 / 1.32 ms;
     `NARROW=1 tools/rowgroup_shapes.py`; results of at most 4 columns have the row-vector kernel).  Thresholds
-    measured on MI355X (tools/tiled_crossover.py): it needs >= 117 workgroups of 560 rows to beat the row-group
-    kernel, and a density of >= 0.3 % (12 stored elements per 32 x 128 cells: ~16 per (35-row x 160-column) list) — half
+    measured on MI355X (tools/tiled_crossover.py, tools/r04/m_crossover.py): enough rows for the width (`_tiled_min_rows`)
+    and a density of >= 0.3 % (12 stored elements per 32 x 128 cells: ~16 per (35-row x 160-column) list) — half
     that when B is too large for the row-group kernel's gathers to stay in cache (>= 16 MB).  The inspector costs about one row-group product, so
     a single product breaks even and every further one is 2-3x faster."""
     M, N = out_shape
@@ -361,7 +361,25 @@ def _tiled_eligible(data, bt, out_shape, Kd):
         # the executor on these shapes (config 3: 0.13-0.15 ms against 0.143 ms) without an inspector or a second copy of A
         return False
     per_list = int(data.numel()) * 4096 / max(M * Kd, 1)
-    return M >= 65536 and (per_list >= 12 or (per_list >= 6 and Kd * N * bt.element_size() >= (16 << 20)))
+    return M >= _tiled_min_rows(N * dt.itemsize) and (
+        per_list >= 12 or (per_list >= 6 and Kd * N * bt.element_size() >= (16 << 20)))
+
+
+def _tiled_min_rows(row_bytes):
+    """Fewest rows at which the executor beats the row-group kernel, by the width of a result row.  The executor's time
+    has a floor (every workgroup walks all of K: 0.108 ms at K = 10^4) but does not grow with the number of column
+    panels until the chip is full, while the row-group kernel's grows with M x N and doubles again for 8-byte values.
+    Round 4, 1 % density, K = 10^4 (tools/r04/m_crossover.py; executor / row-group ms):
+      fp32 N = 128: M = 40960 0.109 / 0.106, 50000 0.112 / 0.129, 65536 0.113 / 0.167;
+      fp32 N = 512: M = 4096 0.109 / 0.068, 8192 0.109 / 0.165, 16384 0.113 / 0.342, 32768 0.125 / 0.699;
+      fp64 N = 128: M = 8192 0.115 / 0.064, 16384 0.119 / 0.130, 32768 0.120 / 0.264;
+      fp64 N = 512: M = 4096 0.118 / 0.171, 16384 0.149 / 0.788, 65536 0.542 / 3.24.
+    (Rounds 1-3 asked for 65536 rows whatever the width - 117 workgroups of 560 rows - and so left the 3-6x of the wide
+    and float64 cases unused.)  Partial panels keep the old bound: the row-group kernel is at its best on narrow rows."""
+    if row_bytes < 512:
+        return 65536
+    panels = -(-row_bytes // 512)
+    return 45056 if panels == 1 else max(4096, 40960 // panels)
 
 
 DERIVED_CACHES = ("_csr_view", "_csr_twin", "_tiled_layouts", "_spmm_uses", "_nan_memo", "_derived_stamp", "_sddmm_plan", "_t_view", "_coo_view")

@@ -261,3 +261,27 @@ def test_large_coo_operand_takes_the_inspector_at_its_first_product(sp):
         assert torch.float32 in coo2.__dict__.get("_tiled_layouts", {})
     finally:
         _dot.COO_TILED_FIRST_NNZ = old
+
+
+@pytest.mark.parametrize("dtype, M, N, takes", [(torch.float32, 12_000, 512, True), (torch.float32, 9_000, 512, False),
+                                                (torch.float64, 21_000, 128, True), (torch.float64, 6_000, 512, True),
+                                                (torch.float32, 46_000, 128, True), (torch.float32, 40_000, 128, False),
+                                                (torch.float32, 50_000, 64, False), (torch.int32, 12_000, 512, True)])
+def test_executor_row_bound_follows_the_result_width(sp, dtype, M, N, takes):
+    """Round 4 (`_dot._tiled_min_rows`): the fewest rows at which `a @ dense` takes the inspector/executor shrinks with the
+    number of 512-byte column panels of the result (measured crossovers, tools/r04/m_crossover.py); either way the
+    result is the row-group kernel's bit for bit (same k-ascending FMA per output element)."""
+    from bench import make_csr_device
+    from sparse_amd import _kernels
+
+    Kd = 4000
+    data, idx, ptr = make_csr_device(M, Kd, 0.01, seed=M % 97, dtype=torch.float32 if dtype == torch.int32 else dtype)
+    if dtype == torch.int32:
+        data = (data * 1000).to(torch.int32)
+        b = torch.randint(-1000, 1000, (Kd, N), device="cuda", dtype=torch.int32)
+    else:
+        b = torch.rand((Kd, N), device="cuda", dtype=dtype) - 0.5
+    a = sp.GCXS((data, idx, ptr), shape=(M, Kd), compressed_axes=(0,))
+    got = a @ b
+    assert bool(getattr(a, "_tiled_layouts", None)) == takes
+    assert torch.equal(got, _kernels.dot_csr_ndarray((M, N), data, idx, ptr, b))
