@@ -345,8 +345,7 @@ def _tiled_eligible(data, bt, out_shape, Kd):
     fp32 N = 8 / 16 / 32: 0.80 vs 1.14 / 1.17 / 1.18 ms, fp64 N = 5 / 8 / 16: 1.02 vs 1.17 / 1.33 / 1.32 ms;
     `NARROW=1 tools/rowgroup_shapes.py`; results of at most 4 columns have the row-vector kernel).  Thresholds
     measured on MI355X (tools/tiled_crossover.py, tools/r04/m_crossover.py): enough rows for the width (`_tiled_min_rows`)
-    and a density of >= 0.3 % (12 stored elements per 32 x 128 cells: ~16 per (35-row x 160-column) list) — half
-    that when B is too large for the row-group kernel's gathers to stay in cache (>= 16 MB).  The inspector costs about one row-group product, so
+    and enough stored elements per 32 x 128 cells for the width (`_tiled_min_density`: 5-12).  The inspector costs about one row-group product, so
     a single product breaks even and every further one is 2-3x faster."""
     M, N = out_shape
     if _settings.TILED_SPMM == "never" or bt.dim() != 2:
@@ -361,8 +360,22 @@ def _tiled_eligible(data, bt, out_shape, Kd):
         # the executor on these shapes (config 3: 0.13-0.15 ms against 0.143 ms) without an inspector or a second copy of A
         return False
     per_list = int(data.numel()) * 4096 / max(M * Kd, 1)
-    return M >= _tiled_min_rows(N * dt.itemsize) and (
-        per_list >= 12 or (per_list >= 6 and Kd * N * bt.element_size() >= (16 << 20)))
+    return M >= _tiled_min_rows(N * dt.itemsize) and per_list >= _tiled_min_density(N * dt.itemsize, Kd * N * bt.element_size())
+
+
+def _tiled_min_density(row_bytes, b_bytes):
+    """Fewest stored elements per 4096 cells (a 32 x 128 patch) at which the executor wins.  Its time barely depends on the
+    density below ~0.5 % (it walks every list, empty or not), the row-group kernel's is linear in it and in the width.
+    Round 4, M = 262144, K = 10^4 (tools/r04/density_crossover.py; executor / row-group ms at 4.1, 8.2, 12.3 per 4096):
+      fp32 N = 128: 0.156 / 0.125, 0.157 / 0.172, 0.162 / 0.236;      fp32 N = 512: 0.610 / 0.684, 0.609 / 1.26, 0.630 / 1.82;
+      fp64 N = 128: 0.304 / 0.264, 0.310 / 0.479, 0.314 / 0.694;      fp64 N = 512: 1.21 / 1.52, 1.23 / 2.83, 1.25 / 4.19;
+    K = 10^5 (B of 51-410 MB: the row-group kernel's gathers miss the caches) crosses at ~3.4 for every width.
+    Rounds 1-3 asked for 12 (6 with a large B) whatever the width."""
+    if row_bytes < 512:
+        return 6 if b_bytes >= (16 << 20) else 12
+    panels = -(-row_bytes // 512)
+    need = 9 if panels == 1 else (6 if panels == 2 else 5)
+    return min(need, 5) if b_bytes >= (16 << 20) else need
 
 
 def _tiled_min_rows(row_bytes):

@@ -263,19 +263,23 @@ def test_large_coo_operand_takes_the_inspector_at_its_first_product(sp):
         _dot.COO_TILED_FIRST_NNZ = old
 
 
-@pytest.mark.parametrize("dtype, M, N, takes", [(torch.float32, 12_000, 512, True), (torch.float32, 9_000, 512, False),
-                                                (torch.float64, 21_000, 128, True), (torch.float64, 6_000, 512, True),
-                                                (torch.float32, 46_000, 128, True), (torch.float32, 40_000, 128, False),
-                                                (torch.float32, 50_000, 64, False), (torch.int32, 12_000, 512, True)])
-def test_executor_row_bound_follows_the_result_width(sp, dtype, M, N, takes):
-    """Round 4 (`_dot._tiled_min_rows`): the fewest rows at which `a @ dense` takes the inspector/executor shrinks with the
-    number of 512-byte column panels of the result (measured crossovers, tools/r04/m_crossover.py); either way the
-    result is the row-group kernel's bit for bit (same k-ascending FMA per output element)."""
+@pytest.mark.parametrize("dtype, M, N, density, takes", [
+    (torch.float32, 12_000, 512, 0.01, True), (torch.float32, 9_000, 512, 0.01, False),
+    (torch.float64, 21_000, 128, 0.01, True), (torch.float64, 6_000, 512, 0.01, True),
+    (torch.float32, 46_000, 128, 0.01, True), (torch.float32, 40_000, 128, 0.01, False),
+    (torch.float32, 50_000, 64, 0.01, False), (torch.int32, 12_000, 512, 0.01, True),
+    (torch.float32, 70_000, 512, 0.0015, True), (torch.float32, 70_000, 128, 0.0015, False),
+    (torch.float64, 70_000, 128, 0.0016, True), (torch.float64, 70_000, 128, 0.001, False)])
+def test_executor_bounds_follow_the_result_width(sp, dtype, M, N, density, takes):
+    """Round 4 (`_dot._tiled_min_rows`, `_dot._tiled_min_density`): the fewest rows and the lowest density at which
+    `a @ dense` takes the inspector/executor shrink with the number of 512-byte column panels of the result (measured
+    crossovers, tools/r04/m_crossover.py and density_crossover.py); either way the result is the row-group kernel's
+    bit for bit (same k-ascending FMA per output element)."""
     from bench import make_csr_device
     from sparse_amd import _kernels
 
     Kd = 4000
-    data, idx, ptr = make_csr_device(M, Kd, 0.01, seed=M % 97, dtype=torch.float32 if dtype == torch.int32 else dtype)
+    data, idx, ptr = make_csr_device(M, Kd, density, seed=M % 97, dtype=torch.float32 if dtype == torch.int32 else dtype)
     if dtype == torch.int32:
         data = (data * 1000).to(torch.int32)
         b = torch.randint(-1000, 1000, (Kd, N), device="cuda", dtype=torch.int32)
