@@ -18,8 +18,14 @@
 
 namespace spamd {
 
-constexpr int MP_THREADS = 512;
-constexpr int MP_VT = 8;
+#ifndef SPAMD_MP_THREADS
+#define SPAMD_MP_THREADS 1024
+#endif
+#ifndef SPAMD_MP_VT
+#define SPAMD_MP_VT 4
+#endif
+constexpr int MP_THREADS = SPAMD_MP_THREADS;
+constexpr int MP_VT = SPAMD_MP_VT;
 constexpr int MP_TILE = MP_THREADS * MP_VT;
 
 // ---- the elementwise functions (same codes as spamd_ewise_binary) --------------------------------
@@ -127,9 +133,13 @@ __device__ __forceinline__ int64_t mp_diag_wave(const int64_t* __restrict__ a, i
 // kernel), and the workspace `counts` = [ticket, done, unused, state words ...] is left ZERO by the kernel itself (the
 // last tile to finish its look-back clears it: no memset before the next call).  The number of outputs goes to
 // offs[0] (device) and, when given, to *out_total_host - pinned host memory the caller spins on instead of copying back.
-// VT items per thread (tile = MP_THREADS * VT): 8.  (Measured at config 1, 2 x 10^6 items: 2048-item tiles, VT = 4, put
-// four workgroups on a CU instead of two but double the diagonal searches of the fused form: 0.080 ms per `x + y`
-// against 0.062 ms.)
+// VT items per thread (tile = MP_THREADS * VT).  Rounds 1-3: 512 threads x 8 items.  Round 4: 1024 threads x 4 items - the
+// same 4096-item tile (same LDS, two workgroups per CU) with twice the waves, so the chain ticket -> diagonals -> segment
+// loads -> look-back of a tile has 8 waves per SIMD to hide behind instead of 4 and the serial part of the merge is half as
+// long (float64, 10^8 + 10^8 items: x + y 2.38 -> 2.01 ms, x * y 1.89 -> 1.53 ms; config 1 0.060 -> 0.058 ms).  Measured
+// and worse, same two rows: 512 x 4 (2048-item tiles, the same wave count: 2.44 / 1.85 - the per-tile chain is what costs),
+// 256 x 8 2.80 / 2.07, 256 x 4 3.05 / 2.88, 1024 x 8 (one workgroup per CU) 2.72 / 1.91, 1024 x 6 2.69 / 2.03,
+// 1024 x 2 2.68 / 2.14 (tools/r04/run_mp.sh with -DSPAMD_MP_THREADS / -DSPAMD_MP_VT).
 template <typename T, typename O, int MODE, int VT = MP_VT>
 __global__ void __launch_bounds__(MP_THREADS)
 mp_union_kernel(int op, const int64_t* __restrict__ ka, const T* __restrict__ va, int64_t na,
@@ -327,15 +337,8 @@ extern "C" int64_t spamd_merge_num_blocks(int64_t na, int64_t nb) {
   return t <= 0 ? 0 : (t + MP_TILE - 1) / MP_TILE;
 }
 
-// tiles of the fused form (spamd_merge_union_fused); MP_FUSED_SMALL = item count up to which it would take 2048-item tiles
-// (0: never, see the note on VT above)
-constexpr int64_t MP_FUSED_SMALL = 0;
-extern "C" int64_t spamd_merge_fused_blocks(int64_t na, int64_t nb) {
-  const int64_t t = na + nb;
-  if (t <= 0) return 0;
-  const int64_t tile = t <= MP_FUSED_SMALL ? MP_THREADS * 4 : MP_TILE;
-  return (t + tile - 1) / tile;
-}
+// tiles of the fused form (spamd_merge_union_fused)
+extern "C" int64_t spamd_merge_fused_blocks(int64_t na, int64_t nb) { return spamd_merge_num_blocks(na, nb); }
 
 extern "C" int spamd_merge_partition(int64_t na, const int64_t* ka, int64_t nb, const int64_t* kb, int64_t* part,
                                      void* stream) {
@@ -412,22 +415,15 @@ extern "C" int spamd_merge_union_fused(int op, int val_dtype, int64_t na, const 
   if (na < 0 || nb < 0 || !ws || !total_dev) return SPAMD_EINVAL;
   const int64_t nblocks = spamd_merge_fused_blocks(na, nb);
   if (nblocks == 0) return SPAMD_EINVAL;   // (nothing to merge: the caller returns an empty result without a launch)
-  const bool small = na + nb <= MP_FUSED_SMALL;
   hipStream_t s = (hipStream_t)stream;
   const bool to_bool = op >= 32 && op < 64;
   if (op >= 64 && (val_dtype == SPAMD_F32 || val_dtype == SPAMD_F64)) return SPAMD_ETYPE;
   if (op == 6) return SPAMD_ETYPE;  // power: use the aligned-array path
 #define MP_FUSED(T, O)                                                                                          \
-  if (small)                                                                                                    \
-    hipLaunchKernelGGL((mp_union_kernel<T, O, 3, 4>), dim3((unsigned)nblocks), dim3(MP_THREADS), 0, s, op, ka,   \
-                       (const T*)va, na, kb, (const T*)vb, nb, from_bits<T>(fill_a_bits),                       \
-                       from_bits<T>(fill_b_bits), from_bits<O>(fill_out_bits), (const int64_t*)nullptr, ws,     \
-                       total_dev, out_keys, (O*)out_vals, total_host);                                          \
-  else                                                                                                          \
-    hipLaunchKernelGGL((mp_union_kernel<T, O, 3>), dim3((unsigned)nblocks), dim3(MP_THREADS), 0, s, op, ka,      \
-                       (const T*)va, na, kb, (const T*)vb, nb, from_bits<T>(fill_a_bits),                       \
-                       from_bits<T>(fill_b_bits), from_bits<O>(fill_out_bits), (const int64_t*)nullptr, ws,     \
-                       total_dev, out_keys, (O*)out_vals, total_host)
+  hipLaunchKernelGGL((mp_union_kernel<T, O, 3>), dim3((unsigned)nblocks), dim3(MP_THREADS), 0, s, op, ka,        \
+                     (const T*)va, na, kb, (const T*)vb, nb, from_bits<T>(fill_a_bits),                         \
+                     from_bits<T>(fill_b_bits), from_bits<O>(fill_out_bits), (const int64_t*)nullptr, ws,       \
+                     total_dev, out_keys, (O*)out_vals, total_host)
   switch (val_dtype) {
     case SPAMD_F32: if (to_bool) MP_FUSED(float, uint8_t); else MP_FUSED(float, float); break;
     case SPAMD_F64: if (to_bool) MP_FUSED(double, uint8_t); else MP_FUSED(double, double); break;
