@@ -24,6 +24,9 @@ namespace spamd {
 #ifndef SPAMD_MP_VT
 #define SPAMD_MP_VT 4
 #endif
+#ifndef SPAMD_MP_ABL
+#define SPAMD_MP_ABL 0   // timing ablations of mp_union_kernel (wrong results): 1 no stores, 2 no merge, 3 no look-back
+#endif
 constexpr int MP_THREADS = SPAMD_MP_THREADS;
 constexpr int MP_VT = SPAMD_MP_VT;
 constexpr int MP_TILE = MP_THREADS * MP_VT;
@@ -140,6 +143,16 @@ __device__ __forceinline__ int64_t mp_diag_wave(const int64_t* __restrict__ a, i
 // and worse, same two rows: 512 x 4 (2048-item tiles, the same wave count: 2.44 / 1.85 - the per-tile chain is what costs),
 // 256 x 8 2.80 / 2.07, 256 x 4 3.05 / 2.88, 1024 x 8 (one workgroup per CU) 2.72 / 1.91, 1024 x 6 2.69 / 2.03,
 // 1024 x 2 2.68 / 2.14 (tools/r04/run_mp.sh with -DSPAMD_MP_THREADS / -DSPAMD_MP_VT).
+// Where the rest goes (-DSPAMD_MP_ABL, `merge_union` wall clock on 10^8 + 10^8 float64 items, 1.81 ms): without the merge
+// (segments copied straight through) 1.87, without the stores 1.40, without the look-back (static offsets) 1.35 - the serial
+// merge is free, the launch is the two streams plus the wait for the predecessors' totals.  Built on that and measured
+// worse (all bit-identical to the two-pass form, tools/r04/merge_stream_check.py; the kernels are not kept):
+//  * a persistent form (two resident workgroups per CU, the next tile's segments requested into registers one tile ahead,
+//    its diagonals two ahead): tickets taken ahead put a tile that is only being prefetched in front of tiles others are
+//    merging (3.8 ms); tiles dealt round-robin instead: 3.0 ms at 64 VGPRs (25 spilled dwords), 1.88 ms with one 1024-thread
+//    workgroup per CU at 97 VGPRs, 2.34 ms as 512 x 8 - the prefetch buys what the second workgroup per CU bought, not more;
+//  * 4 / 8 / 16 look-back windows per round trip instead of one: 2.26 / 2.29 / 2.36 ms (more state words polled by 512
+//    workgroups at once; a prefix is usually found in the first window anyway).
 template <typename T, typename O, int MODE, int VT = MP_VT>
 __global__ void __launch_bounds__(MP_THREADS)
 mp_union_kernel(int op, const int64_t* __restrict__ ka, const T* __restrict__ va, int64_t na,
@@ -202,7 +215,7 @@ mp_union_kernel(int op, const int64_t* __restrict__ ka, const T* __restrict__ va
   const int total = la + lb;
   if (diag > total) diag = total;
   int lo = diag > lb ? diag - lb : 0, hi = diag < la ? diag : la;
-  while (lo < hi) {
+  while (SPAMD_MP_ABL != 2 && lo < hi) {
     const int mid = (lo + hi) >> 1;
     if (A[mid] <= B[diag - 1 - mid]) lo = mid + 1; else hi = mid;
   }
@@ -210,9 +223,12 @@ mp_union_kernel(int op, const int64_t* __restrict__ ka, const T* __restrict__ va
   int64_t okey[VT];
   O oval[VT];
   int cnt = 0;
+#if SPAMD_MP_ABL == 2
+  for (int s = 0; s < VT; ++s) if (tid * VT + s < total) { okey[cnt] = A[tid * VT + s]; oval[cnt] = (O)AV[tid * VT + s]; ++cnt; }
+#endif
 #pragma unroll
   for (int s = 0; s < VT; ++s) {
-    if (diag + s < total) {
+    if (SPAMD_MP_ABL != 2 && diag + s < total) {
       const bool takeA = (i < la) && (j >= lb || A[i] <= B[j]);
       if (takeA) {
         const int64_t k = A[i];
@@ -264,7 +280,8 @@ mp_union_kernel(int op, const int64_t* __restrict__ ka, const T* __restrict__ va
     } else {
       __shared__ int64_t excl_s;
       if (tid < 64) {  // wave 0 looks back 64 predecessors at a time
-        const unsigned long long excl = lookback_exclusive(states, blk, (unsigned long long)tot, tid);
+        const unsigned long long excl = SPAMD_MP_ABL == 3 ? (unsigned long long)(blk * TILE)
+                                                          : lookback_exclusive(states, blk, (unsigned long long)tot, tid);
         if (tid == 0) {
           if (blk == nblocks - 1) {
             const int64_t total = (int64_t)(excl + (unsigned long long)tot);
@@ -306,6 +323,7 @@ mp_union_kernel(int op, const int64_t* __restrict__ ka, const T* __restrict__ va
       }
       __syncthreads();
       for (int t = tid; t < tot; t += MP_THREADS) {
+        if (SPAMD_MP_ABL == 1 && sk[t] != -12345) continue;
         out_keys[o + t] = sk[t];
         out_vals[o + t] = so[t];
       }
@@ -372,7 +390,7 @@ extern "C" int spamd_merge_union(int fill, int op, int val_dtype, int64_t na, co
   if (op == 6) return SPAMD_ETYPE;  // power: use the aligned-array path
 #define MP_LAUNCH(T, O)                                                                                       \
   do {                                                                                                        \
-    if (fill == 2)                                                                                            \
+    if (fill == 2)                                                                                     \
       hipLaunchKernelGGL((mp_union_kernel<T, O, 2>), dim3((unsigned)nblocks), dim3(MP_THREADS), 0, s, op, ka,    \
                          (const T*)va, na, kb, (const T*)vb, nb, from_bits<T>(fill_a_bits),                   \
                          from_bits<T>(fill_b_bits), from_bits<O>(fill_out_bits), part, counts,                \
