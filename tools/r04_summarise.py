@@ -38,10 +38,10 @@ for kern, c in pmc.items():
 # bytes the row's operation really moved, for bench_paths.py's `pmc_bytes` (profiles/paths_pmc.json).  Only rows whose
 # kernels are not shared with rows of another size are listed (rocprofv3 averages a kernel over all its dispatches).
 ROWS = {
-    "A7_1e8_add": ["spamd::mp_partition_kernel", "spamd::mp_union_kernel<double, double, 2, 8>"],
-    "A7_1e8_multiply": ["spamd::mp_partition_kernel", "spamd::mp_union_kernel<double, double, 2, 8>"],
-    "A7_add_config1": ["spamd::mp_union_kernel<double, double, 3, 8>"],
-    "A7_multiply_config1": ["spamd::mp_union_kernel<double, double, 3, 8>"],
+    "A7_1e8_add": ["spamd::mp_partition_kernel", "spamd::mp_union_kernel<double, double, 2, 4>"],
+    "A7_1e8_multiply": ["spamd::mp_partition_kernel", "spamd::mp_union_kernel<double, double, 2, 4>"],
+    "A7_add_config1": ["spamd::mp_union_kernel<double, double, 3, 4>"],
+    "A7_multiply_config1": ["spamd::mp_union_kernel<double, double, 3, 4>"],
     "A9_sddmm_bf16": ["spamd::sddmm_panel_kernel<__hip_bfloat16"],
     "A9_sddmm_f32": ["spamd::sddmm_rowcache_kernel<float, float, int, 16, 4, 4, true>"],
     "A4_spgemm_config5_share": ["spamd::spgemm_bitmap_kernel<float, int, 16, 1024, 512, false>", "spamd::spgemm_row_products_kernel<int>"],
