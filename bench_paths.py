@@ -254,7 +254,7 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
             es = dv.element_size()
             emit(f"A1_shapes_n{n_v}_{'f32' if es == 4 else 'f64'}",
                  row(f"config-2 matrix x dense {Kd}x{n_v} {'fp32' if es == 4 else 'fp64'} ({'matrix-vector product' if n_v == 1 else 'narrow result'}: "
-                     f"row-vector kernel, B {'resident in LDS' if Kd * n_v * es <= 144 * 1024 else 'gathered from global memory'})", ms_v,
+                     f"row-vector kernel, B {'resident in LDS' if Kd * n_v * es <= 160 * 1024 else 'gathered from global memory'})", ms_v,
                      nnz * (es + 4) + (M + 1) * 4 + Kd * n_v * es + M * n_v * es, flops=2.0 * nnz * n_v, rowgroup_ms=ms_rg,
                      speedup_vs_rowgroup=ms_rg / ms_v))
             del dv, bv

@@ -306,7 +306,7 @@ spmm_csr_rowvec_kernel(int64_t M, const T* __restrict__ a_data, const I* __restr
 // CU's vector-memory pipe one cache line per lane (measured: 0.50 ms with them, 0.30 ms with coalesced stand-ins, config 2's
 // matrix times a vector), the LDS serves them at bank rate.  Persistent blocks, as many per CU as the size of B allows
 // (512 threads, up to four; one of 1024 threads above 80 KB); each copies B once.
-constexpr int ROWVEC_LDS_BYTES = 144 * 1024;   // of the CU's 160 KB
+constexpr int ROWVEC_LDS_BYTES = 160 * 1024;   // all of the CU's LDS (round 4; 144 KB before: config 2 x 4 fp32 columns is 156.25 KB)
 
 template <typename T, typename I, int NV>
 __global__ void __launch_bounds__(1024)

@@ -208,6 +208,16 @@ def test_rowvec_dense_operand_gathered(orc, dtype, idt, N, M, K, avg):
     _rowvec_check(orc, M, K, N, M * avg, dtype, idt, seed=avg + N, empty_rows=(1, M - 1), long_row=M // 2)
 
 
+@pytest.mark.parametrize("dtype,idt,N,K", [(np.float32, np.int32, 4, 10240), (np.float32, np.int32, 4, 10241),
+                                           (np.float64, np.int32, 2, 10240), (np.float64, np.int64, 4, 5120),
+                                           (np.float32, np.int32, 3, 13653), (np.float32, np.int32, 3, 13654)])
+def test_rowvec_dense_operand_fills_the_whole_lds(orc, dtype, idt, N, K):
+    """Round 4: the resident copy of B may take all 160 KB of the CU (config 2's matrix times 4 fp32 columns is 156.25 KB:
+    0.81 -> 0.35 ms); one row more and the kernel gathers from global memory.  Both sides of the bound, last row of B used."""
+    M = 33000
+    _rowvec_check(orc, M, K, N, M * 20, dtype, idt, seed=N + K % 7, empty_rows=(0, M - 1), long_row=4242)
+
+
 @pytest.mark.parametrize("N", [1, 2, 4])
 @pytest.mark.parametrize("M", [1000, 40000])
 def test_rowvec_leading_dimensions_and_misaligned_operand(orc, N, M):
