@@ -254,7 +254,7 @@ def test_reduction_drops_results_equal_to_the_fill_value_in_one_read(sp):
     assert s.nnz == 4 and 0 not in s.coords[0].tolist()
 
 
-@pytest.mark.parametrize("dtype, N", [(np.float32, 32), (np.float32, 48), (np.float32, 160), (np.float32, 34), (np.float32, 33),
+@pytest.mark.parametrize("dtype, N", [(np.float32, 6), (np.float32, 7), (np.float32, 32), (np.float32, 48), (np.float32, 160), (np.float32, 34), (np.float32, 33),
                                       (np.float64, 16), (np.float64, 80), (np.float64, 17)])
 def test_narrow_results_through_the_executor(sp, dtype, N):
     """Results narrower than a whole number of column panels: B is zero-padded to whole panels, C is not - the last panel
