@@ -147,7 +147,7 @@ int spamd_spmm_tiled_pack(int val_dtype, int64_t nnz, const int64_t* tiled_keys_
 /* executor.  N = the PADDED width (whole panels; B provides that many columns, zero-padded).  flags: SPAMD_EXACT_MULADD,
  * SPAMD_TILED_GROUP_ENDS, SPAMD_TILED_INT32, bits 8..15 = lines of a list to prefetch (0: default), bits 16..23 = columns of the LAST panel
  * that are stored (0: all) - a narrower result is then written without padding: `out` holds N - panel + that many
- * columns per row (even for float32). */
+ * columns per row (any count; until late round 4 float32 took even counts only). */
 int spamd_spmm_tiled(int val_dtype, int64_t M, int64_t K, int64_t N, const int* blocks, const int* blk_off32,
                      const void* b, int64_t ldb, void* out, int64_t ldo, unsigned flags, void* stream);
 

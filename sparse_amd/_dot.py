@@ -341,11 +341,11 @@ LDSB_MAX_K = 575      # (K + 1) rows of 256 bytes within 144 KB of LDS: `spamd_s
 
 def _tiled_eligible(data, bt, out_shape, Kd):
     """The inspector/executor kernel covers float32 and float64 products whose B is (padded to) whole 128- / 64-column
-    panels; from N = 6 (float32; 8 until late round 4) / 5 (float64) on the padded product beats the row-group kernel (round 3, config-2 operand:
+    panels; from N = 5 (float32: 8 until late round 4) on the padded product beats the row-group kernel (round 3, config-2 operand:
     fp32 N = 8 / 16 / 32: 0.80 vs 1.14 / 1.17 / 1.18 ms, fp64 N = 5 / 8 / 16: 1.02 vs 1.17 / 1.33 / 1.32 ms;
     `NARROW=1 tools/rowgroup_shapes.py`; late round 4, tools/r04/narrow_n.py: fp32 N = 5 / 6 / 7 0.84 / 0.77 / 0.83 vs 0.86 /
-    1.08 / 0.83 ms - odd widths pay a slice of the padded result - so fp32 starts at N = 6; results of at most 4 columns
-    have the row-vector kernel).  Thresholds
+    1.08 / 0.83 ms - odd widths paid a slice of the padded result; with the single-column store of the straddling lane
+    0.80 / 0.78 / 0.78 ms, so fp32 starts at N = 5 as well; results of at most 4 columns have the row-vector kernel).  Thresholds
     measured on MI355X (tools/tiled_crossover.py, tools/r04/m_crossover.py): enough rows for the width (`_tiled_min_rows`)
     and enough stored elements per 32 x 128 cells for the width (`_tiled_min_density`: 5-12).  The inspector costs about one row-group product, so
     a single product breaks even and every further one is 2-3x faster."""
@@ -353,7 +353,7 @@ def _tiled_eligible(data, bt, out_shape, Kd):
     if _settings.TILED_SPMM == "never" or bt.dim() != 2:
         return False
     dt = _tiled_dtype(data, bt)
-    if dt is None or N < (5 if dt == torch.float64 else 6):   # narrower results: the row-group / row-vector kernels
+    if dt is None or N < 5:   # narrower results: the row-vector kernel
         return False
     if (Kd + 512) * N * bt.element_size() >= (1 << 32):   # the executor walks B with 32-bit byte offsets (buffer-form tile DMA)
         return False
@@ -560,13 +560,11 @@ def _gcxs_times_dense(a, bt, out_shape):
         bt = bt.to(dt)
         if N % panel:
             # a workgroup covers whole 512-byte column panels: B (small) is zero-padded to the next panel; the result is
-            # NOT - the last panel stores its leading columns only (float32: a lane stores two columns, so an odd N
-            # still takes the padded result + slice)
+            # NOT - the last panel stores its leading columns only (float32: a lane holds two columns; the lane that
+            # straddles the end of an odd-width row stores its first one alone - late round 4, a padded result + slice before)
             npad = -(-N // panel) * panel
             bp = torch.zeros((Kd, npad), dtype=dt, device=bt.device)
             bp[:, :N] = bt
-            if dt != torch.float64 and N % 2:
-                return _tiled_product(a, dt, (M, npad), Kd, bp)[:, :N].contiguous()
             return _tiled_product(a, dt, (M, N), Kd, bp)
         return _tiled_product(a, dt, out_shape, Kd, bt)
     return K.dot_csr_ndarray(out_shape, data, indices, indptr, bt, exact=_settings.EXACT_MULADD)

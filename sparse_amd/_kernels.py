@@ -1210,13 +1210,13 @@ def csr_tiled_layout(a_data, a_indices, a_indptr, M, Kd, force_sort=False, dtype
 def dot_csr_ndarray_tiled(layout, out_shape, Kd, b, out=None, exact=False):
     """Executor: C = A @ B from the tiled layout; `exact` = separate multiply and add (the reference's arithmetic) instead
     of one FMA per term.  B provides whole column panels (float32: 128 columns, float64: 64; `b.shape[1]` a multiple of
-    that, zero-padded by the caller); `out_shape[1]` may be narrower than B (even for float32): the last panel then stores
-    its leading columns only - no padded result, no slice afterwards."""
+    that, zero-padded by the caller); `out_shape[1]` may be narrower than B (any width since late round 4): the last panel
+    then stores its leading columns only - no padded result, no slice afterwards."""
     blocks, blk_off, dtype = layout
     M, N = int(out_shape[0]), int(b.shape[1])
     Nout = int(out_shape[1])
     panel = 64 if dtype == torch.float64 else 128
-    if N % panel or not (N - panel < Nout <= N) or (dtype != torch.float64 and Nout % 2):
+    if N % panel or not (N - panel < Nout <= N):
         raise ValueError(f"tiled executor: B has {N} columns (whole {panel}-column panels expected), result {Nout}")
     last_cols = (Nout - (N - panel)) % panel    # 0 = the whole last panel
     dev = require_hip(blocks, blk_off, b)

@@ -566,12 +566,22 @@ spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, int touch_lines, const int* 
   int bx2, by2;   // (recomputed from the kernel arguments: nothing of the mapping stays live across the asm blocks, whose
   tl_block_map(blockIdx.x, npanels, nblocks, bx2, by2);   //  scalar operands leave the compiler s0..s35)
   const int ncols = (last_cols > 0 && by2 == npanels - 1) ? last_cols : PANEL;
-  if (lane * CPL < ncols)
+  if (lane * CPL + CPL <= ncols)
     asm volatile(TL_ASM_STORE
                  :
                  : [lo] "v"((unsigned)((uintptr_t)obase_p & 0xffffffffu)), [hi] "v"((unsigned)((uintptr_t)obase_p >> 32)),
                    [stride] "s"(stride_bytes), [n] "s"(nvalid)
                  : "memory", "scc", "s36", TL_ASM_BASE, TL_ASM_TOUCH, TL_CLOB_ACC);
+  if constexpr (CPL == 2) {
+    // an odd width (late round 4; a padded result and a slice pass before): the lane whose pair straddles the end of the
+    // row stores its first column alone (the accumulators are still where the loop left them)
+    if (lane * CPL + 1 == ncols)
+      asm volatile(TL_ASM_STORE1
+                   :
+                   : [lo] "v"((unsigned)((uintptr_t)obase_p & 0xffffffffu)), [hi] "v"((unsigned)((uintptr_t)obase_p >> 32)),
+                     [stride] "s"(stride_bytes), [n] "s"(nvalid)
+                   : "memory", "scc", "s36", TL_ASM_BASE, TL_ASM_TOUCH);
+  }
 }
 
 static int64_t tl_grid_groups(int64_t M) { return ceil_div(ceil_div(M, (int64_t)TL_RG), (int64_t)TL_WAVES) * TL_WAVES; }
@@ -771,7 +781,9 @@ extern "C" int spamd_spmm_tiled(int val_dtype, int64_t M, int64_t K, int64_t N, 
   const int esz = val_dtype == SPAMD_F32 ? 4 : 8;
   if (M < 0 || K <= 0 || N <= 0 || N % panel != 0 || N / panel > 65535 || K / TL_KB >= ((int64_t)1 << 30)) return SPAMD_EINVAL;
   if (M == 0) return 0;
-  if (((uintptr_t)b % 16) || ((ldb * esz) % 16) || ((uintptr_t)out % 8) || ((ldo * esz) % 8) || ((uintptr_t)blocks % 64))
+  // (rows of `out` need element alignment only: an odd float32 width puts every other row on a 4-byte boundary, which the
+  // 8-byte stores of a lane's column pair take - global memory is in unaligned-access mode)
+  if (((uintptr_t)b % 16) || ((ldb * esz) % 16) || ((uintptr_t)out % esz) || ((uintptr_t)blocks % 64))
     return SPAMD_EINVAL;
   if ((K + 2 * TL_KB) * ldb * esz >= ((int64_t)1 << 32)) return SPAMD_EINVAL;  // the tile DMA walks B with 32-bit byte offsets
   hipStream_t s = (hipStream_t)stream;
@@ -781,9 +793,9 @@ extern "C" int spamd_spmm_tiled(int val_dtype, int64_t M, int64_t K, int64_t N, 
   if (i32 && val_dtype != SPAMD_F32) return SPAMD_EINVAL;
   // flags bits 16..23: columns of the LAST panel that are stored (0 = the whole panel).  N stays the padded width (whole
   // panels, which is what B must provide: the tile DMA reads 512 bytes of every row of B per panel); `out` then needs room for
-  // N - panel + that many columns per row only.  Even for float32 (a lane stores two columns).
+  // N - panel + that many columns per row only (any count: an odd float32 one ends with a single-column store).
   const int last_cols = (int)((flags >> 16) & 0xffu);
-  if (last_cols > panel || (val_dtype == SPAMD_F32 && (last_cols & 1))) return SPAMD_EINVAL;
+  if (last_cols > panel) return SPAMD_EINVAL;
   if (ldo < N - panel + (last_cols ? last_cols : panel)) return SPAMD_EINVAL;   // a row of `out` holds every stored column
   // lines of a list that are pulled into L2 two phases ahead (flags bits 8..15; 0 = default): the launcher derives
   // it from the mean list length, longer lists pay the HBM latency on their remaining blocks

@@ -158,7 +158,7 @@ def test_exact_mode_uses_the_tiled_path_and_small_n_keeps_the_rowgroup_kernel(mo
     assert torch.equal(r, a @ b)
     monkeypatch.setattr(_settings, "TILED_SPMM", "auto")
     monkeypatch.setattr(_settings, "EXACT_MULADD", False)
-    a2, b2, _ = _product_case(N=5, seed=13)     # (round 3: fp32 results of 8 columns and more take the executor, padded B; round 4: from 6)
+    a2, b2, _ = _product_case(N=4, seed=13)     # (results of at most 4 columns: the row-vector kernel; from 5 on the executor, padded B)
     a2 @ b2
     assert not getattr(a2, "_tiled_layouts", None)
 

@@ -403,6 +403,18 @@ def store():
     return o
 
 
+def store1():
+    """the first column of the lane's pair only (float32 layout: the lane that holds the last column of an odd-width result)"""
+    o = [f"v_mov_b32 v{BASE}, %[lo]", f"v_mov_b32 v{BASE + 1}, %[hi]", "s_mov_b32 s36, 0"]
+    for j in range(ROWS):
+        o += ["s_cmp_ge_i32 s36, %[n]", "s_cbranch_scc1 9f",
+              f"global_store_dword v[{BASE}:{BASE + 1}], v{ACC0 + 2 * j}, off nt",
+              f"v_lshl_add_u64 v[{BASE}:{BASE + 1}], %[stride], 0, v[{BASE}:{BASE + 1}]",
+              "s_add_i32 s36, s36, 1"]
+    o.append("9:")
+    return o
+
+
 def zero():
     return [f"v_mov_b32 v{r}, 0" for r in range(JUNK, ACC0 + 2 * ROWS)]
 
@@ -448,6 +460,7 @@ def main():
            *i32_variant(),
            lit("TL_ASM_TILE0", tile0()),
            lit("TL_ASM_STORE", store()),
+           lit("TL_ASM_STORE1", store1()),
            lit("TL_ASM_ZERO", zero()),
            f"#define TL_CLOB_SGPR {clob('s', 36, 95)}\n",
            f"#define TL_CLOB_TMP {clob('v', WADDR if STAGE else BASE, JUNK - 1)}\n",
