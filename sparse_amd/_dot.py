@@ -532,6 +532,19 @@ def _csr_triplet(a):
 
 
 COO_TILED_FIRST_NNZ = 20_000_000
+COO_TILED_FIRST_BYTES = 4_000_000_000
+
+
+def _coo_first_product_tiled(nnz, row_bytes):
+    """Does the FIRST eligible product of a COO operand pay for its inspector?  Results of one 512-byte column panel: from
+    COO_TILED_FIRST_NNZ stored elements (round 4: 2.9 -> 1.73 ms at config 2's size; 0.54 against 0.50 ms at 1.6 x 10^7).
+    Wider and float64 results, where the row-group kernel's cost per element grows with the width: from
+    nnz x (bytes of a result row) = COO_TILED_FIRST_BYTES - tools/r04/coo_first_sweep.py, inspector + executor against
+    the row-group kernel, ms: fp32 N = 512: 2 x 10^6 elements 0.38 / 0.52, 4 x 10^6 0.42 / 0.95, 4 x 10^7 1.94 / 8.95;
+    fp64 N = 128: 2 x 10^6 0.32 / 0.22, 4 x 10^6 0.34 / 0.39, 1.6 x 10^7 0.90 / 1.45; fp64 N = 512: 4 x 10^6 0.71 / 2.15."""
+    if nnz >= COO_TILED_FIRST_NNZ:
+        return True
+    return row_bytes > 512 and nnz * row_bytes >= COO_TILED_FIRST_BYTES
 
 
 def _gcxs_times_dense(a, bt, out_shape):
@@ -549,7 +562,7 @@ def _gcxs_times_dense(a, bt, out_shape):
         # the verdict read-back: ~0.15 ms) is then below what the executor saves over the cache-less kernel (config 2's
         # size: inspector 0.57 + executor 0.85 ms against 2.8 ms).
         a._spmm_uses = getattr(a, "_spmm_uses", 0) + 1
-        use_tiled = a._spmm_uses >= 2 or int(data.numel()) >= COO_TILED_FIRST_NNZ
+        use_tiled = a._spmm_uses >= 2 or _coo_first_product_tiled(int(data.numel()), out_shape[1] * _tiled_dtype(data, bt).itemsize)
     if use_tiled:
         # the inspector costs about one product (1.25 ms at config 2 against 0.85 ms per tiled and 2.8 ms per
         # row-group product), so it runs at the first eligible product and is cached on the array

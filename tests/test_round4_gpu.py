@@ -263,6 +263,28 @@ def test_large_coo_operand_takes_the_inspector_at_its_first_product(sp):
         _dot.COO_TILED_FIRST_NNZ = old
 
 
+@pytest.mark.parametrize("dtype, N, nnz_rows, first", [(torch.float32, 512, 60_000, True), (torch.float32, 512, 30_000, False),
+                                                        (torch.float64, 128, 120_000, True), (torch.float32, 128, 120_000, False)])
+def test_coo_first_product_bound_follows_the_result_width(sp, dtype, N, nnz_rows, first):
+    """Late round 4 (`_dot._coo_first_product_tiled`): a COO operand's FIRST product takes the inspector from
+    nnz x (bytes of a result row) = 4 x 10^9 on when the result is wider than one 512-byte panel (the row-group kernel's cost
+    per element grows with the width); otherwise at its second product, as before.  Bit-identical either way."""
+    from sparse_amd import _kernels as K
+
+    M, Kd = nnz_rows, 4000                      # 40 stored elements per row
+    g = sp.random((M, Kd), density=0.01, random_state=3, dtype=np.float32, idx_dtype=np.int32, format="gcxs", compressed_axes=(0,))
+    data = g.data.to(dtype)
+    rows = K.csr_to_keys(g.indptr, torch.zeros_like(g.indices), M, 1).to(torch.int32)
+    coo = sp.COO(torch.stack([rows, g.indices]), data, shape=(M, Kd), has_duplicates=False, sorted=True)
+    b = torch.rand((Kd, N), device=data.device, dtype=dtype) - 0.5
+    want = K.dot_csr_ndarray((M, N), data, g.indices, g.indptr, b)
+    r1 = coo @ b
+    assert bool(coo.__dict__.get("_tiled_layouts")) == first
+    r2 = coo @ b
+    assert coo.__dict__.get("_tiled_layouts")
+    assert torch.equal(r1, want) and torch.equal(r2, want)
+
+
 @pytest.mark.parametrize("dtype, M, N, density, takes", [
     (torch.float32, 12_000, 512, 0.01, True), (torch.float32, 9_000, 512, 0.01, False),
     (torch.float64, 21_000, 128, 0.01, True), (torch.float64, 6_000, 512, 0.01, True),
