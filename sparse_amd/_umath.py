@@ -129,7 +129,9 @@ MERGE_FUSED = True         # one launch (partition inside the kernel, self-clean
 # (latency: 4 rounds instead of ~23), which touches ~0.5 K cache lines per tile.  At config 1 (2 x 10^6 items, everything
 # resident in the Infinity Cache) that is the cheaper trade: 0.109 -> 0.062 ms per `x + y`; at 2 x 10^8 items the probes
 # are HBM traffic of the size of the operands themselves (2.4 -> 4.5 ms), so large merges keep the partition kernel.
-MERGE_FUSED_MAX_ITEMS = 1 << 23
+# Late round 4 (1024-thread tiles; tools/r04/merge_fused_crossover.py, fused / partition + single pass, ms): 2^21 items 0.050 / 0.061,
+# 2^22 0.083 / 0.080, 2^23 0.148 / 0.112, 2^24 0.305 / 0.199 - the bound moves from 2^23 to 2^22.
+MERGE_FUSED_MAX_ITEMS = 1 << 22
 
 
 class _MergeWorkspace:
