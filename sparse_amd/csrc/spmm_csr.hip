@@ -322,6 +322,9 @@ spmm_csr_rowvec_lds_kernel(int64_t M, int64_t K, const T* __restrict__ a_data, c
 #undef SPAMD_ROWVEC_PICK
 
 constexpr int ROWVEC_MAX_N = 4;
+#ifndef SPAMD_ROWVEC_LDS_MIN_M
+#define SPAMD_ROWVEC_LDS_MIN_M 32768   // fewer rows: the blocks' copies of B cost more than the gathers they save
+#endif
 
 template <typename T, typename I>
 static int launch_rowvec(int64_t M, int64_t K, int64_t N, const T* a_data, const I* a_idx, const I* a_ptr, const T* b,
@@ -330,7 +333,7 @@ static int launch_rowvec(int64_t M, int64_t K, int64_t N, const T* a_data, const
   // strides over the rows)
   const size_t rowbytes = sizeof(T) * (size_t)N;
   const size_t ldsbytes = rowbytes * (size_t)K;
-  const bool lds = ldsbytes <= (size_t)ROWVEC_LDS_BYTES && M >= 32768;
+  const bool lds = ldsbytes <= (size_t)ROWVEC_LDS_BYTES && M >= SPAMD_ROWVEC_LDS_MIN_M;
   const bool big = ldsbytes > 80 * 1024;
   int64_t blocks = ceil_div(M, 4);
   if (blocks > 256 * 8) blocks = 256 * 8;
