@@ -36,11 +36,13 @@ while time.time() < t_end:
     elif kind == 2:
         a = a.tocoo()
     want = K.dot_csr_ndarray((M, N), data, idx, ptr, b)
+    flip = kind != 2 and int(rng.integers(0, 4)) == 0     # dense @ sparse: (b^T a^T)^T through the same kernels
+    at, bt_ = (a.T, b.t().contiguous()) if flip else (None, None)
     for rep in range(2):
-        got = a @ b
+        got = (bt_ @ at).t() if flip else a @ b
         if not torch.equal(got, want):
             print("MISMATCH", dt, M, Kd, N, dens, kind, rep, bool(getattr(a, "_tiled_layouts", None)), float((got.double() - want.double()).abs().max()))
             sys.exit(1)
-    took += bool(getattr(a, "_tiled_layouts", None))
+    took += bool(getattr(a, "_tiled_layouts", None)) or bool(flip and getattr(at.__dict__.get("_t_view"), "_tiled_layouts", None))
     it += 1
 print(f"fuzz_policy ok: {it} products, {took} through the executor")
