@@ -336,7 +336,7 @@ def _tiled_dtype(data, bt):
     return None
 
 
-LDSB_MAX_K = 575      # (K + 1) rows of 256 bytes within 144 KB of LDS: `spamd_spmm_csr_ldsb_fits`
+LDSB_MAX_K = 639      # (K + 1) rows of 256 bytes within the 160 KB of LDS: `spamd_spmm_csr_ldsb_fits` (575 / 144 KB until late round 4)
 
 
 def _tiled_eligible(data, bt, out_shape, Kd):

@@ -20,7 +20,7 @@ namespace spamd {
 
 constexpr int LB_LANES = 16;                 // lanes per row: one 256-byte panel row
 constexpr int LB_ROW_BYTES = 256;
-constexpr int LB_LDS_BYTES = 144 * 1024;     // of the CU's 160 KB
+constexpr int LB_LDS_BYTES = 160 * 1024;     // all of the CU's LDS (144 KB until late round 4)
 
 template <int J, typename T>
 __device__ __forceinline__ T row_bcast(T x) {

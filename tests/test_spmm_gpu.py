@@ -290,7 +290,7 @@ def _ldsb_case(M, K, N, nnz, dtype, idt, seed, exact, **kw):
 
 
 @pytest.mark.parametrize("dtype,idt", [(np.float32, np.int32), (np.float64, np.int64), (np.float32, np.int64)])
-@pytest.mark.parametrize("K,N", [(512, 512), (575, 68), (64, 32), (300, 130 * 2), (1, 64)])
+@pytest.mark.parametrize("K,N", [(512, 512), (575, 68), (639, 68), (64, 32), (300, 130 * 2), (1, 64)])
 @pytest.mark.parametrize("avg", [0.5, 5, 40])
 def test_ldsb_exact_mode_is_bit_identical(orc, dtype, idt, K, N, avg):
     """M >= 8192, (K + 1) rows of 256 bytes within the LDS budget, N * itemsize >= 128: rows shorter and longer than the
