@@ -443,10 +443,28 @@ def prepare_spmm(a, dtype=None, force_sort=False):
     _validate_derived(a)
     layouts = a.__dict__.setdefault("_tiled_layouts", {})
     if dtype not in layouts:
+        if not force_sort and _csc_without_twin(a) and a.nnz >= CSC_INSPECT_MIN_NNZ:
+            # a csc operand (the reference's default for a tall matrix) that has no CSR twin yet: the block stream is built
+            # from the CSC arrays themselves (K.csc_tiled_layout) - no conversion, no twin
+            lay = K.csc_tiled_layout(a.data, a.indices, a.indptr, int(a.shape[0]), int(a.shape[1]), dtype=dtype)
+            if lay is not None:
+                layouts[dtype] = lay
+                return True
         d, i, p = _csr_triplet(a)
         layouts[dtype] = K.csr_tiled_layout(d, i, p, int(a.shape[0]), int(a.shape[1]), dtype=dtype, force_sort=force_sort,
                                             defer_check=True)
     return True
+
+
+# Late round 4 (tools/r04/csc_inspect.py; CSC inspector against CSC -> CSR + CSR inspector, ms): 4.2 x 10^4 stored elements
+# 0.10 / 0.06, 1.2 x 10^5 0.07 / 0.08, 10^6 0.08 / 0.13, 8 x 10^6 0.19 / 0.36, 10^8 1.75 / 3.5 (float64: 2.35 / 5.3).
+CSC_INSPECT_MIN_NNZ = 200_000
+
+
+def _csc_without_twin(a):
+    from ._gcxs import GCXS
+
+    return isinstance(a, GCXS) and a.ndim == 2 and a.compressed_axes == (1,) and a.__dict__.get("_csr_twin") is None
 
 
 def prepare_operand(a, b_like):
@@ -464,7 +482,7 @@ def prepare_operand(a, b_like):
         if isinstance(v, _Verdict):
             _PENDING_PREP.append(v)     # read (and memoised on `a`) by the next `matmul` through `_drain_prepared`
     if isinstance(a, GCXS) or getattr(a, "_tiled_layouts", None):
-        data, _, _ = _csr_triplet(a)
+        data = a.data if _csc_without_twin(a) else _csr_triplet(a)[0]
         out_shape = (int(a.shape[0]), int(b_like.shape[1]))
         if _tiled_eligible(data, b_like, out_shape, int(a.shape[1])):
             prepare_spmm(a, _tiled_dtype(data, b_like))
@@ -551,8 +569,15 @@ def _gcxs_times_dense(a, bt, out_shape):
     """GCXS or canonical 2-D COO times dense."""
     from ._coo import COO
 
-    data, indices, indptr = _csr_triplet(a)
+    _validate_derived(a)
     Kd = int(a.shape[1])
+    direct = _csc_without_twin(a)     # (eligibility needs the values' count and type only: no CSR twin for the executor's sake)
+    data = a.data if direct else None
+    if direct and not (_tiled_eligible(data, bt, out_shape, Kd) and
+                       (a.nnz >= CSC_INSPECT_MIN_NNZ or (getattr(a, "_tiled_layouts", None) or {}).get(_tiled_dtype(data, bt)))):
+        direct = False
+    if not direct:
+        data, indices, indptr = _csr_triplet(a)
     use_tiled = _tiled_eligible(data, bt, out_shape, Kd)
     if use_tiled and isinstance(a, COO) and not getattr(a, "_tiled_layouts", None):
         # COO operands of `tensordot` are usually temporaries (an N-D array reshaped to 2-D): for small ones the inspector

@@ -121,6 +121,8 @@ SIGNATURES = {
     "spamd_spmm_tiled_count": (_int, [_int, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "spamd_spmm_tiled_fill": (_int, [_int, _int, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "spamd_spmm_tiled_inspect": (_int, [_int, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "spamd_spmm_tiled_inspect_csc_ws": (_i64, [_i64, _i64]),
+    "spamd_spmm_tiled_inspect_csc": (_int, [_int, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spamd_spmm_tiled_keys": (_int, [_i64, _vp, _i64, _vp, _vp]),
     "spamd_spmm_tiled_lists": (_int, [_int, _i64, _vp, _i64, _i64, _vp, _vp, _vp]),
     "spamd_spmm_tiled_pack": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),

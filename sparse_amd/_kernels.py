@@ -1207,6 +1207,40 @@ def csr_tiled_layout(a_data, a_indices, a_indptr, M, Kd, force_sort=False, dtype
         "spamd_spmm_tiled_pack", vc, nnz, ptr(tk), ptr(vals), ptr(seg_start), ptr(bo), total, ptr(blocks), s))
 
 
+def csc_tiled_layout(a_data, a_indices, a_indptr, M, Kd, dtype=None):
+    """The one-pass inspector for a CSC operand (`a_indices` = row indices, `a_indptr` = Kd + 1 column pointers): the same
+    block stream as `csr_tiled_layout(..., defer_check=True)` of the CSR twin would give the executor, without building the
+    twin (late round 4: the reference-default tall operand paid 4.3 ms of CSC -> CSR at config 2's size before its first
+    product).  Returns None when the shape is outside the one-pass builder (more than `direct_max` tiles).  Rows that do
+    not ascend inside a column are reported like unsorted columns are: the layout's `pending` word, read behind the first
+    product (`UnsortedColumns`; the lists are then empty and the caller converts to CSR)."""
+    dev = require_hip(a_data, a_indices, a_indptr)
+    if dtype is None:
+        dtype = a_data.dtype if a_data.dtype in TILED_DTYPES else torch.float32
+    dtype = torch_dtype(dtype)
+    rg, kb, gpb, epb, slack, direct_max, _ = tiled_params(dtype)
+    nnz = int(a_data.numel())
+    ntiles = -(-Kd // kb)
+    groups = -(-(-(-M // rg)) // gpb) * gpb
+    nseg = groups * ntiles
+    upper = -(-nnz // epb) + nseg
+    if ntiles > direct_max or upper >= 2 ** 31 or groups == 0 or not TILED_ONE_PASS_INSPECTOR:
+        return None
+    if not index_dtype_ok(a_indices) or a_indices.dtype != a_indptr.dtype:
+        a_indices, a_indptr = a_indices.to(torch.int64), a_indptr.to(torch.int64)
+    vals = a_data.to(dtype).contiguous()
+    if dtype == torch.int32:
+        vals = vals.view(torch.float32)
+    blocks = torch.empty((upper + slack) * 16, dtype=torch.int32, device=dev)
+    blk_off = torch.empty(groups * (ntiles + 1), dtype=torch.int32, device=dev)
+    split = torch.empty(int(_ffi.lib().spamd_spmm_tiled_inspect_csc_ws(M, Kd)), dtype=torch.int32, device=dev)   # (workspace)
+    state = torch.empty(1, dtype=torch.int64, device=dev)
+    _ffi.call("spamd_spmm_tiled_inspect_csc", code_of(_tiled_layout_dtype(dtype)), code_of(a_indices.dtype), M, Kd, ptr(vals),
+              ptr(a_indices.contiguous()), ptr(a_indptr.contiguous()), ptr(split), ptr(state), ptr(blk_off), ptr(blocks),
+              stream_ptr(dev))
+    return TiledLayout(blocks, blk_off, dtype, nnz / epb / max(nseg, 1) + 0.5, group_ends=True, pending=state)
+
+
 def dot_csr_ndarray_tiled(layout, out_shape, Kd, b, out=None, exact=False):
     """Executor: C = A @ B from the tiled layout; `exact` = separate multiply and add (the reference's arithmetic) instead
     of one FMA per term.  B provides whole column panels (float32: 128 columns, float64: 64; `b.shape[1]` a multiple of

@@ -748,6 +748,356 @@ extern "C" int spamd_spmm_tiled_inspect(int val_dtype, int idx_dtype, int64_t M,
   return SPAMD_ETYPE;
 }
 
+// ---- the same block stream straight from CSC (late round 4) -------------------------------------------------------------
+// The reference's default construction of a tall matrix is CSC (compressed_axes = argmin(shape)), and `a @ dense` then
+// paid a CSC -> CSR sort of every stored element (4.3 ms of 7.4 at config 2's size) before the inspector above could run.
+// But a K-tile's elements are CONTIGUOUS in CSC (160 whole columns), and inside a column the rows ascend, so a workgroup's
+// 560 rows own one short run per column: no sort at all.
+//   tl_csc_split_kernel   one pass over the row indices: split[bb][c] = first element (relative to the column's start) of
+//                         column c whose row is >= 560 bb; also the "rows ascend inside every column" verdict.
+//   tl_csc_count_kernel   workgroup = (560-row block = the 16 row groups of one executor workgroup, four tiles): the sizes of
+//                         its (group, tile) lists, by walking its runs.
+//   tl_csc_offsets_kernel / tl_csc_scan_kernel: blocks of every list, scanned per group; elements before every group -
+//                         groups are then placed by the SAME closed form as the CSR inspector.
+//   tl_csc_fill_kernel    the same workgroups walk their runs again (staged in LDS by a coalesced walk, then a thread per
+//                         column of the tile places them).  Inside a list the entries are in column order (CSR inspector:
+//                         row order) - an output element's terms stay k-ascending either way, which is all the products
+//                         depend on.  (One workgroup per block walking all tiles one after the other - the first form -
+//                         is a chain of ~130 dependent steps per workgroup: 2.1 / 2.6 ms.)
+constexpr int TL_BLOCK_ROWS = TL_RG * TL_WAVES;
+
+template <typename I>
+__global__ void __launch_bounds__(256) tl_csc_split_kernel(int64_t M, int64_t K, int64_t nblocks, const I* __restrict__ indices,
+                                                           const I* __restrict__ indptr, int* __restrict__ split,
+                                                           unsigned long long* __restrict__ state) {
+  const int tid = threadIdx.x;
+  bool bad = false;
+  for (int64_t c = blockIdx.x; c < K; c += gridDim.x) {
+    const int64_t a = (int64_t)indptr[c], b = (int64_t)indptr[c + 1];
+    if (b - a >= ((int64_t)1 << 31)) bad = true;
+    if (a >= b) {
+      for (int64_t bb = tid; bb <= nblocks; bb += 256) split[bb * K + c] = 0;
+      continue;
+    }
+    for (int64_t e = a + tid; e < b; e += 256) {
+      const int64_t r = (int64_t)indices[e];
+      const int64_t rp = e > a ? (int64_t)indices[e - 1] : -1;
+      if (rp > r || r < 0 || r >= M) bad = true;
+      int64_t bc = r / TL_BLOCK_ROWS, bp = e > a ? rp / TL_BLOCK_ROWS : -1;
+      if (bc < 0) bc = 0;
+      if (bc >= nblocks) bc = nblocks - 1;
+      if (bp >= nblocks) bp = nblocks - 1;
+      for (int64_t bb = bp + 1; bb <= bc; ++bb) split[bb * K + c] = (int)(e - a);
+      if (e == b - 1)
+        for (int64_t bb = bc + 1; bb <= nblocks; ++bb) split[bb * K + c] = (int)(b - a);
+    }
+  }
+  if (bad) atomicOr(&state[0], 1ull);
+}
+
+constexpr int TL_CSC_STAGE = 1024;   // elements of a (row block, tile) staged in LDS at a time (a tile's runs hold ~900 at 1 %)
+#ifndef SPAMD_CSC_TC
+#define SPAMD_CSC_TC 4
+#endif
+constexpr int TL_CSC_TC = SPAMD_CSC_TC;         // tiles per workgroup (count and fill kernels: grid = row blocks x tile chunks)
+
+// the runs of tile t of row block b: rstart[j] = first element of the block's run in column j of the tile, pre[j] =
+// exclusive prefix of the run lengths (pre[TL_KB] = the tile's element count, returned to every thread).  The tile's
+// elements in (column, row) order are then positions 0 .. total - 1; tl_csc_locate maps a position to its element, so that
+// consecutive lanes read consecutive elements of a run (a thread per column instead - the first form of these kernels -
+// costs the texture addresser one cache line per LANE: 3.6 / 5.2 ms at config 2's size against 2.1 / 2.6 ms).
+template <typename I>
+__device__ __forceinline__ int tl_csc_runs(int t, int64_t K, const I* __restrict__ indptr, const int* __restrict__ s0,
+                                           const int* __restrict__ s1, long long* rstart, int* pre, int* wsum) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t c = (int64_t)t * TL_KB + tid;
+  int len = 0;
+  if (tid < TL_KB && c < K) {
+    const int a0 = s0[c];
+    len = s1[c] - a0;
+    rstart[tid] = (int64_t)indptr[c] + a0;
+  }
+  int x = len;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int u = __shfl_up(x, d, 64);
+    if (lane >= d) x += u;
+  }
+  if (lane == 63) wsum[wv] = x;
+  __syncthreads();
+  int off = 0;
+  for (int w = 0; w < wv; ++w) off += wsum[w];
+  if (tid < TL_KB) pre[tid] = off + x - len;
+  const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  if (tid == 0) pre[TL_KB] = total;
+  __syncthreads();
+  return total;
+}
+
+__device__ __forceinline__ int64_t tl_csc_locate(int k, const long long* rstart, const int* pre) {
+  int lo = 0, hi = TL_KB - 1;       // largest j with pre[j] <= k (pre[0] = 0; empty columns are skipped: they share a prefix)
+#pragma unroll
+  for (int step = 0; step < 8; ++step) {
+    const int mid = (lo + hi + 1) >> 1;
+    const bool le = pre[mid] <= k;
+    lo = le ? mid : lo;
+    hi = le ? hi : mid - 1;
+  }
+  return rstart[lo] + (k - pre[lo]);
+}
+
+// cnt[g * ntiles + t] = elements of list (g, t)
+template <typename I>
+__global__ void __launch_bounds__(256) tl_csc_count_kernel(int64_t K, int ntiles, const I* __restrict__ indices,
+                                                           const I* __restrict__ indptr, const int* __restrict__ split,
+                                                           const unsigned long long* __restrict__ state, int* __restrict__ cnt) {
+  __shared__ long long rstart[TL_KB];
+  __shared__ int pre[TL_KB + 1];
+  __shared__ int wsum[4];
+  __shared__ int c16[TL_WAVES];
+  const int tid = threadIdx.x;
+  const int64_t b = blockIdx.x;
+  const int64_t r_base = b * TL_BLOCK_ROWS;
+  if (__hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+  const int t_end = ((int)blockIdx.y + 1) * TL_CSC_TC < ntiles ? ((int)blockIdx.y + 1) * TL_CSC_TC : ntiles;
+  for (int t = (int)blockIdx.y * TL_CSC_TC; t < t_end; ++t) {
+    if (tid < TL_WAVES) c16[tid] = 0;
+    const int total = tl_csc_runs<I>(t, K, indptr, split + b * K, split + (b + 1) * K, rstart, pre, wsum);
+    for (int k = tid; k < total; k += 256) {
+      const int64_t e = tl_csc_locate(k, rstart, pre);
+      atomicAdd(&c16[(int)(((int64_t)indices[e] - r_base) / TL_RG)], 1);
+    }
+    __syncthreads();
+    if (tid < TL_WAVES) cnt[(b * TL_WAVES + tid) * ntiles + t] = c16[tid];
+    __syncthreads();
+  }
+}
+
+// per group: its lists' first blocks relative to the group's own (rel[g * (ntiles + 1) + t], the last entry = the group's
+// blocks) and its element count
+template <int EPB>
+__global__ void __launch_bounds__(256) tl_csc_offsets_kernel(int64_t groups, int ntiles, const int* __restrict__ cnt,
+                                                             const unsigned long long* __restrict__ state,
+                                                             int* __restrict__ rel, long long* __restrict__ gcnt) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= groups) return;
+  const bool bad = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+  int run = 0;
+  long long tot = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    const int c = bad ? 0 : cnt[g * ntiles + t];
+    rel[g * (ntiles + 1) + t] = run;
+    run += (c + EPB - 1) / EPB;
+    tot += c;
+  }
+  rel[g * (ntiles + 1) + ntiles] = run;
+  gcnt[g] = tot;
+}
+
+// e0[g] = elements of the groups before g (one workgroup: a few ten thousand groups)
+__global__ void __launch_bounds__(1024) tl_csc_scan_kernel(int64_t groups, const long long* __restrict__ gcnt,
+                                                           long long* __restrict__ e0) {
+  __shared__ long long part[1024];
+  const int tid = threadIdx.x;
+  const int64_t per = (groups + 1023) / 1024;
+  const int64_t lo = tid * per, hi = lo + per < groups ? lo + per : groups;
+  long long sum = 0;
+  for (int64_t g = lo; g < hi; ++g) sum += gcnt[g];
+  part[tid] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const long long u = tid >= d ? part[tid - d] : 0;
+    __syncthreads();
+    part[tid] += u;
+    __syncthreads();
+  }
+  long long run = part[tid] - sum;
+  for (int64_t g = lo; g < hi; ++g) {
+    e0[g] = run;
+    run += gcnt[g];
+  }
+  if (tid == 1023) e0[groups] = part[1023];
+}
+
+template <typename I, typename T>
+__global__ void __launch_bounds__(256) tl_csc_fill_kernel(int64_t K, int ntiles, const T* __restrict__ vals,
+                                                          const I* __restrict__ indices, const I* __restrict__ indptr,
+                                                          const int* __restrict__ split,
+                                                          const unsigned long long* __restrict__ state,
+                                                          const int* __restrict__ rel, const long long* __restrict__ e0,
+                                                          int* __restrict__ blk_off, int* __restrict__ stream) {
+  constexpr int EPB = TlFmt<T>::EPB;
+  constexpr int GPB = TL_WAVES;         // row groups of a block
+  constexpr int CC = GPB + 1;           // (odd pitch: the per-group column scan walks the columns of one group)
+  __shared__ long long rstart[TL_KB];
+  __shared__ int pre[TL_KB + 1];
+  __shared__ int wsum[4];
+  __shared__ long long goff_s[GPB];
+  __shared__ int tbase[GPB], lo16[GPB];
+  __shared__ int colcnt[TL_KB * CC];
+  __shared__ unsigned short srow[TL_CSC_STAGE];   // staged: row inside the block
+  __shared__ T sval[TL_CSC_STAGE];
+  const int tid = threadIdx.x;
+  const int64_t b = blockIdx.x;
+  const int64_t r_base = b * TL_BLOCK_ROWS;
+  const int t_beg = (int)blockIdx.y * TL_CSC_TC;
+  const int t_end = t_beg + TL_CSC_TC < ntiles ? t_beg + TL_CSC_TC : ntiles;
+  const bool last_chunk = t_end == ntiles;
+  if (__hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+    // rows that do not ascend inside a column: the runs are meaningless.  Empty lists (memory-safe for the one product that
+    // runs before the caller reads the verdict and takes the CSR route).
+    for (int i = tid; i < GPB * (t_end - t_beg + (last_chunk ? 1 : 0)); i += 256) {
+      const int gi = i % GPB, t = t_beg + i / GPB;
+      blk_off[(b * GPB + gi) * (ntiles + 1) + t] = 0;
+    }
+    return;
+  }
+  if (tid < GPB) {
+    const int64_t g = b * GPB + tid;
+    goff_s[tid] = tl_group_first_block(e0[g], g, ntiles, EPB);
+  }
+  __syncthreads();
+  if (last_chunk) {
+    // the group's end and the zeroed gap in front of the next group
+    for (int gi = 0; gi < GPB; ++gi) {
+      const int64_t g = b * GPB + gi;
+      const int64_t gend = goff_s[gi] + rel[g * (ntiles + 1) + ntiles];
+      const int64_t gnext = tl_group_first_block(e0[g + 1], g + 1, ntiles, EPB);
+      if (tid == 0) blk_off[g * (ntiles + 1) + ntiles] = (int)gend;
+      for (int64_t i = gend * TL_BLOCK_INTS + tid; i < gnext * TL_BLOCK_INTS; i += 256) stream[i] = 0;
+    }
+  }
+  for (int t = t_beg; t < t_end; ++t) {
+    if (tid < GPB) {
+      tbase[tid] = 0;
+      lo16[tid] = rel[(b * GPB + tid) * (ntiles + 1) + t];
+    }
+    const int total = tl_csc_runs<I>(t, K, indptr, split + b * K, split + (b + 1) * K, rstart, pre, wsum);
+    if (tid < GPB) blk_off[(b * GPB + tid) * (ntiles + 1) + t] = (int)(goff_s[tid] + lo16[tid]);
+    for (int w0 = 0; w0 < total; w0 += TL_CSC_STAGE) {
+      const int w1 = w0 + TL_CSC_STAGE < total ? w0 + TL_CSC_STAGE : total;
+      for (int k = w0 + tid; k < w1; k += 256) {
+        const int64_t e = tl_csc_locate(k, rstart, pre);
+        srow[k - w0] = (unsigned short)((int64_t)indices[e] - r_base);
+        sval[k - w0] = vals[e];
+      }
+      for (int i = tid; i < TL_KB * CC; i += 256) colcnt[i] = 0;
+      __syncthreads();
+      // my column's part of the window
+      int kb = 0, ke = 0;
+      if (tid < TL_KB) {
+        kb = pre[tid] > w0 ? pre[tid] : w0;
+        ke = pre[tid + 1] < w1 ? pre[tid + 1] : w1;
+        for (int k = kb; k < ke; ++k) colcnt[tid * CC + srow[k - w0] / TL_RG] += 1;
+      }
+      __syncthreads();
+      {  // per group: exclusive scan over the tile's columns (16 lanes per group, TL_KB / 16 columns each)
+        constexpr int PER = TL_KB / 16;
+        static_assert(TL_KB % 16 == 0 && GPB * 16 == 256, "256 threads = 16 groups x 16 column chunks");
+        const int gi = tid >> 4, ch = tid & 15;
+        int sum = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) sum += colcnt[(ch * PER + q) * CC + gi];
+        int x = sum;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+          const int u = __shfl_up(x, d, 16);
+          if (ch >= d) x += u;
+        }
+        int run = tbase[gi] + x - sum;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+          const int v = colcnt[(ch * PER + q) * CC + gi];
+          colcnt[(ch * PER + q) * CC + gi] = run;
+          run += v;
+        }
+        if (ch == 15) tbase[gi] = run;   // (read above by the same 16 lanes only)
+      }
+      __syncthreads();
+      // (Assembling the tile's 16 lists in an LDS image - padding included - and copying them out with consecutive lanes on
+      // consecutive 16 bytes was built and measured: float32 1.79 -> 2.08 ms, float64 2.43 -> 2.41 ms at config 2's size -
+      // three more barriers per tile and a workgroup less per CU cost what the coalesced stores save.)
+      if (tid < TL_KB) {
+        for (int k = kb; k < ke; ++k) {
+          const int rr = srow[k - w0];
+          const int gi = rr / TL_RG, lr = rr - gi * TL_RG;
+          const int pos = colcnt[tid * CC + gi];
+          colcnt[tid * CC + gi] = pos + 1;
+          const int64_t dst = (goff_s[gi] + lo16[gi]) * EPB + pos;
+          TlFmt<T>::put(stream, dst, tl_d0(tid, lr), sval[k - w0]);
+        }
+      }
+      __syncthreads();
+    }
+    // padding entries of the tile's lists (zero d0 and value: they accumulate into the junk register pair)
+    if (tid < GPB) {
+      const int c = tbase[tid], nb = (c + EPB - 1) / EPB;
+      const int64_t first = (goff_s[tid] + lo16[tid]) * EPB;
+      for (int q = c; q < nb * EPB; ++q) TlFmt<T>::put(stream, first + q, 0, T(0));
+    }
+    __syncthreads();
+  }
+}
+
+template <typename I, typename T>
+static int tl_launch_inspect_csc(int64_t M, int64_t K, int64_t ntiles, const T* a_data, const I* a_indices, const I* a_indptr,
+                                 int* ws, unsigned long long* state, int* blk_off, int* blocks, hipStream_t s) {
+  const int64_t groups = tl_grid_groups(M);
+  const int64_t nblocks = groups / TL_WAVES;
+  if (nblocks >= ((int64_t)1 << 31)) return SPAMD_EINVAL;
+  // workspace: split[(nblocks + 1) * K], cnt[groups * ntiles], rel[groups * (ntiles + 1)], gcnt[groups], e0[groups + 1] (8-byte)
+  int* const split = ws;
+  int* const cnt = split + (nblocks + 1) * K;
+  int* const rel = cnt + groups * ntiles;
+  const int64_t words = ((nblocks + 1) * K + groups * ntiles + groups * (ntiles + 1) + 1) & ~(int64_t)1;   // (8-byte alignment)
+  long long* const gcnt = reinterpret_cast<long long*>(ws + words);
+  long long* const e0 = gcnt + groups;
+  const unsigned sgrid = (unsigned)std::min<int64_t>(K, (int64_t)256 * 64);
+  hipLaunchKernelGGL((tl_csc_split_kernel<I>), dim3(sgrid), dim3(256), 0, s, M, K, nblocks, a_indices, a_indptr, split, state);
+  const dim3 grid((unsigned)nblocks, (unsigned)ceil_div(ntiles, (int64_t)TL_CSC_TC));
+  hipLaunchKernelGGL((tl_csc_count_kernel<I>), grid, dim3(256), 0, s, K, (int)ntiles, a_indices, a_indptr, (const int*)split,
+                     (const unsigned long long*)state, cnt);
+  hipLaunchKernelGGL((tl_csc_offsets_kernel<TlFmt<T>::EPB>), dim3((unsigned)ceil_div(groups, (int64_t)256)), dim3(256), 0, s,
+                     groups, (int)ntiles, (const int*)cnt, (const unsigned long long*)state, rel, gcnt);
+  hipLaunchKernelGGL(tl_csc_scan_kernel, dim3(1), dim3(1024), 0, s, groups, (const long long*)gcnt, e0);
+  hipLaunchKernelGGL((tl_csc_fill_kernel<I, T>), grid, dim3(256), 0, s, K, (int)ntiles, a_data, a_indices, a_indptr,
+                     (const int*)split, (const unsigned long long*)state, (const int*)rel, (const long long*)e0, blk_off, blocks);
+  return launch_status();
+}
+
+// int32 words of workspace spamd_spmm_tiled_inspect_csc needs
+extern "C" int64_t spamd_spmm_tiled_inspect_csc_ws(int64_t M, int64_t K) {
+  if (M < 0 || K <= 0) return -1;
+  const int64_t ntiles = ceil_div(K, (int64_t)TL_KB), groups = tl_grid_groups(M), nblocks = groups / TL_WAVES;
+  return (nblocks + 1) * K + groups * ntiles + groups * (ntiles + 1) + 2 + 2 * (2 * groups + 1) + 16;
+}
+
+// The one-pass inspector for a CSC operand (a_indices = row indices, a_indptr = K + 1 column pointers; rows ascending inside
+// every column): same outputs as spamd_spmm_tiled_inspect (blk_off[groups * (tiles + 1)], SPAMD_TILED_GROUP_ENDS; the
+// stream with room for ceil(nnz / entries_per_block) + lists + slack blocks; state = one 64-bit word, non-zero on return =
+// rows out of order: the lists are then left EMPTY and the caller takes the CSR route).  ws: int32 workspace of
+// spamd_spmm_tiled_inspect_csc_ws(M, K) words, 8-byte aligned.
+extern "C" int spamd_spmm_tiled_inspect_csc(int val_dtype, int idx_dtype, int64_t M, int64_t K, const void* a_data,
+                                            const void* a_indices, const void* a_indptr, int* ws, void* state, int* blk_off,
+                                            int* blocks, void* stream) {
+  if (M < 0 || K <= 0) return SPAMD_EINVAL;
+  if (!tl_epb(val_dtype)) return SPAMD_ETYPE;
+  if ((uintptr_t)ws % 8) return SPAMD_EINVAL;
+  const int64_t ntiles = ceil_div(K, (int64_t)TL_KB);
+  if (ntiles > TL_DIRECT_MAX_TILES) return SPAMD_EINVAL;
+  hipError_t e = hipMemsetAsync(state, 0, sizeof(unsigned long long), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  if (tl_grid_groups(M) == 0) return 0;
+  SPAMD_DISPATCH_IDX(idx_dtype, I, {
+    if (val_dtype == SPAMD_F32)
+      return tl_launch_inspect_csc<I, float>(M, K, ntiles, (const float*)a_data, (const I*)a_indices, (const I*)a_indptr, ws,
+                                             (unsigned long long*)state, blk_off, blocks, (hipStream_t)stream);
+    return tl_launch_inspect_csc<I, double>(M, K, ntiles, (const double*)a_data, (const I*)a_indices, (const I*)a_indptr, ws,
+                                            (unsigned long long*)state, blk_off, blocks, (hipStream_t)stream);
+  })
+  return SPAMD_ETYPE;
+}
+
 static int tl_set_lds_once(const void* kern) {
   static std::mutex mu;
   static std::set<const void*> done;

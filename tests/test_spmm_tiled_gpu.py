@@ -113,8 +113,9 @@ def test_product_path_column_panels(orc, monkeypatch, N):
     assert_within_fma_bound(got.cpu().numpy(), want, data, idx, ptr, bh)
 
 
-def test_product_path_csc_operand_uses_the_csr_twin(orc, monkeypatch):
-    """Default-compressed tall matrix (csc): the cached CSR twin feeds the inspector."""
+def test_product_path_csc_operand_builds_the_stream_from_the_csc_arrays(orc, monkeypatch):
+    """Default-compressed tall matrix (csc): the CSC-native inspector builds the block stream (late round 4: no CSR twin;
+    until then the cached twin fed the CSR inspector)."""
     import sparse_amd as sp
     from sparse_amd import _settings
 
@@ -123,7 +124,8 @@ def test_product_path_csc_operand_uses_the_csr_twin(orc, monkeypatch):
     a, b, (data, idx, ptr, bh) = _product_case(seed=11)
     acsc = a.change_compressed_axes((1,))
     got = acsc @ b
-    assert acsc._tiled_layouts and acsc._csr_twin is not None
+    assert acsc._tiled_layouts and getattr(acsc, "_csr_twin", None) is None
+    assert torch.equal(got, a @ b)      # the CSR operand's own stream: the same products bit for bit
     want = orc.dot_csr_ndarray((a.shape[0], 128), data, idx, ptr, bh)
     assert_within_fma_bound(got.cpu().numpy(), want, data, idx, ptr, bh)
 
