@@ -189,7 +189,7 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
         ms_dfirst, _ = timed(lambda: first(adef, b64), reps=3, warm=2)
         ms_dsteady, r = timed(lambda: adef @ b64, reps=5)
         emit("A2_default_gcxs_first", row(f"config 2 as the reference constructs it by default (float64, int64, compressed_axes=(1,) = CSC, {nnz} nnz) "
-                                          f"x dense {Kd}x{N} fp64: FIRST product (CSC -> CSR twin + inspector + two-panel executor)", ms_dfirst,
+                                          f"x dense {Kd}x{N} fp64: FIRST product (CSC-native inspector + two-panel executor; until late round 4 a CSC -> CSR twin came first: 7.4 ms)", ms_dfirst,
                                           by64, flops=2.0 * nnz * N))
         emit("A2_default_gcxs_steady", row("the same operand, steady state (cached CSR twin and block stream)", ms_dsteady, by64,
                                            flops=2.0 * nnz * N))
