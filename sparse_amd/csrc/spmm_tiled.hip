@@ -759,8 +759,9 @@ extern "C" int spamd_spmm_tiled_inspect(int val_dtype, int idx_dtype, int64_t M,
 //                         its (group, tile) lists, by walking its runs.
 //   tl_csc_offsets_kernel / tl_csc_scan_kernel: blocks of every list, scanned per group; elements before every group -
 //                         groups are then placed by the SAME closed form as the CSR inspector.
-//   tl_csc_fill_kernel    the same workgroups walk their runs again (staged in LDS by a coalesced walk, then a thread per
-//                         column of the tile places them).  Inside a list the entries are in column order (CSR inspector:
+//   tl_csc_fill_kernel    the same workgroups walk their runs again, consecutive lanes on consecutive elements; an element's
+//                         place in its list comes from ballots over its wave + per-chunk counts in LDS.  Inside a list
+//                         the entries are in column order (CSR inspector:
 //                         row order) - an output element's terms stay k-ascending either way, which is all the products
 //                         depend on.  (One workgroup per block walking all tiles one after the other - the first form -
 //                         is a chain of ~130 dependent steps per workgroup: 2.1 / 2.6 ms.)
@@ -873,10 +874,44 @@ __global__ void __launch_bounds__(256) tl_csc_count_kernel(int64_t K, int ntiles
   }
 }
 
+// The same counts without the runs (late round 4): a workgroup takes a QUARTER of a tile's columns (whole columns: rows of
+// every block) and histograms the row groups of their elements in LDS (4 bytes per group: up to TL_CSC_HIST_GROUPS groups);
+// its counts go to its own quarter of `cntq`, which tl_csc_offsets_kernel adds up.  No position search, every row index
+// read once, coalesced: 0.41 / 0.45 ms (count kernel above, int32 / int64 indices at config 2's size) -> see the launcher.
+constexpr int TL_CSC_HIST_GROUPS = 38 * 1024;   // 152 KB of LDS
+#ifndef SPAMD_CSC_HIST_PARTS
+#define SPAMD_CSC_HIST_PARTS 4
+#endif
+constexpr int TL_CSC_HIST_PARTS = SPAMD_CSC_HIST_PARTS;
+
+template <typename I>
+__global__ void __launch_bounds__(1024) tl_csc_hist_kernel(int64_t K, int ntiles, int64_t groups, const I* __restrict__ indices,
+                                                           const I* __restrict__ indptr, int* __restrict__ cntq) {
+  extern __shared__ int tl_hist_lds[];
+  const int tid = threadIdx.x;
+  const int t = blockIdx.x, q = blockIdx.y;
+  for (int64_t i = tid; i < groups; i += 1024) tl_hist_lds[i] = 0;
+  __syncthreads();
+  constexpr int CPQ = TL_KB / TL_CSC_HIST_PARTS;
+  int64_t c0 = (int64_t)t * TL_KB + q * CPQ, c1 = c0 + CPQ;
+  if (c0 > K) c0 = K;
+  if (c1 > K) c1 = K;
+  const int64_t a = (int64_t)indptr[c0], b = (int64_t)indptr[c1];
+  for (int64_t e = a + tid; e < b; e += 1024) {
+    int64_t g = (int64_t)indices[e] / TL_RG;
+    if (g < 0) g = 0;
+    if (g >= groups) g = groups - 1;       // (rows out of range are reported by the split kernel; stay inside the histogram)
+    atomicAdd(&tl_hist_lds[g], 1);
+  }
+  __syncthreads();
+  int* const out = cntq + (int64_t)q * groups * ntiles;
+  for (int64_t g = tid; g < groups; g += 1024) out[g * ntiles + t] = tl_hist_lds[g];
+}
+
 // per group: its lists' first blocks relative to the group's own (rel[g * (ntiles + 1) + t], the last entry = the group's
 // blocks) and its element count
 template <int EPB>
-__global__ void __launch_bounds__(256) tl_csc_offsets_kernel(int64_t groups, int ntiles, const int* __restrict__ cnt,
+__global__ void __launch_bounds__(256) tl_csc_offsets_kernel(int64_t groups, int ntiles, const int* __restrict__ cnt, int parts,
                                                              const unsigned long long* __restrict__ state,
                                                              int* __restrict__ rel, long long* __restrict__ gcnt) {
   const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -885,7 +920,9 @@ __global__ void __launch_bounds__(256) tl_csc_offsets_kernel(int64_t groups, int
   int run = 0;
   long long tot = 0;
   for (int t = 0; t < ntiles; ++t) {
-    const int c = bad ? 0 : cnt[g * ntiles + t];
+    int c = 0;
+    if (!bad)
+      for (int q = 0; q < parts; ++q) c += cnt[(q * groups + g) * ntiles + t];
     rel[g * (ntiles + 1) + t] = run;
     run += (c + EPB - 1) / EPB;
     tot += c;
@@ -927,17 +964,16 @@ __global__ void __launch_bounds__(256) tl_csc_fill_kernel(int64_t K, int ntiles,
                                                           const int* __restrict__ rel, const long long* __restrict__ e0,
                                                           int* __restrict__ blk_off, int* __restrict__ stream) {
   constexpr int EPB = TlFmt<T>::EPB;
-  constexpr int GPB = TL_WAVES;         // row groups of a block
-  constexpr int CC = GPB + 1;           // (odd pitch: the per-group column scan walks the columns of one group)
+  constexpr int GPB = TL_WAVES;               // row groups of a block
+  constexpr int PER = TL_CSC_STAGE / 256;     // elements of a window per thread
+  constexpr int CHUNKS = TL_CSC_STAGE / 64;   // 64-element chunks of a window (one per wave and step)
   __shared__ long long rstart[TL_KB];
   __shared__ int pre[TL_KB + 1];
   __shared__ int wsum[4];
   __shared__ long long goff_s[GPB];
   __shared__ int tbase[GPB], lo16[GPB];
-  __shared__ int colcnt[TL_KB * CC];
-  __shared__ unsigned short srow[TL_CSC_STAGE];   // staged: row inside the block
-  __shared__ T sval[TL_CSC_STAGE];
-  const int tid = threadIdx.x;
+  __shared__ int ccnt[CHUNKS * GPB];          // elements of a chunk per group, then their exclusive prefix over the window
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t b = blockIdx.x;
   const int64_t r_base = b * TL_BLOCK_ROWS;
   const int t_beg = (int)blockIdx.y * TL_CSC_TC;
@@ -967,6 +1003,7 @@ __global__ void __launch_bounds__(256) tl_csc_fill_kernel(int64_t K, int ntiles,
       for (int64_t i = gend * TL_BLOCK_INTS + tid; i < gnext * TL_BLOCK_INTS; i += 256) stream[i] = 0;
     }
   }
+  const unsigned long long below = (1ull << lane) - 1;
   for (int t = t_beg; t < t_end; ++t) {
     if (tid < GPB) {
       tbase[tid] = 0;
@@ -974,57 +1011,70 @@ __global__ void __launch_bounds__(256) tl_csc_fill_kernel(int64_t K, int ntiles,
     }
     const int total = tl_csc_runs<I>(t, K, indptr, split + b * K, split + (b + 1) * K, rstart, pre, wsum);
     if (tid < GPB) blk_off[(b * GPB + tid) * (ntiles + 1) + t] = (int)(goff_s[tid] + lo16[tid]);
+    // The tile's elements in (column, row) order, a window at a time: consecutive lanes take consecutive elements (of a
+    // run), an element's place inside its list = the elements of its group in front of it: its rank among the equal-group
+    // lanes of its wave (ballots) + the group's count in the chunks before (LDS).  Lanes of one group write consecutive
+    // entries: a store instruction touches ~16 runs of lines instead of 64 lines.
     for (int w0 = 0; w0 < total; w0 += TL_CSC_STAGE) {
       const int w1 = w0 + TL_CSC_STAGE < total ? w0 + TL_CSC_STAGE : total;
-      for (int k = w0 + tid; k < w1; k += 256) {
-        const int64_t e = tl_csc_locate(k, rstart, pre);
-        srow[k - w0] = (unsigned short)((int64_t)indices[e] - r_base);
-        sval[k - w0] = vals[e];
-      }
-      for (int i = tid; i < TL_KB * CC; i += 256) colcnt[i] = 0;
+      int rr[PER], rank[PER], col[PER];
+      T vv[PER];
+      for (int i = tid; i < CHUNKS * GPB; i += 256) ccnt[i] = 0;
       __syncthreads();
-      // my column's part of the window
-      int kb = 0, ke = 0;
-      if (tid < TL_KB) {
-        kb = pre[tid] > w0 ? pre[tid] : w0;
-        ke = pre[tid + 1] < w1 ? pre[tid + 1] : w1;
-        for (int k = kb; k < ke; ++k) colcnt[tid * CC + srow[k - w0] / TL_RG] += 1;
-      }
-      __syncthreads();
-      {  // per group: exclusive scan over the tile's columns (16 lanes per group, TL_KB / 16 columns each)
-        constexpr int PER = TL_KB / 16;
-        static_assert(TL_KB % 16 == 0 && GPB * 16 == 256, "256 threads = 16 groups x 16 column chunks");
-        const int gi = tid >> 4, ch = tid & 15;
-        int sum = 0;
 #pragma unroll
-        for (int q = 0; q < PER; ++q) sum += colcnt[(ch * PER + q) * CC + gi];
-        int x = sum;
+      for (int p = 0; p < PER; ++p) {
+        const int k = w0 + tid + 256 * p;
+        const bool valid = k < w1;
+        rr[p] = 0;
+        vv[p] = T(0);
+        col[p] = 0;
+        if (valid) {
+          int lo = 0, hi = TL_KB - 1;       // largest j with pre[j] <= k
 #pragma unroll
-        for (int d = 1; d < 16; d <<= 1) {
-          const int u = __shfl_up(x, d, 16);
-          if (ch >= d) x += u;
+          for (int step = 0; step < 8; ++step) {
+            const int mid = (lo + hi + 1) >> 1;
+            const bool le = pre[mid] <= k;
+            lo = le ? mid : lo;
+            hi = le ? hi : mid - 1;
+          }
+          const int64_t e = rstart[lo] + (k - pre[lo]);
+          col[p] = lo;
+          rr[p] = (int)((int64_t)indices[e] - r_base);
+          vv[p] = vals[e];
         }
-        int run = tbase[gi] + x - sum;
+        const int gi = rr[p] / TL_RG;
+        unsigned long long m = __ballot(valid);
 #pragma unroll
-        for (int q = 0; q < PER; ++q) {
-          const int v = colcnt[(ch * PER + q) * CC + gi];
-          colcnt[(ch * PER + q) * CC + gi] = run;
-          run += v;
+        for (int bit = 0; bit < 4; ++bit) {
+          const unsigned long long bb = __ballot(valid && ((gi >> bit) & 1));
+          m &= ((gi >> bit) & 1) ? bb : ~bb;
         }
-        if (ch == 15) tbase[gi] = run;   // (read above by the same 16 lanes only)
+        rank[p] = __popcll(m & below);
+        if (valid && rank[p] == 0) ccnt[(wv + 4 * p) * GPB + gi] = __popcll(m);
       }
       __syncthreads();
-      // (Assembling the tile's 16 lists in an LDS image - padding included - and copying them out with consecutive lanes on
-      // consecutive 16 bytes was built and measured: float32 1.79 -> 2.08 ms, float64 2.43 -> 2.41 ms at config 2's size -
-      // three more barriers per tile and a workgroup less per CU cost what the coalesced stores save.)
-      if (tid < TL_KB) {
-        for (int k = kb; k < ke; ++k) {
-          const int rr = srow[k - w0];
-          const int gi = rr / TL_RG, lr = rr - gi * TL_RG;
-          const int pos = colcnt[tid * CC + gi];
-          colcnt[tid * CC + gi] = pos + 1;
+      {  // exclusive prefix over the window's chunks, per group (thread = (chunk, group)); the tile's running totals
+        static_assert(CHUNKS * GPB == 256, "one thread per (chunk, group)");
+        const int gi = tid & (GPB - 1), ch = tid / GPB;
+        int sum = tbase[gi], all = 0;
+        for (int c = 0; c < CHUNKS; ++c) {
+          const int x = ccnt[c * GPB + gi];
+          sum += c < ch ? x : 0;
+          all += x;
+        }
+        __syncthreads();
+        ccnt[ch * GPB + gi] = sum;
+        if (ch == 0) tbase[gi] += all;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int p = 0; p < PER; ++p) {
+        const int k = w0 + tid + 256 * p;
+        if (k < w1) {
+          const int gi = rr[p] / TL_RG, lr = rr[p] - gi * TL_RG;
+          const int pos = ccnt[(wv + 4 * p) * GPB + gi] + rank[p];
           const int64_t dst = (goff_s[gi] + lo16[gi]) * EPB + pos;
-          TlFmt<T>::put(stream, dst, tl_d0(tid, lr), sval[k - w0]);
+          TlFmt<T>::put(stream, dst, tl_d0(col[p], lr), vv[p]);
         }
       }
       __syncthreads();
@@ -1046,19 +1096,32 @@ static int tl_launch_inspect_csc(int64_t M, int64_t K, int64_t ntiles, const T* 
   const int64_t nblocks = groups / TL_WAVES;
   if (nblocks >= ((int64_t)1 << 31)) return SPAMD_EINVAL;
   // workspace: split[(nblocks + 1) * K], cnt[groups * ntiles], rel[groups * (ntiles + 1)], gcnt[groups], e0[groups + 1] (8-byte)
+  const bool hist = groups <= TL_CSC_HIST_GROUPS;
+  const int parts = hist ? TL_CSC_HIST_PARTS : 1;
   int* const split = ws;
   int* const cnt = split + (nblocks + 1) * K;
-  int* const rel = cnt + groups * ntiles;
-  const int64_t words = ((nblocks + 1) * K + groups * ntiles + groups * (ntiles + 1) + 1) & ~(int64_t)1;   // (8-byte alignment)
+  int* const rel = cnt + TL_CSC_HIST_PARTS * groups * ntiles;
+  const int64_t words = ((nblocks + 1) * K + TL_CSC_HIST_PARTS * groups * ntiles + groups * (ntiles + 1) + 1) & ~(int64_t)1;   // (8-byte alignment)
   long long* const gcnt = reinterpret_cast<long long*>(ws + words);
   long long* const e0 = gcnt + groups;
   const unsigned sgrid = (unsigned)std::min<int64_t>(K, (int64_t)256 * 64);
   hipLaunchKernelGGL((tl_csc_split_kernel<I>), dim3(sgrid), dim3(256), 0, s, M, K, nblocks, a_indices, a_indptr, split, state);
   const dim3 grid((unsigned)nblocks, (unsigned)ceil_div(ntiles, (int64_t)TL_CSC_TC));
-  hipLaunchKernelGGL((tl_csc_count_kernel<I>), grid, dim3(256), 0, s, K, (int)ntiles, a_indices, a_indptr, (const int*)split,
-                     (const unsigned long long*)state, cnt);
+  if (hist) {
+    auto hk = &tl_csc_hist_kernel<I>;
+    const int lds = (int)(groups * sizeof(int));
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hk), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(hk, dim3((unsigned)ntiles, TL_CSC_HIST_PARTS), dim3(1024), lds, s, K, (int)ntiles, groups, a_indices,
+                       a_indptr, cnt);
+  } else {
+    hipLaunchKernelGGL((tl_csc_count_kernel<I>), grid, dim3(256), 0, s, K, (int)ntiles, a_indices, a_indptr, (const int*)split,
+                       (const unsigned long long*)state, cnt);
+  }
   hipLaunchKernelGGL((tl_csc_offsets_kernel<TlFmt<T>::EPB>), dim3((unsigned)ceil_div(groups, (int64_t)256)), dim3(256), 0, s,
-                     groups, (int)ntiles, (const int*)cnt, (const unsigned long long*)state, rel, gcnt);
+                     groups, (int)ntiles, (const int*)cnt, parts, (const unsigned long long*)state, rel, gcnt);
   hipLaunchKernelGGL(tl_csc_scan_kernel, dim3(1), dim3(1024), 0, s, groups, (const long long*)gcnt, e0);
   hipLaunchKernelGGL((tl_csc_fill_kernel<I, T>), grid, dim3(256), 0, s, K, (int)ntiles, a_data, a_indices, a_indptr,
                      (const int*)split, (const unsigned long long*)state, (const int*)rel, (const long long*)e0, blk_off, blocks);
@@ -1069,7 +1132,7 @@ static int tl_launch_inspect_csc(int64_t M, int64_t K, int64_t ntiles, const T* 
 extern "C" int64_t spamd_spmm_tiled_inspect_csc_ws(int64_t M, int64_t K) {
   if (M < 0 || K <= 0) return -1;
   const int64_t ntiles = ceil_div(K, (int64_t)TL_KB), groups = tl_grid_groups(M), nblocks = groups / TL_WAVES;
-  return (nblocks + 1) * K + groups * ntiles + groups * (ntiles + 1) + 2 + 2 * (2 * groups + 1) + 16;
+  return (nblocks + 1) * K + TL_CSC_HIST_PARTS * groups * ntiles + groups * (ntiles + 1) + 2 + 2 * (2 * groups + 1) + 16;
 }
 
 // The one-pass inspector for a CSC operand (a_indices = row indices, a_indptr = K + 1 column pointers; rows ascending inside
