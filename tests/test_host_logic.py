@@ -331,3 +331,37 @@ def test_committed_bench_rows_move_the_bytes_they_claim():
         checked += 1
     assert checked >= 5
     assert not line["paths"].get("_accounting_errors")
+
+
+def test_executor_policy_bounds_follow_the_result_width():
+    """`_dot._tiled_min_rows / _tiled_min_density / _coo_first_product_tiled` (round 4: measured crossovers, see their
+    docstrings): wider results and 8-byte values lower the bounds, results narrower than a panel keep rounds 1-3's, and the
+    functions are monotone in the width."""
+    from sparse_amd import _dot
+
+    assert _dot._tiled_min_rows(128) == 65536 and _dot._tiled_min_rows(508) == 65536        # narrower than a 512-byte panel
+    assert _dot._tiled_min_rows(512) == 45056
+    assert _dot._tiled_min_rows(1024) == 20480 and _dot._tiled_min_rows(2048) == 10240 and _dot._tiled_min_rows(4096) == 5120
+    assert _dot._tiled_min_rows(1 << 20) == 4096                                               # never below 4096 rows
+    widths = [512 * k for k in range(1, 40)]
+    rows = [_dot._tiled_min_rows(w) for w in widths]
+    assert all(a >= b for a, b in zip(rows, rows[1:]))
+    small_b, big_b = 1 << 20, 32 << 20
+    assert _dot._tiled_min_density(128, small_b) == 12 and _dot._tiled_min_density(128, big_b) == 6
+    assert [_dot._tiled_min_density(w, small_b) for w in (512, 1024, 2048, 4096)] == [9, 6, 5, 5]
+    assert _dot._tiled_min_density(512, big_b) == 5
+    # a COO operand's first product: one panel from 2 x 10^7 stored elements, wider from nnz x row bytes = 4 x 10^9
+    assert not _dot._coo_first_product_tiled(19_999_999, 512) and _dot._coo_first_product_tiled(20_000_000, 512)
+    assert not _dot._coo_first_product_tiled(1_900_000, 2048) and _dot._coo_first_product_tiled(2_000_000, 2048)
+    assert _dot._coo_first_product_tiled(1_000_000, 4096) and not _dot._coo_first_product_tiled(7_000_000, 256)
+
+
+def test_csc_inspector_workspace_covers_its_arrays(hiplib):
+    """`spamd_spmm_tiled_inspect_csc_ws` (int32 words): split[(row blocks + 1) x K] + four count partials + the relative
+    offsets + two 8-byte arrays over the groups, whatever the alignment padding"""
+    rg, kb, gpb = 35, 160, 16
+    for M, K in ((1, 1), (559, 161), (560 * 3, 1000), (1_000_000, 10_000), (70_001, 40_960)):
+        groups = -(-(-(-M // rg)) // gpb) * gpb
+        ntiles = -(-K // kb)
+        need = (groups // gpb + 1) * K + 4 * groups * ntiles + groups * (ntiles + 1) + 1 + 2 * (2 * groups + 1)
+        assert hiplib.spamd_spmm_tiled_inspect_csc_ws(M, K) >= need
