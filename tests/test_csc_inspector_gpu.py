@@ -106,3 +106,16 @@ def test_default_construction_never_builds_a_csr_twin_for_the_executor(sp):
     assert torch.equal(r1, ref @ b) and torch.equal(a @ b, r1)
     rt = (b.t().contiguous() @ a.T)            # dense @ sparse: the transposed view shares the buffers and takes the CSR inspector
     assert torch.equal(rt.t(), r1)
+
+
+def test_csc_inspector_more_row_groups_than_the_lds_histogram_holds():
+    """above 38 912 row groups (1.36 x 10^6 rows) the list sizes come from the workgroups' own runs (`tl_csc_count_kernel`)
+    instead of the LDS histograms over the row groups"""
+    from sparse_amd import _kernels as K
+
+    M, Kd = 1_400_123, 330
+    data, idx, ptr = _case(M, Kd, 0.004, torch.float64, torch.int64, seed=8)
+    cd, ci, cp = K.csx_swap_2d(data, idx, ptr, M, Kd)
+    b = torch.rand((Kd, 64), device="cuda", dtype=torch.float64) - 0.5
+    got = K.dot_csr_ndarray_tiled(K.csc_tiled_layout(cd, ci, cp, M, Kd), (M, 64), Kd, b)
+    assert torch.equal(got, K.dot_csr_ndarray((M, 64), data, idx, ptr, b))
