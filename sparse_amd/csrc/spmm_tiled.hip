@@ -878,7 +878,8 @@ __global__ void __launch_bounds__(256) tl_csc_count_kernel(int64_t K, int ntiles
 // The same counts without the runs (late round 4): a workgroup takes a QUARTER of a tile's columns (whole columns: rows of
 // every block) and histograms the row groups of their elements in LDS (4 bytes per group: up to TL_CSC_HIST_GROUPS groups);
 // its counts go to its own quarter of `cntq`, which tl_csc_offsets_kernel adds up.  No position search, every row index
-// read once, coalesced: 0.41 / 0.45 ms (count kernel above, int32 / int64 indices at config 2's size) -> see the launcher.
+// read once, coalesced: 0.41 / 0.45 ms (count kernel above, int32 / int64 indices at config 2's size) -> 0.26 / 0.31 ms; the
+// split pointers of its columns are written in the same pass (tl_csc_split_kernel is then not launched: 0.28 / 0.34 ms).
 constexpr int TL_CSC_HIST_GROUPS = 38 * 1024;   // 152 KB of LDS
 #ifndef SPAMD_CSC_HIST_PARTS
 #define SPAMD_CSC_HIST_PARTS 4
@@ -886,8 +887,10 @@ constexpr int TL_CSC_HIST_GROUPS = 38 * 1024;   // 152 KB of LDS
 constexpr int TL_CSC_HIST_PARTS = SPAMD_CSC_HIST_PARTS;
 
 template <typename I>
-__global__ void __launch_bounds__(1024) tl_csc_hist_kernel(int64_t K, int ntiles, int64_t groups, const I* __restrict__ indices,
-                                                           const I* __restrict__ indptr, int* __restrict__ cntq) {
+__global__ void __launch_bounds__(1024) tl_csc_hist_kernel(int64_t M, int64_t K, int ntiles, int64_t groups, int64_t nblocks,
+                                                           const I* __restrict__ indices, const I* __restrict__ indptr,
+                                                           int* __restrict__ cntq, int* __restrict__ split,
+                                                           unsigned long long* __restrict__ state) {
   extern __shared__ int tl_hist_lds[];
   const int tid = threadIdx.x;
   const int t = blockIdx.x, q = blockIdx.y;
@@ -897,27 +900,34 @@ __global__ void __launch_bounds__(1024) tl_csc_hist_kernel(int64_t K, int ntiles
   int64_t c0 = (int64_t)t * TL_KB + q * CPQ, c1 = c0 + CPQ;
   if (c0 > K) c0 = K;
   if (c1 > K) c1 = K;
-  const int64_t a = (int64_t)indptr[c0], b = (int64_t)indptr[c1];
-  // (eight independent loads per thread and step: with one, the ~390 steps of a workgroup each wait for their own load -
-  // 0.31-0.34 ms for this kernel at config 2's size)
-  constexpr int U = 8;
-  for (int64_t e = a + tid; e < b; e += (int64_t)U * 1024) {
-    int64_t r[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t ee = e + (int64_t)u * 1024;
-      r[u] = ee < b ? (int64_t)indices[ee] : -1;
+  // the split pointers of my columns in the same pass (tl_csc_split_kernel's loop, 1024 threads per column)
+  bool bad = false;
+  for (int64_t c = c0; c < c1; ++c) {
+    const int64_t a = (int64_t)indptr[c], b = (int64_t)indptr[c + 1];
+    if (b - a >= ((int64_t)1 << 31)) bad = true;
+    if (a >= b) {
+      for (int64_t bb = tid; bb <= nblocks; bb += 1024) split[bb * K + c] = 0;
+      continue;
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (e + (int64_t)u * 1024 < b) {
-        int64_t g = r[u] / TL_RG;
-        if (g < 0) g = 0;
-        if (g >= groups) g = groups - 1;       // (rows out of range are reported by the split kernel; stay inside the histogram)
-        atomicAdd(&tl_hist_lds[g], 1);
-      }
+#pragma unroll 2
+    for (int64_t e = a + tid; e < b; e += 1024) {
+      const int64_t r = (int64_t)indices[e];
+      const int64_t rp = e > a ? (int64_t)indices[e - 1] : -1;
+      if (rp > r || r < 0 || r >= M) bad = true;
+      int64_t g = r / TL_RG;
+      if (g < 0) g = 0;
+      if (g >= groups) g = groups - 1;       // (rows out of range are reported above; stay inside the histogram)
+      atomicAdd(&tl_hist_lds[g], 1);
+      int64_t bc = r / TL_BLOCK_ROWS, bp = e > a ? rp / TL_BLOCK_ROWS : -1;
+      if (bc < 0) bc = 0;
+      if (bc >= nblocks) bc = nblocks - 1;
+      if (bp >= nblocks) bp = nblocks - 1;
+      for (int64_t bb = bp + 1; bb <= bc; ++bb) split[bb * K + c] = (int)(e - a);
+      if (e == b - 1)
+        for (int64_t bb = bc + 1; bb <= nblocks; ++bb) split[bb * K + c] = (int)(b - a);
     }
   }
+  if (bad) atomicOr(&state[0], 1ull);
   __syncthreads();
   int* const out = cntq + (int64_t)q * groups * ntiles;
   for (int64_t g = tid; g < groups; g += 1024) out[g * ntiles + t] = tl_hist_lds[g];
@@ -1125,8 +1135,10 @@ static int tl_launch_inspect_csc(int64_t M, int64_t K, int64_t ntiles, const T* 
   const int64_t words = ((nblocks + 1) * K + TL_CSC_HIST_PARTS * groups * ntiles + groups * (ntiles + 1) + 1) & ~(int64_t)1;   // (8-byte alignment)
   long long* const gcnt = reinterpret_cast<long long*>(ws + words);
   long long* const e0 = gcnt + groups;
-  const unsigned sgrid = (unsigned)std::min<int64_t>(K, (int64_t)256 * 64);
-  hipLaunchKernelGGL((tl_csc_split_kernel<I>), dim3(sgrid), dim3(256), 0, s, M, K, nblocks, a_indices, a_indptr, split, state);
+  if (!hist) {
+    const unsigned sgrid = (unsigned)std::min<int64_t>(K, (int64_t)256 * 64);
+    hipLaunchKernelGGL((tl_csc_split_kernel<I>), dim3(sgrid), dim3(256), 0, s, M, K, nblocks, a_indices, a_indptr, split, state);
+  }
   const dim3 grid((unsigned)nblocks, (unsigned)ceil_div(ntiles, (int64_t)TL_CSC_TC));
   if (hist) {
     auto hk = &tl_csc_hist_kernel<I>;
@@ -1135,8 +1147,8 @@ static int tl_launch_inspect_csc(int64_t M, int64_t K, int64_t ntiles, const T* 
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hk), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(hk, dim3((unsigned)ntiles, TL_CSC_HIST_PARTS), dim3(1024), lds, s, K, (int)ntiles, groups, a_indices,
-                       a_indptr, cnt);
+    hipLaunchKernelGGL(hk, dim3((unsigned)ntiles, TL_CSC_HIST_PARTS), dim3(1024), lds, s, M, K, (int)ntiles, groups, nblocks,
+                       a_indices, a_indptr, cnt, split, state);
   } else {
     hipLaunchKernelGGL((tl_csc_count_kernel<I>), grid, dim3(256), 0, s, K, (int)ntiles, a_indices, a_indptr, (const int*)split,
                        (const unsigned long long*)state, cnt);
