@@ -753,7 +753,7 @@ extern "C" int spamd_spmm_tiled_inspect(int val_dtype, int idx_dtype, int64_t M,
 // paid a CSC -> CSR sort of every stored element (4.3 ms of 7.4 at config 2's size) before the inspector above could run.
 // But a K-tile's elements are CONTIGUOUS in CSC (160 whole columns), and inside a column the rows ascend, so a workgroup's
 // 560 rows own one short run per column: no sort at all.
-//   tl_csc_split_kernel   one pass over the row indices: split[bb][c] = first element (relative to the column's start) of
+//   tl_csc_split_kernel   one pass over the row indices: split[c][bb] = first element (relative to the column's start) of
 //                         column c whose row is >= 560 bb; also the "rows ascend inside every column" verdict.
 //   tl_csc_count_kernel   workgroup = (560-row block = the 16 row groups of one executor workgroup, four tiles): the sizes of
 //                         its (group, tile) lists, by walking its runs.
@@ -777,7 +777,7 @@ __global__ void __launch_bounds__(256) tl_csc_split_kernel(int64_t M, int64_t K,
     const int64_t a = (int64_t)indptr[c], b = (int64_t)indptr[c + 1];
     if (b - a >= ((int64_t)1 << 31)) bad = true;
     if (a >= b) {
-      for (int64_t bb = tid; bb <= nblocks; bb += 256) split[bb * K + c] = 0;
+      for (int64_t bb = tid; bb <= nblocks; bb += 256) split[c * (nblocks + 1) + bb] = 0;
       continue;
     }
 #pragma unroll 4
@@ -789,9 +789,9 @@ __global__ void __launch_bounds__(256) tl_csc_split_kernel(int64_t M, int64_t K,
       if (bc < 0) bc = 0;
       if (bc >= nblocks) bc = nblocks - 1;
       if (bp >= nblocks) bp = nblocks - 1;
-      for (int64_t bb = bp + 1; bb <= bc; ++bb) split[bb * K + c] = (int)(e - a);
+      for (int64_t bb = bp + 1; bb <= bc; ++bb) split[c * (nblocks + 1) + bb] = (int)(e - a);
       if (e == b - 1)
-        for (int64_t bb = bc + 1; bb <= nblocks; ++bb) split[bb * K + c] = (int)(b - a);
+        for (int64_t bb = bc + 1; bb <= nblocks; ++bb) split[c * (nblocks + 1) + bb] = (int)(b - a);
     }
   }
   if (bad) atomicOr(&state[0], 1ull);
@@ -809,14 +809,14 @@ constexpr int TL_CSC_TC = SPAMD_CSC_TC;         // tiles per workgroup (count an
 // consecutive lanes read consecutive elements of a run (a thread per column instead - the first form of these kernels -
 // costs the texture addresser one cache line per LANE: 3.6 / 5.2 ms at config 2's size against 2.1 / 2.6 ms).
 template <typename I>
-__device__ __forceinline__ int tl_csc_runs(int t, int64_t K, const I* __restrict__ indptr, const int* __restrict__ s0,
-                                           const int* __restrict__ s1, long long* rstart, int* pre, int* wsum) {
+__device__ __forceinline__ int tl_csc_runs(int t, int64_t K, const I* __restrict__ indptr, const int* __restrict__ sp,
+                                           int64_t pitch, long long* rstart, int* pre, int* wsum) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t c = (int64_t)t * TL_KB + tid;
   int len = 0;
   if (tid < TL_KB && c < K) {
-    const int a0 = s0[c];
-    len = s1[c] - a0;
+    const int a0 = sp[c * pitch], a1 = sp[c * pitch + 1];   // (this block's and the next one's pointer: adjacent words)
+    len = a1 - a0;
     rstart[tid] = (int64_t)indptr[c] + a0;
   }
   int x = len;
@@ -850,7 +850,7 @@ __device__ __forceinline__ int64_t tl_csc_locate(int k, const long long* rstart,
 
 // cnt[g * ntiles + t] = elements of list (g, t)
 template <typename I>
-__global__ void __launch_bounds__(256) tl_csc_count_kernel(int64_t K, int ntiles, const I* __restrict__ indices,
+__global__ void __launch_bounds__(256) tl_csc_count_kernel(int64_t K, int ntiles, int64_t nblocks, const I* __restrict__ indices,
                                                            const I* __restrict__ indptr, const int* __restrict__ split,
                                                            const unsigned long long* __restrict__ state, int* __restrict__ cnt) {
   __shared__ long long rstart[TL_KB];
@@ -864,7 +864,7 @@ __global__ void __launch_bounds__(256) tl_csc_count_kernel(int64_t K, int ntiles
   const int t_end = ((int)blockIdx.y + 1) * TL_CSC_TC < ntiles ? ((int)blockIdx.y + 1) * TL_CSC_TC : ntiles;
   for (int t = (int)blockIdx.y * TL_CSC_TC; t < t_end; ++t) {
     if (tid < TL_WAVES) c16[tid] = 0;
-    const int total = tl_csc_runs<I>(t, K, indptr, split + b * K, split + (b + 1) * K, rstart, pre, wsum);
+    const int total = tl_csc_runs<I>(t, K, indptr, split + b, nblocks + 1, rstart, pre, wsum);
     for (int k = tid; k < total; k += 256) {
       const int64_t e = tl_csc_locate(k, rstart, pre);
       atomicAdd(&c16[(int)(((int64_t)indices[e] - r_base) / TL_RG)], 1);
@@ -906,7 +906,7 @@ __global__ void __launch_bounds__(1024) tl_csc_hist_kernel(int64_t M, int64_t K,
     const int64_t a = (int64_t)indptr[c], b = (int64_t)indptr[c + 1];
     if (b - a >= ((int64_t)1 << 31)) bad = true;
     if (a >= b) {
-      for (int64_t bb = tid; bb <= nblocks; bb += 1024) split[bb * K + c] = 0;
+      for (int64_t bb = tid; bb <= nblocks; bb += 1024) split[c * (nblocks + 1) + bb] = 0;
       continue;
     }
 #pragma unroll 2
@@ -922,9 +922,9 @@ __global__ void __launch_bounds__(1024) tl_csc_hist_kernel(int64_t M, int64_t K,
       if (bc < 0) bc = 0;
       if (bc >= nblocks) bc = nblocks - 1;
       if (bp >= nblocks) bp = nblocks - 1;
-      for (int64_t bb = bp + 1; bb <= bc; ++bb) split[bb * K + c] = (int)(e - a);
+      for (int64_t bb = bp + 1; bb <= bc; ++bb) split[c * (nblocks + 1) + bb] = (int)(e - a);
       if (e == b - 1)
-        for (int64_t bb = bc + 1; bb <= nblocks; ++bb) split[bb * K + c] = (int)(b - a);
+        for (int64_t bb = bc + 1; bb <= nblocks; ++bb) split[c * (nblocks + 1) + bb] = (int)(b - a);
     }
   }
   if (bad) atomicOr(&state[0], 1ull);
@@ -1040,7 +1040,7 @@ __global__ void __launch_bounds__(256) tl_csc_fill_kernel(int64_t K, int ntiles,
       tbase[tid] = 0;
       lo16[tid] = rel[(b * GPB + tid) * (ntiles + 1) + t];
     }
-    const int total = tl_csc_runs<I>(t, K, indptr, split + b * K, split + (b + 1) * K, rstart, pre, wsum);
+    const int total = tl_csc_runs<I>(t, K, indptr, split + b, nblocks + 1, rstart, pre, wsum);
     if (tid < GPB) blk_off[(b * GPB + tid) * (ntiles + 1) + t] = (int)(goff_s[tid] + lo16[tid]);
     // The tile's elements in (column, row) order, a window at a time: consecutive lanes take consecutive elements (of a
     // run), an element's place inside its list = the elements of its group in front of it: its rank among the equal-group
@@ -1126,7 +1126,8 @@ static int tl_launch_inspect_csc(int64_t M, int64_t K, int64_t ntiles, const T* 
   const int64_t groups = tl_grid_groups(M);
   const int64_t nblocks = groups / TL_WAVES;
   if (nblocks >= ((int64_t)1 << 31)) return SPAMD_EINVAL;
-  // workspace: split[(nblocks + 1) * K], cnt[groups * ntiles], rel[groups * (ntiles + 1)], gcnt[groups], e0[groups + 1] (8-byte)
+  // workspace: split[K * (nblocks + 1)] (column-major: a column's pointers are written next to each other - block-major, every
+  // 4-byte pointer dirtied a cache line of its own: 0.8 GB written back for 0.07 GB of pointers), cnt[groups * ntiles], rel[groups * (ntiles + 1)], gcnt[groups], e0[groups + 1] (8-byte)
   const bool hist = groups <= TL_CSC_HIST_GROUPS;
   const int parts = hist ? TL_CSC_HIST_PARTS : 1;
   int* const split = ws;
@@ -1150,7 +1151,7 @@ static int tl_launch_inspect_csc(int64_t M, int64_t K, int64_t ntiles, const T* 
     hipLaunchKernelGGL(hk, dim3((unsigned)ntiles, TL_CSC_HIST_PARTS), dim3(1024), lds, s, M, K, (int)ntiles, groups, nblocks,
                        a_indices, a_indptr, cnt, split, state);
   } else {
-    hipLaunchKernelGGL((tl_csc_count_kernel<I>), grid, dim3(256), 0, s, K, (int)ntiles, a_indices, a_indptr, (const int*)split,
+    hipLaunchKernelGGL((tl_csc_count_kernel<I>), grid, dim3(256), 0, s, K, (int)ntiles, nblocks, a_indices, a_indptr, (const int*)split,
                        (const unsigned long long*)state, cnt);
   }
   hipLaunchKernelGGL((tl_csc_offsets_kernel<TlFmt<T>::EPB>), dim3((unsigned)ceil_div(groups, (int64_t)256)), dim3(256), 0, s,
