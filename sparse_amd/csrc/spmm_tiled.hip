@@ -848,9 +848,10 @@ __device__ __forceinline__ int64_t tl_csc_locate(int k, const long long* rstart,
   return rstart[lo] + (k - pre[lo]);
 }
 
-// cnt[g * ntiles + t] = elements of list (g, t)
+// cnt[t * groups + g] = elements of list (g, t)
 template <typename I>
-__global__ void __launch_bounds__(256) tl_csc_count_kernel(int64_t K, int ntiles, int64_t nblocks, const I* __restrict__ indices,
+__global__ void __launch_bounds__(256) tl_csc_count_kernel(int64_t K, int ntiles, int64_t nblocks, int64_t groups,
+                                                           const I* __restrict__ indices,
                                                            const I* __restrict__ indptr, const int* __restrict__ split,
                                                            const unsigned long long* __restrict__ state, int* __restrict__ cnt) {
   __shared__ long long rstart[TL_KB];
@@ -870,7 +871,7 @@ __global__ void __launch_bounds__(256) tl_csc_count_kernel(int64_t K, int ntiles
       atomicAdd(&c16[(int)(((int64_t)indices[e] - r_base) / TL_RG)], 1);
     }
     __syncthreads();
-    if (tid < TL_WAVES) cnt[(b * TL_WAVES + tid) * ntiles + t] = c16[tid];
+    if (tid < TL_WAVES) cnt[(int64_t)t * groups + b * TL_WAVES + tid] = c16[tid];
     __syncthreads();
   }
 }
@@ -930,7 +931,7 @@ __global__ void __launch_bounds__(1024) tl_csc_hist_kernel(int64_t M, int64_t K,
   if (bad) atomicOr(&state[0], 1ull);
   __syncthreads();
   int* const out = cntq + (int64_t)q * groups * ntiles;
-  for (int64_t g = tid; g < groups; g += 1024) out[g * ntiles + t] = tl_hist_lds[g];
+  for (int64_t g = tid; g < groups; g += 1024) out[(int64_t)t * groups + g] = tl_hist_lds[g];   // (tile-major: written and read coalesced)
 }
 
 // per group: its lists' first blocks relative to the group's own (rel[g * (ntiles + 1) + t], the last entry = the group's
@@ -947,7 +948,7 @@ __global__ void __launch_bounds__(256) tl_csc_offsets_kernel(int64_t groups, int
   for (int t = 0; t < ntiles; ++t) {
     int c = 0;
     if (!bad)
-      for (int q = 0; q < parts; ++q) c += cnt[(q * groups + g) * ntiles + t];
+      for (int q = 0; q < parts; ++q) c += cnt[((int64_t)q * ntiles + t) * groups + g];
     rel[g * (ntiles + 1) + t] = run;
     run += (c + EPB - 1) / EPB;
     tot += c;
@@ -1151,7 +1152,7 @@ static int tl_launch_inspect_csc(int64_t M, int64_t K, int64_t ntiles, const T* 
     hipLaunchKernelGGL(hk, dim3((unsigned)ntiles, TL_CSC_HIST_PARTS), dim3(1024), lds, s, M, K, (int)ntiles, groups, nblocks,
                        a_indices, a_indptr, cnt, split, state);
   } else {
-    hipLaunchKernelGGL((tl_csc_count_kernel<I>), grid, dim3(256), 0, s, K, (int)ntiles, nblocks, a_indices, a_indptr, (const int*)split,
+    hipLaunchKernelGGL((tl_csc_count_kernel<I>), grid, dim3(256), 0, s, K, (int)ntiles, nblocks, groups, a_indices, a_indptr, (const int*)split,
                        (const unsigned long long*)state, cnt);
   }
   hipLaunchKernelGGL((tl_csc_offsets_kernel<TlFmt<T>::EPB>), dim3((unsigned)ceil_div(groups, (int64_t)256)), dim3(256), 0, s,
