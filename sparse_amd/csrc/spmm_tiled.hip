@@ -934,7 +934,7 @@ __global__ void __launch_bounds__(1024) tl_csc_hist_kernel(int64_t M, int64_t K,
   for (int64_t g = tid; g < groups; g += 1024) out[(int64_t)t * groups + g] = tl_hist_lds[g];   // (tile-major: written and read coalesced)
 }
 
-// per group: its lists' first blocks relative to the group's own (rel[g * (ntiles + 1) + t], the last entry = the group's
+// per group: its lists' first blocks relative to the group's own (rel[t * groups + g], tile-major like cnt; row ntiles = the group's
 // blocks) and its element count
 template <int EPB>
 __global__ void __launch_bounds__(256) tl_csc_offsets_kernel(int64_t groups, int ntiles, const int* __restrict__ cnt, int parts,
@@ -949,11 +949,11 @@ __global__ void __launch_bounds__(256) tl_csc_offsets_kernel(int64_t groups, int
     int c = 0;
     if (!bad)
       for (int q = 0; q < parts; ++q) c += cnt[((int64_t)q * ntiles + t) * groups + g];
-    rel[g * (ntiles + 1) + t] = run;
+    rel[(int64_t)t * groups + g] = run;
     run += (c + EPB - 1) / EPB;
     tot += c;
   }
-  rel[g * (ntiles + 1) + ntiles] = run;
+  rel[(int64_t)ntiles * groups + g] = run;
   gcnt[g] = tot;
 }
 
@@ -1003,6 +1003,7 @@ __global__ void __launch_bounds__(256) tl_csc_fill_kernel(int64_t K, int ntiles,
   // workgroup L runs on XCD L % 8 (observed placement; for speed only): an XCD takes a contiguous eighth of the row blocks,
   // consecutive workgroups of an XCD = consecutive blocks of the same tiles - their runs share cache lines (a 128-byte line
   // of row indices spans 3-6 blocks), which are then found in that XCD's L2
+  const int64_t groups = nblocks * GPB;
   const int64_t per_x = (nblocks + 7) / 8;
   const int64_t seq = (int64_t)(blockIdx.x >> 3);
   const int64_t b = (int64_t)(blockIdx.x & 7u) * per_x + seq % per_x;
@@ -1029,7 +1030,7 @@ __global__ void __launch_bounds__(256) tl_csc_fill_kernel(int64_t K, int ntiles,
     // the group's end and the zeroed gap in front of the next group
     for (int gi = 0; gi < GPB; ++gi) {
       const int64_t g = b * GPB + gi;
-      const int64_t gend = goff_s[gi] + rel[g * (ntiles + 1) + ntiles];
+      const int64_t gend = goff_s[gi] + rel[(int64_t)ntiles * groups + g];
       const int64_t gnext = tl_group_first_block(e0[g + 1], g + 1, ntiles, EPB);
       if (tid == 0) blk_off[g * (ntiles + 1) + ntiles] = (int)gend;
       for (int64_t i = gend * TL_BLOCK_INTS + tid; i < gnext * TL_BLOCK_INTS; i += 256) stream[i] = 0;
@@ -1039,7 +1040,7 @@ __global__ void __launch_bounds__(256) tl_csc_fill_kernel(int64_t K, int ntiles,
   for (int t = t_beg; t < t_end; ++t) {
     if (tid < GPB) {
       tbase[tid] = 0;
-      lo16[tid] = rel[(b * GPB + tid) * (ntiles + 1) + t];
+      lo16[tid] = rel[(int64_t)t * groups + b * GPB + tid];
     }
     const int total = tl_csc_runs<I>(t, K, indptr, split + b, nblocks + 1, rstart, pre, wsum);
     if (tid < GPB) blk_off[(b * GPB + tid) * (ntiles + 1) + t] = (int)(goff_s[tid] + lo16[tid]);
