@@ -457,7 +457,7 @@ def prepare_spmm(a, dtype=None, force_sort=False):
 
 
 # Late round 4 (tools/r04/csc_inspect.py; CSC inspector against CSC -> CSR + CSR inspector, ms): 4.2 x 10^4 stored elements
-# 0.07 / 0.06, 1.2 x 10^5 0.09 / 0.08, 10^6 0.07 / 0.14, 8 x 10^6 0.18 / 0.36, 10^8 1.36 / 3.4 (float64: 1.7 / 5.2).
+# 0.07 / 0.06, 1.2 x 10^5 0.09 / 0.08, 10^6 0.07 / 0.14, 8 x 10^6 0.18 / 0.36, 10^8 1.36 / 3.4 (float64: 1.5 / 5.2).
 CSC_INSPECT_MIN_NNZ = 200_000
 
 

@@ -797,6 +797,10 @@ __global__ void __launch_bounds__(256) tl_csc_split_kernel(int64_t M, int64_t K,
   if (bad) atomicOr(&state[0], 1ull);
 }
 
+#ifndef SPAMD_CSC_ABL
+#define SPAMD_CSC_ABL 0   // timing ablations of tl_csc_fill_kernel (wrong streams): 1 no entry stores, 3 no value loads
+#endif
+constexpr int TL_CSC_IMG_BLOCKS = 256;   // 64-byte blocks of a tile's 16 lists assembled in LDS (~190 for float64 at 1 %)
 constexpr int TL_CSC_STAGE = 1024;   // elements of a (row block, tile) staged in LDS at a time (a tile's runs hold ~900 at 1 %)
 #ifndef SPAMD_CSC_TC
 #define SPAMD_CSC_TC 4
@@ -999,6 +1003,8 @@ __global__ void __launch_bounds__(256) tl_csc_fill_kernel(int64_t K, int ntiles,
   __shared__ long long goff_s[GPB];
   __shared__ int tbase[GPB], lo16[GPB];
   __shared__ int ccnt[CHUNKS * GPB];          // elements of a chunk per group, then their exclusive prefix over the window
+  __shared__ __attribute__((aligned(16))) int img[TL_CSC_IMG_BLOCKS * TL_BLOCK_INTS];   // the tile's lists as they go to the stream
+  __shared__ int ib[GPB], tsum_s;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // workgroup L runs on XCD L % 8 (observed placement; for speed only): an XCD takes a contiguous eighth of the row blocks,
   // consecutive workgroups of an XCD = consecutive blocks of the same tiles - their runs share cache lines (a 128-byte line
@@ -1043,6 +1049,7 @@ __global__ void __launch_bounds__(256) tl_csc_fill_kernel(int64_t K, int ntiles,
       lo16[tid] = rel[(int64_t)t * groups + b * GPB + tid];
     }
     const int total = tl_csc_runs<I>(t, K, indptr, split + b, nblocks + 1, rstart, pre, wsum);
+    bool padded = false;
     if (tid < GPB) blk_off[(b * GPB + tid) * (ntiles + 1) + t] = (int)(goff_s[tid] + lo16[tid]);
     // The tile's elements in (column, row) order, a window at a time: consecutive lanes take consecutive elements (of a
     // run), an element's place inside its list = the elements of its group in front of it: its rank among the equal-group
@@ -1073,7 +1080,11 @@ __global__ void __launch_bounds__(256) tl_csc_fill_kernel(int64_t K, int ntiles,
           const int64_t e = rstart[lo] + (k - pre[lo]);
           col[p] = lo;
           rr[p] = (int)((int64_t)indices[e] - r_base);
+#if SPAMD_CSC_ABL == 3
+          vv[p] = T(1);
+#else
           vv[p] = vals[e];
+#endif
         }
         const int gi = rr[p] / TL_RG;
         unsigned long long m = __ballot(valid);
@@ -1097,23 +1108,73 @@ __global__ void __launch_bounds__(256) tl_csc_fill_kernel(int64_t K, int ntiles,
         }
         __syncthreads();
         ccnt[ch * GPB + gi] = sum;
-        if (ch == 0) tbase[gi] += all;
+        if (ch == 0) {
+          tbase[gi] += all;
+          // blocks of the tile's lists and their starts inside the LDS image (meaningful when the tile is one window)
+          const int nb = (tbase[gi] + EPB - 1) / EPB;
+          int x = nb;
+#pragma unroll
+          for (int d = 1; d < GPB; d <<= 1) {
+            const int u = __shfl_up(x, d, GPB);
+            if (gi >= d) x += u;
+          }
+          ib[gi] = x - nb;
+          if (gi == GPB - 1) tsum_s = x;
+        }
       }
       __syncthreads();
+      // A tile in one window whose lists fit the LDS image (the usual case) is assembled there - padding included - and
+      // copied out with consecutive lanes on consecutive 16 bytes of a list: an entry's own stores (8 bytes; float64: 4 + 8 in
+      // two places of its block) cost this kernel 0.3 ms (float32) / 0.6 ms (float64) of 1.0 / 1.3 at config 2's size.
+      const bool img_path = total <= TL_CSC_STAGE && tsum_s <= TL_CSC_IMG_BLOCKS;     // (tsum_s: written with the prefix above)
+      if (img_path) {
+        for (int i = tid; i < tsum_s * TL_BLOCK_INTS; i += 256) img[i] = 0;
+        __syncthreads();
+      }
 #pragma unroll
       for (int p = 0; p < PER; ++p) {
         const int k = w0 + tid + 256 * p;
         if (k < w1) {
           const int gi = rr[p] / TL_RG, lr = rr[p] - gi * TL_RG;
           const int pos = ccnt[(wv + 4 * p) * GPB + gi] + rank[p];
-          const int64_t dst = (goff_s[gi] + lo16[gi]) * EPB + pos;
-          TlFmt<T>::put(stream, dst, tl_d0(col[p], lr), vv[p]);
+          if (img_path) {
+            const int e = ib[gi] * EPB + pos;
+            const int d0 = tl_d0(col[p], lr);
+            if constexpr (sizeof(T) == 4) {
+              img[(e / EPB) * TL_BLOCK_INTS + (e % EPB) * 2] = d0;
+              img[(e / EPB) * TL_BLOCK_INTS + (e % EPB) * 2 + 1] = __builtin_bit_cast(int, vv[p]);
+            } else {
+              const long long bits = __builtin_bit_cast(long long, vv[p]);
+              const int base = (e / EPB) * TL_BLOCK_INTS, slot = e % EPB;
+              img[base + slot] = d0;
+              img[base + 6 + 2 * slot] = (int)(bits & 0xffffffffll);
+              img[base + 7 + 2 * slot] = (int)(bits >> 32);
+            }
+          } else {
+            const int64_t dst = (goff_s[gi] + lo16[gi]) * EPB + pos;
+            TlFmt<T>::put(stream, dst, tl_d0(col[p], lr), vv[p]);
+          }
         }
       }
       __syncthreads();
+      if (img_path) {
+        typedef int int4v __attribute__((ext_vector_type(4)));
+        const int nvec = tsum_s * (TL_BLOCK_INTS / 4);
+        for (int i = tid; i < nvec; i += 256) {
+          const int blk = i >> 2;
+          int gi = 0;
+#pragma unroll
+          for (int q = 1; q < GPB; ++q) gi += ib[q] <= blk ? 1 : 0;   // the list of this block (empty lists share a start: skipped)
+          const int64_t dst = (goff_s[gi] + lo16[gi] + (blk - ib[gi])) * TL_BLOCK_INTS + (i & 3) * 4;
+          *reinterpret_cast<int4v*>(stream + dst) = *reinterpret_cast<const int4v*>(&img[i * 4]);
+        }
+        __syncthreads();
+        padded = true;
+      }
     }
-    // padding entries of the tile's lists (zero d0 and value: they accumulate into the junk register pair)
-    if (tid < GPB) {
+    // padding entries of the tile's lists (zero d0 and value: they accumulate into the junk register pair); the LDS image
+    // carried them already
+    if (!padded && tid < GPB) {
       const int c = tbase[tid], nb = (c + EPB - 1) / EPB;
       const int64_t first = (goff_s[tid] + lo16[tid]) * EPB;
       for (int q = c; q < nb * EPB; ++q) TlFmt<T>::put(stream, first + q, 0, T(0));
