@@ -25,7 +25,7 @@ for p in glob.glob(os.path.join(root, "pmc_paths", "*", "**", "*counter_collecti
         seq.setdefault(kern, {})[ctr] = [per[k] for k in sorted(per, key=int)]   # per dispatch, in launch order
 out = {}
 for kern, c in pmc.items():
-    if "spamd" not in kern and "reduce_fill" not in kern:
+    if "spamd" not in kern and "reduce_fill" not in kern and "tl_csc" not in kern:
         continue
     e = dict(c)
     if "FETCH_SIZE" in c: e["fabric_read_bytes_per_launch"] = 2 * c["FETCH_SIZE"] * 1024
@@ -49,6 +49,9 @@ ROWS = {
                                     "spamd::spgemm_bsplit_kernel<long>"],
     "A1_f64": ["spamd::spmm_tiled_kernel<0, 4, double>"],
     "A2_default_gcxs_steady": ["spamd::spmm_tiled_kernel<0, 4, double>"],
+    # the reference-default operand's first product: CSC-native inspector (one launch of each kernel) + the float64 executor
+    "A2_default_gcxs_first": ["tl_csc_hist_kernel<long>", "tl_csc_offsets_kernel<5>", "tl_csc_scan_kernel", "tl_csc_fill_kernel<long, double>",
+                              "spamd::spmm_tiled_kernel<0, 4, double>"],
 }
 # rows that share their kernels with another row of a different size: (first, last) share of the kernels' dispatches, in
 # launch order (bench_paths.py runs `add` - plain and with coordinates - before `multiply`)
