@@ -43,15 +43,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HBM_MEASURED_GBS = 6290.0  # float4 copy on this part (same guide): the achievable streaming rate
 LDS_READ_PEAK_BPS = 150e12 # all 256 CUs reading LDS with ds_read_b64/b128 (same guide, LDS section)
-# Round-3 ablations of the executor at config 2 (tools/tiled_geo_time.py on -DSPAMD_TUNING builds; raw output in
-# profiles/r03_tiled_ablation.txt): what the kernel takes with parts of its work assembled out.  Constants of THIS source
-# tree, recorded here so that the bound is stated next to the number it explains; they are not re-measured by this run.
-TILED_ABLATION_R03 = {
-    "full": 0.834, "no_tile_dma": 0.748, "no_fma": 0.703, "no_lds_reads_no_fma": 0.673,
-    "scalar_stream_heads_barriers_only": 0.471, "tile_dma_barriers_heads_only(all lists empty)": 0.504,
-    "note": "the block stream through the scalar cache (0.47) and the L2->LDS delivery of B (0.50) are the two floors; "
-            "they overlap to 0.67, the LDS reads and FMAs add 0.16",
-}
+TILED_ABLATION_FILE = "profiles/r03_tiled_ablation.txt"   # round-3 ablations of the (since unchanged) executor: a pointer, not a measurement of this run
 
 
 def make_csr_device(M, K, density, seed, idx_dtype=torch.int32, dtype=torch.float32, device="cuda"):
@@ -167,6 +159,77 @@ def load_traffic(kernel_substr):
         return None, None
 
 
+RCCL_PROBE = r"""
+import json, os, sys, time, datetime
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0),
+                        timeout=datetime.timedelta(seconds=60))
+K, N = int(sys.argv[1]), int(sys.argv[2])
+b = torch.rand((K, N), device="cuda")
+out = torch.empty_like(b)
+for _ in range(5):
+    dist.all_gather_into_tensor(out, b)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+t0 = time.perf_counter(); e0.record()
+for _ in range(50):
+    dist.all_gather_into_tensor(out, b)
+e1.record(); torch.cuda.synchronize()
+print(json.dumps({"device_ms": e0.elapsed_time(e1) / 50, "host_wall_ms": (time.perf_counter() - t0) * 1e3 / 50,
+                  "same": bool(torch.equal(out, b))}))
+dist.destroy_process_group()
+"""
+
+
+def rccl_world1_gather_ms(K, N):
+    """The FIXED part of the per-step exchange: `all_gather_into_tensor` of a K x N fp32 operand on an RCCL communicator of
+    world size 1 (launch + the collective's own kernel; no xGMI traffic - that part needs the 8-GPU node), in a child
+    process under a timeout so that a communicator that does not come up cannot take the bench line with it."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run([sys.executable, "-c", RCCL_PROBE, str(K), str(N)], env=env, capture_output=True, text=True, timeout=120)
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:200]}
+
+
+def scaling_proxy(sp, _dist, data, idx, ptr, b_full, K, whole_ms, steps):
+    """{world: {max_ms, mean_ms, nnz_imbalance, speedup}} for world in 2, 4, 8: EVERY block of the nnz-balanced partition
+    multiplied alone on this GPU (B resident, `matmul` incl. its NaN pass, block streams cached as in the steady state)."""
+    res = {}
+    for w in (2, 4, 8):
+        bounds = _dist.partition_rows_by_nnz(ptr, w)
+        ms, nn = [], []
+        for r in range(w):
+            d, i, p, r0, r1 = _dist.shard_csr(data, idx, ptr, r, w, bounds)
+            a = sp.GCXS((d.contiguous(), i.contiguous(), p.contiguous()), shape=(r1 - r0, K), compressed_axes=(0,))
+            for _ in range(5):
+                o = sp.matmul(a, b_full)
+            ms.append(dev_time(lambda: sp.matmul(a, b_full), steps))
+            nn.append(int(d.numel()))
+            del a, o, d, i, p
+        sp.flush_warnings()
+        mean = sum(ms) / w
+        res[str(w)] = {"max_ms": round(max(ms), 4), "mean_ms": round(mean, 4), "min_ms": round(min(ms), 4),
+                       "time_imbalance": round(max(ms) / mean, 4), "nnz_imbalance": round(max(nn) / (sum(nn) / w), 5),
+                       "speedup_vs_whole": round(whole_ms / max(ms), 3)}
+    res["rccl_world1_all_gather_B"] = rccl_world1_gather_ms(K, int(b_full.shape[1]))
+    g = res["rccl_world1_all_gather_B"].get("device_ms")
+    if g is not None:
+        for w in ("2", "4", "8"):
+            res[w]["speedup_with_fixed_gather"] = round(whole_ms / (res[w]["max_ms"] + g), 3)
+    res["what"] = ("every nnz-balanced row block timed ALONE on one GPU, B resident: step time at world w = max over blocks "
+                   "(+ the exchange; only its fixed part, an RCCL world-size-1 all-gather, is measurable here)")
+    return res
+
+
 def relaunch_distributed(n):
     """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU."""
     s = socket.socket()
@@ -264,8 +327,8 @@ def main():
     tiled = False
     if _dot._tiled_eligible(a.data, b_full, (Mloc, N), K):
         rowgroup = lambda: _kernels.dot_csr_ndarray((Mloc, N), data, idx, ptr, b_full, exact=False)
-        rowgroup()
-        rowgroup_ms = dev_time(rowgroup, 5)   # the general cache-less kernel (every dtype / shape the executor does not take)
+        # (timed AFTER the timed region, warm: round 4 timed it here, inside the first-call window, and reported 9.7 ms
+        # for a kernel rocprofv3 sees at 2.8 ms)
 
         def first_product():
             _dot.drop_derived(a)               # forget the cached block stream: inspector + executor, as at a first product
@@ -339,28 +402,31 @@ def main():
         kern = lambda: _kernels.dot_csr_ndarray((Mloc, N), data, idx, ptr, b_full, exact=bool(args.exact), out=out)
     kern()
     kernel_ms = dev_time(kern, args.steps)
-    # ---- the only scaling proxy one GPU can give: a rank's share at world size 8 (the first of 8 nnz-balanced row blocks of
-    # THIS matrix, B resident: what `--gpus 8 --scaling strong` runs per rank besides the all-gather of B), timed alone
-    shard8 = None
+    if tiled:
+        for _ in range(3):
+            rowgroup()
+        rowgroup_ms = dev_time(rowgroup, 5)   # the general cache-less kernel (every dtype / shape the executor does not take)
+    # ---- what one GPU can say about scaling (no 8-GPU node is available to this run): for world sizes 2, 4, 8
+    # EVERY block of the nnz-balanced partition of THIS matrix is timed alone (B resident, through `matmul`): the step time
+    # of the sharded product is the MAX over the blocks + the exchange; its fixed part (an RCCL all-gather of B launched at
+    # world size 1) is measured in a child process
+    proxy = None
     if world == 1 and tiled and not args.no_paths:   # (not in the profiled headline run: its kernel average must be the headline's alone)
         try:
-            b8 = _dist.partition_rows_by_nnz(ptr, 8)
-            d8, i8, p8, s0, s1 = _dist.shard_csr(data, idx, ptr, 0, 8, b8)
-            a8 = sparse_amd.GCXS((d8.contiguous(), i8.contiguous(), p8.contiguous()), shape=(s1 - s0, K), compressed_axes=(0,))
-            for _ in range(5):
-                o8 = sparse_amd.matmul(a8, b_full)
-            shard8 = {"ms": dev_time(lambda: sparse_amd.matmul(a8, b_full), args.steps), "rows": s1 - s0, "nnz": int(d8.numel())}
-            shard8["speedup_vs_whole"] = ms_per_step / shard8["ms"]
-            del a8, o8, d8, i8, p8
+            proxy = scaling_proxy(sparse_amd, _dist, data, idx, ptr, b_full, K, ms_per_step, args.steps)
         except Exception as e:   # noqa: BLE001 - the headline line must still be printed
-            shard8 = {"error": repr(e)}
+            proxy = {"error": repr(e)}
     nan_check_ms = None
     if _settings.NAN_CHECK:
-        _settings.NAN_CHECK = False
-        no_nan_ms = dev_time(lambda: sparse_amd.matmul(a, b_full), args.steps)
-        _settings.NAN_CHECK = True
-        with_nan_ms = dev_time(lambda: sparse_amd.matmul(a, b_full), args.steps)
-        nan_check_ms = with_nan_ms - no_nan_ms
+        # what `matmul` adds to a product: the scans of both operands (A's verdict is memoised per buffer version, so in the
+        # steady state this is the scan of B and the bookkeeping), HIP events around the scans alone
+        def scans():
+            for x in (a, b_full):
+                v = _dot.check_class_nan(x, deferred=True)
+                if not isinstance(v, bool):
+                    v()
+        scans()
+        nan_check_ms = dev_time(scans, args.steps)
 
     if rank == 0:
         total_nnz = sum(nnz_ranks)
@@ -370,50 +436,44 @@ def main():
         rd, wr = algorithmic_bytes(Mloc, K, N, nnz, 4, ib)
         ach = (rd + wr) / (kernel_ms * 1e-3) / 1e9
         traffic, traffic_src = load_traffic("spmm_tiled" if tiled else "spmm_csr")
+        lds_floor = nnz * N * 4 / LDS_READ_PEAK_BPS * 1e3
+        r4 = lambda x: None if x is None else round(x, 4)
         line = {
             "metric": "GCXS x dense SpMM throughput (GFLOP/s)",
-            "value": flops_total / (ms_per_step * 1e-3) / 1e9,
+            "value": round(flops_total / (ms_per_step * 1e-3) / 1e9, 2),
             "unit": "GFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
+            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": (f"GCXS(CSR, compressed_axes=(0,)) {M}x{K} @ {args.density:g} ({global_nnz} nnz, {args.idx} indices)"
-                             f" split into {world} nnz-balanced row block(s)" if strong else
-                             f"GCXS(CSR, compressed_axes=(0,)) {world}x({M}x{K}) @ {args.density:g} ({nnz} nnz/GPU, {args.idx} indices)")
-                            + f" x dense {K}x{N} fp32 -> dense, row-sharded",
+                "workload": (f"GCXS(CSR) {M}x{K} @ {args.density:g} ({global_nnz} nnz, {args.idx} idx) in {world} nnz-balanced row block(s)"
+                             if strong else f"GCXS(CSR) {world}x({M}x{K}) @ {args.density:g} ({nnz} nnz/GPU, {args.idx} idx)")
+                            + f" x dense {K}x{N} fp32",
                 "world_size": world, "nnz_per_rank": nnz_ranks,
-                "nnz_imbalance": max(nnz_ranks) / (total_nnz / world) if total_nnz else 1.0,
+                "nnz_imbalance": round(max(nnz_ranks) / (total_nnz / world), 5) if total_nnz else 1.0,
                 "rows_rank0": Mloc, "idx_dtype": args.idx,
                 "parallelism": f"row-block x{world}" + (" + RCCL all-gather(B) per step" if sharded_b else ""),
-                "ms_per_step_with_B_gathered_once": ms_static_b,
+                "ms_per_step_with_B_gathered_once": r4(ms_static_b),
                 "mul_add": "separate (bit-exact)" if args.exact else "fma",
-                "nan_check_in_timed_region": bool(_settings.NAN_CHECK), "nan_check_ms_per_product": nan_check_ms,
+                "nan_check_in_timed_region": bool(_settings.NAN_CHECK), "nan_check_ms_per_product": r4(nan_check_ms),
                 "nan_warning": _settings.NAN_WARNING, "prewarm_products": PREWARM,
                 "kernel": "spmm_tiled (cached block stream)" if tiled else "spmm_csr_rowgroup",
-                "first_call_ms": first_call_ms, "first_call_cold_ms": first_call_cold_ms,
-                "first_call_gflops": flops_local / (first_call_ms * 1e-3) / 1e9 if first_call_ms else None,
-                "inspector_ms": inspector_ms, "rowgroup_ms": rowgroup_ms,
-                "rowgroup_gflops": flops_local / (rowgroup_ms * 1e-3) / 1e9 if rowgroup_ms else None,
+                "first_call_ms": r4(first_call_ms), "first_call_cold_ms": r4(first_call_cold_ms),
+                "inspector_ms": r4(inspector_ms), "rowgroup_ms": r4(rowgroup_ms),
             },
             "roofline": {
-                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "frac_of_measured_copy_rate": ach / HBM_MEASURED_GBS,
+                "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 5), "frac_of_measured_copy_rate": round(ach / HBM_MEASURED_GBS, 5),
                 "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes": rd + wr, "algorithmic_read_bytes": rd,
-                "read_only_frac": rd / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "kernel_ms": kernel_ms, "gflops_per_gpu": flops_local / (kernel_ms * 1e-3) / 1e9,
+                "kernel_ms": round(kernel_ms, 5), "gflops_per_gpu": round(flops_local / (kernel_ms * 1e-3) / 1e9, 1),
                 # the ceiling of ANY design that reads one 512-byte row of B from LDS per stored element (no two rows of a
                 # row group share a column at 1 % density, so there is no register-level reuse): nnz x N x 4 bytes at the
                 # ~150 TB/s all CUs' ds_read_b64 deliver (MI355X_MICROARCH.md, LDS section)
-                "lds_floor_ms": nnz * N * 4 / LDS_READ_PEAK_BPS * 1e3,
-                "frac_of_lds_floor": (nnz * N * 4 / LDS_READ_PEAK_BPS * 1e3) / kernel_ms,
-                "hbm_frac_at_lds_floor": (rd + wr) / (nnz * N * 4 / LDS_READ_PEAK_BPS) / 1e9 / HBM_PEAK_GBS,
-                # a rank's share at world size 8 timed alone on this GPU (B resident, no collective): ideal strong scaling
-                # would be 8x; what is missing is the fixed part of a product (launches, the per-tile phases of a shorter grid)
-                "shard_ms_at_world8": shard8,
-                "ablation_ms": TILED_ABLATION_R03 if tiled and world == 1 and (M, K, N) == (1_000_000, 10_000, 128) else None,
-                "what": "rank 0's launch: algorithmic bytes of its row block / average of `steps` back-to-back executor launches (HIP events)",
+                "lds_floor_ms": r4(lds_floor), "frac_of_lds_floor": r4(lds_floor / kernel_ms),
+                "scaling_proxy": proxy,
+                "ablation": TILED_ABLATION_FILE if tiled else None,
+                "what": "rank 0: algorithmic bytes of its row block / mean of `steps` back-to-back executor launches (HIP events)",
             },
         }
         if world == 1 and not args.no_cpu:
@@ -423,22 +483,31 @@ def main():
                 line["cpu_baseline"] = {"error": repr(e)}
         if world == 1 and not args.no_paths:
             del out
+            # the other section-8 rows: the FULL dict goes to an earlier stdout line and to gpurun_out/paths.json; the LAST
+            # line (the one the driver parses; round 4's 23 KB line did not parse) carries compact maps only
             try:
                 import bench_paths
 
-                line["paths"] = bench_paths.run(int64_of=(data, idx, ptr, b_full, M, K, N), verbose=False)
-                # (the driver's parser keeps `roofline` and drops unknown top-level keys: a compact {row: fraction of
-                # the 8 TB/s roofline} map of every other section-8 row rides along here)
-                line["roofline"]["paths_frac"] = {k: round(v["frac"], 4) for k, v in line["paths"].items()
-                                                  if isinstance(v, dict) and "frac" in v}
-                line["roofline"]["paths_ms"] = {k: round(v["ms"], 4) for k, v in line["paths"].items()
-                                                if isinstance(v, dict) and "ms" in v}
-                line["roofline"]["paths_pmc_over_algorithmic"] = {k: round(v["pmc_over_algorithmic"], 3) for k, v in line["paths"].items()
-                                                                  if isinstance(v, dict) and "pmc_over_algorithmic" in v}
-                line["roofline"]["paths_accounting_errors"] = line["paths"].get("_accounting_errors", [])
+                paths = bench_paths.run(int64_of=(data, idx, ptr, b_full, M, K, N), verbose=False)
+                print(json.dumps({"paths": paths}), flush=True)
+                try:
+                    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                    with open(os.path.join(ROOT, "gpurun_out", "paths.json"), "w") as f:
+                        json.dump(paths, f, indent=1)
+                except OSError:
+                    pass
+                rows = {k: v for k, v in paths.items() if isinstance(v, dict)}
+                rl = line["roofline"]
+                rl["paths_frac"] = {k: round(v["frac"], 4) for k, v in rows.items() if "frac" in v}
+                rl["paths_ms"] = {k: round(v["ms"], 4) for k, v in rows.items() if "ms" in v}
+                rl["paths_pmc_over_algorithmic"] = {k: round(v["pmc_over_algorithmic"], 3) for k, v in rows.items()
+                                                    if v.get("pmc_over_algorithmic") is not None}
+                rl["paths_pmc_source"] = paths.get("_pmc_source")
+                rl["paths_accounting_errors"] = paths.get("_accounting_errors", [])
+                rl["paths_full"] = "previous stdout line + gpurun_out/paths.json"
             except Exception as e:
-                line["paths"] = {"error": repr(e)}
-        print(json.dumps(line), flush=True)
+                line["roofline"]["paths_error"] = repr(e)
+        print(json.dumps(line, separators=(",", ":")), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

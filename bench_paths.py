@@ -115,6 +115,8 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
         return only is None or any(rid.startswith(o) for o in only)
 
     pmc = _pmc_rows()
+    out["_pmc_source"] = ("profiles/paths_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench_paths.py "
+                          "(tools/run_profiles.sh); reads = 2 x FETCH_SIZE x 1024, writes = WRITE_SIZE x 1024 on gfx950")
 
     def emit(rid, d):
         # HBM bytes the row's kernels really moved (rocprofv3 PMC passes over this script, committed as
@@ -123,11 +125,17 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
         p = pmc.get(rid)
         if p is not None:
             d["pmc_bytes"] = int(p["pmc_bytes"])
-            d["pmc_source"] = p.get("source", "profiles/paths_pmc.json")
             d["pmc_over_algorithmic"] = p["pmc_bytes"] / max(d["algorithmic_bytes"], 1)
             if p["pmc_bytes"] < 0.9 * d["algorithmic_bytes"] and not p.get("cache_resident"):
                 d["accounting_error"] = "PMC bytes below 0.9 x algorithmic bytes"
                 out.setdefault("_accounting_errors", []).append(rid)
+        else:
+            # rocprofv3 averages a kernel's counters over ALL its dispatches of a process: a row whose kernels also serve rows
+            # of other sizes (the executor, the row-group kernel, the library sort) has no per-row attribution in the committed
+            # passes - said here, not left out
+            d["pmc_bytes"] = None
+            d["pmc_over_algorithmic"] = None
+            d["pmc_null_reason"] = "kernels shared with rows of other sizes in the PMC pass (per-kernel averages only)"
         out[rid] = d
         if verbose:
             print(json.dumps({"row": rid, **d}), flush=True)
@@ -139,14 +147,17 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
         a64 = sp.GCXS((data, i64, p64), shape=(M, Kd), compressed_axes=(0,))
         nnz = int(data.numel())
         bytes64 = nnz * 12 + (M + 1) * 8 + Kd * N * 4 + M * N * 4
+        # the steady state reads the cached block stream, whose entries are 8 bytes whatever the index width was: its bytes are
+        # the int32 product's (round 4 divided the int64 bytes by this time: bytes not moved).  The int64 arrays are read where
+        # they are paid for: by the inspector at the FIRST product, and by the cache-less kernel.
+        bytes_steady = nnz * 8 + (M + 1) * 4 + Kd * N * 4 + M * N * 4
         ms_rg, _ = timed(lambda: K.dot_csr_ndarray((M, N), data, i64, p64, b), reps=3)
         ms_first, _ = timed(lambda: (_dot.drop_derived(a64), _dot._gcxs_times_dense(a64, b, (M, N)))[1], reps=3)
         ms, r = timed(lambda: a64 @ b, reps=10)
-        emit("A1_int64_idx", row(f"config 2 with int64 indices/indptr: GCXS(CSR) {M}x{Kd} ({nnz} nnz) x dense {Kd}x{N} fp32", ms, bytes64,
-                                 flops=2.0 * nnz * N, first_call_ms=ms_first, rowgroup_ms=ms_rg,
-                                 rowgroup_frac=bytes64 / ms_rg / 1e6 / HBM,
-                                 note="steady state reads the cached block stream (index width no longer matters); "
-                                      "first_call_ms = inspector + executor, rowgroup_ms = the cache-less kernel on int64 indices"))
+        emit("A1_int64_idx", row(f"config 2 with int64 indices/indptr: GCXS(CSR) {M}x{Kd} ({nnz} nnz) x dense {Kd}x{N} fp32, steady state "
+                                 "(cached block stream: 8-byte entries, so the bytes moved are the int32 product's)", ms, bytes_steady,
+                                 flops=2.0 * nnz * N, first_call_ms=ms_first, first_call_frac=bytes64 / ms_first / 1e6 / HBM,
+                                 first_call_bytes=bytes64, rowgroup_ms=ms_rg, rowgroup_frac=bytes64 / ms_rg / 1e6 / HBM))
         del a64, i64, p64, r
         torch.cuda.empty_cache()
 
