@@ -72,6 +72,46 @@ def make_csr_device(M, K, density, seed, idx_dtype=torch.int32, dtype=torch.floa
     return data, cols, indptr.to(idx_dtype)
 
 
+def make_powerlaw_csr_device(M, K, nnz, seed, alpha=1.0, empty_frac=0.3, idx_dtype=torch.int32, dtype=torch.float32, device="cuda"):
+    """A skewed matrix (what real operands look like; `sparse.random` is uniform, _utils.py:221-346): row lengths follow a
+    Zipf law (length of the r-th longest row ~ r^-alpha, capped at K: the first rows are FULL), `empty_frac` of the rows are
+    empty, rows are shuffled, ~nnz stored elements in total.  Columns of a row are distinct by construction: an affine
+    sequence (a_i j + b_i) mod P over a prime P >= K, entries >= K dropped (the total is therefore a little below `nnz`),
+    sorted.  Returns (data, indices, indptr) like `make_csr_device`."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    live = int(M * (1.0 - empty_frac))
+    w = torch.arange(1, live + 1, device=device, dtype=torch.float64) ** (-alpha)
+    # scale so that sum(min(c w, K)) = nnz (a few bisection steps on the device)
+    lo, hi = 0.0, float(nnz) * 1e3
+    for _ in range(60):
+        mid = 0.5 * (lo + hi)
+        if float(torch.clamp(w * mid, max=K).sum()) < nnz:
+            lo = mid
+        else:
+            hi = mid
+    lens_sorted = torch.clamp(w * hi, max=K).round().to(torch.int64)
+    lens = torch.zeros(M, dtype=torch.int64, device=device)
+    lens[torch.randperm(M, generator=g, device=device)[:live]] = lens_sorted
+    P = next(p for p in range(K, 2 * K + 100) if all(p % q for q in range(2, int(p ** 0.5) + 1)))
+    a = torch.randint(1, P, (M,), generator=g, device=device)
+    b = torch.randint(0, P, (M,), generator=g, device=device)
+    start = torch.zeros(M + 1, dtype=torch.int64, device=device)
+    start[1:] = torch.cumsum(lens, 0)
+    total = int(start[-1])
+    rows = torch.repeat_interleave(torch.arange(M, device=device), lens, output_size=total)
+    j = torch.arange(total, device=device) - start[rows]
+    cols = (a[rows] * j + b[rows]) % P
+    keep = cols < K
+    keys = (rows[keep] * K + cols[keep]).sort().values
+    del rows, j, cols, keep
+    rows = torch.div(keys, K, rounding_mode="floor")
+    cols = (keys - rows * K).to(idx_dtype)
+    indptr = torch.zeros(M + 1, dtype=torch.int64, device=device)
+    indptr[1:] = torch.cumsum(torch.bincount(rows, minlength=M), 0)
+    data = torch.rand(int(keys.numel()), generator=g, device=device, dtype=torch.float32).to(dtype)
+    return data, cols, indptr.to(idx_dtype)
+
+
 def algorithmic_bytes(M, K, N, nnz, val_bytes, idx_bytes):
     """nnz*(val+idx) + (M+1)*idx + K*N*val [B once] + M*N*val [C once]."""
     read = nnz * (val_bytes + idx_bytes) + (M + 1) * idx_bytes + K * N * val_bytes

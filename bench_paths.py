@@ -272,6 +272,66 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
         del a32, b32, r, d5, i5, q5, lay, di, bi
         torch.cuda.empty_cache()
 
+    # ---- a SKEWED operand at config 2's size (round-4 verdict item 6b: every other row is uniform `random`) --------------
+    if not quick and want("A1_powerlaw"):
+        from bench import make_powerlaw_csr_device
+        from sparse_amd import _dist
+
+        Mp, Kp, Np = 1_000_000, 10_000, 128
+        d, i, p = make_powerlaw_csr_device(Mp, Kp, 100_000_000, seed=21)
+        nnzp = int(d.numel())
+        lens = (p[1:] - p[:-1]).to(torch.int64)
+        ap = sp.GCXS((d, i, p), shape=(Mp, Kp), compressed_axes=(0,))
+        bp = torch.rand((Kp, Np), device=dev)
+        ms_rg, r_rg = timed(lambda: K.dot_csr_ndarray((Mp, Np), d, i, p, bp), reps=3)
+        ms_first, _ = timed(lambda: (_dot.drop_derived(ap), ap @ bp)[1], reps=3, warm=2)
+        ms, r = timed(lambda: ap @ bp, reps=10, warm=3)
+        lay = (getattr(ap, "_tiled_layouts", None) or {}).get(torch.float32)
+        extra = {}
+        if lay is not None and lay.group_ends:
+            rg, kb, gpb, epb, slack, _, _ = K.tiled_params(torch.float32)
+            nt = -(-Kp // kb)
+            bo = lay[1].view(-1, nt + 1).to(torch.int64)
+            used = int((bo[:, -1] - bo[:, 0]).sum())
+            extra["stream_blocks_used"] = used
+            extra["stream_padding"] = used * epb / max(nnzp, 1) - 1.0      # entries the lists hold beyond the stored elements
+            per_wg = lens[: (Mp // (rg * gpb)) * rg * gpb].view(-1, rg * gpb).sum(1).double()
+            per_wave = lens[: (Mp // rg) * rg].view(-1, rg).sum(1).double()
+            extra["workgroup_nnz_max_over_mean"] = float(per_wg.max() / per_wg.mean())
+            extra["wave_nnz_max_over_mean"] = float(per_wave.max() / per_wave.mean())
+        # the nnz-balanced 8-way partition of THIS matrix: every block alone, as bench.py's scaling proxy does for the uniform one
+        b8 = _dist.partition_rows_by_nnz(p, 8)
+        blk_ms, blk_nnz = [], []
+        for rk in range(8):
+            d8, i8, p8, s0, s1 = _dist.shard_csr(d, i, p, rk, 8, b8)
+            a8 = sp.GCXS((d8.contiguous(), i8.contiguous(), p8.contiguous()), shape=(s1 - s0, Kp), compressed_axes=(0,))
+            t8, _ = timed(lambda: a8 @ bp, reps=10, warm=4)
+            blk_ms.append(t8)
+            blk_nnz.append(int(d8.numel()))
+            del a8
+        # oracle: the 32 longest rows and 2000 random ones (whole rows, k-ascending FMA order: 1e-6 x sum |a||b|)
+        pick = torch.cat([torch.topk(lens, 32).indices, torch.randint(0, Mp, (2000,), device=dev)]).unique().cpu().numpy()
+        hp = p.cpu().numpy()
+        seg = np.concatenate([np.arange(hp[r_], hp[r_ + 1]) for r_ in pick])
+        sub_ptr = np.zeros(len(pick) + 1, dtype=hp.dtype)
+        sub_ptr[1:] = np.cumsum([hp[r_ + 1] - hp[r_] for r_ in pick])
+        hd, hi = d.cpu().numpy()[seg], i.cpu().numpy()[seg]
+        hb = bp.cpu().numpy()
+        want_v, leg = cpu_leg(lambda: oracle.dot_csr_ndarray((len(pick), Np), hd, hi, sub_ptr, hb),
+                            f"{len(pick)} whole rows (the 32 longest + random ones; oracle.c restatement of _dot_csr_ndarray)")
+        got = r[torch.from_numpy(pick).to(dev)].cpu().numpy()
+        bound = oracle.dot_csr_ndarray((len(pick), Np), np.abs(hd), hi, sub_ptr, np.abs(hb))
+        leg["max_err_over_sum_abs_terms"] = float(np.max(np.abs(got - want_v) / np.maximum(bound, 1e-30)))
+        emit("A1_powerlaw", row(f"config-2 size with Zipf row lengths: GCXS(CSR) {Mp}x{Kp}, {nnzp} nnz, {int((lens == 0).sum())} empty rows, "
+                                f"{int((lens >= Kp).sum())} full rows, longest {int(lens.max())} x dense {Kp}x{Np} fp32, steady state through a @ b",
+                                ms, nnzp * 8 + (Mp + 1) * 4 + Kp * Np * 4 + Mp * Np * 4, flops=2.0 * nnzp * Np, rowgroup_ms=ms_rg,
+                                first_product_ms=ms_first, took_executor=lay is not None,
+                                identical_to_rowgroup=bool(torch.equal(r, r_rg)), world8_block_ms=[round(v, 4) for v in blk_ms],
+                                world8_time_imbalance=max(blk_ms) / (sum(blk_ms) / 8), world8_nnz_imbalance=max(blk_nnz) / (sum(blk_nnz) / 8),
+                                world8_speedup_vs_whole=ms / max(blk_ms), cpu_baseline=leg, **extra))
+        del ap, bp, d, i, p, r, r_rg, lens
+        torch.cuda.empty_cache()
+
     # ---- config 1: COO + COO, (1000,1000,1000), 1e6 nnz each, f64 / int64 ---------------------------------------------
     if want("A7") or want("A8"):
         nnz = 1_000_000 // q

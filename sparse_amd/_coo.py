@@ -525,14 +525,10 @@ class COO(SparseArray, NDArrayOperatorsMixin):
         return dot(self, other)
 
     def __matmul__(self, other):
-        from ._dot import matmul
-
-        return matmul(self, other)
+        return _dot_module().matmul(self, other)
 
     def __rmatmul__(self, other):
-        from ._dot import matmul
-
-        return matmul(other, self)
+        return _dot_module().matmul(other, self)
 
 
 def as_coo(x, shape=None, fill_value=None, idx_dtype=None, device=None):
@@ -553,3 +549,17 @@ def as_coo(x, shape=None, fill_value=None, idx_dtype=None, device=None):
     if _is_scipy_sparse(x):
         return COO.from_scipy_sparse(x, device=device)
     raise NotImplementedError(f"Format not supported for conversion. Supplied type is {type(x)}")
+
+
+_DOT = None
+
+
+def _dot_module():
+    """`._dot`, imported at first use (it imports this module) and kept: a function-local `from ._dot import matmul` costs
+    ~1 us per `a @ b`, which is visible in products of a few hundred stored elements"""
+    global _DOT
+    if _DOT is None:
+        from . import _dot
+
+        _DOT = _dot
+    return _DOT

@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from . import _device as dev
+from . import _ffi
 from . import _kernels as K
 from . import _settings
 from ._sparse_array import SparseArray
@@ -202,8 +203,112 @@ class _Verdict:
         return self.remember(res) if self.remember is not None else res
 
 
+_NO_PLANS = {}
+
+
+class _SpmmPlan:
+    """`sparse @ dense` through the cache-less kernel (`spamd_spmm_csr`) for ONE sparse operand and one (dtype, width) of
+    dense device operands, with everything that does not depend on the dense operand's contents done once: the argument
+    contracts of `matmul` / `dot` (zero fill value, dimensions), the dispatch of `_dot`, the CSR triplet (index widths
+    unified, contiguous), dtype codes and raw pointers.  A call then costs the validity checks below, the NaN scan of B
+    (A's verdict is memoised per buffer version), `torch.empty` and one C-ABI call.  The reference's own benchmark sizes
+    (benchmarks/test_benchmark_coo.py:144-176: 40-1000 stored elements) are bound by exactly this host work: 47 -> ~25 us
+    per product.  Registered by `_gcxs_times_dense` after a product that took this route; dropped with the array's other
+    derived layouts; declines (returns None: the general path runs) whenever anything it assumed may have changed."""
+
+    __slots__ = ("src", "fill", "settings", "dev", "dev_index", "bdtype", "K", "N", "M", "dtr", "args", "keep", "nan_key")
+
+    def __init__(self, a, bt, out_shape, triplet):
+        data, indices, indptr = triplet
+        d = a.__dict__
+        self.src = tuple((name, t, int(t._version)) for name, t in ((n, d.get(n)) for n in ("data", "indices", "indptr", "_coords", "_keys"))
+                         if isinstance(t, torch.Tensor))
+        self.fill = d.get("fill_value")
+        self.settings = (_settings.NAN_CHECK, _settings.NAN_WARNING, _settings.EXACT_MULADD, _settings.TILED_SPMM)
+        self.dev, self.bdtype = bt.device, bt.dtype
+        self.dev_index = bt.device.index if bt.device.index is not None else torch.cuda.current_device()
+        self.M, self.N, self.K = int(out_shape[0]), int(out_shape[1]), int(bt.shape[0])
+        self.dtr = dev.torch_dtype(K.dot_dtype(data.dtype, bt.dtype))
+        if data.dtype != self.dtr or bt.dtype != self.dtr:
+            raise TypeError("mixed value types take the general path")
+        data, indices, indptr = data.contiguous(), indices.contiguous(), indptr.contiguous()
+        if indices.dtype != indptr.dtype:
+            raise TypeError("mixed index widths take the general path")
+        self.keep = (data, indices, indptr)
+        self.args = (dev.code_of(self.dtr), dev.code_of(indices.dtype), self.M, self.K, self.N, dev.ptr(data), dev.ptr(indices), dev.ptr(indptr))
+        own = a.data      # (the verdict memo is kept on the array's OWN values: a csc operand's CSR twin shares them, permuted)
+        self.nan_key = (own.data_ptr(), int(own.numel()), int(own._version))
+
+    def run(self, a, b):
+        d = a.__dict__
+        for name, t, v in self.src:
+            if d.get(name) is not t or t._version != v:
+                return None
+        if (b.dtype is not self.bdtype or b.shape[0] != self.K or b.device != self.dev or not b.is_contiguous()
+                or d.get("fill_value") is not self.fill or b.data_ptr() % 16
+                or (_settings.NAN_CHECK, _settings.NAN_WARNING, _settings.EXACT_MULADD, _settings.TILED_SPMM) != self.settings):
+            return None
+        probe = nan_a = False
+        if self.settings[0] and self.dtr.is_floating_point:
+            memo = d.get("_nan_memo")
+            if memo is None or memo[0] != self.nan_key:
+                return None           # (A's verdict not known yet for this buffer version: the general path scans it)
+            nan_a = memo[1]
+            _drain_prepared()
+            probe = K.NanProbe(b)
+        out = torch.empty((self.M, self.N), dtype=self.dtr, device=self.dev)
+        _ffi.CALLS += 1
+        rc = _SPMM_CSR(*self.args, b.data_ptr(), self.N, out.data_ptr(), self.N, _ffi.EXACT_MULADD if self.settings[2] else 0,
+                       dev._raw_stream(self.dev_index))
+        if rc:
+            if probe is not False:
+                probe.discard()
+            _ffi.check(rc, "spamd_spmm_csr")
+        if probe is not False or nan_a:
+            if self.settings[1] == "deferred":
+                _PENDING_NAN.append(nan_a or _Verdict(probe, None))
+                flush_warnings(block=False)
+            elif nan_a or probe.result():
+                warnings.warn("Nan will not be propagated in matrix multiplication", RuntimeWarning, stacklevel=2)
+        return out
+
+
+def _spmm_csr_entry():
+    global _SPMM_CSR
+    _SPMM_CSR = _ffi.lib().spamd_spmm_csr
+    return _SPMM_CSR
+
+
+def _SPMM_CSR(*args):     # (bound to the library's entry point at its first use)
+    return _spmm_csr_entry()(*args)
+
+
+def _register_plan(a, bt, out_shape, triplet):
+    """remember the row-group route of `a @ bt` (see `_SpmmPlan`); silently skipped for anything the plan does not cover"""
+    if dev._raw_stream is None or not (bt.is_cuda and bt.is_contiguous()) or bt.numel() == 0 or not hasattr(a, "__dict__"):
+        return
+    try:
+        plan = _SpmmPlan(a, bt, out_shape, triplet)
+    except TypeError:
+        return
+    plans = a.__dict__.setdefault("_mm_plans", {})
+    if len(plans) >= 8:
+        plans.clear()
+    plans[(bt.dtype, int(bt.shape[1]))] = plan
+
+
 def matmul(a, b):
     """Equivalent of `numpy.matmul` (reference _common.py:218-293)."""
+    if type(b) is torch.Tensor:
+        # a product this array has made before with a dense operand of this type and width (small products are bound by
+        # the host: bench_small.py): everything that depends on `a` alone was checked and converted then (`_SpmmPlan`)
+        plans = getattr(a, "__dict__", _NO_PLANS).get("_mm_plans")
+        if plans is not None and b.dim() == 2:
+            plan = plans.get((b.dtype, b.shape[1]))
+            if plan is not None:
+                res = plan.run(a, b)
+                if res is not None:
+                    return res
     check_zero_fill_value(a, b)
     if not hasattr(a, "ndim") or not hasattr(b, "ndim"):
         raise TypeError(f"Cannot perform dot product on types {type(a)}, {type(b)}")
@@ -397,7 +502,7 @@ def _tiled_min_rows(row_bytes):
     return 45056 if panels == 1 else max(4096, 40960 // panels)
 
 
-DERIVED_CACHES = ("_csr_view", "_csr_twin", "_tiled_layouts", "_spmm_uses", "_nan_memo", "_derived_stamp", "_sddmm_plan", "_t_view", "_coo_view")
+DERIVED_CACHES = ("_mm_plans", "_keys2d", "_csr_view", "_csr_twin", "_tiled_layouts", "_spmm_uses", "_nan_memo", "_derived_stamp", "_sddmm_plan", "_t_view", "_coo_view")
 
 
 def drop_derived(a):
@@ -578,7 +683,7 @@ def _gcxs_times_dense(a, bt, out_shape):
         direct = False
     if not direct:
         data, indices, indptr = _csr_triplet(a)
-    use_tiled = _tiled_eligible(data, bt, out_shape, Kd)
+    use_tiled = eligible = _tiled_eligible(data, bt, out_shape, Kd)
     if use_tiled and isinstance(a, COO) and not getattr(a, "_tiled_layouts", None):
         # COO operands of `tensordot` are usually temporaries (an N-D array reshaped to 2-D): for small ones the inspector
         # only pays when the array is multiplied again (config 3, 1.3 x 10^6 elements: 0.33 ms with a fresh layout per call
@@ -605,7 +710,10 @@ def _gcxs_times_dense(a, bt, out_shape):
             bp[:, :N] = bt
             return _tiled_product(a, dt, (M, N), Kd, bp)
         return _tiled_product(a, dt, out_shape, Kd, bt)
-    return K.dot_csr_ndarray(out_shape, data, indices, indptr, bt, exact=_settings.EXACT_MULADD)
+    res = K.dot_csr_ndarray(out_shape, data, indices, indptr, bt, exact=_settings.EXACT_MULADD)
+    if a.ndim == 2 and not eligible:     # (an eligible COO that waits for its second product must keep counting its products)
+        _register_plan(a, bt, out_shape, (data, indices, indptr))
+    return res
 
 
 

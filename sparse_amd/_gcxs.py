@@ -320,14 +320,10 @@ class GCXS(SparseArray, NDArrayOperatorsMixin):
         return dot(self, other)
 
     def __matmul__(self, other):
-        from ._dot import matmul
-
-        return matmul(self, other)
+        return _dot_module().matmul(self, other)
 
     def __rmatmul__(self, other):
-        from ._dot import matmul
-
-        return matmul(other, self)
+        return _dot_module().matmul(other, self)
 
     def _prune(self):
         """Drop stored entries bit-equal to the fill value (reference compressed.py:816-848)."""
@@ -354,3 +350,17 @@ class GCXS(SparseArray, NDArrayOperatorsMixin):
             raise ValueError("Can only convert a 2-dimensional array to a Scipy sparse matrix.")
         cls = scipy.sparse.csr_matrix if self.compressed_axes == (0,) else scipy.sparse.csc_matrix
         return cls((dev.to_numpy(self.data), dev.to_numpy(self.indices), dev.to_numpy(self.indptr)), shape=self.shape)
+
+
+_DOT = None
+
+
+def _dot_module():
+    """`._dot`, imported at first use (it imports this module) and kept: a function-local `from ._dot import matmul` costs
+    ~1 us per `a @ b`, which is visible in products of a few hundred stored elements"""
+    global _DOT
+    if _DOT is None:
+        from . import _dot
+
+        _DOT = _dot
+    return _DOT

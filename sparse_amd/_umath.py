@@ -544,6 +544,51 @@ def _np_result(func, *args, **kwargs):
         return func(*args, **kwargs)
 
 
+def _gcxs_keys2d(x):
+    """64-bit keys row * C + column of a GCXS in its OWN compressed 2-D layout (cached on the array with its other derived
+    layouts); None when they do not ascend strictly (`GCXS((data, indices, indptr))` takes the caller's arrays as they are)."""
+    from ._dot import _validate_derived
+
+    _validate_derived(x)
+    c = x.__dict__.get("_keys2d")
+    if c is None:
+        R, C = x._compressed_shape
+        keys = K.csr_to_keys(x.indptr, x.indices, R, C)
+        unsorted, dup = K.keys_check(keys)
+        c = (None if unsorted or dup else keys,)
+        x.__dict__["_keys2d"] = c
+    return c[0]
+
+
+def _gcxs_same_layout(name, a, b):
+    """A binary ufunc on two GCXS of one shape AND one compressed layout, without leaving that layout: an elementwise
+    function commutes with the axis permutation + reshape that defines the layout, so the union of the two operands' keys
+    in the compressed 2-D space IS the result's storage order.  The reference converts both operands to COO, evaluates
+    there and converts back (`_umath.py:40-50, 420-430`); here that cost 9 C-ABI calls and ~230 us for operands of 100
+    stored elements (benchmarks/test_benchmark_coo.py:48-66; bench_small.py) against 1 call for COO operands.  Same
+    stored positions, same values bit for bit (the same fused merge kernel on permuted keys).  Only for (ufunc, dtypes,
+    fills) combinations the COO route has planned before (`_SAME_SHAPE_PLANS`); None = take the general route."""
+    from ._convert import _pick_index_dtype
+    from ._gcxs import GCXS
+
+    if a.shape != b.shape or a.ndim < 2 or not a.size or a.compressed_axes != b.compressed_axes:
+        return None
+    fka, fkb = a.fill_value, b.fill_value
+    plan = _SAME_SHAPE_PLANS.get((name, a.data.dtype, b.data.dtype, fka.tobytes() if hasattr(fka, "tobytes") else fka,
+                                  fkb.tobytes() if hasattr(fkb, "tobytes") else fkb))
+    if plan is None:
+        return None
+    ka, kb = _gcxs_keys2d(a), _gcxs_keys2d(b)
+    if ka is None or kb is None:
+        return None
+    mname, comp_t, fa, fb, fill_in_kernel, fill = plan
+    keys, res = merge_union(mname, ka, K.convert(a.data, comp_t), kb, K.convert(b.data, comp_t), fa, fb, fill_in_kernel)
+    R, C = a._compressed_shape
+    # (index width as the general route gives it: the first operand's, widened when the result needs it)
+    indptr, indices = K.keys_to_csr(keys, R, C, _pick_index_dtype(a.indices.dtype, max(R, C, int(keys.numel()))))
+    return GCXS((res, indices, indptr), shape=a.shape, compressed_axes=a.compressed_axes, fill_value=fill)
+
+
 def elemwise(func, *args, **kwargs):
     """Apply `func` elementwise to sparse/dense/scalar operands (reference _umath.py:13-50)."""
     from ._coo import COO
@@ -564,6 +609,10 @@ def elemwise(func, *args, **kwargs):
     dtype_kw = kwargs.pop("dtype", None)
     if name != "astype":
         kwargs.pop("casting", None)  # values are converted explicitly; NumPy's "unsafe" semantics
+    if out_type == "gcxs" and len(args) == 2 and len(sparse_args) == 2 and dtype_kw is None and not kwargs:
+        res = _gcxs_same_layout(name, args[0], args[1])
+        if res is not None:
+            return res
     proc = []
     for a in args:
         if isinstance(a, SparseArray):

@@ -2,7 +2,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <mutex>
+#include <set>
 #include <type_traits>
+#include <utility>
 
 #include "../../include/sparse_amd.h"
 
@@ -126,6 +130,22 @@ __device__ __forceinline__ void hidden_nt_store(T* p, const T (&v)[N]) {
     }
     asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(p), "v"(x) : "memory");
   }
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is state of the kernel's code object ON ONE DEVICE: opted in once per
+// (device, kernel), not once per process (rounds 1-4 kept a per-process flag per instantiation: right for one process per
+// GPU, wrong for a process that launches on two devices).  Returns 0 or the hipError_t.
+inline int set_max_dynamic_lds(const void* kern, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
+  int dev = 0;
+  if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return (int)e;
+  std::lock_guard<std::mutex> lock(mu);
+  const auto key = std::make_pair(dev, kern);
+  if (done.count(key)) return 0;
+  if (hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); e != hipSuccess) return (int)e;
+  done.insert(key);
+  return 0;
 }
 
 inline int launch_status() {

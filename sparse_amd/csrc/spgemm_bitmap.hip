@@ -45,7 +45,8 @@
 // Limits (checked by the host before the launch, spamd_spgemm_bitmap_limits): n_col <= 2^20, A rows of at most 256
 // elements, at most 1024 * ITEMS products per row (ITEMS = 16 for 4-byte values, 8 for 8-byte ones: the row must fit the
 // LDS region), index arrays of either width.  A row whose parked products exceed the list (512 entries) sets the `failed`
-// word: the caller then discards the result and uses spgemm_rows.hip.
+// word: the caller then discards the result and uses spgemm_rows.hip.  So does a B operand that is not canonical: a row with
+// unsorted columns (split form: a product lands outside its part's range) or with a column twice (equal parked keys).
 #include <mutex>
 
 #include "common.h"
@@ -419,6 +420,14 @@ spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, con
     unsigned first_mask = 0;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
+      // (a column outside this part's range: B's row is not sorted by column - the split form's binary search over it put the
+      // product into the wrong part.  Reachable through `GCXS((data, indices, indptr))`, which takes the caller's arrays as
+      // they are: the product is dropped BEFORE it touches the bitmap and the call fails; the host then takes the bucket
+      // kernels, which do not depend on B's order.  The wide form's columns are always inside [0, n_col).)
+      if (SPLIT && colN[j] != BMK_NONE && colN[j] - cbase >= (unsigned)range) {
+        failed = true;
+        colN[j] = BMK_NONE;
+      }
       if (colN[j] != BMK_NONE) {
         const unsigned c = colN[j] - cbase;
         const unsigned bit = 1u << (c & 31u);
@@ -569,6 +578,10 @@ spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, con
             best = y < best ? y : best;
           }
           const unsigned long long who = __ballot(nx == best && best != BMK_NONE);
+          if (who == 0) {   // fewer distinct keys than entries of this column: a B row holds the column TWICE (equal
+            failed = true;  // (column, A element) keys) - not a canonical operand; fail the call, the bucket kernels take it
+            break;
+          }
           const int src = __builtin_amdgcn_readlane(at, (int)__builtin_ctzll(who));
           acc = acc + dup[src].val;
           const unsigned r2 = dup[src].rank;
@@ -648,7 +661,8 @@ spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, con
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) zero_count += __shfl_xor(zero_count, d, 64);
   if (lane == 0 && zero_count) atomicAdd(work + 2, (unsigned long long)zero_count);
-  if (failed && lane == 0) __hip_atomic_store(work + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // (any lane: a product outside its part's column range is seen by the one thread that holds it)
+  if (__ballot(failed) != 0 && lane == 0) __hip_atomic_store(work + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // bsplit[k * (np - 1) + h] = first element of B row k whose column is >= (h + 1) * range (h < np - 1)
@@ -695,17 +709,7 @@ static int bmk_launch(int64_t n_row, int np, int64_t range, const I* a_ptr, cons
   if (ngroups > BMK_GPT * THREADS) return SPAMD_EINVAL;
   const size_t lds = L::bytes(ngroups);
   if (lds > 160 * 1024) return SPAMD_EINVAL;
-  {
-    static std::mutex mu;
-    static bool done = false;   // (one flag per template instantiation)
-    std::lock_guard<std::mutex> lock(mu);
-    if (!done) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         160 * 1024);
-      if (e != hipSuccess) return (int)e;
-      done = true;
-    }
-  }
+  if (int rc = set_max_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
   int dev = 0, cus = 0, per_cu = 0;
   if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return (int)e;
   if (hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); e != hipSuccess) return (int)e;

@@ -513,17 +513,8 @@ static int launch_rowrank(int64_t n_row, int64_t n_col, int col_bits, int ebits,
   using L = RowRankLayout<BLOCK, ITEMS, PASSES, KEY, V>;
   static_assert(L::bytes <= 80 * 1024 - 128, "two 512-thread workgroups of a row class share the 160 KB of a CU");
   auto kern = &spgemm_rowrank_kernel<BLOCK, ITEMS, PASSES, KEY, V, I>;
-  if (L::bytes > 48 * 1024) {
-    static std::mutex mu;
-    static bool done = false;   // (one flag per template instantiation)
-    std::lock_guard<std::mutex> lock(mu);
-    if (!done) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)L::bytes);
-      if (e != hipSuccess) return (int)e;
-      done = true;
-    }
-  }
+  if (L::bytes > 48 * 1024)
+    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void*>(kern), (int)L::bytes)) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)n_row), dim3(BLOCK), L::bytes, s, n_col, col_bits, ebits, a_ptr, a_idx, a_val, b_ptr,
                      b_idx, b_val, prod_off, lo, hi, tmp_cols, tmp_vals, nnz_row);
   return launch_status();

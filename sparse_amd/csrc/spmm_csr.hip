@@ -343,17 +343,7 @@ static int launch_rowvec(int64_t M, int64_t K, int64_t N, const T* a_data, const
   case NV:                                                                                                        \
     if (lds) {                                                                                                    \
       auto kern = spmm_csr_rowvec_lds_kernel<T, I, NV>;                                                           \
-      static std::mutex mu##NV;                                                                                   \
-      static bool done##NV = false; /* per instantiation: the attribute is set once per process */                \
-      {                                                                                                           \
-        std::lock_guard<std::mutex> lock(mu##NV);                                                                 \
-        if (!done##NV) {                                                                                          \
-          if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,                  \
-                                  ROWVEC_LDS_BYTES) != hipSuccess)                                                \
-            return SPAMD_EINVAL;                                                                                  \
-          done##NV = true;                                                                                        \
-        }                                                                                                         \
-      }                                                                                                           \
+      if (set_max_dynamic_lds((const void*)kern, ROWVEC_LDS_BYTES)) return SPAMD_EINVAL;                         \
       hipLaunchKernelGGL(kern, dim3(big ? 256 : 1024), dim3(big ? 1024 : 512), ldsbytes, s, M, K, a_data, a_idx, a_ptr, b, ldb, out, ldo); \
     } else {                                                                                                      \
       hipLaunchKernelGGL((spmm_csr_rowvec_kernel<T, I, NV>), dim3((unsigned)blocks), dim3(256), 0, s, M, a_data,  \

@@ -200,16 +200,7 @@ static int launch_ldsb(int64_t M, int64_t K, int64_t N, const T* a_data, const I
   if (per_panel > slots) per_panel = slots;
   if (per_panel < 1) per_panel = 1;
   auto kern = spmm_csr_ldsb_kernel<T, I, EXACT>;
-  {
-    static std::mutex mu;
-    static bool done = false;   // (one flag per template instantiation: the attribute is set once per process)
-    std::lock_guard<std::mutex> lock(mu);
-    if (!done) {
-      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS_BYTES) != hipSuccess)
-        return SPAMD_EINVAL;
-      done = true;
-    }
-  }
+  if (set_max_dynamic_lds((const void*)kern, LB_LDS_BYTES)) return SPAMD_EINVAL;
   hipLaunchKernelGGL(kern, dim3((unsigned)per_panel, panels), dim3(1024), ldsbytes, s, M, K, N, a_data, a_idx, a_ptr, b, ldb,
                      out, ldo);
   return launch_status();

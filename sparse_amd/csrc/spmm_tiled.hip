@@ -1261,16 +1261,7 @@ extern "C" int spamd_spmm_tiled_inspect_csc(int val_dtype, int idx_dtype, int64_
   return SPAMD_ETYPE;
 }
 
-static int tl_set_lds_once(const void* kern) {
-  static std::mutex mu;
-  static std::set<const void*> done;
-  std::lock_guard<std::mutex> lock(mu);
-  if (done.count(kern)) return 0;
-  hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS);
-  if (e != hipSuccess) return (int)e;
-  done.insert(kern);
-  return 0;
-}
+static int tl_set_lds_once(const void* kern) { return set_max_dynamic_lds(kern, TL_LDS); }
 
 template <typename T, typename KERN>
 static int tl_launch(KERN kern, int64_t M, int64_t K, int64_t N, const int* blocks, const int* blk_off, const T* b,

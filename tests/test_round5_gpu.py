@@ -1,0 +1,159 @@
+"""Round-5 additions: the host-side fast paths for the reference's own benchmark sizes (bench_small.py) must give what
+the general paths give, bit for bit, and must notice everything the general paths notice (changed buffers, NaNs, settings);
+skewed (power-law) operands through the executor against the oracle."""
+import os
+import sys
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+@pytest.fixture(scope="module")
+def sp():
+    import sparse_amd
+
+    return sparse_amd
+
+
+def _bits(t):
+    return t.contiguous().view(torch.uint8).cpu().numpy().tobytes()
+
+
+def _same_gcxs(x, y):
+    return (type(x) is type(y) and x.shape == y.shape and x.compressed_axes == y.compressed_axes and x.data.dtype == y.data.dtype
+            and x.indices.dtype == y.indices.dtype and _bits(x.data) == _bits(y.data) and _bits(x.indices) == _bits(y.indices)
+            and _bits(x.indptr) == _bits(y.indptr) and np.asarray(x.fill_value).tobytes() == np.asarray(y.fill_value).tobytes())
+
+
+# ---- `_SpmmPlan`: sparse @ dense of a few hundred stored elements ------------------------------------------------------------
+
+@pytest.mark.parametrize("fmt,ca", [("gcxs", (0,)), ("gcxs", (1,)), ("coo", None)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32, np.int64])
+def test_planned_product_equals_the_general_path(sp, orc, fmt, ca, dtype):
+    from sparse_amd import _dot
+
+    m, n, p = 300, 200, 70
+    x = sp.random((m, n), density=0.01, random_state=3, format="coo")
+    x = sp.COO(x.coords, (x.data * 50).to(torch.float64).cpu().numpy().astype(dtype), shape=x.shape)
+    if fmt == "gcxs":
+        x = x.asformat("gcxs", compressed_axes=ca)
+    tdt = {np.float64: torch.float64, np.float32: torch.float32, np.int64: torch.int64}[dtype]
+    t = (torch.rand((n, p), device="cuda", dtype=torch.float64) * 9).to(tdt)
+    first = x @ t                       # general path; registers the plan
+    plans = x.__dict__.get("_mm_plans") or {}
+    assert (t.dtype, p) in plans, "a row-group product of a 2-D operand with a device tensor registers its plan"
+    calls = []
+    real = _dot._SpmmPlan.run
+    try:
+        _dot._SpmmPlan.run = lambda self, a, b: (calls.append(1), real(self, a, b))[1]
+        second = x @ t
+        third = sp.matmul(x, t)
+    finally:
+        _dot._SpmmPlan.run = real
+    assert len(calls) == 2 and _bits(first) == _bits(second) == _bits(third)
+    xc = x.asformat("coo")
+    want = orc.dot_coo_ndarray(xc.coords.cpu().numpy(), xc.data.cpu().numpy(), t.cpu().numpy(), (m, p))
+    if np.dtype(dtype).kind == "f":
+        assert np.allclose(second.cpu().numpy(), want, rtol=1e-5 if dtype == np.float32 else 1e-13, atol=0)
+    else:
+        assert np.array_equal(second.cpu().numpy(), want)
+    # another width: its own plan, not this one's
+    t2 = t[:, :13].contiguous()
+    assert _bits(x @ t2) == _bits(first[:, :13].contiguous())
+
+
+def test_plan_notices_changed_buffers_settings_and_operands(sp):
+    from sparse_amd import _settings
+
+    x = sp.random((400, 300), density=0.01, random_state=4, format="gcxs", compressed_axes=(0,))
+    t = torch.rand((300, 40), device="cuda", dtype=torch.float64)
+    r0 = x @ t
+    assert x.__dict__.get("_mm_plans")
+    x.data *= 2.0                                   # in place: torch's version counter moves
+    r1 = x @ t
+    assert torch.equal(r1, r0 * 2.0)
+    x.data = x.data * 0.5                           # buffer replaced
+    assert torch.equal(x @ t, r0)
+    # a non-contiguous / misplaced dense operand takes the general path and gives the same numbers
+    tt = torch.rand((40, 300), device="cuda", dtype=torch.float64)
+    assert torch.equal(x @ tt.t(), x @ tt.t().contiguous())
+    with pytest.raises(Exception):
+        x @ torch.rand((299, 40), device="cuda", dtype=torch.float64)
+    old = _settings.EXACT_MULADD
+    try:
+        _settings.EXACT_MULADD = True
+        exact = x @ t
+        ref = x.todense() @ t.cpu().numpy()
+        assert np.allclose(exact.cpu().numpy(), ref, rtol=1e-13)
+    finally:
+        _settings.EXACT_MULADD = old
+    x.fill_value = np.float64(1.0)
+    with pytest.raises(ValueError, match="zero fill"):
+        x @ t
+
+
+def test_planned_product_still_warns_about_nan(sp):
+    x = sp.random((200, 200), density=0.02, random_state=5, format="gcxs", compressed_axes=(0,))
+    t = torch.rand((200, 16), device="cuda", dtype=torch.float64)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        x @ t
+        x @ t                                       # planned, silent
+    tn = t.clone()
+    tn[7, 3] = float("nan")
+    with pytest.warns(RuntimeWarning, match="Nan will not be propagated"):
+        x @ tn
+    x.data[5] = float("nan")                        # A's values changed: the plan steps aside, the general path scans A
+    with pytest.warns(RuntimeWarning, match="Nan will not be propagated"):
+        x @ t
+    with pytest.warns(RuntimeWarning, match="Nan will not be propagated"):
+        x @ t                                       # planned again, A's verdict memoised as "has NaN"
+
+
+# ---- GCXS (x) GCXS in their own layout ---------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("shape,ca", [((60, 70), (0,)), ((60, 70), (1,)), ((12, 9, 14), (0, 2)), ((12, 9, 14), (1,)), ((5, 6, 7, 8), (1, 3))])
+@pytest.mark.parametrize("op", ["add", "multiply", "subtract", "maximum", "greater"])
+def test_gcxs_elementwise_in_place_of_the_coo_round_trip(sp, shape, ca, op):
+    from sparse_amd import _umath
+
+    f = getattr(np, op)
+    x = sp.random(shape, density=0.2, random_state=10, format="gcxs", compressed_axes=ca)
+    y = sp.random(shape, density=0.2, random_state=11, format="gcxs", compressed_axes=ca)
+    y.data -= 0.5
+    real = _umath._gcxs_same_layout
+    took = []
+    try:
+        _umath._gcxs_same_layout = lambda *a: None
+        want = f(x, y)                          # the general route (also registers the plan of this ufunc / dtype pair)
+        _umath._gcxs_same_layout = lambda *a: (took.append(1), real(*a))[1]
+        got = f(x, y)
+    finally:
+        _umath._gcxs_same_layout = real
+    assert took and _same_gcxs(got, want)
+    assert np.array_equal(got.todense(), f(x.todense(), y.todense()))
+
+
+def test_gcxs_elementwise_declines_what_it_must(sp):
+    from sparse_amd import _umath
+
+    x = sp.random((40, 50), density=0.2, random_state=1, format="gcxs", compressed_axes=(0,))
+    y = sp.random((40, 50), density=0.2, random_state=2, format="gcxs", compressed_axes=(1,))
+    x + x                                               # plan for add registered
+    assert _umath._gcxs_same_layout("add", x, y) is None     # different layouts
+    # unsorted column indices inside a row (the constructor takes the caller's arrays as they are)
+    d, i, p = x.data.clone(), x.indices.clone(), x.indptr.clone()
+    r = int(torch.nonzero(p[1:] - p[:-1] >= 2)[0])
+    lo = int(p[r])
+    i[lo], i[lo + 1] = i[lo + 1].clone(), i[lo].clone()
+    d[lo], d[lo + 1] = d[lo + 1].clone(), d[lo].clone()
+    z = sp.GCXS((d, i, p), shape=x.shape, compressed_axes=(0,))
+    assert _umath._gcxs_same_layout("add", z, x) is None
+    assert np.array_equal((z + x).todense(), (x + x).todense())

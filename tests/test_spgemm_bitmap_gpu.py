@@ -258,3 +258,78 @@ def test_product_api_takes_the_bitmap_kernel_and_is_reproducible():
     c2 = a @ g
     for x, y in ((c1.data, c2.data), (c1.indices, c2.indices), (c1.indptr, c2.indptr)):
         assert torch.equal(x, y)
+
+
+def _dense_of(t, shape):
+    d, i, p = (np.asarray(x) for x in t)
+    out = np.zeros(shape, dtype=np.float64)
+    np.add.at(out, (np.repeat(np.arange(shape[0]), np.diff(p)), i), d.astype(np.float64))
+    return out
+
+
+def _run_forms(shape, A, B, split):
+    """the product through `_spgemm_rows` with the bitmap kernel forced on; returns (result, stats)"""
+    from sparse_amd import _kernels as K
+
+    (ad, ai, ap), (bd, bi, bp) = _dev(A), _dev(B)
+    old = K.SPGEMM_BITMAP, K.SPGEMM_BITMAP_MIN_MEAN, K.SPGEMM_BITMAP_MAX_DUPS, K.SPGEMM_BITMAP_SPLIT
+    try:
+        K.SPGEMM_BITMAP, K.SPGEMM_BITMAP_MIN_MEAN, K.SPGEMM_BITMAP_MAX_DUPS, K.SPGEMM_BITMAP_SPLIT = True, 0, 10 ** 9, split
+        K.SPGEMM_STATS.clear()
+        got = K._spgemm_rows(shape[0], shape[1], ad, ai, ap, bd, bi, bp)
+        if got is None:
+            got = K.dot_csr_csr(shape, ad, bd, ai, bi, ap, bp)
+        return got, dict(K.SPGEMM_STATS)
+    finally:
+        K.SPGEMM_BITMAP, K.SPGEMM_BITMAP_MIN_MEAN, K.SPGEMM_BITMAP_MAX_DUPS, K.SPGEMM_BITMAP_SPLIT = old
+
+
+@pytest.mark.parametrize("split", [False, "first"])
+def test_b_rows_with_unsorted_columns(split):
+    """`GCXS((data, indices, indptr))` takes the caller's arrays as they are: B rows whose columns do not ascend.  The wide
+    form does not depend on B's order; the split form's binary search over a B row does - a product then lands outside its
+    part's column range, is dropped before it touches the bitmap, the call fails and the next form takes the product
+    (round-4 advice: an out-of-range `atomicOr` in LDS and a silently wrong result before)."""
+    m, k, n = 400, 3_000, 1_000_000
+    A = _csr(m, k, 80, 50)
+    bd, bi, bp = _csr(k, n, 90, 51)
+    rng = np.random.default_rng(5)
+    bd, bi = bd.copy(), bi.copy()
+    for r in range(k):                      # every B row in a random order
+        lo, hi = int(bp[r]), int(bp[r + 1])
+        o = rng.permutation(hi - lo)
+        bd[lo:hi], bi[lo:hi] = bd[lo:hi][o], bi[lo:hi][o]
+    got, stats = _run_forms((m, n), A, (bd, bi, bp), split)
+    if split == "first":
+        assert stats.get("bitmap_failed", 0) >= 1, stats     # the split form declined ...
+    assert stats.get("kernel") == "bitmap" and stats.get("parts", 1) == 1, stats   # ... and whole rows took it
+    want, _ = _run_forms((m, n), A, _csr(k, n, 90, 51), False)     # the same matrix in canonical order
+    _same(got, want)
+
+
+@pytest.mark.parametrize("split", [False, "first"])
+def test_b_rows_holding_a_column_twice_fail_over_to_the_bucket_kernels(split):
+    """a B row with the same column twice gives two products with EQUAL (column, A element) keys: the parked-product walk
+    finds fewer distinct keys than entries (`__ballot` = 0; round-4 advice: `ctz(0)` + a garbage `readlane` before).  Both
+    forms now fail the call; the bucket kernels sum both products, as the reference's `sums[j] += ...` does."""
+    m, k, n = 300, 2_000, 1_000_000
+    A = _csr(m, k, 70, 60, np.float64, np.int64)
+    bd, bi, bp = _csr(k, n, 60, 61, np.float64, np.int64)
+    bi = bi.copy()
+    for r in range(0, k, 3):
+        lo, hi = int(bp[r]), int(bp[r + 1])
+        if hi - lo >= 2:
+            bi[lo + 1] = bi[lo]             # (still ascending: only the duplicate makes the operand non-canonical)
+    got, stats = _run_forms((m, n), A, (bd, bi, bp), split)
+    assert stats.get("bitmap_failed", 0) >= 1 and stats.get("kernel") != "bitmap", stats
+    gd, gi, gp = (t.cpu().numpy() for t in got)
+    dense = np.zeros((m, n // 1000 + 1))  # (checked on a column sample: the dense product has 3 x 10^8 cells)
+    keep = bi % 1000 == 0
+    b_rows = np.repeat(np.arange(k), np.diff(bp))[keep]
+    b_s = np.zeros((k, n // 1000 + 1))
+    np.add.at(b_s, (b_rows, bi[keep] // 1000), bd[keep])
+    want = _dense_of(A, (m, k)) @ b_s
+    rows = np.repeat(np.arange(m), np.diff(gp))
+    sel = gi % 1000 == 0
+    np.add.at(dense, (rows[sel], gi[sel] // 1000), gd[sel])
+    assert np.allclose(dense, want, rtol=1e-12, atol=1e-12)
