@@ -235,7 +235,10 @@ def rccl_world1_gather_ms(K, N):
         env.pop(k, None)
     try:
         r = subprocess.run([sys.executable, "-c", RCCL_PROBE, str(K), str(N)], env=env, capture_output=True, text=True, timeout=120)
-        return json.loads(r.stdout.strip().splitlines()[-1])
+        lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+        if not lines:
+            return {"error": f"rc {r.returncode}: " + (r.stderr.strip().splitlines() or ["no output"])[-1][:300]}
+        return json.loads(lines[-1])
     except Exception as e:  # noqa: BLE001
         return {"error": repr(e)[:200]}
 

@@ -459,9 +459,16 @@ int spamd_sddmm(int in_dtype, int s_dtype, int idx_dtype, int64_t nnz, const voi
 int spamd_sddmm_has_panels(int in_dtype, int64_t K); /* 1: spamd_sddmm_panels has a kernel for this K */
 int spamd_sddmm_panel_keys(int idx_dtype, int64_t nnz, const void* cols, int64_t width, int64_t per_xcd, void* keys,
                            void* stream);
+/* Rows of exactly 1 KB (fp32 K = 256, fp64 K = 128, bf16 K = 512): with `part` (nnz words of the accumulator type - fp32, or
+ * fp64 for F64 operands - of caller-owned scratch) the product runs as TWO passes over 512-byte half-rows (the first leaves its
+ * sums in `part` in panel order, the second adds its half and writes s * sum), so that a panel holds twice the Bt rows in the
+ * same L2 bytes and A is streamed half as often (config 4 fp32: 6.4 GB -> ~2.5 GB of fabric traffic); the panels are then
+ * built for the row length spamd_sddmm_panel_row_bytes() reports (512).  part = NULL, or any other row length: one pass. */
+int64_t spamd_sddmm_panel_row_bytes(int in_dtype, int64_t K); /* bytes of a Bt row the panel width is computed for */
 int spamd_sddmm_panels(int in_dtype, int s_dtype, int idx_dtype, int64_t nnz, const void* rows_p, const void* cols_p,
                        const int64_t* perm, const void* s_p, const void* A, int64_t lda, const void* Bt, int64_t ldb,
-                       int64_t K, int64_t chunk, const int64_t* xcd_first, int64_t xcd_max, void* out, void* stream);
+                       int64_t K, int64_t chunk, const int64_t* xcd_first, int64_t xcd_max, void* part, void* out,
+                       void* stream);
 
 /* A9, dense-tile form (north_star: "MFMA used only on the dense tile of SDDMM"): the 32 x 32 tiles of the mask that
  * hold at least `threshold` samples are computed as one 32 x 32 x K bf16 product on the matrix cores

@@ -92,7 +92,8 @@ SIGNATURES = {
     "spamd_sddmm": (_int, [_int, _int, _int, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp]),
     "spamd_sddmm_has_panels": (_int, [_int, _i64]),
     "spamd_sddmm_panel_keys": (_int, [_int, _i64, _vp, _i64, _i64, _vp, _vp]),
-    "spamd_sddmm_panels": (_int, [_int, _int, _int, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),
+    "spamd_sddmm_panel_row_bytes": (_i64, [_int, _i64]),
+    "spamd_sddmm_panels": (_int, [_int, _int, _int, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp]),
     "spamd_sddmm_tile_size": (_int, []),
     "spamd_sddmm_tile_keys": (_int, [_int, _i64, _vp, _vp, _i64, _vp, _vp]),
     "spamd_sddmm_tile_classify": (_int, [_i64, _vp, _i64, _vp, _vp, _vp]),

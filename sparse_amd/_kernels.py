@@ -882,6 +882,9 @@ def sddmm_panel_width(bt):
         return 0
     if not sddmm_has_panels(bt.dtype, bt.shape[1]):
         return 0
+    if SDDMM_TWO_PASS:
+        # rows of 1 KB run as two passes over 512-byte halves (round 5): a panel is sized for the half-rows
+        row_bytes = int(_ffi.lib().spamd_sddmm_panel_row_bytes(code_of(bt.dtype), int(bt.shape[1]))) or row_bytes
     if SDDMM_XCD_PANELS and int(bt.shape[0]) * row_bytes >= 8 * SDDMM_PANEL_BYTES:
         # XCD-private panels: a multiple of eight panels of at most 7/6 of the panel size (3.5 MiB), so that every XCD owns the same number
         # (measured at config 4: 16 panels of 6250 rows 0.357 ms private vs 0.390 shared; 17 panels of 6144 rows 0.402 vs 0.396)
@@ -923,6 +926,7 @@ def sddmm_tiles_pay(plan, a, bt, width):
     return True
 
 
+SDDMM_TWO_PASS = True     # rows of exactly 1 KB in two launches over 512-byte halves and half-row panels (False: the row-cached kernel on whole rows, rounds 2-4)
 SDDMM_XCD_PANELS = True   # panels are private to an XCD (workgroup b serves XCD b % 8: the placement MI355X is observed to use;
                           # only speed depends on it); False: every XCD walks every panel
 
@@ -960,10 +964,13 @@ def sddmm_panels(coords, shape, width, subset=None, xcd=None):
 
 def _sddmm_panels_into(panels, s_orig, s_data, a, bt, out):
     """The elements of `panels` (all of the mask or a subset), written to their positions in `out`."""
+    part = None
+    if SDDMM_TWO_PASS and int(a.shape[1]) * a.element_size() == 1024:
+        part = torch.empty(panels.count, dtype=out.dtype, device=out.device)     # (first-half sums, panel order)
     _ffi.call("spamd_sddmm_panels", code_of(a.dtype), code_of(out.dtype), code_of(panels.rows.dtype), panels.count,
               ptr(panels.rows), ptr(panels.cols), ptr(panels.pos), ptr(panels.values(s_orig, s_data)), ptr(a), a.stride(0),
               ptr(bt), bt.stride(0), int(a.shape[1]), int(panels.chunk), ptr(panels.xstate) if panels.xstate is not None else None,
-              int(panels.xmax), ptr(out), stream_ptr(out.device))
+              int(panels.xmax), ptr(part) if part is not None else None, ptr(out), stream_ptr(out.device))
 
 
 def sddmm_coo(coords, s_data, a, bt, panels=None):

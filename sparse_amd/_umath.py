@@ -552,8 +552,11 @@ def _gcxs_keys2d(x):
     _validate_derived(x)
     c = x.__dict__.get("_keys2d")
     if c is None:
-        R, C = x._compressed_shape
-        keys = K.csr_to_keys(x.indptr, x.indices, R, C)
+        if x.ndim == 1:      # (a 1-D GCXS stores its coordinates: `indices`, no pointers)
+            keys = x.indices if x.indices.dtype == torch.int64 else x.indices.to(torch.int64)
+        else:
+            R, C = x._compressed_shape
+            keys = K.csr_to_keys(x.indptr, x.indices, R, C)
         unsorted, dup = K.keys_check(keys)
         c = (None if unsorted or dup else keys,)
         x.__dict__["_keys2d"] = c
@@ -571,7 +574,7 @@ def _gcxs_same_layout(name, a, b):
     from ._convert import _pick_index_dtype
     from ._gcxs import GCXS
 
-    if a.shape != b.shape or a.ndim < 2 or not a.size or a.compressed_axes != b.compressed_axes:
+    if a.shape != b.shape or a.ndim < 1 or not a.size or a.compressed_axes != b.compressed_axes:
         return None
     fka, fkb = a.fill_value, b.fill_value
     plan = _SAME_SHAPE_PLANS.get((name, a.data.dtype, b.data.dtype, fka.tobytes() if hasattr(fka, "tobytes") else fka,
@@ -583,6 +586,9 @@ def _gcxs_same_layout(name, a, b):
         return None
     mname, comp_t, fa, fb, fill_in_kernel, fill = plan
     keys, res = merge_union(mname, ka, K.convert(a.data, comp_t), kb, K.convert(b.data, comp_t), fa, fb, fill_in_kernel)
+    if a.ndim == 1:
+        return GCXS((res, keys if a.indices.dtype == torch.int64 else keys.to(a.indices.dtype), ()), shape=a.shape,
+                    compressed_axes=None, fill_value=fill)
     R, C = a._compressed_shape
     # (index width as the general route gives it: the first operand's, widened when the result needs it)
     indptr, indices = K.keys_to_csr(keys, R, C, _pick_index_dtype(a.indices.dtype, max(R, C, int(keys.numel()))))

@@ -100,7 +100,7 @@ __device__ __forceinline__ void sd_batch4(int cnt, int sub, I myrow, I mycol, co
       _Pragma("unroll") for (int s = 0; s < KS; ++s)                                                          \
         av[s] = STREAM_A ? sd_load_nt<VT>(ap + s * step_b) : *reinterpret_cast<const VT*>(ap + s * step_b);  \
     }                                                                                                         \
-    const ACC t = sd_group_sum<LPN>(sd_dot<TIN, VT, KS>(av, bv[k]));                                          \
+    const ACC t = sd_dot_group<TIN, VT, LPN, KS>(av, bv[k]);                                                  \
     res = sub == U0 + k ? t : res;                                                                            \
   }
   SD_DOT(0) SD_DOT(1) SD_DOT(2) SD_DOT(3)

@@ -44,6 +44,15 @@ __device__ __forceinline__ typename Acc<TIN>::type sd_dot(const VT (&av)[KS], co
   return acc;
 }
 
+template <int LPN, typename ACC>
+__device__ __forceinline__ ACC sd_group_sum(ACC acc);
+
+// The dot product of a lane group in the order every kernel of the family uses.  Rows of exactly 1 KB (LPN = 16, KS = 4) are
+// summed as TWO 512-byte halves - each half's 16-lane sum, then first + second - because the column-panel order computes them
+// in two passes over half-rows (spamd_sddmm_panels); every other row length is one sum over the lanes' whole shares.
+template <typename TIN, typename VT, int LPN, int KS>
+__device__ __forceinline__ typename Acc<TIN>::type sd_dot_group(const VT (&av)[KS], const VT (&bv)[KS]);
+
 template <int CTRL>
 __device__ __forceinline__ float sd_dpp(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
@@ -66,6 +75,21 @@ __device__ __forceinline__ ACC sd_group_sum(ACC acc) {
     for (int off = LPN / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
   }
   return acc;
+}
+
+template <typename TIN, typename VT, int LPN, int KS>
+__device__ __forceinline__ typename Acc<TIN>::type sd_dot_group(const VT (&av)[KS], const VT (&bv)[KS]) {
+  if constexpr (LPN == 16 && KS == 4) {
+    const VT(&a0)[2] = reinterpret_cast<const VT(&)[2]>(av[0]);
+    const VT(&a1)[2] = reinterpret_cast<const VT(&)[2]>(av[2]);
+    const VT(&b0)[2] = reinterpret_cast<const VT(&)[2]>(bv[0]);
+    const VT(&b1)[2] = reinterpret_cast<const VT(&)[2]>(bv[2]);
+    const auto first = sd_group_sum<LPN>(sd_dot<TIN, VT, 2>(a0, b0));
+    const auto second = sd_group_sum<LPN>(sd_dot<TIN, VT, 2>(a1, b1));
+    return first + second;
+  } else {
+    return sd_group_sum<LPN>(sd_dot<TIN, VT, KS>(av, bv));
+  }
 }
 
 // Lane `U` of every 16-lane row -> all lanes of that row (v_mov_b32_dpp row_newbcast:U); wider groups go through a

@@ -18,6 +18,7 @@
 //     (tests/test_sddmm_gpu.py::test_sddmm_column_panel_order_is_bit_identical).
 #include "sddmm_common.h"
 #include <algorithm>
+#include <stdlib.h>
 
 
 namespace spamd {
@@ -92,7 +93,7 @@ struct SdpBatch {
 #pragma unroll
           for (int s = 0; s < KS; ++s) av[s] = *reinterpret_cast<const VT*>(ap + s * (LPN * 16));
         }
-        const ACC t = sd_group_sum<LPN>(sd_dot<TIN, VT, KS>(av, bv[K]));
+        const ACC t = sd_dot_group<TIN, VT, LPN, KS>(av, bv[K]);
         res = sub == U0 + K ? t : res;
       }
       dot<K + 1>(cnt, sub, bv, sl, rr, sa, cap, Ab, lda_b, koff_b, res);
@@ -158,7 +159,10 @@ template <typename TIN, typename TS, typename I, int LPN, int KS, int UNR, int B
 __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(SDP_WPE, 8)))
 sddmm_panel_kernel(int64_t nnz, int cap, const I* __restrict__ rows, const I* __restrict__ cols,
                    const TS* __restrict__ s_data, const TIN* __restrict__ A, int64_t lda, const TIN* __restrict__ Bt,
-                   int64_t ldb, TS* __restrict__ out, const int64_t* __restrict__ perm, const int64_t* __restrict__ xstate) {
+                   int64_t ldb, TS* __restrict__ out, const int64_t* __restrict__ perm, const int64_t* __restrict__ xstate,
+                   int mode, typename Acc<TIN>::type* __restrict__ part) {
+  // mode (rows of 1 KB in two 512-byte halves, see spamd_sddmm_panels): 0 = the whole dot product, out[perm[n]] = s * dot;
+  // 1 = first half: part[n] = dot (panel order: coalesced); 2 = last half: out[perm[n]] = s * (part[n] + dot)
   using ACC = typename Acc<TIN>::type;
   using VT = Vec<TIN, 16 / (int)sizeof(TIN)>;
   static_assert(LPN % UNR == 0 && BLK % LPN == 0 && BLK % 64 == 0, "whole batches per step, whole lane groups per workgroup");
@@ -205,12 +209,14 @@ sddmm_panel_kernel(int64_t nnz, int cap, const I* __restrict__ rows, const I* __
 #else
     c = __builtin_nontemporal_load(cols + nl);
 #endif
-    sv = __builtin_nontemporal_load(s_data + nl);
-    pos = __builtin_nontemporal_load(perm + nl);
+    if (mode != 1) {   // (the first half stores its partial sums in panel order: neither the mask value nor the position)
+      sv = __builtin_nontemporal_load(s_data + nl);
+      pos = __builtin_nontemporal_load(perm + nl);
+    }
   };
   I nrow, ncol;
-  TS ns;
-  int64_t npos;
+  TS ns = TS(0);
+  int64_t npos = 0;
   fetch(wb, nrow, ncol, ns, npos);
 #pragma unroll 1
   for (int64_t pb = wb; pb < we; pb += BLK) {
@@ -222,6 +228,8 @@ sddmm_panel_kernel(int64_t nnz, int cap, const I* __restrict__ rows, const I* __
     const TS mys = ns;
     const int64_t mypos = npos;
     if (SDP_CHUNKS > 1 && pe < we) fetch(pe, nrow, ncol, ns, npos);
+    ACC prev = 0;      // the first half's sum of my element (requested here, used after the dot product)
+    if (mode == 2) prev = __builtin_nontemporal_load(part + nl);
 
     // distinct rows of the chunk's elements: heads of runs of equal rows, numbered by a block scan
     srow[tid] = myrow;
@@ -250,6 +258,10 @@ sddmm_panel_kernel(int64_t nnz, int cap, const I* __restrict__ rows, const I* __
     // The Bt rows of the lane group's first batch are requested first (into registers), then ONE burst of LDS-DMA brings the
     // staged A rows straight into LDS (no staging registers: `global_load_lds_dwordx4`, a wave-instruction moves 1 KB =
     // 64 consecutive 16-byte vectors of the staged area); both are in flight together and waited for once.
+    // (Both 512-byte halves of 1 KB rows inside ONE launch - the chunk's A rows staged half by half, the second half's sums
+    // added to the first's - was built and measured in round 5: 0.98 ms at config 4 fp32 against 0.90 for the row-cached
+    // kernel and 0.79-0.83 for two launches over half-row panels: the second round repeats the staging burst, its wait and
+    // two barriers per chunk, and the panels still hold whole rows.  Removed.)
     const int nstage = ndist < cap ? ndist : cap;
     const int nvec = nstage * VPR;   // (>= VPR: the chunk has at least one element)
     using B0 = SdpBatch<TIN, I, LPN, KS, UNR, 0>;
@@ -280,7 +292,12 @@ sddmm_panel_kernel(int64_t nnz, int cap, const I* __restrict__ rows, const I* __
 #if defined(SDP_ABL) && SDP_ABL == 1   // timing ablation (wrong order): results stored in panel order, coalesced
     if (mine) __builtin_nontemporal_store((TS)((ACC)mys * res), out + nl + (mypos & 0));
 #else
-    if (mine) __builtin_nontemporal_store((TS)((ACC)mys * res), out + mypos);  // scattered: keep these lines out of the panel's way
+    if (mode == 1) {
+      if (mine) __builtin_nontemporal_store(res, part + nl);
+    } else {
+      if (mode == 2) res = prev + res;   // (first half + second half: the row-major kernel adds its two halves the same way, sd_dot_1k)
+      if (mine) __builtin_nontemporal_store((TS)((ACC)mys * res), out + mypos);  // scattered: keep these lines out of the panel's way
+    }
 #endif
     if (SDP_CHUNKS > 1) __syncthreads();   // (the next chunk re-uses the staged rows' LDS)
   }
@@ -289,7 +306,7 @@ sddmm_panel_kernel(int64_t nnz, int cap, const I* __restrict__ rows, const I* __
 template <typename TIN, typename TS, typename I>
 static int launch_panel(int64_t nnz, const I* rows, const I* cols, const TS* s, const TIN* A, int64_t lda, const TIN* Bt,
                         int64_t ldb, int64_t K, TS* out, hipStream_t st, const int64_t* perm, int64_t cap_rows,
-                        const int64_t* xstate, int64_t xmax) {
+                        const int64_t* xstate, int64_t xmax, int mode = 0, typename Acc<TIN>::type* part = nullptr) {
   constexpr int EPL = 16 / (int)sizeof(TIN);
   const int64_t vecs = K / EPL;
   for (int L = 16; L <= 64; L <<= 1) {
@@ -316,13 +333,24 @@ static int launch_panel(int64_t nnz, const I* rows, const I* cols, const TS* s, 
       if (e != hipSuccess) return (int)e;                                                                      \
     }                                                                                                          \
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BLK), lds, st, nnz, cap, rows, cols, s, A, lda, Bt,  \
-                       ldb, out, perm, xstate);                                                                \
+                       ldb, out, perm, xstate, mode, part);                                                    \
     return launch_status();                                                                                    \
   }
     SDP(16, 1, SDP_UNR) SDP(16, 2, SDP_UNR) SDP(32, 1, SDP_UNR)   // (rows below 1 KB: see spamd_sddmm_panels)
 #undef SDP
   }
   return SPAMD_EINVAL;
+}
+
+// rows of 1 KB: the first 512-byte halves into `part` (panel order), then the second halves on top of them
+template <typename TIN, typename TS, typename I>
+static int launch_panel_halves(int64_t nnz, const I* rows, const I* cols, const TS* s, const TIN* A, int64_t lda, const TIN* Bt,
+                               int64_t ldb, int64_t K, TS* out, hipStream_t st, const int64_t* perm, int64_t cap_rows,
+                               const int64_t* xstate, int64_t xmax, typename Acc<TIN>::type* part) {
+  const int64_t kh = K / 2;
+  if (int rc = launch_panel<TIN, TS, I>(nnz, rows, cols, s, A, lda, Bt, ldb, kh, out, st, perm, cap_rows, xstate, xmax, 1, part))
+    return rc;
+  return launch_panel<TIN, TS, I>(nnz, rows, cols, s, A + kh, lda, Bt + kh, ldb, kh, out, st, perm, cap_rows, xstate, xmax, 2, part);
 }
 
 }  // namespace spamd
@@ -337,10 +365,25 @@ int sddmm_rowcache_panels(int in_dtype, int s_dtype, int idx_dtype, int64_t nnz,
 // spamd_sddmm_panel_keys); out stays in the mask's own order: out[perm[n]] = s_p[n] * <A[rows_p[n]], Bt[cols_p[n]]>.
 // `chunk` > 0: LDS slots for A rows per workgroup (default: 24 KB worth; rows below 1 KB only).  SPAMD_EINVAL when K has no row-cached kernel
 // (use spamd_sddmm).
+// Rows of exactly 1 KB (fp32 K = 256, fp64 K = 128, bf16 K = 512) with `part` (nnz accumulator-type words of scratch): TWO
+// passes over the mask, one per 512-byte half of the rows (round 5).  The distinct A rows of a workgroup do not fit LDS at
+// 1 KB, so until round 4 these rows kept the row-cached kernel, whose panels hold whole 1 KB Bt rows: 32 panels at config 4,
+// every one streaming all of A (3.2 GB) - 6.4 GB of fabric traffic for 0.26 GB of operands.  Half-rows double the rows
+// a panel holds in the same L2 bytes (the caller builds the panels for 512-byte rows: `spamd_sddmm_panel_row_bytes`), so A
+// is streamed 16 x 2 halves = half as often, and each pass is the LDS-staged kernel at its native row length.  Pass 1
+// leaves every element's first-half sum in `part` IN PANEL ORDER (coalesced, 4 or 8 bytes per element), pass 2 adds the
+// second half and writes s * sum to the element's place.  spamd_sddmm's row-major kernel adds its halves in the same
+// order (sd_dot_1k), so the two orders stay bit-identical.
+extern "C" int64_t spamd_sddmm_panel_row_bytes(int in_dtype, int64_t K) {
+  const int esz = in_dtype == SPAMD_BF16 ? 2 : (in_dtype == SPAMD_F32 ? 4 : (in_dtype == SPAMD_F64 ? 8 : 0));
+  if (!esz || K <= 0) return 0;
+  return K * esz == 1024 ? 512 : K * esz;
+}
+
 extern "C" int spamd_sddmm_panels(int in_dtype, int s_dtype, int idx_dtype, int64_t nnz, const void* rows_p,
                                   const void* cols_p, const int64_t* perm, const void* s_p, const void* A, int64_t lda,
                                   const void* Bt, int64_t ldb, int64_t K, int64_t chunk, const int64_t* xcd_first,
-                                  int64_t xcd_max, void* out, void* stream) {
+                                  int64_t xcd_max, void* part, void* out, void* stream) {
   if (!perm || (xcd_first && xcd_max < 0) || nnz < 0 || K <= 0) return SPAMD_EINVAL;
   if (nnz == 0) return 0;
   if (((uintptr_t)A % 16) || ((uintptr_t)Bt % 16)) return SPAMD_EINVAL;
@@ -350,10 +393,28 @@ extern "C" int spamd_sddmm_panels(int in_dtype, int s_dtype, int idx_dtype, int6
   // Rows of 1 KB and more (fp32 K = 256, ...): the distinct A rows of a workgroup no longer fit LDS at an occupancy that
   // pays (10 KB per wave; measured 0.92 ms against 0.87 ms at config 4's shapes in fp32), so those keep the row-cached
   // kernel of sddmm.hip, which holds the current A row in registers.
-  if (K * esz >= 1024)
+  const bool halves = K * esz == 1024 && part != nullptr;
+  if (K * esz >= 1024 && !halves)
     return sddmm_rowcache_panels(in_dtype, s_dtype, idx_dtype, nnz, rows_p, cols_p, s_p, A, lda, Bt, ldb, K, out, stream, perm,
                                  0, xcd_first, xcd_max);
   hipStream_t st = (hipStream_t)stream;
+  if (halves) {
+    SPAMD_DISPATCH_IDX(idx_dtype, I, {
+      const I* r = (const I*)rows_p;
+      const I* c = (const I*)cols_p;
+      if (in_dtype == SPAMD_BF16 && s_dtype == SPAMD_F32)
+        return launch_panel_halves<__hip_bfloat16, float, I>(nnz, r, c, (const float*)s_p, (const __hip_bfloat16*)A, lda,
+                                                             (const __hip_bfloat16*)Bt, ldb, K, (float*)out, st, perm, chunk,
+                                                             xcd_first, xcd_max, (float*)part);
+      if (in_dtype == SPAMD_F32 && s_dtype == SPAMD_F32)
+        return launch_panel_halves<float, float, I>(nnz, r, c, (const float*)s_p, (const float*)A, lda, (const float*)Bt, ldb, K,
+                                                    (float*)out, st, perm, chunk, xcd_first, xcd_max, (float*)part);
+      if (in_dtype == SPAMD_F64 && s_dtype == SPAMD_F64)
+        return launch_panel_halves<double, double, I>(nnz, r, c, (const double*)s_p, (const double*)A, lda, (const double*)Bt, ldb,
+                                                      K, (double*)out, st, perm, chunk, xcd_first, xcd_max, (double*)part);
+    })
+    return SPAMD_ETYPE;
+  }
   SPAMD_DISPATCH_IDX(idx_dtype, I, {
     const I* r = (const I*)rows_p;
     const I* c = (const I*)cols_p;

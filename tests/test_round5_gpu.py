@@ -23,7 +23,7 @@ def sp():
 
 
 def _bits(t):
-    return t.contiguous().view(torch.uint8).cpu().numpy().tobytes()
+    return t.contiguous().view(torch.uint8).cpu().numpy().tobytes() if t.numel() else b""
 
 
 def _same_gcxs(x, y):
@@ -119,7 +119,7 @@ def test_planned_product_still_warns_about_nan(sp):
 
 # ---- GCXS (x) GCXS in their own layout ---------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("shape,ca", [((60, 70), (0,)), ((60, 70), (1,)), ((12, 9, 14), (0, 2)), ((12, 9, 14), (1,)), ((5, 6, 7, 8), (1, 3))])
+@pytest.mark.parametrize("shape,ca", [((500,), None), ((60, 70), (0,)), ((60, 70), (1,)), ((12, 9, 14), (0, 2)), ((12, 9, 14), (1,)), ((5, 6, 7, 8), (1, 3))])
 @pytest.mark.parametrize("op", ["add", "multiply", "subtract", "maximum", "greater"])
 def test_gcxs_elementwise_in_place_of_the_coo_round_trip(sp, shape, ca, op):
     from sparse_amd import _umath
