@@ -297,8 +297,20 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
             extra["stream_padding"] = used * epb / max(nnzp, 1) - 1.0      # entries the lists hold beyond the stored elements
             per_wg = lens[: (Mp // (rg * gpb)) * rg * gpb].view(-1, rg * gpb).sum(1).double()
             per_wave = lens[: (Mp // rg) * rg].view(-1, rg).sum(1).double()
-            extra["workgroup_nnz_max_over_mean"] = float(per_wg.max() / per_wg.mean())
-            extra["wave_nnz_max_over_mean"] = float(per_wave.max() / per_wave.mean())
+            extra["natural_workgroup_nnz_max_over_mean"] = float(per_wg.max() / per_wg.mean())
+            extra["natural_wave_nnz_max_over_mean"] = float(per_wave.max() / per_wave.mean())
+            extra["balanced_layout"] = lay.rowmap is not None
+            extra["row_groups"] = int(lay.groups) if lay.rowmap is not None else int(bo.shape[0])
+            if lay.rowmap is not None:
+                # the same operand in the NATURAL layout (35 consecutive rows per wave: rounds 1-4), for the comparison
+                K.TILED_BALANCE = False
+                try:
+                    lay_n = K.csr_tiled_layout(d, i, p, Mp, Kp)
+                    extra["natural_layout_ms"], r_n = timed(lambda: K.dot_csr_ndarray_tiled(lay_n, (Mp, Np), Kp, bp), reps=5)
+                    extra["identical_to_natural_layout"] = bool(torch.equal(r_n, r))
+                    del lay_n, r_n
+                finally:
+                    K.TILED_BALANCE = True
         # the nnz-balanced 8-way partition of THIS matrix: every block alone, as bench.py's scaling proxy does for the uniform one
         b8 = _dist.partition_rows_by_nnz(p, 8)
         blk_ms, blk_nnz = [], []

@@ -147,6 +147,29 @@ int64_t spamd_spmm_tiled_inspect_csc_ws(int64_t M, int64_t K);
 int spamd_spmm_tiled_inspect_csc(int val_dtype, int idx_dtype, int64_t M, int64_t K, const void* a_data,
                                  const void* a_indices, const void* a_indptr, int* ws, void* state, int* blk_off,
                                  int* blocks, void* stream);
+/* Balanced layouts for SKEWED matrices (round 5; the reference's loop, _common.py:744-753, is indifferent to row lengths -
+ * one wave per 35 consecutive rows is not: Zipf row lengths cost 4x at config 2's size).  Rows are sorted by length and classed
+ * against `cap` (a power of two; longer than cap/2: a group of its own, then 2 / 4 / 8 / 16 rows to a group, everything else 35),
+ * so that the 16 groups of a workgroup are equally heavy; rows are read and stored through a row map; entries, lists and the
+ * order of every output element's terms are unchanged (bit-identical products).
+ *   spamd_spmm_tiled_map_stats   keys[M] = K - length of every row, rows[M] = 0..M-1, stats[8] (zeroed here): rows per class [0..5],
+ *                                stored elements of the heaviest NATURAL 35-row group [6] (the caller's "is it skewed" test)
+ *   (caller)                     stable sort of rows by keys (spamd_sort_kv: longest rows first), class counts read back
+ *   spamd_spmm_tiled_map_groups  groups of the layout for these class counts (host arithmetic)
+ *   spamd_spmm_tiled_map_build   rowmap[groups * rows_per_group + 16] (-1 = unused slot), gload[groups + 1] (stored elements
+ *                                per group, then 0): the caller's exclusive scan of gload is `vstart`
+ *   spamd_spmm_tiled_inspect_mapped / spamd_spmm_tiled_mapped: the one-pass inspector and the executor on that layout. */
+int spamd_spmm_tiled_map_stats(int idx_dtype, int64_t M, int64_t K, int64_t cap, const void* a_indptr, int64_t* keys,
+                               int* rows, int64_t* stats, void* stream);
+int64_t spamd_spmm_tiled_map_groups(const int64_t* class_counts /* host, 6 entries */);
+int spamd_spmm_tiled_map_build(int idx_dtype, int64_t M, int64_t cap, const void* a_indptr, const int* rows_sorted,
+                               const int64_t* class_counts /* host */, int* rowmap, int64_t* gload, void* stream);
+int spamd_spmm_tiled_inspect_mapped(int val_dtype, int idx_dtype, int64_t M, int64_t K, int64_t groups, const void* a_data,
+                                    const void* a_indices, const void* a_indptr, const int* rowmap, const int64_t* vstart,
+                                    void* state, int* blk_off, int* blocks, void* stream);
+int spamd_spmm_tiled_mapped(int val_dtype, int64_t M, int64_t groups, int64_t K, int64_t N, const int* blocks,
+                            const int* blk_off, const int* rowmap, const void* b, int64_t ldb, void* out, int64_t ldo,
+                            unsigned flags, void* stream);
 int spamd_spmm_tiled_keys(int64_t nnz, const int64_t* rowcol_keys, int64_t K, int64_t* tiled_keys, void* stream);
 int spamd_spmm_tiled_lists(int val_dtype, int64_t nnz, const int64_t* tiled_keys_sorted, int64_t M, int64_t K,
                            int64_t* seg_start, int64_t* nblk, void* stream);

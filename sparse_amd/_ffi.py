@@ -124,6 +124,11 @@ SIGNATURES = {
     "spamd_spmm_tiled_inspect": (_int, [_int, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spamd_spmm_tiled_inspect_csc_ws": (_i64, [_i64, _i64]),
     "spamd_spmm_tiled_inspect_csc": (_int, [_int, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "spamd_spmm_tiled_map_stats": (_int, [_int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "spamd_spmm_tiled_map_groups": (_i64, [_vp]),
+    "spamd_spmm_tiled_map_build": (_int, [_int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "spamd_spmm_tiled_inspect_mapped": (_int, [_int, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "spamd_spmm_tiled_mapped": (_int, [_int, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _u32, _vp]),
     "spamd_spmm_tiled_keys": (_int, [_i64, _vp, _i64, _vp, _vp]),
     "spamd_spmm_tiled_lists": (_int, [_int, _i64, _vp, _i64, _i64, _vp, _vp, _vp]),
     "spamd_spmm_tiled_pack": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),

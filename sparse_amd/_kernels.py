@@ -1127,11 +1127,13 @@ class TiledLayout(tuple):
     launcher turns into the executor's prefetch width without reading anything back from the device, + `group_ends`:
     blk_off holds tiles + 1 entries per row group (the one-pass inspector's form) instead of one running array"""
 
-    def __new__(cls, blocks, blk_off, dtype, mean_blocks, group_ends=False, pending=None):
+    def __new__(cls, blocks, blk_off, dtype, mean_blocks, group_ends=False, pending=None, rowmap=None, groups=None):
         self = super().__new__(cls, (blocks, blk_off, dtype))
         self.mean_blocks = mean_blocks
         self.group_ends = group_ends
         self.pending = pending   # device word of a one-pass layout whose "unsorted column indices" verdict was not read yet
+        self.rowmap = rowmap     # balanced layout (round 5): the row of every slot of every group, int32[groups * rows_per_group + 16]
+        self.groups = groups
         return self
 
 
@@ -1175,6 +1177,11 @@ def csr_tiled_layout(a_data, a_indices, a_indptr, M, Kd, force_sort=False, dtype
         fill(blk_off, total, blocks)
         return TiledLayout(blocks, convert(blk_off, torch.int32), dtype, total / max(nseg, 1))
 
+    if ntiles <= direct_max and not force_sort and TILED_ONE_PASS_INSPECTOR and TILED_BALANCE and nnz >= TILED_BALANCE_MIN_NNZ \
+            and 0 < M < 2 ** 31:
+        lay = _balanced_tiled_layout(vals, a_indices.contiguous(), a_indptr.contiguous(), M, Kd, dtype, nnz, defer_check, dev, s)
+        if lay is not None:
+            return lay
     if ntiles <= direct_max and not force_sort and TILED_ONE_PASS_INSPECTOR:
         # one pass over A (csrc/spmm_tiled.hip `tl_inspect_kernel`): count, fill and padding in a single launch with no
         # dependence between row groups (a group's first block is a closed-form upper bound from the row pointers); the
@@ -1212,6 +1219,59 @@ def csr_tiled_layout(a_data, a_indices, a_indptr, M, Kd, force_sort=False, dtype
     _ffi.call("spamd_spmm_tiled_lists", vc, nnz, ptr(tk), M, Kd, ptr(seg_start), ptr(nblk), s)
     return finish(exclusive_scan(nblk), lambda bo, total, blocks: _ffi.call(
         "spamd_spmm_tiled_pack", vc, nnz, ptr(tk), ptr(vals), ptr(seg_start), ptr(bo), total, ptr(blocks), s))
+
+
+TILED_BALANCE = True            # skewed row lengths: a balanced (row-mapped) layout instead of consecutive rows per wave
+TILED_BALANCE_MIN_NNZ = 1 << 20
+TILED_BALANCE_SKEW = 1.6        # natural layout kept while its heaviest row group holds at most this x the mean group
+TILED_BALANCE_CAPMUL = 2        # cap = the power of two >= this x the mean 35-row group (rows above cap / 2 get a group of their own)
+TILED_BALANCE_STATS = {}        # the last decision (tests, benches)
+
+
+def _balanced_tiled_layout(vals, ind, ptr_, M, Kd, dtype, nnz, defer_check, dev, s):
+    """The block stream of a SKEWED matrix (csrc/spmm_tiled.hip, `tl_map_*`): rows sorted by length, heavy rows given
+    groups of their own (or shared by 2 / 4 / 8 / 16), a workgroup's 16 groups equally heavy, rows read and stored
+    through a row map.  Returns None when the natural layout is balanced enough (its heaviest 35-row group at most
+    TILED_BALANCE_SKEW x the mean: uniform `random` matrices measure ~1.1) - one small read-back decides.  Measured on a Zipf
+    matrix of config 2's size (bench row A1_powerlaw): natural layout 3.5 ms per product, balanced see DESIGN.md."""
+    rg, kb, gpb, epb, slack, direct_max, _ = tiled_params(dtype)
+    ntiles = -(-Kd // kb)
+    ic, vc = code_of(ind.dtype), code_of(_tiled_layout_dtype(dtype))
+    mean_group = nnz * rg / max(M, 1)
+    cap = 32
+    while cap < TILED_BALANCE_CAPMUL * mean_group:
+        cap *= 2
+    keys = torch.empty(M, dtype=torch.int64, device=dev)
+    rows = torch.empty(M, dtype=torch.int32, device=dev)
+    stats = torch.empty(8, dtype=torch.int64, device=dev)
+    _ffi.call("spamd_spmm_tiled_map_stats", ic, M, Kd, cap, ptr(ptr_), ptr(keys), ptr(rows), ptr(stats), s)
+    st = stats.tolist()                                   # (the one read-back of the decision)
+    skew = st[6] / max(mean_group, 1.0)
+    TILED_BALANCE_STATS.update(cap=cap, class_rows=st[:6], natural_max_group=st[6], skew=skew, balanced=False)
+    if skew <= TILED_BALANCE_SKEW:
+        return None
+    counts = _harr64(st[:6])
+    groups = int(_ffi.lib().spamd_spmm_tiled_map_groups(counts))
+    nseg = groups * ntiles
+    upper = -(-nnz // epb) + nseg
+    if groups <= 0 or upper >= 2 ** 31:
+        return None
+    keys, rows = sort_key_value(keys, rows, max(Kd, 1))  # longest rows first (stable): neighbours in a workgroup are equally long
+    rowmap = torch.empty(groups * rg + 16, dtype=torch.int32, device=dev)
+    gload = torch.empty(groups + 1, dtype=torch.int64, device=dev)
+    _ffi.call("spamd_spmm_tiled_map_build", ic, M, cap, ptr(ptr_), ptr(rows), counts, ptr(rowmap), ptr(gload), s)
+    vstart = exclusive_scan(gload)
+    blocks = torch.empty((upper + slack) * 16, dtype=torch.int32, device=dev)
+    blk_off = torch.empty(groups * (ntiles + 1), dtype=torch.int32, device=dev)
+    state = torch.empty(1, dtype=torch.int64, device=dev)
+    _ffi.call("spamd_spmm_tiled_inspect_mapped", vc, ic, M, Kd, groups, ptr(vals), ptr(ind), ptr(ptr_), ptr(rowmap), ptr(vstart),
+              ptr(state), ptr(blk_off), ptr(blocks), s)
+    TILED_BALANCE_STATS.update(balanced=True, groups=groups)
+    lay = TiledLayout(blocks, blk_off, dtype, nnz / epb / max(nseg, 1) + 0.5, group_ends=True, pending=state if defer_check else None,
+                      rowmap=rowmap, groups=groups)
+    if not defer_check and int(state[0]) != 0:
+        return None          # unsorted column indices: the caller's key-sort recipe (natural layout)
+    return lay
 
 
 def csc_tiled_layout(a_data, a_indices, a_indptr, M, Kd, dtype=None):
@@ -1274,8 +1334,14 @@ def dot_csr_ndarray_tiled(layout, out_shape, Kd, b, out=None, exact=False):
         hint = _TOUCH_OVERRIDE
     ends = _ffi.TILED_GROUP_ENDS if getattr(layout, "group_ends", False) else 0
     ints = _ffi.TILED_INT32 if dtype == torch.int32 else 0
-    _ffi.call("spamd_spmm_tiled", code_of(_tiled_layout_dtype(dtype)), M, Kd, N, ptr(blocks), ptr(blk_off), ptr(b), N, ptr(out), Nout,
-              (_ffi.EXACT_MULADD if exact and not ints else 0) | ends | ints | (hint << 8) | (last_cols << 16), stream_ptr(dev))
+    flags = (_ffi.EXACT_MULADD if exact and not ints else 0) | ends | ints | (hint << 8) | (last_cols << 16)
+    rowmap = getattr(layout, "rowmap", None)
+    if rowmap is not None:
+        _ffi.call("spamd_spmm_tiled_mapped", code_of(_tiled_layout_dtype(dtype)), M, int(layout.groups), Kd, N, ptr(blocks), ptr(blk_off),
+                  ptr(rowmap), ptr(b), N, ptr(out), Nout, flags, stream_ptr(dev))
+    else:
+        _ffi.call("spamd_spmm_tiled", code_of(_tiled_layout_dtype(dtype)), M, Kd, N, ptr(blocks), ptr(blk_off), ptr(b), N, ptr(out), Nout,
+                  flags, stream_ptr(dev))
     pending = getattr(layout, "pending", None)
     if pending is not None:   # first product of a layout built with defer_check: the verdict is read now, behind the launch
         layout.pending = None

@@ -242,13 +242,17 @@ __host__ __device__ inline int64_t tl_group_first_block(int64_t e0, int64_t g, i
   return (e0 + g * ntiles * (epb - 1) + epb - 1) / epb;
 }
 
+// `rowmap` (round 5, balanced layouts): the group's TL_RG rows are rowmap[g * TL_RG + lr] (negative = an unused slot) instead of
+// the consecutive rows g * TL_RG + lr, and `vstart[g]` = the stored elements of the groups before g (which the closed-form block
+// offsets need: the natural layout reads them off the row pointers).
 template <typename I, typename T>
 __global__ void __launch_bounds__(256) tl_inspect_kernel(int64_t M, int ntiles, int64_t groups, const T* __restrict__ vals,
                                                          const I* __restrict__ indices, const I* __restrict__ indptr,
                                                          unsigned long long* __restrict__ state, int* __restrict__ blk_off,
-                                                         int* __restrict__ stream) {
-  extern __shared__ int tl_fill_lds[];  // before[RG][ntiles], runstart[RG][ntiles] (relative to e0), loff[ntiles + 1]
-  __shared__ int64_t rs[TL_RG + 1];
+                                                         int* __restrict__ stream, const int* __restrict__ rowmap,
+                                                         const int64_t* __restrict__ vstart) {
+  extern __shared__ int tl_fill_lds[];  // before[RG][ntiles], runstart[RG][ntiles] (relative to the row's start), loff[ntiles + 1]
+  __shared__ int64_t rsa[TL_RG + 1], rsb[TL_RG + 1];   // first element and end of every row of the group
   __shared__ int wtot[5];
   __shared__ int group_bad;   // a row of THIS group has unsorted column indices: its lists are written as zeros
   constexpr int EPB = TlFmt<T>::EPB;
@@ -258,14 +262,21 @@ __global__ void __launch_bounds__(256) tl_inspect_kernel(int64_t M, int ntiles, 
   const int tid = threadIdx.x;
   const int64_t g = blockIdx.x;
   const int64_t r0 = g * TL_RG;
-  if (tid <= TL_RG) {
-    const int64_t r = r0 + tid;
-    rs[tid] = (int64_t)indptr[r < M ? r : M];
+  if (tid < TL_RG) {
+    if (rowmap) {
+      const int r = rowmap[r0 + tid];
+      rsa[tid] = r >= 0 ? (int64_t)indptr[r] : 0;
+      rsb[tid] = r >= 0 ? (int64_t)indptr[r + 1] : 0;
+    } else {
+      const int64_t r = r0 + tid;
+      rsa[tid] = (int64_t)indptr[r < M ? r : M];
+      rsb[tid] = (int64_t)indptr[r + 1 < M ? r + 1 : M];
+    }
   }
   for (int i = tid; i < TL_RG * ntiles; i += 256) before[i] = 0;
   if (tid == 0) group_bad = 0;
   __syncthreads();
-  const int64_t e0 = rs[0], e1 = rs[TL_RG];
+  const int64_t e0 = rowmap ? vstart[g] : rsa[0], e1 = rowmap ? vstart[g + 1] : rsb[TL_RG - 1];
   bool bad = false;
   // A wave per row (rows wave-strided: the row in the group is known without a bisection over the row starts).  The first
   // TL_PRE * 64 elements of each of the wave's rows (column and value) are requested up front and stay in registers for
@@ -279,7 +290,7 @@ __global__ void __launch_bounds__(256) tl_inspect_kernel(int64_t M, int ntiles, 
 #pragma unroll
   for (int i = 0; i < RPW; ++i) {
     const int lr = wv + 4 * i;
-    const int64_t ra = lr < TL_RG ? rs[lr] : 0, rb = lr < TL_RG ? rs[lr + 1] : 0;
+    const int64_t ra = lr < TL_RG ? rsa[lr] : 0, rb = lr < TL_RG ? rsb[lr] : 0;
 #pragma unroll
     for (int p = 0; p < TL_PRE; ++p) {
       const int64_t e = ra + lane + 64 * p;
@@ -291,13 +302,13 @@ __global__ void __launch_bounds__(256) tl_inspect_kernel(int64_t M, int ntiles, 
     const int t = (int)(c / (unsigned)TL_KB);
     atomicAdd(&before[lr * ntiles + t], 1);
     if (!row_start && cp > c) bad = true;
-    if (row_start || (int)(cp / (unsigned)TL_KB) != t) runstart[lr * ntiles + t] = (int)(e - e0);
+    if (row_start || (int)(cp / (unsigned)TL_KB) != t) runstart[lr * ntiles + t] = (int)(e - ra);
   };
 #pragma unroll
   for (int i = 0; i < RPW; ++i) {
     const int lr = wv + 4 * i;
     if (lr >= TL_RG) break;
-    const int64_t ra = rs[lr], rb = rs[lr + 1];
+    const int64_t ra = rsa[lr], rb = rsb[lr];
 #pragma unroll
     for (int p = 0; p < TL_PRE; ++p) {
       const int64_t e = ra + lane + 64 * p;
@@ -369,23 +380,23 @@ __global__ void __launch_bounds__(256) tl_inspect_kernel(int64_t M, int ntiles, 
     return;
   }
   // fill (a wave per row again; the preloaded elements come from registers)
-  auto fill_one = [&](int lr, int64_t e, unsigned c, T v) {
+  auto fill_one = [&](int lr, int64_t ra, int64_t e, unsigned c, T v) {
     const int t = (int)(c / (unsigned)TL_KB);
     const int lc = (int)(c - (unsigned)t * (unsigned)TL_KB);
-    const int64_t dst = (goff + loff[t]) * EPB + before[lr * ntiles + t] + ((int)(e - e0) - runstart[lr * ntiles + t]);
+    const int64_t dst = (goff + loff[t]) * EPB + before[lr * ntiles + t] + ((int)(e - ra) - runstart[lr * ntiles + t]);
     TlFmt<T>::put(stream, dst, tl_d0(lc, lr), v);
   };
 #pragma unroll
   for (int i = 0; i < RPW; ++i) {
     const int lr = wv + 4 * i;
     if (lr >= TL_RG) break;
-    const int64_t ra = rs[lr], rb = rs[lr + 1];
+    const int64_t ra = rsa[lr], rb = rsb[lr];
 #pragma unroll
     for (int p = 0; p < TL_PRE; ++p) {
       const int64_t e = ra + lane + 64 * p;
-      if (e < rb) fill_one(lr, e, cpre[i][p], vpre[i][p]);
+      if (e < rb) fill_one(lr, ra, e, cpre[i][p], vpre[i][p]);
     }
-    for (int64_t e = ra + lane + 64 * TL_PRE; e < rb; e += 64) fill_one(lr, e, (unsigned)indices[e], vals[e]);
+    for (int64_t e = ra + lane + 64 * TL_PRE; e < rb; e += 64) fill_one(lr, ra, e, (unsigned)indices[e], vals[e]);
   }
   // padding entries of my list (zero d0 and value: they accumulate into the junk register pair)
   if (tid < ntiles) {
@@ -453,7 +464,7 @@ template <int DBG, int MODE, typename T>
 __global__ void __launch_bounds__(TL_WAVES * 64) __attribute__((amdgpu_num_vgpr(TL_ASM_COMP)))
 spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, int touch_lines, const int* __restrict__ stream,
                   const int* __restrict__ blk_off, const T* __restrict__ b, int64_t ldb,
-                  T* __restrict__ out, int64_t ldo, int last_cols, int npanels, int nblocks) {
+                  T* __restrict__ out, int64_t ldo, int last_cols, int npanels, int nblocks, const int* __restrict__ rowmap) {
   constexpr int PANEL = TlFmt<T>::PANEL;            // columns per workgroup: 512 bytes of every B row
   constexpr int CPL = PANEL / 64;                   // columns per lane
   extern __shared__ __attribute__((aligned(16))) char lds[];  // the only LDS object: starts at LDS byte 0
@@ -471,7 +482,11 @@ spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, int touch_lines, const int* 
   int bx, by;
   tl_block_map(blockIdx.x, npanels, nblocks, bx, by);
   if (bx >= nblocks || by >= npanels) return;              // (whole rounds of the eight XCDs, whole pairs of panels)
-  const int64_t g = (int64_t)bx * TL_WAVES + wv;           // my row group (lists exist for every wave of the grid)
+  // my row group (lists exist for every wave of the grid).  A 32-bit value ON PURPOSE (the launcher bounds the grid): as an
+  // int64 its (always zero) high half stayed live across the phase loop, and with the balanced layout's store below the
+  // compiler ran out of the SGPRs the asm blocks leave it and spilled that half into a VGPR lane - a build that faulted
+  // intermittently on the GPU (round 5; tools/check_tiled_regs.py now refuses any SGPR spill in these kernels).
+  const int g = bx * TL_WAVES + wv;
   b += (int64_t)by * PANEL;                                // column panel of B and of the result
   out += (int64_t)by * PANEL;
 
@@ -530,7 +545,7 @@ spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, int touch_lines, const int* 
   // CU whether it hits or not (tools/micro/smem_lat.hip), so extra requests cost more than the latency they save.)
   // (bits 16.. of `touch_lines`: 1 = blk_off holds ntiles + 1 entries per group — each group's own end — instead of
   // one running array in which a group ends where the next one starts: the one-pass inspector's layout)
-  const int* const myoff = blk_off + g * (int64_t)(ntiles + (touch_lines >> 16));
+  const int* const myoff = blk_off + (int64_t)g * (ntiles + (touch_lines >> 16));
   touch_lines &= 0xffff;
   const int toff = (lane < touch_lines ? lane : touch_lines - 1) * 64;  // byte offset of the line this lane touches
   int t = 0;
@@ -555,7 +570,7 @@ spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, int touch_lines, const int* 
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
   // write my rows
-  const int64_t row0 = g * TL_RG;
+  const int64_t row0 = (int64_t)g * TL_RG;
   const int64_t left = M - row0;
   const int nvalid = left <= 0 ? 0 : (left < TL_RG ? (int)left : TL_RG);
   T* const obase_p = out + row0 * ldo + lane * CPL;
@@ -566,6 +581,26 @@ spmm_tiled_kernel(int64_t M, int64_t K, int ntiles, int touch_lines, const int* 
   int bx2, by2;   // (recomputed from the kernel arguments: nothing of the mapping stays live across the asm blocks, whose
   tl_block_map(blockIdx.x, npanels, nblocks, bx2, by2);   //  scalar operands leave the compiler s0..s35)
   const int ncols = (last_cols > 0 && by2 == npanels - 1) ? last_cols : PANEL;
+  if (rowmap) {
+    // balanced layout: row j of my group is rowmap[g * TL_RG + j] (negative: an unused slot), see tl_map_build_kernel
+    const int* const rm = rowmap + (int64_t)g * TL_RG;
+    T* const base_p = out + lane * CPL;
+    if (lane * CPL + CPL <= ncols)
+      asm volatile(TL_ASM_STORE_PERM
+                   :
+                   : [lo] "v"((unsigned)((uintptr_t)base_p & 0xffffffffu)), [hi] "v"((unsigned)((uintptr_t)base_p >> 32)),
+                     [stride] "s"((unsigned)stride_bytes), [rm] "s"(rm)
+                   : "memory", "scc", TL_CLOB_SGPR, TL_CLOB_TMP, TL_CLOB_ACC);
+    if constexpr (CPL == 2) {
+      if (lane * CPL + 1 == ncols)
+        asm volatile(TL_ASM_STORE1_PERM
+                     :
+                     : [lo] "v"((unsigned)((uintptr_t)base_p & 0xffffffffu)), [hi] "v"((unsigned)((uintptr_t)base_p >> 32)),
+                       [stride] "s"((unsigned)stride_bytes), [rm] "s"(rm)
+                     : "memory", "scc", TL_CLOB_SGPR, TL_CLOB_TMP);
+    }
+    return;
+  }
   if (lane * CPL + CPL <= ncols)
     asm volatile(TL_ASM_STORE
                  :
@@ -709,8 +744,9 @@ extern "C" int spamd_spmm_tiled_fill(int val_dtype, int idx_dtype, int64_t M, in
 
 template <typename I, typename T>
 static int tl_launch_inspect(int64_t M, int64_t ntiles, const T* a_data, const I* a_indices, const I* a_indptr,
-                             unsigned long long* state, int* blk_off, int* blocks, hipStream_t s) {
-  const int64_t groups = tl_grid_groups(M);
+                             unsigned long long* state, int* blk_off, int* blocks, hipStream_t s, int64_t map_groups = 0,
+                             const int* rowmap = nullptr, const int64_t* vstart = nullptr) {
+  const int64_t groups = rowmap ? map_groups : tl_grid_groups(M);
   const int lds = (int)((2 * TL_RG * ntiles + ntiles + 1) * sizeof(int));
   auto kern = &tl_inspect_kernel<I, T>;
   if (lds > 48 * 1024) {
@@ -718,8 +754,83 @@ static int tl_launch_inspect(int64_t M, int64_t ntiles, const T* a_data, const I
     if (e != hipSuccess) return (int)e;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(256), lds, s, M, (int)ntiles, groups, a_data, a_indices, a_indptr,
-                     state, blk_off, blocks);
+                     state, blk_off, blocks, rowmap, vstart);
   return launch_status();
+}
+
+// ---- balanced layouts for skewed matrices (round 5) -----------------------------------------------------------------------
+// The natural layout gives wave w of a workgroup the 35 CONSECUTIVE rows of its group.  A wave works through its list of a
+// tile at ~65 cycles per entry whatever its neighbours do (a chain of scalar-load, LDS and FMA latencies: the 16 waves of a
+// workgroup hide each other's, not their own), and every tile ends with a barrier: a tile phase lasts as long as the LONGEST
+// of the 16 lists.  With Zipf row lengths (a real graph; every bench row until round 5 was uniform `random`) one wave's lists
+// are 9x the mean while its 15 neighbours wait - 3.5 ms for config 2's 10^8 elements instead of 0.85.  A balanced layout
+// gives every group a ROW MAP instead:
+//   * rows are sorted by length, longest first (stable), and classed against a cap C (a power of two, ~2 x the mean group):
+//     longer than C/2 -> a group of its own, C/4 -> two to a group, C/8 -> 4, C/16 -> 8, C/32 -> 16, everything else 35 to a
+//     group (the unused slots of a group are -1 and cost a zeroed register pair);
+//   * groups are numbered in that order, so the 16 groups of a workgroup hold rows of nearly the same length: every phase's
+//     16 lists are equally long, whether they hold 160 entries (full rows) or 20.  (Dealing the groups to the workgroups like
+//     cards - every workgroup the same mix - was built first and measured: 3.7 ms; the heaviest list still sets each phase.)
+//     Heavy workgroups come first, so the tail of the launch is made of light ones;
+//   * the inspector reads a group's rows through the map (`vstart` = stored elements before each group, for the closed-form
+//     block offsets), the executor stores them through it (TL_ASM_STORE_PERM).  Nothing else changes: the entries, the lists
+//     and the order in which an output element's terms are added are the same, so the product is bit-identical.
+constexpr int TL_MAP_CLASSES = 6;
+__host__ __device__ inline int tl_map_slots(int c) { return c == 5 ? TL_RG : (1 << c); }
+__host__ __device__ inline int tl_map_class(int64_t len, int64_t cap) {
+  return len > cap / 2 ? 0 : (len > cap / 4 ? 1 : (len > cap / 8 ? 2 : (len > cap / 16 ? 3 : (len > cap / 32 ? 4 : 5))));
+}
+
+// keys[r] = maxlen - length of row r (ascending keys = longest rows first), rows[r] = r; stats[0..5] += rows per class,
+// stats[6] = max stored elements of a NATURAL group
+template <typename I>
+__global__ void __launch_bounds__(256) tl_map_stats_kernel(int64_t M, int64_t cap, int64_t maxlen, const I* __restrict__ indptr,
+                                                           int64_t* __restrict__ keys, int* __restrict__ rows,
+                                                           unsigned long long* __restrict__ stats) {
+  __shared__ unsigned cnt[TL_MAP_CLASSES];
+  __shared__ unsigned long long gmax;
+  if (threadIdx.x < TL_MAP_CLASSES) cnt[threadIdx.x] = 0;
+  if (threadIdx.x == 0) gmax = 0;
+  __syncthreads();
+  unsigned long long mine = 0;
+  GRID_STRIDE(r, M) {
+    const int64_t a = (int64_t)indptr[r], len = (int64_t)indptr[r + 1] - a;
+    const int c = tl_map_class(len, cap);
+    keys[r] = len < maxlen ? maxlen - len : 0;
+    rows[r] = (int)r;
+    atomicAdd(&cnt[c], 1u);
+    if (r % TL_RG == 0) {
+      const int64_t e = r + TL_RG < M ? r + TL_RG : M;
+      const unsigned long long load = (unsigned long long)((int64_t)indptr[e] - a);
+      mine = load > mine ? load : mine;
+    }
+  }
+  if (mine) atomicMax(&gmax, mine);
+  __syncthreads();
+  if (threadIdx.x < TL_MAP_CLASSES && cnt[threadIdx.x]) atomicAdd(&stats[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
+  if (threadIdx.x == 0 && gmax) atomicMax(&stats[6], gmax);
+}
+
+struct TlMapPlan {
+  int64_t cstart[TL_MAP_CLASSES];   // first sorted position of every class
+  int64_t gstart[TL_MAP_CLASSES];   // first group of every class
+};
+
+// rows_sorted = the rows by descending length (stable; classes are then contiguous): fills rowmap[groups * TL_RG] (pre-set to -1) and gload[groups] (zeroed)
+template <typename I>
+__global__ void __launch_bounds__(256) tl_map_build_kernel(int64_t M, int64_t cap, const I* __restrict__ indptr,
+                                                           const int* __restrict__ rows_sorted, TlMapPlan plan,
+                                                           int* __restrict__ rowmap, unsigned long long* __restrict__ gload) {
+  GRID_STRIDE(i, M) {
+    const int r = rows_sorted[i];
+    const int64_t len = (int64_t)indptr[r + 1] - (int64_t)indptr[r];
+    const int c = tl_map_class(len, cap);
+    const int64_t j = i - plan.cstart[c];
+    const int sl = tl_map_slots(c);
+    const int64_t group = plan.gstart[c] + j / sl;
+    rowmap[group * TL_RG + (int)(j % sl)] = r;
+    if (len) atomicAdd(&gload[group], (unsigned long long)len);
+  }
 }
 
 // One-pass inspector for CSR with sorted column indices and at most `direct_max_tiles` tiles: fills
@@ -744,6 +855,85 @@ extern "C" int spamd_spmm_tiled_inspect(int val_dtype, int idx_dtype, int64_t M,
                                          (unsigned long long*)state, blk_off, blocks, (hipStream_t)stream);
     return tl_launch_inspect<I, double>(M, ntiles, (const double*)a_data, (const I*)a_indices, (const I*)a_indptr,
                                         (unsigned long long*)state, blk_off, blocks, (hipStream_t)stream);
+  })
+  return SPAMD_ETYPE;
+}
+
+// Balanced layouts, step 1: keys[M] = K - length of every row (int64: the sort key - ascending = longest rows first; a row
+// holds at most K elements), rows[M] = 0 .. M - 1 (the sort's payload), stats[8] (zeroed here): rows per class against `cap`
+// [0..5], the largest natural group's stored elements [6].  The caller reads stats (one small read-back), decides (natural
+// layout when [6] is close to the mean group), sorts rows by key (stable) and calls spamd_spmm_tiled_map_build.
+extern "C" int spamd_spmm_tiled_map_stats(int idx_dtype, int64_t M, int64_t K, int64_t cap, const void* a_indptr, int64_t* keys,
+                                          int* rows, int64_t* stats, void* stream) {
+  if (M < 0 || M >= ((int64_t)1 << 31) || K <= 0 || cap < 32 || (cap & (cap - 1)) || !keys || !rows || !stats) return SPAMD_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipError_t e = hipMemsetAsync(stats, 0, 8 * sizeof(int64_t), s); e != hipSuccess) return (int)e;
+  if (M == 0) return 0;
+  SPAMD_DISPATCH_IDX(idx_dtype, I, {
+    hipLaunchKernelGGL((tl_map_stats_kernel<I>), dim3(tl_blocks_for(M)), dim3(256), 0, s, M, cap, K, (const I*)a_indptr, keys, rows,
+                       (unsigned long long*)stats);
+    return launch_status();
+  })
+  return SPAMD_ETYPE;
+}
+
+// groups of a balanced layout for these class counts (a multiple of the groups per workgroup); -1 on bad arguments
+extern "C" int64_t spamd_spmm_tiled_map_groups(const int64_t* class_counts) {
+  if (!class_counts) return -1;
+  int64_t g = 0;
+  for (int c = 0; c < TL_MAP_CLASSES; ++c) {
+    if (class_counts[c] < 0) return -1;
+    g += ceil_div(class_counts[c], (int64_t)tl_map_slots(c));
+  }
+  return ceil_div(g, (int64_t)TL_WAVES) * TL_WAVES;
+}
+
+// Balanced layouts, step 2: rows_sorted = the rows by descending length (stable sort of step 1's keys), class_counts = stats[0..5]
+// (HOST array).  Fills rowmap[groups * rows_per_group + 16] (every unused slot -1) and gload[groups + 1] (stored elements of
+// every group, then one zero: the caller's exclusive scan of it is the `vstart` of spamd_spmm_tiled_inspect_mapped).
+extern "C" int spamd_spmm_tiled_map_build(int idx_dtype, int64_t M, int64_t cap, const void* a_indptr, const int* rows_sorted,
+                                          const int64_t* class_counts, int* rowmap, int64_t* gload, void* stream) {
+  const int64_t groups = spamd_spmm_tiled_map_groups(class_counts);
+  if (M < 0 || M >= ((int64_t)1 << 31) || groups <= 0 || !rowmap || !gload || !rows_sorted) return SPAMD_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipError_t e = hipMemsetAsync(rowmap, 0xff, (size_t)(groups * TL_RG + 16) * sizeof(int), s); e != hipSuccess) return (int)e;
+  if (hipError_t e = hipMemsetAsync(gload, 0, (size_t)(groups + 1) * sizeof(int64_t), s); e != hipSuccess) return (int)e;
+  TlMapPlan plan;
+  int64_t pos = 0, g = 0;
+  for (int c = 0; c < TL_MAP_CLASSES; ++c) {
+    plan.cstart[c] = pos;
+    plan.gstart[c] = g;
+    pos += class_counts[c];
+    g += ceil_div(class_counts[c], (int64_t)tl_map_slots(c));
+  }
+  if (pos != M) return SPAMD_EINVAL;
+  if (M == 0) return 0;
+  SPAMD_DISPATCH_IDX(idx_dtype, I, {
+    hipLaunchKernelGGL((tl_map_build_kernel<I>), dim3(tl_blocks_for(M)), dim3(256), 0, s, M, cap, (const I*)a_indptr, rows_sorted,
+                       plan, rowmap, (unsigned long long*)gload);
+    return launch_status();
+  })
+  return SPAMD_ETYPE;
+}
+
+// The one-pass inspector on a balanced layout: as spamd_spmm_tiled_inspect, with `groups` row groups whose rows come from
+// `rowmap` and vstart[groups + 1] = stored elements before every group (and the total).  blk_off[groups * (tiles + 1)].
+extern "C" int spamd_spmm_tiled_inspect_mapped(int val_dtype, int idx_dtype, int64_t M, int64_t K, int64_t groups,
+                                               const void* a_data, const void* a_indices, const void* a_indptr,
+                                               const int* rowmap, const int64_t* vstart, void* state, int* blk_off, int* blocks,
+                                               void* stream) {
+  if (M < 0 || K <= 0 || groups <= 0 || groups % TL_WAVES || !rowmap || !vstart) return SPAMD_EINVAL;
+  if (!tl_epb(val_dtype)) return SPAMD_ETYPE;
+  const int64_t ntiles = ceil_div(K, (int64_t)TL_KB);
+  if (ntiles > TL_DIRECT_MAX_TILES) return SPAMD_EINVAL;
+  hipError_t e = hipMemsetAsync(state, 0, sizeof(unsigned long long), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  SPAMD_DISPATCH_IDX(idx_dtype, I, {
+    if (val_dtype == SPAMD_F32)
+      return tl_launch_inspect<I, float>(M, ntiles, (const float*)a_data, (const I*)a_indices, (const I*)a_indptr,
+                                         (unsigned long long*)state, blk_off, blocks, (hipStream_t)stream, groups, rowmap, vstart);
+    return tl_launch_inspect<I, double>(M, ntiles, (const double*)a_data, (const I*)a_indices, (const I*)a_indptr,
+                                        (unsigned long long*)state, blk_off, blocks, (hipStream_t)stream, groups, rowmap, vstart);
   })
   return SPAMD_ETYPE;
 }
@@ -1265,21 +1455,41 @@ static int tl_set_lds_once(const void* kern) { return set_max_dynamic_lds(kern, 
 
 template <typename T, typename KERN>
 static int tl_launch(KERN kern, int64_t M, int64_t K, int64_t N, const int* blocks, const int* blk_off, const T* b,
-                     int64_t ldb, T* out, int64_t ldo, int touch_lines, bool group_ends, int last_cols, hipStream_t s) {
+                     int64_t ldb, T* out, int64_t ldo, int touch_lines, bool group_ends, int last_cols, hipStream_t s,
+                     const int* rowmap = nullptr, int64_t map_groups = 0) {
   // the 160 KB dynamic-LDS opt-in is a per-function attribute: set once per kernel, not on every multiply
   if (int rc = tl_set_lds_once(reinterpret_cast<const void*>(kern))) return rc;
-  const int64_t blocks_n = tl_grid_groups(M) / TL_WAVES;
+  const int64_t blocks_n = (rowmap ? map_groups : tl_grid_groups(M)) / TL_WAVES;
   const int64_t npanels = N / TlFmt<T>::PANEL;
   const int64_t grid = ceil_div(blocks_n, (int64_t)8) * 8 * (npanels > 1 ? ceil_div(npanels, (int64_t)2) * 2 : 1);
   if (grid >= ((int64_t)1 << 31) || blocks_n >= ((int64_t)1 << 31)) return SPAMD_EINVAL;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(TL_WAVES * 64), TL_LDS, s, M, K,
                      (int)ceil_div(K, (int64_t)TL_KB), touch_lines | (group_ends ? 1 << 16 : 0), blocks, blk_off, b, ldb, out, ldo,
-                     last_cols, (int)npanels, (int)blocks_n);
+                     last_cols, (int)npanels, (int)blocks_n, rowmap);
   return launch_status();
 }
 
+static int tl_product(int val_dtype, int64_t M, int64_t K, int64_t N, const int* blocks, const int* blk_off, const void* b,
+                      int64_t ldb, void* out, int64_t ldo, unsigned flags, void* stream, const int* rowmap, int64_t map_groups);
+
 extern "C" int spamd_spmm_tiled(int val_dtype, int64_t M, int64_t K, int64_t N, const int* blocks, const int* blk_off,
                                 const void* b, int64_t ldb, void* out, int64_t ldo, unsigned flags, void* stream) {
+  return tl_product(val_dtype, M, K, N, blocks, blk_off, b, ldb, out, ldo, flags, stream, nullptr, 0);
+}
+
+// The executor on a BALANCED layout (spamd_spmm_tiled_map_* / spamd_spmm_tiled_inspect_mapped): `groups` row groups (a
+// multiple of the groups per workgroup), rowmap[groups * rows_per_group + 16] = the row of every slot (negative: unused).
+// Everything else as spamd_spmm_tiled (the layout always carries per-group ends: SPAMD_TILED_GROUP_ENDS is implied).
+extern "C" int spamd_spmm_tiled_mapped(int val_dtype, int64_t M, int64_t groups, int64_t K, int64_t N, const int* blocks,
+                                       const int* blk_off, const int* rowmap, const void* b, int64_t ldb, void* out, int64_t ldo,
+                                       unsigned flags, void* stream) {
+  if (!rowmap || groups <= 0 || groups % TL_WAVES) return SPAMD_EINVAL;
+  if (ldo * (val_dtype == SPAMD_F32 ? 4 : 8) >= ((int64_t)1 << 32)) return SPAMD_EINVAL;   // (32-bit row pitch in the mapped store)
+  return tl_product(val_dtype, M, K, N, blocks, blk_off, b, ldb, out, ldo, flags | SPAMD_TILED_GROUP_ENDS, stream, rowmap, groups);
+}
+
+static int tl_product(int val_dtype, int64_t M, int64_t K, int64_t N, const int* blocks, const int* blk_off, const void* b,
+                      int64_t ldb, void* out, int64_t ldo, unsigned flags, void* stream, const int* rowmap, int64_t map_groups) {
   if (!tl_epb(val_dtype)) return SPAMD_ETYPE;
   const int panel = val_dtype == SPAMD_F32 ? TlFmt<float>::PANEL : TlFmt<double>::PANEL;
   const int esz = val_dtype == SPAMD_F32 ? 4 : 8;
@@ -1309,8 +1519,8 @@ extern "C" int spamd_spmm_tiled(int val_dtype, int64_t M, int64_t K, int64_t N, 
   if (val_dtype == SPAMD_F64) {
     const double* bb = (const double*)b;
     double* oo = (double*)out;
-    return exact ? tl_launch<double>(&spmm_tiled_kernel<0, 5, double>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s)
-                 : tl_launch<double>(&spmm_tiled_kernel<0, 4, double>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s);
+    return exact ? tl_launch<double>(&spmm_tiled_kernel<0, 5, double>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s, rowmap, map_groups)
+                 : tl_launch<double>(&spmm_tiled_kernel<0, 4, double>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s, rowmap, map_groups);
   }
   const float* bb = (const float*)b;
   float* oo = (float*)out;
@@ -1319,12 +1529,12 @@ extern "C" int spamd_spmm_tiled(int val_dtype, int64_t M, int64_t K, int64_t N, 
   // reads/fma, 7 = neither DMA nor LDS reads nor fma.  The shipped library never reads the environment.
   const char* dbg_env = getenv("SPAMD_TILED_DBG");
   const int dbg = dbg_env ? atoi(dbg_env) : 0;
-  if (dbg == 2) return tl_launch<float>(&spmm_tiled_kernel<2, 0, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s);
-  if (dbg == 5) return tl_launch<float>(&spmm_tiled_kernel<0, 1, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s);
-  if (dbg == 6) return tl_launch<float>(&spmm_tiled_kernel<0, 2, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s);
-  if (dbg == 7) return tl_launch<float>(&spmm_tiled_kernel<2, 2, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s);
+  if (dbg == 2) return tl_launch<float>(&spmm_tiled_kernel<2, 0, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s, rowmap, map_groups);
+  if (dbg == 5) return tl_launch<float>(&spmm_tiled_kernel<0, 1, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s, rowmap, map_groups);
+  if (dbg == 6) return tl_launch<float>(&spmm_tiled_kernel<0, 2, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s, rowmap, map_groups);
+  if (dbg == 7) return tl_launch<float>(&spmm_tiled_kernel<2, 2, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s, rowmap, map_groups);
 #endif
-  if (i32) return tl_launch<float>(&spmm_tiled_kernel<0, 6, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s);
-  return exact ? tl_launch<float>(&spmm_tiled_kernel<0, 3, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s)
-               : tl_launch<float>(&spmm_tiled_kernel<0, 0, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s);
+  if (i32) return tl_launch<float>(&spmm_tiled_kernel<0, 6, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s, rowmap, map_groups);
+  return exact ? tl_launch<float>(&spmm_tiled_kernel<0, 3, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s, rowmap, map_groups)
+               : tl_launch<float>(&spmm_tiled_kernel<0, 0, float>, M, K, N, blocks, blk_off, bb, ldb, oo, ldo, touch, ends, last_cols, s, rowmap, map_groups);
 }

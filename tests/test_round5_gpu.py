@@ -157,3 +157,85 @@ def test_gcxs_elementwise_declines_what_it_must(sp):
     z = sp.GCXS((d, i, p), shape=x.shape, compressed_axes=(0,))
     assert _umath._gcxs_same_layout("add", z, x) is None
     assert np.array_equal((z + x).todense(), (x + x).todense())
+
+
+# ---- balanced (row-mapped) executor layouts for skewed matrices ----------------------------------------------------------------
+
+def _zipf_csr(M, K, nnz, seed, dtype=torch.float32):
+    from bench import make_powerlaw_csr_device
+
+    return make_powerlaw_csr_device(M, K, nnz, seed, dtype=dtype)
+
+
+@pytest.mark.parametrize("dtype,N", [(torch.float32, 128), (torch.float32, 77), (torch.float64, 64), (torch.float64, 130), (torch.int32, 128)])
+def test_balanced_layout_is_bit_identical_to_the_row_group_kernel(sp, orc, dtype, N):
+    """Zipf row lengths (the longest rows are full, 30 % are empty): the inspector classes the rows, deals the groups and the
+    executor reads / stores through the row map - every output element still adds its terms k-ascending, so the product is
+    the row-group kernel's bit for bit in both arithmetic modes, and the oracle's within 1e-6 x sum |a||b|."""
+    from sparse_amd import _kernels as K
+
+    M, Kd = 30_011, 2_000          # (not a multiple of the 35-row groups)
+    d, i, p = _zipf_csr(M, Kd, 3_000_000, 7, dtype=torch.float32 if dtype == torch.int32 else dtype)
+    if dtype == torch.int32:
+        d = (d * 100).to(torch.int32)
+        b = (torch.rand((Kd, N), device="cuda") * 10).to(torch.int32)
+    else:
+        b = torch.rand((Kd, N), device="cuda", dtype=dtype)
+    old = K.TILED_BALANCE_MIN_NNZ
+    try:
+        K.TILED_BALANCE_MIN_NNZ = 0
+        lay = K.csr_tiled_layout(d, i, p, M, Kd, dtype=dtype)
+    finally:
+        K.TILED_BALANCE_MIN_NNZ = old
+    assert lay.rowmap is not None and K.TILED_BALANCE_STATS["balanced"], K.TILED_BALANCE_STATS
+    rm = lay.rowmap[: lay.groups * 35].cpu().numpy()
+    used = np.sort(rm[rm >= 0])
+    assert np.array_equal(used, np.arange(M)), "every row sits in exactly one slot"
+    panel = 64 if dtype == torch.float64 else 128
+    npad = -(-N // panel) * panel
+    bp = torch.zeros((Kd, npad), dtype=dtype, device="cuda")
+    bp[:, :N] = b
+    for exact in (False, True):
+        got = K.dot_csr_ndarray_tiled(lay, (M, N), Kd, bp, exact=exact)
+        want = K.dot_csr_ndarray((M, N), d, i, p, b, exact=exact)
+        assert _bits(got) == _bits(want), f"exact={exact}"
+    hd, hi, hp, hb = (t.cpu().numpy() for t in (d, i, p, b))
+    ref = orc.dot_csr_ndarray((M, N), hd, hi, hp, hb)
+    if dtype == torch.int32:
+        assert np.array_equal(got.cpu().numpy(), ref)
+    else:
+        bound = orc.dot_csr_ndarray((M, N), np.abs(hd), hi, hp, np.abs(hb))
+        assert np.all(np.abs(K.dot_csr_ndarray_tiled(lay, (M, N), Kd, bp).cpu().numpy() - ref) <= 1e-6 * bound + 1e-30)
+        assert _bits(got) == _bits(torch.from_numpy(ref).cuda())       # exact mode: the reference's own bits
+
+
+def test_balanced_layout_through_the_product_api_and_the_natural_one_for_uniform_matrices(sp):
+    from sparse_amd import _dot, _kernels as K
+    from bench import make_csr_device
+
+    old = K.TILED_BALANCE_MIN_NNZ
+    try:
+        K.TILED_BALANCE_MIN_NNZ = 0
+        M, Kd, N = 80_000, 3_000, 128
+        d, i, p = _zipf_csr(M, Kd, 4_000_000, 9)
+        a = sp.GCXS((d, i, p), shape=(M, Kd), compressed_axes=(0,))
+        b = torch.rand((Kd, N), device="cuda")
+        r = a @ b
+        lay = (getattr(a, "_tiled_layouts", None) or {}).get(torch.float32)
+        assert lay is not None and lay.rowmap is not None, "the product API takes the balanced layout for a skewed operand"
+        assert torch.equal(r, K.dot_csr_ndarray((M, N), d, i, p, b))
+        assert torch.equal(a @ b, r)
+        # uniform `random` rows: the natural layout stays (its heaviest group is within TILED_BALANCE_SKEW of the mean)
+        du, iu, pu = make_csr_device(M, Kd, 0.015, seed=3)
+        lay_u = K.csr_tiled_layout(du, iu, pu, M, Kd)
+        assert lay_u.rowmap is None and not K.TILED_BALANCE_STATS["balanced"] and K.TILED_BALANCE_STATS["skew"] < 1.6
+        # unsorted column indices in a heavy row: reported like in the natural layout, the product recovers through the key sort
+        heavy = int(torch.argmax(p[1:] - p[:-1]))
+        lo = int(p[heavy])
+        i2, d2 = i.clone(), d.clone()
+        i2[lo], i2[lo + 1] = i[lo + 1], i[lo]
+        d2[lo], d2[lo + 1] = d[lo + 1], d[lo]
+        a2 = sp.GCXS((d2, i2, p), shape=(M, Kd), compressed_axes=(0,))
+        assert torch.allclose(a2 @ b, r, rtol=1e-5, atol=1e-5)
+    finally:
+        K.TILED_BALANCE_MIN_NNZ = old

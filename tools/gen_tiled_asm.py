@@ -415,6 +415,31 @@ def store1():
     return o
 
 
+def _store_perm(op, src):
+    """the wave's rows through a ROW MAP (round 5, balanced layouts): %[rm] points at the group's ROWS row numbers (int32;
+    negative = an unused slot of the group), row j goes to base + row[j] * stride.  The row numbers arrive with three scalar
+    loads (ROWS + 1 <= 36 dwords are readable), the address is the lane's base + a 64-bit scalar product."""
+    assert ROWS <= 35
+    t = BASE + 2
+    o = [f"v_mov_b32 v{BASE}, %[lo]", f"v_mov_b32 v{BASE + 1}, %[hi]",
+         "s_load_dwordx16 s[40:55], %[rm], 0x0", "s_load_dwordx16 s[56:71], %[rm], 0x40", "s_load_dwordx4 s[72:75], %[rm], 0x80",
+         "s_waitcnt lgkmcnt(0)"]
+    for j in range(ROWS):
+        o += [f"s_cmp_lt_i32 s{40 + j}, 0", f"s_cbranch_scc1 {200 + j}f",
+              f"s_mul_hi_u32 s89, s{40 + j}, %[stride]", f"s_mul_i32 s88, s{40 + j}, %[stride]",
+              f"v_lshl_add_u64 v[{t}:{t + 1}], s[88:89], 0, v[{BASE}:{BASE + 1}]",
+              f"{op} v[{t}:{t + 1}], {src(j)}, off nt", f"{200 + j}:"]
+    return o
+
+
+def store_perm():
+    return _store_perm("global_store_dwordx2", lambda j: f"v[{ACC0 + 2 * j}:{ACC0 + 1 + 2 * j}]")
+
+
+def store1_perm():
+    return _store_perm("global_store_dword", lambda j: f"v{ACC0 + 2 * j}")
+
+
 def zero():
     return [f"v_mov_b32 v{r}, 0" for r in range(JUNK, ACC0 + 2 * ROWS)]
 
@@ -461,6 +486,8 @@ def main():
            lit("TL_ASM_TILE0", tile0()),
            lit("TL_ASM_STORE", store()),
            lit("TL_ASM_STORE1", store1()),
+           lit("TL_ASM_STORE_PERM", store_perm()),
+           lit("TL_ASM_STORE1_PERM", store1_perm()),
            lit("TL_ASM_ZERO", zero()),
            f"#define TL_CLOB_SGPR {clob('s', 36, 95)}\n",
            f"#define TL_CLOB_TMP {clob('v', WADDR if STAGE else BASE, JUNK - 1)}\n",
