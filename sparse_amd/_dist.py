@@ -204,7 +204,8 @@ def all_gather_csr(data, indices, indptr, group=None):
     """All-gather row-block shards of a CSR matrix into the whole matrix on every rank — the
     exchange step of row-sharded SpGEMM (B's triplet, 0.8 GB for config 5).
     ONE size exchange ((stored elements, rows) per rank) and ONE collective: every rank packs its values, column indices
-    and row-pointer heads (relative to its own first pointer, so a shard may be a row-slice view of a larger CSR) into one
+    and row-pointer heads (relative to its own first pointer; a shard may be a row-slice view of a larger CSR: only its own
+    elements [indptr[0], indptr[-1]) are sent) into one
     byte buffer, 16-byte aligned sections, padded to the largest rank's; the receiver slices the three sections per rank and
     shifts rank r's heads by the stored elements of the ranks before it - the gathered pointers are the whole matrix's
     without a scan over the rows."""
@@ -212,9 +213,20 @@ def all_gather_csr(data, indices, indptr, group=None):
 
     world = dist.get_world_size(group)
     dev = data.device
-    nnz, rows = int(data.numel()), int(indptr.numel()) - 1
-    if int(indices.numel()) != nnz:
+    rows = int(indptr.numel()) - 1
+    if int(indices.numel()) != int(data.numel()):
         raise ValueError("data and indices differ in length")
+    # a shard may be a row-slice VIEW of a larger CSR with pointers not rebased: data / indices are then either the shard's
+    # own elements or the PARENT's arrays, of which [indptr[0], indptr[-1]) are the shard's (round-4 advice: the parent's
+    # arrays were sent from element 0)
+    first, last = (int(v) for v in torch.stack([indptr[0], indptr[-1]]).tolist()) if rows >= 0 and indptr.numel() else (0, 0)
+    nnz = last - first
+    if nnz == int(data.numel()):
+        pass                        # data / indices ARE the shard's elements (pointers rebased or not: heads are rebased below)
+    elif 0 <= first <= last <= int(data.numel()):
+        data, indices = data[first:last], indices[first:last]     # the parent's arrays: the shard's own piece of them
+    else:
+        raise ValueError("indptr does not describe data / indices (nor a slice of them)")
     got = torch.empty(2 * world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(got, torch.tensor([nnz, rows], dtype=torch.int64, device=dev), group=group)
     got = got.tolist()

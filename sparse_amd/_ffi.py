@@ -159,7 +159,9 @@ def check(code, what):
     if code != 0:
         kind = {-1: "invalid argument", -2: "unsupported dtype", -3: "workspace too small"}.get(
             code, f"hipError_t {code}" if code > 0 else f"error {code}")
-        raise HipBackendError(f"{what} failed: {kind}")
+        err = HipBackendError(f"{what} failed: {kind}")
+        err.code = code      # > 0: a hipError_t (a device fault, not a declined argument); < 0: SPAMD_E*
+        raise err
 
 
 CALLS = 0   # C-ABI calls made so far (a cheap counter: the benches report calls per operation from its differences)

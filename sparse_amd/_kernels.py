@@ -681,6 +681,9 @@ SPGEMM_BITMAP_MIN_MEAN = 1536   # mean products per row from which the per-row b
 SPGEMM_BITMAP_MAX_DUPS = 120    # expected products per row that share an output element with an earlier one (list of 512)
 
 
+_BITMAP_UNSUPPORTED = set()    # (device index, split form?) whose launch the library refused once
+
+
 def _spgemm_bitmap(vcode, it, n_row, n_inner, n_col, parts, total, a_indptr, a_indices, a_data, b_indptr, b_indices, b_data, dtr,
                    dev, s):
     """C = A @ B by csrc/spgemm_bitmap.hip: (data, int64 indices, int64 indptr), or None when a row (or part of a row)
@@ -692,9 +695,18 @@ def _spgemm_bitmap(vcode, it, n_row, n_inner, n_col, parts, total, a_indptr, a_i
     out_ptr = torch.empty(n_row + 1, dtype=torch.int64, device=dev)
     work = torch.empty(n_row * parts + 32, dtype=torch.int64, device=dev)
     bsplit = torch.empty(max(n_inner * (parts - 1), 1), dtype=it, device=dev) if parts > 1 else None
-    _ffi.call("spamd_spgemm_bitmap", vcode, code_of(it), n_row, n_inner, n_col, parts, ptr(a_indptr), ptr(a_indices), ptr(a_data),
-              ptr(b_indptr), ptr(b_indices), ptr(b_data), ptr(bsplit) if bsplit is not None else None, ptr(work), ptr(out_ptr),
-              ptr(out_idx), ptr(out_val), s)
+    if (dev.index, parts > 1) in _BITMAP_UNSUPPORTED:
+        return None
+    try:
+        _ffi.call("spamd_spgemm_bitmap", vcode, code_of(it), n_row, n_inner, n_col, parts, ptr(a_indptr), ptr(a_indices), ptr(a_data),
+                  ptr(b_indptr), ptr(b_indices), ptr(b_data), ptr(bsplit) if bsplit is not None else None, ptr(work), ptr(out_ptr),
+                  ptr(out_idx), ptr(out_val), s)
+    except _ffi.HipBackendError:
+        # the launch itself was refused (the 160 KB LDS opt-in on a part with less, a range / LDS check, the occupancy query):
+        # this form is not available on this device - remembered, and the next form (or the bucket kernels) takes the product
+        _BITMAP_UNSUPPORTED.add((dev.index, parts > 1))
+        SPGEMM_STATS["bitmap_refused"] = SPGEMM_STATS.get("bitmap_refused", 0) + 1
+        return None
     failed, zeros, nnz = (int(v) for v in torch.cat([work[1:3], out_ptr[-1:]]).tolist())   # ONE read-back
     if os.environ.get("SPAMD_BMK_PROF"):     # (-DBMK_PROF builds of csrc/spgemm_bitmap.hip: cycles per phase, thread 0 of every workgroup)
         SPGEMM_STATS["phase_cycles"] = work[4:20].tolist()

@@ -352,6 +352,7 @@ def _loose_all_equal(value, array):
 
 
 ELEMWISE_ON_DEVICE = True   # plain callables whose operations are exactly reproducible run on the device (`_trace`)
+DEVICE_FALLBACKS = {"untraceable": 0, "declined": 0}   # traced callables that fell back to the host evaluation, by reason
 
 
 def _on_device(func, ops, slots, keys, n, full_shape, out_dtype, devi):
@@ -387,8 +388,14 @@ def _on_device(func, ops, slots, keys, n, full_shape, out_dtype, devi):
             arrays.append(None)
     try:
         res = _trace.run(root, arrays, n, devi)
-    except (_trace.Untraceable, _ffi.HipBackendError, KeyError, TypeError, NotImplementedError):
-        return None     # (an operation / dtype pair the kernels decline is as untraceable as a data-dependent branch)
+    except (_trace.Untraceable, KeyError, TypeError, NotImplementedError):
+        DEVICE_FALLBACKS["untraceable"] += 1
+        return None     # (an operation / dtype pair the graph does not cover is as untraceable as a data-dependent branch)
+    except _ffi.HipBackendError as e:
+        if getattr(e, "code", 1) > 0:
+            raise       # a hipError_t is a device fault, not "this kernel declines the dtype": never masked by the host path
+        DEVICE_FALLBACKS["declined"] += 1
+        return None
     if res.dtype != torch_dtype(out_dtype):
         res = K.convert(res, torch_dtype(out_dtype))
     return res

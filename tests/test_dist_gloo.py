@@ -234,6 +234,10 @@ def _worker_calls_dist(rank, world, port, ret):
     # a shard whose pointers are NOT rebased (a row-slice view of the whole matrix's pointer array) gathers to the same matrix
     gd, gi, gp = _dist.all_gather_csr(sd, si, tbp[s0:s1 + 1])
     assert np.array_equal(gd.numpy(), bd) and np.array_equal(gi.numpy(), bi) and np.array_equal(gp.numpy(), bp)
+    # ... and so does one that hands over the PARENT's data / indices with those pointers (round-4 advice: they were sent from
+    # element 0, misaligning every rank's rows but the first's)
+    gd, gi, gp = _dist.all_gather_csr(torch.from_numpy(bd), torch.from_numpy(bi), tbp[s0:s1 + 1])
+    assert np.array_equal(gd.numpy(), bd) and np.array_equal(gi.numpy(), bi) and np.array_equal(gp.numpy(), bp)
 
     # ---- sharded_sddmm: mask rows and A rows co-sharded, Bt gathered
     Ms, Nc, Kd = 211, 157, 24
