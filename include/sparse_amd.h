@@ -448,6 +448,18 @@ int spamd_spgemm_pack(int val_dtype, int64_t n_row, const int64_t* prod_off, con
  *     trims to out_indptr[n_row]); work = n_row + 32 int64 words, zeroed here: afterwards work[1] != 0 = a row was outside
  *     the limits (discard the result, use spamd_spgemm_rows), work[2] = values written whose bits are all zero. */
 int64_t spamd_spgemm_bitmap_limits(int val_dtype, int which);
+/* A4 / A5 for SMALL operands (round 5): the reference's row loop (`_dot_csr_csr`, _common.py:639-717: a dense accumulator per
+ * output row, the row's A elements in storage order) with a WAVE per output row, accumulator and touched-column bitmap in LDS,
+ * rows written column-sorted to their final place through a look-back over the rows - ONE launch, one read-back.  The sizes
+ * of the reference's own benchmark (benchmarks/test_benchmark_coo.py:9-40) are launch-bound on the general path.
+ * out_indices / out_data: room for n_row * n_col entries; work: n_row + 4 words (zeroed here); afterwards work[1] != 0 = failed
+ * (a B row not strictly ascending or out of range: discard, use the general path), work[2] = exact zeros written.
+ * n_col <= spamd_spgemm_small_max_cols(val_dtype). */
+int64_t spamd_spgemm_small_max_cols(int val_dtype);
+int spamd_spgemm_small(int val_dtype, int idx_dtype, int64_t n_row, int64_t n_col, const void* a_indptr, const void* a_indices,
+                       const void* a_data, const void* b_indptr, const void* b_indices, const void* b_data, int64_t* work,
+                       int64_t* out_indptr, int64_t* out_indices, void* out_data, void* stream);
+
 /* parts = 1: whole rows, one 1024-thread workgroup per CU (n_col <= limit 2).  parts > 1: every row in `parts`
  * column ranges (ceil(n_col / parts) rounded up to 256 <= limit 5), 512-thread workgroups, two per CU; bsplit = n_inner *
  * (parts - 1) words of the index type (workspace, filled here: where each B row crosses a range boundary), n_inner = rows

@@ -160,6 +160,8 @@ def gcxs_prune(x):
     """Remove stored fill values, rebuilding indptr (reference compressed.py:816-848)."""
     if x.nnz == 0:
         return
+    if K.known_eq_bits(x.data, x.fill_value) == 0:     # (the kernel that wrote the values counted its exact zeros: nothing to read)
+        return
     if x.nnz >= K.PRUNE_COUNT_FIRST and K.count_eq_bits(x.data, x.fill_value) == 0:
         return
     flags = K.flag_ne_bits(x.data, x.fill_value)

@@ -207,6 +207,8 @@ class COO(SparseArray, NDArrayOperatorsMixin):
         """Drop stored elements bit-identical to the fill value (reference core.py:1355-1371)."""
         if self.nnz == 0:
             return
+        if K.known_eq_bits(self.data, self.fill_value) == 0:     # (the kernel that wrote the values counted its exact zeros: nothing to read)
+            return
         if self.nnz >= K.PRUNE_COUNT_FIRST and K.count_eq_bits(self.data, self.fill_value) == 0:
             return
         flags = K.flag_ne_bits(self.data, self.fill_value)

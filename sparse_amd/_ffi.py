@@ -109,6 +109,8 @@ SIGNATURES = {
     "spamd_spgemm_row_products": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spamd_spgemm_rows_capacity": (_i64, [_int, _i64, _i64]),
     "spamd_spgemm_rows": (_int, [_int, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "spamd_spgemm_small_max_cols": (_i64, [_int]),
+    "spamd_spgemm_small": (_int, [_int, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spamd_spgemm_bitmap_limits": (_i64, [_int, _int]),
     "spamd_spgemm_bitmap": (_int, [_int, _int, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spamd_spgemm_classify_rows": (_int, [_int, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),

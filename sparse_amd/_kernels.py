@@ -352,6 +352,16 @@ def note_zero_bits_count(data, count):
     data._zero_bits_count = (count, data._version)
 
 
+def known_eq_bits(data, fill_value):
+    """The number of stored elements bit-identical to `fill_value` when the producer of `data` left it on the tensor
+    (`note_zero_bits_count`: all-zero bits only) and the tensor was not written since; None otherwise.  No device work."""
+    known = getattr(data, "_zero_bits_count", None)
+    if known is None or known[1] != data._version or data.numel() == 0:
+        return None
+    bits, bits_hi = _fill_words(fill_value, np_dtype(data.dtype))
+    return known[0] if bits == 0 and bits_hi == 0 else None
+
+
 def count_eq_bits(data, fill_value):
     """Number of stored elements bit-identical to fill_value (one read-only pass)."""
     dev = require_hip(data)
@@ -746,10 +756,52 @@ def _spgemm_bitmap_forms(vcode, n_col, max_prod):
     return forms
 
 
+SPGEMM_SMALL = True
+SPGEMM_SMALL_MAX_CELLS = 1 << 22     # n_row x n_col of the result: its upper-bound buffers (12-16 B per cell) stay below 64 MB
+SPGEMM_SMALL_MAX_NNZ = 1 << 16       # stored elements of A (a wave walks its row's elements one after the other): beyond this the
+                                     # kernels that spread a row's products over a workgroup have enough work to pay their set-up
+
+
+def _spgemm_small(n_row, n_col, a_data, a_indices, a_indptr, b_data, b_indices, b_indptr):
+    """csrc/spgemm_small.hip: the whole product in one launch and one read-back (the reference's own benchmark sizes,
+    benchmarks/test_benchmark_coo.py:9-40, are launch-bound on the general path: 230-300 us against ~70).  None when the
+    operands are outside its limits or B is not canonical (the caller takes the general path)."""
+    dev = require_hip(a_data, b_data)
+    dtr = torch_dtype(dot_dtype(a_data.dtype, b_data.dtype))
+    try:
+        vcode = code_of(dtr)
+    except TypeError:
+        return None
+    if n_row == 0 or n_col > int(_ffi.lib().spamd_spgemm_small_max_cols(vcode)):
+        return None
+    a_data = a_data.to(dtr).contiguous() if a_data.dtype != dtr else a_data.contiguous()
+    b_data = b_data.to(dtr).contiguous() if b_data.dtype != dtr else b_data.contiguous()
+    (a_indices, a_indptr, b_indices, b_indptr), it = _unify_index(a_indices.contiguous(), a_indptr.contiguous(),
+                                                                  b_indices.contiguous(), b_indptr.contiguous())
+    cells = n_row * n_col
+    out_idx = torch.empty(cells, dtype=torch.int64, device=dev)
+    out_val = torch.empty(cells, dtype=dtr, device=dev)
+    head = torch.empty(2 * n_row + 8, dtype=torch.int64, device=dev)      # [work (n_row + 4) | out_indptr (n_row + 1)]: one buffer, one read-back
+    work, out_ptr = head[: n_row + 4], head[n_row + 4: 2 * n_row + 5]
+    _ffi.call("spamd_spgemm_small", vcode, code_of(it), n_row, n_col, ptr(a_indptr), ptr(a_indices), ptr(a_data), ptr(b_indptr),
+              ptr(b_indices), ptr(b_data), ptr(work), ptr(out_ptr), ptr(out_idx), ptr(out_val), stream_ptr(dev))
+    failed, zeros, nnz = (int(v) for v in head[1:4].tolist())      # ONE read-back (three adjacent words)
+    if failed:
+        return None
+    out_idx, out_val = (out_idx[:nnz].clone(), out_val[:nnz].clone()) if nnz * 4 < cells * 3 else (out_idx[:nnz], out_val[:nnz])
+    note_zero_bits_count(out_val, zeros)
+    SPGEMM_STATS.update(kernel="small", rows=n_row, heavy_or_declined=0)
+    return out_val, out_idx, out_ptr
+
+
 def _spgemm_rows(n_row, n_col, a_data, a_indices, a_indptr, b_data, b_indices, b_indptr):
     """Row-local SpGEMM (csrc/spgemm_rows.hip): (data, int64 indices, int64 indptr) of A @ B.  Rows too heavy for LDS
     are computed by the global expand-sort-compress and merged in; None when most of the work is in such rows (the
     caller then uses the global form throughout)."""
+    if SPGEMM_SMALL and n_row * n_col <= SPGEMM_SMALL_MAX_CELLS and int(a_data.numel()) <= SPGEMM_SMALL_MAX_NNZ:
+        res = _spgemm_small(n_row, n_col, a_data, a_indices, a_indptr, b_data, b_indices, b_indptr)
+        if res is not None:
+            return res
     dev = require_hip(a_data, b_data)
     dtr = torch_dtype(dot_dtype(a_data.dtype, b_data.dtype))
     vcode = code_of(dtr)

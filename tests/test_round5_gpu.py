@@ -239,3 +239,60 @@ def test_balanced_layout_through_the_product_api_and_the_natural_one_for_uniform
         assert torch.allclose(a2 @ b, r, rtol=1e-5, atol=1e-5)
     finally:
         K.TILED_BALANCE_MIN_NNZ = old
+
+
+# ---- the small sparse @ sparse product in one launch -------------------------------------------------------------------------
+
+@pytest.mark.parametrize("dtype,idt", [(np.float64, np.int64), (np.float32, np.int32), (np.int64, np.int64), (np.int32, np.int32)])
+@pytest.mark.parametrize("m,k,n,da,db", [(200, 200, 200, 0.01, 0.01), (1000, 1000, 1000, 0.01, 0.01), (37, 500, 4000, 0.2, 0.05),
+                                         (300, 64, 7000, 0.5, 0.3), (1, 10, 10, 1.0, 1.0), (500, 300, 33, 0.05, 0.5)])
+def test_small_spgemm_equals_the_general_path_and_the_oracle(sp, orc, dtype, idt, m, k, n, da, db):
+    from sparse_amd import _kernels as K
+    from util import random_csr
+
+    ad, ai, ap = random_csr(m, k, da, 1, dtype, idt, empty_rows=(0,) if m > 3 else ())
+    bd, bi, bp = random_csr(k, n, db, 2, dtype, idt, empty_rows=(1,) if k > 3 else ())
+    dev = [torch.from_numpy(x).cuda() for x in (ad, ai, ap, bd, bi, bp)]
+    if n > int(__import__("sparse_amd")._ffi.lib().spamd_spgemm_small_max_cols(K.code_of(dev[0].dtype))):
+        pytest.skip("wider than the kernel's accumulator")
+    got = K._spgemm_small(m, n, dev[0], dev[1], dev[2], dev[3], dev[4], dev[5])
+    assert got is not None
+    old = K.SPGEMM_SMALL
+    try:
+        K.SPGEMM_SMALL = False
+        want = K.dot_csr_csr((m, n), dev[0], dev[3], dev[1], dev[4], dev[2], dev[5])
+    finally:
+        K.SPGEMM_SMALL = old
+    for g, w in zip(got, want):
+        assert g.dtype == w.dtype and _bits(g) == _bits(w)
+    wd, wi, wp = orc.dot_csr_csr((m, n), ad, bd, ai, bi, ap, bp)
+    gd, gi, gp = (t.cpu().numpy() for t in got)
+    assert np.array_equal(gp, wp)
+    for r in range(m):
+        o = np.argsort(wi[wp[r]:wp[r + 1]], kind="stable")      # the reference emits rows in reverse discovery order
+        assert np.array_equal(gi[gp[r]:gp[r + 1]], wi[wp[r]:wp[r + 1]][o])
+        assert gd[gp[r]:gp[r + 1]].tobytes() == wd[wp[r]:wp[r + 1]][o].tobytes()
+
+
+def test_small_spgemm_through_the_api_and_its_fallback(sp):
+    from sparse_amd import _kernels as K
+
+    x = sp.random((300, 400), density=0.02, random_state=1, format="gcxs", compressed_axes=(0,))
+    y = sp.random((400, 250), density=0.02, random_state=2, format="gcxs", compressed_axes=(0,))
+    K.SPGEMM_STATS.clear()
+    z = x @ y
+    assert K.SPGEMM_STATS.get("kernel") == "small"
+    assert np.allclose(z.todense(), x.todense() @ y.todense(), rtol=1e-13, atol=0)
+    xc, yc = x.asformat("coo"), y.asformat("coo")
+    assert np.array_equal((xc @ yc).todense(), z.todense())
+    # a B row with unsorted columns: the kernel reports it, the general path (which does not depend on B's order) answers
+    d, i, p = y.data.clone(), y.indices.clone(), y.indptr.clone()
+    r = int(torch.nonzero(p[1:] - p[:-1] >= 2)[0])
+    lo = int(p[r])
+    i[lo], i[lo + 1] = i[lo + 1].clone(), i[lo].clone()
+    d[lo], d[lo + 1] = d[lo + 1].clone(), d[lo].clone()
+    y2 = sp.GCXS((d, i, p), shape=y.shape, compressed_axes=(0,))
+    K.SPGEMM_STATS.clear()
+    z2 = x @ y2
+    assert K.SPGEMM_STATS.get("kernel") != "small"
+    assert np.allclose(z2.todense(), z.todense(), rtol=1e-13, atol=0)
