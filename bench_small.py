@@ -69,7 +69,7 @@ def rel_err(got, want):
 
 
 def host(t):
-    return t.cpu().numpy()
+    return t if isinstance(t, np.ndarray) else t.cpu().numpy()
 
 
 def run(quick=False, profile=False, reps=200):

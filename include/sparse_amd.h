@@ -142,7 +142,7 @@ int spamd_spmm_tiled_inspect(int val_dtype, int idx_dtype, int64_t M, int64_t K,
  * inside every column) - no CSC -> CSR conversion: a K-tile is 160 whole columns of the CSC arrays and a workgroup's rows own
  * one short run per column.  ws = int32 workspace of spamd_spmm_tiled_inspect_csc_ws(M, K) words, 8-byte aligned;
  * state[0] != 0 afterwards: rows out of order - the lists are then EMPTY (blk_off all zero) and the caller converts to CSR.  Replaces, for `csc @ dense`, the reference's `_dot_csc_ndarray`
- * (_common.py:1118-1174) together with the conversion this backend needed before it. */
+ * (_common.py:869-904) together with the conversion this backend needed before it. */
 int64_t spamd_spmm_tiled_inspect_csc_ws(int64_t M, int64_t K);
 int spamd_spmm_tiled_inspect_csc(int val_dtype, int idx_dtype, int64_t M, int64_t K, const void* a_data,
                                  const void* a_indices, const void* a_indptr, int* ws, void* state, int* blk_off,

@@ -1,5 +1,5 @@
 """The CSC-native inspector (csrc/spmm_tiled.hip `tl_csc_*`, C ABI `spamd_spmm_tiled_inspect_csc`): the executor's block stream
-built from the CSC arrays of `csc @ dense` (reference `_dot_csc_ndarray`, _common.py:1118-1174) without a CSC -> CSR
+built from the CSC arrays of `csc @ dense` (reference `_dot_csc_ndarray`, _common.py:869-904) without a CSC -> CSR
 conversion.  Every product from it must be the row-group kernel's on the CSR arrays bit for bit (an output element's terms are
 added k-ascending by both)."""
 import numpy as np
@@ -119,3 +119,57 @@ def test_csc_inspector_more_row_groups_than_the_lds_histogram_holds():
     b = torch.rand((Kd, 64), device="cuda", dtype=torch.float64) - 0.5
     got = K.dot_csr_ndarray_tiled(K.csc_tiled_layout(cd, ci, cp, M, Kd), (M, 64), Kd, b)
     assert torch.equal(got, K.dot_csr_ndarray((M, 64), data, idx, ptr, b))
+
+
+# ---- against the ORACLE itself (round-4 verdict: the tests above compare with the row-group kernel, a second HIP path) ---------
+
+@pytest.mark.parametrize("dtype, itype", [(torch.float32, torch.int32), (torch.float64, torch.int64)])
+@pytest.mark.parametrize("M, Kd, density", [(3000, 700, 0.02), (560 * 3 + 1, 4000, 0.004), (1121, 321, 0.3)])
+def test_csc_inspector_products_against_the_oracle(orc, dtype, itype, M, Kd, density):
+    """the reference's own loop for a CSC operand (`_dot_csc_ndarray`, _common.py:893-902: out[indices[k]] += data[k] * b[j] per
+    column j) restated in oracle.c, on the CSC arrays the inspector reads: exact mode bit for bit, FMA mode within
+    1e-6 x sum |a||b| of it"""
+    from sparse_amd import _kernels as K
+
+    data, idx, ptr = _case(M, Kd, density, dtype, itype, seed=3)
+    cd, ci, cp = K.csx_swap_2d(data, idx, ptr, M, Kd)
+    n = 128 if dtype == torch.float32 else 64
+    b = torch.rand((Kd, n), device="cuda", dtype=dtype) - 0.5
+    lay = K.csc_tiled_layout(cd, ci, cp, M, Kd, dtype=dtype)
+    assert lay is not None
+    hd, hi, hp, hb = (t.cpu().numpy() for t in (cd, ci, cp, b))
+    want = orc.dot_csc_ndarray((M, Kd), (Kd, n), hd, hi, hp, hb)
+    exact = K.dot_csr_ndarray_tiled(lay, (M, n), Kd, b, exact=True).cpu().numpy()
+    assert exact.tobytes() == want.tobytes()
+    fma = K.dot_csr_ndarray_tiled(lay, (M, n), Kd, b).cpu().numpy()
+    bound = orc.dot_csc_ndarray((M, Kd), (Kd, n), np.abs(hd), hi, hp, np.abs(hb))
+    assert np.all(np.abs(fma - want) <= 1e-6 * bound + 1e-300)
+
+
+def test_default_operand_at_config2_size_against_the_oracle(sp, orc):
+    """the reference-default construction of BASELINE config 2 (float64 values, int64 indices, compressed by columns: CSC) through
+    `a @ b` - the CSC-native inspector + the float64 executor at full size - against the oracle's `_dot_csr_ndarray` loop on
+    2500 sampled rows (whole rows, gathered from the CSR arrays the operand was made from; exact mode: bit for bit)"""
+    from bench import make_csr_device
+    from sparse_amd import _settings
+
+    M, Kd, N = 1_000_000, 10_000, 128
+    d, i, p = make_csr_device(M, Kd, 0.01, seed=77, dtype=torch.float64)
+    a = sp.GCXS((d, i.to(torch.int64), p.to(torch.int64)), shape=(M, Kd), compressed_axes=(0,)).change_compressed_axes((1,))
+    assert a.compressed_axes == (1,) and a.data.dtype == torch.float64 and a.indices.dtype == torch.int64
+    b = torch.rand((Kd, N), device="cuda", dtype=torch.float64) - 0.5
+    old = _settings.EXACT_MULADD
+    try:
+        _settings.EXACT_MULADD = True
+        r = a @ b
+    finally:
+        _settings.EXACT_MULADD = old
+    assert getattr(a, "_tiled_layouts", None) and a.__dict__.get("_csr_twin") is None, "the CSC-native inspector, no CSR twin"
+    pick = np.sort(np.random.default_rng(5).choice(M, size=2500, replace=False))
+    hp = p.cpu().numpy()
+    seg = np.concatenate([np.arange(hp[r_], hp[r_ + 1]) for r_ in pick])
+    sub_ptr = np.zeros(len(pick) + 1, dtype=np.int64)
+    sub_ptr[1:] = np.cumsum([hp[r_ + 1] - hp[r_] for r_ in pick])
+    want = orc.dot_csr_ndarray((len(pick), N), d.cpu().numpy()[seg], i.cpu().numpy()[seg].astype(np.int64), sub_ptr, b.cpu().numpy())
+    got = r[torch.from_numpy(pick).cuda()].cpu().numpy()
+    assert got.tobytes() == want.tobytes()
