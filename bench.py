@@ -550,6 +550,18 @@ def main():
                 rl["paths_full"] = "previous stdout line + gpurun_out/paths.json"
             except Exception as e:
                 line["roofline"]["paths_error"] = repr(e)
+            # the reference's own benchmark sizes (bench_small.py; the full table: profiles/rNN_small_workloads.json): host-bound
+            # microseconds per call, a few representative cases beside the single-core oracle leg
+            try:
+                import bench_small
+
+                sw = bench_small.run(quick=True, reps=100)
+                pick = {"dense_1000^3_gcxs0": sw["dense"].get("1000x1000x1000_gcxs0"), "spsp_1000^3_gcxs": sw["spsp"].get("1000x1000x1000_gcxs"),
+                        "add_side1000_rank2_coo": sw["ewise"].get("add_side1000_rank2_coo"), "add_side1000_rank2_gcxs": sw["ewise"].get("add_side1000_rank2_gcxs")}
+                line["roofline"]["small_workloads_us"] = {k: {a: v[a] for a in ("us_sync", "us_pipe", "cpu_us") if a in v}
+                                                          for k, v in pick.items() if v}
+            except Exception as e:
+                line["roofline"]["small_workloads_error"] = repr(e)
         print(json.dumps(line, separators=(",", ":")), flush=True)
     if dist is not None:
         dist.barrier()

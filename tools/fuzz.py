@@ -6,7 +6,7 @@ import sys, time, numpy as np, torch
 sys.path.insert(0, "/root/repo")
 import sparse_amd as sp
 from sparse_amd import _kernels as K, _umath as U
-from bench import make_csr_device
+from bench import make_csr_device, make_powerlaw_csr_device
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 ONLY_SPMM = len(sys.argv) > 2 and sys.argv[2] == "spmm"   # with PYTORCH_NO_CUDA_MEMORY_CACHING=1: catches reads past a buffer
@@ -23,10 +23,18 @@ while time.time() < t_end:
     dt = torch.float32 if rng.random() < 0.5 else torch.float64
     panel = 128 if dt == torch.float32 else 64
     N = panel * int(rng.integers(1, 4))
-    data, idx, ptr = make_csr_device(M, Kd, dens, seed=int(rng.integers(1 << 30)), dtype=dt,
-                                     idx_dtype=torch.int32 if rng.random() < 0.7 else torch.int64)
+    it = torch.int32 if rng.random() < 0.7 else torch.int64
+    if rng.random() < 0.4 and M >= 513 and Kd >= 127 and dens > 0:
+        # round 5: Zipf row lengths (the balanced, row-mapped layout; full rows, 30 % empty rows) at any size
+        K.TILED_BALANCE_MIN_NNZ = 0
+        data, idx, ptr = make_powerlaw_csr_device(M, Kd, max(int(M * Kd * dens), 1), seed=int(rng.integers(1 << 30)), dtype=dt, idx_dtype=it,
+                                                  alpha=float(rng.choice([0.7, 1.0, 1.4])))
+        n["zipf"] = n.get("zipf", 0) + 1
+    else:
+        data, idx, ptr = make_csr_device(M, Kd, dens, seed=int(rng.integers(1 << 30)), dtype=dt, idx_dtype=it)
     b = torch.randn((Kd, N), device="cuda", dtype=dt)
     layout = K.csr_tiled_layout(data, idx, ptr, M, Kd)
+    n["balanced"] = n.get("balanced", 0) + (layout.rowmap is not None)
     for exact in (False, True):
         got = K.dot_csr_ndarray_tiled(layout, (M, N), Kd, b, exact=exact)
         ref = K.dot_csr_ndarray((M, N), data, idx, ptr, b, exact=exact)
