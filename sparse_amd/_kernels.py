@@ -1206,7 +1206,7 @@ class UnsortedColumns(ValueError):
     the layout (and the product just computed from it) is invalid; rebuild with `force_sort=True`."""
 
 
-def csr_tiled_layout(a_data, a_indices, a_indptr, M, Kd, force_sort=False, dtype=None, defer_check=False):
+def csr_tiled_layout(a_data, a_indices, a_indptr, M, Kd, force_sort=False, dtype=None, defer_check=False, balance=None):
     """Inspector: the K-tiled block stream of a CSR matrix used by `dot_csr_ndarray_tiled`, for float32 or float64
     values (`dtype`, default: a_data's if it is one of them, else float32).
     Returns (blocks int32[(total_blocks + slack) * 16], blk_off int32[nseg + 1], value dtype).
@@ -1215,7 +1215,11 @@ def csr_tiled_layout(a_data, a_indices, a_indptr, M, Kd, force_sort=False, dtype
     with zeroed blocks between them, and blk_off is int32[groups * (tiles + 1)]: `TiledLayout.group_ends`);
     anything else the general key-sort recipe.  The one-pass builder reports unsorted column indices in a device word;
     with `defer_check` that word is not read here (no host wait between the inspector and the first product):
-    `dot_csr_ndarray_tiled` reads it after enqueueing its first product and raises `UnsortedColumns`."""
+    `dot_csr_ndarray_tiled` reads it after enqueueing its first product and raises `UnsortedColumns`.
+    `balance` (round 5, skewed row lengths): None = decide - with `defer_check` the test itself is deferred as well (the natural
+    layout is built, the heaviest row group's size travels with the "unsorted" word and is read behind the first product,
+    which then marks the layout `rebalance` for its owner: no host wait on the common, unskewed path), without it the
+    statistics are read here; True = build the balanced layout if the operand is skewed at all, reading here; False = never."""
     dev = require_hip(a_data, a_indices, a_indptr)
     if dtype is None:
         dtype = a_data.dtype if a_data.dtype in TILED_DTYPES else torch.float32
@@ -1241,11 +1245,13 @@ def csr_tiled_layout(a_data, a_indices, a_indptr, M, Kd, force_sort=False, dtype
         fill(blk_off, total, blocks)
         return TiledLayout(blocks, convert(blk_off, torch.int32), dtype, total / max(nseg, 1))
 
-    if ntiles <= direct_max and not force_sort and TILED_ONE_PASS_INSPECTOR and TILED_BALANCE and nnz >= TILED_BALANCE_MIN_NNZ \
-            and 0 < M < 2 ** 31:
+    may_balance = (ntiles <= direct_max and not force_sort and TILED_ONE_PASS_INSPECTOR and TILED_BALANCE and balance is not False
+                   and nnz >= TILED_BALANCE_MIN_NNZ and 0 < M < 2 ** 31)
+    if may_balance and (balance or not defer_check):
         lay = _balanced_tiled_layout(vals, a_indices.contiguous(), a_indptr.contiguous(), M, Kd, dtype, nnz, defer_check, dev, s)
         if lay is not None:
             return lay
+        may_balance = False      # (measured here: not skewed)
     if ntiles <= direct_max and not force_sort and TILED_ONE_PASS_INSPECTOR:
         # one pass over A (csrc/spmm_tiled.hip `tl_inspect_kernel`): count, fill and padding in a single launch with no
         # dependence between row groups (a group's first block is a closed-form upper bound from the row pointers); the
@@ -1256,11 +1262,16 @@ def csr_tiled_layout(a_data, a_indices, a_indptr, M, Kd, force_sort=False, dtype
         if upper < 2 ** 31:
             blocks = torch.empty((upper + slack) * 16, dtype=torch.int32, device=dev)
             blk_off = torch.empty(groups * (ntiles + 1), dtype=torch.int32, device=dev)
-            state = torch.empty(1, dtype=torch.int64, device=dev)
+            state = torch.empty(9, dtype=torch.int64, device=dev)       # [0] unsorted columns; [1..8] = the skew statistics' eight words ([7] = heaviest natural group)
             _ffi.call("spamd_spmm_tiled_inspect", vc, ic, M, Kd, ptr(vals), ptr(ind), ptr(ptr_), ptr(state), ptr(blk_off),
                       ptr(blocks), s)
             if defer_check:
-                return TiledLayout(blocks, blk_off, dtype, nnz / epb / max(nseg, 1) + 0.5, group_ends=True, pending=state)
+                lay = TiledLayout(blocks, blk_off, dtype, nnz / epb / max(nseg, 1) + 0.5, group_ends=True, pending=state)
+                if may_balance:
+                    # the skew test rides along: the heaviest natural group (one thread per group) lands in state[7]
+                    _ffi.call("spamd_spmm_tiled_map_stats", ic, M, Kd, 32, ptr(ptr_), None, None, ptr(state) + 8, s)
+                    lay.skew_mean = nnz * rg / max(M, 1)
+                return lay
             if int(state[0]) == 0:      # (sorted column indices everywhere)
                 return TiledLayout(blocks, blk_off, dtype, nnz / epb / max(nseg, 1) + 0.5, group_ends=True)
     elif ntiles <= direct_max and not force_sort:
@@ -1305,15 +1316,18 @@ def _balanced_tiled_layout(vals, ind, ptr_, M, Kd, dtype, nnz, defer_check, dev,
     cap = 32
     while cap < TILED_BALANCE_CAPMUL * mean_group:
         cap *= 2
-    keys = torch.empty(M, dtype=torch.int64, device=dev)
-    rows = torch.empty(M, dtype=torch.int32, device=dev)
     stats = torch.empty(8, dtype=torch.int64, device=dev)
-    _ffi.call("spamd_spmm_tiled_map_stats", ic, M, Kd, cap, ptr(ptr_), ptr(keys), ptr(rows), ptr(stats), s)
+    _ffi.call("spamd_spmm_tiled_map_stats", ic, M, Kd, cap, ptr(ptr_), None, None, ptr(stats), s)    # statistics only: 4-8 B per row
     st = stats.tolist()                                   # (the one read-back of the decision)
     skew = st[6] / max(mean_group, 1.0)
     TILED_BALANCE_STATS.update(cap=cap, class_rows=st[:6], natural_max_group=st[6], skew=skew, balanced=False)
     if skew <= TILED_BALANCE_SKEW:
         return None
+    keys = torch.empty(M, dtype=torch.int64, device=dev)
+    rows = torch.empty(M, dtype=torch.int32, device=dev)
+    _ffi.call("spamd_spmm_tiled_map_stats", ic, M, Kd, cap, ptr(ptr_), ptr(keys), ptr(rows), ptr(stats), s)      # + the sort's keys and payload, rows per class
+    st = stats.tolist()
+    TILED_BALANCE_STATS.update(class_rows=st[:6])
     counts = _harr64(st[:6])
     groups = int(_ffi.lib().spamd_spmm_tiled_map_groups(counts))
     nseg = groups * ntiles
@@ -1409,6 +1423,10 @@ def dot_csr_ndarray_tiled(layout, out_shape, Kd, b, out=None, exact=False):
     pending = getattr(layout, "pending", None)
     if pending is not None:   # first product of a layout built with defer_check: the verdict is read now, behind the launch
         layout.pending = None
-        if int(pending[0]) != 0:
+        words = pending.tolist()
+        mean = getattr(layout, "skew_mean", None)
+        if mean and len(words) >= 8 and words[7] > TILED_BALANCE_SKEW * max(mean, 1.0):
+            layout.rebalance = True       # (the product just enqueued is correct; the owner rebuilds a balanced layout for the next ones)
+        if int(words[0]) != 0:
             raise UnsortedColumns("tiled layout built from rows with unsorted column indices")
     return out

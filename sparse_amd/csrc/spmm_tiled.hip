@@ -245,7 +245,7 @@ __host__ __device__ inline int64_t tl_group_first_block(int64_t e0, int64_t g, i
 // `rowmap` (round 5, balanced layouts): the group's TL_RG rows are rowmap[g * TL_RG + lr] (negative = an unused slot) instead of
 // the consecutive rows g * TL_RG + lr, and `vstart[g]` = the stored elements of the groups before g (which the closed-form block
 // offsets need: the natural layout reads them off the row pointers).
-template <typename I, typename T>
+template <typename I, typename T, bool MAPPED>
 __global__ void __launch_bounds__(256) tl_inspect_kernel(int64_t M, int ntiles, int64_t groups, const T* __restrict__ vals,
                                                          const I* __restrict__ indices, const I* __restrict__ indptr,
                                                          unsigned long long* __restrict__ state, int* __restrict__ blk_off,
@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(256) tl_inspect_kernel(int64_t M, int ntiles, 
   const int64_t g = blockIdx.x;
   const int64_t r0 = g * TL_RG;
   if (tid < TL_RG) {
-    if (rowmap) {
+    if constexpr (MAPPED) {
       const int r = rowmap[r0 + tid];
       rsa[tid] = r >= 0 ? (int64_t)indptr[r] : 0;
       rsb[tid] = r >= 0 ? (int64_t)indptr[r + 1] : 0;
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(256) tl_inspect_kernel(int64_t M, int ntiles, 
   for (int i = tid; i < TL_RG * ntiles; i += 256) before[i] = 0;
   if (tid == 0) group_bad = 0;
   __syncthreads();
-  const int64_t e0 = rowmap ? vstart[g] : rsa[0], e1 = rowmap ? vstart[g + 1] : rsb[TL_RG - 1];
+  const int64_t e0 = MAPPED ? vstart[g] : rsa[0], e1 = MAPPED ? vstart[g + 1] : rsb[TL_RG - 1];
   bool bad = false;
   // A wave per row (rows wave-strided: the row in the group is known without a bisection over the row starts).  The first
   // TL_PRE * 64 elements of each of the wave's rows (column and value) are requested up front and stay in registers for
@@ -748,7 +748,7 @@ static int tl_launch_inspect(int64_t M, int64_t ntiles, const T* a_data, const I
                              const int* rowmap = nullptr, const int64_t* vstart = nullptr) {
   const int64_t groups = rowmap ? map_groups : tl_grid_groups(M);
   const int lds = (int)((2 * TL_RG * ntiles + ntiles + 1) * sizeof(int));
-  auto kern = &tl_inspect_kernel<I, T>;
+  auto kern = rowmap ? &tl_inspect_kernel<I, T, true> : &tl_inspect_kernel<I, T, false>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
@@ -781,34 +781,53 @@ __host__ __device__ inline int tl_map_class(int64_t len, int64_t cap) {
   return len > cap / 2 ? 0 : (len > cap / 4 ? 1 : (len > cap / 8 ? 2 : (len > cap / 16 ? 3 : (len > cap / 32 ? 4 : 5))));
 }
 
-// keys[r] = maxlen - length of row r (ascending keys = longest rows first), rows[r] = r; stats[0..5] += rows per class,
-// stats[6] = max stored elements of a NATURAL group
+// keys[r] = maxlen - length of row r (ascending keys = longest rows first), rows[r] = r; stats[0..5] += rows per class
 template <typename I>
 __global__ void __launch_bounds__(256) tl_map_stats_kernel(int64_t M, int64_t cap, int64_t maxlen, const I* __restrict__ indptr,
                                                            int64_t* __restrict__ keys, int* __restrict__ rows,
                                                            unsigned long long* __restrict__ stats) {
   __shared__ unsigned cnt[TL_MAP_CLASSES];
-  __shared__ unsigned long long gmax;
   if (threadIdx.x < TL_MAP_CLASSES) cnt[threadIdx.x] = 0;
-  if (threadIdx.x == 0) gmax = 0;
   __syncthreads();
-  unsigned long long mine = 0;
-  GRID_STRIDE(r, M) {
-    const int64_t a = (int64_t)indptr[r], len = (int64_t)indptr[r + 1] - a;
-    const int c = tl_map_class(len, cap);
-    keys[r] = len < maxlen ? maxlen - len : 0;
-    rows[r] = (int)r;
-    atomicAdd(&cnt[c], 1u);
-    if (r % TL_RG == 0) {
-      const int64_t e = r + TL_RG < M ? r + TL_RG : M;
-      const unsigned long long load = (unsigned long long)((int64_t)indptr[e] - a);
-      mine = load > mine ? load : mine;
+  const int lane = threadIdx.x & 63;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t r0 = (int64_t)blockIdx.x * blockDim.x; r0 < M; r0 += stride) {     // (whole waves: the class counts are ballots)
+    const int64_t r = r0 + threadIdx.x;
+    int c = -1;
+    if (r < M) {
+      const int64_t len = (int64_t)indptr[r + 1] - (int64_t)indptr[r];
+      c = tl_map_class(len, cap);
+      keys[r] = len < maxlen ? maxlen - len : 0;
+      rows[r] = (int)r;
+    }
+#pragma unroll
+    for (int k = 0; k < TL_MAP_CLASSES; ++k) {
+      const unsigned long long m = __ballot(c == k);
+      if (lane == 0 && m) atomicAdd(&cnt[k], (unsigned)__popcll(m));
     }
   }
-  if (mine) atomicMax(&gmax, mine);
   __syncthreads();
   if (threadIdx.x < TL_MAP_CLASSES && cnt[threadIdx.x]) atomicAdd(&stats[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
-  if (threadIdx.x == 0 && gmax) atomicMax(&stats[6], gmax);
+}
+
+// stats[6] = stored elements of the heaviest NATURAL row group (35 consecutive rows): the "is this operand skewed" test, one
+// thread per group - all an operand that is not skewed pays for the balanced layouts
+template <typename I>
+__global__ void __launch_bounds__(256) tl_map_skew_kernel(int64_t M, const I* __restrict__ indptr,
+                                                          unsigned long long* __restrict__ stats) {
+  const int64_t groups = (M + TL_RG - 1) / TL_RG;
+  unsigned long long mine = 0;
+  GRID_STRIDE(g, groups) {
+    const int64_t r = g * TL_RG, e = r + TL_RG < M ? r + TL_RG : M;
+    const unsigned long long load = (unsigned long long)((int64_t)indptr[e] - (int64_t)indptr[r]);
+    mine = load > mine ? load : mine;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const unsigned long long y = __shfl_xor(mine, d, 64);
+    mine = y > mine ? y : mine;
+  }
+  if ((threadIdx.x & 63) == 0 && mine) atomicMax(&stats[6], mine);
 }
 
 struct TlMapPlan {
@@ -862,16 +881,21 @@ extern "C" int spamd_spmm_tiled_inspect(int val_dtype, int idx_dtype, int64_t M,
 // Balanced layouts, step 1: keys[M] = K - length of every row (int64: the sort key - ascending = longest rows first; a row
 // holds at most K elements), rows[M] = 0 .. M - 1 (the sort's payload), stats[8] (zeroed here): rows per class against `cap`
 // [0..5], the largest natural group's stored elements [6].  The caller reads stats (one small read-back), decides (natural
-// layout when [6] is close to the mean group), sorts rows by key (stable) and calls spamd_spmm_tiled_map_build.
+// layout when [6] is close to the mean group), sorts rows by key (stable) and calls spamd_spmm_tiled_map_build.  keys = rows =
+// NULL: the statistics only (what an operand that turns out NOT to be skewed pays: one pass over the row pointers).
 extern "C" int spamd_spmm_tiled_map_stats(int idx_dtype, int64_t M, int64_t K, int64_t cap, const void* a_indptr, int64_t* keys,
                                           int* rows, int64_t* stats, void* stream) {
-  if (M < 0 || M >= ((int64_t)1 << 31) || K <= 0 || cap < 32 || (cap & (cap - 1)) || !keys || !rows || !stats) return SPAMD_EINVAL;
+  if (M < 0 || M >= ((int64_t)1 << 31) || K <= 0 || cap < 32 || (cap & (cap - 1)) || (keys != nullptr) != (rows != nullptr) || !stats)
+    return SPAMD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (hipError_t e = hipMemsetAsync(stats, 0, 8 * sizeof(int64_t), s); e != hipSuccess) return (int)e;
   if (M == 0) return 0;
   SPAMD_DISPATCH_IDX(idx_dtype, I, {
-    hipLaunchKernelGGL((tl_map_stats_kernel<I>), dim3(tl_blocks_for(M)), dim3(256), 0, s, M, cap, K, (const I*)a_indptr, keys, rows,
+    hipLaunchKernelGGL((tl_map_skew_kernel<I>), dim3(tl_blocks_for(ceil_div(M, (int64_t)TL_RG))), dim3(256), 0, s, M, (const I*)a_indptr,
                        (unsigned long long*)stats);
+    if (keys)
+      hipLaunchKernelGGL((tl_map_stats_kernel<I>), dim3(tl_blocks_for(M)), dim3(256), 0, s, M, cap, K, (const I*)a_indptr, keys, rows,
+                         (unsigned long long*)stats);
     return launch_status();
   })
   return SPAMD_ETYPE;
