@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(256) tl_inspect_kernel(int64_t M, int ntiles, 
                                                          int* __restrict__ stream, const int* __restrict__ rowmap,
                                                          const int64_t* __restrict__ vstart) {
   extern __shared__ int tl_fill_lds[];  // before[RG][ntiles], runstart[RG][ntiles] (relative to the row's start), loff[ntiles + 1]
-  __shared__ int64_t rsa[TL_RG + 1], rsb[TL_RG + 1];   // first element and end of every row of the group
+  __shared__ __attribute__((aligned(16))) int64_t rsab[2 * (TL_RG + 1)];   // (first element, end) of every row of the group: adjacent words, one LDS read
   __shared__ int wtot[5];
   __shared__ int group_bad;   // a row of THIS group has unsorted column indices: its lists are written as zeros
   constexpr int EPB = TlFmt<T>::EPB;
@@ -265,18 +265,18 @@ __global__ void __launch_bounds__(256) tl_inspect_kernel(int64_t M, int ntiles, 
   if (tid < TL_RG) {
     if constexpr (MAPPED) {
       const int r = rowmap[r0 + tid];
-      rsa[tid] = r >= 0 ? (int64_t)indptr[r] : 0;
-      rsb[tid] = r >= 0 ? (int64_t)indptr[r + 1] : 0;
+      rsab[2 * (tid)] = r >= 0 ? (int64_t)indptr[r] : 0;
+      rsab[2 * (tid) + 1] = r >= 0 ? (int64_t)indptr[r + 1] : 0;
     } else {
       const int64_t r = r0 + tid;
-      rsa[tid] = (int64_t)indptr[r < M ? r : M];
-      rsb[tid] = (int64_t)indptr[r + 1 < M ? r + 1 : M];
+      rsab[2 * (tid)] = (int64_t)indptr[r < M ? r : M];
+      rsab[2 * (tid) + 1] = (int64_t)indptr[r + 1 < M ? r + 1 : M];
     }
   }
   for (int i = tid; i < TL_RG * ntiles; i += 256) before[i] = 0;
   if (tid == 0) group_bad = 0;
   __syncthreads();
-  const int64_t e0 = MAPPED ? vstart[g] : rsa[0], e1 = MAPPED ? vstart[g + 1] : rsb[TL_RG - 1];
+  const int64_t e0 = MAPPED ? vstart[g] : rsab[2 * (0)], e1 = MAPPED ? vstart[g + 1] : rsab[2 * (TL_RG - 1) + 1];
   bool bad = false;
   // A wave per row (rows wave-strided: the row in the group is known without a bisection over the row starts).  The first
   // TL_PRE * 64 elements of each of the wave's rows (column and value) are requested up front and stay in registers for
@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(256) tl_inspect_kernel(int64_t M, int ntiles, 
 #pragma unroll
   for (int i = 0; i < RPW; ++i) {
     const int lr = wv + 4 * i;
-    const int64_t ra = lr < TL_RG ? rsa[lr] : 0, rb = lr < TL_RG ? rsb[lr] : 0;
+    const int64_t ra = lr < TL_RG ? rsab[2 * (lr)] : 0, rb = lr < TL_RG ? rsab[2 * (lr) + 1] : 0;
 #pragma unroll
     for (int p = 0; p < TL_PRE; ++p) {
       const int64_t e = ra + lane + 64 * p;
@@ -302,13 +302,13 @@ __global__ void __launch_bounds__(256) tl_inspect_kernel(int64_t M, int ntiles, 
     const int t = (int)(c / (unsigned)TL_KB);
     atomicAdd(&before[lr * ntiles + t], 1);
     if (!row_start && cp > c) bad = true;
-    if (row_start || (int)(cp / (unsigned)TL_KB) != t) runstart[lr * ntiles + t] = (int)(e - ra);
+    if (row_start || (int)(cp / (unsigned)TL_KB) != t) runstart[lr * ntiles + t] = (int)(e - (MAPPED ? ra : e0));   // (natural layout: relative to the group's first element, a scalar)
   };
 #pragma unroll
   for (int i = 0; i < RPW; ++i) {
     const int lr = wv + 4 * i;
     if (lr >= TL_RG) break;
-    const int64_t ra = rsa[lr], rb = rsb[lr];
+    const int64_t ra = rsab[2 * (lr)], rb = rsab[2 * (lr) + 1];
 #pragma unroll
     for (int p = 0; p < TL_PRE; ++p) {
       const int64_t e = ra + lane + 64 * p;
@@ -383,14 +383,14 @@ __global__ void __launch_bounds__(256) tl_inspect_kernel(int64_t M, int ntiles, 
   auto fill_one = [&](int lr, int64_t ra, int64_t e, unsigned c, T v) {
     const int t = (int)(c / (unsigned)TL_KB);
     const int lc = (int)(c - (unsigned)t * (unsigned)TL_KB);
-    const int64_t dst = (goff + loff[t]) * EPB + before[lr * ntiles + t] + ((int)(e - ra) - runstart[lr * ntiles + t]);
+    const int64_t dst = (goff + loff[t]) * EPB + before[lr * ntiles + t] + ((int)(e - (MAPPED ? ra : e0)) - runstart[lr * ntiles + t]);
     TlFmt<T>::put(stream, dst, tl_d0(lc, lr), v);
   };
 #pragma unroll
   for (int i = 0; i < RPW; ++i) {
     const int lr = wv + 4 * i;
     if (lr >= TL_RG) break;
-    const int64_t ra = rsa[lr], rb = rsb[lr];
+    const int64_t ra = rsab[2 * (lr)], rb = rsab[2 * (lr) + 1];
 #pragma unroll
     for (int p = 0; p < TL_PRE; ++p) {
       const int64_t e = ra + lane + 64 * p;
