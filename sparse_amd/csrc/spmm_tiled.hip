@@ -1219,6 +1219,8 @@ __global__ void __launch_bounds__(256) tl_csc_fill_kernel(int64_t K, int ntiles,
   __shared__ int ccnt[CHUNKS * GPB];          // elements of a chunk per group, then their exclusive prefix over the window
   __shared__ __attribute__((aligned(16))) int img[TL_CSC_IMG_BLOCKS * TL_BLOCK_INTS];   // the tile's lists as they go to the stream
   __shared__ int ib[GPB], tsum_s;
+  __shared__ unsigned char colof[TL_CSC_STAGE];   // column (inside the tile) of every position of the current window
+  static_assert(TL_KB <= 256, "a tile's columns fit a byte");
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // workgroup L runs on XCD L % 8 (observed placement; for speed only): an XCD takes a contiguous eighth of the row blocks,
   // consecutive workgroups of an XCD = consecutive blocks of the same tiles - their runs share cache lines (a 128-byte line
@@ -1274,6 +1276,13 @@ __global__ void __launch_bounds__(256) tl_csc_fill_kernel(int64_t K, int ntiles,
       int rr[PER], rank[PER], col[PER];
       T vv[PER];
       for (int i = tid; i < CHUNKS * GPB; i += 256) ccnt[i] = 0;
+      // position -> column of the window, written by the columns themselves (a run holds ~6 positions): an element then finds
+      // its column with ONE LDS read instead of an 8-step binary search over the runs' prefix - eight DEPENDENT LDS round
+      // trips per element on the critical path of every window (round 5)
+      if (tid < TL_KB) {
+        const int a = pre[tid] > w0 ? pre[tid] : w0, b = pre[tid + 1] < w1 ? pre[tid + 1] : w1;
+        for (int k = a; k < b; ++k) colof[k - w0] = (unsigned char)tid;
+      }
       __syncthreads();
 #pragma unroll
       for (int p = 0; p < PER; ++p) {
@@ -1283,14 +1292,7 @@ __global__ void __launch_bounds__(256) tl_csc_fill_kernel(int64_t K, int ntiles,
         vv[p] = T(0);
         col[p] = 0;
         if (valid) {
-          int lo = 0, hi = TL_KB - 1;       // largest j with pre[j] <= k
-#pragma unroll
-          for (int step = 0; step < 8; ++step) {
-            const int mid = (lo + hi + 1) >> 1;
-            const bool le = pre[mid] <= k;
-            lo = le ? mid : lo;
-            hi = le ? hi : mid - 1;
-          }
+          const int lo = colof[k - w0];       // the column whose run holds position k
           const int64_t e = rstart[lo] + (k - pre[lo]);
           col[p] = lo;
           rr[p] = (int)((int64_t)indices[e] - r_base);
