@@ -322,6 +322,10 @@ def test_committed_bench_rows_move_the_bytes_they_claim():
     lines = sorted(glob.glob(os.path.join(root, "profiles", "r0*_bench_line.json")))
     assert lines
     line = json.load(open(lines[-1]))
+    if "paths" not in line:
+        # round 5: the driver-parsed line is compact; the full rows of the same run are published beside it
+        line["paths"] = json.load(open(lines[-1].replace("_bench_line.json", "_paths.json")))
+        assert line["roofline"]["paths_accounting_errors"] == []
     pmc = json.load(open(os.path.join(root, "profiles", "paths_pmc.json")))["rows"]
     checked = 0
     for rid, row in line["paths"].items():
