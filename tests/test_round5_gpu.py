@@ -296,3 +296,22 @@ def test_small_spgemm_through_the_api_and_its_fallback(sp):
     z2 = x @ y2
     assert K.SPGEMM_STATS.get("kernel") != "small"
     assert np.allclose(z2.todense(), z.todense(), rtol=1e-13, atol=0)
+
+
+def test_tensordot_views_are_kept_and_follow_the_operand(sp):
+    """small sparse operands keep the 2-D form a tensordot made of them (`_dot._permute_reshape`): the second contraction re-uses
+    it, an in-place change of the operand drops it"""
+    x = sp.random((20, 15, 12, 9), density=0.05, random_state=3)
+    t = torch.rand((20, 15), device="cuda", dtype=torch.float64)
+    r1 = sp.tensordot(x, t, axes=([0, 1], [0, 1]))
+    views = x.__dict__.get("_tdot_views")
+    assert views and len(views) == 1
+    first = next(iter(views.values()))
+    r2 = sp.tensordot(x, t, axes=([0, 1], [0, 1]))
+    assert next(iter(x.__dict__["_tdot_views"].values())) is first and torch.equal(r1, r2)
+    want = np.tensordot(x.todense(), t.cpu().numpy(), axes=([0, 1], [0, 1]))
+    assert np.allclose(r1.cpu().numpy(), want, rtol=1e-12)
+    x.data *= 3.0
+    r3 = sp.tensordot(x, t, axes=([0, 1], [0, 1]))
+    assert next(iter(x.__dict__["_tdot_views"].values())) is not first
+    assert np.allclose(r3.cpu().numpy(), 3.0 * want, rtol=1e-12)
