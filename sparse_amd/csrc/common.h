@@ -32,6 +32,34 @@ __device__ __forceinline__ T wave_bcast(T x, int src) {
   }
 }
 
+// Whole-wave reductions on DPP (VALU speed: six dependent steps of a few cycles; `__shfl_xor` is a ds_bpermute per step,
+// ~100 cycles each through the LDS pipeline).  quad_perm xor 1 / xor 2, row_half_mirror, row_mirror leave every lane of a
+// row of 16 with the row's result; row_bcast15 / row_bcast31 carry it into the later rows; lane 63 holds the wave's.
+// All 64 lanes must be active.  The result is wave-uniform (an SGPR).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_mov(unsigned old, unsigned src) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+  auto mn = [](unsigned a, unsigned b) { return a < b ? a : b; };
+  v = mn(v, dpp_mov<0xB1, 0xf>(v, v));    // quad_perm [1,0,3,2]
+  v = mn(v, dpp_mov<0x4E, 0xf>(v, v));    // quad_perm [2,3,0,1]
+  v = mn(v, dpp_mov<0x141, 0xf>(v, v));   // row_half_mirror
+  v = mn(v, dpp_mov<0x140, 0xf>(v, v));   // row_mirror
+  v = mn(v, dpp_mov<0x142, 0xa>(v, v));   // row_bcast15 -> rows 1, 3
+  v = mn(v, dpp_mov<0x143, 0xc>(v, v));   // row_bcast31 -> rows 2, 3
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
+  v += dpp_mov<0xB1, 0xf>(0u, v);
+  v += dpp_mov<0x4E, 0xf>(0u, v);
+  v += dpp_mov<0x141, 0xf>(0u, v);
+  v += dpp_mov<0x140, 0xf>(0u, v);
+  v += dpp_mov<0x142, 0xa>(0u, v);
+  v += dpp_mov<0x143, 0xc>(0u, v);
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // Tell the compiler a value is wave-uniform (moves it to SGPRs; enables scalar branches).
 __device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ int64_t uniform(int64_t x) {

@@ -57,6 +57,8 @@ constexpr int BMK_THREADS = 1024;                           // the wide form (on
 constexpr int BMK_STAGE = 256;                              // A elements a row may have
 constexpr int BMK_MAX_GROUPS = 4096;                        // groups of 256 columns (8 bitmap words)
 constexpr int BMK_GPT = 4;                                  // groups per thread = 16-bit fields of the packed scan
+constexpr int BMK_CHUNKS = 256;                             // 64-product chunks of a row: 1024 threads x 16 products
+constexpr int BMK_LEN_BITS = 23;                            // staging scan: B-row lengths (clamped) below, rows that are not empty above
 constexpr int BMK_DUP = 512;                                // parked products per row (wide form; the split form: 256)
 constexpr unsigned BMK_NONE = 0xffffffffu;
 constexpr int BMK_HEADER = 32;                              // words of `work` before the per-row state words
@@ -76,10 +78,11 @@ struct BmkDup {
 };
 
 template <typename V>
-struct BmkStage {   // one A row: prefix[e] = products of the elements before e, start of B row k_e, A value
-  int prefix[BMK_STAGE + 4];
-  int64_t bstart[BMK_STAGE];
-  V aval[BMK_STAGE];
+struct BmkStage {   // one A row, its elements with an EMPTY B row left out: prefix[e] = products of the elements before e
+  unsigned short prefix[BMK_STAGE + 4];   // (strictly ascending, <= 16384; prefix[number of elements] = products of the row)
+  int64_t bstart[BMK_STAGE];          // start of B row k_e
+  V aval[BMK_STAGE];                  // A value
+  unsigned char cst[BMK_CHUNKS];      // element of product 64 * k: chunk k of the row's products is what ONE wave requests at a time
 };
 
 struct BmkMisc {
@@ -102,7 +105,7 @@ template <typename V, int THREADS, int ITEMS, int DUP>
 struct BmkLayout {
   static constexpr size_t row_bytes = (size_t)THREADS * ITEMS * (4 + sizeof(V));
   __host__ __device__ static size_t bitmap_bytes(int ngroups) { return (size_t)ngroups * 32; }
-  __host__ __device__ static size_t pref_bytes(int ngroups) { return ((size_t)ngroups * 2 + 15) / 16 * 16; }
+  __host__ __device__ static size_t pref_bytes(int ngroups) { return ((size_t)ngroups * 4 + 15) / 16 * 16; }   // two per group
   __host__ __device__ static size_t front_bytes(int ngroups) {
     const size_t a = bitmap_bytes(ngroups) + pref_bytes(ngroups);
     return a > row_bytes ? a : row_bytes;
@@ -164,22 +167,25 @@ __device__ __forceinline__ void bmk_block_scan(unsigned long long& a, unsigned& 
   tb = m->wb[THREADS / 64];
 }
 
-__device__ __forceinline__ int bmk_popc_group(const unsigned* bm, int g) {
+// set bits of group g (8 words = 256 columns): the first four words' count in `lo`, all eight returned
+__device__ __forceinline__ int bmk_popc_group(const unsigned* bm, int g, int& lo_cnt) {
   const uint4 lo = *reinterpret_cast<const uint4*>(bm + (size_t)g * 8);
   const uint4 hi = *reinterpret_cast<const uint4*>(bm + (size_t)g * 8 + 4);
-  return __popc(lo.x) + __popc(lo.y) + __popc(lo.z) + __popc(lo.w) + __popc(hi.x) + __popc(hi.y) + __popc(hi.z) + __popc(hi.w);
+  lo_cnt = __popc(lo.x) + __popc(lo.y) + __popc(lo.z) + __popc(lo.w);
+  return lo_cnt + __popc(hi.x) + __popc(hi.y) + __popc(hi.z) + __popc(hi.w);
 }
 
-// number of set bits below column `col`: the column's position in the sorted row
+// number of set bits below column `col`: the column's position in the sorted row.  pref[] holds the bits below every HALF
+// group (128 columns = one 16-byte read; round 4 kept one per 256 columns and read 32 bytes per product: the positions were
+// the phase with the most LDS traffic)
 __device__ __forceinline__ int bmk_rank(const unsigned* bm, const unsigned short* pref, unsigned col) {
-  const unsigned g = col >> 8, wi = (col >> 5) & 7u;
-  const uint4 lo = *reinterpret_cast<const uint4*>(bm + (size_t)g * 8);
-  const uint4 hi = *reinterpret_cast<const uint4*>(bm + (size_t)g * 8 + 4);
-  const unsigned w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-  int r = (int)pref[g];
+  const unsigned h = col >> 7, wi = (col >> 5) & 3u;
+  const uint4 q = *reinterpret_cast<const uint4*>(bm + (size_t)h * 4);
+  const unsigned w[4] = {q.x, q.y, q.z, q.w};
+  int r = (int)pref[h];
   unsigned cur = w[0];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < 4; ++i) {
     r += (unsigned)i < wi ? __popc(w[i]) : 0;
     cur = (unsigned)i == wi ? w[i] : cur;
   }
@@ -268,6 +274,7 @@ spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, con
   constexpr unsigned FILT_MASK = FILT_WORDS * 32 - 1;
   static_assert(BMK_GPT * THREADS * 256 >= (1 << 19), "column range of a part");
   static_assert(ITEMS % 4 == 0, "A-element indices are packed four to a register");
+  static_assert(THREADS * ITEMS <= 65535, "the staged prefix is 16 bits wide");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned* const bm = reinterpret_cast<unsigned*>(smem);
   unsigned short* const pref = reinterpret_cast<unsigned short*>(smem + L::bitmap_bytes(ngroups));
@@ -289,6 +296,7 @@ spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, con
   BmkMisc* const misc = reinterpret_cast<BmkMisc*>(stage + 2);
   unsigned long long* const state = work + BMK_HEADER;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wid_s = __builtin_amdgcn_readfirstlane(wid);
   constexpr int CAP = THREADS * ITEMS;
 
   // ---- set-up: clean LDS, the first two tickets -------------------------------------------------------------------------
@@ -342,25 +350,56 @@ spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, con
   unsigned colN[ITEMS];
   V bvN[ITEMS];
   unsigned eN[ITEMS / 4];
-  auto expand = [&](const BmkStage<V>* st, int nA, int P) {
+  // chunk table of a staged row (its prefix must be visible): the last element e with prefix[e] <= 64 * k, one branch-free
+  // binary search per chunk by the last waves of the workgroup (wave 0 has the look-back)
+  auto build_cst = [&](BmkStage<V>* st, int nE) {
+    constexpr int NCH = CAP / 64;
+    static_assert(NCH <= BMK_CHUNKS && NCH <= THREADS, "chunk table");
+    const int k = tid - (THREADS - NCH);
+    if (k >= 0) {
+      const int p = k * 64;
+      int e = 0;
+#pragma unroll
+      for (int step = BMK_STAGE / 2; step >= 1; step >>= 1) {
+        const int t = e + step;              // (<= 255: always inside the staging array, whatever nE is)
+        const int at_t = (int)st->prefix[t];
+        e = ((t < nE) & (at_t <= p)) ? t : e;
+      }
+      st->cst[k] = (unsigned char)e;
+    }
+  };
+  // Product p = 64 * k + lane of the row belongs to lane `lane` of the wave that takes chunk k: item j of wave w is chunk
+  // j * (THREADS / 64) + w (= product j * THREADS + tid: for one item index consecutive lanes read consecutive entries of a
+  // B row).  The element of the chunk's first product comes from the table; the prefix is strictly ascending, so at most 63
+  // element boundaries lie inside the chunk, and they are the first of the 64 that follow that element: lane l fetches
+  // boundary l, and a product's element is the table's plus the boundaries at or below it - four of them straight-line
+  // (rows of B with ~100 elements: 0-2 per chunk), the rest in a wave-uniform loop.  (Round 4 searched the prefix per
+  // product: 8 dependent LDS reads x 16 items per thread, a quarter of the kernel's LDS instructions.)
+  auto expand = [&](const BmkStage<V>* st, int nE, int P) {
+    // (an opaque zero: without it the sixteen product numbers and chunk ends are loop invariants of the row loop, the
+    // compiler keeps them in registers across it and spills - and a spill reload among the product requests waits for all of
+    // them: vmcnt counts in order)
+    int z;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+    const int pt = tid + z;                 // product of item 0
+    const int cw = wid_s * 64 + z;          // its chunk's first product (wave-uniform)
+    const unsigned char* const cstp = st->cst + wid;
 #pragma unroll
     for (int j = 0; j < ITEMS / 4; ++j) eN[j] = 0;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-      const int p = j * THREADS + tid;
+      const int p = pt + j * THREADS;
       colN[j] = BMK_NONE;
       bvN[j] = V(0);
-      // the A element of product p: the last e with prefix[e] <= p (empty B rows are skipped by construction).  A
-      // branch-free binary search: data-dependent loops here, sixteen times over, cost the register allocator 300 spills.
-      int e = 0;
-#pragma unroll
-      for (int step = BMK_STAGE / 2; step >= 1; step >>= 1) {
-        const int t = e + step;              // (<= 255: always inside the staging array, whatever nA is)
-        const int at_t = st->prefix[t];
-        e = ((t < nA) & (at_t <= p)) ? t : e;
-      }
+      const int e0 = cstp[j * (THREADS / 64)];
+      const int bi = e0 + 1 + lane;
+      const int b = bi <= nE ? (int)st->prefix[bi] : 0x7fffffff;   // (a boundary beyond the chunk is above every p of it)
+      int e = e0 + (p >= __builtin_amdgcn_readlane(b, 0)) + (p >= __builtin_amdgcn_readlane(b, 1)) +
+              (p >= __builtin_amdgcn_readlane(b, 2)) + (p >= __builtin_amdgcn_readlane(b, 3));
+      unsigned long long more = __ballot(b <= cw + j * THREADS + 63) >> 4;
+      for (int i = 4; more & 1ull; more >>= 1, ++i) e += p >= __builtin_amdgcn_readlane(b, i);
       if (p < P) {
-        const int64_t q = st->bstart[e] + (int64_t)(p - st->prefix[e]);
+        const int64_t q = st->bstart[e] + (int64_t)(p - (int)st->prefix[e]);
         colN[j] = (unsigned)b_idx[q];
         bvN[j] = b_val[q];
         eN[j / 4] |= (unsigned)e << (8 * (j % 4));
@@ -368,31 +407,46 @@ spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, con
       if (j % 8 == 7) __builtin_amdgcn_sched_barrier(0);   // (keeps the scheduler from hoisting all 2 x ITEMS address chains)
     }
   };
+  // the staging scan sums (B-row length clamped to CAP + 1: 256 of them stay below 2^23) | (1 << 23 for a row that is not empty)
+  auto scan_word = [&](unsigned len) -> unsigned {
+    return (len > (unsigned)CAP ? (unsigned)CAP + 1u : len) | (len ? 1u << BMK_LEN_BITS : 0u);
+  };
+  // one thread per A element puts it at its place among the elements whose B row is not empty
+  auto stage_row = [&](BmkStage<V>* st, unsigned excl, unsigned tot, unsigned len, int64_t bs, V av, int& nE, int& P) {
+    unsigned tl = tot & ((1u << BMK_LEN_BITS) - 1u);
+    nE = (int)(tot >> BMK_LEN_BITS);
+    if (tl > (unsigned)CAP) {
+      failed = true;
+      tl = 0;
+    }
+    P = (int)tl;
+    if (len) {
+      const int ce = (int)(excl >> BMK_LEN_BITS);
+      st->prefix[ce] = tl ? (unsigned short)(excl & ((1u << BMK_LEN_BITS) - 1u)) : (unsigned short)0;
+      st->bstart[ce] = bs;
+      st->aval[ce] = av;
+    }
+    if (tid == 0) st->prefix[nE] = (unsigned short)tl;
+  };
 
   // ---- prologue: stage the first row, request its products, fetch the second row's A elements ---------------------------
-  int nA_c, nA_n, P_c;
+  int nA_n, nE_c, P_c;   // A elements of the next row (to fetch), staged elements and products of the current one
   int64_t ka;
   V av;
   {
     int64_t bs;
     unsigned len;
+    int nA_c;
     load_arow(cur, nA_c, ka, av);
     load_brow(cur, nA_c, ka, bs, len);
     unsigned long long za = 0, ta;
-    unsigned excl = len, tl;
+    unsigned excl = scan_word(len), tl;
     bmk_block_scan<THREADS>(za, excl, ta, tl, misc);
-    if (tl > (unsigned)CAP) {
-      failed = true;
-      tl = 0;
-    }
-    if (tid <= nA_c) stage[0].prefix[tid] = tl ? (int)excl : 0;
-    if (tid < nA_c) {
-      stage[0].bstart[tid] = bs;
-      stage[0].aval[tid] = av;
-    }
-    P_c = (int)tl;
+    stage_row(&stage[0], excl, tl, len, bs, av, nE_c, P_c);
     lds_barrier();
-    expand(&stage[0], nA_c, P_c);
+    build_cst(&stage[0], nE_c);
+    lds_barrier();
+    expand(&stage[0], nE_c, P_c);
     load_arow(nxt, nA_n, ka, av);
   }
   int buf = 0;
@@ -418,6 +472,52 @@ spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, con
     // (the products stay where the prefetch put them - colN / bvN / eN - until the row is assembled in step 4: a second
     // copy of them, as keys and values, had the kernel spill 30 registers)
     unsigned first_mask = 0;
+#ifdef BMK_BATCH
+    // all of a thread's bitmap atomics are issued before the first answer is looked at (one LDS latency instead of ITEMS)
+    unsigned seen = 0;
+#pragma unroll
+    for (int j0 = 0; j0 < ITEMS; j0 += BMK_BATCH) {
+      unsigned oldw[BMK_BATCH];
+#pragma unroll
+      for (int jj = 0; jj < BMK_BATCH; ++jj) {
+        const int j = j0 + jj;
+        if (SPLIT && colN[j] != BMK_NONE && colN[j] - cbase >= (unsigned)range) {   // (see below)
+          failed = true;
+          colN[j] = BMK_NONE;
+        }
+        // (no branch around the atomic: a lane without a product ORs nothing into a word of its own)
+        const bool valid = colN[j] != BMK_NONE;
+        const unsigned c = colN[j] - cbase;
+        unsigned* const at = valid ? &bm[c >> 5] : &filt[lane];
+        oldw[jj] = atomicOr(at, valid ? 1u << (c & 31u) : 0u);
+      }
+#pragma unroll
+      for (int jj = 0; jj < BMK_BATCH; ++jj) {
+        const int j = j0 + jj;
+        const bool valid = colN[j] != BMK_NONE;
+        const unsigned c = colN[j] - cbase;
+        seen |= (valid && ((oldw[jj] >> (c & 31u)) & 1u)) ? 1u << j : 0u;
+        first_mask |= valid ? 1u << j : 0u;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    first_mask &= ~seen;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      if ((seen >> j) & 1u) {   // the output element has a product already: park this one
+        const unsigned c = colN[j] - cbase;
+        const unsigned e = (eN[j / 4] >> (8 * (j % 4))) & 255u;
+        const unsigned h = (c ^ (c >> 14)) & FILT_MASK;
+        atomicOr(&filt[h >> 5], 1u << (h & 31u));
+        const int slot = atomicAdd(ndup, 1);
+        if (slot < DUP) {
+          dup[slot].key = (c << 8) | e;
+          dup[slot].rank = BMK_NONE;
+          dup[slot].val = sc->aval[e] * bvN[j];
+        }
+      }
+    }
+#else
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
       // (a column outside this part's range: B's row is not sorted by column - the split form's binary search over it put the
@@ -448,39 +548,41 @@ spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, con
       }
       if (j % 8 == 7) __builtin_amdgcn_sched_barrier(0);
     }
+#endif
     BMK_T(1)
     lds_barrier();
     BMK_T(2)
     // ---- 2. popcount scan: positions of the columns; the same scan sums the next row's B-row lengths --------------------
     unsigned long long cnts = 0;
+    unsigned los = 0;   // bits of the first half of each of the thread's groups (<= 128: a byte each)
 #pragma unroll
     for (int m = 0; m < BMK_GPT; ++m) {
       const int g = tid + THREADS * m;
-      if (g < ngroups) cnts |= (unsigned long long)bmk_popc_group(bm, g) << (16 * m);
+      if (g < ngroups) {
+        int lo_cnt;
+        cnts |= (unsigned long long)bmk_popc_group(bm, g, lo_cnt) << (16 * m);
+        los |= (unsigned)lo_cnt << (8 * m);
+      }
     }
     unsigned long long excl_c = cnts, tot_c;
-    unsigned excl_l = len, tot_l;
+    unsigned excl_l = scan_word(len), tot_l;
     bmk_block_scan<THREADS>(excl_c, excl_l, tot_c, tot_l, misc);
     int row_nnz = 0;
 #pragma unroll
     for (int m = 0; m < BMK_GPT; ++m) {
       const int g = tid + THREADS * m;
-      if (g < ngroups) pref[g] = (unsigned short)(row_nnz + (int)((excl_c >> (16 * m)) & 0xffffu));
+      if (g < ngroups) {
+        const unsigned below = (unsigned)row_nnz + (unsigned)((excl_c >> (16 * m)) & 0xffffu);
+        reinterpret_cast<unsigned*>(pref)[g] = below | ((below + ((los >> (8 * m)) & 0xffu)) << 16);
+      }
       row_nnz += (int)((tot_c >> (16 * m)) & 0xffffu);
     }
-    if (tot_l > (unsigned)CAP) {
-      failed = true;
-      tot_l = 0;
-    }
-    const int P_n = (int)tot_l;
-    if (tid <= nA_n) sn->prefix[tid] = P_n ? (int)excl_l : 0;
-    if (tid < nA_n) {
-      sn->bstart[tid] = bs;
-      sn->aval[tid] = av_n;
-    }
+    int nE_n, P_n;
+    stage_row(sn, excl_l, tot_l, len, bs, av_n, nE_n, P_n);
     BMK_T(3)
     lds_barrier();
     BMK_T(4)
+    build_cst(sn, nE_n);   // (visible to the expansion in step 4: one more barrier on the way)
     // ---- 3. the row's length is known: wave 0 publishes it and looks back for the row's offset, while every first
     // arriver finds its column's position (unless products of its column are parked: then it joins them) ---------------
     // (only the publication happens here: the look-back itself waits until the row is assembled - step 5 -, by which time
@@ -526,7 +628,7 @@ spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, con
       }
     }
     BMK_T(8)
-    expand(sn, nA_n, P_n);
+    expand(sn, nE_n, P_n);
     BMK_T(9)
     // ---- 5. parked products: a WAVE per entry scans the list (8 entries per lane at most); the entry with the smallest
     // A-element index of its column adds the column's products left to right, in the order of A's elements ------------
@@ -552,12 +654,8 @@ spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, con
           lo = m && lk[t] < lo ? lk[t] : lo;
           cnt += m;
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          const unsigned y = __shfl_xor(lo, o, 64);
-          lo = y < lo ? y : lo;
-          cnt += __shfl_xor(cnt, o, 64);
-        }
+        lo = wave_min_u32(lo);                   // (DPP: round 4 reduced through ds_bpermute - a parked entry cost ~2 k cycles)
+        cnt = (int)wave_sum_u32((unsigned)cnt);
         if (lo != kd) continue;                  // not the first A element of this column (wave-uniform)
         V acc = dup[d].val;
         unsigned rank = dup[d].rank;
@@ -571,12 +669,7 @@ spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, con
             nx = m ? lk[t] : nx;
             at = m ? lane + 64 * t : at;
           }
-          unsigned best = nx;
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) {
-            const unsigned y = __shfl_xor(best, o, 64);
-            best = y < best ? y : best;
-          }
+          const unsigned best = wave_min_u32(nx);
           const unsigned long long who = __ballot(nx == best && best != BMK_NONE);
           if (who == 0) {   // fewer distinct keys than entries of this column: a B row holds the column TWICE (equal
             failed = true;  // (column, A element) keys) - not a canonical operand; fail the call, the bucket kernels take it
@@ -648,8 +741,8 @@ spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, con
     BMK_T(13)
     cur = nxt;
     nxt = nn;
-    nA_c = nA_n;
     nA_n = nA_nn;
+    nE_c = nE_n;
     P_c = P_n;
     buf ^= 1;
   }
@@ -691,10 +784,18 @@ struct BmkSplitItems {
 };
 
 template <typename V>
+static int64_t bmk_wide_max_groups() {   // groups of 256 columns whose bitmap + positions fit next to the rest in 160 KB
+  using L = BmkLayout<V, BMK_THREADS, BmkItems<V>::value, BMK_DUP>;
+  int64_t g = BMK_MAX_GROUPS;
+  while (g > 0 && (int64_t)L::bytes((int)g) > 160 * 1024) --g;
+  return g;
+}
+
+template <typename V>
 static int64_t bmk_split_max_groups() {   // groups of 256 columns whose bitmap + positions fit next to the rest in 80 KB
   using L = BmkLayout<V, BMK_SPLIT_THREADS, BmkSplitItems<V>::value, BMK_SPLIT_DUP>;
   const int64_t rest = (int64_t)L::bytes(0) - (int64_t)L::front_bytes(0);
-  int64_t g = (80 * 1024 - rest) / 34;
+  int64_t g = (80 * 1024 - rest) / 36;
   while (g > 0 && (int64_t)L::bytes((int)g) > 80 * 1024) --g;
   return g;
 }
@@ -736,7 +837,7 @@ extern "C" int64_t spamd_spgemm_bitmap_limits(int val_dtype, int which) {
   switch (which) {
     case 0: return (int64_t)BMK_THREADS * (v4 ? BmkItems<float>::value : BmkItems<double>::value);
     case 1: return BMK_STAGE;
-    case 2: return (int64_t)BMK_MAX_GROUPS * 256;
+    case 2: return (v4 ? bmk_wide_max_groups<float>() : bmk_wide_max_groups<double>()) * 256;
     case 3: return BMK_DUP;
     case 4: return (int64_t)BMK_SPLIT_THREADS * (v4 ? BmkSplitItems<float>::value : BmkSplitItems<double>::value);
     case 5: return (v4 ? bmk_split_max_groups<float>() : bmk_split_max_groups<double>()) * 256;
@@ -756,9 +857,9 @@ extern "C" int spamd_spgemm_bitmap(int val_dtype, int idx_dtype, int64_t n_row, 
                                    const void* b_indices, const void* b_data, void* bsplit, int64_t* work,
                                    int64_t* out_indptr, int64_t* out_indices, void* out_data, void* stream) {
   if (n_row < 0 || n_inner < 0 || n_col <= 0 || parts < 1 || parts > 4096 || !work || !out_indptr) return SPAMD_EINVAL;
-  if (parts == 1 && n_col > (int64_t)BMK_MAX_GROUPS * 256) return SPAMD_EINVAL;
   if (parts > 1 && !bsplit) return SPAMD_EINVAL;
   const bool v4 = val_dtype == SPAMD_F32 || val_dtype == SPAMD_I32;
+  if (parts == 1 && n_col > (v4 ? bmk_wide_max_groups<float>() : bmk_wide_max_groups<double>()) * 256) return SPAMD_EINVAL;
   int64_t range = ceil_div(ceil_div(n_col, (int64_t)parts), (int64_t)256) * 256;
   if (parts > 1 && range > (v4 ? bmk_split_max_groups<float>() : bmk_split_max_groups<double>()) * 256) return SPAMD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
