@@ -6,6 +6,10 @@ import sparse_amd as sp
 from sparse_amd import _kernels as K
 n, share = 1_000_000, 8
 f64 = "f64" in sys.argv
+if "nopack" in sys.argv:
+    K.SPGEMM_PACK_B = False
+if "split" in sys.argv:
+    K.SPGEMM_BITMAP_SPLIT = "first"
 gB = sp.random((n, n), density=1e-4, random_state=7, dtype=np.float64 if f64 else np.float32,
                idx_dtype=np.int64 if f64 else np.int32, format="gcxs", compressed_axes=(0,))
 rows = n // share
@@ -24,4 +28,4 @@ pc = st.pop("phase_cycles", None)
 print(f"share{' f64' if f64 else ''}: {ms:.2f} ms per product, checks {ref}, stats {st}")
 if pc:
     per = [v / 256 / (rows / 256) for v in pc]
-    print("cycles per row (thread 0), phases 0-15:", [round(v / 1000, 1) for v in per], "sum", round(sum(per) / 1000, 1), "k")
+    print("cycles per row (thread 0), phases:", [round(v / 1000, 1) for v in per], "sum", round(sum(per) / 1000, 1), "k")
