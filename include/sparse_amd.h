@@ -469,20 +469,6 @@ int spamd_spgemm_bitmap(int val_dtype, int idx_dtype, int64_t n_row, int64_t n_i
                         const void* b_indices, const void* b_data, void* bsplit, int64_t* work, int64_t* out_indptr,
                         int64_t* out_indices, void* out_data, void* stream);
 
-/* Round 5: the same product with B's elements as (column, value) RECORDS - a product is one load instead of two and a B row
- * one run of cache lines instead of two (the kernel waits for its product requests more than for anything else).  The
- * records are a derived layout of B (the host keeps them with B like a CSR twin): spamd_spgemm_record_bytes(val_dtype) per
- * element (8: {column, value bits}; 16 for 8-byte values: {column, 0, value}), written by spamd_spgemm_pack_b.
- * spamd_spgemm_bitmap_packed = spamd_spgemm_bitmap with `b_records` in the place of b_data (b_indices is still read where
- * rows are cut into parts).  Replaces the same reference loops (`_dot_csr_csr`, _common.py:639-717). */
-int64_t spamd_spgemm_record_bytes(int val_dtype);
-int spamd_spgemm_pack_b(int val_dtype, int idx_dtype, int64_t nnz, const void* b_indices, const void* b_data, void* records,
-                        void* stream);
-int spamd_spgemm_bitmap_packed(int val_dtype, int idx_dtype, int64_t n_row, int64_t n_inner, int64_t n_col, int parts,
-                               const void* a_indptr, const void* a_indices, const void* a_data, const void* b_indptr,
-                               const void* b_indices, const void* b_records, void* bsplit, int64_t* work, int64_t* out_indptr,
-                               int64_t* out_indices, void* out_data, void* stream);
-
 /* ---------------------------------------------------------------------------------------
  * A9  SDDMM      out[n] = s[n] * sum_k A[rows[n], k] * Bt[cols[n], k]
  *   replaces the reference's formulation `s * (a @ b)` (examples/sddmm_example.py:51-52: a dense

@@ -113,9 +113,6 @@ SIGNATURES = {
     "spamd_spgemm_small": (_int, [_int, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spamd_spgemm_bitmap_limits": (_i64, [_int, _int]),
     "spamd_spgemm_bitmap": (_int, [_int, _int, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "spamd_spgemm_bitmap_packed": (_int, [_int, _int, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "spamd_spgemm_record_bytes": (_i64, [_int]),
-    "spamd_spgemm_pack_b": (_int, [_int, _int, _i64, _vp, _vp, _vp, _vp]),
     "spamd_spgemm_classify_rows": (_int, [_int, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "spamd_spgemm_unpack": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spamd_spgemm_pack": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

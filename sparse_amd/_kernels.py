@@ -694,31 +694,6 @@ SPGEMM_BITMAP_MAX_DUPS = 120    # expected products per row that share an output
 _BITMAP_UNSUPPORTED = set()    # (device index, split form?) whose launch the library refused once
 
 
-SPGEMM_PACK_B = True           # the bitmap kernel reads B as (column, value) records kept with B's arrays (below)
-SPGEMM_PACK_MIN_PRODUCTS = 1 << 24   # products of the call from which writing the records (2 x B's bytes, once per B) is worth it
-
-
-def _spgemm_b_records(vcode, it, b_indices, b_data, dev, s):
-    """B's elements as (column, value) records for `spamd_spgemm_bitmap_packed`: a derived layout of B, kept ON B's data tensor
-    (like the block streams on an array) and dropped when either array is replaced or written to (tensor identity and
-    version).  8 bytes per element for 4-byte values, 16 for 8-byte ones."""
-    memo = b_data.__dict__.get("_spamd_records")
-    stamp = (id(b_indices), b_indices._version, b_data._version, b_indices.data_ptr(), b_data.data_ptr(), b_indices.dtype)
-    if memo is not None and memo[0] == stamp and memo[1]() is b_indices:
-        SPGEMM_STATS["records"] = "kept"
-        return memo[2]
-    import weakref
-    nnz = int(b_data.numel())
-    rec = torch.empty(max(nnz, 1) * int(_ffi.lib().spamd_spgemm_record_bytes(vcode)), dtype=torch.uint8, device=dev)
-    _ffi.call("spamd_spgemm_pack_b", vcode, code_of(it), nnz, ptr(b_indices), ptr(b_data), ptr(rec), s)
-    try:
-        b_data.__dict__["_spamd_records"] = (stamp, weakref.ref(b_indices), rec)
-    except (AttributeError, TypeError):   # (a tensor subclass without a dict: the records are rebuilt per call)
-        pass
-    SPGEMM_STATS["records"] = "built"
-    return rec
-
-
 def _spgemm_bitmap(vcode, it, n_row, n_inner, n_col, parts, total, a_indptr, a_indices, a_data, b_indptr, b_indices, b_data, dtr,
                    dev, s):
     """C = A @ B by csrc/spgemm_bitmap.hip: (data, int64 indices, int64 indptr), or None when a row (or part of a row)
@@ -732,17 +707,10 @@ def _spgemm_bitmap(vcode, it, n_row, n_inner, n_col, parts, total, a_indptr, a_i
     bsplit = torch.empty(max(n_inner * (parts - 1), 1), dtype=it, device=dev) if parts > 1 else None
     if (dev.index, parts > 1) in _BITMAP_UNSUPPORTED:
         return None
-    SPGEMM_STATS.pop("records", None)
     try:
-        if SPGEMM_PACK_B and total >= SPGEMM_PACK_MIN_PRODUCTS:
-            rec = _spgemm_b_records(vcode, it, b_indices, b_data, dev, s)
-            _ffi.call("spamd_spgemm_bitmap_packed", vcode, code_of(it), n_row, n_inner, n_col, parts, ptr(a_indptr), ptr(a_indices),
-                      ptr(a_data), ptr(b_indptr), ptr(b_indices), ptr(rec), ptr(bsplit) if bsplit is not None else None, ptr(work),
-                      ptr(out_ptr), ptr(out_idx), ptr(out_val), s)
-        else:
-            _ffi.call("spamd_spgemm_bitmap", vcode, code_of(it), n_row, n_inner, n_col, parts, ptr(a_indptr), ptr(a_indices), ptr(a_data),
-                      ptr(b_indptr), ptr(b_indices), ptr(b_data), ptr(bsplit) if bsplit is not None else None, ptr(work), ptr(out_ptr),
-                      ptr(out_idx), ptr(out_val), s)
+        _ffi.call("spamd_spgemm_bitmap", vcode, code_of(it), n_row, n_inner, n_col, parts, ptr(a_indptr), ptr(a_indices), ptr(a_data),
+                  ptr(b_indptr), ptr(b_indices), ptr(b_data), ptr(bsplit) if bsplit is not None else None, ptr(work), ptr(out_ptr),
+                  ptr(out_idx), ptr(out_val), s)
     except _ffi.HipBackendError:
         # the launch itself was refused (the 160 KB LDS opt-in on a part with less, a range / LDS check, the occupancy query):
         # this form is not available on this device - remembered, and the next form (or the bucket kernels) takes the product
@@ -751,7 +719,7 @@ def _spgemm_bitmap(vcode, it, n_row, n_inner, n_col, parts, total, a_indptr, a_i
         return None
     failed, zeros, nnz = (int(v) for v in torch.cat([work[1:3], out_ptr[-1:]]).tolist())   # ONE read-back
     if os.environ.get("SPAMD_BMK_PROF"):     # (-DBMK_PROF builds of csrc/spgemm_bitmap.hip: cycles per phase, thread 0 of every workgroup)
-        SPGEMM_STATS["phase_cycles"] = work[4:28].tolist()
+        SPGEMM_STATS["phase_cycles"] = work[4:20].tolist()
     if failed:
         SPGEMM_STATS["bitmap_failed"] = SPGEMM_STATS.get("bitmap_failed", 0) + 1
         return None

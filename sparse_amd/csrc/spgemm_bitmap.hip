@@ -59,7 +59,6 @@ constexpr int BMK_MAX_GROUPS = 4096;                        // groups of 256 col
 constexpr int BMK_GPT = 4;                                  // groups per thread = 16-bit fields of the packed scan
 constexpr int BMK_CHUNKS = 256;                             // 64-product chunks of a row: 1024 threads x 16 products
 constexpr int BMK_LEN_BITS = 23;                            // staging scan: B-row lengths (clamped) below, rows that are not empty above
-constexpr int BMK_CHAIN = 4;                                // products of one output element a lane adds by itself
 constexpr int BMK_DUP = 512;                                // parked products per row (wide form; the split form: 256)
 constexpr unsigned BMK_NONE = 0xffffffffu;
 constexpr int BMK_HEADER = 32;                              // words of `work` before the per-row state words
@@ -72,9 +71,9 @@ constexpr int BMK_HEADER = 32;                              // words of `work` b
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <typename V>
-struct BmkDup {   // (the size of a parked product: the kernel keeps the three fields in three arrays)
-  unsigned key;
-  unsigned rank;
+struct BmkDup {
+  unsigned key;   // (column << 8) | index of the A element
+  unsigned rank;  // position of the column in the row (first arrivers), BMK_NONE otherwise
   V val;
 };
 
@@ -120,7 +119,7 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ unsigned bmk_dpp0(unsigned src) {   // lanes without a source read 0
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)src, CTRL, ROW_MASK, 0xf, true);
 }
-// inclusive scan over the wave (ROWS = 4) or over the first row of 16 lanes (ROWS = 1) on DPP row shifts
+// inclusive scan of three words per lane over the wave (ROWS = 4) or over the first row of 16 lanes (ROWS = 1) on DPP row shifts
 template <int ROWS>
 __device__ __forceinline__ void bmk_wave_scan3(unsigned& x, unsigned& y, unsigned& z) {
 #define BMK_STEP(CTRL, MASK) { const unsigned tx = bmk_dpp0<CTRL, MASK>(x), ty = bmk_dpp0<CTRL, MASK>(y), tz = bmk_dpp0<CTRL, MASK>(z); x += tx; y += ty; z += tz; }
@@ -134,8 +133,9 @@ __device__ __forceinline__ void bmk_wave_scan3(unsigned& x, unsigned& y, unsigne
   }
 #undef BMK_STEP
 }
-// exclusive block scan of (a: four packed 16-bit counts - no field overflows, so the halves add independently -, b: one
-// 32-bit count); totals in ta / tb.  Two LDS barriers.
+// exclusive block scan of (a: four packed 16-bit counts - no field overflows, so the two halves add independently -, b: one
+// 32-bit count); totals in ta / tb.  Two LDS barriers.  (Round 4 went through `__shfl_up`, a ds_bpermute per step and word:
+// 6.5 k of a row's cycles; on DPP 1.7 k.)
 template <int THREADS>
 __device__ __forceinline__ void bmk_block_scan(unsigned long long& a, unsigned& b, unsigned long long& ta, unsigned& tb,
                                                BmkMisc* m) {
@@ -266,7 +266,7 @@ __device__ __forceinline__ int bmk_is_zero_bits(V v) {
 // ("virtual row" v = r * np + h; np = 1: whole rows).  Parts of one row are emitted one behind the other, so the look-back
 // runs over the virtual rows and the result is the same CSR.  With np > 1, `bsplit[k * (np - 1) + h]` = the first element of
 // B row k whose column is >= (h + 1) * range (spgemm_bsplit_kernel): a part's products are contiguous pieces of B rows.
-template <typename V, typename I, int ITEMS, int THREADS, int DUP, bool SPLIT, bool PACKED>
+template <typename V, typename I, int ITEMS, int THREADS, int DUP, bool SPLIT>
 __global__ void __launch_bounds__(THREADS, 4)   // (four waves per SIMD: one 1024-thread or two 512-thread workgroups per CU)
 spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, const I* __restrict__ a_ptr, const I* __restrict__ a_idx,
                      const V* __restrict__ a_val, const I* __restrict__ b_ptr, const I* __restrict__ bsplit,
@@ -283,11 +283,7 @@ spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, con
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned* const bm = reinterpret_cast<unsigned*>(smem);
   unsigned short* const pref = reinterpret_cast<unsigned short*>(smem + L::bitmap_bytes(ngroups));
-  // parked products, one array per field (the keys are scanned four to a read): key = (column << 8) | index of the A element;
-  // rank = position of the column in the row (first arrivers), BMK_NONE otherwise; the product.  Unused slots hold BMK_NONE.
-  unsigned* const dkey = reinterpret_cast<unsigned*>(smem + L::front_bytes(ngroups));
-  unsigned* const drank = dkey + DUP;
-  V* const dval = reinterpret_cast<V*>(drank + DUP);
+  BmkDup<V>* const dup = reinterpret_cast<BmkDup<V>*>(smem + L::front_bytes(ngroups));
   // the finished row in output order: 4-byte values as {column, value bits} pairs, 8-byte values as two arrays
   uint2* const row_cv = reinterpret_cast<uint2*>(smem);
   unsigned* const row_c = reinterpret_cast<unsigned*>(smem);
@@ -300,7 +296,7 @@ spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, con
       row_v[at] = v;
     }
   };
-  unsigned* const filt = reinterpret_cast<unsigned*>(dval + DUP);
+  unsigned* const filt = reinterpret_cast<unsigned*>(dup + DUP);
   BmkStage<V>* const stage = reinterpret_cast<BmkStage<V>*>(filt + FILT_WORDS);
   BmkMisc* const misc = reinterpret_cast<BmkMisc*>(stage + 2);
   unsigned long long* const state = work + BMK_HEADER;
@@ -311,7 +307,6 @@ spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, con
   // ---- set-up: clean LDS, the first two tickets -------------------------------------------------------------------------
   for (int i = tid; i < ngroups * 2; i += THREADS) reinterpret_cast<uint4*>(bm)[i] = make_uint4(0, 0, 0, 0);
   for (int i = tid; i < FILT_WORDS; i += THREADS) filt[i] = 0;
-  for (int i = tid; i < DUP; i += THREADS) dkey[i] = BMK_NONE;
   if (tid == 0) misc->ndup[0] = misc->ndup[1] = 0;
   lds_barrier();
   // Rows are dealt round-robin: workgroup w takes rows w, w + G, w + 2 G, ... (G = the grid = one workgroup per CU, all
@@ -410,20 +405,8 @@ spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, con
       for (int i = 4; more & 1ull; more >>= 1, ++i) e += p >= __builtin_amdgcn_readlane(b, i);
       if (p < P) {
         const int64_t q = st->bstart[e] + (int64_t)(p - (int)st->prefix[e]);
-        if constexpr (PACKED) {   // (b_val points at B's elements as (column, value) records: ONE load per product, one
-          if constexpr (sizeof(V) == 4) {   // run of cache lines per B row instead of two)
-            const uint2 cv = reinterpret_cast<const uint2*>(b_val)[q];
-            colN[j] = cv.x;
-            bvN[j] = __builtin_bit_cast(V, cv.y);
-          } else {
-            const uint4 cv = reinterpret_cast<const uint4*>(b_val)[q];
-            colN[j] = cv.x;
-            bvN[j] = __builtin_bit_cast(V, ((unsigned long long)cv.w << 32) | cv.z);
-          }
-        } else {
-          colN[j] = (unsigned)b_idx[q];
-          bvN[j] = b_val[q];
-        }
+        colN[j] = (unsigned)b_idx[q];
+        bvN[j] = b_val[q];
         eN[j / 4] |= (unsigned)e << (8 * (j % 4));
       }
       if (j % 8 == 7) __builtin_amdgcn_sched_barrier(0);   // (keeps the scheduler from hoisting all 2 x ITEMS address chains)
@@ -474,7 +457,7 @@ spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, con
   int buf = 0;
   int zero_count = 0;
 #ifdef BMK_PROF
-  unsigned long long prof[24] = {0};
+  unsigned long long prof[16] = {0};
   unsigned long long tprev = __builtin_readcyclecounter();
 #endif
 
@@ -494,6 +477,52 @@ spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, con
     // (the products stay where the prefetch put them - colN / bvN / eN - until the row is assembled in step 4: a second
     // copy of them, as keys and values, had the kernel spill 30 registers)
     unsigned first_mask = 0;
+#ifdef BMK_BATCH
+    // all of a thread's bitmap atomics are issued before the first answer is looked at (one LDS latency instead of ITEMS)
+    unsigned seen = 0;
+#pragma unroll
+    for (int j0 = 0; j0 < ITEMS; j0 += BMK_BATCH) {
+      unsigned oldw[BMK_BATCH];
+#pragma unroll
+      for (int jj = 0; jj < BMK_BATCH; ++jj) {
+        const int j = j0 + jj;
+        if (SPLIT && colN[j] != BMK_NONE && colN[j] - cbase >= (unsigned)range) {   // (see below)
+          failed = true;
+          colN[j] = BMK_NONE;
+        }
+        // (no branch around the atomic: a lane without a product ORs nothing into a word of its own)
+        const bool valid = colN[j] != BMK_NONE;
+        const unsigned c = colN[j] - cbase;
+        unsigned* const at = valid ? &bm[c >> 5] : &filt[lane];
+        oldw[jj] = atomicOr(at, valid ? 1u << (c & 31u) : 0u);
+      }
+#pragma unroll
+      for (int jj = 0; jj < BMK_BATCH; ++jj) {
+        const int j = j0 + jj;
+        const bool valid = colN[j] != BMK_NONE;
+        const unsigned c = colN[j] - cbase;
+        seen |= (valid && ((oldw[jj] >> (c & 31u)) & 1u)) ? 1u << j : 0u;
+        first_mask |= valid ? 1u << j : 0u;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    first_mask &= ~seen;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      if ((seen >> j) & 1u) {   // the output element has a product already: park this one
+        const unsigned c = colN[j] - cbase;
+        const unsigned e = (eN[j / 4] >> (8 * (j % 4))) & 255u;
+        const unsigned h = (c ^ (c >> 14)) & FILT_MASK;
+        atomicOr(&filt[h >> 5], 1u << (h & 31u));
+        const int slot = atomicAdd(ndup, 1);
+        if (slot < DUP) {
+          dup[slot].key = (c << 8) | e;
+          dup[slot].rank = BMK_NONE;
+          dup[slot].val = sc->aval[e] * bvN[j];
+        }
+      }
+    }
+#else
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
       // (a column outside this part's range: B's row is not sorted by column - the split form's binary search over it put the
@@ -514,9 +543,9 @@ spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, con
           atomicOr(&filt[h >> 5], 1u << (h & 31u));
           const int slot = atomicAdd(ndup, 1);
           if (slot < DUP) {
-            dkey[slot] = (c << 8) | e;
-            drank[slot] = BMK_NONE;
-            dval[slot] = sc->aval[e] * bvN[j];
+            dup[slot].key = (c << 8) | e;
+            dup[slot].rank = BMK_NONE;
+            dup[slot].val = sc->aval[e] * bvN[j];
           }
         } else {
           first_mask |= 1u << j;
@@ -524,6 +553,7 @@ spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, con
       }
       if (j % 8 == 7) __builtin_amdgcn_sched_barrier(0);
     }
+#endif
     BMK_T(1)
     lds_barrier();
     BMK_T(2)
@@ -539,12 +569,9 @@ spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, con
         los |= (unsigned)lo_cnt << (8 * m);
       }
     }
-    BMK_T(16)
     unsigned long long excl_c = cnts, tot_c;
     unsigned excl_l = scan_word(len), tot_l;
-    BMK_T(17)
     bmk_block_scan<THREADS>(excl_c, excl_l, tot_c, tot_l, misc);
-    BMK_T(18)
     int row_nnz = 0;
 #pragma unroll
     for (int m = 0; m < BMK_GPT; ++m) {
@@ -585,9 +612,9 @@ spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, con
           const unsigned e = (eN[j / 4] >> (8 * (j % 4))) & 255u;
           const int slot = atomicAdd(ndup, 1);
           if (slot < DUP) {
-            dkey[slot] = (c << 8) | e;
-            drank[slot] = (unsigned)r;
-            dval[slot] = sc->aval[e] * bvN[j];
+            dup[slot].key = (c << 8) | e;
+            dup[slot].rank = (unsigned)r;
+            dup[slot].val = sc->aval[e] * bvN[j];
           }
         }
       }
@@ -608,117 +635,58 @@ spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, con
     BMK_T(8)
     expand(sn, nE_n, P_n);
     BMK_T(9)
-    // ---- 5. parked products: the entry with the smallest A-element index of its column adds the column's products left to
-    // right, in the order of A's elements.  A LANE per entry, four waves (one per SIMD; wave 0 looks back meanwhile): every
-    // lane reads the whole key list, four keys to a (broadcast) read - ~130 entries at config 5: the 50 parked products,
-    // their columns' first arrivers and ~30 the filter sent along.  One pass finds the column's smallest key and its entry
-    // count, one more pass per further product of the column the next larger key.  (Round 4: a wave per entry, 8 entries per
-    // wave one after the other, each a chain of LDS reads and two wave reductions: 10-17 k of a row's 60 k cycles.)  Columns
-    // with more than BMK_CHAIN products - a hot column of B - go through that wave-per-entry form afterwards.
+    // ---- 5. parked products: a WAVE per entry scans the list (8 entries per lane at most); the entry with the smallest
+    // A-element index of its column adds the column's products left to right, in the order of A's elements ------------
     {
       int n = *ndup;
       if (n > DUP) {
         failed = true;
         n = DUP;
       }
-      constexpr int PW0 = 4, PWN = 4;
-      static_assert(PW0 + PWN <= THREADS / 64, "the waves that add the parked products");
-      if (wid >= PW0 && wid < PW0 + PWN) {
-        for (int base = (wid - PW0) * 64; base < n; base += PWN * 64) {   // (wave-uniform)
-          const int d = base + lane;
-          const bool act = d < n;
-          const unsigned kd = act ? dkey[d] : BMK_NONE;
-          const unsigned c = kd >> 8;     // (lanes without an entry: the column of the unused slots - they do nothing with it)
-          unsigned lo = BMK_NONE;
-          int cnt = 0;
-          for (int i = 0; i < n; i += 4) {
-            const uint4 k4 = *reinterpret_cast<const uint4*>(dkey + i);
-            const unsigned kk[4] = {k4.x, k4.y, k4.z, k4.w};
+      constexpr int PER = DUP / 64;
+      unsigned lk[PER];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const bool m = (kk[q] >> 8) == c;
-              lo = m && kk[q] < lo ? kk[q] : lo;
-              cnt += m;
-            }
-          }
-          const bool head = act && lo == kd;
-          const bool hot = head && cnt > BMK_CHAIN;
-          V acc = V(0);
-          unsigned rank = BMK_NONE, last = kd;
-          if (head && !hot) {
-            acc = dval[d];
-            rank = drank[d];
-          }
-          int left = head && !hot ? cnt - 1 : 0;
-          while (__ballot(left > 0) != 0) {   // (at most BMK_CHAIN - 1 passes)
-            unsigned nx = BMK_NONE;
-            int at = 0;
-            for (int i = 0; i < n; i += 4) {
-              const uint4 k4 = *reinterpret_cast<const uint4*>(dkey + i);
-              const unsigned kk[4] = {k4.x, k4.y, k4.z, k4.w};
+      for (int t = 0; t < PER; ++t) lk[t] = lane + 64 * t < n ? dup[lane + 64 * t].key : BMK_NONE;
+      for (int d = wid; d < n; d += THREADS / 64) {
+        const unsigned kd = dup[d].key;          // (wave-uniform)
+        const unsigned c = kd >> 8;
+        // smallest key of the column, and where the column's position is recorded (exactly one entry has it)
+        unsigned lo = BMK_NONE;
+        int cnt = 0, holder = -1;
 #pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const bool m = (kk[q] >> 8) == c && kk[q] > last && kk[q] < nx;
-                nx = m ? kk[q] : nx;
-                at = m ? i + q : at;
-              }
-            }
-            if (left > 0) {
-              if (nx == BMK_NONE) {   // fewer distinct keys than entries of this column: a B row holds the column TWICE
-                failed = true;        // (equal (column, A element) keys) - not a canonical operand; the bucket kernels take it
-                left = 0;
-              } else {
-                acc = acc + dval[at];
-                const unsigned r2 = drank[at];
-                rank = r2 != BMK_NONE ? r2 : rank;
-                last = nx;
-                --left;
-              }
-            }
-          }
-          if (head && !hot && rank != BMK_NONE) put(rank, c + cbase, acc);   // (always a position, unless the list overflowed)
-          // hot columns: the wave takes them one after the other, the key list spread over its lanes
-          unsigned long long hots = __ballot(hot);
-          if (hots) {
-            constexpr int PER = DUP / 64;
-            unsigned lk[PER];
-#pragma unroll
-            for (int t = 0; t < PER; ++t) lk[t] = dkey[lane + 64 * t];
-            while (hots) {
-              const int hl = (int)__builtin_ctzll(hots);
-              hots &= hots - 1;
-              const int hd = base + hl;
-              const unsigned hk = (unsigned)__builtin_amdgcn_readlane((int)kd, hl);
-              const unsigned hc = hk >> 8;
-              const int hcnt = __builtin_amdgcn_readlane(cnt, hl);
-              V hacc = dval[hd];
-              unsigned hrank = drank[hd];
-              unsigned hlast = hk;
-              for (int step = 1; step < hcnt; ++step) {   // the next larger A-element index of this column, hcnt - 1 times
-                unsigned nx = BMK_NONE;
-                int at = 0;
-#pragma unroll
-                for (int t = 0; t < PER; ++t) {
-                  const bool m = (lk[t] >> 8) == hc && lk[t] > hlast && lk[t] < nx;
-                  nx = m ? lk[t] : nx;
-                  at = m ? lane + 64 * t : at;
-                }
-                const unsigned best = wave_min_u32(nx);
-                const unsigned long long who = __ballot(nx == best && best != BMK_NONE);
-                if (who == 0) {
-                  failed = true;
-                  break;
-                }
-                const int src = __builtin_amdgcn_readlane(at, (int)__builtin_ctzll(who));
-                hacc = hacc + dval[src];
-                const unsigned r2 = drank[src];
-                hrank = r2 != BMK_NONE ? r2 : hrank;
-                hlast = best;
-              }
-              if (lane == 0 && hrank != BMK_NONE) put(hrank, hc + cbase, hacc);
-            }
-          }
+        for (int t = 0; t < PER; ++t) {
+          const bool m = lk[t] != BMK_NONE && (lk[t] >> 8) == c;
+          lo = m && lk[t] < lo ? lk[t] : lo;
+          cnt += m;
         }
+        lo = wave_min_u32(lo);                   // (DPP: round 4 reduced through ds_bpermute - a parked entry cost ~2 k cycles)
+        cnt = (int)wave_sum_u32((unsigned)cnt);
+        if (lo != kd) continue;                  // not the first A element of this column (wave-uniform)
+        V acc = dup[d].val;
+        unsigned rank = dup[d].rank;
+        unsigned last = kd;
+        for (int step = 1; step < cnt; ++step) {   // the next larger A-element index of this column, cnt - 1 times
+          unsigned nx = BMK_NONE;
+          int at = 0;
+#pragma unroll
+          for (int t = 0; t < PER; ++t) {
+            const bool m = lk[t] != BMK_NONE && (lk[t] >> 8) == c && lk[t] > last && lk[t] < nx;
+            nx = m ? lk[t] : nx;
+            at = m ? lane + 64 * t : at;
+          }
+          const unsigned best = wave_min_u32(nx);
+          const unsigned long long who = __ballot(nx == best && best != BMK_NONE);
+          if (who == 0) {   // fewer distinct keys than entries of this column: a B row holds the column TWICE (equal
+            failed = true;  // (column, A element) keys) - not a canonical operand; fail the call, the bucket kernels take it
+            break;
+          }
+          const int src = __builtin_amdgcn_readlane(at, (int)__builtin_ctzll(who));
+          acc = acc + dup[src].val;
+          const unsigned r2 = dup[src].rank;
+          rank = r2 != BMK_NONE ? r2 : rank;
+          last = best;
+        }
+        if (lane == 0 && rank != BMK_NONE) put(rank, c + cbase, acc);   // (always a position, unless the list overflowed: failed anyway)
       }
     }
     BMK_T(10)
@@ -772,7 +740,6 @@ spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, con
       }
     }
     for (int i = tid; i < FILT_WORDS; i += THREADS) filt[i] = 0;
-    for (int i = tid; i < DUP; i += THREADS) dkey[i] = BMK_NONE;
     if (tid == 0) misc->ndup[buf ^ 1] = 0;   // (the previous row's count: read for the last time two barriers ago)
     BMK_T(12)
     lds_barrier();
@@ -786,7 +753,7 @@ spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, con
   }
 #ifdef BMK_PROF
   if (tid == 0)
-    for (int k = 0; k < 24; ++k) atomicAdd(work + 4 + k, prof[k]);
+    for (int k = 0; k < 16; ++k) atomicAdd(work + 4 + k, prof[k]);
 #endif
   // ---- epilogue: exact zeros written, failure word ------------------------------------------------------------------------
 #pragma unroll
@@ -838,12 +805,12 @@ static int64_t bmk_split_max_groups() {   // groups of 256 columns whose bitmap 
   return g;
 }
 
-template <typename V, typename I, int ITEMS, int THREADS, int DUP, bool SPLIT, bool PACKED>
+template <typename V, typename I, int ITEMS, int THREADS, int DUP, bool SPLIT>
 static int bmk_launch(int64_t n_row, int np, int64_t range, const I* a_ptr, const I* a_idx, const V* a_val, const I* b_ptr,
                       const I* bsplit, const I* b_idx, const V* b_val, unsigned long long* work, int64_t* out_ptr,
                       int64_t* out_idx, V* out_val, hipStream_t s) {
   using L = BmkLayout<V, THREADS, ITEMS, DUP>;
-  auto kern = &spgemm_bitmap_kernel<V, I, ITEMS, THREADS, DUP, SPLIT, PACKED>;
+  auto kern = &spgemm_bitmap_kernel<V, I, ITEMS, THREADS, DUP, SPLIT>;
   const int ngroups = (int)ceil_div(range, (int64_t)256);
   if (ngroups > BMK_GPT * THREADS) return SPAMD_EINVAL;
   const size_t lds = L::bytes(ngroups);
@@ -890,10 +857,10 @@ extern "C" int64_t spamd_spgemm_bitmap_limits(int val_dtype, int which) {
 // = n_inner * (parts - 1) words of the index type, filled here (n_inner = rows of B).  work: n_row * parts + 32 words,
 // zeroed here; afterwards work[1] != 0 = failed (a row or part outside the limits, or with more parked products than the
 // list holds: discard the result), work[2] = values written whose bits are all zero.
-static int bmk_run(bool packed, int val_dtype, int idx_dtype, int64_t n_row, int64_t n_inner, int64_t n_col, int parts,
-                   const void* a_indptr, const void* a_indices, const void* a_data, const void* b_indptr,
-                   const void* b_indices, const void* b_data, void* bsplit, int64_t* work,
-                   int64_t* out_indptr, int64_t* out_indices, void* out_data, void* stream) {
+extern "C" int spamd_spgemm_bitmap(int val_dtype, int idx_dtype, int64_t n_row, int64_t n_inner, int64_t n_col, int parts,
+                                   const void* a_indptr, const void* a_indices, const void* a_data, const void* b_indptr,
+                                   const void* b_indices, const void* b_data, void* bsplit, int64_t* work,
+                                   int64_t* out_indptr, int64_t* out_indices, void* out_data, void* stream) {
   if (n_row < 0 || n_inner < 0 || n_col <= 0 || parts < 1 || parts > 4096 || !work || !out_indptr) return SPAMD_EINVAL;
   if (parts > 1 && !bsplit) return SPAMD_EINVAL;
   const bool v4 = val_dtype == SPAMD_F32 || val_dtype == SPAMD_I32;
@@ -911,12 +878,9 @@ static int bmk_run(bool packed, int val_dtype, int idx_dtype, int64_t n_row, int
   }
   unsigned long long* const w = reinterpret_cast<unsigned long long*>(work);
 #define BMK_GO(V, I, ITEMS, THREADS, DUP, SPLIT)                                                                                  \
-  return (packed ? bmk_launch<V, I, ITEMS, THREADS, DUP, SPLIT, true>(n_row, parts, range, (const I*)a_indptr, (const I*)a_indices, \
-                       (const V*)a_data, (const I*)b_indptr, (const I*)bsplit, (const I*)b_indices, (const V*)b_data, w,          \
-                       out_indptr, out_indices, (V*)out_data, s)                                                                  \
-                 : bmk_launch<V, I, ITEMS, THREADS, DUP, SPLIT, false>(n_row, parts, range, (const I*)a_indptr, (const I*)a_indices, \
-                       (const V*)a_data, (const I*)b_indptr, (const I*)bsplit, (const I*)b_indices, (const V*)b_data, w,          \
-                       out_indptr, out_indices, (V*)out_data, s));
+  return (bmk_launch<V, I, ITEMS, THREADS, DUP, SPLIT>(n_row, parts, range, (const I*)a_indptr, (const I*)a_indices, (const V*)a_data, \
+                                                (const I*)b_indptr, (const I*)bsplit, (const I*)b_indices, (const V*)b_data, w,  \
+                                                out_indptr, out_indices, (V*)out_data, s));
   if (parts > 1) {
     SPAMD_DISPATCH_VAL(val_dtype, V, {
       SPAMD_DISPATCH_IDX(idx_dtype, I, { BMK_GO(V, I, BmkSplitItems<V>::value, BMK_SPLIT_THREADS, BMK_SPLIT_DUP, true) })
@@ -927,60 +891,5 @@ static int bmk_run(bool packed, int val_dtype, int idx_dtype, int64_t n_row, int
     SPAMD_DISPATCH_IDX(idx_dtype, I, { BMK_GO(V, I, BmkItems<V>::value, BMK_THREADS, BMK_DUP, false) })
   })
 #undef BMK_GO
-  return SPAMD_ETYPE;
-}
-
-extern "C" int spamd_spgemm_bitmap(int val_dtype, int idx_dtype, int64_t n_row, int64_t n_inner, int64_t n_col, int parts,
-                                   const void* a_indptr, const void* a_indices, const void* a_data, const void* b_indptr,
-                                   const void* b_indices, const void* b_data, void* bsplit, int64_t* work,
-                                   int64_t* out_indptr, int64_t* out_indices, void* out_data, void* stream) {
-  return bmk_run(false, val_dtype, idx_dtype, n_row, n_inner, n_col, parts, a_indptr, a_indices, a_data, b_indptr, b_indices, b_data,
-                 bsplit, work, out_indptr, out_indices, out_data, stream);
-}
-
-// The same product with B's elements as (column, value) RECORDS (spamd_spgemm_pack_b): a product is one load instead of two,
-// a B row one run of cache lines instead of two (round 5: the product requests are what the kernel waits for).  b_indices is
-// still read where a row is cut into parts (parts > 1); b_records replaces b_data.
-extern "C" int spamd_spgemm_bitmap_packed(int val_dtype, int idx_dtype, int64_t n_row, int64_t n_inner, int64_t n_col, int parts,
-                                          const void* a_indptr, const void* a_indices, const void* a_data, const void* b_indptr,
-                                          const void* b_indices, const void* b_records, void* bsplit, int64_t* work,
-                                          int64_t* out_indptr, int64_t* out_indices, void* out_data, void* stream) {
-  if (!b_records) return SPAMD_EINVAL;
-  return bmk_run(true, val_dtype, idx_dtype, n_row, n_inner, n_col, parts, a_indptr, a_indices, a_data, b_indptr, b_indices, b_records,
-                 bsplit, work, out_indptr, out_indices, out_data, stream);
-}
-
-namespace spamd {
-template <typename V, typename I>
-__global__ void __launch_bounds__(256) spgemm_pack_b_kernel(int64_t nnz, const I* __restrict__ idx, const V* __restrict__ val,
-                                                            void* __restrict__ rec) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= nnz) return;
-  if constexpr (sizeof(V) == 4) {
-    reinterpret_cast<uint2*>(rec)[i] = make_uint2((unsigned)idx[i], __builtin_bit_cast(unsigned, val[i]));
-  } else {
-    const unsigned long long b = __builtin_bit_cast(unsigned long long, val[i]);
-    reinterpret_cast<uint4*>(rec)[i] = make_uint4((unsigned)idx[i], 0u, (unsigned)b, (unsigned)(b >> 32));
-  }
-}
-}  // namespace spamd
-
-// records[nnz] for spamd_spgemm_bitmap_packed: 8 bytes {column, value bits} for 4-byte values, 16 bytes {column, 0, value}
-// for 8-byte ones (columns < 2^32: the bitmap kernel's own limit is far below)
-extern "C" int64_t spamd_spgemm_record_bytes(int val_dtype) {
-  return (val_dtype == SPAMD_F32 || val_dtype == SPAMD_I32) ? 8 : 16;
-}
-extern "C" int spamd_spgemm_pack_b(int val_dtype, int idx_dtype, int64_t nnz, const void* b_indices, const void* b_data, void* records,
-                                   void* stream) {
-  if (nnz < 0 || (nnz && (!b_indices || !b_data || !records))) return SPAMD_EINVAL;
-  if (nnz == 0) return 0;
-  hipStream_t s = (hipStream_t)stream;
-  SPAMD_DISPATCH_VAL(val_dtype, V, {
-    SPAMD_DISPATCH_IDX(idx_dtype, I, {
-      hipLaunchKernelGGL((spgemm_pack_b_kernel<V, I>), dim3((unsigned)ceil_div(nnz, (int64_t)256)), dim3(256), 0, s, nnz,
-                         (const I*)b_indices, (const V*)b_data, records);
-      return launch_status();
-    })
-  })
   return SPAMD_ETYPE;
 }
