@@ -25,40 +25,70 @@ __device__ __forceinline__ int64_t max_seen(const int64_t* p) {  // a stale read
   return __builtin_nontemporal_load(p);
 }
 
+// products per output row: prod[r] = sum over A's elements (r, k) of the length of B row k; maxes = {largest prod, longest A row}.
+// A workgroup takes SPG_RP_ROWS consecutive rows and walks their elements FLAT (element e belongs to the last row whose
+// pointer is <= e: a binary search over the workgroup's pointers in LDS), four elements per thread and trip so that their
+// index loads and then their eight pointer loads are in flight together; a wave whose 64 elements are of one row adds once.
+// (Rounds 2-4: a wave per row, one element per lane and trip - 0.49-0.57 ms for config 5's block of 1.25e7 elements.)
+constexpr int SPG_RP_ROWS = 64;
 template <typename I>
 __global__ void __launch_bounds__(256) spgemm_row_products_kernel(int64_t n_row, const I* __restrict__ a_ptr,
                                                                   const I* __restrict__ a_idx, const I* __restrict__ b_ptr,
                                                                   int64_t* __restrict__ prod, int64_t* __restrict__ maxes) {
-  // one wave per row
-  const int lane = threadIdx.x & 63;
-  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  int64_t a0 = 0, a1 = 0;
-  if (row < n_row) {
-    a0 = (int64_t)a_ptr[row];
-    a1 = (int64_t)a_ptr[row + 1];
-  }
-  int64_t s = 0;
-  for (int64_t e = a0 + lane; e < a1; e += 64) {
-    const int64_t k = (int64_t)a_idx[e];
-    s += (int64_t)b_ptr[k + 1] - (int64_t)b_ptr[k];
-  }
+  __shared__ int64_t rp[SPG_RP_ROWS + 1];
+  __shared__ unsigned long long acc[SPG_RP_ROWS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int64_t r0 = (int64_t)blockIdx.x * SPG_RP_ROWS;
+  const int nr = (int)(n_row - r0 < SPG_RP_ROWS ? n_row - r0 : SPG_RP_ROWS);
+  if (tid <= nr) rp[tid] = (int64_t)a_ptr[r0 + tid];
+  if (tid < SPG_RP_ROWS) acc[tid] = 0;
+  __syncthreads();
+  const int64_t e0 = rp[0], e1 = rp[nr];
+  for (int64_t eb = e0 + (tid & ~63) * 4; eb < e1; eb += 256 * 4) {   // (a wave takes 4 x 64 consecutive elements per trip)
+    int64_t k[4], lo[4], hi[4];
 #pragma unroll
-  for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
-  // block maxima first: 10^5 same-address atomics from every wave serialise (2 ms); one pair per workgroup does not
-  __shared__ int64_t wmax[2][4];
-  if (lane == 0) {
-    if (row < n_row) prod[row] = s;
-    wmax[0][threadIdx.x >> 6] = s;
-    wmax[1][threadIdx.x >> 6] = a1 - a0;
+    for (int u = 0; u < 4; ++u) {
+      const int64_t e = eb + 64 * u + lane;
+      k[u] = e < e1 ? (int64_t)a_idx[e] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      lo[u] = k[u] >= 0 ? (int64_t)b_ptr[k[u]] : 0;
+      hi[u] = k[u] >= 0 ? (int64_t)b_ptr[k[u] + 1] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t e = eb + 64 * u + lane;
+      int t = 0;
+#pragma unroll
+      for (int step = SPG_RP_ROWS / 2; step >= 1; step >>= 1) t = (t + step <= nr && rp[t + step] <= e) ? t + step : t;
+      const unsigned long long len = k[u] >= 0 ? (unsigned long long)(hi[u] - lo[u]) : 0ull;
+      const int t0 = __builtin_amdgcn_readfirstlane(t);
+      if (__ballot(t != t0) == 0) {          // one row (or nothing but the tail beyond e1, which adds 0)
+        unsigned long long v = len;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+        if (lane == 0 && v) atomicAdd(&acc[t0 < nr ? t0 : nr - 1], v);
+      } else if (len) {
+        atomicAdd(&acc[t < nr ? t : nr - 1], len);
+      }
+    }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int64_t m0 = 0, m1 = 0;
-    const int64_t first = (int64_t)blockIdx.x * 4;
-    for (int w = 0; w < 4 && first + w < n_row; ++w) {
-      m0 = wmax[0][w] > m0 ? wmax[0][w] : m0;
-      m1 = wmax[1][w] > m1 ? wmax[1][w] : m1;
-    }
+  int64_t m0 = 0, m1 = 0;
+  if (tid < nr) {
+    m0 = (int64_t)acc[tid];
+    m1 = rp[tid + 1] - rp[tid];
+    prod[r0 + tid] = m0;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const int64_t y0 = __shfl_xor(m0, d, 64), y1 = __shfl_xor(m1, d, 64);
+    m0 = y0 > m0 ? y0 : m0;
+    m1 = y1 > m1 ? y1 : m1;
+  }
+  // (one pair of atomics per workgroup at most: 10^5 same-address atomics from every wave serialise - 2 ms)
+  if (tid == 0) {   // (rows sit in the first wave: SPG_RP_ROWS = 64)
     if (m0 > max_seen(maxes)) atomicMax(reinterpret_cast<unsigned long long*>(maxes), (unsigned long long)m0);
     if (m1 > max_seen(maxes + 1)) atomicMax(reinterpret_cast<unsigned long long*>(maxes + 1), (unsigned long long)m1);
   }
@@ -607,7 +637,7 @@ extern "C" int spamd_spgemm_row_products(int idx_dtype, int64_t n_row, const voi
   e = hipMemsetAsync(prod + n_row, 0, sizeof(int64_t), s);
   if (e != hipSuccess) return (int)e;
   if (n_row == 0) return 0;
-  SPAMD_DISPATCH_IDX(idx_dtype, I, hipLaunchKernelGGL(spgemm_row_products_kernel<I>, dim3((unsigned)ceil_div(n_row, (int64_t)4)),
+  SPAMD_DISPATCH_IDX(idx_dtype, I, hipLaunchKernelGGL(spgemm_row_products_kernel<I>, dim3((unsigned)ceil_div(n_row, (int64_t)SPG_RP_ROWS)),
                                                       dim3(256), 0, s, n_row, (const I*)a_indptr, (const I*)a_indices,
                                                       (const I*)b_indptr, prod, maxes))
   return launch_status();
