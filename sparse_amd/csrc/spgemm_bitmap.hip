@@ -42,7 +42,11 @@
 // third; waiting for the products before the row's stores are issued (so that no later wait covers the stores) 13.3: no change.
 // Model: per row and CU ~15 k cycles of product loads, ~15 k of result stores and ~35 k of LDS
 // phases run one after the other (64 k cycles per row); the fabric moves 30 GB per product at 2.4 TB/s.
-// Limits (checked by the host before the launch, spamd_spgemm_bitmap_limits): n_col <= 2^20, A rows of at most 256
+// Round 5 (13.3 -> 11.2 ms, bit-identical; docs/history/r05.md): the numbers above are round 4's.  Since then a product's A
+// element comes from a chunk table (one search per 64 products) instead of a search per product, a position is read from
+// 16 bytes (a count per half group) instead of 32, the block scans and the parked products' reductions run on DPP instead of
+// ds_bpermute, and no instance spills a register.  Per row now ~28 k cycles of LDS phases + ~25 k of memory time, in sequence.
+// Limits (checked by the host before the launch, spamd_spgemm_bitmap_limits): n_col <= 2^20 (8-byte values: ~1.02e6), A rows of at most 256
 // elements, at most 1024 * ITEMS products per row (ITEMS = 16 for 4-byte values, 8 for 8-byte ones: the row must fit the
 // LDS region), index arrays of either width.  A row whose parked products exceed the list (512 entries) sets the `failed`
 // word: the caller then discards the result and uses spgemm_rows.hip.  So does a B operand that is not canonical: a row with
