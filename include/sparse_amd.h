@@ -469,6 +469,18 @@ int spamd_spgemm_bitmap(int val_dtype, int idx_dtype, int64_t n_row, int64_t n_i
                         const void* b_indices, const void* b_data, void* bsplit, int64_t* work, int64_t* out_indptr,
                         int64_t* out_indices, void* out_data, void* stream);
 
+/* A8 / A6 (round 5): keys of a canonical COO with its LEADING axes moved last, sorted, without a sort.  The reference's
+ * reduction over axes 0 .. m-1 transposes the kept axes first and sorts every stored element (`COO.reduce` ->
+ * `_reduce_calc`, _coo/core.py:693-723; `transpose` + `reshape`, :1601-1661).  Sorted keys = S sorted runs (one per index of the
+ * leading axes), merged by ranges of kept cells in LDS (csrc/lead_rotate.hip).  keys[n] sorted and duplicate-free,
+ * key = s * P + c; out_keys[n] = c * S + s ascending, out_vals in that order (val_bytes 4 / 8, bit-wise).
+ * cells_per_range: a power of two <= spamd_keys_lead_last_limits(1); bounds: S * (ceil(P / cells_per_range) + 1) ints of
+ * workspace; S <= limits(0); n < 2^31.  *failed (device, zeroed here) != 0: a range held more than limits(2) elements or a
+ * cell more than 64 - out_* are incomplete, use spamd_permute_keys + spamd_sort_kv. */
+int64_t spamd_keys_lead_last_limits(int which);
+int spamd_keys_lead_last(int val_bytes, int64_t n, const int64_t* keys, const void* vals, int64_t S, int64_t P,
+                         int64_t cells_per_range, int* bounds, int64_t* out_keys, void* out_vals, int64_t* failed, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * A9  SDDMM      out[n] = s[n] * sum_k A[rows[n], k] * Bt[cols[n], k]
  *   replaces the reference's formulation `s * (a @ b)` (examples/sddmm_example.py:51-52: a dense

@@ -239,6 +239,37 @@ def permute_keys(keys, src_shape, perm):
     return out
 
 
+LEAD_LAST = True               # reductions over the leading axes: the kept-axes-first order by merging the slabs (csrc/lead_rotate.hip)
+LEAD_LAST_RANGE = 2048         # elements a cell range should hold (the kernel's arrays take 4096)
+LEAD_LAST_STATS = {}
+
+
+def keys_lead_last(keys, vals, n_slabs, n_cells, failed):
+    """(keys', vals') of a canonical COO whose leading axes (n_slabs index values) are moved behind the kept ones (n_cells):
+    keys' = cell * n_slabs + slab, ascending - what `permute_keys` + `sort_key_value` return, without the sort.  None when
+    the shape of the problem is not the kernel's (many slabs, few elements in a huge key space); `failed`: a device int64
+    word the kernels set when a range was too full (the caller reads it with its own read-back and takes the sort then)."""
+    dev = require_hip(keys, vals)
+    n = int(keys.numel())
+    lim = _ffi.lib().spamd_keys_lead_last_limits
+    if (not LEAD_LAST or n == 0 or n >= 2 ** 31 or n_slabs > int(lim(0)) or vals.element_size() not in (4, 8)
+            or n_cells >= 2 ** 42):
+        return None
+    cells = 1
+    while cells * 2 <= int(lim(1)) and cells * 2 * n <= LEAD_LAST_RANGE * n_cells:
+        cells *= 2
+    ranges = -(-n_cells // cells)
+    # (every range is a workgroup, every (slab, range) a boundary word: a key space far larger than the element count is the sort's)
+    if ranges > max(4096, n // 64) or n_slabs * (ranges + 1) > 8 * n + (1 << 20):
+        return None
+    bounds = torch.empty(n_slabs * (ranges + 1), dtype=torch.int32, device=dev)
+    ko, vo = torch.empty_like(keys), torch.empty_like(vals)
+    _ffi.call("spamd_keys_lead_last", vals.element_size(), n, ptr(keys.contiguous()), ptr(vals.contiguous()), int(n_slabs), int(n_cells),
+              cells, ptr(bounds), ptr(ko), ptr(vo), ptr(failed), stream_ptr(dev))
+    LEAD_LAST_STATS.update(cells=cells, ranges=ranges, calls=LEAD_LAST_STATS.get("calls", 0) + 1)
+    return ko, vo
+
+
 def keys_check(keys):
     """(not_sorted, has_duplicates) of a key array — the `np.diff(linear)` checks of reference
     core.py:1310-1313,1331-1338.  Synchronises (8 bytes copied back)."""

@@ -41,7 +41,7 @@ def segment_reduce(data, heads, offs, count, op, want_counts=False, sequential=F
     return (out, counts) if want_counts else out
 
 
-def group_reduce(keys, divisor, data, op, key_bound=0, sync=True):
+def group_reduce(keys, divisor, data, op, key_bound=0, sync=True, ng=None):
     """One pass over SORTED keys: runs of equal `keys // divisor` -> (group ids, reduced values, run lengths).
     C ABI `spamd_group_reduce` (reference `_reduce_calc`, _coo/core.py:1601-1661).  `sync=False`: nothing is read back -
     returns the n-sized output buffers and a device int64[2] whose first word is the number of groups."""
@@ -53,7 +53,8 @@ def group_reduce(keys, divisor, data, op, key_bound=0, sync=True):
     gids = torch.empty(n, dtype=torch.int64, device=dev)
     vals = torch.empty(n, dtype=data.dtype, device=dev)
     counts = torch.empty(n, dtype=torch.int64, device=dev)
-    ng = torch.empty(2, dtype=torch.int64, device=dev)
+    if ng is None:
+        ng = torch.empty(2, dtype=torch.int64, device=dev)
     ws_bytes = int(_ffi.lib().spamd_group_reduce_ws_bytes(code, n))
     if ws_bytes < 0:
         raise _ffi.HipBackendError(f"spamd_group_reduce_ws_bytes failed: {ws_bytes}")
@@ -136,7 +137,7 @@ def _reduce_on_host(x, method, axis, keepdims, kwargs, out_gcxs):
     return out.asformat("gcxs") if out_gcxs else out
 
 
-def reduce_impl(x, method, axis=(0,), keepdims=False, **kwargs):
+def reduce_impl(x, method, axis=(0,), keepdims=False, _no_merge=False, **kwargs):
     from ._coo import COO
     from ._gcxs import GCXS
 
@@ -185,13 +186,23 @@ def reduce_impl(x, method, axis=(0,), keepdims=False, **kwargs):
     # move kept axes first (key permutation + stable sort), group id = key // n_cols
     keys = x.linear_loc()
     order = kept + tuple(axis)
+    ng = None        # [groups, results equal to the fill value, "the slab merge gave up"]: one read-back below
     if order != tuple(range(x.ndim)) and x.nnz:
-        keys = K.permute_keys(keys, x.shape, order)
-        if data.element_size() in (4, 8):  # the values ride along as the sort payload (no permutation + gather)
-            keys, data = K.sort_key_value(keys, data, max(x.size - 1, 1))
+        merged = None
+        if not _no_merge and tuple(axis) == tuple(range(len(axis))) and n_groups > 0:
+            # the reduced axes lead: the elements are n_cols sorted runs (one per index of those axes) - merged, not sorted
+            ng = torch.zeros(3, dtype=torch.int64, device=dev)
+            merged = K.keys_lead_last(keys, data, n_cols, n_groups, ng[2:])
+        if merged is not None:
+            keys, data = merged
         else:
-            keys, perm = K.sort_keys(keys, max(x.size - 1, 1))
-            data = K.gather(data, perm)
+            ng = None
+            keys = K.permute_keys(keys, x.shape, order)
+            if data.element_size() in (4, 8):  # the values ride along as the sort payload (no permutation + gather)
+                keys, data = K.sort_key_value(keys, data, max(x.size - 1, 1))
+            else:
+                keys, perm = K.sort_keys(keys, max(x.size - 1, 1))
+                data = K.gather(data, perm)
     result_fill = np.asarray(fv).astype(res_np_dtype)[()] if name not in ("logical_or", "logical_and") else np.bool_(fv)
     if super_ufunc is not None:
         with np.errstate(all="ignore"):
@@ -204,7 +215,7 @@ def reduce_impl(x, method, axis=(0,), keepdims=False, **kwargs):
         # result's fill value, and both numbers come back in a single copy (each `.item()` is a stream synchronisation,
         # which at config-1 sizes costs as much as the kernels)
         n = int(keys.numel())
-        gids, vals, counts, ng = group_reduce(keys, max(n_cols, 1), data, name, key_bound=max(int(x.size), 1), sync=False)
+        gids, vals, counts, ng = group_reduce(keys, max(n_cols, 1), data, name, key_bound=max(int(x.size), 1), sync=False, ng=ng)
         vcode = _ffi.U8 if vals.dtype == torch.uint8 else code_of(vals.dtype)
         fvn = np.asarray(result_fill if super_ufunc is None else fv)
         with np.errstate(all="ignore"):
@@ -214,7 +225,14 @@ def reduce_impl(x, method, axis=(0,), keepdims=False, **kwargs):
         eq_bits = int(np.asarray(final_fill).astype(eq_np).reshape(1).view(f"u{eq_np.itemsize}")[0])
         _ffi.call("spamd_reduce_fill_count", _RED_OPS[name], vcode, n, ptr(ng), ptr(vals), ptr(counts), int(n_cols),
                   fill_f, fill_i, eq_bits, ptr(ng) + 8, stream_ptr(dev))
-        count, n_eq = (int(v) for v in ng.tolist())
+        head = [int(v) for v in ng.tolist()]
+        count, n_eq = head[0], head[1]
+        if len(head) > 2 and head[2]:
+            # a cell range (or one output cell) held more elements than the merge kernel's arrays: the general order by sorting
+            if dtype is not None:
+                kwargs["dtype"] = dtype
+            r = reduce_impl(x, method, axis=axis, keepdims=keepdims, _no_merge=True, **kwargs)
+            return r.asformat("gcxs") if out_gcxs and not isinstance(r, GCXS) and getattr(r, "ndim", 0) else r
         gids, vals = gids[:count], vals[:count]
         if n_eq:    # results equal to the fill value are not stored (rare: a sum that cancels exactly, a max of zeros)
             flags = K.flag_ne_bits(vals, final_fill if vals.dtype != torch.uint8 else np.uint8(bool(final_fill)))

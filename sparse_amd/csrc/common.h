@@ -60,6 +60,22 @@ __device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// Inclusive scan over the wave on DPP row shifts (row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, row_bcast15 / 31 across
+// them): six VALU steps instead of six ds_bpermute round trips.  All 64 lanes must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_shift0(unsigned src) {   // lanes without a source read 0
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)src, CTRL, ROW_MASK, 0xf, true);
+}
+__device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned x) {
+  x += dpp_shift0<0x111, 0xf>(x);
+  x += dpp_shift0<0x112, 0xf>(x);
+  x += dpp_shift0<0x114, 0xf>(x);
+  x += dpp_shift0<0x118, 0xf>(x);
+  x += dpp_shift0<0x142, 0xa>(x);
+  x += dpp_shift0<0x143, 0xc>(x);
+  return x;
+}
+
 // Tell the compiler a value is wave-uniform (moves it to SGPRs; enables scalar branches).
 __device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ int64_t uniform(int64_t x) {

@@ -315,3 +315,34 @@ def test_tensordot_views_are_kept_and_follow_the_operand(sp):
     r3 = sp.tensordot(x, t, axes=([0, 1], [0, 1]))
     assert next(iter(x.__dict__["_tdot_views"].values())) is not first
     assert np.allclose(r3.cpu().numpy(), 3.0 * want, rtol=1e-12)
+
+
+@pytest.mark.parametrize("shape,axis,density", [((1000, 100, 100), 0, 0.01), ((40, 50, 60, 7), (0, 1), 0.02), ((3, 5000, 40), 0, 0.05),
+                                                ((2000, 4), 0, 0.9), ((1500, 3000), 0, 0.002), ((7, 11), 0, 0.5)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int64])
+def test_reductions_over_leading_axes_merge_the_slabs_instead_of_sorting(sp, shape, axis, density, dtype):
+    """csrc/lead_rotate.hip: the kept-axes-first order of a reduction over the leading axes comes from merging the sorted runs
+    of the leading indices; results (coordinates, values, fill value) equal the sort's bit for bit - sums are added in the same
+    order -, also where a cell range overflows the kernel's arrays (the 2000 x 4 case: 4 cells for 7200 elements) and the
+    host takes the sort after all."""
+    from sparse_amd import _kernels as K
+    rng = np.random.default_rng(hash((shape, str(dtype))) % 2 ** 32)
+    x = sp.random(shape, density=density, random_state=rng, dtype=np.float64)
+    tdt = {np.float32: torch.float32, np.float64: torch.float64, np.int64: torch.int64}[dtype]
+    x = sp.COO(x.coords, (x.data * 100 - 50).to(tdt), shape=shape)
+    for red in ("sum", "max", "prod") if dtype != np.int64 else ("sum", "min"):
+        K.LEAD_LAST = False
+        try:
+            want = getattr(x, red)(axis=axis)
+        finally:
+            K.LEAD_LAST = True
+        K.LEAD_LAST_STATS.clear()
+        got = getattr(x, red)(axis=axis)
+        assert K.LEAD_LAST_STATS.get("calls", 0) == 1, (red, K.LEAD_LAST_STATS)
+        assert got.shape == want.shape and got.nnz == want.nnz
+        assert torch.equal(got.coords, want.coords)
+        assert got.data.dtype == want.data.dtype and _bits(got.data) == _bits(want.data)
+        assert np.array_equal(np.asarray(got.fill_value), np.asarray(want.fill_value), equal_nan=True)
+    # against NumPy on the dense form (the golden fixtures cover the reference's own cases)
+    d = x.todense()
+    assert np.array_equal(np.asarray(x.sum(axis=axis).todense()), d.sum(axis=axis)) or dtype != np.int64
