@@ -392,14 +392,18 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
                 leg["max_rel_err"] = rel_err(s.data.cpu().numpy(), wv) if leg["keys_bit_exact"] else None
                 extra = {}
                 if ax == 0:
-                    # what the leading-axis reduction pays that the trailing one does not: the stable radix sort of the
-                    # (permuted key, value) pairs - timed alone on this row's own keys, so that the row's fraction is explained
-                    # in the line (one histogram + four 8-bit onesweep passes over 2 x 10^6 16-byte pairs: launch-bound)
-                    pk = z.linear_loc() % 1_000_000 * 1000 + z.linear_loc() // 1_000_000
+                    # what the leading-axis reduction pays that the trailing one does not: the kept-axes-first order of the
+                    # elements.  Round 5: by merging the 1000 sorted runs (csrc/lead_rotate.hip); rounds 1-4 (and the fallback):
+                    # a stable radix sort of the (permuted key, value) pairs - both timed alone on this row's own keys
+                    lin = z.linear_loc()
+                    flag = torch.zeros(1, dtype=torch.int64, device=lin.device)
+                    extra["slab_merge_ms"], _ = timed(lambda: K.keys_lead_last(lin, z.data, 1000, 1_000_000, flag), reps=100, warm=10)
+                    pk = lin % 1_000_000 * 1000 + lin // 1_000_000
                     extra["key_sort_ms"], _ = timed(lambda: K.sort_key_value(pk, z.data, 10 ** 9 - 1), reps=100, warm=10)
+                    extra["order_by"] = "slab merge" if K.LEAD_LAST_STATS.get("calls") else "key sort"
                     extra["sum_axis2_ms_for_comparison"] = out.get("A8_sum_axis2_config1", {}).get("ms")
                 emit(f"A8_sum_axis{ax}_config1", row(f"config 1: COO(1000^3, {z.nnz} nnz).sum(axis={ax})"
-                                                     + (" (needs a key sort)" if ax == 0 else ""), ms,
+                                                     + (" (kept axes first: merge of the sorted runs)" if ax == 0 else ""), ms,
                                                      z.nnz * 16 + s.nnz * 16, groups=s.nnz, cpu_baseline=leg,
                                                      **extra, **overheads(lambda: z.sum(axis=ax))))
         del x, y
