@@ -95,6 +95,15 @@ while time.time() < t_end:
         want[tuple(x.coords.long())] = x.data.double()
     assert np.allclose(s, want.sum(dim=ax).cpu().numpy(), rtol=1e-11, atol=1e-13), ("reduce", shape, ax)
     n["reduce"] += 1
+    # ---- reductions over leading axes: the slab merge (csrc/lead_rotate.hip) against the key sort, bit for bit
+    lead = (0,) if rng.integers(0, 2) else (0, 1)
+    K.LEAD_LAST = False
+    w1, w2 = x.max(axis=lead), x.sum(axis=lead)
+    K.LEAD_LAST = True
+    g1, g2 = x.max(axis=lead), x.sum(axis=lead)
+    for g, w in ((g1, w1), (g2, w2)):
+        assert torch.equal(g.linear_loc(), w.linear_loc()) and torch.equal(g.data.view(torch.int64) if g.data.dtype == torch.float64 else g.data, w.data.view(torch.int64) if w.data.dtype == torch.float64 else w.data), ("lead", shape, lead)
+    n["lead"] = n.get("lead", 0) + 1
     # ---- SpGEMM
     ng = int(rng.choice([50, 2000, 20000]))
     dg = float(rng.choice([0.0005, 0.005, 0.02]))
