@@ -161,6 +161,41 @@ def run(quick=False, profile=False, reps=200):
                     "max_rel_err": rel_err(host(rc.data), wv) if same_keys else None}
     out["ewise"] = rows
 
+    # ---- elementwise with broadcasting, and a comparison (test_benchmark_coo.py:69-94; test_elemwise.py:31-33: add, mul, gt) ----
+    rows = {}
+    for side in ([100, 1000] if quick else [100, 500, 1000]):
+        for fmt in ("coo", "gcxs"):
+            x = sp.random((side, 1, side), density=0.001, random_state=rng, format=fmt)
+            y = sp.random((side, side), density=0.001, random_state=rng, format=fmt)
+            xd, yd = np.asarray(x.todense()), np.asarray(y.todense())
+            for name, f, uf in (("add", lambda: x + y, np.add), ("mul", lambda: x * y, np.multiply)):
+                us_sync, r = wall(f, reps, True)
+                us_pipe, _ = wall(f, reps, False)
+                c0 = _ffi.CALLS
+                f()
+                calls = _ffi.CALLS - c0
+                t0 = time.perf_counter()
+                want = uf(xd, yd)
+                rows[f"{name}_side{side}_{fmt}"] = {"nnz": [int(x.nnz), int(y.nnz)], "out_nnz": int(r.nnz), "us_sync": round(us_sync, 1),
+                                                  "us_pipe": round(us_pipe, 1), "c_abi_calls": calls,
+                                                  "numpy_dense_us": round((time.perf_counter() - t0) * 1e6, 1),
+                                                  "equal_to_numpy_on_the_dense_form": bool(np.array_equal(np.asarray(r.todense()), want))}
+    out["ewise_broadcast"] = rows
+    rows = {}
+    for side in ([1000] if quick else [100, 500, 1000]):
+        x = sp.random((side, side), density=0.001, random_state=rng, format="coo") * 10
+        y = sp.random((side, side), density=0.001, random_state=rng, format="coo") * 10
+        xd, yd = np.asarray(x.todense()), np.asarray(y.todense())
+        f = lambda: x > y
+        us_sync, r = wall(f, reps, True)
+        us_pipe, _ = wall(f, reps, False)
+        c0 = _ffi.CALLS
+        f()
+        rows[f"gt_side{side}_coo"] = {"nnz": [int(x.nnz), int(y.nnz)], "out_nnz": int(r.nnz), "us_sync": round(us_sync, 1),
+                                     "us_pipe": round(us_pipe, 1), "c_abi_calls": _ffi.CALLS - c0,
+                                     "equal_to_numpy_on_the_dense_form": bool(np.array_equal(np.asarray(r.todense()), xd > yd))}
+    out["ewise_compare"] = rows
+
     # ---- tensordot --------------------------------------------------------------------------------------------------
     rows = {}
     sides4 = list(itertools.product([10, 50], [10, 20], [20, 50], [10, 50]))

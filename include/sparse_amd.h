@@ -481,6 +481,14 @@ int64_t spamd_keys_lead_last_limits(int which);
 int spamd_keys_lead_last(int val_bytes, int64_t n, const int64_t* keys, const void* vals, int64_t S, int64_t P,
                          int64_t cells_per_range, int* bounds, int64_t* out_keys, void* out_vals, int64_t* failed, void* stream);
 
+/* N3 / A7 (round 5): a canonical COO broadcast to a larger shape in one pass, sorted by construction (csrc/broadcast.hip).
+ * Replaces the operand expansion of the reference's elementwise broadcasting (`broadcast_to`, _umath.py:344-389;
+ * `_get_expanded_coords_data`, :96-167).  The target's axes, left to right, are [B0][K1][B1][K2][B2] - B: groups of broadcast
+ * axes, K: groups of the operand's own axes, sizes b0 k1 b1 k2 b2 (1 for an empty group); keys[n] sorted and duplicate-free
+ * over (K1, K2); out_keys[n b0 b1 b2] over the target's axes, ascending; out_vals the replicated values (val_bytes 1/2/4/8). */
+int spamd_coo_broadcast(int val_bytes, int64_t n, const int64_t* keys, const void* vals, int64_t b0, int64_t k1, int64_t b1,
+                        int64_t k2, int64_t b2, int64_t* out_keys, void* out_vals, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * A9  SDDMM      out[n] = s[n] * sum_k A[rows[n], k] * Bt[cols[n], k]
  *   replaces the reference's formulation `s * (a @ b)` (examples/sddmm_example.py:51-52: a dense

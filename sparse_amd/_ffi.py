@@ -55,6 +55,7 @@ SIGNATURES = {
     "spamd_coo_delinearize": (_int, [_int, _int, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     "spamd_permute_keys": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spamd_keys_check": (_int, [_i64, _vp, _vp, _vp]),
+    "spamd_coo_broadcast": (_int, [_int, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "spamd_keys_lead_last_limits": (_i64, [_int]),
     "spamd_keys_lead_last": (_int, [_int, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "spamd_coords_check": (_int, [_int, _int, _i64, _vp, _i64, _vp, _vp, _vp]),

@@ -346,3 +346,50 @@ def test_reductions_over_leading_axes_merge_the_slabs_instead_of_sorting(sp, sha
     # against NumPy on the dense form (the golden fixtures cover the reference's own cases)
     d = x.todense()
     assert np.array_equal(np.asarray(x.sum(axis=axis).todense()), d.sum(axis=axis)) or dtype != np.int64
+
+
+@pytest.mark.parametrize("xshape,target", [((30, 1, 40), (30, 25, 40)), ((35, 40), (20, 35, 40)), ((30, 40, 1), (30, 40, 7)),
+                                           ((1, 9, 1, 11, 1), (4, 9, 5, 11, 3)), ((6, 1, 1, 7), (6, 3, 2, 7)), ((1, 1), (5, 6)),
+                                           ((5, 1, 6, 1, 7), (5, 2, 6, 3, 7)), ((8,), (3, 4, 8)), ((2, 1, 3), (4, 2, 5, 3))])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32, np.int8, bool])
+def test_broadcast_to_in_one_pass_equals_the_general_construction(sp, xshape, target, dtype):
+    """csrc/broadcast.hip writes the replicas of a broadcast operand already sorted when the target's axes are (broadcast)(own)
+    (broadcast)(own)(broadcast) groups; other patterns (the (5, 1, 6, 1, 7) case: three own groups) keep the outer-sum + sort
+    construction.  Same keys, same values, and NumPy's `broadcast_to` on the dense form."""
+    from sparse_amd import _broadcast as B
+    rng = np.random.default_rng(len(xshape) * 1000 + sum(target))
+    dense = rng.random(xshape)
+    dense[rng.random(xshape) < 0.6] = 0
+    dense = (dense * 100).astype(dtype)
+    x = sp.COO.from_numpy(dense)
+    B.BROADCAST_FUSED = False
+    try:
+        want = sp.broadcast_to(x, target)
+    finally:
+        B.BROADCAST_FUSED = True
+    B.BROADCAST_STATS.clear()
+    got = sp.broadcast_to(x, target)
+    fused_expected = xshape != (5, 1, 6, 1, 7)
+    assert bool(B.BROADCAST_STATS.get("fused")) == (fused_expected and x.nnz > 0), B.BROADCAST_STATS
+    assert got.shape == want.shape == tuple(target) and got.nnz == want.nnz
+    assert torch.equal(got.linear_loc(), want.linear_loc()) and torch.equal(got.coords, want.coords)
+    assert got.data.dtype == want.data.dtype and _bits(got.data) == _bits(want.data)
+    assert np.array_equal(np.asarray(got.todense()), np.broadcast_to(dense, target))
+
+
+def test_elementwise_broadcasting_at_the_reference_benchmark_shapes(sp):
+    """benchmarks/test_benchmark_coo.py:69-94: (side, 1, side) op (side, side), COO and GCXS - three C-ABI calls per operation
+    (two operand expansions + the fused union) instead of 27."""
+    from sparse_amd import _ffi
+    side = 300
+    for fmt in ("coo", "gcxs"):
+        x = sp.random((side, 1, side), density=0.001, random_state=5, format=fmt)
+        y = sp.random((side, side), density=0.001, random_state=6, format=fmt)
+        xd, yd = np.asarray(x.todense()), np.asarray(y.todense())
+        for f, uf in ((lambda a, b: a + b, np.add), (lambda a, b: a * b, np.multiply), (lambda a, b: a > b, np.greater)):
+            r = f(x, y)
+            assert np.array_equal(np.asarray(r.todense()), uf(xd, yd))
+        if fmt == "coo":
+            c0 = _ffi.CALLS
+            x + y
+            assert _ffi.CALLS - c0 <= 4
