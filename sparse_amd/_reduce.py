@@ -234,6 +234,16 @@ def reduce_impl(x, method, axis=(0,), keepdims=False, _no_merge=False, **kwargs)
             r = reduce_impl(x, method, axis=axis, keepdims=keepdims, _no_merge=True, **kwargs)
             return r.asformat("gcxs") if out_gcxs and not isinstance(r, GCXS) and getattr(r, "ndim", 0) else r
         gids, vals = gids[:count], vals[:count]
+        if not kept and not keepdims:
+            # everything reduced: a 0-d result, whose value becomes the fill value of an array without stored elements
+            # (reference :432-435) - one more 8-byte read instead of a dense 0-d tensor, its scan and its compaction
+            value = final_fill
+            if count == 1 and not n_eq:
+                hv = vals[:1].cpu().numpy()
+                value = (hv.view(np.bool_) if res_np_dtype == np.dtype(bool) else hv)[0]
+            return COO._from_sorted_keys(torch.empty(0, dtype=torch.int64, device=dev), vals[:0] if vals.dtype != torch.uint8 or
+                                         res_np_dtype != np.dtype(bool) else vals[:0].view(torch.bool), (),
+                                         np.asarray(value).astype(res_np_dtype)[()], torch.int64)
         if n_eq:    # results equal to the fill value are not stored (rare: a sum that cancels exactly, a max of zeros)
             flags = K.flag_ne_bits(vals, final_fill if vals.dtype != torch.uint8 else np.uint8(bool(final_fill)))
             offs = K.exclusive_scan(flags)

@@ -393,3 +393,29 @@ def test_elementwise_broadcasting_at_the_reference_benchmark_shapes(sp):
             c0 = _ffi.CALLS
             x + y
             assert _ffi.CALLS - c0 <= 4
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32, np.int64, bool])
+def test_full_reductions_return_the_same_0d_array_as_before(sp, dtype):
+    """`x.sum()` / `x.max()` / `x.any()`: the 0-d result (no stored element, the value as fill value) is built from one 8-byte
+    read; values, dtypes and fill values as NumPy gives them on the dense form, also for a non-zero fill value and with
+    `keepdims` (which keeps the general construction)."""
+    rng = np.random.default_rng(11)
+    dense = rng.random((40, 50))
+    dense[rng.random((40, 50)) < 0.7] = 0
+    dense = (dense * 100).astype(dtype)
+    x = sp.COO.from_numpy(dense)
+    for red, npf in (("sum", np.sum), ("max", np.max), ("min", np.min)) if dtype != bool else (("any", np.any), ("all", np.all), ("sum", np.sum)):
+        r = getattr(x, red)()
+        want = npf(dense)
+        assert r.shape == () and r.nnz == 0
+        got = np.asarray(r.todense())[()]
+        assert got.dtype == np.asarray(want).dtype, (red, got.dtype, np.asarray(want).dtype)
+        assert np.array_equal(got, want) or np.allclose(got, want, rtol=1e-6 if dtype == np.float32 else 1e-12), (red, got, want)
+        rk = getattr(x, red)(keepdims=True)
+        assert rk.shape == (1, 1) and np.allclose(np.asarray(rk.todense()).astype(np.float64), np.asarray(want, dtype=np.float64), rtol=1e-6)
+    if dtype == np.float64:
+        y = sp.COO.from_numpy(dense + 2.5, fill_value=2.5)
+        assert np.allclose(np.asarray(y.sum().todense()), (dense + 2.5).sum(), rtol=1e-12)
+        empty = sp.COO.from_numpy(np.zeros((3, 4)))
+        assert empty.sum().nnz == 0 and np.asarray(empty.sum().todense()) == 0.0
