@@ -557,7 +557,8 @@ def main():
 
                 sw = bench_small.run(quick=True, reps=100)
                 pick = {"dense_1000^3_gcxs0": sw["dense"].get("1000x1000x1000_gcxs0"), "spsp_1000^3_gcxs": sw["spsp"].get("1000x1000x1000_gcxs"),
-                        "add_side1000_rank2_coo": sw["ewise"].get("add_side1000_rank2_coo"), "add_side1000_rank2_gcxs": sw["ewise"].get("add_side1000_rank2_gcxs")}
+                        "add_side1000_rank2_coo": sw["ewise"].get("add_side1000_rank2_coo"), "add_side1000_rank2_gcxs": sw["ewise"].get("add_side1000_rank2_gcxs"),
+                        "broadcast_add_side1000_coo": sw.get("ewise_broadcast", {}).get("add_side1000_coo")}
                 line["roofline"]["small_workloads_us"] = {k: {a: v[a] for a in ("us_sync", "us_pipe", "cpu_us") if a in v}
                                                           for k, v in pick.items() if v}
             except Exception as e:

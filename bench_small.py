@@ -9,6 +9,8 @@ Workloads (reference `benchmarks/`, default dtypes: float64 values, int64 coordi
   spsp    test_benchmark_coo.py:9-40   `test_matmul`: x(m x n) @ y(n x p), density 0.01, COO and GCXS
   ewise   test_benchmark_coo.py:48-66  `test_elemwise`: add / mul, side in {100, 500, 1000}, rank 1-4 (side**rank < 2**26), COO / GCXS
   tdot    test_tensordot.py:9-68       `test_tensordot`: dense.coo, coo.coo, coo.dense with m, n, p, q in {10, 50} x {10, 20} x {20, 50} x {10, 50}
+  ewise_broadcast  test_benchmark_coo.py:69-94 `test_elemwise_broadcast`: (side, 1, side) add / mul (side, side), density 0.001, COO / GCXS
+  ewise_compare    test_elemwise.py:31-33: `operator.gt` of two side x side operands (add / mul of it are `ewise` rank 2)
 
 These sizes hold 40-10^5 stored elements: no kernel of them takes more than a few microseconds, the call is bound by the
 host (Python, C-ABI launches, the NaN verdict).  Per workload:
@@ -248,6 +250,7 @@ def run(quick=False, profile=False, reps=200):
         "ewise_median_us_sync": med("ewise", "us_sync"), "ewise_median_us_pipe": med("ewise", "us_pipe"),
         "ewise_median_cpu_us": med("ewise", "cpu_us"),
         "tdot_median_us_sync": med("tdot", "us_sync"),
+        "ewise_broadcast_median_us_sync": med("ewise_broadcast", "us_sync"), "ewise_compare_median_us_sync": med("ewise_compare", "us_sync"),
     }
 
     if profile:
