@@ -14,8 +14,8 @@ Workloads (reference `benchmarks/`, default dtypes: float64 values, int64 coordi
 
 These sizes hold 40-10^5 stored elements: no kernel of them takes more than a few microseconds, the call is bound by the
 host (Python, C-ABI launches, the NaN verdict).  Per workload:
-  us_sync   wall-clock per call with the result COMPLETE on the device before the next call starts (perf_counter around
-            call + torch.cuda.synchronize(); the dense operand resident on the device) - a user's latency
+  us_sync   wall-clock of the MEDIAN call with the result COMPLETE on the device before the next call starts (perf_counter
+            around call + torch.cuda.synchronize(); the dense operand resident on the device) - a user's latency
   us_pipe   wall-clock per call of a loop that synchronises once at its end - a user's throughput
   us_numpy  (dense workloads) the drop-in form of the reference's benchmark: t is a NumPy array, the result comes back as
             a NumPy array (H2D of t and D2H of the result over PCIe inside every call)
@@ -24,6 +24,7 @@ host (Python, C-ABI launches, the NaN verdict).  Per workload:
 `--profile`: cProfile of the 1000 x 1000 x 1000 GCXS-0 @ dense loop + C-ABI calls and torch-visible syncs per call.
 """
 import argparse
+import gc
 import itertools
 import json
 import os
@@ -38,16 +39,39 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+LAST_SPREAD = {}
+
+
 def wall(fn, reps, sync_each):
-    fn()
+    for _ in range(3):   # (layouts derived on an operand's second or third product, a kernel's first launch: outside the timing)
+        fn()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        r = fn()
-        if sync_each:
-            torch.cuda.synchronize()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / reps * 1e6, r
+    # like `timeit`: no cyclic garbage collection inside the timed loop (a generation-2 pass over this process's objects takes
+    # ~35 ms - 700 us per call of a 50-call loop, in whichever workload it happens to fall)
+    gc.collect()
+    gc.disable()
+    global LAST_SPREAD
+    try:
+        per = []
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            t1 = time.perf_counter()
+            r = fn()
+            if sync_each:
+                torch.cuda.synchronize()
+                per.append(time.perf_counter() - t1)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        gc.enable()
+    if per:
+        # us_sync is the MEDIAN call: one call in a few hundred of this process takes 15-80 ms (at no particular call or
+        # workload: the same workload alone never shows it - tools/r05/prof_tdot_slow.py), which moves the mean of a 50-call loop by
+        # up to 1 ms; the mean and the slowest call are kept beside it
+        LAST_SPREAD = {"median_us": round(float(np.median(per)) * 1e6, 1), "max_us": round(max(per) * 1e6, 1),
+                       "max_at_call": int(np.argmax(per)), "mean_us": round(dt / reps * 1e6, 1)}
+        return LAST_SPREAD["median_us"], r
+    return dt / reps * 1e6, r
 
 
 def cpu_time(fn, budget_s=0.2, max_reps=200):
@@ -222,6 +246,7 @@ def run(quick=False, profile=False, reps=200):
                 f = lambda: sp.tensordot(lt, rt, axes=([0, li], [0, ri]), return_type=rtype)
                 try:
                     us_sync, r = wall(f, max(reps // 2, 10), True)
+                    spread = dict(LAST_SPREAD)
                     us_pipe, _ = wall(f, max(reps // 2, 10), False)
                     c0 = _ffi.CALLS
                     f()
@@ -230,7 +255,8 @@ def run(quick=False, profile=False, reps=200):
                     rd = rt.todense() if hasattr(rt, "todense") else host(rt)
                     want = np.tensordot(np.asarray(ld), np.asarray(rd), axes=([0, li], [0, ri]))
                     got = r.todense() if hasattr(r, "todense") else host(r)
-                    rows[f"{m}-{n}-{p}-{q}_{tag}_{rname}"] = {"us_sync": round(us_sync, 1), "us_pipe": round(us_pipe, 1), "c_abi_calls": calls,
+                    rows[f"{m}-{n}-{p}-{q}_{tag}_{rname}"] = {"us_sync": round(us_sync, 1), "us_sync_mean": spread.get("mean_us"),
+                                                             "us_sync_max": spread.get("max_us"), "us_pipe": round(us_pipe, 1), "c_abi_calls": calls,
                                                              "max_abs_err_vs_numpy_dense": float(np.max(np.abs(np.asarray(got) - want))) if want.size else 0.0}
                 except Exception as e:  # noqa: BLE001
                     rows[f"{m}-{n}-{p}-{q}_{tag}_{rname}"] = {"error": repr(e)[:200]}
