@@ -602,6 +602,40 @@ def _gcxs_same_layout(name, a, b):
     return GCXS((res, indices, indptr), shape=a.shape, compressed_axes=a.compressed_axes, fill_value=fill)
 
 
+GCXS_SINGLE = True
+
+
+def _gcxs_single(func, args, g, kwargs):
+    """A function of ONE GCXS operand and scalars (`g * 2`, `abs(g)`, `g > 0.5`, `g.astype(...)`), evaluated on the operand's own
+    layout: elementwise functions commute with the axis permutation + reshape that defines it, so the operand stands in as a
+    COO over its compressed 2-D space (its keys there are kept with it) and the result takes the operand's `indices` /
+    `indptr` as they are whenever nothing was pruned.  The reference - and rounds 1-4 here - convert to COO and back
+    (`_umath.py:40-50`): 8 C-ABI calls and ~180 us for 10^3 stored elements against 3 and ~75 us for a COO operand."""
+    from ._coo import COO
+    from ._convert import _pick_index_dtype
+    from ._gcxs import GCXS
+
+    if g.ndim < 1 or not g.size or any(not (a is g or _scalar_like(a)) for a in args):
+        return None
+    keys = _gcxs_keys2d(g)
+    if keys is None:
+        return None
+    shape2 = (int(g.shape[0]),) if g.ndim == 1 else tuple(int(v) for v in g._compressed_shape)
+    stand_in = COO._from_sorted_keys(keys, g.data, shape2, g.fill_value, torch.int64)
+    res = elemwise(func, *[stand_in if a is g else a for a in args], **kwargs)
+    if not isinstance(res, COO) or res.shape != shape2:
+        return None
+    if g.ndim == 1:
+        rk = res.linear_loc()
+        return GCXS((res.data, rk if g.indices.dtype == torch.int64 else rk.to(g.indices.dtype), ()), shape=g.shape,
+                    compressed_axes=None, fill_value=res.fill_value)
+    if res.nnz == g.nnz:     # nothing pruned: the same stored positions
+        return GCXS((res.data, g.indices, g.indptr), shape=g.shape, compressed_axes=g.compressed_axes, fill_value=res.fill_value)
+    R, C = shape2
+    indptr, indices = K.keys_to_csr(res.linear_loc(), R, C, _pick_index_dtype(g.indices.dtype, max(R, C, res.nnz)))
+    return GCXS((res.data, indices, indptr), shape=g.shape, compressed_axes=g.compressed_axes, fill_value=res.fill_value)
+
+
 def elemwise(func, *args, **kwargs):
     """Apply `func` elementwise to sparse/dense/scalar operands (reference _umath.py:13-50)."""
     from ._coo import COO
@@ -624,6 +658,10 @@ def elemwise(func, *args, **kwargs):
         kwargs.pop("casting", None)  # values are converted explicitly; NumPy's "unsafe" semantics
     if out_type == "gcxs" and len(args) == 2 and len(sparse_args) == 2 and dtype_kw is None and not kwargs:
         res = _gcxs_same_layout(name, args[0], args[1])
+        if res is not None:
+            return res
+    if out_type == "gcxs" and len(sparse_args) == 1 and GCXS_SINGLE:
+        res = _gcxs_single(func, args, sparse_args[0], dict(kwargs, **({"dtype": dtype_kw} if dtype_kw is not None else {})))
         if res is not None:
             return res
     proc = []

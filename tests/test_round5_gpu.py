@@ -419,3 +419,24 @@ def test_full_reductions_return_the_same_0d_array_as_before(sp, dtype):
         assert np.allclose(np.asarray(y.sum().todense()), (dense + 2.5).sum(), rtol=1e-12)
         empty = sp.COO.from_numpy(np.zeros((3, 4)))
         assert empty.sum().nnz == 0 and np.asarray(empty.sum().todense()) == 0.0
+
+
+@pytest.mark.parametrize("shape,ca", [((60, 70), (0,)), ((60, 70), (1,)), ((9, 10, 11), (0, 2)), ((500,), None)])
+def test_functions_of_one_gcxs_stay_in_its_layout(sp, shape, ca):
+    """`g * 2`, `abs(g)`, `g > 0.5`, `2 ** g`, `g.astype(...)`, `g * 0`: evaluated on the operand's compressed layout
+    (`_umath._gcxs_single`) - the same GCXS, bit for bit, as the COO round trip gives, also when the fill value changes
+    (`2 ** g`: fill 1) and when results are pruned (`g * 0` keeps nothing, `g > 0.5` some)."""
+    from sparse_amd import _umath as U
+    g = sp.random(shape, density=0.2, random_state=4, format="gcxs", **({"compressed_axes": ca} if ca is not None else {}))
+    g = g - 0.3 * (g > 0.6)       # some negative-free variety: values in (0, 1) and (0.3, 0.7)
+    fs = {"mul2": lambda v: v * 2, "abs": lambda v: abs(v), "gt": lambda v: v > 0.5, "pow": lambda v: 2 ** v,
+          "f32": lambda v: v.astype(np.float32), "mul0": lambda v: v * 0, "sin": lambda v: np.sin(v), "rsub": lambda v: 1.5 - v}
+    for name, f in fs.items():
+        U.GCXS_SINGLE = False
+        try:
+            want = f(g)
+        finally:
+            U.GCXS_SINGLE = True
+        got = f(g)
+        assert _same_gcxs(got, want), name
+        assert np.array_equal(np.asarray(got.todense()), np.asarray(want.todense()), equal_nan=True)
