@@ -144,7 +144,21 @@ def reduce_impl(x, method, axis=(0,), keepdims=False, _no_merge=False, **kwargs)
     name = getattr(method, "__name__", str(method))
     out_gcxs = isinstance(x, GCXS)
     if out_gcxs:
-        x = x.tocoo()
+        # a 2-D GCXS is reduced through the keys of its own compressed layout (kept with it: no conversion to COO per call);
+        # compressed_axes = (1,) stores the transpose, so the axes swap
+        stand_in = None
+        if x.ndim == 2 and x.size and axis is not None and x.compressed_axes in ((0,), (1,)):
+            from ._umath import _gcxs_keys2d
+
+            k2 = _gcxs_keys2d(x)
+            ax = normalize_axis(axis, 2)
+            ax = ax if isinstance(ax, tuple) else (ax,)
+            if k2 is not None and x.compressed_axes == (0,):
+                stand_in, axis = COO._from_sorted_keys(k2, x.data, x.shape, x.fill_value, torch.int64), ax
+            elif k2 is not None and len(ax) == 1 and not keepdims:   # (more axes / keepdims: the result's axes would need swapping back)
+                stand_in = COO._from_sorted_keys(k2, x.data, (x.shape[1], x.shape[0]), x.fill_value, torch.int64)
+                axis = (1 - ax[0],)
+        x = stand_in if stand_in is not None else x.tocoo()
     kwargs.pop("out", None)
     axis = normalize_axis(axis, x.ndim)
     fv = x.fill_value

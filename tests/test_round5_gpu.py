@@ -440,3 +440,21 @@ def test_functions_of_one_gcxs_stay_in_its_layout(sp, shape, ca):
         got = f(g)
         assert _same_gcxs(got, want), name
         assert np.array_equal(np.asarray(got.todense()), np.asarray(want.todense()), equal_nan=True)
+
+
+@pytest.mark.parametrize("ca", [(0,), (1,)])
+@pytest.mark.parametrize("axis", [0, 1, (0, 1), -1])
+def test_reductions_of_a_2d_gcxs_through_its_own_keys(sp, ca, axis):
+    """`GCXS.sum / max(axis=...)` of a matrix: the keys of the compressed layout stand in for the COO form (no conversion per
+    call); same GCXS result as through `tocoo()`, and NumPy's on the dense form."""
+    g = sp.random((300, 200), density=0.05, random_state=9, format="gcxs", compressed_axes=ca)
+    c = g.tocoo()
+    d = np.asarray(g.todense())
+    for red, npf in (("sum", np.sum), ("max", np.max)):
+        for keep in (False, True):
+            got = getattr(g, red)(axis=axis, keepdims=keep)
+            want = getattr(c, red)(axis=axis, keepdims=keep)
+            assert type(got).__name__ == ("GCXS" if got.ndim else "COO") or got.ndim == 0
+            gd, wd = np.asarray(got.todense()), np.asarray(want.todense())
+            assert gd.shape == wd.shape and np.array_equal(gd, wd)
+            assert np.allclose(gd, npf(d, axis=axis, keepdims=keep), rtol=1e-12)
