@@ -489,6 +489,14 @@ int spamd_keys_lead_last(int val_bytes, int64_t n, const int64_t* keys, const vo
 int spamd_coo_broadcast(int val_bytes, int64_t n, const int64_t* keys, const void* vals, int64_t b0, int64_t k1, int64_t b1,
                         int64_t k2, int64_t b2, int64_t* out_keys, void* out_vals, void* stream);
 
+/* N1 (round 5): a dense array's stored elements in one pass (reference `COO.from_numpy`, _coo/core.py:341-384: the elements not
+ * equal to the fill value and their positions).  vals[n] (val_bytes 1 / 2 / 4 / 8); fill_bits: the fill value's bit pattern;
+ * out_keys / out_vals: room for n entries, the first work[1] are written (indices ascending); work:
+ * spamd_dense_nonfill_work_words(n) int64 words, zeroed here (a ticket, the count, one look-back word per 2048 elements). */
+int64_t spamd_dense_nonfill_work_words(int64_t n);
+int spamd_dense_nonfill(int val_bytes, int64_t n, const void* vals, uint64_t fill_bits, int64_t* work, int64_t* out_keys,
+                        void* out_vals, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * A9  SDDMM      out[n] = s[n] * sum_k A[rows[n], k] * Bt[cols[n], k]
  *   replaces the reference's formulation `s * (a @ b)` (examples/sddmm_example.py:51-52: a dense

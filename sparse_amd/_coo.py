@@ -261,6 +261,10 @@ class COO(SparseArray, NDArrayOperatorsMixin):
         if fill_value is None:
             fill_value = zero_of_dtype(npdt) if shape else npdt.type(xt.item())
         flat = xt.reshape(-1).contiguous()
+        it = torch.int64 if idx_dtype is None or np.dtype(idx_dtype).itemsize > 4 else torch.int32
+        fused = K.dense_nonfill(flat, fill_value)
+        if fused is not None:
+            return cls._from_sorted_keys(fused[0], fused[1], shape, fill_value, it)
         flags = K.flag_ne_bits(flat, fill_value)
         offs = K.exclusive_scan(flags)
         count = int(offs[-1])

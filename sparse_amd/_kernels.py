@@ -366,6 +366,29 @@ def flag_ne_bits(data, fill_value):
     return f
 
 
+DENSE_NONFILL = True
+DENSE_NONFILL_DIRECT = 1 << 24     # elements up to which the outputs are allocated for the worst case (12-16 bytes each) and trimmed
+
+
+def dense_nonfill(flat, fill_value):
+    """(keys, values) of the elements of a flat dense tensor that are not bit-identical to `fill_value`, keys ascending - one
+    pass (csrc/prims.hip `spamd_dense_nonfill`) instead of flags + scan + iota + two compactions.  None for element sizes the
+    kernel does not take (complex128) and for inputs so large that worst-case outputs would not be reasonable."""
+    dev = require_hip(flat)
+    n = int(flat.numel())
+    if not DENSE_NONFILL or flat.element_size() not in (1, 2, 4, 8) or n == 0 or n > DENSE_NONFILL_DIRECT:
+        return None
+    lo, _ = _fill_words(fill_value, np_dtype(flat.dtype))
+    work = torch.empty(int(_ffi.lib().spamd_dense_nonfill_work_words(n)), dtype=torch.int64, device=dev)
+    keys = torch.empty(n, dtype=torch.int64, device=dev)
+    vals = torch.empty(n, dtype=flat.dtype, device=dev)
+    _ffi.call("spamd_dense_nonfill", flat.element_size(), n, ptr(flat.contiguous()), lo, ptr(work), ptr(keys), ptr(vals), stream_ptr(dev))
+    count = int(work[1])
+    if count * 4 < n * 3:
+        return keys[:count].clone(), vals[:count].clone()
+    return keys[:count], vals[:count]
+
+
 def _fill_words(fill_value, npdt):
     """The fill value's bit pattern as (low 8 bytes, bytes 8..15): the second word is only non-zero for 16-byte
     elements (complex128: real part, imaginary part)."""

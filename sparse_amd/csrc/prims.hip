@@ -847,3 +847,98 @@ extern "C" int spamd_csx_swap8(int idx_dtype, int64_t n_major, int64_t n_minor, 
                                void* ws, int64_t ws_bytes, void* stream) {
   return csx_swap<uint64_t>(idx_dtype, n_major, n_minor, nnz, data, indices, indptr, out_data, out_indices, out_indptr, ws, ws_bytes, stream);
 }
+
+// ---- dense -> stored elements in ONE pass (round 5) -----------------------------------------------------------------------
+// `COO.from_numpy` (reference `COO.from_numpy`, sparse/numba_backend/_coo/core.py:341-384: `np.nonzero` of "not equal to the
+// fill value" + a gather) was flag pass + exclusive scan + iota + two compactions: five launches and ~40 bytes of traffic per
+// dense element (the flags, their offsets and the iota are 8 bytes each).  Here a tile of 2048 elements is read once, its
+// elements that are not bit-identical to the fill value are counted, the tile's offset comes from a decoupled look-back over
+// one state word per tile (tiles are numbered by a ticket, so a tile only waits for tiles that are running), and (index,
+// value) go straight to their place: out_keys ascend.
+namespace spamd {
+
+constexpr int DN_THREADS = 256, DN_ITEMS = 8, DN_TILE = DN_THREADS * DN_ITEMS;
+
+template <typename V>
+__global__ void __launch_bounds__(DN_THREADS) dense_nonfill_kernel(int64_t n, const V* __restrict__ vals, V fill, int64_t ntiles,
+                                                                  unsigned long long* __restrict__ work,
+                                                                  int64_t* __restrict__ out_keys, V* __restrict__ out_vals) {
+  __shared__ long long s_blk;
+  __shared__ unsigned long long s_base;
+  __shared__ int wsum[DN_THREADS / 64 + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) s_blk = (long long)atomicAdd(work, 1ull);
+  __syncthreads();
+  const int64_t blk = s_blk;
+  unsigned long long* const state = work + 2;
+  const int64_t i0 = blk * DN_TILE + (int64_t)tid * DN_ITEMS;
+  V v[DN_ITEMS];
+  unsigned keep = 0;
+#pragma unroll
+  for (int j = 0; j < DN_ITEMS; ++j) {
+    v[j] = fill;
+    if (i0 + j < n) v[j] = vals[i0 + j];
+    keep |= (v[j] != fill) ? 1u << j : 0u;     // (V is an unsigned integer type: a comparison of bit patterns)
+  }
+  const int mine = __popc(keep);
+  const int incl = (int)wave_incl_scan_u32((unsigned)mine);
+  if (lane == 63) wsum[wid] = incl;
+  __syncthreads();
+  int before = incl - mine, total = 0;
+#pragma unroll
+  for (int w = 0; w < DN_THREADS / 64; ++w) {
+    before += w < wid ? wsum[w] : 0;
+    total += wsum[w];
+  }
+  if (wid == 0) {
+    const unsigned long long excl = lookback_exclusive(state, blk, (unsigned long long)total, lane);
+    if (lane == 0) {
+      s_base = excl;
+      if (blk == ntiles - 1) work[1] = excl + (unsigned long long)total;   // (the last tile: the number of stored elements)
+    }
+  }
+  __syncthreads();
+  int64_t at = (int64_t)s_base + before;
+#pragma unroll
+  for (int j = 0; j < DN_ITEMS; ++j) {
+    if ((keep >> j) & 1u) {
+      out_keys[at] = i0 + j;
+      out_vals[at] = v[j];
+      ++at;
+    }
+  }
+}
+
+}  // namespace spamd
+
+// work words of spamd_dense_nonfill for n elements
+extern "C" int64_t spamd_dense_nonfill_work_words(int64_t n) {
+  return n < 0 ? -1 : spamd::ceil_div(n > 0 ? n : 1, (int64_t)spamd::DN_TILE) + 2;
+}
+
+// vals[n] (val_bytes 1 / 2 / 4 / 8) -> the elements whose bits differ from `fill_bits`: out_keys (their indices, ascending) and
+// out_vals, both with room for n entries; work: spamd_dense_nonfill_work_words(n) int64 words (zeroed here), afterwards
+// work[1] = the number of elements written.
+extern "C" int spamd_dense_nonfill(int val_bytes, int64_t n, const void* vals, uint64_t fill_bits, int64_t* work, int64_t* out_keys,
+                                   void* out_vals, void* stream) {
+  using namespace spamd;
+  if (n < 0 || !work) return SPAMD_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t ntiles = ceil_div(n > 0 ? n : 1, (int64_t)DN_TILE);
+  if (ntiles >= ((int64_t)1 << 31)) return SPAMD_EINVAL;
+  if (hipError_t e = hipMemsetAsync(work, 0, (size_t)(ntiles + 2) * sizeof(int64_t), s); e != hipSuccess) return (int)e;
+  if (n == 0) return 0;
+  unsigned long long* const w = reinterpret_cast<unsigned long long*>(work);
+#define DN_GO(V)                                                                                                              \
+  hipLaunchKernelGGL(dense_nonfill_kernel<V>, dim3((unsigned)ntiles), dim3(DN_THREADS), 0, s, n, (const V*)vals, (V)fill_bits, \
+                     ntiles, w, out_keys, (V*)out_vals);                                                                      \
+  return launch_status();
+  switch (val_bytes) {
+    case 1: { DN_GO(uint8_t) }
+    case 2: { DN_GO(uint16_t) }
+    case 4: { DN_GO(uint32_t) }
+    case 8: { DN_GO(uint64_t) }
+    default: return SPAMD_ETYPE;
+  }
+#undef DN_GO
+}

@@ -458,3 +458,29 @@ def test_reductions_of_a_2d_gcxs_through_its_own_keys(sp, ca, axis):
             gd, wd = np.asarray(got.todense()), np.asarray(want.todense())
             assert gd.shape == wd.shape and np.array_equal(gd, wd)
             assert np.allclose(gd, npf(d, axis=axis, keepdims=keep), rtol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32, np.int64, np.int32, np.int8, bool])
+@pytest.mark.parametrize("shape", [(1,), (2047,), (2048,), (2049,), (37, 113), (5, 6, 7, 8), (3000, 700)])
+def test_from_numpy_in_one_pass_equals_the_five_pass_construction(sp, dtype, shape):
+    """`COO.from_numpy`: the stored elements (not bit-identical to the fill value; -0.0 is stored) and their positions come out
+    of one kernel (tile counts + look-back) - same keys and values as flags + scan + iota + two compactions, for a zero and a
+    non-zero fill value, for arrays that are all fill and that hold no fill at all."""
+    from sparse_amd import _kernels as K
+    rng = np.random.default_rng(sum(shape) + np.dtype(dtype).itemsize)
+    base = rng.random(shape)
+    for frac, fill in ((0.9, 0), (0.5, 3), (1.1, 0), (-1.0, 0)):
+        d = (base * 100).astype(dtype)
+        d[rng.random(shape) < frac] = np.asarray(fill).astype(dtype)
+        if dtype in (np.float64, np.float32) and d.size > 4:
+            d.reshape(-1)[1] = -0.0
+        fv = np.asarray(fill).astype(dtype)[()]
+        K.DENSE_NONFILL = False
+        try:
+            want = sp.COO.from_numpy(d, fill_value=fv)
+        finally:
+            K.DENSE_NONFILL = True
+        got = sp.COO.from_numpy(d, fill_value=fv)
+        assert got.nnz == want.nnz and torch.equal(got.linear_loc(), want.linear_loc())
+        assert got.data.dtype == want.data.dtype and _bits(got.data) == _bits(want.data)
+        assert np.array_equal(np.asarray(got.todense()), d)
