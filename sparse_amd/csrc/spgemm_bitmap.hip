@@ -481,52 +481,6 @@ spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, con
     // (the products stay where the prefetch put them - colN / bvN / eN - until the row is assembled in step 4: a second
     // copy of them, as keys and values, had the kernel spill 30 registers)
     unsigned first_mask = 0;
-#ifdef BMK_BATCH
-    // all of a thread's bitmap atomics are issued before the first answer is looked at (one LDS latency instead of ITEMS)
-    unsigned seen = 0;
-#pragma unroll
-    for (int j0 = 0; j0 < ITEMS; j0 += BMK_BATCH) {
-      unsigned oldw[BMK_BATCH];
-#pragma unroll
-      for (int jj = 0; jj < BMK_BATCH; ++jj) {
-        const int j = j0 + jj;
-        if (SPLIT && colN[j] != BMK_NONE && colN[j] - cbase >= (unsigned)range) {   // (see below)
-          failed = true;
-          colN[j] = BMK_NONE;
-        }
-        // (no branch around the atomic: a lane without a product ORs nothing into a word of its own)
-        const bool valid = colN[j] != BMK_NONE;
-        const unsigned c = colN[j] - cbase;
-        unsigned* const at = valid ? &bm[c >> 5] : &filt[lane];
-        oldw[jj] = atomicOr(at, valid ? 1u << (c & 31u) : 0u);
-      }
-#pragma unroll
-      for (int jj = 0; jj < BMK_BATCH; ++jj) {
-        const int j = j0 + jj;
-        const bool valid = colN[j] != BMK_NONE;
-        const unsigned c = colN[j] - cbase;
-        seen |= (valid && ((oldw[jj] >> (c & 31u)) & 1u)) ? 1u << j : 0u;
-        first_mask |= valid ? 1u << j : 0u;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    first_mask &= ~seen;
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-      if ((seen >> j) & 1u) {   // the output element has a product already: park this one
-        const unsigned c = colN[j] - cbase;
-        const unsigned e = (eN[j / 4] >> (8 * (j % 4))) & 255u;
-        const unsigned h = (c ^ (c >> 14)) & FILT_MASK;
-        atomicOr(&filt[h >> 5], 1u << (h & 31u));
-        const int slot = atomicAdd(ndup, 1);
-        if (slot < DUP) {
-          dup[slot].key = (c << 8) | e;
-          dup[slot].rank = BMK_NONE;
-          dup[slot].val = sc->aval[e] * bvN[j];
-        }
-      }
-    }
-#else
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
       // (a column outside this part's range: B's row is not sorted by column - the split form's binary search over it put the
@@ -557,7 +511,6 @@ spgemm_bitmap_kernel(int64_t n_vrow, int np_arg, int64_t range, int ngroups, con
       }
       if (j % 8 == 7) __builtin_amdgcn_sched_barrier(0);
     }
-#endif
     BMK_T(1)
     lds_barrier();
     BMK_T(2)
