@@ -491,11 +491,13 @@ int spamd_coo_broadcast(int val_bytes, int64_t n, const int64_t* keys, const voi
 
 /* N1 (round 5): a dense array's stored elements in one pass (reference `COO.from_numpy`, _coo/core.py:341-384: the elements not
  * equal to the fill value and their positions).  vals[n] (val_bytes 1 / 2 / 4 / 8); fill_bits: the fill value's bit pattern;
+ * cmp_mask: the bits compared (all ones = bit-identity; a floating type's mask without the sign bit + fill 0 = `value != 0`, the
+ * test of the reference's COO-returning products `_common.py:1049, 1139`);
  * out_keys / out_vals: room for n entries, the first work[1] are written (indices ascending); work:
  * spamd_dense_nonfill_work_words(n) int64 words, zeroed here (a ticket, the count, one look-back word per 2048 elements). */
 int64_t spamd_dense_nonfill_work_words(int64_t n);
-int spamd_dense_nonfill(int val_bytes, int64_t n, const void* vals, uint64_t fill_bits, int64_t* work, int64_t* out_keys,
-                        void* out_vals, void* stream);
+int spamd_dense_nonfill(int val_bytes, int64_t n, const void* vals, uint64_t fill_bits, uint64_t cmp_mask, int64_t* work,
+                        int64_t* out_keys, void* out_vals, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * A9  SDDMM      out[n] = s[n] * sum_k A[rows[n], k] * Bt[cols[n], k]

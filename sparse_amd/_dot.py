@@ -520,7 +520,7 @@ def _tiled_min_rows(row_bytes):
     return 45056 if panels == 1 else max(4096, 40960 // panels)
 
 
-DERIVED_CACHES = ("_mm_plans", "_keys2d", "_tdot_views", "_csr_view", "_csr_twin", "_tiled_layouts", "_spmm_uses", "_nan_memo", "_derived_stamp", "_sddmm_plan", "_t_view", "_coo_view")
+DERIVED_CACHES = ("_mm_plans", "_keys2d", "_tdot_views", "_csr_of_t", "_csr_view", "_csr_twin", "_tiled_layouts", "_spmm_uses", "_nan_memo", "_derived_stamp", "_sddmm_plan", "_t_view", "_coo_view")
 
 
 def drop_derived(a):
@@ -828,16 +828,24 @@ def _dot(a, b, return_type=None):
         bt = dev.to_device(b, a.device)
         if rk in (None, "ndarray"):
             return io.out(_gcxs_times_dense(a, bt, out_shape))
-        coords, data = K.dot_coo_ndarray_sparse(a.coords, a.data, bt, out_shape)
-        out = COO(coords, data, shape=out_shape, has_duplicates=False, sorted=True)
+        keys, data = K.dot_coo_ndarray_sparse(a.coords, a.data, bt, out_shape, as_keys=True)
+        out = COO._from_sorted_keys(keys, data, out_shape, np.zeros((), dtype=dev.np_dtype(data.dtype))[()], torch.int64)
         return out.asformat("gcxs") if rk == "gcxs" else out
 
     if _is_dense(a) and isinstance(b, COO):
         at = dev.to_device(a, b.device)
+        # b's transpose compressed by rows - what the product runs on - depends on b alone: kept with b (dropped with its other
+        # derived layouts when a stored buffer changes); small operands only (it doubles b's storage)
+        st = None
+        if b.nnz <= TDOT_VIEW_MAX_NNZ and hasattr(b, "__dict__"):
+            _validate_derived(b)
+            st = b.__dict__.get("_csr_of_t")
+            if st is None:
+                st = b.__dict__["_csr_of_t"] = K.coo_transposed_csr(b.coords, b.data, int(b.shape[0]), int(b.shape[1]))
         if rk in (None, "ndarray"):
-            return io.out(K.dot_ndarray_coo(at, b.coords, b.data, out_shape, exact=_settings.EXACT_MULADD))
-        coords, data = K.dot_ndarray_coo_sparse(at, b.coords, b.data, out_shape)
-        out = COO(coords, data, shape=out_shape, has_duplicates=False, sorted=True, prune=True)
+            return io.out(K.dot_ndarray_coo(at, b.coords, b.data, out_shape, exact=_settings.EXACT_MULADD, st=st))
+        keys, data = K.dot_ndarray_coo_sparse(at, b.coords, b.data, out_shape, as_keys=True, st=st)
+        out = COO._from_sorted_keys(keys, data, out_shape, np.zeros((), dtype=dev.np_dtype(data.dtype))[()], torch.int64)
         return out.asformat("gcxs") if rk == "gcxs" else out
 
     if _is_dense(a) and _is_dense(b):

@@ -57,7 +57,7 @@ SIGNATURES = {
     "spamd_keys_check": (_int, [_i64, _vp, _vp, _vp]),
     "spamd_coo_broadcast": (_int, [_int, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "spamd_dense_nonfill_work_words": (_i64, [_i64]),
-    "spamd_dense_nonfill": (_int, [_int, _i64, _vp, _C.c_uint64, _vp, _vp, _vp, _vp]),
+    "spamd_dense_nonfill": (_int, [_int, _i64, _vp, _C.c_uint64, _C.c_uint64, _vp, _vp, _vp, _vp]),
     "spamd_keys_lead_last_limits": (_i64, [_int]),
     "spamd_keys_lead_last": (_int, [_int, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "spamd_coords_check": (_int, [_int, _int, _i64, _vp, _i64, _vp, _vp, _vp]),

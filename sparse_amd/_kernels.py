@@ -370,7 +370,7 @@ DENSE_NONFILL = True
 DENSE_NONFILL_DIRECT = 1 << 24     # elements up to which the outputs are allocated for the worst case (12-16 bytes each) and trimmed
 
 
-def dense_nonfill(flat, fill_value):
+def dense_nonfill(flat, fill_value, numeric=False):
     """(keys, values) of the elements of a flat dense tensor that are not bit-identical to `fill_value`, keys ascending - one
     pass (csrc/prims.hip `spamd_dense_nonfill`) instead of flags + scan + iota + two compactions.  None for element sizes the
     kernel does not take (complex128) and for inputs so large that worst-case outputs would not be reasonable."""
@@ -379,10 +379,16 @@ def dense_nonfill(flat, fill_value):
     if not DENSE_NONFILL or flat.element_size() not in (1, 2, 4, 8) or n == 0 or n > DENSE_NONFILL_DIRECT:
         return None
     lo, _ = _fill_words(fill_value, np_dtype(flat.dtype))
+    mask = (1 << 64) - 1
+    if numeric:     # `value != 0`: +0 and -0 are one value (NaN is not zero: kept, as NumPy's comparison keeps it)
+        if lo != 0:
+            return None
+        if flat.dtype.is_floating_point:
+            mask = (1 << (8 * flat.element_size() - 1)) - 1
     work = torch.empty(int(_ffi.lib().spamd_dense_nonfill_work_words(n)), dtype=torch.int64, device=dev)
     keys = torch.empty(n, dtype=torch.int64, device=dev)
     vals = torch.empty(n, dtype=flat.dtype, device=dev)
-    _ffi.call("spamd_dense_nonfill", flat.element_size(), n, ptr(flat.contiguous()), lo, ptr(work), ptr(keys), ptr(vals), stream_ptr(dev))
+    _ffi.call("spamd_dense_nonfill", flat.element_size(), n, ptr(flat.contiguous()), lo, mask, ptr(work), ptr(keys), ptr(vals), stream_ptr(dev))
     count = int(work[1])
     if count * 4 < n * 3:
         return keys[:count].clone(), vals[:count].clone()
@@ -589,16 +595,24 @@ def dot_coo_ndarray(coords, data, b, out_shape, *, exact=False):
     return dot_csr_ndarray(out_shape, data, cols, indptr, b, exact=exact)
 
 
-def dot_ndarray_coo(a, coords, data, out_shape, *, exact=False):
-    """C = A @ S, A dense (M x K), S 2-D COO (K x N) — `_dot_ndarray_coo`
-    (reference _common.py:1075-1103), computed as (S^T @ A^T)^T with S^T compressed by rows."""
-    M, N = int(out_shape[0]), int(out_shape[1])
-    Kd = int(a.shape[1])
+def coo_transposed_csr(coords, data, Kd, N):
+    """S^T compressed by rows - (data, indices, indptr) - of a 2-D COO S (Kd x N): what `dot_ndarray_coo` multiplies with.
+    Depends on S alone; `_dot` keeps it with the operand between products."""
     keys = linearize(coords, (Kd, N), axis_order=(1, 0))    # col * K + row
     keys, perm = sort_keys(keys, max(Kd * N - 1, 1))
     it = coords.dtype if index_dtype_ok(coords) else torch.int64
     indptr, indices = keys_to_csr(keys, N, Kd, it)
-    res = dot_csr_ndarray((N, M), gather(data, perm), indices, indptr, a.t().contiguous(), exact=exact)
+    return gather(data, perm), indices, indptr
+
+
+def dot_ndarray_coo(a, coords, data, out_shape, *, exact=False, st=None):
+    """C = A @ S, A dense (M x K), S 2-D COO (K x N) — `_dot_ndarray_coo`
+    (reference _common.py:1075-1103), computed as (S^T @ A^T)^T with S^T compressed by rows (`st`: that form, when the
+    caller has it already)."""
+    M, N = int(out_shape[0]), int(out_shape[1])
+    Kd = int(a.shape[1])
+    tdata, indices, indptr = st if st is not None else coo_transposed_csr(coords, data, Kd, N)
+    res = dot_csr_ndarray((N, M), tdata, indices, indptr, a.t().contiguous(), exact=exact)
     return res.t()
 
 
@@ -607,6 +621,10 @@ def _sparsify(dense, struct_mask=None, numeric=False):
     dtype, nonzero = structurally present) restricts them; `numeric=True` keeps value != 0
     (the COO variants' `if data_curr != 0`), otherwise bit-pattern != +0 (GCXS prune)."""
     flat = dense.reshape(-1).contiguous()
+    if struct_mask is None and flat.dtype in (torch.float32, torch.float64, torch.int32, torch.int64):
+        fused = dense_nonfill(flat, 0, numeric=numeric)
+        if fused is not None:
+            return fused
     if numeric:
         from ._umath import binary_arrays
 
@@ -663,18 +681,19 @@ def dot_csc_ndarray_sparse(a_shape, b_shape, a_data, a_indices, a_indptr, b):
     return data, indices, indptr
 
 
-def dot_coo_ndarray_sparse(coords, data, b, out_shape):
-    """COO @ dense returned as COO (coords, data) — reference _common.py:1017-1072."""
+def dot_coo_ndarray_sparse(coords, data, b, out_shape, as_keys=False):
+    """COO @ dense returned as COO (coords, data) — reference _common.py:1017-1072.  `as_keys`: (sorted linear keys, data)
+    instead - the caller's container builds coordinates on demand."""
     dense = dot_coo_ndarray(coords, data, b, out_shape, exact=True)
     keys, vals = _sparsify(dense, numeric=True)
-    return delinearize(keys, tuple(int(s) for s in out_shape), torch.int64), vals
+    return (keys, vals) if as_keys else (delinearize(keys, tuple(int(s) for s in out_shape), torch.int64), vals)
 
 
-def dot_ndarray_coo_sparse(a, coords, data, out_shape):
+def dot_ndarray_coo_sparse(a, coords, data, out_shape, as_keys=False, st=None):
     """dense @ COO returned as COO — reference _common.py:1106-1158."""
-    dense = dot_ndarray_coo(a, coords, data, out_shape, exact=True).contiguous()
+    dense = dot_ndarray_coo(a, coords, data, out_shape, exact=True, st=st).contiguous()
     keys, vals = _sparsify(dense, numeric=True)
-    return delinearize(keys, tuple(int(s) for s in out_shape), torch.int64), vals
+    return (keys, vals) if as_keys else (delinearize(keys, tuple(int(s) for s in out_shape), torch.int64), vals)
 
 
 SPGEMM_CHUNK_PRODUCTS = 1 << 27  # products expanded/sorted at a time (bounds workspace to ~5 GB)

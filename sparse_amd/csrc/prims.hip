@@ -860,7 +860,7 @@ namespace spamd {
 constexpr int DN_THREADS = 256, DN_ITEMS = 8, DN_TILE = DN_THREADS * DN_ITEMS;
 
 template <typename V>
-__global__ void __launch_bounds__(DN_THREADS) dense_nonfill_kernel(int64_t n, const V* __restrict__ vals, V fill, int64_t ntiles,
+__global__ void __launch_bounds__(DN_THREADS) dense_nonfill_kernel(int64_t n, const V* __restrict__ vals, V fill, V cmask, int64_t ntiles,
                                                                   unsigned long long* __restrict__ work,
                                                                   int64_t* __restrict__ out_keys, V* __restrict__ out_vals) {
   __shared__ long long s_blk;
@@ -878,7 +878,7 @@ __global__ void __launch_bounds__(DN_THREADS) dense_nonfill_kernel(int64_t n, co
   for (int j = 0; j < DN_ITEMS; ++j) {
     v[j] = fill;
     if (i0 + j < n) v[j] = vals[i0 + j];
-    keep |= (v[j] != fill) ? 1u << j : 0u;     // (V is an unsigned integer type: a comparison of bit patterns)
+    keep |= ((V)((v[j] ^ fill) & cmask) != (V)0) ? 1u << j : 0u;   // (bit patterns; cmask without the sign bit: +-0 are one value)
   }
   const int mine = __popc(keep);
   const int incl = (int)wave_incl_scan_u32((unsigned)mine);
@@ -916,11 +916,12 @@ extern "C" int64_t spamd_dense_nonfill_work_words(int64_t n) {
   return n < 0 ? -1 : spamd::ceil_div(n > 0 ? n : 1, (int64_t)spamd::DN_TILE) + 2;
 }
 
-// vals[n] (val_bytes 1 / 2 / 4 / 8) -> the elements whose bits differ from `fill_bits`: out_keys (their indices, ascending) and
+// vals[n] (val_bytes 1 / 2 / 4 / 8) -> the elements whose bits differ from `fill_bits` under `cmp_mask` (all ones: bit-identity;
+// without a floating type's sign bit and fill_bits = 0: the numeric test `value != 0`): out_keys (their indices, ascending) and
 // out_vals, both with room for n entries; work: spamd_dense_nonfill_work_words(n) int64 words (zeroed here), afterwards
 // work[1] = the number of elements written.
-extern "C" int spamd_dense_nonfill(int val_bytes, int64_t n, const void* vals, uint64_t fill_bits, int64_t* work, int64_t* out_keys,
-                                   void* out_vals, void* stream) {
+extern "C" int spamd_dense_nonfill(int val_bytes, int64_t n, const void* vals, uint64_t fill_bits, uint64_t cmp_mask, int64_t* work,
+                                   int64_t* out_keys, void* out_vals, void* stream) {
   using namespace spamd;
   if (n < 0 || !work) return SPAMD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
@@ -931,7 +932,7 @@ extern "C" int spamd_dense_nonfill(int val_bytes, int64_t n, const void* vals, u
   unsigned long long* const w = reinterpret_cast<unsigned long long*>(work);
 #define DN_GO(V)                                                                                                              \
   hipLaunchKernelGGL(dense_nonfill_kernel<V>, dim3((unsigned)ntiles), dim3(DN_THREADS), 0, s, n, (const V*)vals, (V)fill_bits, \
-                     ntiles, w, out_keys, (V*)out_vals);                                                                      \
+                     (V)cmp_mask, ntiles, w, out_keys, (V*)out_vals);                                                                      \
   return launch_status();
   switch (val_bytes) {
     case 1: { DN_GO(uint8_t) }

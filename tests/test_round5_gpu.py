@@ -484,3 +484,21 @@ def test_from_numpy_in_one_pass_equals_the_five_pass_construction(sp, dtype, sha
         assert got.nnz == want.nnz and torch.equal(got.linear_loc(), want.linear_loc())
         assert got.data.dtype == want.data.dtype and _bits(got.data) == _bits(want.data)
         assert np.array_equal(np.asarray(got.todense()), d)
+
+
+def test_dense_times_coo_keeps_the_transposed_form_and_follows_the_operand(sp):
+    """dense @ COO runs on the COO's transpose compressed by rows; that form is kept with the operand (`_csr_of_t`) and rebuilt
+    when a stored buffer is written to; sparse and dense results, against NumPy."""
+    rng = np.random.default_rng(3)
+    a = rng.random((30, 40))
+    b = sp.random((40, 50), density=0.05, random_state=7, format="coo")
+    at = torch.from_numpy(a).cuda()
+    for _ in range(2):
+        r = sp.matmul(at, b)
+        assert "_csr_of_t" in b.__dict__
+        assert np.allclose(np.asarray(r.cpu() if hasattr(r, "cpu") else r), a @ np.asarray(b.todense()), rtol=1e-12)
+        rs = sp.tensordot(at, b, axes=1, return_type=sp.COO)
+        assert np.allclose(np.asarray(rs.todense()), a @ np.asarray(b.todense()), rtol=1e-12) and isinstance(rs, sp.COO)
+    b.data[:5] = 2.0          # (in place: the derived forms must go)
+    r = sp.matmul(at, b)
+    assert np.allclose(np.asarray(r.cpu() if hasattr(r, "cpu") else r), a @ np.asarray(b.todense()), rtol=1e-12)
