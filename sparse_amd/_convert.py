@@ -106,10 +106,8 @@ def gcxs_to_coo(x):
         keys, perm = K.sort_keys(keys, max(x.size - 1, 1))
         data = K.gather(data, perm)
     it = x.indices.dtype if max(x.shape) < 2 ** 31 or x.indices.dtype == torch.int64 else torch.int64
-    out = COO(K.delinearize(keys, x.shape, it), data, shape=x.shape, has_duplicates=False, sorted=True,
-              fill_value=x.fill_value)
-    out._keys = keys
-    return out
+    # (sorted, duplicate-free keys: the coordinates are split off when somebody asks for them)
+    return COO._from_sorted_keys(keys, data, x.shape, x.fill_value, it)
 
 
 def gcxs_relayout(x, shape, axes, compressed_axes, transpose=False, reshape=False):

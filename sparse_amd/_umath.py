@@ -603,6 +603,23 @@ def _gcxs_same_layout(name, a, b):
 
 
 GCXS_SINGLE = True
+COO_VIEW_MAX_NNZ = 1 << 18
+
+
+def _coo_of(g):
+    """The COO form of a GCXS operand; small operands keep it with their other derived layouts (dropped when a stored buffer
+    changes): an elementwise operation on GCXS operands of different layouts or shapes converts each of them per call otherwise
+    (three C-ABI calls and a read-back per operand)."""
+    from ._dot import _validate_derived
+
+    if not hasattr(g, "__dict__") or g.ndim < 2 or g.nnz > COO_VIEW_MAX_NNZ:
+        return g.asformat("coo")
+    _validate_derived(g)
+    v = g.__dict__.get("_coo_view")
+    if v is None:
+        v = g.__dict__["_coo_view"] = g.asformat("coo")
+    return v
+
 
 
 def _gcxs_single(func, args, g, kwargs):
@@ -667,7 +684,7 @@ def elemwise(func, *args, **kwargs):
     proc = []
     for a in args:
         if isinstance(a, SparseArray):
-            a = a if isinstance(a, COO) else a.asformat("coo")
+            a = a if isinstance(a, COO) else _coo_of(a)
             if a.ndim == 0:
                 a = a.todense()
         elif not (_scalar_like(a) or isinstance(a, (np.ndarray, torch.Tensor))):
