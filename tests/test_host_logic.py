@@ -369,3 +369,21 @@ def test_csc_inspector_workspace_covers_its_arrays(hiplib):
         ntiles = -(-K // kb)
         need = (groups // gpb + 1) * K + 4 * groups * ntiles + groups * (ntiles + 1) + 1 + 2 * (2 * groups + 1)
         assert hiplib.spamd_spmm_tiled_inspect_csc_ws(M, K) >= need
+
+
+def test_broadcast_axis_groups_of_the_one_pass_expansion():
+    """`_broadcast._broadcast_groups`: the target's axes as (broadcast)(own)(broadcast)(own)(broadcast) group sizes, or None when
+    the operand's own axes form more than two groups (csrc/broadcast.hip takes the former, the sort-based construction the rest)."""
+    from sparse_amd._broadcast import _broadcast_groups as g
+
+    assert g((30, 1, 40), (30, 25, 40)) == (1, 30, 25, 40, 1)          # the reference benchmark's left operand
+    assert g((1, 35, 40), (20, 35, 40)) == (1, 1, 20, 35 * 40, 1)      # ... and its right one: a leading group
+    assert g((30, 40, 1), (30, 40, 7)) == (1, 1, 1, 30 * 40, 7)        # trailing
+    assert g((1, 9, 1, 11, 1), (4, 9, 5, 11, 3)) == (4, 9, 5, 11, 3)   # all five groups
+    assert g((6, 1, 1, 7), (6, 3, 2, 7)) == (1, 6, 6, 7, 1)            # adjacent broadcast axes are one group
+    assert g((1, 1), (5, 6)) == (1, 1, 1, 1, 30)                        # nothing of its own: one trailing group
+    assert g((5, 1, 6, 1, 7), (5, 2, 6, 3, 7)) is None                 # three groups of own axes
+    assert g((2, 1, 3), (2, 1, 3)) == (1, 1, 1, 6, 1)                  # (axes of size 1 in both shapes belong to their neighbours)
+    for xs, shape in (((30, 1, 40), (30, 25, 40)), ((1, 9, 1, 11, 1), (4, 9, 5, 11, 3))):
+        b0, k1, b1, k2, b2 = g(xs, shape)
+        assert b0 * k1 * b1 * k2 * b2 == int(np.prod(shape)) and k1 * k2 == int(np.prod(xs))
