@@ -244,24 +244,33 @@ LEAD_LAST_RANGE = 2048         # elements a cell range should hold (the kernel's
 LEAD_LAST_STATS = {}
 
 
+def lead_last_plan(n, n_slabs, n_cells, max_slabs=2048, max_cells=2048):
+    """(cells per range, ranges) of the slab merge for n elements in n_slabs sorted runs over n_cells kept cells, or None when
+    the problem is the sort's: too many runs, or a key space so much larger than the element count that most workgroups (one
+    per range) and most boundary words (one per run and range) would be empty.  A range aims at LEAD_LAST_RANGE elements."""
+    if n <= 0 or n >= 2 ** 31 or n_slabs > max_slabs or n_cells >= 2 ** 42 or n_cells < 1:
+        return None
+    cells = 1
+    while cells * 2 <= max_cells and cells * 2 * n <= LEAD_LAST_RANGE * n_cells:
+        cells *= 2
+    ranges = -(-n_cells // cells)
+    if ranges > max(4096, n // 64) or n_slabs * (ranges + 1) > 8 * n + (1 << 20):
+        return None
+    return cells, ranges
+
+
 def keys_lead_last(keys, vals, n_slabs, n_cells, failed):
     """(keys', vals') of a canonical COO whose leading axes (n_slabs index values) are moved behind the kept ones (n_cells):
     keys' = cell * n_slabs + slab, ascending - what `permute_keys` + `sort_key_value` return, without the sort.  None when
-    the shape of the problem is not the kernel's (many slabs, few elements in a huge key space); `failed`: a device int64
-    word the kernels set when a range was too full (the caller reads it with its own read-back and takes the sort then)."""
+    the shape of the problem is not the kernel's (`lead_last_plan`); `failed`: a device int64 word the kernels set when a range
+    was too full (the caller reads it with its own read-back and takes the sort then)."""
     dev = require_hip(keys, vals)
     n = int(keys.numel())
     lim = _ffi.lib().spamd_keys_lead_last_limits
-    if (not LEAD_LAST or n == 0 or n >= 2 ** 31 or n_slabs > int(lim(0)) or vals.element_size() not in (4, 8)
-            or n_cells >= 2 ** 42):
+    plan = lead_last_plan(n, n_slabs, n_cells, int(lim(0)), int(lim(1))) if LEAD_LAST and vals.element_size() in (4, 8) else None
+    if plan is None:
         return None
-    cells = 1
-    while cells * 2 <= int(lim(1)) and cells * 2 * n <= LEAD_LAST_RANGE * n_cells:
-        cells *= 2
-    ranges = -(-n_cells // cells)
-    # (every range is a workgroup, every (slab, range) a boundary word: a key space far larger than the element count is the sort's)
-    if ranges > max(4096, n // 64) or n_slabs * (ranges + 1) > 8 * n + (1 << 20):
-        return None
+    cells, ranges = plan
     bounds = torch.empty(n_slabs * (ranges + 1), dtype=torch.int32, device=dev)
     ko, vo = torch.empty_like(keys), torch.empty_like(vals)
     _ffi.call("spamd_keys_lead_last", vals.element_size(), n, ptr(keys.contiguous()), ptr(vals.contiguous()), int(n_slabs), int(n_cells),

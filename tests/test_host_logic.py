@@ -387,3 +387,21 @@ def test_broadcast_axis_groups_of_the_one_pass_expansion():
     for xs, shape in (((30, 1, 40), (30, 25, 40)), ((1, 9, 1, 11, 1), (4, 9, 5, 11, 3))):
         b0, k1, b1, k2, b2 = g(xs, shape)
         assert b0 * k1 * b1 * k2 * b2 == int(np.prod(shape)) and k1 * k2 == int(np.prod(xs))
+
+
+def test_slab_merge_plan_of_leading_axis_reductions():
+    """`_kernels.lead_last_plan`: ranges of a power-of-two number of kept cells holding ~2048 elements each; the sort keeps
+    problems with more than 2048 runs and key spaces far larger than the element count."""
+    from sparse_amd._kernels import lead_last_plan as plan
+
+    assert plan(10 ** 6, 1000, 10 ** 6) == (2048, 489)          # config 1, sum(axis=0)
+    assert plan(2 * 10 ** 6, 1000, 10 ** 6) == (1024, 977)      # ... of the sum of two such arrays
+    assert plan(7200, 2000, 4) == (1, 4)                        # four cells for 7200 elements: the kernel will give up, not the plan
+    assert plan(10 ** 6, 4096, 10 ** 6) is None                 # more runs than a workgroup has threads for
+    assert plan(1000, 100, 10 ** 12) is None                    # 10^3 elements in a 10^12-cell key space
+    assert plan(0, 10, 10) is None and plan(2 ** 31, 10, 10 ** 6) is None
+    for n, S, P in ((10 ** 5, 37, 10 ** 7), (5 * 10 ** 7, 2048, 10 ** 6), (123456, 1, 999)):
+        p = plan(n, S, P)
+        if p is not None:
+            cells, ranges = p
+            assert cells & (cells - 1) == 0 and 1 <= cells <= 2048 and (ranges - 1) * cells < P <= ranges * cells
