@@ -241,6 +241,11 @@ def permute_keys(keys, src_shape, perm):
 
 LEAD_LAST = True               # reductions over the leading axes: the kept-axes-first order by merging the slabs (csrc/lead_rotate.hip)
 LEAD_LAST_RANGE = 2048         # elements a cell range should hold (the kernel's arrays take 4096)
+LEAD_LAST_MAX_NNZ = 1 << 22     # beyond this the radix sort wins (it streams; the merge is a latency chain per range): measured at
+#                                S = 1000, P = 10^6, whole reduction by merge / by sort: 10^6 elements 0.15 / 0.22 ms, 2 x 10^6: 0.22 / 0.25,
+#                                10^7: merge kernel alone 0.43 ms against 0.64 ms for everything with the sort
+LEAD_LAST_MIN_SLABS = 64
+LEAD_LAST_MAX_BOUNDS = 1 << 20  # boundary words (runs x (ranges + 1)) of the slab merge: 4 MB
 LEAD_LAST_STATS = {}
 
 
@@ -248,13 +253,19 @@ def lead_last_plan(n, n_slabs, n_cells, max_slabs=2048, max_cells=2048):
     """(cells per range, ranges) of the slab merge for n elements in n_slabs sorted runs over n_cells kept cells, or None when
     the problem is the sort's: too many runs, or a key space so much larger than the element count that most workgroups (one
     per range) and most boundary words (one per run and range) would be empty.  A range aims at LEAD_LAST_RANGE elements."""
-    if n <= 0 or n >= 2 ** 31 or n_slabs > max_slabs or n_cells >= 2 ** 42 or n_cells < 1:
+    if n <= 0 or n > LEAD_LAST_MAX_NNZ or n_slabs > max_slabs or n_cells >= 2 ** 42 or n_cells < 1:
         return None
+    # (a run's piece of a range is walked by ONE thread: a range holds at most ~32 elements per run, and below 64 runs a
+    # workgroup's 512 threads have nothing to share - the sort)
+    if n_slabs < LEAD_LAST_MIN_SLABS:
+        return None
+    target = min(LEAD_LAST_RANGE, 32 * n_slabs)
     cells = 1
-    while cells * 2 <= max_cells and cells * 2 * n <= LEAD_LAST_RANGE * n_cells:
+    while cells * 2 <= max_cells and cells * 2 * n <= target * n_cells:
         cells *= 2
     ranges = -(-n_cells // cells)
-    if ranges > max(4096, n // 64) or n_slabs * (ranges + 1) > 8 * n + (1 << 20):
+    # (every range is a workgroup, every (run, range) a boundary word found by a binary search of the keys)
+    if ranges > max(4096, n // 64) or n_slabs * (ranges + 1) > LEAD_LAST_MAX_BOUNDS:
         return None
     return cells, ranges
 

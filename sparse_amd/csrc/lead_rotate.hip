@@ -8,19 +8,20 @@
 // But the input is NOT arbitrary: its keys are sorted, key = s * P + c with s = the leading axes' index ("slab", S of them)
 // and c = the kept axes' index ("cell", P of them), so the elements are S sorted runs - one per slab - and the wanted order
 // (by c, then s) is their S-way merge.  With few slabs (S <= 2048) that merge is done by cell RANGES:
-//   rl_split_kernel   one flat pass over the keys: bnd[s][b] = first element of slab s whose cell is >= b * C (C cells per
-//                     range, a power of two).  Sorted keys make the flattened (s, b) index non-decreasing along the elements:
-//                     every boundary is written once, by the element that crosses it.
+//   rl_bounds_kernel  bnd[s][b] = first element of slab s whose cell is >= b * C (C cells per range, a power of two): a binary
+//                     search of the sorted keys per boundary word.
 //   rl_merge_kernel   a workgroup per cell range: thread s takes slab s's piece [bnd[s][b], bnd[s][b + 1]) (short: ~n C / (S P)
 //                     elements), the range's elements (~1000-1500) are counted per cell in LDS, placed into per-cell segments and
 //                     every segment (the elements of ONE output cell: ~1, from distinct slabs) is ordered by slab by one thread.
 //                     The range's first output position is the number of elements in the ranges before it = sum over the slabs
 //                     of bnd[s][b] - bnd[s][0]: no scan over workgroups, no look-back.
-// Measured at config 1 (10^6 elements, S = 1000, P = 10^6; rocprofv3): split 9 us + merge 34 us against 145 us of key
-// permutation + radix sort; `sum(axis=0)` 0.232 -> 0.135 ms.  On the way: boundaries slab-major (every thread of a merge
+// Measured at config 1 (10^6 elements, S = 1000, P = 10^6): boundaries ~25 us + merge 34 us against 145 us of key
+// permutation + radix sort; `sum(axis=0)` 0.23 -> 0.15 ms; S = 64 .. 2000 runs and 10^5 .. 4 x 10^6 elements: 0.11-0.30 ms
+// against 0.15-0.34 ms (tools/r05/sum0_shapes.py).  On the way: boundaries slab-major (every thread of a merge
 // workgroup on a cache line of its own) 18 of 50 us in the first phase alone -> range-major; 1024-thread workgroups at 72
 // VGPRs fit ONE per CU -> 512 threads; ranges of ~1000 elements = 977 workgroups in two rounds -> ~2000 elements, one round;
-// the split with two 64-bit divides per element and two per boundary 12 us -> reciprocal multiply, none per boundary.
+// the boundaries written by a pass over the ELEMENTS (9 us on dense data, but gaps filled word by word by one thread:
+// 1.1 ms for 90 empty trailing runs) -> a binary search per boundary word.
 // Output: out_keys[i] = c * S + s ascending (exactly `spamd_permute_keys` + `spamd_sort_kv`), values moved bit-wise.
 // A range with more elements than the LDS arrays hold, or a cell with more than RL_MAX_PER_CELL elements, sets `failed`
 // (nothing is written for that range): the caller then takes the sort.  Keys must be sorted and duplicate-free.
@@ -36,52 +37,26 @@ constexpr int RL_CAP = 4096;             // elements of a range
 constexpr int RL_MAX_PER_CELL = 64;      // elements of one output cell ordered by one thread (insertion)
 constexpr int RL_SLAB_BITS = 11;
 
-__global__ void __launch_bounds__(256) rl_split_kernel(int64_t n, const int64_t* __restrict__ keys, int64_t S, int64_t P, double rp,
-                                                      int cshift, int64_t nb1, int* __restrict__ bnd) {
-  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (q >= n) return;
-  // (slab, range) of a key: the slab by a reciprocal multiply in double + an exact correction (a 64-bit divide is ~100
-  // instructions; keys are below 2^53 - the host checks)
-  auto slab_of = [&](int64_t k) {
-    int64_t s = (int64_t)((double)k * rp);
-    int64_t r = k - s * P;
-    while (r < 0) { --s; r += P; }
-    while (r >= P) { ++s; r -= P; }
-    return s;
-  };
-  const int64_t k = keys[q];
-  const int64_t s = slab_of(k), b = (k - s * P) >> cshift;
-  // the boundaries between the previous element's (slab, range) and mine - in (slab, range) order, every one written once,
-  // range-major (bnd[b * S + s]: a workgroup of the merge kernel reads its two rows of boundaries contiguously; slab-major,
-  // every thread of it touched a cache line of its own - 18 of that kernel's 50 us at config 1)
-  int64_t ws = 0, wb = 0;
-  if (q > 0) {
-    const int64_t kp = keys[q - 1];
-    ws = slab_of(kp);
-    wb = ((kp - ws * P) >> cshift) + 1;
+// bnd[b * S + s] = first element of run s whose cell is >= b * C (b = 0 .. nb; b = nb: the run's end), range-major so that a
+// workgroup of the merge kernel reads its two rows of boundaries contiguously.  One thread per boundary word: a binary search
+// of the sorted keys for s * P + min(b * C, P), the word written where the thread's index says - coalesced.
+// (First form, measured: one flat pass over the ELEMENTS, every element writing the boundaries between its predecessor's
+// (run, range) and its own - 9 us at config 1, but a gap of empty runs or ranges is then filled by ONE thread, word by word,
+// with scattered 4-byte stores: 90 empty trailing runs of 1000 cost 1.1 ms, and a table beyond the L2 10 ms.)
+__global__ void __launch_bounds__(256) rl_bounds_kernel(int64_t n, const int64_t* __restrict__ keys, int64_t S, int64_t P, int64_t C,
+                                                       int64_t nb1, int* __restrict__ bnd) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= S * nb1) return;
+  const int64_t b = t / S, s = t - b * S;
+  const int64_t c = b * C < P ? b * C : P;
+  const int64_t target = s * P + c;
+  int64_t lo = 0, hi = n;      // first index with keys[idx] >= target
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (keys[mid] < target) lo = mid + 1;
+    else hi = mid;
   }
-  while (ws < s || (ws == s && wb <= b)) {
-    if (wb == nb1) {
-      ++ws;
-      wb = 0;
-      continue;
-    }
-    bnd[wb * S + ws] = (int)q;
-    ++wb;
-  }
-  if (q == n - 1) {
-    ws = s;
-    wb = b + 1;
-    while (ws < S) {
-      if (wb == nb1) {
-        ++ws;
-        wb = 0;
-        continue;
-      }
-      bnd[wb * S + ws] = (int)n;
-      ++wb;
-    }
-  }
+  bnd[t] = (int)lo;
 }
 
 // exclusive scan of one int per thread over the workgroup; total returned to every thread.  Two barriers.
@@ -269,11 +244,10 @@ extern "C" int spamd_keys_lead_last(int val_bytes, int64_t n, const int64_t* key
   hipStream_t s = (hipStream_t)stream;
   if (hipError_t e = hipMemsetAsync(failed, 0, sizeof(int64_t), s); e != hipSuccess) return (int)e;
   if (n == 0) return 0;
-  int cshift = 0;
-  while (((int64_t)1 << cshift) < cells_per_range) ++cshift;
   const int64_t nb = ceil_div(P, cells_per_range), nb1 = nb + 1;
   if (nb >= ((int64_t)1 << 31)) return SPAMD_EINVAL;
-  hipLaunchKernelGGL(rl_split_kernel, dim3((unsigned)ceil_div(n, (int64_t)256)), dim3(256), 0, s, n, keys, S, P, 1.0 / (double)P, cshift, nb1, bounds);
+  hipLaunchKernelGGL(rl_bounds_kernel, dim3((unsigned)ceil_div(S * nb1, (int64_t)256)), dim3(256), 0, s, n, keys, S, P, cells_per_range, nb1,
+                     bounds);
   if (int rc = launch_status()) return rc;
   if (val_bytes == 4)
     hipLaunchKernelGGL(rl_merge_kernel<uint32_t>, dim3((unsigned)nb), dim3(RL_THREADS), 0, s, n, keys, (const uint32_t*)vals, S, P,

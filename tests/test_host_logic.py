@@ -400,7 +400,9 @@ def test_slab_merge_plan_of_leading_axis_reductions():
     assert plan(10 ** 6, 4096, 10 ** 6) is None                 # more runs than a workgroup has threads for
     assert plan(1000, 100, 10 ** 12) is None                    # 10^3 elements in a 10^12-cell key space
     assert plan(0, 10, 10) is None and plan(2 ** 31, 10, 10 ** 6) is None
-    for n, S, P in ((10 ** 5, 37, 10 ** 7), (5 * 10 ** 7, 2048, 10 ** 6), (123456, 1, 999)):
+    assert plan(10 ** 7, 1000, 10 ** 6) is None                 # beyond ~4 x 10^6 elements the radix sort is the faster order
+    assert plan(4 * 10 ** 6, 1000, 10 ** 6) is None             # ... and so is a boundary table beyond the L2 (1000 runs x 1955 ranges)
+    for n, S, P in ((10 ** 5, 37, 10 ** 7), (4 * 10 ** 6, 100, 10 ** 6), (123456, 1, 999)):
         p = plan(n, S, P)
         if p is not None:
             cells, ranges = p

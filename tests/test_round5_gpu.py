@@ -317,7 +317,7 @@ def test_tensordot_views_are_kept_and_follow_the_operand(sp):
     assert np.allclose(r3.cpu().numpy(), 3.0 * want, rtol=1e-12)
 
 
-@pytest.mark.parametrize("shape,axis,density", [((1000, 100, 100), 0, 0.01), ((40, 50, 60, 7), (0, 1), 0.02), ((3, 5000, 40), 0, 0.05),
+@pytest.mark.parametrize("shape,axis,density", [((1000, 100, 100), 0, 0.01), ((40, 50, 60, 7), (0, 1), 0.02), ((3, 5000, 40), 0, 0.05), ((70, 300, 30), 0, 0.05),
                                                 ((2000, 4), 0, 0.9), ((1500, 3000), 0, 0.002), ((7, 11), 0, 0.5)])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int64])
 def test_reductions_over_leading_axes_merge_the_slabs_instead_of_sorting(sp, shape, axis, density, dtype):
@@ -338,7 +338,10 @@ def test_reductions_over_leading_axes_merge_the_slabs_instead_of_sorting(sp, sha
             K.LEAD_LAST = True
         K.LEAD_LAST_STATS.clear()
         got = getattr(x, red)(axis=axis)
-        assert K.LEAD_LAST_STATS.get("calls", 0) == 1, (red, K.LEAD_LAST_STATS)
+        ax = axis if isinstance(axis, tuple) else (axis,)
+        n_slabs = int(np.prod([shape[a] for a in ax]))
+        planned = K.lead_last_plan(x.nnz, n_slabs, int(np.prod(shape)) // n_slabs) is not None and x.data.element_size() in (4, 8)
+        assert K.LEAD_LAST_STATS.get("calls", 0) == (1 if planned else 0), (red, K.LEAD_LAST_STATS)   # (fewer than 64 runs: the sort)
         assert got.shape == want.shape and got.nnz == want.nnz
         assert torch.equal(got.coords, want.coords)
         assert got.data.dtype == want.data.dtype and _bits(got.data) == _bits(want.data)
