@@ -8,8 +8,8 @@
 // But the input is NOT arbitrary: its keys are sorted, key = s * P + c with s = the leading axes' index ("slab", S of them)
 // and c = the kept axes' index ("cell", P of them), so the elements are S sorted runs - one per slab - and the wanted order
 // (by c, then s) is their S-way merge.  With few slabs (S <= 2048) that merge is done by cell RANGES:
-//   rl_bounds_kernel  bnd[s][b] = first element of slab s whose cell is >= b * C (C cells per range, a power of two): a binary
-//                     search of the sorted keys per boundary word.
+//   rl_split_kernel + rl_bounds_kernel   bnd[s][b] = first element of slab s whose cell is >= b * C (C cells per range, a power
+//                     of two): short gaps by the elements themselves, the rest by a binary search per boundary word.
 //   rl_merge_kernel   a workgroup per cell range: thread s takes slab s's piece [bnd[s][b], bnd[s][b + 1]) (short: ~n C / (S P)
 //                     elements), the range's elements (~1000-1500) are counted per cell in LDS, placed into per-cell segments and
 //                     every segment (the elements of ONE output cell: ~1, from distinct slabs) is ordered by slab by one thread.
@@ -38,15 +38,52 @@ constexpr int RL_MAX_PER_CELL = 64;      // elements of one output cell ordered 
 constexpr int RL_SLAB_BITS = 11;
 
 // bnd[b * S + s] = first element of run s whose cell is >= b * C (b = 0 .. nb; b = nb: the run's end), range-major so that a
-// workgroup of the merge kernel reads its two rows of boundaries contiguously.  One thread per boundary word: a binary search
-// of the sorted keys for s * P + min(b * C, P), the word written where the thread's index says - coalesced.
-// (First form, measured: one flat pass over the ELEMENTS, every element writing the boundaries between its predecessor's
-// (run, range) and its own - 9 us at config 1, but a gap of empty runs or ranges is then filled by ONE thread, word by word,
-// with scattered 4-byte stores: 90 empty trailing runs of 1000 cost 1.1 ms, and a table beyond the L2 10 ms.)
+// workgroup of the merge kernel reads its two rows of boundaries contiguously.  Two passes over a table preset to -1:
+//   rl_split_kernel   one flat pass over the ELEMENTS: sorted keys make the flattened (run, range) index non-decreasing along
+//                     them, so the words between an element's predecessor and the element itself are all "this element" -
+//                     written by it when they are at most RL_GAP (dense data: 0 or 1 word per element, 9 us at config 1);
+//   rl_bounds_kernel  one thread per word that is still -1 (longer gaps: empty runs, sparse runs, the table's head and tail):
+//                     a binary search of the keys for s * P + min(b * C, P).
+// (The element pass alone filled a gap of ANY length word by word in one thread: 1.1 ms for 90 empty trailing runs of 1000;
+// the search alone costs the dense case ~45 us at 10^6 words.)
+constexpr int RL_GAP = 8;
+
+__global__ void __launch_bounds__(256) rl_split_kernel(int64_t n, const int64_t* __restrict__ keys, int64_t S, int64_t P, double rp,
+                                                      int cshift, int64_t nb1, int* __restrict__ bnd) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= n) return;
+  // (run, range) of a key: the run by a reciprocal multiply in double + an exact correction (keys are below 2^53)
+  auto slab_of = [&](int64_t k) {
+    int64_t s = (int64_t)((double)k * rp);
+    int64_t r = k - s * P;
+    while (r < 0) { --s; r += P; }
+    while (r >= P) { ++s; r -= P; }
+    return s;
+  };
+  const int64_t k = keys[q];
+  const int64_t s = slab_of(k), b = (k - s * P) >> cshift;
+  int64_t ws = 0, wb = 0;       // the first word after my predecessor's
+  if (q > 0) {
+    const int64_t kp = keys[q - 1];
+    ws = slab_of(kp);
+    wb = ((kp - ws * P) >> cshift) + 1;     // (<= nb1 - 1: a range index is below nb1 - 1)
+  }
+  const int64_t cnt = (s - ws) * nb1 + (b - wb) + 1;   // words from (ws, wb) to (s, b) in (run, range) order
+  if (cnt <= 0 || cnt > RL_GAP) return;
+  for (int64_t i = 0; i < cnt; ++i) {
+    if (wb == nb1) {
+      ++ws;
+      wb = 0;
+    }
+    bnd[wb * S + ws] = (int)q;
+    ++wb;
+  }
+}
+
 __global__ void __launch_bounds__(256) rl_bounds_kernel(int64_t n, const int64_t* __restrict__ keys, int64_t S, int64_t P, int64_t C,
                                                        int64_t nb1, int* __restrict__ bnd) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= S * nb1) return;
+  if (t >= S * nb1 || bnd[t] != -1) return;
   const int64_t b = t / S, s = t - b * S;
   const int64_t c = b * C < P ? b * C : P;
   const int64_t target = s * P + c;
@@ -246,6 +283,12 @@ extern "C" int spamd_keys_lead_last(int val_bytes, int64_t n, const int64_t* key
   if (n == 0) return 0;
   const int64_t nb = ceil_div(P, cells_per_range), nb1 = nb + 1;
   if (nb >= ((int64_t)1 << 31)) return SPAMD_EINVAL;
+  int cshift = 0;
+  while (((int64_t)1 << cshift) < cells_per_range) ++cshift;
+  if (hipError_t e = hipMemsetAsync(bounds, 0xff, (size_t)(S * nb1) * sizeof(int), s); e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(rl_split_kernel, dim3((unsigned)ceil_div(n, (int64_t)256)), dim3(256), 0, s, n, keys, S, P, 1.0 / (double)P, cshift, nb1,
+                     bounds);
+  if (int rc = launch_status()) return rc;
   hipLaunchKernelGGL(rl_bounds_kernel, dim3((unsigned)ceil_div(S * nb1, (int64_t)256)), dim3(256), 0, s, n, keys, S, P, cells_per_range, nb1,
                      bounds);
   if (int rc = launch_status()) return rc;
