@@ -15,13 +15,13 @@
 //                     every segment (the elements of ONE output cell: ~1, from distinct slabs) is ordered by slab by one thread.
 //                     The range's first output position is the number of elements in the ranges before it = sum over the slabs
 //                     of bnd[s][b] - bnd[s][0]: no scan over workgroups, no look-back.
-// Measured at config 1 (10^6 elements, S = 1000, P = 10^6): boundaries ~25 us + merge 34 us against 145 us of key
-// permutation + radix sort; `sum(axis=0)` 0.23 -> 0.15 ms; S = 64 .. 2000 runs and 10^5 .. 4 x 10^6 elements: 0.11-0.30 ms
+// Measured at config 1 (10^6 elements, S = 1000, P = 10^6): boundaries ~15 us + merge 34 us against 145 us of key
+// permutation + radix sort; `sum(axis=0)` 0.23 -> 0.14 ms; S = 64 .. 2000 runs and 10^5 .. 4 x 10^6 elements: 0.12-0.31 ms
 // against 0.15-0.34 ms (tools/r05/sum0_shapes.py).  On the way: boundaries slab-major (every thread of a merge
 // workgroup on a cache line of its own) 18 of 50 us in the first phase alone -> range-major; 1024-thread workgroups at 72
 // VGPRs fit ONE per CU -> 512 threads; ranges of ~1000 elements = 977 workgroups in two rounds -> ~2000 elements, one round;
-// the boundaries written by a pass over the ELEMENTS (9 us on dense data, but gaps filled word by word by one thread:
-// 1.1 ms for 90 empty trailing runs) -> a binary search per boundary word.
+// the boundaries written by a pass over the ELEMENTS alone (9 us on dense data, but gaps filled word by word by one thread:
+// 1.1 ms for 90 empty trailing runs) -> short gaps by the elements, a binary search for the words left unset.
 // Output: out_keys[i] = c * S + s ascending (exactly `spamd_permute_keys` + `spamd_sort_kv`), values moved bit-wise.
 // A range with more elements than the LDS arrays hold, or a cell with more than RL_MAX_PER_CELL elements, sets `failed`
 // (nothing is written for that range): the caller then takes the sort.  Keys must be sorted and duplicate-free.
