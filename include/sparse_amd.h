@@ -48,6 +48,7 @@ extern "C" {
 #define SPAMD_TILED_INT32 8u /* spamd_spmm_tiled with val_dtype SPAMD_F32: the stream's values, B and the result are int32 BIT
                              * PATTERNS (the inspector only moves value bits: build the stream from the int32 values viewed
                              * as float32); products and sums wrap around like NumPy's int32 (`_dot_dtype`, _common.py:635) */
+#define SPAMD_SPMM_ROWVEC 16u /* spamd_spmm_csr: results of at most 4 columns keep the row-vector kernel (lanes along a row) instead of the stream form */
 #define SPAMD_SPMM_ROWGROUP 4u /* spamd_spmm_csr: the k-ascending row-group kernel whatever the shape (no row-vector, no LDS-resident-B path) */
 
 /* Library/ABI version: major*10000 + minor*100 + patch. */
@@ -92,6 +93,22 @@ int spamd_spmm_csr_ldsb(int val_dtype, int idx_dtype, int64_t M, int64_t K, int6
                         const void* a_data, const void* a_indices, const void* a_indptr,
                         const void* b, int64_t ldb, void* out, int64_t ldo,
                         unsigned flags, void* stream);
+
+/* The same product for results of at most 4 columns (N = 1: `x @ v`, the matrix-vector product) organised around the
+ * CSR triplet's STREAM (`_dot_csr_ndarray`, `_common.py:744-753`, whose inner loop over one output column is this product):
+ * every wave owns a piece of the stream that starts and ends on row boundaries, reads it once in 16-byte loads with four
+ * 256-element subtiles in flight, takes B from LDS (K * N values <= 160 KB - 512 B), closes the rows with a segmented scan
+ * over the lanes and stores `out` in row order.  A row's products are added in a fixed tree order (deterministic; floating
+ * point within rounding of the storage-order sum, integers identical) - SPAMD_EXACT_MULADD is not accepted here.
+ * spamd_spmm_csr takes this path for N <= 4 when `..._fits` says 1 and M >= 32768, unless SPAMD_SPMM_ROWGROUP,
+ * SPAMD_SPMM_ROWVEC or (for floating point) SPAMD_EXACT_MULADD is set.  `..._fits`: N in 1..4 (1..3 for 8-byte values), M < 2^28, B within the LDS
+ * budget, a_data and a_indices 16-byte aligned.  `nnz` = a_indptr[M] when the caller knows it, -1 otherwise (the kernel then reads it: one
+ * more memory latency at the head of every wave).  flags bits 8..15 (tuning hint, 0 = default): workgroups per resident slot. */
+int spamd_spmm_csr_stream_fits(int val_dtype, int64_t M, int64_t K, int64_t N, const void* a_data, const void* a_indices);
+int spamd_spmm_csr_stream(int val_dtype, int idx_dtype, int64_t M, int64_t K, int64_t N,
+                          const void* a_data, const void* a_indices, const void* a_indptr,
+                          const void* b, int64_t ldb, void* out, int64_t ldo,
+                          int64_t nnz, unsigned flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * A1 (inspector/executor form)   same product as spamd_spmm_csr for F32 (N % 128 == 0) and F64 (N % 64 == 0),

@@ -19,6 +19,7 @@ EXACT_MULADD = 1
 TILED_GROUP_ENDS = 2
 TILED_INT32 = 8
 SPMM_ROWGROUP = 4
+SPMM_ROWVEC = 16
 
 _lib = None
 
@@ -144,6 +145,8 @@ SIGNATURES = {
     "spamd_has_nan_async": (_int, [_int, _i64, _vp, _vp, _vp]),
     "spamd_spmm_csr": (_int, [_int, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _u32, _vp]),
     "spamd_spmm_csr_ldsb": (_int, [_int, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _u32, _vp]),
+    "spamd_spmm_csr_stream": (_int, [_int, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _u32, _vp]),
+    "spamd_spmm_csr_stream_fits": (_int, [_int, _i64, _i64, _i64, _vp, _vp]),
     "spamd_spmm_csr_ldsb_fits": (_int, [_int, _i64, _i64, _i64, _vp, _i64, _vp, _i64]),
 }
 

@@ -27,11 +27,15 @@ def _unify_index(*idx):
     return [i if i.dtype == want else i.to(want) for i in idx], want
 
 
-def dot_csr_ndarray(out_shape, a_data, a_indices, a_indptr, b, *, exact=False, out=None, keep_order=False):
+STREAM_MIN_ROWS = 32768   # spamd_spmm_csr's own bound for the stream form (SPAMD_ROWVEC_LDS_MIN_M, spmm_csr.hip)
+
+
+def dot_csr_ndarray(out_shape, a_data, a_indices, a_indptr, b, *, exact=False, out=None, keep_order=False, rowvec=False):
     """C = A @ B, A in CSR, B dense row-major, C dense — `_dot_csr_ndarray`
     (reference _common.py:720-755).  `exact=True` reproduces the reference's separate
     multiply/add bit-for-bit; the default uses one FMA per term (same k-ascending order; results of at most 4 columns
-    are summed in a per-row tree order by the row-vector kernel unless `keep_order`)."""
+    are summed in a per-row tree order by the stream / row-vector kernels unless `keep_order`; `rowvec` keeps the
+    row-vector kernel where the stream form would run)."""
     M, N = int(out_shape[0]), int(out_shape[1])
     dev = require_hip(a_data, a_indices, a_indptr, b)
     dtr = torch_dtype(dot_dtype(a_data.dtype, b.dtype))
@@ -52,9 +56,18 @@ def dot_csr_ndarray(out_shape, a_data, a_indices, a_indptr, b, *, exact=False, o
         out = torch.empty((M, N), dtype=dtr, device=dev)
     elif out.shape != (M, N) or out.dtype != dtr or not out.is_contiguous():
         raise ValueError("out buffer has wrong shape/dtype/layout")
+    if (1 <= N <= 4 and M >= STREAM_MIN_ROWS and K > 0 and not keep_order and not rowvec
+            and not (exact and dtr.is_floating_point)
+            and _ffi.lib().spamd_spmm_csr_stream_fits(vcode, M, K, N, ptr(a_data), ptr(a_indices))):
+        # what spamd_spmm_csr's own dispatch would pick, with the number of stored elements handed over (the kernel need
+        # not read it from indptr at the head of every wave's start-up chain)
+        _ffi.call("spamd_spmm_csr_stream", vcode, code_of(it), M, K, N, ptr(a_data), ptr(a_indices), ptr(a_indptr),
+                  ptr(b), N, ptr(out), N, int(a_data.numel()), 0, stream_ptr(dev))
+        return out
     _ffi.call("spamd_spmm_csr", vcode, code_of(it), M, K, N, ptr(a_data), ptr(a_indices),
               ptr(a_indptr), ptr(b), max(N, 1), ptr(out), max(N, 1),
-              (_ffi.EXACT_MULADD if exact else 0) | (_ffi.SPMM_ROWGROUP if keep_order else 0), stream_ptr(dev))
+              (_ffi.EXACT_MULADD if exact else 0) | (_ffi.SPMM_ROWGROUP if keep_order else 0) |
+              (_ffi.SPMM_ROWVEC if rowvec else 0), stream_ptr(dev))
     return out
 
 

@@ -483,6 +483,12 @@ extern "C" int spamd_spmm_csr_ldsb(int val_dtype, int idx_dtype, int64_t M, int6
                                    const void* a_indices, const void* a_indptr, const void* b, int64_t ldb, void* out,
                                    int64_t ldo, unsigned flags, void* stream);
 
+extern "C" int spamd_spmm_csr_stream_fits(int val_dtype, int64_t M, int64_t K, int64_t N, const void* a_data,
+                                          const void* a_indices);
+extern "C" int spamd_spmm_csr_stream(int val_dtype, int idx_dtype, int64_t M, int64_t K, int64_t N, const void* a_data,
+                                     const void* a_indices, const void* a_indptr, const void* b, int64_t ldb, void* out,
+                                     int64_t ldo, int64_t nnz, unsigned flags, void* stream);
+
 extern "C" int spamd_spmm_csr(int val_dtype, int idx_dtype, int64_t M, int64_t K, int64_t N,
                               const void* a_data, const void* a_indices, const void* a_indptr,
                               const void* b, int64_t ldb, void* out, int64_t ldo, unsigned flags,
@@ -498,6 +504,11 @@ extern "C" int spamd_spmm_csr(int val_dtype, int idx_dtype, int64_t M, int64_t K
   if (!(flags & SPAMD_SPMM_ROWGROUP) && M >= 8192 && N * ((val_dtype == SPAMD_F64 || val_dtype == SPAMD_I64) ? 8 : 4) >= 128 &&
       spamd_spmm_csr_ldsb_fits(val_dtype, M, K, N, b, ldb, out, ldo))
     return spamd_spmm_csr_ldsb(val_dtype, idx_dtype, M, K, N, a_data, a_indices, a_indptr, b, ldb, out, ldo, flags, stream);
+  // results of at most 4 columns, B fits LDS: the stream form (spmm_stream.hip; tree order per row like the row-vector kernel)
+  if (N <= ROWVEC_MAX_N && !(flags & (SPAMD_SPMM_ROWGROUP | SPAMD_SPMM_ROWVEC)) && M >= SPAMD_ROWVEC_LDS_MIN_M && K > 0 &&
+      !(exact && (val_dtype == SPAMD_F32 || val_dtype == SPAMD_F64)) &&
+      spamd_spmm_csr_stream_fits(val_dtype, M, K, N, a_data, a_indices))
+    return spamd_spmm_csr_stream(val_dtype, idx_dtype, M, K, N, a_data, a_indices, a_indptr, b, ldb, out, ldo, -1, 0u, stream);
   SPAMD_DISPATCH_VAL(val_dtype, T, {
     SPAMD_DISPATCH_IDX(idx_dtype, I, {
       const T* ad = (const T*)a_data;

@@ -1,0 +1,119 @@
+"""A1, results of at most 4 columns: the STREAM form (`sparse_amd/csrc/spmm_stream.hip`) of `_dot_csr_ndarray`
+(reference sparse/numba_backend/_common.py:720-755) against the CPU oracle, through the C ABI (`spamd_spmm_csr_stream`
+directly, so that small matrices reach it too, and `spamd_spmm_csr`'s own dispatch at a size that takes it)."""
+import numpy as np
+import pytest
+import torch
+
+from util import assert_within_fma_bound, random_csr, random_dense
+
+pytestmark = pytest.mark.gpu
+
+
+def _stream(M, K, N, data, idx, ptr, b, mult=0, known_nnz=True):
+    from sparse_amd import _ffi
+    from sparse_amd._device import code_of, ptr as p_, stream_ptr
+
+    d = torch.device("cuda")
+    td, ti, tp, tb = (torch.from_numpy(np.ascontiguousarray(x)).to(d) for x in (data, idx, ptr, b))
+    out = torch.full((M, N), -7, dtype=td.dtype, device=d)   # every element must be written
+    assert _ffi.lib().spamd_spmm_csr_stream_fits(code_of(td.dtype), M, K, N, p_(td), p_(ti)) == 1
+    nnz_arg = len(data) if known_nnz else -1
+    _ffi.call("spamd_spmm_csr_stream", code_of(td.dtype), code_of(ti.dtype), M, K, N, p_(td), p_(ti), p_(tp), p_(tb), N,
+              p_(out), N, nnz_arg, mult << 8, stream_ptr(d))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def _check(orc, M, K, N, data, idx, ptr, b, **kw):
+    got = _stream(M, K, N, data, idx, ptr, b, **kw)
+    want = orc.dot_csr_ndarray((M, N), data, idx, ptr, b)
+    if np.dtype(data.dtype).kind == "f":
+        assert_within_fma_bound(got, want, data, idx, ptr, b)
+    else:
+        assert got.dtype == want.dtype and np.array_equal(got, want)
+    return got
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int32, np.int64])
+@pytest.mark.parametrize("idt", [np.int32, np.int64])
+@pytest.mark.parametrize("N", [1, 2, 3, 4])
+def test_stream_vs_oracle(orc, dtype, idt, N):
+    M, K = 5000, 900
+    data, idx, ptr = random_csr(M, K, 0.02, 11 + N, dtype, idt)
+    if N == 4 and np.dtype(dtype).itemsize == 8:   # declined (32-byte rows of B): spamd_spmm_csr keeps the row-vector kernel
+        from sparse_amd import _ffi
+        from sparse_amd._device import code_of, ptr as p_
+
+        td = torch.from_numpy(data).cuda()
+        assert _ffi.lib().spamd_spmm_csr_stream_fits(code_of(td.dtype), M, K, N, p_(td), p_(td)) == 0
+        return
+    _check(orc, M, K, N, data, idx, ptr, random_dense(K, N, 5, dtype))
+
+
+@pytest.mark.parametrize("density,M,K", [(0.0, 300, 50), (0.0005, 40000, 300), (0.004, 30000, 700), (0.3, 3000, 1000),
+                                         (1.0, 700, 1200)])
+@pytest.mark.parametrize("N", [1, 4])
+def test_row_lengths_from_empty_to_dense(orc, density, M, K, N):
+    """rows of 0 / ~0.15 / ~3 / 300 / 1200 elements: windows of row ends exhausted several times per subtile (phase
+    A's and B's window loops) up to rows that span five subtiles (the carry between subtiles)."""
+    data, idx, ptr = random_csr(M, K, density, 3, np.float32, np.int32)
+    got = _check(orc, M, K, N, data, idx, ptr, random_dense(K, N, 9, np.float32))
+    if density == 0.0:
+        assert not got.any()
+
+
+def test_empty_row_runs_and_a_long_row(orc):
+    M, K = 9000, 2000
+    empty = tuple(range(0, 200)) + tuple(range(4000, 4300)) + tuple(range(8990, 9000)) + (777, 779)
+    data, idx, ptr = random_csr(M, K, 0.01, 4, np.float64, np.int64, empty_rows=empty, long_row=5000)
+    got = _check(orc, M, K, 2, data, idx, ptr, random_dense(K, 2, 2, np.float64))
+    assert not got[list(empty)].any()
+
+
+def test_misaligned_piece_starts_and_partial_last_vector(orc):
+    """nnz % 4 != 0 (the array's last 16-byte vector is partial) and many pieces (a wave's piece starts at a row start,
+    almost never on a 16-byte boundary)."""
+    for seed, M in ((1, 2049), (2, 2050), (3, 2051)):
+        K = 333
+        data, idx, ptr = random_csr(M, K, 0.03, seed, np.float32, np.int32)
+        if len(data) % 4 == 0:
+            data, idx = data[:-1], idx[:-1]
+            ptr = np.minimum(ptr, len(data)).astype(ptr.dtype)
+        _check(orc, M, K, 1, data, idx, ptr, random_dense(K, 1, 8, np.float32))
+        _check(orc, M, K, 3, data, idx, ptr, random_dense(K, 3, 8, np.float32), mult=3, known_nnz=False)
+
+
+def test_special_values_do_not_leak(orc):
+    """inf / nan in rows of B that a wave's masked lanes (outside its piece) would read must not reach the sums"""
+    M, K = 4000, 64
+    data, idx, ptr = random_csr(M, K, 0.1, 6, np.float32, np.int32)
+    b = random_dense(K, 1, 7, np.float32)
+    b[0, 0] = np.inf          # masked lanes gather row 0
+    keep = idx != 0
+    rows = np.repeat(np.arange(M), np.diff(ptr))[keep]
+    data, idx = data[keep], idx[keep]
+    ptr = np.zeros(M + 1, ptr.dtype)
+    np.cumsum(np.bincount(rows, minlength=M), out=ptr[1:])
+    got = _stream(M, K, 1, data, idx, ptr, b)
+    assert np.isfinite(got).all()
+    b[0, 0] = 0.0
+    assert np.array_equal(got, _stream(M, K, 1, data, idx, ptr, b))
+
+
+def test_run_twice_identical_and_dispatch_takes_the_stream_form(orc):
+    from sparse_amd import _ffi, _kernels as Kn
+
+    M, K, N = 70000, 500, 1
+    data, idx, ptr = random_csr(M, K, 0.02, 12, np.float32, np.int32)
+    b = random_dense(K, N, 13, np.float32)
+    a = _stream(M, K, N, data, idx, ptr, b)
+    assert np.array_equal(a, _stream(M, K, N, data, idx, ptr, b))
+    d = torch.device("cuda")
+    args = [torch.from_numpy(x).to(d) for x in (data, idx, ptr, b)]
+    via = Kn.dot_csr_ndarray((M, N), *args).cpu().numpy()          # M >= 32768: spamd_spmm_csr routes here
+    assert np.array_equal(via, a)
+    rv = Kn.dot_csr_ndarray((M, N), *args, rowvec=True).cpu().numpy()  # the row-vector kernel it replaces
+    want = orc.dot_csr_ndarray((M, N), data, idx, ptr, b)
+    assert_within_fma_bound(rv, want, data, idx, ptr, b)
+    assert_within_fma_bound(via, want, data, idx, ptr, b)
