@@ -256,18 +256,20 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
                                            nnz * 8 + (M + 1) * 4 + Kd * N * 4 + M * N * 4, flops=2.0 * nnz * N, rowgroup_ms=ms_irg,
                                            identical_to_rowgroup=bool(torch.equal(ri, K.dot_csr_ndarray((M, N), di, idx, ptr, bi)))))
         del ai, ri
-        # matrix x vector and results of 2..4 columns: the row-vector kernel (lanes along the row; B in LDS when it fits)
+        # matrix x vector and results of 2..4 columns: the stream form (spmm_stream.hip: a piece of the CSR stream per wave, B in
+        # LDS) where B fits LDS, else the row-vector kernel (lanes along the row); `rowvec_ms` = that kernel on the same operands
         for n_v, dt_v in ((1, torch.float32), (2, torch.float32), (4, torch.float32), (1, torch.float64)):
             dv = data if dt_v == torch.float32 else data.to(dt_v)
             bv = b[:, :n_v].to(dt_v).contiguous()
             ms_rg, _ = timed(lambda: K.dot_csr_ndarray((M, n_v), dv, idx, ptr, bv, keep_order=True), reps=5)
             ms_v, _ = timed(lambda: K.dot_csr_ndarray((M, n_v), dv, idx, ptr, bv), reps=10)
+            ms_rv, _ = timed(lambda: K.dot_csr_ndarray((M, n_v), dv, idx, ptr, bv, rowvec=True), reps=5)
             es = dv.element_size()
             emit(f"A1_shapes_n{n_v}_{'f32' if es == 4 else 'f64'}",
                  row(f"config-2 matrix x dense {Kd}x{n_v} {'fp32' if es == 4 else 'fp64'} ({'matrix-vector product' if n_v == 1 else 'narrow result'}: "
-                     f"row-vector kernel, B {'resident in LDS' if Kd * n_v * es <= 160 * 1024 else 'gathered from global memory'})", ms_v,
+                     f"{'stream kernel, B resident in LDS' if Kd * n_v * es + 1024 <= 160 * 1024 and not (es == 8 and n_v == 4) else 'row-vector kernel'})", ms_v,
                      nnz * (es + 4) + (M + 1) * 4 + Kd * n_v * es + M * n_v * es, flops=2.0 * nnz * n_v, rowgroup_ms=ms_rg,
-                     speedup_vs_rowgroup=ms_rg / ms_v))
+                     rowvec_ms=ms_rv, speedup_vs_rowgroup=ms_rg / ms_v))
             del dv, bv
         del a32, b32, r, d5, i5, q5, lay, di, bi
         torch.cuda.empty_cache()

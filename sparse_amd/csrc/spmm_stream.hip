@@ -4,9 +4,10 @@
 // The product is the CSR triplet's stream - 8 / 12 / 16 bytes per stored element, read once - and nothing else, so the
 // kernel is organised around the stream instead of around the rows (spmm_csr.hip's row-vector kernel gives a row to L lanes:
 // 4-byte loads at row-aligned addresses, ~1 KB per wave in flight, 4.45 TB/s on config 2's matrix):
-//   * every wave owns a contiguous piece of the stream that starts and ends on row boundaries (64-ary search in indptr for
-//     w * nnz / W), walks it in subtiles of 512 elements with 16-byte loads at 16-byte aligned addresses - lane l holds
-//     the elements 8 l .. 8 l + 7 - and keeps two subtiles in flight (8 KB of index + value per wave at fp32);
+//   * every wave owns a contiguous piece of the stream that starts and ends on row boundaries (search in indptr for
+//     w * nnz / W, after one round of coalesced loads around the place where an even spread of the elements puts it),
+//     walks it in subtiles of 512 elements with 16-byte loads at 16-byte aligned addresses - lane l holds the elements
+//     8 l .. 8 l + 7 - and has the next subtile in flight while it works on one (4 KB of index + value per wave at fp32);
 //   * B (K x N values) is resident in LDS, one copy per workgroup;
 //   * where the rows end inside a subtile comes from a WINDOW of 64 row ends held one per lane (the next window is
 //     requested when the current one becomes current, i.e. thousands of elements ahead); the lanes of the window mark
@@ -35,15 +36,6 @@ constexpr int stream_epl() {
 #define SPAMD_STREAM_ABLATE 0   // timing experiments only (wrong results): 1 = stream loads alone, 2 = + gathers and sums, 3 = + row-end marks, 4 = + scan
 #endif
 constexpr int ST_ABL = SPAMD_STREAM_ABLATE;
-// buffers in the ring of subtiles: one worked on, the others in flight
-template <typename T, typename I, int NV>
-constexpr int stream_nbuf() {
-#ifdef SPAMD_STREAM_NBUF
-  return SPAMD_STREAM_NBUF;
-#endif
-  if (sizeof(T) == 4 && sizeof(I) == 4 && NV <= 2) return 3;
-  return 2;
-}
 constexpr int ST_MASK_WORDS_MAX = 16;         // the row-end mask of one wave: a bit per element of a subtile
 constexpr int ST_LDS_BYTES = 160 * 1024;
 
@@ -169,90 +161,6 @@ __device__ __forceinline__ void stream_load(StreamSub<T, I, EPL>& x, const T* __
   }
 }
 
-// ---- the stream's loads as inline assembly ------------------------------------------------------------------------------
-// A ring of ST_NBUF subtiles per wave: the compiler's own waits cannot express it (its loads of an unrolled ring are merged
-// into one block at the loop's head behind vmcnt(0); a `cur = nxt` pair of buffers keeps ONE subtile in flight, and a wave
-// then needs a full memory latency per subtile: the first wave of a SIMD finished its piece in 142 us, the fourth in 160).
-// The loads below are invisible to the compiler's counting; the wait before a buffer's use is written by hand:
-// vmcnt(number of stream loads issued after the buffer's) - loads return in order, so whatever else is outstanding
-// (window loads, the hidden stores) can only make that wait longer than needed, never shorter.  What must not happen is a
-// compiler-made copy of a buffer register between its load and its wait; `tools/check_stream_regs.py` reads the ISA for that.
-typedef unsigned raw4_t __attribute__((ext_vector_type(4)));
-template <typename T, typename I, int EPL>
-struct RawSub {
-  static constexpr int NI = EPL * (int)sizeof(I) / 16, NT = EPL * (int)sizeof(T) / 16;
-  raw4_t i[NI], v[NT];
-};
-template <int OFF>
-__device__ __forceinline__ void asm_load16(raw4_t& dst, const void* p) {
-  // "+v": the destination is the register the buffer already lives in.  A fresh output register ("=v") per load site
-  // leaves the ring's loop-carried values in different registers at the loop's end and at its head, and the compiler
-  // joins them with v_mov copies of registers whose loads are still in flight.
-  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "+v"(dst) : "v"(p), "n"(OFF) : "memory");
-}
-template <typename T, typename I, int EPL>
-__device__ __forceinline__ void raw_load(RawSub<T, I, EPL>& x, const T* __restrict__ a_data, const I* __restrict__ a_idx,
-                                         int64_t base, int rel, int lim) {
-#pragma unroll
-  for (int h = 0; h < EPL / 4; ++h) {
-    int o = rel + 4 * h;
-    o = o < lim ? o : lim;
-    const I* pi = a_idx + base + o;
-    const T* pv = a_data + base + o;
-    if constexpr (sizeof(I) == 4) {
-      asm_load16<0>(x.i[h], pi);
-    } else {
-      asm_load16<0>(x.i[2 * h], pi);
-      asm_load16<16>(x.i[2 * h + 1], pi);
-    }
-    if constexpr (sizeof(T) == 4) {
-      asm_load16<0>(x.v[h], pv);
-    } else {
-      asm_load16<0>(x.v[2 * h], pv);
-      asm_load16<16>(x.v[2 * h + 1], pv);
-    }
-  }
-}
-// wait until at most `LATER` stream loads are outstanding and hand the buffer to the compiler as freshly defined
-template <int LATER, typename T, typename I, int EPL>
-__device__ __forceinline__ void raw_wait(RawSub<T, I, EPL>& x) {
-  using R = RawSub<T, I, EPL>;
-  if constexpr (R::NI == 2 && R::NT == 2)
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(x.i[0]), "+v"(x.i[1]), "+v"(x.v[0]), "+v"(x.v[1]) : "n"(LATER));
-  else if constexpr (R::NI == 1 && R::NT == 1)
-    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(x.i[0]), "+v"(x.v[0]) : "n"(LATER));
-  else if constexpr (R::NI == 2 && R::NT == 4)
-    asm volatile("s_waitcnt vmcnt(%6)" : "+v"(x.i[0]), "+v"(x.i[1]), "+v"(x.v[0]), "+v"(x.v[1]), "+v"(x.v[2]), "+v"(x.v[3]) : "n"(LATER));
-  else if constexpr (R::NI == 4 && R::NT == 2)
-    asm volatile("s_waitcnt vmcnt(%6)" : "+v"(x.i[0]), "+v"(x.i[1]), "+v"(x.i[2]), "+v"(x.i[3]), "+v"(x.v[0]), "+v"(x.v[1]) : "n"(LATER));
-  else if constexpr (R::NI == 1 && R::NT == 2)
-    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(x.i[0]), "+v"(x.v[0]), "+v"(x.v[1]) : "n"(LATER));
-  else if constexpr (R::NI == 2 && R::NT == 1)
-    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(x.i[0]), "+v"(x.i[1]), "+v"(x.v[0]) : "n"(LATER));
-  else if constexpr (R::NI == 4 && R::NT == 4)
-    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(x.i[0]), "+v"(x.i[1]), "+v"(x.i[2]), "+v"(x.i[3]), "+v"(x.v[0]), "+v"(x.v[1]), "+v"(x.v[2]), "+v"(x.v[3]) : "n"(LATER));
-  else
-    static_assert(R::NI < 0, "unexpected buffer shape");
-}
-template <typename E>
-__device__ __forceinline__ Vec<E, 4> raw_vec(const raw4_t* r) {
-  if constexpr (sizeof(E) == 4) {
-    return __builtin_bit_cast(Vec<E, 4>, r[0]);
-  } else {
-    struct Two { raw4_t a, b; };
-    const Two t = {r[0], r[1]};
-    return __builtin_bit_cast(Vec<E, 4>, t);
-  }
-}
-template <typename T, typename I, int EPL>
-__device__ __forceinline__ void raw_view(const RawSub<T, I, EPL>& x, StreamSub<T, I, EPL>& y) {
-#pragma unroll
-  for (int h = 0; h < EPL / 4; ++h) {
-    y.i[h] = raw_vec<I>(&x.i[h * (int)sizeof(I) / 4]);
-    y.v[h] = raw_vec<T>(&x.v[h * (int)sizeof(T) / 4]);
-  }
-}
-
 template <typename T, int NV>
 __device__ __forceinline__ void lds_row(const T* bl, unsigned k, T (&o)[NV]) {
   if constexpr (NV == 3) {
@@ -344,7 +252,11 @@ __device__ unsigned long long st_prof[16384 * 4];
 __device__ unsigned long long st_phase[16384 * 8];
 #define ST_STAMP(k) do { if (lane == 0 && w < 16384) st_prof[w * 4 + (k)] = wall_clock64(); } while (0)
 // cycles (s_memtime) between consecutive probes, summed per wave and phase
+#ifdef SPAMD_STREAM_PHASES
 #define ST_PROBE(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph_acc[k] += now_ - ph_last; ph_last = now_; } while (0)
+#else
+#define ST_PROBE(k) do { } while (0)
+#endif
 #else
 #define ST_STAMP(k) do { } while (0)
 #define ST_PROBE(k) do { } while (0)
@@ -469,41 +381,23 @@ spmm_stream_kernel(int64_t M, int64_t K, const T* __restrict__ a_data, const I* 
   };
   // One subtile in flight per wave while the one before it is worked on (4 KB of index + value at fp32; 64 KB per CU): the
   // next subtile is requested into `nxt` at the top of a trip and copied into `cur` at the top of the following one - the
-  // copy is where the wave waits for it.  (Deeper rings of buffers in an unrolled loop: hipcc merges their load sites into
-  // one block at the loop's head and drains the queue there, vmcnt(0), every trip.)
+  // copy is where the wave waits for it.  Deeper rings were built and measured (docs/history/r06.md): as compiler loads in
+  // an unrolled loop hipcc merges their load sites into one block at the loop's head behind vmcnt(0); as inline-assembly
+  // loads with hand-counted waits (three buffers, no copies) the first wave of every SIMD finished its piece in 92 us
+  // instead of 115, the fourth as late as before, and the product took 5 % longer.
   StreamSub<T, I, ST_EPL> cur, nxt;
-  constexpr int LPS = RawSub<T, I, ST_EPL>::NI + RawSub<T, I, ST_EPL>::NT;  // stream loads per subtile and lane
-#ifdef SPAMD_STREAM_COMPILER_LOADS
   stream_load<T, I, ST_EPL>(nxt, a_data, a_idx, t_begin, rel, lim_of(t_begin));
-#else
-  constexpr int ST_NBUF = stream_nbuf<T, I, NV>();
-  RawSub<T, I, ST_EPL> ring[ST_NBUF];
-#pragma unroll
-  for (int u = 0; u < ST_NBUF; ++u) {
-#pragma unroll
-    for (int h = 0; h < RawSub<T, I, ST_EPL>::NI; ++h) ring[u].i[h] = raw4_t{0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int h = 0; h < RawSub<T, I, ST_EPL>::NT; ++h) ring[u].v[h] = raw4_t{0u, 0u, 0u, 0u};
-  }
-#pragma unroll
-  for (int u = 0; u + 1 < ST_NBUF; ++u)
-    raw_load<T, I, ST_EPL>(ring[u], a_data, a_idx, t_begin + (int64_t)u * ST_SUB, rel, lim_of(t_begin + (int64_t)u * ST_SUB));
-#endif
 
   T carry[NV];
 #pragma unroll
   for (int c = 0; c < NV; ++c) carry[c] = T(0);
   if constexpr (ST_ABL == 5) {  // start-up alone: everything up to the first subtile's loads
-#ifndef SPAMD_STREAM_COMPILER_LOADS
-    raw_wait<0>(ring[0]);
-    raw_view(ring[0], nxt);
-#endif
     carry[0] = (T)(nxt.v[0].v[0] + (T)nxt.i[0].v[0] + (T)w1 + (T)ne0);
     store_row<T, NV>(out, r_lo + lane, ldo, carry, vec_ok);
     return;
   }
 
-#ifdef SPAMD_STREAM_PROF
+#ifdef SPAMD_STREAM_PHASES
   unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_last = __builtin_amdgcn_s_memtime();
 #endif
   int64_t t0 = t_begin;
@@ -528,7 +422,7 @@ spmm_stream_kernel(int64_t M, int64_t K, const T* __restrict__ a_data, const I* 
       if (t0 >= e) store_row<T, NV>(out, r_lo + lane, ldo, carry, vec_ok);
       return;
     }
-    ST_PROBE(0);   // waiting for the ring
+    ST_PROBE(0);   // waiting for the subtile
     // ---- phase A: the window lanes mark the last element of every row that ends in (t0, t_end] ----------------------
     if (lane < ST_MASK_WORDS) mask[lane] = 0;
     const bool in = lane >= off && w0 <= t_end;
@@ -537,9 +431,6 @@ spmm_stream_kernel(int64_t M, int64_t K, const T* __restrict__ a_data, const I* 
     const int cnt = __builtin_popcountll(__ballot(in));
     const bool exhausted = off + cnt == 64 && wbase + 64 < r_hi;
     if (exhausted) {  // rows of later windows end here as well (rows shorter than ~8 elements, runs of empty rows)
-      // (w1 is an ordinary load: the compiler waits for it here with vmcnt(0), which also empties the ring of stream
-      // requests - once per window of 64 rows.  Hiding that load as well is not possible: the compiler moves a
-      // long-lived loop-carried value between registers when it likes, in flight or not.)
       int64_t a0 = w1, a_base = wbase + 64, a_prev = wave_bcast(w0, 63);
       while (true) {
         const bool ain = a0 <= t_end;
@@ -699,7 +590,6 @@ spmm_stream_kernel(int64_t M, int64_t K, const T* __restrict__ a_data, const I* 
     t0 = t_end;
   };
 
-#ifdef SPAMD_STREAM_COMPILER_LOADS
 #pragma nounroll
   while (true) {
     cur = nxt;
@@ -710,39 +600,13 @@ spmm_stream_kernel(int64_t M, int64_t K, const T* __restrict__ a_data, const I* 
       subtile(cur, std::false_type{});
     if (t0 >= e) {
       ST_STAMP(3);
+#ifdef SPAMD_STREAM_PHASES
+      if (lane == 0 && w < 16384)
+        for (int k = 0; k < 8; ++k) st_phase[w * 8 + k] = ph_acc[k];
+#endif
       return;
     }
   }
-#else
-  static_assert((ST_NBUF - 1) * LPS <= 63, "vmcnt has six bits");
-  // Step u of the unrolled ring works on buffer u.  The buffer of the step before it is free - that step used its
-  // contents up - and takes the request for the subtile ST_NBUF - 1 ahead; then the wave waits until only the requests
-  // issued behind buffer u's are outstanding.  Every buffer is requested at one place and waited for at one place per
-  // trip, always in the same registers ("+v" on both): no copies, ST_NBUF - 1 subtiles in flight while one is worked on.
-  while (true) {
-#pragma unroll
-    for (int u = 0; u < ST_NBUF; ++u) {
-      constexpr int NB = ST_NBUF;
-      const int64_t ahead = t0 + (int64_t)(NB - 1) * ST_SUB;
-      raw_load<T, I, ST_EPL>(ring[(u + NB - 1) % NB], a_data, a_idx, ahead, rel, lim_of(ahead));
-      raw_wait<(NB - 1) * LPS>(ring[u]);
-      raw_view(ring[u], cur);
-      if (t0 >= s && t0 + ST_SUB <= e)
-        subtile(cur, std::true_type{});
-      else
-        subtile(cur, std::false_type{});
-      if (t0 >= e) {
-        ST_STAMP(3);
-#ifdef SPAMD_STREAM_PROF
-        if (lane == 0 && w < 16384)
-          for (int k = 0; k < 8; ++k) st_phase[w * 8 + k] = ph_acc[k];
-#endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring's last requests land before the registers are given up
-        return;
-      }
-    }
-  }
-#endif
 }
 
 template <typename T, typename I>
@@ -751,7 +615,8 @@ static int launch_stream(int64_t M, int64_t K, int64_t N, const T* a_data, const
   const size_t bbytes = ((sizeof(T) * (size_t)N * (size_t)K) + 15) & ~(size_t)15;
   // workgroups of 16 waves, as many per CU as LDS and the kernel's registers (SPAMD_STREAM_WPE waves per SIMD) allow
   int threads = 1024;
-  if (((flags >> 16) & 3u) == 2u) threads = 512;  // tuning hint bits 16..17: 2 = workgroups of 8 waves
+  if (((flags >> 16) & 3u) == 2u) threads = 512;  // tuning hint bits 16..17: 2 = workgroups of 8 waves, 3 = of 5
+  if (((flags >> 16) & 3u) == 3u) threads = 320;
   const size_t lds = bbytes + (size_t)(threads / 64) * ST_MASK_WORDS_MAX * 4;
   int per_cu = (int)((size_t)ST_LDS_BYTES / lds);
   const int by_regs = SPAMD_STREAM_WPE * 4 * 64 / threads;

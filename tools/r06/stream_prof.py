@@ -40,6 +40,8 @@ for n_v, dt in ((1, torch.float32), (4, torch.float32), (1, torch.float64)):
     print("  end by wave slot in block:", " ".join(f"{np.median(end[np.arange(nw) % nwv == x]):6.1f}" for x in range(nwv)))
     per_blk = end.reshape(-1, nwv)
     print("  per-block max-min of end: ", q(per_blk.max(1) - per_blk.min(1)), " block medians:", q(np.median(per_blk, 1)))
+    if not os.environ.get("PHASES"):
+        continue
     ph = np.zeros(nw * 8, dtype=np.uint64)
     fn2 = _ffi.lib().spamd_stream_phase_read
     fn2.argtypes = [ctypes.c_void_p, ctypes.c_int]
