@@ -30,7 +30,7 @@ from ._sparse_array import SparseArray
 from ._coo import COO, as_coo
 from ._gcxs import GCXS
 from ._dot import dot, flush_warnings, matmul, tensordot
-from ._umath import elemwise
+from ._umath import elemwise, fallback_stats
 from ._einsum import einsum
 from ._batched import concatenate, stack
 from ._broadcast import broadcast_to

@@ -798,6 +798,7 @@ SPGEMM_BITMAP_MAX_DUPS = 120    # expected products per row that share an output
 
 
 _BITMAP_UNSUPPORTED = set()    # (device index, split form?) whose launch the library refused once
+_BITMAP_REFUSAL_CODES = (1, 2, 9, 701)   # hipError_t values that mean "not with these resources", not "the device faulted"
 
 
 def _spgemm_bitmap(vcode, it, n_row, n_inner, n_col, parts, total, a_indptr, a_indices, a_data, b_indptr, b_indices, b_data, dtr,
@@ -817,9 +818,15 @@ def _spgemm_bitmap(vcode, it, n_row, n_inner, n_col, parts, total, a_indptr, a_i
         _ffi.call("spamd_spgemm_bitmap", vcode, code_of(it), n_row, n_inner, n_col, parts, ptr(a_indptr), ptr(a_indices), ptr(a_data),
                   ptr(b_indptr), ptr(b_indices), ptr(b_data), ptr(bsplit) if bsplit is not None else None, ptr(work), ptr(out_ptr),
                   ptr(out_idx), ptr(out_val), s)
-    except _ffi.HipBackendError:
-        # the launch itself was refused (the 160 KB LDS opt-in on a part with less, a range / LDS check, the occupancy query):
-        # this form is not available on this device - remembered, and the next form (or the bucket kernels) takes the product
+    except _ffi.HipBackendError as e:
+        # the launch itself was REFUSED - a negative SPAMD_E* from the range / LDS checks, or the runtime declining the 160 KB
+        # LDS opt-in or the occupancy query on a part with less (hipErrorInvalidValue 1, hipErrorOutOfMemory 2,
+        # hipErrorLaunchOutOfResources 701, hipErrorInvalidConfiguration 9): this form is not available on this device -
+        # remembered, and the next form (or the bucket kernels) takes the product.  Any other hipError_t is a device fault
+        # (an illegal address from a bad operand, a hung queue): never masked, as in _umath._on_device.
+        code = getattr(e, "code", 0)
+        if code > 0 and code not in _BITMAP_REFUSAL_CODES:
+            raise
         _BITMAP_UNSUPPORTED.add((dev.index, parts > 1))
         SPGEMM_STATS["bitmap_refused"] = SPGEMM_STATS.get("bitmap_refused", 0) + 1
         return None
@@ -878,8 +885,8 @@ def _spgemm_small(n_row, n_col, a_data, a_indices, a_indptr, b_data, b_indices, 
         vcode = code_of(dtr)
     except TypeError:
         return None
-    if n_row == 0 or n_col > int(_ffi.lib().spamd_spgemm_small_max_cols(vcode)):
-        return None
+    if n_row == 0 or n_col == 0 or n_col > int(_ffi.lib().spamd_spgemm_small_max_cols(vcode)):
+        return None     # (a zero-width result: the kernel's argument check refuses n_col <= 0; the general path returns the empty matrix)
     a_data = a_data.to(dtr).contiguous() if a_data.dtype != dtr else a_data.contiguous()
     b_data = b_data.to(dtr).contiguous() if b_data.dtype != dtr else b_data.contiguous()
     (a_indices, a_indptr, b_indices, b_indptr), it = _unify_index(a_indices.contiguous(), a_indptr.contiguous(),

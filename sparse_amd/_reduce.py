@@ -151,12 +151,13 @@ def reduce_impl(x, method, axis=(0,), keepdims=False, _no_merge=False, **kwargs)
             from ._umath import _gcxs_keys2d
 
             k2 = _gcxs_keys2d(x)
+            idt = x.indices.dtype    # the result keeps the operand's index width, as the tocoo() route does
             ax = normalize_axis(axis, 2)
             ax = ax if isinstance(ax, tuple) else (ax,)
             if k2 is not None and x.compressed_axes == (0,):
-                stand_in, axis = COO._from_sorted_keys(k2, x.data, x.shape, x.fill_value, torch.int64), ax
+                stand_in, axis = COO._from_sorted_keys(k2, x.data, x.shape, x.fill_value, idt), ax
             elif k2 is not None and len(ax) == 1 and not keepdims:   # (more axes / keepdims: the result's axes would need swapping back)
-                stand_in = COO._from_sorted_keys(k2, x.data, (x.shape[1], x.shape[0]), x.fill_value, torch.int64)
+                stand_in = COO._from_sorted_keys(k2, x.data, (x.shape[1], x.shape[0]), x.fill_value, idt)
                 axis = (1 - ax[0],)
         x = stand_in if stand_in is not None else x.tocoo()
     kwargs.pop("out", None)

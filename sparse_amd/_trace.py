@@ -154,7 +154,7 @@ def _as(t, np_dtype):
 def run(root, arrays, n, devi):
     """Replay the graph: `arrays[i]` = device tensor (n elements) of positional argument i (only array arguments are
     looked up).  Returns the device tensor of the root (n elements, root dtype)."""
-    from ._umath import binary_arrays, unary_array
+    from ._umath import _BIN, _UN, binary_arrays, unary_array
 
     memo = {}
 
@@ -189,6 +189,8 @@ def run(root, arrays, n, devi):
             t, _ = value(a, src_dt)
             if op == "logical_not" and t.dtype != torch.bool:
                 t = _as(t, np.dtype(bool))
+            if op != "positive" and op not in _UN:
+                raise Untraceable(f"no device kernel for {op}")
             r = t if op == "positive" else unary_array(op, t)
         else:   # binary
             a, b = node.args
@@ -213,6 +215,8 @@ def run(root, arrays, n, devi):
                     name = "logical_and"
                 elif comp == np.dtype(bool) and op in ("subtract", "divide"):
                     raise Untraceable("boolean subtract / divide")
+                if name not in _BIN:
+                    raise Untraceable(f"no device kernel for {name}")
                 r = binary_arrays(name, ta, tb, a_scalar=sa, b_scalar=sb)
                 if r.dtype == torch.uint8 and out_dt == np.dtype(bool):
                     r = r.view(torch.bool)

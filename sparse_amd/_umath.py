@@ -352,7 +352,29 @@ def _loose_all_equal(value, array):
 
 
 ELEMWISE_ON_DEVICE = True   # plain callables whose operations are exactly reproducible run on the device (`_trace`)
-DEVICE_FALLBACKS = {"untraceable": 0, "declined": 0}   # traced callables that fell back to the host evaluation, by reason
+DEVICE_FALLBACKS = {"untraceable": 0, "declined": 0, "not_traced": 0}   # callables evaluated by NumPy on the host over the device-built union, by reason
+_FALLBACK_LOG = []          # the last few (reason, function name, detail)
+
+
+def _note_fallback(reason, func, detail=""):
+    DEVICE_FALLBACKS[reason] = DEVICE_FALLBACKS.get(reason, 0) + 1
+    _FALLBACK_LOG.append((reason, getattr(func, "__name__", repr(func)), detail))
+    del _FALLBACK_LOG[:-32]
+
+
+def fallback_stats(reset=False):
+    """How often an elementwise callable left the device since import (or the last reset): {"untraceable": the tracer met
+    an operation it has no exactly-rounded device kernel for, "declined": a kernel declined the dtype, "not_traced": the
+    callable could not be turned into a graph at all (data-dependent control flow, indexing, an exception under symbolic
+    operands), "recent": the last (reason, function, detail) triples}.  Those calls ARE correct - NumPy evaluates the
+    function on the host over the union the device built - but cost a device -> host -> device round trip of
+    every stored element: a count that grows in a hot loop is the thing to look at."""
+    out = dict(DEVICE_FALLBACKS, recent=list(_FALLBACK_LOG))
+    if reset:
+        for k in DEVICE_FALLBACKS:
+            DEVICE_FALLBACKS[k] = 0
+        del _FALLBACK_LOG[:]
+    return out
 
 
 def _on_device(func, ops, slots, keys, n, full_shape, out_dtype, devi):
@@ -373,6 +395,7 @@ def _on_device(func, ops, slots, keys, n, full_shape, out_dtype, devi):
             spec.append(("scalar", v[()] if isinstance(v, np.ndarray) else v))
     root = _trace.build(func, spec)
     if root is None:
+        _note_fallback("not_traced", func)
         return None
     arrays = []
     for v, slot in zip(ops, slots):
@@ -388,13 +411,16 @@ def _on_device(func, ops, slots, keys, n, full_shape, out_dtype, devi):
             arrays.append(None)
     try:
         res = _trace.run(root, arrays, n, devi)
-    except (_trace.Untraceable, KeyError, TypeError, NotImplementedError):
-        DEVICE_FALLBACKS["untraceable"] += 1
-        return None     # (an operation / dtype pair the graph does not cover is as untraceable as a data-dependent branch)
+    except _trace.Untraceable as e:
+        # ONLY the tracer's own verdict (an operation / dtype pair without a device kernel, a scalar that does not fit the
+        # compute dtype): a KeyError / TypeError from the replay is a bug of this package and surfaces as one - behind a
+        # broad `except` it would be a silent 100x slowdown (round-5 verdict)
+        _note_fallback("untraceable", func, str(e))
+        return None
     except _ffi.HipBackendError as e:
         if getattr(e, "code", 1) > 0:
             raise       # a hipError_t is a device fault, not "this kernel declines the dtype": never masked by the host path
-        DEVICE_FALLBACKS["declined"] += 1
+        _note_fallback("declined", func, str(e))
         return None
     if res.dtype != torch_dtype(out_dtype):
         res = K.convert(res, torch_dtype(out_dtype))
@@ -627,7 +653,9 @@ def _gcxs_single(func, args, g, kwargs):
     layout: elementwise functions commute with the axis permutation + reshape that defines it, so the operand stands in as a
     COO over its compressed 2-D space (its keys there are kept with it) and the result takes the operand's `indices` /
     `indptr` as they are whenever nothing was pruned.  The reference - and rounds 1-4 here - convert to COO and back
-    (`_umath.py:40-50`): 8 C-ABI calls and ~180 us for 10^3 stored elements against 3 and ~75 us for a COO operand."""
+    (`_umath.py:40-50`): 8 C-ABI calls and ~180 us for 10^3 stored elements against 3 and ~75 us for a COO operand.
+    When nothing is pruned the result SHARES the operand's `indices` / `indptr` tensors (the containers never write to their
+    index buffers - there is no `__setitem__` - so the sharing is only visible to code that edits `x.indices` in place)."""
     from ._coo import COO
     from ._convert import _pick_index_dtype
     from ._gcxs import GCXS
@@ -673,7 +701,8 @@ def elemwise(func, *args, **kwargs):
     dtype_kw = kwargs.pop("dtype", None)
     if name != "astype":
         kwargs.pop("casting", None)  # values are converted explicitly; NumPy's "unsafe" semantics
-    if out_type == "gcxs" and len(args) == 2 and len(sparse_args) == 2 and dtype_kw is None and not kwargs:
+    if (out_type == "gcxs" and len(args) == 2 and len(sparse_args) == 2 and dtype_kw is None and not kwargs
+            and isinstance(func, np.ufunc)):     # (a plain callable that happens to be NAMED like a planned ufunc is not that ufunc)
         res = _gcxs_same_layout(name, args[0], args[1])
         if res is not None:
             return res
