@@ -2,6 +2,7 @@
 """bench.py — BASELINE.json headline metric: GCXS(CSR) x dense SpMM on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling strong|weak]
+    python bench.py --workload spgemm [--gpus N] [--steps K] [--warmup W]      BASELINE configs[4] (bench_spgemm.py), same schema
 
 Workload (BASELINE.json configs[1]): A = CSR 10^6 x 10^4 at 1 % (exactly 10^8 stored elements, uniform, sorted column
 indices, int32 indices, explicit compressed_axes=(0,)), B = dense 10^4 x 128 fp32, C = A @ B dense 10^6 x 128 fp32.
@@ -302,12 +303,27 @@ def main():
     ap.add_argument("--no-nan-check", action="store_true", help="switch matmul's NaN pass off in the timed region")
     ap.add_argument("--exact", action="store_true", help="bit-exact mul+add instead of FMA")
     ap.add_argument("--no-tiled", action="store_true", help="row-group kernel only (no cached block stream)")
+    ap.add_argument("--workload", choices=["spmm", "spgemm"], default="spmm",
+                    help="spmm = the headline (BASELINE configs[1]); spgemm = configs[4], G @ G row-block sharded (bench_spgemm.py)")
+    ap.add_argument("--spgemm-n", type=int, default=1_000_000)
+    ap.add_argument("--spgemm-density", type=float, default=1e-4)
+    ap.add_argument("--spgemm-dtype", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--chunk-rows", type=int, default=125_000, help="spgemm: rows per local product (bounds the result buffers)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         if torch.cuda.device_count() < args.gpus:
             raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} HIP device(s) visible")
         raise SystemExit(relaunch_distributed(args.gpus))
+
+    if args.workload == "spgemm":
+        import bench_spgemm
+
+        if "--steps" not in sys.argv:
+            args.steps = 3          # a step is ~90 ms of products at N = 1
+        if "--warmup" not in sys.argv:
+            args.warmup = 1
+        return bench_spgemm.main(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -437,6 +453,22 @@ def main():
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         ms_static_b = float(tm.item()) / args.steps * 1e3
 
+    # ---- the same loop under the package's DEFAULT settings (NAN_WARNING = "sync": the host waits for every product's NaN
+    # verdict before it returns, as the reference's `matmul` has its warning raised inside the call) - printed beside the
+    # headline, which runs with the verdicts deferred to `flush_warnings()` (round-5 verdict, item 9)
+    ms_default = None
+    if world == 1:
+        _settings.NAN_WARNING = "sync"
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        torch.cuda.synchronize()
+        ms_default = (time.perf_counter() - t0) / args.steps * 1e3
+        _settings.NAN_WARNING = "deferred"
+
     # ---- the dominant kernel alone: K back-to-back launches of the executor between two HIP events --------------------
     if tiled:
         layout = a._tiled_layouts[torch.float32]
@@ -500,6 +532,8 @@ def main():
                 "mul_add": "separate (bit-exact)" if args.exact else "fma",
                 "nan_check_in_timed_region": bool(_settings.NAN_CHECK), "nan_check_ms_per_product": r4(nan_check_ms),
                 "nan_warning": _settings.NAN_WARNING, "prewarm_products": PREWARM,
+                "ms_per_step_default_settings": r4(ms_default), "default_settings": 'NAN_WARNING="sync" (verdict read inside every product)',
+
                 "kernel": "spmm_tiled (cached block stream)" if tiled else "spmm_csr_rowgroup",
                 "first_call_ms": r4(first_call_ms), "first_call_cold_ms": r4(first_call_cold_ms),
                 "inspector_ms": r4(inspector_ms), "rowgroup_ms": r4(rowgroup_ms),

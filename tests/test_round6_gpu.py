@@ -94,3 +94,133 @@ def test_config2_full_size_rows_against_the_oracle(orc):
     y = a @ v
     assert_within_fma_bound(y[rows].cpu().numpy(), orc.dot_csr_ndarray((len(rows), 1), sd, si, spn, bn[:, :1].copy()), sd, si, spn,
                             bn[:, :1])
+
+
+def _run_bench_under_launcher(extra):
+    """`bench.py` the way the driver launches it for N > 1 (torch.distributed.run, one rank per GPU, RCCL), at N = 1: the
+    launcher path - RANK / LOCAL_RANK / WORLD_SIZE from the environment, init_process_group("nccl"), barriers, the max over
+    ranks - had never run under the driver (round-5 verdict 3c).  Returns the parsed last stdout line."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", *extra]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines, r.stdout[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_runs_under_the_distributed_launcher():
+    line = _run_bench_under_launcher(["--steps", "2", "--warmup", "1", "--no-cpu", "--no-paths"])
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["unit"] == "GFLOP/s" and line["value"] > 0
+    assert line["config"]["world_size"] == 1 and "roofline" in line and 0 < line["roofline"]["frac"] < 1
+
+
+def test_spgemm_workload_runs_under_the_distributed_launcher():
+    """configs[4] at a tenth of its side (10^5 x 10^5 at 10^-3: the same 100 stored elements per row and 10^4 products per
+    row), in two pieces per rank"""
+    line = _run_bench_under_launcher(["--workload", "spgemm", "--spgemm-n", "100000", "--spgemm-density", "0.001", "--steps", "2",
+                                      "--warmup", "1", "--chunk-rows", "50000", "--no-cpu"])
+    assert line["metric"].startswith("GCXS x GCXS SpGEMM") and line["n_gpus"] == 1 and line["value"] > 0
+    cfg = line["config"]
+    assert cfg["pieces_rank0"] == 2 and sum(cfg["products_per_rank"]) > 9e8 and line["roofline"]["kernel_ms"] > 0
+
+
+def test_results_beyond_2_to_31_stored_elements(orc):
+    """Two adjacent row blocks of config 5 on one GPU through `a @ b`: 2.5 x 10^9 products and ~2.49 x 10^9 stored elements in
+    ONE result (`_dot_csr_csr` uses intp throughout, _common.py:669-671; no test had crossed 2^31): pointers int64 and
+    monotone, 200 sampled rows bit-equal to the oracle (columns after the canonical sort; values are the same left-to-right
+    sums), a second run identical on the sampled rows, and the first block's rows equal to the block computed alone."""
+    import sparse_amd as sp
+
+    n = 1_000_000
+    free, _ = torch.cuda.mem_get_info()
+    if free < 120 * 2 ** 30:
+        pytest.skip("needs ~100 GB of free HBM")
+    g = sp.random((n, n), density=1e-4, random_state=7, dtype=np.float32, idx_dtype=np.int32, format="gcxs", compressed_axes=(0,))
+    rows = n // 4
+    p1 = int(g.indptr[rows])
+    a = sp.GCXS((g.data[:p1].contiguous(), g.indices[:p1].contiguous(), g.indptr[:rows + 1].contiguous()), shape=(rows, n),
+                compressed_axes=(0,))
+    c = a @ g
+    assert c.nnz > 2 ** 31 and c.indptr.dtype == torch.int64 and int(c.indptr[-1]) == c.nnz
+    assert bool((c.indptr[1:] >= c.indptr[:-1]).all()) and int(c.indptr[0]) == 0
+    rng = np.random.default_rng(3)
+    pick = np.sort(np.concatenate([rng.choice(rows, 196, replace=False), [0, 1, rows - 2, rows - 1]]))
+    hA = [t.cpu().numpy() for t in (a.data, a.indices, a.indptr)]
+    hB = [t.cpu().numpy() for t in (g.data, g.indices, g.indptr)]
+    segs = [np.arange(hA[2][r], hA[2][r + 1]) for r in pick]
+    sub_ptr = np.zeros(len(pick) + 1, dtype=hA[2].dtype)
+    sub_ptr[1:] = np.cumsum([len(s) for s in segs])
+    sel = np.concatenate(segs)
+    wd, wi, wp = orc.dot_csr_csr((len(pick), n), hA[0][sel], hB[0], hA[1][sel], hB[1], sub_ptr, hB[2])
+    cp = c.indptr.cpu().numpy()
+    got = []
+    for j, r in enumerate(pick):
+        lo, hi = int(cp[r]), int(cp[r + 1])
+        gi, gd = c.indices[lo:hi].cpu().numpy(), c.data[lo:hi].cpu().numpy()
+        wl, wh = int(wp[j]), int(wp[j + 1])
+        o = np.argsort(wi[wl:wh], kind="stable")
+        keep = wd[wl:wh][o].view(np.uint32) != 0
+        assert np.array_equal(gi, wi[wl:wh][o][keep]), r
+        assert np.array_equal(gd, wd[wl:wh][o][keep]), r
+        got.append((gi, gd))
+    assert hi > 2 ** 31                      # the last sampled row lies beyond the 32-bit range of positions
+    del c
+    torch.cuda.empty_cache()
+    c2 = a @ g
+    cp2 = c2.indptr.cpu().numpy()
+    assert np.array_equal(cp, cp2)
+    for (gi, gd), r in zip(got, pick):
+        lo, hi = int(cp2[r]), int(cp2[r + 1])
+        assert np.array_equal(c2.indices[lo:hi].cpu().numpy(), gi) and np.array_equal(c2.data[lo:hi].cpu().numpy(), gd)
+
+
+def test_all_gather_csr_rebases_pointers_beyond_2_to_31():
+    """`all_gather_csr`'s pointer rebasing with a total beyond 2^31 stored elements (one rank, RCCL at world size 1 is enough
+    to run the packing / slicing / rebasing code on the device): 2.2 x 10^9 one-byte... no - int8 values are not a CSR value
+    type; float32 values and int32 columns, 17.6 GB of them."""
+    import torch.distributed as dist
+
+    from sparse_amd import _dist
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80 * 2 ** 30:
+        pytest.skip("needs ~60 GB of free HBM")
+    started = False
+    if not dist.is_initialized():
+        import os
+        import socket
+
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s.getsockname()[1]))
+        s.close()
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        started = True
+    try:
+        rows, per = 2_200_000, 1000
+        nnz = rows * per                               # 2.2e9 > 2^31
+        data = torch.empty(nnz, dtype=torch.float32, device="cuda")
+        data[::1000003] = 1.5
+        idx = torch.empty(nnz, dtype=torch.int32, device="cuda")
+        idx[-5:] = torch.arange(5, dtype=torch.int32, device="cuda")
+        ptr = torch.arange(0, nnz + 1, per, dtype=torch.int64, device="cuda")
+        d, i, ip = _dist.all_gather_csr(data, idx, ptr)
+        assert ip.dtype == torch.int64 and int(ip[-1]) == nnz and int(ip[rows // 2]) == (rows // 2) * per
+        assert bool((ip[1:] - ip[:-1] == per).all())
+        assert torch.equal(i[-5:], idx[-5:]) and float(d[2 * 1000003]) == 1.5 and d.numel() == nnz
+    finally:
+        if started:
+            dist.destroy_process_group()
