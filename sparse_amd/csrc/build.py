@@ -61,15 +61,47 @@ def _own_deps(src, obj):
     return files + [os.path.abspath(__file__)]
 
 
+# Kernels that share their register file with hand-written assembly (spmm_tiled: accumulators in a fixed VGPR block, VGPR
+# index mode around the list loop) must not have ANY register spilled by the compiler: a round-5 build whose SGPR pressure
+# made hipcc park a value in a VGPR lane (v_writelane / v_readlane around the phase loop) faulted on the GPU one product in
+# ten.  The build fails on such an object instead of shipping it (tools/check_tiled_regs.py checks the same and more).
+NO_SPILL = {"spmm_tiled.hip": "spmm_tiled_kernel"}
+
+
+def _spills(remarks, needle):
+    """[(function, sgpr spills, vgpr spills)] with a non-zero count, from -Rpass-analysis=kernel-resource-usage remarks"""
+    out, name, sg = [], None, 0
+    for ln in remarks.splitlines():
+        if "Function Name:" in ln:
+            name = ln.split("Function Name:")[1].split()[0]
+        elif "SGPRs Spill:" in ln:
+            sg = int(ln.split("SGPRs Spill:")[1].split()[0])
+        elif "VGPRs Spill:" in ln and name is not None:
+            vg = int(ln.split("VGPRs Spill:")[1].split()[0])
+            if needle in name and (sg or vg):
+                out.append((name, sg, vg))
+    return out
+
+
 def _compile(src, force):
     obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
     newest = max(os.path.getmtime(p) for p in [src] + _own_deps(src, obj))
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
         return obj, ""
-    cmd = [_hipcc(), *CXXFLAGS, "-MD", "-MF", obj[:-2] + ".d", "-c", src, "-o", obj]
+    needle = NO_SPILL.get(os.path.basename(src))
+    extra = ["-Rpass-analysis=kernel-resource-usage"] if needle else []
+    cmd = [_hipcc(), *CXXFLAGS, *extra, "-MD", "-MF", obj[:-2] + ".d", "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    if needle:
+        bad = _spills(r.stderr, needle)
+        if bad:
+            os.remove(obj)
+            raise RuntimeError(f"{os.path.basename(src)}: the compiler spilled registers in " +
+                               ", ".join(f"{n[:60]} ({s} SGPR, {v} VGPR)" for n, s, v in bad[:4]) +
+                               " - refused (see NO_SPILL in sparse_amd/csrc/build.py)")
+        return obj, "\n".join(ln for ln in r.stderr.splitlines() if "-Rpass-analysis" not in ln and "remark:" not in ln)
     return obj, r.stderr
 
 
