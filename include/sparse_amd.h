@@ -403,6 +403,14 @@ int spamd_group_reduce(int op, int val_dtype, int64_t n, const int64_t* keys, in
                        const void* data, int64_t* group_ids, void* values, int64_t* counts, int64_t* n_groups, void* ws,
                        int64_t ws_bytes, void* stream);
 
+/* n (1..16) device int64 words to the host WITHOUT a blocking copy: queued behind the stream's work, one thread stores
+ * dev_words[0 .. n-1] into host_words[0 .. n-1] and then, with release semantics, `marker` into host_words[n].
+ * host_words = n + 1 int64 of PINNED host memory mapped to the device (hipHostMalloc / torch pin_memory); the caller picks a
+ * marker host_words[n] does not hold (a per-call sequence number) and spins until it appears.  The read-backs of
+ * data-dependent sizes (`SparseArray.reduce`'s group count, _coo/core.py:693-723) use it: a `.item()` costs a stream
+ * synchronisation plus a copy command, ~20 us - as much as the kernels of a 10^6-element reduction. */
+int spamd_deliver_words(const int64_t* dev_words, int n, int64_t* host_words, int64_t marker, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * A4 / A5  sparse x sparse     replaces `_csr_csr_count_nnz` + `_dot_csr_csr` / `_dot_coo_coo`
  *                              (sparse/numba_backend/_common.py:543-570,639-717,907-976)

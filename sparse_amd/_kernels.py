@@ -85,6 +85,50 @@ def has_nan(data):
     return bool(flag.item())
 
 
+class _WordMailbox:
+    """Per device: pinned host slots the device delivers a few int64 words into (C ABI `spamd_deliver_words`), so that a
+    data-dependent size reaches the host without `tolist()`'s blocking copy (a stream synchronisation plus a copy command,
+    ~20 us).  Slots are used round-robin with a per-call sequence number as the marker: the late store of an abandoned
+    call cannot be mistaken for the current one's."""
+
+    _pool = {}
+    SLOTS, WIDTH = 64, 17
+
+    def __init__(self):
+        self.pinned = torch.zeros(self.SLOTS * self.WIDTH, dtype=torch.int64).pin_memory()
+        self.view = self.pinned.numpy()
+        self.seq = 0
+
+    @classmethod
+    def get(cls, dev):
+        m = cls._pool.get(dev.index)
+        if m is None:
+            m = cls._pool[dev.index] = cls()
+        return m
+
+
+def read_words(t):
+    """The int64 words of a small device tensor (<= 16) as Python ints, behind everything queued on the current stream."""
+    n = int(t.numel())
+    dev = t.device
+    if n > 16 or t.dtype != torch.int64 or not t.is_contiguous():
+        return [int(v) for v in t.tolist()]
+    m = _WordMailbox.get(dev)
+    m.seq += 1
+    k, marker = m.seq % m.SLOTS, m.seq
+    base = k * m.WIDTH
+    _ffi.call("spamd_deliver_words", ptr(t), n, m.pinned.data_ptr() + 8 * base, marker, stream_ptr(dev))
+    view = m.view
+    for _ in range(4_000_000):        # (~0.1 s; then a synchronisation decides)
+        if int(view[base + n]) == marker:
+            break
+    else:
+        torch.cuda.current_stream(dev).synchronize()
+        if int(view[base + n]) != marker:
+            raise _ffi.HipBackendError("spamd_deliver_words did not deliver")
+    return [int(v) for v in view[base: base + n]]
+
+
 class NanProbe:
     """A NaN scan in flight: the kernel writes its verdict into a pinned host int; `result()` waits for the event
     recorded right behind the scan — NOT for whatever was queued after it — and reads the int."""
@@ -898,7 +942,7 @@ def _spgemm_small(n_row, n_col, a_data, a_indices, a_indptr, b_data, b_indices, 
     work, out_ptr = head[: n_row + 4], head[n_row + 4: 2 * n_row + 5]
     _ffi.call("spamd_spgemm_small", vcode, code_of(it), n_row, n_col, ptr(a_indptr), ptr(a_indices), ptr(a_data), ptr(b_indptr),
               ptr(b_indices), ptr(b_data), ptr(work), ptr(out_ptr), ptr(out_idx), ptr(out_val), stream_ptr(dev))
-    failed, zeros, nnz = (int(v) for v in head[1:4].tolist())      # ONE read-back (three adjacent words)
+    failed, zeros, nnz = read_words(head[1:4])      # ONE read-back (three adjacent words, through pinned host memory)
     if failed:
         return None
     out_idx, out_val = (out_idx[:nnz].clone(), out_val[:nnz].clone()) if nnz * 4 < cells * 3 else (out_idx[:nnz], out_val[:nnz])
@@ -930,7 +974,7 @@ def _spgemm_rows(n_row, n_col, a_data, a_indices, a_indptr, b_data, b_indices, b
     _ffi.call("spamd_spgemm_row_products", code_of(it), n_row, ptr(a_indptr), ptr(a_indices), ptr(b_indptr), ptr(prod),
               ptr(maxes), s)
     prod_off = exclusive_scan(prod)
-    max_prod, max_arow = (int(v) for v in maxes.tolist())
+    max_prod, max_arow = read_words(maxes) if maxes.dtype == torch.int64 else (int(v) for v in maxes.tolist())
     cap = int(_ffi.lib().spamd_spgemm_rows_capacity(vcode, n_col, max_arow))
     total = int(prod_off[-1])
     lim = _ffi.lib().spamd_spgemm_bitmap_limits

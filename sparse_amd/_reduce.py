@@ -137,6 +137,9 @@ def _reduce_on_host(x, method, axis, keepdims, kwargs, out_gcxs):
     return out.asformat("gcxs") if out_gcxs else out
 
 
+_SCALAR_PLANS = {}      # (ufunc, value dtype, fill value, dtype keyword) -> the reduction's scalar results (see reduce_impl)
+
+
 def reduce_impl(x, method, axis=(0,), keepdims=False, _no_merge=False, **kwargs):
     from ._coo import COO
     from ._gcxs import GCXS
@@ -163,9 +166,25 @@ def reduce_impl(x, method, axis=(0,), keepdims=False, _no_merge=False, **kwargs)
     kwargs.pop("out", None)
     axis = normalize_axis(axis, x.ndim)
     fv = x.fill_value
-    zero_reduce_result = method.reduce([fv, fv], **kwargs)
     super_ufunc = _SUPER.get(name)
-    if not equivalent(zero_reduce_result, fv) and super_ufunc is None:
+    # the scalar arithmetic of a reduction (is op(fill, fill) the fill, the result's dtype, its fill value and their bit
+    # patterns) depends on (ufunc, dtypes, fill value, reduced length) only: ~20 us of NumPy scalar work per call, kept
+    plan_key = None
+    if isinstance(method, np.ufunc) and set(kwargs) <= {"dtype"}:
+        fvk = np.asarray(fv)
+        plan_key = (name, x.dtype.str, fvk.dtype.str, fvk.tobytes(), str(kwargs.get("dtype")))
+    plan = _SCALAR_PLANS.get(plan_key) if plan_key is not None else None
+    if plan is None:
+        zero_reduce_result = method.reduce([fv, fv], **kwargs)
+        dense_result = not equivalent(zero_reduce_result, fv) and super_ufunc is None
+        if plan_key is not None:
+            plan = {"dense": dense_result}
+            if len(_SCALAR_PLANS) > 512:
+                _SCALAR_PLANS.clear()
+            _SCALAR_PLANS[plan_key] = plan
+    else:
+        dense_result = plan["dense"]
+    if dense_result:
         raise ValueError(f"Performing this reduction operation would produce a dense result: {method!s}")
     dtype = kwargs.pop("dtype", None)
     if not _device_reducible(x, name, dtype, kwargs):
@@ -190,10 +209,14 @@ def reduce_impl(x, method, axis=(0,), keepdims=False, _no_merge=False, **kwargs)
         data = K.convert(data, torch.bool)
         res_np_dtype = np.dtype(bool)
     else:
-        res_np_dtype = np.dtype(dtype) if dtype is not None else (
-            method.reduce(np.zeros(1, dtype=x.dtype)).dtype if x.dtype.kind != "b" else np.dtype(bool))
-        if x.dtype.kind == "b" and name in ("add", "multiply") and dtype is None:
-            res_np_dtype = np.add.reduce(np.zeros(1, dtype=bool)).dtype
+        res_np_dtype = plan.get("res") if plan is not None else None
+        if res_np_dtype is None:
+            res_np_dtype = np.dtype(dtype) if dtype is not None else (
+                method.reduce(np.zeros(1, dtype=x.dtype)).dtype if x.dtype.kind != "b" else np.dtype(bool))
+            if x.dtype.kind == "b" and name in ("add", "multiply") and dtype is None:
+                res_np_dtype = np.add.reduce(np.zeros(1, dtype=bool)).dtype
+            if plan is not None:
+                plan["res"] = res_np_dtype
         data = K.convert(data, torch_dtype(res_np_dtype))
     if data.dtype == torch.bool:
         data = data.view(torch.uint8)
@@ -218,29 +241,35 @@ def reduce_impl(x, method, axis=(0,), keepdims=False, _no_merge=False, **kwargs)
             else:
                 keys, perm = K.sort_keys(keys, max(x.size - 1, 1))
                 data = K.gather(data, perm)
-    result_fill = np.asarray(fv).astype(res_np_dtype)[()] if name not in ("logical_or", "logical_and") else np.bool_(fv)
-    if super_ufunc is not None:
-        with np.errstate(all="ignore"):
-            final_fill = np.asarray(super_ufunc(fv, n_cols)).astype(res_np_dtype)[()]
-    else:
-        final_fill = result_fill
-    if x.nnz:
-        # ONE host read for the whole reduction: the grouped reduce leaves the number of groups on the device, the fold-in
-        # of the implicit fill entries (reference :405-422) reads it from there and counts the results that equal the
-        # result's fill value, and both numbers come back in a single copy (each `.item()` is a stream synchronisation,
-        # which at config-1 sizes costs as much as the kernels)
-        n = int(keys.numel())
-        gids, vals, counts, ng = group_reduce(keys, max(n_cols, 1), data, name, key_bound=max(int(x.size), 1), sync=False, ng=ng)
-        vcode = _ffi.U8 if vals.dtype == torch.uint8 else code_of(vals.dtype)
+    sc = plan.get(("sc", n_cols)) if plan is not None else None
+    if sc is None:
+        result_fill = np.asarray(fv).astype(res_np_dtype)[()] if name not in ("logical_or", "logical_and") else np.bool_(fv)
+        if super_ufunc is not None:
+            with np.errstate(all="ignore"):
+                final_fill = np.asarray(super_ufunc(fv, n_cols)).astype(res_np_dtype)[()]
+        else:
+            final_fill = result_fill
         fvn = np.asarray(result_fill if super_ufunc is None else fv)
         with np.errstate(all="ignore"):
             fill_f = float(fvn.astype(np.float64)) if fvn.dtype.kind != "b" else float(bool(fvn))
             fill_i = int(fvn.astype(res_np_dtype if res_np_dtype.kind in "iu" else np.int64)) if np.isfinite(fill_f) else 0
         eq_np = np.dtype("uint8") if res_np_dtype == np.dtype(bool) else res_np_dtype
         eq_bits = int(np.asarray(final_fill).astype(eq_np).reshape(1).view(f"u{eq_np.itemsize}")[0])
+        sc = (result_fill, final_fill, fill_f, fill_i, eq_bits)
+        if plan is not None:
+            plan[("sc", n_cols)] = sc
+    result_fill, final_fill, fill_f, fill_i, eq_bits = sc
+    if x.nnz:
+        # ONE host read for the whole reduction: the grouped reduce leaves the number of groups on the device, the fold-in
+        # of the implicit fill entries (reference :405-422) reads it from there and counts the results that equal the
+        # result's fill value, and both numbers come back in a single copy (each `.item()` is a stream synchronisation,
+        # which at config-1 sizes costs as much as the kernels)
+        n = int(keys.numel())
+        vcode = _ffi.U8 if data.dtype == torch.uint8 else code_of(data.dtype)
+        gids, vals, counts, ng = group_reduce(keys, max(n_cols, 1), data, name, key_bound=max(int(x.size), 1), sync=False, ng=ng)
         _ffi.call("spamd_reduce_fill_count", _RED_OPS[name], vcode, n, ptr(ng), ptr(vals), ptr(counts), int(n_cols),
                   fill_f, fill_i, eq_bits, ptr(ng) + 8, stream_ptr(dev))
-        head = [int(v) for v in ng.tolist()]
+        head = K.read_words(ng)      # (through pinned host memory: no blocking copy)
         count, n_eq = head[0], head[1]
         if len(head) > 2 and head[2]:
             # a cell range (or one output cell) held more elements than the merge kernel's arrays: the general order by sorting

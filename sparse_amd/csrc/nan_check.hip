@@ -87,3 +87,20 @@ extern "C" int spamd_has_nan_async(int val_dtype, int64_t n, const void* data, i
   }
   return launch_status();
 }
+
+// ---- a few device words to the host without a blocking copy -------------------------------------------------------------------
+// `int(t[0])` / `.tolist()` of a device tensor is a stream synchronisation plus a copy command: ~20 us, as much as the
+// kernels of a config-1-sized reduction.  Here one thread stores the words into PINNED host memory behind whatever the
+// stream holds, then - with release semantics - the call's marker behind them; the host spins on the marker.
+static __global__ void deliver_words_kernel(const long long* __restrict__ dev, int n, long long* __restrict__ host,
+                                            long long marker) {
+  for (int i = 0; i < n; ++i) __hip_atomic_store(&host[i], dev[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&host[n], marker, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+extern "C" int spamd_deliver_words(const int64_t* dev_words, int n, int64_t* host_words, int64_t marker, void* stream) {
+  if (n < 1 || n > 16 || !dev_words || !host_words) return SPAMD_EINVAL;
+  hipLaunchKernelGGL(deliver_words_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const long long*)dev_words, n,
+                     (long long*)host_words, (long long)marker);
+  return spamd::launch_status();
+}
