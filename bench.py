@@ -374,11 +374,12 @@ def main():
     if sharded_b:
         b_shard = _dist.row_shard(b_full, rank, world).contiguous()
 
-    def step(memo=False):
+    def step(memo=False, prefetch=False):
         # B is gathered at EVERY step (memo=False), although it does not change here: the conservative figure.  The gather
         # is launched asynchronously and the local block's NaN scan is queued while it is in flight (`sharded_spmm`).
+        # prefetch=True: the NEXT step's gather is launched before this step's product (still one gather per step).
         if sharded_b:
-            return _dist.sharded_spmm(a, b_shard, K, memo=memo)
+            return _dist.sharded_spmm(a, b_shard, K, memo=memo, prefetch=b_shard if prefetch else None)
         return sparse_amd.matmul(a, b_full)
 
     # ---- what a FIRST product with this A costs (rank-local; all of it outside the timed region) -----------------------
@@ -436,7 +437,7 @@ def main():
         nnz_ranks = [nnz]
     wall = float(tmax.item())
     ms_per_step = wall / args.steps * 1e3
-    ms_static_b = None
+    ms_static_b = ms_prefetch = None
     if sharded_b:
         # the same loop with the gathered B memoised on (shard buffer, version): what a program that multiplies by an
         # unchanged B pays (one all-gather in total); reported beside the headline, never instead of it
@@ -452,6 +453,21 @@ def main():
         tm = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         ms_static_b = float(tm.item()) / args.steps * 1e3
+        # ... and with B gathered at every step, but one step AHEAD (`sharded_spmm(prefetch=...)`): the collective runs on
+        # RCCL's stream beside the executor of the step before it
+        step(prefetch=True)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step(prefetch=True)
+        sparse_amd.flush_warnings()
+        torch.cuda.synchronize()
+        dist.barrier()
+        tm = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        ms_prefetch = float(tm.item()) / args.steps * 1e3
+        _dist.drop_prefetched()
 
     # ---- the same loop under the package's DEFAULT settings (NAN_WARNING = "sync": the host waits for every product's NaN
     # verdict before it returns, as the reference's `matmul` has its warning raised inside the call) - printed beside the
@@ -529,6 +545,7 @@ def main():
                 "rows_rank0": Mloc, "idx_dtype": args.idx,
                 "parallelism": f"row-block x{world}" + (" + RCCL all-gather(B) per step" if sharded_b else ""),
                 "ms_per_step_with_B_gathered_once": r4(ms_static_b),
+                "ms_per_step_with_next_gather_prefetched": r4(ms_prefetch),
                 "mul_add": "separate (bit-exact)" if args.exact else "fma",
                 "nan_check_in_timed_region": bool(_settings.NAN_CHECK), "nan_check_ms_per_product": r4(nan_check_ms),
                 "nan_warning": _settings.NAN_WARNING, "prewarm_products": PREWARM,

@@ -220,6 +220,21 @@ def _worker_calls_dist(rank, world, port, ret):
     assert np.array_equal(_dist.sharded_spmm(a_local, b_shard, K, memo=True), whole[r0:r1])
     assert gathers["n"] == 5
     _dist.invalidate_gather_memo()
+    # prefetch: step i launches step i + 1's gather before its own product is queued; the next call finds it by the shard's
+    # key and starts no gather of its own.  A changing B (a new tensor per step) and an unchanged one (the same tensor).
+    g0, m0 = gathers["n"], calls["matmul"]
+    shards = [(b_shard * float(k + 1)).clone() for k in range(4)]
+    for k in range(4):
+        nxt = shards[k + 1] if k + 1 < 4 else None
+        want_k = oracle.dot_csr_ndarray((M, N), data, idx, ptr, float(k + 1) * b)[r0:r1]
+        assert np.array_equal(_dist.sharded_spmm(a_local, shards[k], K, prefetch=nxt), want_k)
+    assert gathers["n"] - g0 == 4 and calls["matmul"] - m0 == 4 and not _dist._PREFETCHED, (gathers, calls)
+    g0 = gathers["n"]
+    for k in range(3):
+        assert np.array_equal(_dist.sharded_spmm(a_local, b_shard, K, prefetch=b_shard), whole[r0:r1])
+    assert gathers["n"] - g0 == 4 and len(_dist._PREFETCHED) == 1     # one gather ahead is still pending ...
+    _dist.drop_prefetched()                                           # ... and is completed on every rank before the loop is left
+    assert not _dist._PREFETCHED
     _dist._start_gather_rows = real_start
 
     # ---- sharded_spgemm: B's CSR triplet gathered (rebased pointers), local product by the oracle's Gustavson loop
