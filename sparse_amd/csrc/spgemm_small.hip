@@ -55,7 +55,13 @@ spgemm_small_kernel(int64_t n_row, int n_col, int words, const I* __restrict__ a
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) char sm_lds[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t r = (int64_t)blockIdx.x * WAVES + wv;
+  // Rows are numbered by a TICKET the workgroup takes when it starts (work[0], zeroed by the caller), not by blockIdx: the
+  // look-back below waits for the rows before this one, which must then be running or done - HIP does not promise that
+  // workgroups are dispatched in blockIdx order (round-5 advice; dense_nonfill_kernel and the merge kernels do the same).
+  __shared__ unsigned long long sm_ticket;
+  if (threadIdx.x == 0) sm_ticket = atomicAdd(work, 1ull);
+  __syncthreads();
+  const int64_t r = (int64_t)sm_ticket * WAVES + wv;
   if (r >= n_row) return;       // (wave-uniform; no workgroup barrier below)
   const size_t per_wave = ((size_t)n_col * sizeof(V) + (size_t)words * 4 + 15) / 16 * 16;
   V* const acc = reinterpret_cast<V*>(sm_lds + (size_t)wv * per_wave);
