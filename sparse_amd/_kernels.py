@@ -95,9 +95,17 @@ class _WordMailbox:
     SLOTS, WIDTH = 64, 17
 
     def __init__(self):
+        import threading
+
         self.pinned = torch.zeros(self.SLOTS * self.WIDTH, dtype=torch.int64).pin_memory()
         self.view = self.pinned.numpy()
         self.seq = 0
+        self.lock = threading.Lock()     # slots are handed out under it (two host threads must not share one)
+
+    def take(self):
+        with self.lock:
+            self.seq += 1
+            return self.seq % self.SLOTS, self.seq
 
     @classmethod
     def get(cls, dev):
@@ -114,8 +122,7 @@ def read_words(t):
     if n > 16 or t.dtype != torch.int64 or not t.is_contiguous():
         return [int(v) for v in t.tolist()]
     m = _WordMailbox.get(dev)
-    m.seq += 1
-    k, marker = m.seq % m.SLOTS, m.seq
+    k, marker = m.take()
     base = k * m.WIDTH
     _ffi.call("spamd_deliver_words", ptr(t), n, m.pinned.data_ptr() + 8 * base, marker, stream_ptr(dev))
     view = m.view
