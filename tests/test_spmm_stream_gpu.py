@@ -117,3 +117,27 @@ def test_run_twice_identical_and_dispatch_takes_the_stream_form(orc):
     want = orc.dot_csr_ndarray((M, N), data, idx, ptr, b)
     assert_within_fma_bound(rv, want, data, idx, ptr, b)
     assert_within_fma_bound(via, want, data, idx, ptr, b)
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 4])
+def test_strided_dense_operand_and_result(orc, N):
+    """ldb > N (B is a column slice of a wider matrix: copied into LDS value by value) and ldo > N (the result is a column
+    slice: stored value by value, the columns beside it untouched) through the C ABI"""
+    from sparse_amd import _ffi
+    from sparse_amd._device import code_of, ptr as p_, stream_ptr
+
+    M, K, ldb, ldo = 3000, 500, 7, 6
+    data, idx, ptr = random_csr(M, K, 0.03, 21, np.float32, np.int32)
+    wide = random_dense(K, ldb, 22, np.float32)
+    d = torch.device("cuda")
+    td, ti, tp, tb = (torch.from_numpy(np.ascontiguousarray(x)).to(d) for x in (data, idx, ptr, wide))
+    out = torch.full((M, ldo), -7.0, dtype=torch.float32, device=d)
+    bview = tb[:, 2:]                       # first value of the slice: element 2 of every row (8-byte aligned only)
+    _ffi.call("spamd_spmm_csr_stream", code_of(td.dtype), code_of(ti.dtype), M, K, N, p_(td), p_(ti), p_(tp),
+              bview.data_ptr(), ldb, out.data_ptr() + 4, ldo, len(data), 0, stream_ptr(d))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    b = np.ascontiguousarray(wide[:, 2:2 + N])
+    want = orc.dot_csr_ndarray((M, N), data, idx, ptr, b)
+    assert_within_fma_bound(np.ascontiguousarray(got[:, 1:1 + N]), want, data, idx, ptr, b)
+    assert (got[:, 0] == -7.0).all() and (got[:, 1 + N:] == -7.0).all()
