@@ -971,8 +971,8 @@ extern "C" int spamd_spmm_tiled_inspect_mapped(int val_dtype, int idx_dtype, int
 //                         column c whose row is >= 560 bb; also the "rows ascend inside every column" verdict.
 //   tl_csc_count_kernel   workgroup = (560-row block = the 16 row groups of one executor workgroup, four tiles): the sizes of
 //                         its (group, tile) lists, by walking its runs.
-//   tl_csc_offsets_kernel / tl_csc_scan_kernel: blocks of every list, scanned per group; elements before every group -
-//                         groups are then placed by the SAME closed form as the CSR inspector.
+//   tl_csc_offsets_kernel blocks of every list, scanned per group; elements before every group (look-back over the
+//                         workgroups, same launch) - groups are then placed by the SAME closed form as the CSR inspector.
 //   tl_csc_fill_kernel    the same workgroups walk their runs again, consecutive lanes on consecutive elements; an element's
 //                         place in its list comes from ballots over its wave + per-chunk counts in LDS.  Inside a list
 //                         the entries are in column order (CSR inspector:
@@ -984,9 +984,12 @@ constexpr int TL_BLOCK_ROWS = TL_RG * TL_WAVES;
 template <typename I>
 __global__ void __launch_bounds__(256) tl_csc_split_kernel(int64_t M, int64_t K, int64_t nblocks, const I* __restrict__ indices,
                                                            const I* __restrict__ indptr, int* __restrict__ split,
-                                                           unsigned long long* __restrict__ state) {
+                                                           unsigned long long* __restrict__ state,
+                                                           unsigned long long* __restrict__ look, int nlook) {
   const int tid = threadIdx.x;
   bool bad = false;
+  if (blockIdx.x == 0)
+    for (int i = tid; i < nlook; i += 256) look[i] = 0;       // (tl_csc_offsets_kernel's ticket and state words)
   for (int64_t c = blockIdx.x; c < K; c += gridDim.x) {
     const int64_t a = (int64_t)indptr[c], b = (int64_t)indptr[c + 1];
     if (b - a >= ((int64_t)1 << 31)) bad = true;
@@ -1026,17 +1029,9 @@ constexpr int TL_CSC_TC = SPAMD_CSC_TC;         // tiles per workgroup (count an
 // elements in (column, row) order are then positions 0 .. total - 1; tl_csc_locate maps a position to its element, so that
 // consecutive lanes read consecutive elements of a run (a thread per column instead - the first form of these kernels -
 // costs the texture addresser one cache line per LANE: 3.6 / 5.2 ms at config 2's size against 2.1 / 2.6 ms).
-template <typename I>
-__device__ __forceinline__ int tl_csc_runs(int t, int64_t K, const I* __restrict__ indptr, const int* __restrict__ sp,
-                                           int64_t pitch, long long* rstart, int* pre, int* wsum) {
+// (the prefix part: `len` = the length of thread tid's run, 0 for the threads past the tile's columns)
+__device__ __forceinline__ int tl_csc_scan_runs(int len, int* pre, int* wsum) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int64_t c = (int64_t)t * TL_KB + tid;
-  int len = 0;
-  if (tid < TL_KB && c < K) {
-    const int a0 = sp[c * pitch], a1 = sp[c * pitch + 1];   // (this block's and the next one's pointer: adjacent words)
-    len = a1 - a0;
-    rstart[tid] = (int64_t)indptr[c] + a0;
-  }
   int x = len;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -1045,13 +1040,30 @@ __device__ __forceinline__ int tl_csc_runs(int t, int64_t K, const I* __restrict
   }
   if (lane == 63) wsum[wv] = x;
   __syncthreads();
-  int off = 0;
-  for (int w = 0; w < wv; ++w) off += wsum[w];
+  int off = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    off += w < wv ? wsum[w] : 0;
+    total += wsum[w];
+  }
   if (tid < TL_KB) pre[tid] = off + x - len;
-  const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
   if (tid == 0) pre[TL_KB] = total;
   __syncthreads();
   return total;
+}
+
+template <typename I>
+__device__ __forceinline__ int tl_csc_runs(int t, int64_t K, const I* __restrict__ indptr, const int* __restrict__ sp,
+                                           int64_t pitch, long long* rstart, int* pre, int* wsum) {
+  const int tid = threadIdx.x;
+  const int64_t c = (int64_t)t * TL_KB + tid;
+  int len = 0;
+  if (tid < TL_KB && c < K) {
+    const int a0 = sp[c * pitch], a1 = sp[c * pitch + 1];   // (this block's and the next one's pointer: adjacent words)
+    len = a1 - a0;
+    rstart[tid] = (int64_t)indptr[c] + a0;
+  }
+  return tl_csc_scan_runs(len, pre, wsum);
 }
 
 __device__ __forceinline__ int64_t tl_csc_locate(int k, const long long* rstart, const int* pre) {
@@ -1109,41 +1121,109 @@ template <typename I>
 __global__ void __launch_bounds__(1024) tl_csc_hist_kernel(int64_t M, int64_t K, int ntiles, int64_t groups, int64_t nblocks,
                                                            const I* __restrict__ indices, const I* __restrict__ indptr,
                                                            int* __restrict__ cntq, int* __restrict__ split,
-                                                           unsigned long long* __restrict__ state) {
+                                                           unsigned long long* __restrict__ state,
+                                                           unsigned long long* __restrict__ look, int nlook) {
   extern __shared__ int tl_hist_lds[];
   const int tid = threadIdx.x;
   const int t = blockIdx.x, q = blockIdx.y;
-  for (int64_t i = tid; i < groups; i += 1024) tl_hist_lds[i] = 0;
-  __syncthreads();
+  if (t == 0 && q == 0)
+    for (int i = tid; i < nlook; i += 1024) look[i] = 0;       // (tl_csc_offsets_kernel's ticket and state words)
   constexpr int CPQ = TL_KB / TL_CSC_HIST_PARTS;
+  constexpr int U = 4;                         // loads in flight per thread (x 2: the row and the row in front)
+  __shared__ long long cptr[CPQ + 1];          // the pointers of my columns
   int64_t c0 = (int64_t)t * TL_KB + q * CPQ, c1 = c0 + CPQ;
   if (c0 > K) c0 = K;
   if (c1 > K) c1 = K;
-  // the split pointers of my columns in the same pass (tl_csc_split_kernel's loop, 1024 threads per column)
+  const int ncols = (int)(c1 - c0);
+  if (tid <= ncols) cptr[tid] = (int64_t)indptr[c0 + tid];
+  for (int64_t i = tid; i < groups; i += 1024) tl_hist_lds[i] = 0;
+  __syncthreads();
+  // The split pointers of my columns in the same pass (tl_csc_split_kernel's work).  Round 6: my columns' elements are ONE
+  // contiguous range of the arrays; the workgroup walks it 4096 elements at a time with every load of a step issued before
+  // the first is used (a column at a time, one load per thread and step, a wave went through ~400 memory round trips one
+  // behind the other), every thread keeps the column of its position by stepping a cursor through the pointers, and the
+  // arithmetic per element is 32-bit: positions relative to the step's first element (the loads take a uniform base and a
+  // 32-bit offset), rows as unsigned words (this kernel serves at most TL_CSC_HIST_GROUPS * TL_RG rows; a row outside
+  // [0, M) is reported by its own element, so the row in front is read as its low word only).  With 64-bit positions
+  // and three 64-bit divisions by constants per element the kernel was bound by its own instructions: 0.40 ms at config 2's
+  // size (int64 indices) for 0.8 GB read.
   bool bad = false;
-  for (int64_t c = c0; c < c1; ++c) {
-    const int64_t a = (int64_t)indptr[c], b = (int64_t)indptr[c + 1];
+  const unsigned nb1 = (unsigned)nblocks - 1u, ng1 = (unsigned)groups - 1u, Mu = (unsigned)M;
+  for (int j = 0; j < ncols; ++j) {
+    const int64_t a = cptr[j], b = cptr[j + 1];
     if (b - a >= ((int64_t)1 << 31)) bad = true;
-    if (a >= b) {
-      for (int64_t bb = tid; bb <= nblocks; bb += 1024) split[c * (nblocks + 1) + bb] = 0;
-      continue;
+    if (a >= b)
+      for (int64_t bb = tid; bb <= nblocks; bb += 1024) split[(c0 + j) * (nblocks + 1) + bb] = 0;
+  }
+  const int64_t A = cptr[0], B = cptr[ncols];
+  int cj = 0;
+  int64_t ca = A, cb = cptr[ncols > 0 ? 1 : 0];
+  int* sp = split + c0 * (nblocks + 1);
+  auto rel = [](int64_t d) { return (int)(d < -0x7fffffffll ? -0x7fffffffll : d > 0x7fffffffll ? 0x7fffffffll : d); };
+  // (the loads of a step are issued one step ahead, from clamped places past the end: a wave's memory round trip and its
+  // work on the step before overlap)
+  unsigned nlo[U], nhi[U], npl[U];
+  auto load = [&](int64_t base) {
+    const int64_t left = B - base;
+    const int last = left <= 0 ? 0 : (int)(left < 1024 * U ? left : 1024 * U) - 1;
+    const int64_t from = left <= 0 ? B - 1 : base;
+    const int shift = from > 0 ? 0 : 1;                 // (the element in front of the very first one does not exist)
+    const I* const pb = indices + from;
+    const I* const pbm = pb - 1 + shift;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int o = u * 1024 + tid, oc = o < last ? o : last;
+      if constexpr (sizeof(I) == 8) {
+        typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+        const uint2v w = *reinterpret_cast<const uint2v*>(pb + oc);
+        nlo[u] = w.x;
+        nhi[u] = w.y;
+      } else {
+        nlo[u] = (unsigned)pb[oc];
+        nhi[u] = 0;       // (a negative row is a large unsigned one)
+      }
+      npl[u] = *reinterpret_cast<const unsigned*>(pbm + ((oc > shift ? oc : shift) - shift));
     }
-#pragma unroll 2
-    for (int64_t e = a + tid; e < b; e += 1024) {
-      const int64_t r = (int64_t)indices[e];
-      const int64_t rp = e > a ? (int64_t)indices[e - 1] : -1;
-      if (rp > r || r < 0 || r >= M) bad = true;
-      int64_t g = r / TL_RG;
-      if (g < 0) g = 0;
-      if (g >= groups) g = groups - 1;       // (rows out of range are reported above; stay inside the histogram)
-      atomicAdd(&tl_hist_lds[g], 1);
-      int64_t bc = r / TL_BLOCK_ROWS, bp = e > a ? rp / TL_BLOCK_ROWS : -1;
-      if (bc < 0) bc = 0;
-      if (bc >= nblocks) bc = nblocks - 1;
-      if (bp >= nblocks) bp = nblocks - 1;
-      for (int64_t bb = bp + 1; bb <= bc; ++bb) split[c * (nblocks + 1) + bb] = (int)(e - a);
-      if (e == b - 1)
-        for (int64_t bb = bc + 1; bb <= nblocks; ++bb) split[c * (nblocks + 1) + bb] = (int)(b - a);
+  };
+  if (B > A) load(A);
+  for (int64_t base = A; base < B; base += 1024 * U) {
+    const int nrem = (int)(B - base < 1024 * U ? B - base : 1024 * U);
+    unsigned rlo[U], rhi[U], plo[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      rlo[u] = nlo[u];
+      rhi[u] = nhi[u];
+      plo[u] = npl[u];
+    }
+    load(base + 1024 * U);
+    int rel_a = rel(ca - base), rel_b = rel(cb - base);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int o = u * 1024 + tid;
+      if (o < nrem) {
+        while (o >= rel_b && cj + 1 < ncols) {       // (empty columns are stepped over)
+          ++cj;
+          ca = cb;
+          cb = cptr[cj + 1];
+          sp += nblocks + 1;
+          rel_a = rel(ca - base);
+          rel_b = rel(cb - base);
+        }
+        const bool first = o == rel_a;
+        if (rhi[u] != 0 || rlo[u] >= Mu || (!first && plo[u] > rlo[u])) bad = true;
+        unsigned g = rlo[u] / (unsigned)TL_RG;       // (rows out of range are reported above; stay inside the histogram)
+        g = g < ng1 ? g : ng1;
+        atomicAdd(&tl_hist_lds[g], 1);
+        const int bc = (int)(g / (unsigned)TL_WAVES);       // (= row / TL_BLOCK_ROWS, at most nblocks - 1)
+        int bp = -1;
+        if (!first) {
+          const unsigned gp = plo[u] / (unsigned)TL_BLOCK_ROWS;
+          bp = (int)(gp < nb1 ? gp : nb1);
+        }
+        for (int bb = bp + 1; bb <= bc; ++bb) sp[bb] = o - rel_a;
+        if (o == rel_b - 1)
+          for (int64_t bb = (int64_t)bc + 1; bb <= nblocks; ++bb) sp[bb] = rel_b - rel_a;
+      }
     }
   }
   if (bad) atomicOr(&state[0], 1ull);
@@ -1153,51 +1233,59 @@ __global__ void __launch_bounds__(1024) tl_csc_hist_kernel(int64_t M, int64_t K,
 }
 
 // per group: its lists' first blocks relative to the group's own (rel[t * groups + g], tile-major like cnt; row ntiles = the group's
-// blocks) and its element count
-template <int EPB>
-__global__ void __launch_bounds__(256) tl_csc_offsets_kernel(int64_t groups, int ntiles, const int* __restrict__ cnt, int parts,
-                                                             const unsigned long long* __restrict__ state,
-                                                             int* __restrict__ rel, long long* __restrict__ gcnt) {
-  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (g >= groups) return;
+// blocks) and e0[g] = the elements of the groups before g (e0[groups] = all of them).  The scan over the groups runs in the
+// same launch (round 6): workgroups take tickets and look back over one state word per workgroup (common.h); `look` =
+// ticket word, a spare word, then the state words - zeroed by the kernel in front (histogram or split kernel).  As a
+// launch of its own (one workgroup, every thread its own stretch of the groups: 28 dependent loads) the scan took 50 us at
+// config 2's size.
+// One WAVE per workgroup and eight tiles' counts loaded at a time: a thread per group walking its 63 x 4 counts one load
+// behind the other, 112 workgroups of 256 threads, took 47 us at config 2's size (29 MB read).
+constexpr int TL_CSC_OFF_TB = 8;
+template <int EPB, int PARTS>
+__global__ void __launch_bounds__(64) tl_csc_offsets_kernel(int64_t groups, int ntiles, const int* __restrict__ cnt,
+                                                            const unsigned long long* __restrict__ state,
+                                                            int* __restrict__ rel, unsigned long long* __restrict__ look,
+                                                            long long* __restrict__ e0) {
+  constexpr int TB = TL_CSC_OFF_TB;
+  const int lane = threadIdx.x;
+  long long ticket = 0;
+  if (lane == 0) ticket = (long long)atomicAdd(look, 1ull);
+  const int64_t blk = __shfl(ticket, 0, 64);
+  const int64_t g = blk * 64 + lane;
+  const int64_t gc = g < groups ? g : groups - 1;
   const bool bad = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-  int run = 0;
   long long tot = 0;
-  for (int t = 0; t < ntiles; ++t) {
-    int c = 0;
-    if (!bad)
-      for (int q = 0; q < parts; ++q) c += cnt[((int64_t)q * ntiles + t) * groups + g];
-    rel[(int64_t)t * groups + g] = run;
-    run += (c + EPB - 1) / EPB;
-    tot += c;
+  int run = 0;
+  for (int t0 = 0; t0 < ntiles; t0 += TB) {
+    int c[TB];
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+      const int t = t0 + j < ntiles ? t0 + j : ntiles - 1;
+      c[j] = 0;
+#pragma unroll
+      for (int q = 0; q < PARTS; ++q) c[j] += cnt[((int64_t)q * ntiles + t) * groups + gc];
+    }
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+      if (t0 + j < ntiles && g < groups) {
+        const int cc = bad ? 0 : c[j];
+        rel[(int64_t)(t0 + j) * groups + g] = run;
+        run += (cc + EPB - 1) / EPB;
+        tot += cc;
+      }
+    }
   }
-  rel[(int64_t)ntiles * groups + g] = run;
-  gcnt[g] = tot;
-}
-
-// e0[g] = elements of the groups before g (one workgroup: a few ten thousand groups)
-__global__ void __launch_bounds__(1024) tl_csc_scan_kernel(int64_t groups, const long long* __restrict__ gcnt,
-                                                           long long* __restrict__ e0) {
-  __shared__ long long part[1024];
-  const int tid = threadIdx.x;
-  const int64_t per = (groups + 1023) / 1024;
-  const int64_t lo = tid * per, hi = lo + per < groups ? lo + per : groups;
-  long long sum = 0;
-  for (int64_t g = lo; g < hi; ++g) sum += gcnt[g];
-  part[tid] = sum;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    const long long u = tid >= d ? part[tid - d] : 0;
-    __syncthreads();
-    part[tid] += u;
-    __syncthreads();
+  if (g < groups) rel[(int64_t)ntiles * groups + g] = run;
+  long long incl = tot;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const long long u = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += u;
   }
-  long long run = part[tid] - sum;
-  for (int64_t g = lo; g < hi; ++g) {
-    e0[g] = run;
-    run += gcnt[g];
-  }
-  if (tid == 1023) e0[groups] = part[1023];
+  const long long total = __shfl(incl, 63, 64);
+  const long long base = (long long)lookback_exclusive(look + 2, blk, (unsigned long long)total, lane);
+  if (g < groups) e0[g] = base + incl - tot;
+  if (g == groups - 1) e0[groups] = base + incl;
 }
 
 template <typename I, typename T>
@@ -1219,6 +1307,8 @@ __global__ void __launch_bounds__(256) tl_csc_fill_kernel(int64_t K, int ntiles,
   __shared__ int ccnt[CHUNKS * GPB];          // elements of a chunk per group, then their exclusive prefix over the window
   __shared__ __attribute__((aligned(16))) int img[TL_CSC_IMG_BLOCKS * TL_BLOCK_INTS];   // the tile's lists as they go to the stream
   __shared__ int ib[GPB], tsum_s;
+  __shared__ int gbase[GPB];                  // first block of the tile's list of every group (what blk_off holds)
+  __shared__ int bdst[TL_CSC_IMG_BLOCKS];     // where every block of the LDS image goes (written by the block's entries)
   __shared__ unsigned char colof[TL_CSC_STAGE];   // column (inside the tile) of every position of the current window
   static_assert(TL_KB <= 256, "a tile's columns fit a byte");
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1259,14 +1349,52 @@ __global__ void __launch_bounds__(256) tl_csc_fill_kernel(int64_t K, int ntiles,
     }
   }
   const unsigned long long below = (1ull << lane) - 1;
+  // A tile's runs (split pointers, column pointer) and its lists' offsets are loaded one tile ahead, by every thread from
+  // clamped places: three memory round trips one behind the other per tile otherwise (offsets, runs, elements - round 6).
+  // The loads are issued behind the element loads of the tile before and taken over (`take`: real moves, so that the wait
+  // for them stands there) in front of that tile's stores to the stream: at the head of the loop the wait would cover the
+  // stores as well.
+  int nx_a0, nx_a1, nx_rel, cur_a0, cur_a1, cur_rel;
+  long long nx_ip, cur_ip;
+  auto fetch = [&](int t) {
+    int64_t c = (int64_t)t * TL_KB + tid;
+    if (tid >= TL_KB || c >= K) c = (int64_t)t * TL_KB;
+    const int* const q = split + b + c * (nblocks + 1);   // (this block's and the next one's pointer: adjacent words)
+    nx_a0 = q[0];
+    nx_a1 = q[1];
+    nx_ip = (long long)indptr[c];
+    nx_rel = rel[(int64_t)t * groups + b * GPB + (tid & (GPB - 1))];
+  };
+  auto take = [&]() {
+    asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b64 %3, %7"
+                 : "=&v"(cur_a0), "=&v"(cur_a1), "=&v"(cur_rel), "=&v"(cur_ip)
+                 : "v"(nx_a0), "v"(nx_a1), "v"(nx_rel), "v"(nx_ip));
+  };
+  fetch(t_beg);
+  take();
   for (int t = t_beg; t < t_end; ++t) {
+    const int a0 = cur_a0, a1 = cur_a1, rl = cur_rel;
+    const long long ip = cur_ip;
+    const int t_next = t + 1 < t_end ? t + 1 : t;
     if (tid < GPB) {
       tbase[tid] = 0;
-      lo16[tid] = rel[(int64_t)t * groups + b * GPB + tid];
+      lo16[tid] = rl;
     }
-    const int total = tl_csc_runs<I>(t, K, indptr, split + b, nblocks + 1, rstart, pre, wsum);
+    int len = 0;
+    if (tid < TL_KB && (int64_t)t * TL_KB + tid < K) {
+      len = a1 - a0;
+      rstart[tid] = ip + a0;
+    }
+    const int total = tl_csc_scan_runs(len, pre, wsum);
+    if (total <= 0) {       // (no window below)
+      fetch(t_next);
+      take();
+    }
     bool padded = false;
-    if (tid < GPB) blk_off[(b * GPB + tid) * (ntiles + 1) + t] = (int)(goff_s[tid] + lo16[tid]);
+    if (tid < GPB) {
+      gbase[tid] = (int)(goff_s[tid] + lo16[tid]);
+      blk_off[(b * GPB + tid) * (ntiles + 1) + t] = gbase[tid];
+    }
     // The tile's elements in (column, row) order, a window at a time: consecutive lanes take consecutive elements (of a
     // run), an element's place inside its list = the elements of its group in front of it: its rank among the equal-group
     // lanes of its wave (ballots) + the group's count in the chunks before (LDS).  Lanes of one group write consecutive
@@ -1284,33 +1412,51 @@ __global__ void __launch_bounds__(256) tl_csc_fill_kernel(int64_t K, int ntiles,
         for (int k = a; k < b; ++k) colof[k - w0] = (unsigned char)tid;
       }
       __syncthreads();
+      // every load of the window first, from clamped positions (a load under `if (valid)` is waited for on the spot: four
+      // memory round trips one behind the other per window - round 6), then the ranks
 #pragma unroll
       for (int p = 0; p < PER; ++p) {
         const int k = w0 + tid + 256 * p;
-        const bool valid = k < w1;
-        rr[p] = 0;
-        vv[p] = T(0);
-        col[p] = 0;
-        if (valid) {
-          const int lo = colof[k - w0];       // the column whose run holds position k
-          const int64_t e = rstart[lo] + (k - pre[lo]);
-          col[p] = lo;
-          rr[p] = (int)((int64_t)indices[e] - r_base);
+        const int kc = k < w1 ? k : w1 - 1;
+        const int lo = colof[kc - w0];       // the column whose run holds position k
+        const int64_t e = rstart[lo] + (kc - pre[lo]);
+        col[p] = lo;
+        // (the low word of the row: its distance from the block's first row fits an int)
+        rr[p] = (int)(*reinterpret_cast<const unsigned*>(indices + e) - (unsigned)r_base);
 #if SPAMD_CSC_ABL == 3
-          vv[p] = T(1);
+        vv[p] = T(1);
 #else
-          vv[p] = vals[e];
+        vv[p] = vals[e];
 #endif
-        }
-        const int gi = rr[p] / TL_RG;
-        unsigned long long m = __ballot(valid);
+      }
+      {       // (once more per further window of a long tile: harmless.  The tile number goes through an empty asm so that
+              // the loads stay HERE, behind the element loads: hoisted to the head of the window they are waited for first)
+        int tn = t_next;
+        asm volatile("" : "+s"(tn));
+        fetch(tn);
+      }
 #pragma unroll
-        for (int bit = 0; bit < 4; ++bit) {
-          const unsigned long long bb = __ballot(valid && ((gi >> bit) & 1));
-          m &= ((gi >> bit) & 1) ? bb : ~bb;
+      for (int p = 0; p < PER; ++p) {
+        const int k = w0 + tid + 256 * p;
+        rank[p] = 0;
+        if (k < w1) {       // (the ballots see the valid lanes only)
+          const int gi = rr[p] / TL_RG;
+          // the lanes of my group: per bit of the group number, the lanes that agree with me (bit set: the ballot, clear: its
+          // complement) - the bit as 0 / all ones (v_bfe_i32, opaque to the compiler: its own choice was two compares and a
+          // select per bit), one XNOR + AND per half of the mask
+          const unsigned long long act = __ballot(1);
+          unsigned mlo = (unsigned)act, mhi = (unsigned)(act >> 32);
+#pragma unroll
+          for (int bit = 0; bit < 4; ++bit) {
+            int x;
+            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(x) : "v"(gi), "n"(bit));
+            const unsigned long long bb = __ballot(x != 0);
+            mlo &= ~((unsigned)bb ^ (unsigned)x);
+            mhi &= ~((unsigned)(bb >> 32) ^ (unsigned)x);
+          }
+          rank[p] = __popc(mlo & (unsigned)below) + __popc(mhi & (unsigned)(below >> 32));
+          if (rank[p] == 0) ccnt[(wv + 4 * p) * GPB + gi] = __popc(mlo) + __popc(mhi);
         }
-        rank[p] = __popcll(m & below);
-        if (valid && rank[p] == 0) ccnt[(wv + 4 * p) * GPB + gi] = __popcll(m);
       }
       __syncthreads();
       {  // exclusive prefix over the window's chunks, per group (thread = (chunk, group)); the tile's running totals
@@ -1354,34 +1500,39 @@ __global__ void __launch_bounds__(256) tl_csc_fill_kernel(int64_t K, int ntiles,
           const int gi = rr[p] / TL_RG, lr = rr[p] - gi * TL_RG;
           const int pos = ccnt[(wv + 4 * p) * GPB + gi] + rank[p];
           if (img_path) {
-            const int e = ib[gi] * EPB + pos;
+            const int q = pos / EPB, slot = pos - q * EPB;       // block of the list, entry of the block
+            const int base = (ib[gi] + q) * TL_BLOCK_INTS;
             const int d0 = tl_d0(col[p], lr);
+            // the block's place in the stream, by every entry of the block (a block of the image has at least one): the
+            // copy below then reads one word instead of searching the lists' starts - 15 compares per 16 bytes copied (round 6)
+            bdst[ib[gi] + q] = gbase[gi] + q;
             if constexpr (sizeof(T) == 4) {
-              img[(e / EPB) * TL_BLOCK_INTS + (e % EPB) * 2] = d0;
-              img[(e / EPB) * TL_BLOCK_INTS + (e % EPB) * 2 + 1] = __builtin_bit_cast(int, vv[p]);
+              typedef int int2v __attribute__((ext_vector_type(2)));
+              int2v ent;
+              ent.x = d0;
+              ent.y = __builtin_bit_cast(int, vv[p]);
+              *reinterpret_cast<int2v*>(&img[base + slot * 2]) = ent;
             } else {
-              const long long bits = __builtin_bit_cast(long long, vv[p]);
-              const int base = (e / EPB) * TL_BLOCK_INTS, slot = e % EPB;
               img[base + slot] = d0;
-              img[base + 6 + 2 * slot] = (int)(bits & 0xffffffffll);
-              img[base + 7 + 2 * slot] = (int)(bits >> 32);
+              *reinterpret_cast<long long*>(&img[base + 6 + 2 * slot]) = __builtin_bit_cast(long long, vv[p]);
             }
           } else {
-            const int64_t dst = (goff_s[gi] + lo16[gi]) * EPB + pos;
+            const int64_t dst = (int64_t)gbase[gi] * EPB + pos;
             TlFmt<T>::put(stream, dst, tl_d0(col[p], lr), vv[p]);
           }
         }
       }
       __syncthreads();
+      // every element load counts as used on every path from here (a window without valid lanes in some wave skips the
+      // uses above, and the loads would reach the next window's first register write "still in flight": a full wait there)
+#pragma unroll
+      for (int p = 0; p < PER; ++p) asm volatile("" ::"v"(vv[p]), "v"(rr[p]));
+      take();
       if (img_path) {
         typedef int int4v __attribute__((ext_vector_type(4)));
         const int nvec = tsum_s * (TL_BLOCK_INTS / 4);
         for (int i = tid; i < nvec; i += 256) {
-          const int blk = i >> 2;
-          int gi = 0;
-#pragma unroll
-          for (int q = 1; q < GPB; ++q) gi += ib[q] <= blk ? 1 : 0;   // the list of this block (empty lists share a start: skipped)
-          const int64_t dst = (goff_s[gi] + lo16[gi] + (blk - ib[gi])) * TL_BLOCK_INTS + (i & 3) * 4;
+          const int64_t dst = (int64_t)bdst[i >> 2] * TL_BLOCK_INTS + (i & 3) * 4;
           *reinterpret_cast<int4v*>(stream + dst) = *reinterpret_cast<const int4v*>(&img[i * 4]);
         }
         __syncthreads();
@@ -1406,18 +1557,21 @@ static int tl_launch_inspect_csc(int64_t M, int64_t K, int64_t ntiles, const T* 
   const int64_t nblocks = groups / TL_WAVES;
   if (nblocks >= ((int64_t)1 << 31)) return SPAMD_EINVAL;
   // workspace: split[K * (nblocks + 1)] (column-major: a column's pointers are written next to each other - block-major, every
-  // 4-byte pointer dirtied a cache line of its own: 0.8 GB written back for 0.07 GB of pointers), cnt[groups * ntiles], rel[groups * (ntiles + 1)], gcnt[groups], e0[groups + 1] (8-byte)
+  // 4-byte pointer dirtied a cache line of its own: 0.8 GB written back for 0.07 GB of pointers), cnt[groups * ntiles], rel[groups * (ntiles + 1)], look[groups] (ticket + state words of the offsets kernel), e0[groups + 1] (8-byte)
   const bool hist = groups <= TL_CSC_HIST_GROUPS;
-  const int parts = hist ? TL_CSC_HIST_PARTS : 1;
   int* const split = ws;
   int* const cnt = split + (nblocks + 1) * K;
   int* const rel = cnt + TL_CSC_HIST_PARTS * groups * ntiles;
   const int64_t words = ((nblocks + 1) * K + TL_CSC_HIST_PARTS * groups * ntiles + groups * (ntiles + 1) + 1) & ~(int64_t)1;   // (8-byte alignment)
-  long long* const gcnt = reinterpret_cast<long long*>(ws + words);
-  long long* const e0 = gcnt + groups;
+  // (`groups` 8-byte words - the per-group counts of the first form - hold the look-back words of the offsets kernel)
+  unsigned long long* const look = reinterpret_cast<unsigned long long*>(ws + words);
+  long long* const e0 = reinterpret_cast<long long*>(look) + groups;
+  const int64_t owgs = ceil_div(groups, (int64_t)64);
+  const int nlook = (int)(owgs + 2);
+  static_assert(TL_WAVES >= 3, "groups (a multiple of TL_WAVES) >= ceil(groups / 64) + 2");
   if (!hist) {
     const unsigned sgrid = (unsigned)std::min<int64_t>(K, (int64_t)256 * 64);
-    hipLaunchKernelGGL((tl_csc_split_kernel<I>), dim3(sgrid), dim3(256), 0, s, M, K, nblocks, a_indices, a_indptr, split, state);
+    hipLaunchKernelGGL((tl_csc_split_kernel<I>), dim3(sgrid), dim3(256), 0, s, M, K, nblocks, a_indices, a_indptr, split, state, look, nlook);
   }
   const dim3 grid((unsigned)nblocks, (unsigned)ceil_div(ntiles, (int64_t)TL_CSC_TC));
   if (hist) {
@@ -1428,14 +1582,17 @@ static int tl_launch_inspect_csc(int64_t M, int64_t K, int64_t ntiles, const T* 
       if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(hk, dim3((unsigned)ntiles, TL_CSC_HIST_PARTS), dim3(1024), lds, s, M, K, (int)ntiles, groups, nblocks,
-                       a_indices, a_indptr, cnt, split, state);
+                       a_indices, a_indptr, cnt, split, state, look, nlook);
   } else {
     hipLaunchKernelGGL((tl_csc_count_kernel<I>), grid, dim3(256), 0, s, K, (int)ntiles, nblocks, groups, a_indices, a_indptr, (const int*)split,
                        (const unsigned long long*)state, cnt);
   }
-  hipLaunchKernelGGL((tl_csc_offsets_kernel<TlFmt<T>::EPB>), dim3((unsigned)ceil_div(groups, (int64_t)256)), dim3(256), 0, s,
-                     groups, (int)ntiles, (const int*)cnt, parts, (const unsigned long long*)state, rel, gcnt);
-  hipLaunchKernelGGL(tl_csc_scan_kernel, dim3(1), dim3(1024), 0, s, groups, (const long long*)gcnt, e0);
+  if (hist)
+    hipLaunchKernelGGL((tl_csc_offsets_kernel<TlFmt<T>::EPB, TL_CSC_HIST_PARTS>), dim3((unsigned)owgs), dim3(64), 0, s,
+                       groups, (int)ntiles, (const int*)cnt, (const unsigned long long*)state, rel, look, e0);
+  else
+    hipLaunchKernelGGL((tl_csc_offsets_kernel<TlFmt<T>::EPB, 1>), dim3((unsigned)owgs), dim3(64), 0, s,
+                       groups, (int)ntiles, (const int*)cnt, (const unsigned long long*)state, rel, look, e0);
   const int64_t fgrid = 8 * ceil_div(nblocks, (int64_t)8) * ceil_div(ntiles, (int64_t)TL_CSC_TC);
   if (fgrid >= ((int64_t)1 << 31)) return SPAMD_EINVAL;
   hipLaunchKernelGGL((tl_csc_fill_kernel<I, T>), dim3((unsigned)fgrid), dim3(256), 0, s, K, (int)ntiles, a_data, a_indices,
