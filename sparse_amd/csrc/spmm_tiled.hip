@@ -328,6 +328,11 @@ __global__ void __launch_bounds__(256) tl_inspect_kernel(int64_t M, int ntiles, 
     atomicOr(&state[0], 1ull);
     group_bad = 1;
   }
+  // (Round 6: the fill phase's stores each stand behind a full `s_waitcnt vmcnt(0)` - the preloaded values are first used under
+  // `if (e < rb)`, and a wait inside such a block does not hold for the path around it.  Marking every preloaded register as
+  // used here, on every path, removes those waits and the kernel is SLOWER: 0.59 -> 0.71 ms (float32 / int32), 1.18 -> 1.30
+  // (float64 / int64) at config 2's size, twice in one session.  A wave's 8-byte stores to 18 different lists, paced by
+  // their own completion, evidently suit the memory system better than all of them at once.  Left as it was.)
   __syncthreads();
   // per tile: elements of the tile in earlier rows of the group; blocks of the list
   int nb = 0, cnt_t = 0;
@@ -1015,7 +1020,8 @@ __global__ void __launch_bounds__(256) tl_csc_split_kernel(int64_t M, int64_t K,
 }
 
 #ifndef SPAMD_CSC_ABL
-#define SPAMD_CSC_ABL 0   // timing ablations of tl_csc_fill_kernel (wrong streams): 1 no entry stores, 3 no value loads
+#define SPAMD_CSC_ABL 0   // timing ablations of tl_csc_fill_kernel (wrong streams): 1 no stores to the stream, 2 no ranks, 3 no value
+                          // loads, 4 no element loads at all, 5 no image (neither written nor copied out), 6 the runs of every tile only
 #endif
 constexpr int TL_CSC_IMG_BLOCKS = 256;   // 64-byte blocks of a tile's 16 lists assembled in LDS (~190 for float64 at 1 %)
 constexpr int TL_CSC_STAGE = 1024;   // elements of a (row block, tile) staged in LDS at a time (a tile's runs hold ~900 at 1 %)
@@ -1032,12 +1038,7 @@ constexpr int TL_CSC_TC = SPAMD_CSC_TC;         // tiles per workgroup (count an
 // (the prefix part: `len` = the length of thread tid's run, 0 for the threads past the tile's columns)
 __device__ __forceinline__ int tl_csc_scan_runs(int len, int* pre, int* wsum) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  int x = len;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int u = __shfl_up(x, d, 64);
-    if (lane >= d) x += u;
-  }
+  const int x = (int)wave_incl_scan_u32((unsigned)len);       // (DPP: no LDS round trips)
   if (lane == 63) wsum[wv] = x;
   __syncthreads();
   int off = 0, total = 0;
@@ -1386,6 +1387,11 @@ __global__ void __launch_bounds__(256) tl_csc_fill_kernel(int64_t K, int ntiles,
       rstart[tid] = ip + a0;
     }
     const int total = tl_csc_scan_runs(len, pre, wsum);
+#if SPAMD_CSC_ABL == 6
+    fetch(t_next);
+    take();
+    continue;
+#endif
     if (total <= 0) {       // (no window below)
       fetch(t_next);
       take();
@@ -1401,7 +1407,7 @@ __global__ void __launch_bounds__(256) tl_csc_fill_kernel(int64_t K, int ntiles,
     // entries: a store instruction touches ~16 runs of lines instead of 64 lines.
     for (int w0 = 0; w0 < total; w0 += TL_CSC_STAGE) {
       const int w1 = w0 + TL_CSC_STAGE < total ? w0 + TL_CSC_STAGE : total;
-      int rr[PER], rank[PER], col[PER];
+      int rr[PER], rank[PER], col[PER], grp[PER];
       T vv[PER];
       for (int i = tid; i < CHUNKS * GPB; i += 256) ccnt[i] = 0;
       // position -> column of the window, written by the columns themselves (a run holds ~6 positions): an element then finds
@@ -1422,8 +1428,12 @@ __global__ void __launch_bounds__(256) tl_csc_fill_kernel(int64_t K, int ntiles,
         const int64_t e = rstart[lo] + (kc - pre[lo]);
         col[p] = lo;
         // (the low word of the row: its distance from the block's first row fits an int)
+#if SPAMD_CSC_ABL == 4
+        rr[p] = (int)((unsigned)(e * 7 + p) % (unsigned)TL_BLOCK_ROWS);
+#else
         rr[p] = (int)(*reinterpret_cast<const unsigned*>(indices + e) - (unsigned)r_base);
-#if SPAMD_CSC_ABL == 3
+#endif
+#if SPAMD_CSC_ABL == 3 || SPAMD_CSC_ABL == 4
         vv[p] = T(1);
 #else
         vv[p] = vals[e];
@@ -1439,13 +1449,19 @@ __global__ void __launch_bounds__(256) tl_csc_fill_kernel(int64_t K, int ntiles,
       for (int p = 0; p < PER; ++p) {
         const int k = w0 + tid + 256 * p;
         rank[p] = 0;
+        grp[p] = 0;
         if (k < w1) {       // (the ballots see the valid lanes only)
           const int gi = rr[p] / TL_RG;
+          grp[p] = gi;
           // the lanes of my group: per bit of the group number, the lanes that agree with me (bit set: the ballot, clear: its
           // complement) - the bit as 0 / all ones (v_bfe_i32, opaque to the compiler: its own choice was two compares and a
           // select per bit), one XNOR + AND per half of the mask
           const unsigned long long act = __ballot(1);
           unsigned mlo = (unsigned)act, mhi = (unsigned)(act >> 32);
+#if SPAMD_CSC_ABL == 2
+          mlo = lane < 32 ? 1u << lane : 0u;
+          mhi = lane < 32 ? 0u : 1u << (lane - 32);
+#else
 #pragma unroll
           for (int bit = 0; bit < 4; ++bit) {
             int x;
@@ -1454,6 +1470,7 @@ __global__ void __launch_bounds__(256) tl_csc_fill_kernel(int64_t K, int ntiles,
             mlo &= ~((unsigned)bb ^ (unsigned)x);
             mhi &= ~((unsigned)(bb >> 32) ^ (unsigned)x);
           }
+#endif
           rank[p] = __popc(mlo & (unsigned)below) + __popc(mhi & (unsigned)(below >> 32));
           if (rank[p] == 0) ccnt[(wv + 4 * p) * GPB + gi] = __popc(mlo) + __popc(mhi);
         }
@@ -1474,13 +1491,13 @@ __global__ void __launch_bounds__(256) tl_csc_fill_kernel(int64_t K, int ntiles,
           tbase[gi] += all;
           // blocks of the tile's lists and their starts inside the LDS image (meaningful when the tile is one window)
           const int nb = (tbase[gi] + EPB - 1) / EPB;
-          int x = nb;
-#pragma unroll
-          for (int d = 1; d < GPB; d <<= 1) {
-            const int u = __shfl_up(x, d, GPB);
-            if (gi >= d) x += u;
-          }
-          ib[gi] = x - nb;
+          static_assert(GPB == 16, "a DPP row");
+          unsigned x = (unsigned)nb;       // (inclusive scan over the 16 lanes of a DPP row)
+          x += dpp_shift0<0x111, 0xf>(x);
+          x += dpp_shift0<0x112, 0xf>(x);
+          x += dpp_shift0<0x114, 0xf>(x);
+          x += dpp_shift0<0x118, 0xf>(x);
+          ib[gi] = (int)x - nb;
           if (gi == GPB - 1) tsum_s = x;
         }
       }
@@ -1493,11 +1510,14 @@ __global__ void __launch_bounds__(256) tl_csc_fill_kernel(int64_t K, int ntiles,
         for (int i = tid; i < tsum_s * TL_BLOCK_INTS; i += 256) img[i] = 0;
         __syncthreads();
       }
+#if SPAMD_CSC_ABL == 5
+      if (false)
+#endif
 #pragma unroll
       for (int p = 0; p < PER; ++p) {
         const int k = w0 + tid + 256 * p;
         if (k < w1) {
-          const int gi = rr[p] / TL_RG, lr = rr[p] - gi * TL_RG;
+          const int gi = grp[p], lr = rr[p] - gi * TL_RG;
           const int pos = ccnt[(wv + 4 * p) * GPB + gi] + rank[p];
           if (img_path) {
             const int q = pos / EPB, slot = pos - q * EPB;       // block of the list, entry of the block
@@ -1528,11 +1548,14 @@ __global__ void __launch_bounds__(256) tl_csc_fill_kernel(int64_t K, int ntiles,
 #pragma unroll
       for (int p = 0; p < PER; ++p) asm volatile("" ::"v"(vv[p]), "v"(rr[p]));
       take();
-      if (img_path) {
+      if (img_path && SPAMD_CSC_ABL != 5) {
         typedef int int4v __attribute__((ext_vector_type(4)));
         const int nvec = tsum_s * (TL_BLOCK_INTS / 4);
         for (int i = tid; i < nvec; i += 256) {
           const int64_t dst = (int64_t)bdst[i >> 2] * TL_BLOCK_INTS + (i & 3) * 4;
+#if SPAMD_CSC_ABL == 1
+          if (bdst[i >> 2] == 0x7fffffff)
+#endif
           *reinterpret_cast<int4v*>(stream + dst) = *reinterpret_cast<const int4v*>(&img[i * 4]);
         }
         __syncthreads();
