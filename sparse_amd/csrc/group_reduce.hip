@@ -323,12 +323,10 @@ gr_fix_fast_kernel(int op, int64_t ntiles, const int64_t* __restrict__ tile_head
 
 // One workgroup: the same by a segmented scan over all tiles, for arbitrarily long runs.
 template <typename T>
-__global__ void __launch_bounds__(1024)
-gr_fixup_kernel(int op, int64_t ntiles, const int64_t* __restrict__ tile_heads, const int64_t* __restrict__ tile_first,
-                const Part<T>* __restrict__ open_head, const Part<T>* __restrict__ open_tail, T* __restrict__ vals,
-                int64_t* __restrict__ counts, int64_t* __restrict__ n_groups, const int* __restrict__ need_chain) {
-  __shared__ Span<T> lds_wave[1024 / 64];
-  if (*need_chain == 0) return;
+__device__ __forceinline__ void gr_fixup_body(int op, int64_t ntiles, const int64_t* __restrict__ tile_heads,
+                                              const int64_t* __restrict__ tile_first, const Part<T>* __restrict__ open_head,
+                                              const Part<T>* __restrict__ open_tail, T* __restrict__ vals,
+                                              int64_t* __restrict__ counts, int64_t* __restrict__ n_groups, Span<T>* lds_wave) {
   const int64_t per = (ntiles + 1023) / 1024;
   const int64_t b0 = (int64_t)threadIdx.x * per, b1 = b0 + per < ntiles ? b0 + per : ntiles;
   Span<T> mine;
@@ -363,6 +361,68 @@ gr_fixup_kernel(int op, int64_t ntiles, const int64_t* __restrict__ tile_heads, 
       *n_groups = total;
     }
   }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(1024)
+gr_fixup_kernel(int op, int64_t ntiles, const int64_t* __restrict__ tile_heads, const int64_t* __restrict__ tile_first,
+                const Part<T>* __restrict__ open_head, const Part<T>* __restrict__ open_tail, T* __restrict__ vals,
+                int64_t* __restrict__ counts, int64_t* __restrict__ n_groups, const int* __restrict__ need_chain) {
+  __shared__ Span<T> lds_wave[1024 / 64];
+  if (*need_chain == 0) return;
+  gr_fixup_body<T>(op, ntiles, tile_heads, tile_first, open_head, open_tail, vals, counts, n_groups, lds_wave);
+}
+
+// Both of the above in ONE launch of one workgroup, for up to GR_FIX_ONE_TILES tiles (round 6: at launch-bound sizes the two
+// launches cost 5 + 4 us for a few hundred tiles; the chained form's launch did nothing but read `need_chain`).  The fast
+// part asks for everything a tile usually needs - its own and its left neighbour's head counts, the neighbour's open tail,
+// its own open head and first run - before looking at any of it (one memory round trip instead of five one behind the
+// other), and walks further back only when the neighbour has no head.  Same joins in the same order as the two kernels.
+constexpr int64_t GR_FIX_ONE_TILES = 16384;
+
+template <typename T>
+__global__ void __launch_bounds__(1024)
+gr_fix_one_kernel(int op, int64_t ntiles, const int64_t* __restrict__ tile_heads, const int64_t* __restrict__ tile_first,
+                  const Part<T>* __restrict__ open_head, const Part<T>* __restrict__ open_tail, T* __restrict__ vals,
+                  int64_t* __restrict__ counts, int64_t* __restrict__ n_groups) {
+  __shared__ Span<T> lds_wave[1024 / 64];
+  __shared__ int chain;
+  if (threadIdx.x == 0) chain = 0;
+  __syncthreads();
+  for (int64_t b = (int64_t)threadIdx.x + 1; b <= ntiles; b += 1024) {
+    const int64_t bc = b < ntiles ? b : ntiles - 1;       // (clamped: every load below is unconditional)
+    const int64_t hb = tile_heads[bc], hp = tile_heads[b - 1], tf = tile_first[b];
+    const Part<T> tp = open_tail[b - 1], oh = open_head[bc];
+    if (b == ntiles) *n_groups = tf;
+    if (b < ntiles && hb == 0) continue;
+    Part<T> run{(T)0, 0};
+    if (hp != 0 || b == 1) {
+      run = gr_join(op, run, tp);
+    } else {
+      int64_t s = b - 2;  // first tile of the head-less stretch that precedes b
+      int steps = 1;
+      bool far = false;
+      while (s >= 0 && tile_heads[s] == 0) {
+        if (++steps > GR_WALK) {
+          far = true;
+          break;
+        }
+        --s;
+      }
+      if (far) {
+        chain = 1;
+        continue;
+      }
+      for (int64_t t = s < 0 ? 0 : s; t < b; ++t) run = gr_join(op, run, open_tail[t]);
+    }
+    if (b < ntiles) run = gr_join(op, run, oh);
+    if (run.c) {
+      vals[tf - 1] = run.v;
+      counts[tf - 1] = run.c;
+    }
+  }
+  __syncthreads();
+  if (chain) gr_fixup_body<T>(op, ntiles, tile_heads, tile_first, open_head, open_tail, vals, counts, n_groups, lds_wave);
 }
 
 static int64_t gr_tiles(int64_t n) { return ceil_div(n, (int64_t)GR_TILE); }
@@ -404,6 +464,11 @@ static int group_reduce_t(int op, int64_t n, const int64_t* keys, int64_t diviso
   else
     hipLaunchKernelGGL((gr_reduce_kernel<T, GroupOf>), dim3((unsigned)nt), dim3(GR_THREADS), 0, s, op, keys, data, n, gof,
                        tile_first, gids, vals, counts, open_head, open_tail);
+  if (nt <= GR_FIX_ONE_TILES) {
+    hipLaunchKernelGGL(gr_fix_one_kernel<T>, dim3(1), dim3(1024), 0, s, op, nt, tile_heads, tile_first, open_head, open_tail,
+                       vals, counts, n_groups);
+    return launch_status();
+  }
   hipLaunchKernelGGL(gr_fix_fast_kernel<T>, dim3((unsigned)ceil_div(nt, (int64_t)256)), dim3(256), 0, s, op, nt, tile_heads,
                      tile_first, open_head, open_tail, vals, counts, n_groups, need_chain);
   hipLaunchKernelGGL(gr_fixup_kernel<T>, dim3(1), dim3(1024), 0, s, op, nt, tile_heads, tile_first, open_head, open_tail,

@@ -124,5 +124,19 @@ __device__ __forceinline__ VT sd_load_nt(const void* p) {
   return r;
 }
 
+// 16 bytes from memory, waited for INSIDE the statement (`s_waitcnt vmcnt(0)`), as one opaque block: for a load on a rare arm
+// of a branch whose other arm fills the same registers from LDS.  As a plain load the compiler has to assume after the join
+// that the registers are still in flight and puts a full memory wait in front of their first use on BOTH arms - every load
+// issued before it (the loads the common arm wants to keep in flight) is waited for too (round 6, tools/isa_wait_audit.py).
+template <typename VT>
+__device__ __forceinline__ VT sd_load_now(const void* p) {
+  static_assert(sizeof(VT) == 16, "16-byte vectors");
+  typedef unsigned sd_u4 __attribute__((ext_vector_type(4)));
+  sd_u4 x;
+  asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(p) : "memory");
+  VT r;
+  __builtin_memcpy(&r, &x, 16);
+  return r;
+}
 
 }  // namespace spamd

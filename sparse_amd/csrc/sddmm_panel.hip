@@ -88,10 +88,10 @@ struct SdpBatch {
           const char* ap = sa + sl[K] * ROWB + koff_b;
 #pragma unroll
           for (int s = 0; s < KS; ++s) av[s] = *reinterpret_cast<const VT*>(ap + s * (LPN * 16));
-        } else {   // more distinct rows in this workgroup than LDS slots: straight from memory
+        } else {   // more distinct rows in this workgroup than LDS slots: straight from memory, waited for on the spot
           const char* ap = Ab + ((int64_t)rr[K] * lda_b + koff_b);
 #pragma unroll
-          for (int s = 0; s < KS; ++s) av[s] = *reinterpret_cast<const VT*>(ap + s * (LPN * 16));
+          for (int s = 0; s < KS; ++s) av[s] = sd_load_now<VT>(ap + s * (LPN * 16));
         }
         const ACC t = sd_dot_group<TIN, VT, LPN, KS>(av, bv[K]);
         res = sub == U0 + K ? t : res;
