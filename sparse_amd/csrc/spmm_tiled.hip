@@ -1112,7 +1112,10 @@ __global__ void __launch_bounds__(256) tl_csc_count_kernel(int64_t K, int ntiles
 // its counts go to its own quarter of `cntq`, which tl_csc_offsets_kernel adds up.  No position search, every row index
 // read once, coalesced: 0.41 / 0.45 ms (count kernel above, int32 / int64 indices at config 2's size) -> 0.26 / 0.31 ms; the
 // split pointers of its columns are written in the same pass (tl_csc_split_kernel is then not launched: 0.28 / 0.34 ms).
-constexpr int TL_CSC_HIST_GROUPS = 38 * 1024;   // 152 KB of LDS
+// (round 6: two groups share a 32-bit word - a part of a tile holds at most TL_RG * TL_KB / parts = 1400 elements of a group, so
+// 16 bits per count and one 32-bit LDS atomic of 1 or 65536 - which takes the histogram to 76 k groups = 2.66 M rows; above
+// that the split + count kernels: +0.48 ms at 4 M x 2500)
+constexpr int TL_CSC_HIST_GROUPS = 76 * 1024;   // 152 KB of LDS
 #ifndef SPAMD_CSC_HIST_PARTS
 #define SPAMD_CSC_HIST_PARTS 4
 #endif
@@ -1137,7 +1140,9 @@ __global__ void __launch_bounds__(1024) tl_csc_hist_kernel(int64_t M, int64_t K,
   if (c1 > K) c1 = K;
   const int ncols = (int)(c1 - c0);
   if (tid <= ncols) cptr[tid] = (int64_t)indptr[c0 + tid];
-  for (int64_t i = tid; i < groups; i += 1024) tl_hist_lds[i] = 0;
+  static_assert(TL_RG * (TL_KB / TL_CSC_HIST_PARTS) < 65536, "a group's count in a part of a tile fits 16 bits");
+  const int64_t hwords = (groups + 1) / 2;
+  for (int64_t i = tid; i < hwords; i += 1024) tl_hist_lds[i] = 0;
   __syncthreads();
   // The split pointers of my columns in the same pass (tl_csc_split_kernel's work).  Round 6: my columns' elements are ONE
   // contiguous range of the arrays; the workgroup walks it 4096 elements at a time with every load of a step issued before
@@ -1214,7 +1219,7 @@ __global__ void __launch_bounds__(1024) tl_csc_hist_kernel(int64_t M, int64_t K,
         if (rhi[u] != 0 || rlo[u] >= Mu || (!first && plo[u] > rlo[u])) bad = true;
         unsigned g = rlo[u] / (unsigned)TL_RG;       // (rows out of range are reported above; stay inside the histogram)
         g = g < ng1 ? g : ng1;
-        atomicAdd(&tl_hist_lds[g], 1);
+        atomicAdd(&tl_hist_lds[g >> 1], (g & 1u) ? 65536 : 1);
         const int bc = (int)(g / (unsigned)TL_WAVES);       // (= row / TL_BLOCK_ROWS, at most nblocks - 1)
         int bp = -1;
         if (!first) {
@@ -1227,10 +1232,24 @@ __global__ void __launch_bounds__(1024) tl_csc_hist_kernel(int64_t M, int64_t K,
       }
     }
   }
+  __shared__ long long counted;
+  if (tid == 0) counted = 0;
   if (bad) atomicOr(&state[0], 1ull);
   __syncthreads();
   int* const out = cntq + (int64_t)q * groups * ntiles;
-  for (int64_t g = tid; g < groups; g += 1024) out[(int64_t)t * groups + g] = tl_hist_lds[g];   // (tile-major: written and read coalesced)
+  long long mine = 0;
+  for (int64_t g = tid; g < groups; g += 1024) {       // (tile-major: written and read coalesced)
+    const int c = (int)(((unsigned)tl_hist_lds[g >> 1] >> (16 * (int)(g & 1))) & 0xffffu);
+    out[(int64_t)t * groups + g] = c;
+    mine += c;
+  }
+  // A 16-bit count that wrapped (only repeated rows inside a column can do that: 65536 elements of one row group in 40
+  // columns) changes the sum of the counts: reported like rows out of order - the caller takes the CSR route.
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
+  if ((tid & 63) == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&counted), (unsigned long long)mine);
+  __syncthreads();
+  if (tid == 0 && counted != B - A) atomicOr(&state[0], 1ull);
 }
 
 // per group: its lists' first blocks relative to the group's own (rel[t * groups + g], tile-major like cnt; row ntiles = the group's
@@ -1599,7 +1618,7 @@ static int tl_launch_inspect_csc(int64_t M, int64_t K, int64_t ntiles, const T* 
   const dim3 grid((unsigned)nblocks, (unsigned)ceil_div(ntiles, (int64_t)TL_CSC_TC));
   if (hist) {
     auto hk = &tl_csc_hist_kernel<I>;
-    const int lds = (int)(groups * sizeof(int));
+    const int lds = (int)((groups + 1) / 2 * sizeof(int));
     if (lds > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hk), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       if (e != hipSuccess) return (int)e;

@@ -108,17 +108,44 @@ def test_default_construction_never_builds_a_csr_twin_for_the_executor(sp):
     assert torch.equal(rt.t(), r1)
 
 
-def test_csc_inspector_more_row_groups_than_the_lds_histogram_holds():
-    """above 38 912 row groups (1.36 x 10^6 rows) the list sizes come from the workgroups' own runs (`tl_csc_count_kernel`)
-    instead of the LDS histograms over the row groups"""
+@pytest.mark.parametrize("M", [1_400_123, 2_800_123])
+def test_csc_inspector_more_row_groups_than_the_lds_histogram_holds(M):
+    """up to 77 824 row groups (2.72 x 10^6 rows) two 16-bit counts share a word of the LDS histogram (round 6; one count per
+    word up to 38 912 groups before); above that the list sizes come from the workgroups' own runs (`tl_csc_split_kernel`,
+    `tl_csc_count_kernel`)"""
     from sparse_amd import _kernels as K
 
-    M, Kd = 1_400_123, 330
+    Kd = 330
     data, idx, ptr = _case(M, Kd, 0.004, torch.float64, torch.int64, seed=8)
     cd, ci, cp = K.csx_swap_2d(data, idx, ptr, M, Kd)
     b = torch.rand((Kd, 64), device="cuda", dtype=torch.float64) - 0.5
     got = K.dot_csr_ndarray_tiled(K.csc_tiled_layout(cd, ci, cp, M, Kd), (M, 64), Kd, b)
     assert torch.equal(got, K.dot_csr_ndarray((M, 64), data, idx, ptr, b))
+
+
+def test_csc_inspector_repeated_rows_that_overflow_a_16_bit_count_are_reported(sp):
+    """a non-canonical operand: one row stored 70 000 times in one column.  The LDS histogram's 16-bit count of that row group
+    wraps; the kernel notices (the counts no longer add up to the elements it walked) and reports the operand like rows out of
+    order - `a @ b` then takes the CSR route and the product is the canonical operand's"""
+    from sparse_amd import _kernels as K
+
+    M, Kd, rep = 5000, 200, 70_000
+    rng = np.random.default_rng(3)
+    rows = np.sort(np.concatenate([np.full(rep, 1234), rng.integers(0, M, 3000)]))       # column 7 holds all of them
+    indptr = np.zeros(Kd + 1, np.int64)
+    indptr[8:] = len(rows)
+    data = rng.random(len(rows))
+    b = rng.random((Kd, 64))
+    dev = torch.device("cuda:0")
+    cd, ci, cp = (torch.from_numpy(x).to(dev) for x in (data, rows.astype(np.int64), indptr))
+    lay = K.csc_tiled_layout(cd, ci, cp, M, Kd)
+    with pytest.raises(K.UnsortedColumns):
+        K.dot_csr_ndarray_tiled(lay, (M, 64), Kd, torch.from_numpy(b).to(dev))
+    a = sp.GCXS((data, rows.astype(np.int64), indptr), shape=(M, Kd), compressed_axes=(1,), device="cuda:0")
+    got = a @ b
+    want = np.zeros((M, 64))
+    np.add.at(want, rows, data[:, None] * b[7][None, :])
+    assert np.allclose(got, want, rtol=1e-9, atol=1e-9)
 
 
 # ---- against the ORACLE itself (round-4 verdict: the tests above compare with the row-group kernel, a second HIP path) ---------
