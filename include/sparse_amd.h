@@ -103,7 +103,13 @@ int spamd_spmm_csr_ldsb(int val_dtype, int idx_dtype, int64_t M, int64_t K, int6
  * spamd_spmm_csr takes this path for N <= 4 when `..._fits` says 1 and M >= 32768, unless SPAMD_SPMM_ROWGROUP,
  * SPAMD_SPMM_ROWVEC or (for floating point) SPAMD_EXACT_MULADD is set.  `..._fits`: N in 1..4 (1..3 for 8-byte values), M < 2^28, B within the LDS
  * budget, a_data and a_indices 16-byte aligned.  `nnz` = a_indptr[M] when the caller knows it, -1 otherwise (the kernel then reads it: one
- * more memory latency at the head of every wave).  flags bits 8..15 (tuning hint, 0 = default): workgroups per resident slot. */
+ * more memory latency at the head of every wave).  flags bits 8..15 (tuning hint, 0 = default): workgroups per resident slot.
+ * Round 6: `..._fits` returns the number of PASSES over A the product takes - ceil(N / w) for N up to 64 with w = the widest
+ * chunk of columns (<= 4, 8-byte values: 3) whose K x w values fit the LDS; 0 = not this kernel - and spamd_spmm_csr_stream
+ * runs them, one launch per chunk (b and out may be strided: ldb, ldo).  A pass costs A's stream whatever its width, so
+ * spamd_spmm_csr takes up to 3 passes for 5 <= N <= SPAMD_STREAM_MULTI_MAX_N, up to 2 for N <= 4 columns of 8-byte values
+ * and 1 for N <= 4 columns of 4-byte values, under the conditions above. */
+#define SPAMD_STREAM_MULTI_MAX_N 12
 int spamd_spmm_csr_stream_fits(int val_dtype, int64_t M, int64_t K, int64_t N, const void* a_data, const void* a_indices);
 int spamd_spmm_csr_stream(int val_dtype, int idx_dtype, int64_t M, int64_t K, int64_t N,
                           const void* a_data, const void* a_indices, const void* a_indptr,

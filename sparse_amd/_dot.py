@@ -710,6 +710,13 @@ def _gcxs_times_dense(a, bt, out_shape):
     if not direct:
         data, indices, indptr = _csr_triplet(a)
     use_tiled = eligible = _tiled_eligible(data, bt, out_shape, Kd)
+    if use_tiled and not direct and out_shape[1] <= K.STREAM_MULTI_MAX_N and not (
+            _settings.EXACT_MULADD and _tiled_dtype(data, bt).is_floating_point):
+        # a result of 5-12 columns from CSR arrays that are there anyway: two or three passes of the stream kernel over A
+        # (0.36-0.53 ms at config 2's matrix) instead of the executor's padded 128-column panel (0.77 ms) - and no inspector
+        dt = _tiled_dtype(data, bt)
+        if K.stream_passes(int(out_shape[0]), Kd, int(out_shape[1]), dt, data, indices):
+            use_tiled = eligible = False
     if use_tiled and isinstance(a, COO) and not getattr(a, "_tiled_layouts", None):
         # COO operands of `tensordot` are usually temporaries (an N-D array reshaped to 2-D): for small ones the inspector
         # only pays when the array is multiplied again (config 3, 1.3 x 10^6 elements: 0.33 ms with a fresh layout per call

@@ -28,6 +28,21 @@ def _unify_index(*idx):
 
 
 STREAM_MIN_ROWS = 32768   # spamd_spmm_csr's own bound for the stream form (SPAMD_ROWVEC_LDS_MIN_M, spmm_csr.hip)
+STREAM_MULTI_MAX_N = 12   # widest result the stream form takes in several passes (SPAMD_STREAM_MULTI_MAX_N, sparse_amd.h)
+
+
+def stream_passes(M, K, N, dtr, a_data, a_indices):
+    """Passes over A the stream form of CSR x dense (csrc/spmm_stream.hip) takes for this product, 0 = another kernel has
+    it.  A pass holds 4 columns (3 of 8-byte values; fewer when K x width values of B do not fit the LDS) and costs A's stream
+    whatever its width - 0.16-0.18 ms at config 2's matrix, 0.25 with 8-byte values -, so (round 6, tools/r06/width_sweep.py)
+    up to STREAM_MULTI_MAX_N columns are worth 3 passes (the tiled executor's padded panel: 0.77 / 1.0 ms), at most 4 columns of
+    8-byte values 2 (the row-vector kernel: 0.85-0.96 ms) and at most 4 columns of 4-byte values 1 (two tie with the row-vector
+    kernel).  The rule of `spamd_spmm_csr`'s own dispatch."""
+    if not (1 <= N <= STREAM_MULTI_MAX_N and M >= STREAM_MIN_ROWS and K > 0):
+        return 0
+    passes = int(_ffi.lib().spamd_spmm_csr_stream_fits(code_of(dtr), M, K, N, ptr(a_data), ptr(a_indices)))
+    worth = 3 if N > 4 else (2 if dtr.itemsize == 8 else 1)
+    return passes if 1 <= passes <= worth else 0
 
 
 def dot_csr_ndarray(out_shape, a_data, a_indices, a_indptr, b, *, exact=False, out=None, keep_order=False, rowvec=False):
@@ -56,9 +71,8 @@ def dot_csr_ndarray(out_shape, a_data, a_indices, a_indptr, b, *, exact=False, o
         out = torch.empty((M, N), dtype=dtr, device=dev)
     elif out.shape != (M, N) or out.dtype != dtr or not out.is_contiguous():
         raise ValueError("out buffer has wrong shape/dtype/layout")
-    if (1 <= N <= 4 and M >= STREAM_MIN_ROWS and K > 0 and not keep_order and not rowvec
-            and not (exact and dtr.is_floating_point)
-            and _ffi.lib().spamd_spmm_csr_stream_fits(vcode, M, K, N, ptr(a_data), ptr(a_indices))):
+    if (not keep_order and not rowvec and not (exact and dtr.is_floating_point)
+            and stream_passes(M, K, N, dtr, a_data, a_indices)):
         # what spamd_spmm_csr's own dispatch would pick, with the number of stored elements handed over (the kernel need
         # not read it from indptr at the head of every wave's start-up chain)
         _ffi.call("spamd_spmm_csr_stream", vcode, code_of(it), M, K, N, ptr(a_data), ptr(a_indices), ptr(a_indptr),

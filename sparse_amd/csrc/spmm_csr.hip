@@ -504,11 +504,19 @@ extern "C" int spamd_spmm_csr(int val_dtype, int idx_dtype, int64_t M, int64_t K
   if (!(flags & SPAMD_SPMM_ROWGROUP) && M >= 8192 && N * ((val_dtype == SPAMD_F64 || val_dtype == SPAMD_I64) ? 8 : 4) >= 128 &&
       spamd_spmm_csr_ldsb_fits(val_dtype, M, K, N, b, ldb, out, ldo))
     return spamd_spmm_csr_ldsb(val_dtype, idx_dtype, M, K, N, a_data, a_indices, a_indptr, b, ldb, out, ldo, flags, stream);
-  // results of at most 4 columns, B fits LDS: the stream form (spmm_stream.hip; tree order per row like the row-vector kernel)
-  if (N <= ROWVEC_MAX_N && !(flags & (SPAMD_SPMM_ROWGROUP | SPAMD_SPMM_ROWVEC)) && M >= SPAMD_ROWVEC_LDS_MIN_M && K > 0 &&
-      !(exact && (val_dtype == SPAMD_F32 || val_dtype == SPAMD_F64)) &&
-      spamd_spmm_csr_stream_fits(val_dtype, M, K, N, a_data, a_indices))
-    return spamd_spmm_csr_stream(val_dtype, idx_dtype, M, K, N, a_data, a_indices, a_indptr, b, ldb, out, ldo, -1, 0u, stream);
+  // results of at most 4 columns, B fits LDS: the stream form (spmm_stream.hip; tree order per row like the row-vector kernel);
+  // round 6: in several passes over chunks of columns too, while its passes over A cost less than the other kernels - up to
+  // SPAMD_STREAM_MULTI_MAX_N columns in at most 3 passes (against the tiled executor's padded panel and the row-group kernel's
+  // gathers), at most 4 columns of 8-byte values in 2 (against the row-vector kernel: 0.50 against 0.85-0.96 ms at config 2's
+  // matrix; with 4-byte values two passes only tie with it)
+  if (N <= SPAMD_STREAM_MULTI_MAX_N && !(flags & (SPAMD_SPMM_ROWGROUP | SPAMD_SPMM_ROWVEC)) && M >= SPAMD_ROWVEC_LDS_MIN_M && K > 0 &&
+      !(exact && (val_dtype == SPAMD_F32 || val_dtype == SPAMD_F64))) {
+    const int passes = spamd_spmm_csr_stream_fits(val_dtype, M, K, N, a_data, a_indices);
+    const bool wide = val_dtype == SPAMD_F64 || val_dtype == SPAMD_I64;
+    const int worth = N > ROWVEC_MAX_N ? 3 : (wide ? 2 : 1);
+    if (passes >= 1 && passes <= worth)
+      return spamd_spmm_csr_stream(val_dtype, idx_dtype, M, K, N, a_data, a_indices, a_indptr, b, ldb, out, ldo, -1, 0u, stream);
+  }
   SPAMD_DISPATCH_VAL(val_dtype, T, {
     SPAMD_DISPATCH_IDX(idx_dtype, I, {
       const T* ad = (const T*)a_data;

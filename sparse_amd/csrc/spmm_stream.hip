@@ -279,8 +279,13 @@ spmm_stream_kernel(int64_t M, int64_t K, const T* __restrict__ a_data, const I* 
   typedef unsigned bvec_t __attribute__((ext_vector_type(4)));
   const int64_t btot = K * NV;
   const bool bcont = ldb == NV && ((uintptr_t)b & 15) == 0;
-  const int64_t nvec = bcont ? btot * (int64_t)sizeof(T) / 16 : 0;   // whole vectors of a contiguous B
+  // (round 6: NV columns out of a wider B - one pass of a result of more than four columns, spamd_spmm_csr_stream - whose rows
+  // are whole 16-byte vectors at 16-byte places: VPR vectors per row, a row every ldb values)
+  constexpr int VPR = (NV * (int)sizeof(T)) % 16 == 0 ? NV * (int)sizeof(T) / 16 : 0;
+  const bool bstr = !bcont && VPR > 0 && ((uintptr_t)b & 15) == 0 && (ldb * (int64_t)sizeof(T)) % 16 == 0;
+  const int64_t nvec = bcont ? btot * (int64_t)sizeof(T) / 16 : bstr ? K * VPR : 0;   // whole vectors of B copied as such
   const int64_t sc0 = nvec * (16 / (int64_t)sizeof(T));               // first value copied one by one
+  const int64_t ldb_v = ldb * (int64_t)sizeof(T) / 16;                 // (a row's stride in vectors: strided form)
 
   // this wave's rows [r_lo, r_hi): the rows whose first element lies in [w, w + 1) * chunk of the stream
   const int64_t W = (int64_t)gridDim.x * nwv, w = (int64_t)blockIdx.x * nwv + wv;
@@ -321,7 +326,10 @@ spmm_stream_kernel(int64_t M, int64_t K, const T* __restrict__ a_data, const I* 
 #pragma unroll
     for (int j = 0; j < BB; ++j) {
       const int64_t iv = base + threadIdx.x + (int64_t)j * blockDim.x;
-      hold[j] = reinterpret_cast<const bvec_t*>(b)[iv < nvec ? iv : nvec - 1];
+      const int64_t ic = iv < nvec ? iv : nvec - 1;
+      int64_t src = ic;
+      if constexpr (VPR > 0) src = bstr ? (ic / VPR) * ldb_v + (ic % VPR) : ic;
+      hold[j] = reinterpret_cast<const bvec_t*>(b)[src];
     }
 #pragma unroll
     for (int j = 0; j < BB; ++j) {
@@ -663,15 +671,29 @@ extern "C" int spamd_stream_phase_read(unsigned long long* host, int n) {
 }
 #endif
 
+// Width of one pass: the widest column chunk (at most 4; 3 for 8-byte values - 32-byte rows of B with 64-bit indices do not
+// fit the kernel's 128 registers) whose K x width values of B fit the LDS beside the waves' row-end masks; 0 = none.
+static int stream_chunk_width(size_t es, int64_t K) {
+  const size_t room = (size_t)spamd::ST_LDS_BYTES - 16 * spamd::ST_MASK_WORDS_MAX * 4;
+  for (int w = es == 8 ? 3 : 4; w >= 1; --w) {
+    const size_t bbytes = ((es * (size_t)w * (size_t)K) + 15) & ~(size_t)15;
+    if (bbytes <= room) return w;
+  }
+  return 0;
+}
+
+// 0 = the stream form does not take this product; otherwise the number of PASSES over A it takes: ceil(N / chunk width) - 1
+// for results of at most 4 (8-byte values: 3) columns whose B fits the LDS (round 6: a pass costs what A's stream costs
+// whatever its width - 0.16-0.18 ms at config 2's matrix, 0.25 with 8-byte values - so two or three passes beat the padded
+// panel of the tiled executor, 0.77 / 1.0 ms; the caller decides how many passes are worth it: spamd_stream_passes_worth).
 extern "C" int spamd_spmm_csr_stream_fits(int val_dtype, int64_t M, int64_t K, int64_t N, const void* a_data,
                                           const void* a_indices) {
-  if (M <= 0 || M >= spamd::ST_MAX_ROWS || K <= 0 || N < 1 || N > 4) return 0;
+  if (M <= 0 || M >= spamd::ST_MAX_ROWS || K <= 0 || N < 1 || N > 64) return 0;
   const size_t es = (val_dtype == SPAMD_F64 || val_dtype == SPAMD_I64) ? 8 : 4;
-  if (es == 8 && N == 4) return 0;  // 32-byte rows of B with 64-bit indices do not fit the kernel's 128 registers
-  const size_t bbytes = ((es * (size_t)N * (size_t)K) + 15) & ~(size_t)15;
-  if (bbytes + 16 * spamd::ST_MASK_WORDS_MAX * 4 > (size_t)spamd::ST_LDS_BYTES) return 0;
   if ((uintptr_t)a_data % 16 || (uintptr_t)a_indices % 16) return 0;
-  return 1;
+  const int cw = stream_chunk_width(es, K);
+  if (cw == 0) return 0;
+  return (int)((N + cw - 1) / cw);
 }
 
 extern "C" int spamd_spmm_csr_stream(int val_dtype, int idx_dtype, int64_t M, int64_t K, int64_t N, const void* a_data,
@@ -685,8 +707,14 @@ extern "C" int spamd_spmm_csr_stream(int val_dtype, int idx_dtype, int64_t M, in
   hipStream_t s = (hipStream_t)stream;
   SPAMD_DISPATCH_VAL(val_dtype, T, {
     SPAMD_DISPATCH_IDX(idx_dtype, I, {
-      return launch_stream<T, I>(M, K, N, (const T*)a_data, (const I*)a_indices, (const I*)a_indptr, (const T*)b, ldb,
-                                 (T*)out, ldo, nnz, flags, s);
+      const int cw = stream_chunk_width(sizeof(T), K);
+      for (int64_t c0 = 0; c0 < N; c0 += cw) {       // (one launch per chunk of columns: every pass reads all of A)
+        const int64_t nv = N - c0 < cw ? N - c0 : cw;
+        if (int rc = launch_stream<T, I>(M, K, nv, (const T*)a_data, (const I*)a_indices, (const I*)a_indptr, (const T*)b + c0, ldb,
+                                         (T*)out + c0, ldo, nnz, flags, s))
+          return rc;
+      }
+      return 0;
     })
   })
   return SPAMD_ETYPE;

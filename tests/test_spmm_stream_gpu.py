@@ -10,14 +10,14 @@ from util import assert_within_fma_bound, random_csr, random_dense
 pytestmark = pytest.mark.gpu
 
 
-def _stream(M, K, N, data, idx, ptr, b, mult=0, known_nnz=True):
+def _stream(M, K, N, data, idx, ptr, b, mult=0, known_nnz=True, passes=1):
     from sparse_amd import _ffi
     from sparse_amd._device import code_of, ptr as p_, stream_ptr
 
     d = torch.device("cuda")
     td, ti, tp, tb = (torch.from_numpy(np.ascontiguousarray(x)).to(d) for x in (data, idx, ptr, b))
     out = torch.full((M, N), -7, dtype=td.dtype, device=d)   # every element must be written
-    assert _ffi.lib().spamd_spmm_csr_stream_fits(code_of(td.dtype), M, K, N, p_(td), p_(ti)) == 1
+    assert _ffi.lib().spamd_spmm_csr_stream_fits(code_of(td.dtype), M, K, N, p_(td), p_(ti)) == passes
     nnz_arg = len(data) if known_nnz else -1
     _ffi.call("spamd_spmm_csr_stream", code_of(td.dtype), code_of(ti.dtype), M, K, N, p_(td), p_(ti), p_(tp), p_(tb), N,
               p_(out), N, nnz_arg, mult << 8, stream_ptr(d))
@@ -41,14 +41,10 @@ def _check(orc, M, K, N, data, idx, ptr, b, **kw):
 def test_stream_vs_oracle(orc, dtype, idt, N):
     M, K = 5000, 900
     data, idx, ptr = random_csr(M, K, 0.02, 11 + N, dtype, idt)
-    if N == 4 and np.dtype(dtype).itemsize == 8:   # declined (32-byte rows of B): spamd_spmm_csr keeps the row-vector kernel
-        from sparse_amd import _ffi
-        from sparse_amd._device import code_of, ptr as p_
-
-        td = torch.from_numpy(data).cuda()
-        assert _ffi.lib().spamd_spmm_csr_stream_fits(code_of(td.dtype), M, K, N, p_(td), p_(td)) == 0
-        return
-    _check(orc, M, K, N, data, idx, ptr, random_dense(K, N, 5, dtype))
+    # (8-byte values: a pass holds at most 3 columns - 32-byte rows of B with 64-bit indices do not fit the kernel's 128
+    # registers -, so 4 columns are two passes since round 6; declined before)
+    passes = 2 if N == 4 and np.dtype(dtype).itemsize == 8 else 1
+    _check(orc, M, K, N, data, idx, ptr, random_dense(K, N, 5, dtype), passes=passes)
 
 
 @pytest.mark.parametrize("density,M,K", [(0.0, 300, 50), (0.0005, 40000, 300), (0.004, 30000, 700), (0.3, 3000, 1000),
@@ -141,3 +137,59 @@ def test_strided_dense_operand_and_result(orc, N):
     want = orc.dot_csr_ndarray((M, N), data, idx, ptr, b)
     assert_within_fma_bound(np.ascontiguousarray(got[:, 1:1 + N]), want, data, idx, ptr, b)
     assert (got[:, 0] == -7.0).all() and (got[:, 1 + N:] == -7.0).all()
+
+
+# ---- results of 5-12 columns: several passes of the stream kernel over chunks of columns (round 6) ----------------------------
+
+@pytest.mark.parametrize("dtype, itype, N", [(torch.float32, torch.int32, 5), (torch.float32, torch.int32, 8), (torch.float32, torch.int64, 12),
+                                             (torch.float64, torch.int64, 4), (torch.float64, torch.int32, 6), (torch.int32, torch.int32, 7),
+                                             (torch.int64, torch.int64, 5)])
+def test_stream_kernel_in_several_passes(dtype, itype, N):
+    """`dot_csr_ndarray` / `spamd_spmm_csr` take results of up to 12 columns (8-byte values: 6) through the stream kernel,
+    4 (3) columns a pass, b and out strided: every column as the one-pass kernel computes it alone (bit-identical: a column's
+    arithmetic does not depend on its neighbours... of the same chunk width) and within tolerance of the k-ascending sums"""
+    from bench import make_csr_device
+    from sparse_amd import _kernels as K
+
+    M, Kd = 70_000, 3000
+    data, idx, ptr = make_csr_device(M, Kd, 0.01, seed=11, dtype=torch.float32 if not dtype.is_floating_point else dtype)
+    if not dtype.is_floating_point:
+        data = (data * 200 - 100).to(dtype)
+    idx, ptr = idx.to(itype), ptr.to(itype)
+    b = (torch.rand((Kd, N), device="cuda", dtype=torch.float64) - 0.5)
+    b = b.to(dtype) if dtype.is_floating_point else (b * 50).to(dtype)
+    assert K.stream_passes(M, Kd, N, dtype, data, idx) >= 2
+    got = K.dot_csr_ndarray((M, N), data, idx, ptr, b)
+    want = K.dot_csr_ndarray((M, N), data, idx, ptr, b, keep_order=True)       # the row-group kernel: k-ascending sums
+    if dtype.is_floating_point:
+        scale = K.dot_csr_ndarray((M, N), data.abs(), idx, ptr, b.abs(), keep_order=True)
+        tol = 1e-6 if dtype == torch.float32 else 1e-14
+        assert float(((got - want).abs() / scale.clamp_min(1e-30)).max()) < tol
+    else:
+        assert torch.equal(got, want)
+    # through the C ABI's own dispatch (nnz unknown there) and again: the same bits
+    out2 = torch.empty_like(got)
+    from sparse_amd import _ffi
+    from sparse_amd._device import code_of, ptr as dptr, stream_ptr
+    _ffi.call("spamd_spmm_csr", code_of(dtype), code_of(itype), M, Kd, N, dptr(data), dptr(idx), dptr(ptr), dptr(b), N, dptr(out2), N, 0,
+              stream_ptr(got.device))
+    assert torch.equal(out2, got)
+
+
+def test_products_of_a_few_columns_take_the_stream_kernel_not_the_executor():
+    """`a @ b` with 8 columns at a size where the tiled executor would be eligible: no block stream is built"""
+    import sparse_amd as sp
+    from bench import make_csr_device
+
+    M, Kd = 300_000, 4000
+    d, i, p = make_csr_device(M, Kd, 0.01, seed=5)
+    a = sp.GCXS((d, i, p), shape=(M, Kd), compressed_axes=(0,))
+    b = torch.rand((Kd, 8), device="cuda") - 0.5
+    c = a @ b
+    assert not getattr(a, "_tiled_layouts", None)
+    b128 = torch.zeros((Kd, 128), device="cuda")
+    b128[:, :8] = b
+    ref = (a @ b128)[:, :8]
+    assert getattr(a, "_tiled_layouts", None)
+    scale = (sp.GCXS((d.abs(), i, p), shape=(M, Kd), compressed_axes=(0,)) @ b128.abs())[:, :8]
+    assert float(((c - ref).abs() / scale.clamp_min(1e-30)).max()) < 1e-6

@@ -31,7 +31,7 @@ while time.time() < t_end:
     else:
         data, idx, ptr = make_csr_device(M, Kd, dens, seed=seed, idx_dtype=it)
     for _ in range(6):      # several (dtype, N) products per generated matrix
-        N = int(rng.integers(1, 5))
+        N = int(rng.integers(1, 5)) if rng.random() < 0.6 else int(rng.integers(5, 14))     # (5 and more: several passes, round 6)
         dt = [torch.float32, torch.float64, torch.int32, torch.int64][int(rng.integers(0, 4))]
         if dt.is_floating_point:
             dv = (data - 0.4).to(dt)
