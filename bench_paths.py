@@ -258,7 +258,9 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
         del ai, ri
         # matrix x vector and results of 2..4 columns: the stream form (spmm_stream.hip: a piece of the CSR stream per wave, B in
         # LDS) where B fits LDS, else the row-vector kernel (lanes along the row); `rowvec_ms` = that kernel on the same operands
-        for n_v, dt_v in ((1, torch.float32), (2, torch.float32), (4, torch.float32), (1, torch.float64)):
+        # (round 6: 5-12 columns, and 3-4 columns of 8-byte values, in several passes of the same kernel over chunks of columns)
+        for n_v, dt_v in ((1, torch.float32), (2, torch.float32), (4, torch.float32), (1, torch.float64), (8, torch.float32),
+                          (4, torch.float64)):
             dv = data if dt_v == torch.float32 else data.to(dt_v)
             bv = b[:, :n_v].to(dt_v).contiguous()
             ms_rg, _ = timed(lambda: K.dot_csr_ndarray((M, n_v), dv, idx, ptr, bv, keep_order=True), reps=5)
@@ -267,7 +269,7 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
             es = dv.element_size()
             emit(f"A1_shapes_n{n_v}_{'f32' if es == 4 else 'f64'}",
                  row(f"config-2 matrix x dense {Kd}x{n_v} {'fp32' if es == 4 else 'fp64'} ({'matrix-vector product' if n_v == 1 else 'narrow result'}: "
-                     f"{'stream kernel, B resident in LDS' if Kd * n_v * es + 1024 <= 160 * 1024 and not (es == 8 and n_v == 4) else 'row-vector kernel'})", ms_v,
+                     f"stream kernel, B resident in LDS, {K.stream_passes(M, Kd, n_v, dv.dtype, dv, idx)} pass(es) over A)", ms_v,
                      nnz * (es + 4) + (M + 1) * 4 + Kd * n_v * es + M * n_v * es, flops=2.0 * nnz * n_v, rowgroup_ms=ms_rg,
                      rowvec_ms=ms_rv, speedup_vs_rowgroup=ms_rg / ms_v))
             del dv, bv
