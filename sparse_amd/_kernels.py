@@ -1101,7 +1101,7 @@ class SddmmPanels:
     `pos` = the elements' positions in the mask, stably sorted by column panel; `rows`/`cols` = their coordinates in
     that order.  Depends on the coordinates and the panel width only: cached on the mask by `sparse_amd.sddmm`."""
 
-    __slots__ = ("pos", "rows", "cols", "width", "count", "nnz", "chunk", "xstate", "xmax", "_vals", "_vals_key")
+    __slots__ = ("pos", "rows", "cols", "width", "count", "nnz", "chunk", "xstate", "xmax", "_vals", "_vals_key", "row_runs")
 
     def values(self, s_orig, s_data):
         """`s_data` (= `s_orig` in the accumulation dtype) in panel order; kept for as long as the same, unmodified
@@ -1195,6 +1195,9 @@ def sddmm_panels(coords, shape, width, subset=None, xcd=None):
     p.pos = perm if subset is None else gather(subset, perm)
     p.rows, p.cols, p.width, p.count, p.chunk = gather(rows, perm), gather(cols, perm), int(width), n, 0
     p.xstate, p.xmax = None, 0
+    # runs of equal rows in the panel order (one small read-back at plan time): 256 consecutive elements hold about
+    # 256 * row_runs / count + 1 distinct A rows - what the panel kernel's LDS slots are sized for (`_sddmm_row_slots`)
+    p.row_runs = int((p.rows[1:] != p.rows[:-1]).sum().item()) + 1 if n > 0 else 0
     if per_xcd:
         # first element of every (XCD, panel) key in the sorted order -> the nine boundaries of the XCDs' ranges
         first = rows_to_indptr(skeys, 8 * per_xcd)[::per_xcd].contiguous()
@@ -1204,14 +1207,36 @@ def sddmm_panels(coords, shape, width, subset=None, xcd=None):
     return p
 
 
+def _sddmm_row_slots(panels, row_bytes, idx_bytes):
+    """LDS slots for A rows per 256-element workgroup of the panel kernel (`chunk` of spamd_sddmm_panels): enough for the
+    distinct rows such a workgroup meets - a row without a slot is fetched from memory and waited for on the spot - but not
+    past three workgroups per CU.  (Round 6, tools/r06/sddmm_cap_sweep2.py at config 4's mask: 768-byte rows, 61 distinct
+    rows per workgroup: 32 slots - the kernel's own default, 24 KB - 0.82 ms, 52: 1.00, 64: 0.59, 72-96: 0.64, 128: 1.07;
+    512-byte rows, 41 distinct: 44-72 slots 0.324, 80-96: 0.356; 256-byte rows, 21 distinct: 48-72 slots 0.172, 96 - the
+    default - 0.199.)"""
+    if panels.chunk or not panels.count or row_bytes >= 1024:
+        return int(panels.chunk)
+    expected = 256.0 * panels.row_runs / panels.count + 1.0
+    default = max(16, (24 << 10) // row_bytes)                # (the kernel's own choice: 24 KB of rows, launch_panel)
+    three = (160 * 1024 // 3 - 2048 - 1024 - 2 * 256 * idx_bytes - 16) // row_bytes    # (- 2 KB: LDS is handed out in blocks; 65 slots of 768 bytes already leave two workgroups per CU)
+    if expected + 2 > default:                                 # rows without a slot would be the rule
+        return max(16, min(int(1.3 * expected) + 8, three, 256))
+    if default > 64 and 1.3 * expected + 8 <= 64:              # short rows: 64 slots instead of 96 (0.172 against 0.199 ms)
+        return 64
+    return 0
+
+
 def _sddmm_panels_into(panels, s_orig, s_data, a, bt, out):
     """The elements of `panels` (all of the mask or a subset), written to their positions in `out`."""
     part = None
-    if SDDMM_TWO_PASS and int(a.shape[1]) * a.element_size() == 1024:
+    row_bytes = int(a.shape[1]) * a.element_size()
+    if SDDMM_TWO_PASS and row_bytes == 1024:
         part = torch.empty(panels.count, dtype=out.dtype, device=out.device)     # (first-half sums, panel order)
+        row_bytes = 512
+    slots = _sddmm_row_slots(panels, row_bytes, panels.rows.element_size())
     _ffi.call("spamd_sddmm_panels", code_of(a.dtype), code_of(out.dtype), code_of(panels.rows.dtype), panels.count,
               ptr(panels.rows), ptr(panels.cols), ptr(panels.pos), ptr(panels.values(s_orig, s_data)), ptr(a), a.stride(0),
-              ptr(bt), bt.stride(0), int(a.shape[1]), int(panels.chunk), ptr(panels.xstate) if panels.xstate is not None else None,
+              ptr(bt), bt.stride(0), int(a.shape[1]), slots, ptr(panels.xstate) if panels.xstate is not None else None,
               int(panels.xmax), ptr(part) if part is not None else None, ptr(out), stream_ptr(out.device))
 
 

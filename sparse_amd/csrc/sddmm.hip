@@ -221,7 +221,7 @@ static int launch_sddmm(int64_t nnz, const I* rows, const I* cols, const TS* s, 
     for (int L = 16; allow && L <= 64; L <<= 1) {
       if (vecs % L) continue;
       const int ks = (int)(vecs / L);
-      if (ks < 1 || ks > 4 || ks == 3) continue;
+      if (ks < 1 || ks > 4) continue;       // (3: rows of 768 / 1536 / 3072 bytes - K = 192, 384, 768 in fp32 - since round 6)
       constexpr int U = 4;
       const int64_t groups_wanted = 256 * 16 * (256 / L);  // 16 workgroups per CU
       int64_t chunk = ceil_div(nnz, groups_wanted);
@@ -250,7 +250,7 @@ static int launch_sddmm(int64_t nnz, const I* rows, const I* cols, const TS* s, 
     }                                                                                                         \
     return launch_status();                                                                                   \
   }
-      SDR(16, 1) SDR(16, 2) SDR(16, 4) SDR(32, 1) SDR(32, 2) SDR(32, 4) SDR(64, 1) SDR(64, 2) SDR(64, 4)
+      SDR(16, 1) SDR(16, 2) SDR(16, 3) SDR(16, 4) SDR(32, 1) SDR(32, 2) SDR(32, 3) SDR(32, 4) SDR(64, 1) SDR(64, 2) SDR(64, 3) SDR(64, 4)
 #undef SDR
 #undef SDL
     }
@@ -320,7 +320,7 @@ extern "C" int spamd_sddmm_has_panels(int in_dtype, int64_t K) {
   for (int L = 16; L <= 64; L <<= 1) {
     if (vecs % L) continue;
     const int64_t ks = vecs / L;
-    if (ks == 1 || ks == 2 || ks == 4) return 1;
+    if (ks >= 1 && ks <= 4) return 1;
   }
   return 0;
 }

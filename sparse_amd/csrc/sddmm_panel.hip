@@ -312,13 +312,15 @@ static int launch_panel(int64_t nnz, const I* rows, const I* cols, const TS* s, 
   for (int L = 16; L <= 64; L <<= 1) {
     if (vecs % L) continue;
     const int ks = (int)(vecs / L);
-    if (ks != 1 && ks != 2 && ks != 4) continue;
+    if (ks < 1 || ks > 4) continue;
     const int rowb = L * ks * 16;
     // LDS slots for A rows: 24 KB by default (six workgroups per CU), at least 16 rows, never more than a workgroup
     // has elements
     int cap = cap_rows > 0 ? (int)cap_rows : std::max(16, (24 << 10) / rowb);
     const int blk = SDP_BLK;
     if (cap > blk) cap = blk;
+    const int room = (int)((160 * 1024 - 1024 - 2 * blk * (int)sizeof(I) - 16 - 2048) / rowb);   // (one workgroup per CU at most)
+    if (cap > room) cap = room;
     int64_t blocks = ceil_div(nnz, (int64_t)blk * SDP_CHUNKS);
     if (xstate) blocks = 8 * std::max<int64_t>(ceil_div(xmax, (int64_t)blk * SDP_CHUNKS), 1);
     // (+ 1 KB: the last LDS-DMA instruction of the staging burst always writes a whole KB)
@@ -336,7 +338,7 @@ static int launch_panel(int64_t nnz, const I* rows, const I* cols, const TS* s, 
                        ldb, out, perm, xstate, mode, part);                                                    \
     return launch_status();                                                                                    \
   }
-    SDP(16, 1, SDP_UNR) SDP(16, 2, SDP_UNR) SDP(32, 1, SDP_UNR)   // (rows below 1 KB: see spamd_sddmm_panels)
+    SDP(16, 1, SDP_UNR) SDP(16, 2, SDP_UNR) SDP(16, 3, SDP_UNR) SDP(32, 1, SDP_UNR)   // (rows below 1 KB: see spamd_sddmm_panels; 768-byte rows since round 6)
 #undef SDP
   }
   return SPAMD_EINVAL;

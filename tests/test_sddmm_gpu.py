@@ -7,7 +7,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("K", [1, 7, 64, 200, 256, 1000])
+@pytest.mark.parametrize("K", [1, 7, 64, 192, 200, 256, 384, 1000])
 @pytest.mark.parametrize("dt", ["bf16", "f32", "f64"])
 def test_sddmm_vs_dense_formulation(dt, K):
     import sparse_amd as sp
@@ -129,7 +129,8 @@ def _mask(rng, M, N, nnz, idx=np.int32):
 
 
 @pytest.mark.parametrize("dt,Kd", [("bf16", 128), ("bf16", 256), ("bf16", 512), ("bf16", 2048), ("f32", 64), ("f32", 256), ("f32", 512),
-                                   ("f64", 64), ("f64", 256), ("f64", 512)])   # 16-, 32- and 64-lane groups, 1 / 2 / 4 vectors per lane
+                                   ("f64", 64), ("f64", 256), ("f64", 512),   # 16-, 32- and 64-lane groups, 1 / 2 / 4 vectors per lane
+                                   ("bf16", 384), ("f32", 192), ("f64", 96), ("bf16", 768), ("f32", 768), ("f64", 192)])   # 3 vectors per lane (round 6)
 @pytest.mark.parametrize("idx", [np.int32, np.int64])
 def test_sddmm_column_panel_order_is_bit_identical(dt, Kd, idx):
     """spamd_sddmm_panels walks the mask one panel of Bt rows at a time; every stored element is computed by the same
