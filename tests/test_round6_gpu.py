@@ -224,3 +224,44 @@ def test_all_gather_csr_rebases_pointers_beyond_2_to_31():
     finally:
         if started:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dshape", [(50,), (40, 1), (30, 1, 1), (1, 40, 50), (40, 50), (1,), (30, 40, 50)])
+def test_dense_operand_that_broadcasts_into_the_sparse_shape(dshape):
+    """`x * d[None, :]` - a row / column scaling: the dense operand is never copied out at the sparse array's shape (round 6:
+    it was - 8 GB for a vector of 1000 against a 1000^3 array); results as NumPy's on the dense arrays, either operand order,
+    and the reference's error when func(fill, dense) is not constant (reference _umath.py:505-555)"""
+    import sparse_amd as sp
+
+    rng = np.random.default_rng(len(dshape) * 7 + dshape[0])
+    xd = np.where(rng.random((30, 40, 50)) < 0.2, rng.random((30, 40, 50)) - 0.5, 0.0)
+    d = rng.random(dshape) + 0.5
+    x = sp.COO.from_numpy(xd)
+    for f in (np.multiply, np.divide):
+        got = f(x, d)
+        assert isinstance(got, sp.COO) and got.shape == xd.shape and np.array_equal(got.todense(), f(xd, d))
+    got = np.multiply(d, x)
+    assert np.array_equal(got.todense(), d * xd)
+    g = sp.GCXS.from_numpy(xd.reshape(30, 2000))
+    if len(dshape) == 1 and dshape[0] == 50:
+        dv = rng.random(2000) + 0.5
+        assert np.array_equal((g * dv).todense(), xd.reshape(30, 2000) * dv)
+    if dshape == (1,):        # one value: func(fill, dense) IS constant - a sparse result with that fill value
+        got = x + d
+        assert isinstance(got, sp.COO) and got.fill_value == d[0] and np.array_equal(got.todense(), xd + d)
+    elif dshape != (30, 40, 50):
+        with pytest.raises(ValueError, match="dense array"):
+            x + d
+
+
+def test_scaling_a_large_array_by_a_vector_does_not_touch_its_full_shape():
+    """10^6 stored elements of a 4000^3 COO times a vector of 4000: the full shape has 6.4 x 10^10 cells (512 GB of float64)"""
+    import sparse_amd as sp
+
+    x = sp.random((4000, 4000, 4000), density=1.6e-5, random_state=3)
+    v = np.random.default_rng(1).random(4000) + 1.0
+    y = x * v
+    c = x.coords.cpu().numpy()
+    assert y.nnz == x.nnz and np.array_equal(y.data.cpu().numpy(), x.data.cpu().numpy() * v[c[2]])
+    y1 = x * v[:, None]
+    assert np.array_equal(y1.data.cpu().numpy(), x.data.cpu().numpy() * v[c[1]])
