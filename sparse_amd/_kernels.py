@@ -935,12 +935,36 @@ def _spgemm_bitmap_forms(vcode, n_col, max_prod):
 
 
 SPGEMM_SMALL = True
+SPGEMM_SMALL_SECOND = True
 SPGEMM_SMALL_MAX_CELLS = 1 << 22     # n_row x n_col of the result: its upper-bound buffers (12-16 B per cell) stay below 64 MB
 SPGEMM_SMALL_MAX_NNZ = 1 << 16       # stored elements of A (a wave walks its row's elements one after the other): beyond this the
                                      # kernels that spread a row's products over a workgroup have enough work to pay their set-up
 
 
-def _spgemm_small(n_row, n_col, a_data, a_indices, a_indptr, b_data, b_indices, b_indptr):
+SPGEMM_SMALL_MAX_BUFFER = 1 << 30    # entries of the second chance's result buffers (12-16 bytes each)
+
+
+def _spgemm_small_second(vcode, n_row, n_col, total):
+    """Once the row products are known: is this a product for the dense-accumulator kernel after all?  (Round 6,
+    tools/r06/spgemm_small_second.py.)  When the result is dense-ish - at least one product per cell of the result - the bucket
+    kernel's rows overflow their buckets (a column collects many products) and are redone by the global expand-sort-compress,
+    and the bitmap kernel parks too many repeated columns: 3000 x 3000 with 300 elements per row took 28.6 ms, 100000 x 3000
+    with 100 per row 91 ms - 1.1 and 7.3 ms with a wave per row over an LDS accumulator, bit-identical.  Below one product
+    per cell the accumulator kernel still wins while four waves share a workgroup (rows of at most ~4000 float32 / ~2000
+    float64 columns) from a quarter product per cell; with one wave per workgroup or sparser results the other kernels do."""
+    if not (SPGEMM_SMALL and SPGEMM_SMALL_SECOND and total and n_row < 2 ** 31):
+        return False
+    if n_col > int(_ffi.lib().spamd_spgemm_small_max_cols(vcode)) or min(n_row * n_col, total) > SPGEMM_SMALL_MAX_BUFFER:
+        return False
+    fill = total / (n_row * n_col)
+    es = 8 if vcode in (code_of(torch.float64), code_of(torch.int64)) else 4
+    four_waves = ((64 * 1024) // 4 - 32) * 8 // (8 * es + 1)       # (sm_max_cols(4), csrc/spgemm_small.hip)
+    return fill >= 1.0 or (n_col <= four_waves and fill >= 0.25)
+
+
+
+
+def _spgemm_small(n_row, n_col, a_data, a_indices, a_indptr, b_data, b_indices, b_indptr, bound=None):
     """csrc/spgemm_small.hip: the whole product in one launch and one read-back (the reference's own benchmark sizes,
     benchmarks/test_benchmark_coo.py:9-40, are launch-bound on the general path: 230-300 us against ~70).  None when the
     operands are outside its limits or B is not canonical (the caller takes the general path)."""
@@ -956,7 +980,7 @@ def _spgemm_small(n_row, n_col, a_data, a_indices, a_indptr, b_data, b_indices, 
     b_data = b_data.to(dtr).contiguous() if b_data.dtype != dtr else b_data.contiguous()
     (a_indices, a_indptr, b_indices, b_indptr), it = _unify_index(a_indices.contiguous(), a_indptr.contiguous(),
                                                                   b_indices.contiguous(), b_indptr.contiguous())
-    cells = n_row * n_col
+    cells = n_row * n_col if bound is None else min(n_row * n_col, int(bound))     # (the result holds at most one element per product)
     out_idx = torch.empty(cells, dtype=torch.int64, device=dev)
     out_val = torch.empty(cells, dtype=dtr, device=dev)
     head = torch.empty(2 * n_row + 8, dtype=torch.int64, device=dev)      # [work (n_row + 4) | out_indptr (n_row + 1)]: one buffer, one read-back
@@ -1001,6 +1025,10 @@ def _spgemm_rows(n_row, n_col, a_data, a_indices, a_indptr, b_data, b_indices, b
     lim = _ffi.lib().spamd_spgemm_bitmap_limits
     SPGEMM_STATS.update(max_prod=max_prod, max_arow=max_arow, products=total)
     SPGEMM_STATS.pop("bitmap_failed", None)
+    if _spgemm_small_second(vcode, n_row, n_col, total):
+        res = _spgemm_small(n_row, n_col, a_data, a_indices, a_indptr, b_data, b_indices, b_indptr, bound=total)
+        if res is not None:
+            return res
     if SPGEMM_BITMAP and total and max_arow <= lim(vcode, 1) and total >= SPGEMM_BITMAP_MIN_MEAN * n_row:
         n_inner = int(b_indptr.numel()) - 1
         for parts in _spgemm_bitmap_forms(vcode, n_col, max_prod):

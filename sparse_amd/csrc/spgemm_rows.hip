@@ -313,11 +313,13 @@ spgemm_rowrank_kernel(int64_t n_col, int col_bits, int ebits, const I* __restric
   KEY* const lkey = reinterpret_cast<KEY*>(raw);
   V* const lval = reinterpret_cast<V*>(raw + (size_t)CAPP * sizeof(KEY));
   int* const cnt = reinterpret_cast<int*>(raw + L::region);
-  // global bucket of a column: floor(column * scale / 2^32) with scale = floor(NBP * PASSES * 2^32 / n_col) (or the
-  // column itself when there are fewer columns than buckets): monotone in the column, < NBP * PASSES, and the passes get
-  // equal shares of the COLUMN RANGE (a plain shift of the column would hand pass 0 the share 2^k / n_col)
-  const uint64_t scale = (uint64_t)n_col <= (uint64_t)(NBP * PASSES) ? ((uint64_t)1 << 32)
-                                                                     : (((uint64_t)(NBP * PASSES)) << 32) / (uint64_t)n_col;
+  // global bucket of a column: floor(column * scale / 2^32) with scale = floor(NBP * PASSES * 2^32 / n_col): monotone in the
+  // column, < NBP * PASSES, and the passes get equal shares of the COLUMN RANGE (a plain shift of the column would hand pass 0
+  // the share 2^k / n_col).  With fewer columns than buckets the columns are spread out the same way (round 6; until then a
+  // column was its own bucket there, so pass 0 of an 8-pass class took the first 4096 of, say, 10^4 columns - 41 % of the row's
+  // products against the 12.5 % + 1/8 it has room for - and nearly every such row was declined and redone by the global form:
+  // float64 10^4 x 10^4 with 100 elements per row 10.0 ms against 2.7 ms in float32, whose classes have two passes).
+  const uint64_t scale = (((uint64_t)(NBP * PASSES)) << 32) / (uint64_t)n_col;
   auto bucket_of = [&](KEY key) { return (int)(((uint64_t)(key >> ebits) * scale) >> 32); };
   int row_total = 0;
 

@@ -265,3 +265,66 @@ def test_scaling_a_large_array_by_a_vector_does_not_touch_its_full_shape():
     assert y.nnz == x.nnz and np.array_equal(y.data.cpu().numpy(), x.data.cpu().numpy() * v[c[2]])
     y1 = x * v[:, None]
     assert np.array_equal(y1.data.cpu().numpy(), x.data.cpu().numpy() * v[c[1]])
+
+
+@pytest.mark.parametrize("dtype, idt", [(np.float32, np.int32), (np.float64, np.int64), (np.int64, np.int64)])
+@pytest.mark.parametrize("n_row, n, per_row", [(700, 900, 120), (2500, 2500, 60), (300, 7500, 170), (5000, 1500, 25)])
+def test_dense_ish_sparse_products_take_the_accumulator_kernel_and_keep_their_bits(dtype, idt, n_row, n, per_row, orc):
+    """A @ B whose result has about one product per cell or more (round 6): once the row products are known the
+    dense-accumulator kernel takes the product (a wave per row; the bucket kernel's rows overflowed their buckets and were
+    redone by the global form: 3000 x 3000 with 300 per row 28.6 -> 1.1 ms).  Same indices and the same bits as the other
+    kernels give, and as the oracle's `_dot_csr_csr` (reference _common.py:639-717) on sampled rows."""
+    import sparse_amd as sp
+    from sparse_amd import _kernels as K
+
+    kw = dict(dtype=np.float64 if np.dtype(dtype).kind == "i" else dtype, idx_dtype=idt, format="gcxs", compressed_axes=(0,))
+    a = sp.random((n_row, n), density=per_row / n, random_state=11, **kw)
+    b = sp.random((n, n), density=per_row / n, random_state=12, **kw)
+    if np.dtype(dtype).kind == "i":
+        a = sp.GCXS(((a.data * 200 - 100).to(torch.int64), a.indices, a.indptr), shape=a.shape, compressed_axes=(0,))
+        b = sp.GCXS(((b.data * 200 - 100).to(torch.int64), b.indices, b.indptr), shape=b.shape, compressed_axes=(0,))
+    c = a @ b
+    took = K.SPGEMM_STATS.get("kernel")
+    assert took == "small", took
+    K.SPGEMM_SMALL = False
+    try:
+        ref = a @ b
+        assert K.SPGEMM_STATS.get("kernel") != "small"
+    finally:
+        K.SPGEMM_SMALL = True
+    assert c.nnz == ref.nnz and torch.equal(c.indptr.long(), ref.indptr.long()) and torch.equal(c.indices.long(), ref.indices.long())
+    assert torch.equal(c.data, ref.data)
+    pick = np.sort(np.random.default_rng(2).choice(n_row, size=40, replace=False))
+    hA = [t.cpu().numpy() for t in (a.data, a.indices, a.indptr)]
+    hB = [t.cpu().numpy() for t in (b.data, b.indices, b.indptr)]
+    segs = [np.arange(hA[2][r], hA[2][r + 1]) for r in pick]
+    sub_ptr = np.zeros(len(pick) + 1, dtype=hA[2].dtype)
+    sub_ptr[1:] = np.cumsum([len(s) for s in segs])
+    sel = np.concatenate(segs)
+    wd, wi, wp = orc.dot_csr_csr((len(pick), n), hA[0][sel], hB[0], hA[1][sel], hB[1], sub_ptr, hB[2])
+    cp = c.indptr.cpu().numpy()
+    for j, r in enumerate(pick):
+        lo, hi = int(cp[r]), int(cp[r + 1])
+        o = np.argsort(wi[wp[j]:wp[j + 1]], kind="stable")
+        keep = wd[wp[j]:wp[j + 1]][o] != 0 if np.dtype(dtype).kind == "i" else wd[wp[j]:wp[j + 1]][o].view(np.uint64 if wd.itemsize == 8 else np.uint32) != 0
+        assert np.array_equal(c.indices[lo:hi].cpu().numpy(), wi[wp[j]:wp[j + 1]][o][keep])
+        assert np.array_equal(c.data[lo:hi].cpu().numpy(), wd[wp[j]:wp[j + 1]][o][keep])
+
+
+def test_bucket_kernel_spreads_few_columns_over_its_passes():
+    """float64 products of ~10^4 per row over 10^4 columns: the 8-pass class of the bucket kernel (csrc/spgemm_rows.hip) gave
+    pass 0 the first 4096 columns - 41 % of a row's products for a pass with room for 14 % - and declined 97 % of the rows
+    (round 6: columns spread over all buckets whatever their number)"""
+    import sparse_amd as sp
+    from sparse_amd import _kernels as K
+
+    g = sp.random((2000, 10_000), density=0.01, random_state=4, format="gcxs", compressed_axes=(0,))
+    h = sp.random((10_000, 10_000), density=0.0095, random_state=5, format="gcxs", compressed_axes=(0,))
+    K.SPGEMM_SMALL_SECOND = False
+    try:
+        c = g @ h
+        assert K.SPGEMM_STATS.get("kernel") == "buckets" and K.SPGEMM_STATS.get("heavy_or_declined", 0) < 20, dict(K.SPGEMM_STATS)
+    finally:
+        K.SPGEMM_SMALL_SECOND = True
+    c2 = g @ h
+    assert c.nnz == c2.nnz and torch.equal(c.indices.long(), c2.indices.long()) and torch.equal(c.data, c2.data)
