@@ -117,7 +117,11 @@ def _permute_reshape(x, axes, shape):
     # benchmarks/test_tensordot.py:52-68 - then skip the key permutation, its sort and the re-linearisation (6 of ~20 launches
     # at those sizes), and the 2-D form keeps ITS row pointers / CSR view across calls.  The reference memoises the same
     # conversions when asked to (`COO(cache=True)`, _coo/core.py:317-338); large operands are not kept (a second copy of them).
-    if not hasattr(x, "__dict__") or x.nnz > TDOT_VIEW_MAX_NNZ:
+    # (round 6: a contraction over the TRAILING axes in their own order permutes nothing - the 2-D form is a reshape that shares the
+    # operand's keys and values -, so it is kept whatever the size: a 1024^3 operand of 3 x 10^6 elements contracted with a
+    # 1024 x 512 matrix rebuilt its row pointers and its block stream at every call, 0.9 ms per call for a 0.5 ms product)
+    shares = list(axes) == list(range(len(axes)))
+    if not hasattr(x, "__dict__") or (x.nnz > TDOT_VIEW_MAX_NNZ and not shares):
         return x.transpose(axes).reshape(shape)
     _validate_derived(x)
     views = x.__dict__.setdefault("_tdot_views", {})
