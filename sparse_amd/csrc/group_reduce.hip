@@ -188,7 +188,11 @@ __global__ void __launch_bounds__(GR_THREADS) gr_count_kernel(const int64_t* __r
     for (int j = 0; j < GR_ITEMS; ++j) {
       if (base + j < n) {
         const GT g = gof(k[j]);
-        cnt += g != prev;
+        // (the array's first element starts a run WHATEVER its group: a key of group -1 - not a valid key, but what an
+        // unwritten buffer may hold when the slab merge in front declined its ranges and the caller has not read that yet -
+        // equals the "nothing before" mark, the array then had no run at all and the fix-up stored at run -1: a device fault,
+        // found by tools/fuzz_dense.py in round 6)
+        cnt += (g != prev) || (base + j == 0);
         prev = g;
       }
     }
@@ -243,7 +247,7 @@ gr_reduce_kernel(int op, const int64_t* __restrict__ keys, const T* __restrict__
     h[j] = false;
     if (base + j < n) {
       g[j] = gof(kk[j]);
-      h[j] = g[j] != prev;
+      h[j] = (g[j] != prev) || (base + j == 0);       // (as in gr_count_kernel: element 0 is a head whatever its group)
       prev = g[j];
       if (h[j]) {
         mine.heads += 1;
@@ -378,7 +382,10 @@ gr_fixup_kernel(int op, int64_t ntiles, const int64_t* __restrict__ tile_heads, 
 // part asks for everything a tile usually needs - its own and its left neighbour's head counts, the neighbour's open tail,
 // its own open head and first run - before looking at any of it (one memory round trip instead of five one behind the
 // other), and walks further back only when the neighbour has no head.  Same joins in the same order as the two kernels.
-constexpr int64_t GR_FIX_ONE_TILES = 16384;
+#ifndef SPAMD_GR_FIX_ONE_TILES
+#define SPAMD_GR_FIX_ONE_TILES 16384
+#endif
+constexpr int64_t GR_FIX_ONE_TILES = SPAMD_GR_FIX_ONE_TILES;
 
 template <typename T>
 __global__ void __launch_bounds__(1024)

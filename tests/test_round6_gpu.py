@@ -328,3 +328,31 @@ def test_bucket_kernel_spreads_few_columns_over_its_passes():
         K.SPGEMM_SMALL_SECOND = True
     c2 = g @ h
     assert c.nnz == c2.nnz and torch.equal(c.indices.long(), c2.indices.long()) and torch.equal(c.data, c2.data)
+
+
+def test_group_reduce_is_memory_safe_on_keys_that_are_no_keys():
+    """`x.prod(axis=0)` of a nearly dense array: the slab merge (csrc/lead_rotate.hip) declines its ranges (more than 64 elements
+    per cell), leaves its output buffers unwritten and says so in a device word the caller reads LATER - the grouped reduce
+    runs on whatever those buffers hold.  Recycled memory full of 0xff bytes (the merge's own boundary table) made every key
+    -1 = the kernels' "nothing before" mark: no run at all, and the boundary fix-up stored at run -1 - a device fault,
+    round 6, tools/fuzz_dense.py.  The first element is a run head whatever its group."""
+    from sparse_amd import _reduce as R
+
+    dev = torch.device("cuda:0")
+    n = 1_094_340
+    data = torch.randint(-9, 10, (n,), device=dev, dtype=torch.int64)
+    for keys in (torch.full((n,), -1, device=dev, dtype=torch.int64), torch.full((n,), -141, device=dev, dtype=torch.int64),
+                 torch.randint(-2 ** 62, 2 ** 62, (n,), device=dev, dtype=torch.int64)):
+        for op in ("multiply", "add"):
+            out = R.group_reduce(keys, 141, data, op, key_bound=1_155_072, sync=False)
+            torch.cuda.synchronize()
+            assert 1 <= int(out[3][0]) <= n
+    # and the reduction that met it: 141 x 64 x 64 x 2, about 5 % zeros, over the leading axis
+    import sparse_amd as sp
+
+    d = np.random.default_rng(5).integers(-9, 10, (141, 64, 64, 2)).astype(np.int64)
+    x = sp.COO.from_numpy(d)
+    junk = [torch.full((1 << 20,), -1, device=dev, dtype=torch.int64) for _ in range(6)]      # blocks of 0xff for the allocator to recycle
+    del junk
+    for name in ("prod", "sum", "max"):
+        assert np.array_equal(getattr(x, name)(axis=0).todense(), getattr(d, name)(axis=0))

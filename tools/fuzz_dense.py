@@ -11,6 +11,14 @@ rng = np.random.default_rng(seed)
 print("seed", seed, flush=True)
 t_end = time.time() + budget
 it = 0
+TRACE = len(sys.argv) > 3      # any third argument: print every iteration's case and synchronise after every section (to find a device fault)
+
+
+def mark(what):
+    if TRACE:
+        torch.cuda.synchronize()
+        print("  ok", what, flush=True)
+
 
 
 def rand_dense(shape, dtype, density):
@@ -41,6 +49,8 @@ while time.time() < t_end:
     d = rand_dense(shape, dtype, dens)
     x = sp.COO.from_numpy(d)
     ctx = (it, shape, np.dtype(dtype).name, dens)
+    if TRACE:
+        print(ctx, flush=True)
     assert close(x, d, dtype), ("roundtrip", ctx)
     # conversions
     if nd >= 1:
@@ -58,11 +68,13 @@ while time.time() < t_end:
                     g2 = g.change_compressed_axes((1 - ca[0],))
                     assert close(g2, d, dtype), ("swap", ctx)
                     assert close(g.T, d.T, dtype), ("gcxs.T", ctx)
+    mark("conversions")
     perm = tuple(rng.permutation(nd).tolist())
     assert close(x.transpose(perm), d.transpose(perm), dtype), ("transpose", perm, ctx)
     if d.size:
         news = (d.size,) if rng.random() < 0.5 else ((shape[0], d.size // shape[0]) if shape[0] else (d.size,))
         assert close(x.reshape(news), d.reshape(news), dtype), ("reshape", news, ctx)
+    mark("transpose/reshape")
     # elementwise with broadcasting
     bshape = tuple(s if rng.random() < 0.7 else 1 for s in shape)[int(rng.integers(0, nd)):]
     e = rand_dense(bshape, dtype, float(rng.choice([0.05, 0.5])))
@@ -70,6 +82,7 @@ while time.time() < t_end:
     for name, f in (("add", np.add), ("mul", np.multiply), ("max", np.maximum), ("sub", np.subtract)):
         assert close(f(x, y), f(d, e), dtype), (name, bshape, ctx)
     assert close(x * 3, d * 3, dtype) and close(-x, -d, dtype) and close(abs(x), abs(d), dtype), ("scalar", ctx)
+    mark("elementwise")
     # reductions
     for name in ("sum", "max", "min", "prod"):
         axes = [None] + [int(rng.integers(0, nd))] + ([tuple(sorted(rng.choice(nd, 2, replace=False).tolist()))] if nd >= 2 else [])
@@ -77,9 +90,30 @@ while time.time() < t_end:
             if name in ("max", "min") and (d.size == 0 or (ax is not None and any(shape[a] == 0 for a in (ax if isinstance(ax, tuple) else (ax,))))):
                 continue
             want = getattr(d, name)(axis=ax)
+            if TRACE and d.size > 500_000:
+                np.save("gpurun_out/fuzz_case.npy", d)
+                print("   reduce", name, ax, flush=True)
+                if name == "prod" and not getattr(sys, "_ffi_traced", False):      # every C-ABI call by name, synchronised: the last one printed faulted
+                    from sparse_amd import _ffi
+                    sys._ffi_traced = True
+                    real = _ffi.call
+
+                    def traced(fname, *a):
+                        print("      call", fname, [v for v in a if isinstance(v, int) and abs(v) < (1 << 40)][:8], flush=True)
+                        r = real(fname, *a)
+                        torch.cuda.synchronize()
+                        return r
+                    _ffi.call = traced
+                    import sparse_amd._kernels as _K, sparse_amd._reduce as _R
+                    for mod in (_K, _R):
+                        if hasattr(mod, "_ffi"):
+                            mod._ffi.call = traced
             got = getattr(x, name)(axis=ax)
+            if TRACE and d.size > 500_000:
+                torch.cuda.synchronize()
             # fp32 running sums drift like eps * n * |partial sum| (the reference's reduceat accumulates in fp32 too)
             assert close(got, want, dtype, atol=(1e-7 * d.size + 5e-5) if dtype == np.float32 and name in ('sum', 'prod') else None), (name, ax, ctx)
+    mark("reductions")
     # tensordot / matmul with a dense operand
     if nd >= 1 and np.dtype(dtype).kind == "f":
         kdim = shape[-1]
@@ -87,12 +121,16 @@ while time.time() < t_end:
         bd = (rng.random((kdim, n)) - 0.5).astype(dtype)
         bt = torch.from_numpy(bd).cuda()
         assert close(sp.tensordot(x, bt, axes=1), np.tensordot(d, bd, axes=1), dtype), ("tensordot", n, ctx)
+        mark(("tensordot", n))
         if nd == 2:
             assert close(x @ bt, d @ bd, dtype), ("matmul", n, ctx)
             g = sp.GCXS.from_coo(x, compressed_axes=(int(rng.integers(0, 2)),))
+            mark("matmul")
             assert close(g @ bt, d @ bd, dtype), ("gcxs matmul", n, ctx)
+            mark("gcxs matmul")
             x2 = sp.COO.from_numpy(rand_dense((shape[1], int(rng.choice([1, 7, 70]))), dtype, 0.2))
             assert close(x @ x2, d @ x2.todense(), dtype), ("spgemm", ctx)
+            mark("spgemm")
             ad = (rng.random((shape[0], 16)) - 0.5).astype(np.float32)
             bdn = (rng.random((shape[1], 16)) - 0.5).astype(np.float32)
             if dtype == np.float32:
