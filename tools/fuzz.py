@@ -119,7 +119,7 @@ while time.time() < t_end:
     n["spgemm"] += 1
     # ---- SDDMM: column-panel order (also of a subset) vs the mask's own order, bit for bit; both vs float64
     Ms, Ns = int(rng.integers(1, 3000)), int(rng.integers(1, 6000))
-    Ks = int(rng.choice([16, 64, 128, 200, 256, 512]))
+    Ks = int(rng.choice([16, 64, 96, 128, 192, 200, 256, 384, 512, 768]))       # (96 / 192 / 384 / 768: three vectors per lane, round 6)
     sdt = [torch.bfloat16, torch.float32, torch.float64][int(rng.integers(0, 3))]
     ns = int(min(Ms * Ns, rng.integers(0, 400_000)))
     m = sp.random((Ms, Ns), nnz=ns, random_state=int(rng.integers(1 << 30)), dtype=np.float64 if sdt == torch.float64 else np.float32,
