@@ -1026,7 +1026,10 @@ def _spgemm_rows(n_row, n_col, a_data, a_indices, a_indptr, b_data, b_indices, b
     SPGEMM_STATS.update(max_prod=max_prod, max_arow=max_arow, products=total)
     SPGEMM_STATS.pop("bitmap_failed", None)
     if _spgemm_small_second(vcode, n_row, n_col, total):
-        res = _spgemm_small(n_row, n_col, a_data, a_indices, a_indptr, b_data, b_indices, b_indptr, bound=total)
+        try:
+            res = _spgemm_small(n_row, n_col, a_data, a_indices, a_indptr, b_data, b_indices, b_indptr, bound=total)
+        except torch.OutOfMemoryError:       # (its buffers hold min(cells, products) entries: the other kernels need less)
+            res = None
         if res is not None:
             return res
     if SPGEMM_BITMAP and total and max_arow <= lim(vcode, 1) and total >= SPGEMM_BITMAP_MIN_MEAN * n_row:
