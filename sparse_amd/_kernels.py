@@ -856,9 +856,11 @@ SPGEMM_ROW_LOCAL = True  # tuning hook: False = always the global expand-sort-co
 
 SPGEMM_STATS = {}   # last row-local product: rows, rows left to the global form (diagnostics for the benches)
 SPGEMM_BITMAP = True            # wide rows of a matrix with <= 2^20 columns: csrc/spgemm_bitmap.hip (rows written in place)
-SPGEMM_BITMAP_MIN_MEAN = 1536   # mean products per row from which the per-row bitmap scan (n_col / 8 bytes of LDS) pays: measured
-#                                 at n_col = 10^6, 60000 rows (tools/r04/spgemm_sweep.py; ms buckets / bitmap): 900 products per row
-#                                 1.91 / 2.55, 2025: 3.36 / 2.89, 4096: 6.47 / 3.48, 6400: 8.13 / 4.44, 10^4: 13.95 / 6.45
+SPGEMM_BITMAP_MIN_MEAN = 1300   # mean products per row from which the per-row bitmap scan (n_col / 8 bytes of LDS) pays: measured
+#                                 at n_col = 10^6, 60000 rows (tools/r04/spgemm_sweep.py; ms buckets / bitmap), round 6 (the bitmap
+#                                 kernel of round 5): 400 products per row 1.07 / 2.31, 900: 1.79 / 2.40, 1296: 2.51 / 2.51,
+#                                 1600: 2.77 / 2.53, 2025: 3.09 / 2.59, 4096: 6.48 / 3.08, 6400: 8.02 / 3.84, 10^4: 14.0 / 5.34
+#                                 (round 4, when 1536 was chosen: 900: 1.91 / 2.55, 2025: 3.36 / 2.89, 10^4: 13.95 / 6.45)
 SPGEMM_BITMAP_MAX_DUPS = 120    # expected products per row that share an output element with an earlier one (list of 512)
 
 

@@ -4,7 +4,7 @@ sys.path.insert(0, "/root/repo")
 import sparse_amd as sp
 from sparse_amd import _kernels as K
 n = 1_000_000
-for per in (30, 45, 64, 80, 100):
+for per in (20, 30, 36, 40, 45, 64, 80, 100):
     dens = per / n
     gB = sp.random((n, n), density=dens, random_state=7, dtype=np.float32, idx_dtype=np.int32, format="gcxs", compressed_axes=(0,))
     rows = 60_000
