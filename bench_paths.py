@@ -264,7 +264,7 @@ def run(quick=False, only=None, verbose=True, int64_of=None):
             dv = data if dt_v == torch.float32 else data.to(dt_v)
             bv = b[:, :n_v].to(dt_v).contiguous()
             ms_rg, _ = timed(lambda: K.dot_csr_ndarray((M, n_v), dv, idx, ptr, bv, keep_order=True), reps=5)
-            ms_v, _ = timed(lambda: K.dot_csr_ndarray((M, n_v), dv, idx, ptr, bv), reps=10)
+            ms_v, _ = timed(lambda: K.dot_csr_ndarray((M, n_v), dv, idx, ptr, bv), reps=20, warm=5)   # (steady state, like the headline)
             ms_rv, _ = timed(lambda: K.dot_csr_ndarray((M, n_v), dv, idx, ptr, bv, rowvec=True), reps=5)
             es = dv.element_size()
             emit(f"A1_shapes_n{n_v}_{'f32' if es == 4 else 'f64'}",
