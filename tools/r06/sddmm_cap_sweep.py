@@ -1,4 +1,3 @@
-"""768-byte rows (fp32 K = 192, bf16 K = 384, f64 K = 96) in panel order: ms by the number of LDS slots for A rows per workgroup"""
 import sys
 sys.path.insert(0, "/root/repo")
 import torch
@@ -17,15 +16,12 @@ def timeit(f, n=10):
     for _ in range(n): r = f()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n, r
-for dt, Kd in ((torch.bfloat16, 384), (torch.float32, 192), (torch.float64, 96), (torch.bfloat16, 256)):
+for dt, Kd in ((torch.bfloat16, 384), (torch.float32, 192), (torch.bfloat16, 256), (torch.bfloat16, 128)):
     a = torch.rand(M, Kd, device=dev, generator=g).to(dt); bt = torch.rand(N, Kd, device=dev, generator=g).to(dt)
-    ref = K.sddmm_coo(coords, s, a, bt)
+    plan = K.sddmm_panels(coords, (M, N), K.sddmm_panel_width(bt))
     line = []
-    for width_scale in (1.0, 0.75, 0.5):
-        w = int(K.sddmm_panel_width(bt) * width_scale)
-        plan = K.sddmm_panels(coords, (M, N), w)
-        for ch in (0, 32, 36, 40, 44, 48, 56, 64):
-            plan.chunk = ch
-            t1, got = timeit(lambda: K.sddmm_coo(coords, s, a, bt, panels=plan))
-            line.append(f"w{w} cap{ch}: {t1:.3f}{'' if torch.equal(got, ref) else ' WRONG'}")
-    print(str(dt)[6:], Kd, " | ".join(line), flush=True)
+    for ch in (0, 48, 52, 56, 58, 60, 62, 64, 66, 72, 80, 96, 128):
+        plan.chunk = ch
+        t1, got = timeit(lambda: K.sddmm_coo(coords, s, a, bt, panels=plan))
+        line.append(f"cap{ch}: {t1:.3f}")
+    print(str(dt)[6:], Kd, "width", plan.width, " ".join(line), flush=True)
