@@ -1243,7 +1243,7 @@ def sddmm_panels(coords, shape, width, subset=None, xcd=None):
 def _sddmm_row_slots(panels, row_bytes, idx_bytes):
     """LDS slots for A rows per 256-element workgroup of the panel kernel (`chunk` of spamd_sddmm_panels): enough for the
     distinct rows such a workgroup meets - a row without a slot is fetched from memory and waited for on the spot - but not
-    past three workgroups per CU.  (Round 6, tools/r06/sddmm_cap_sweep2.py at config 4's mask: 768-byte rows, 61 distinct
+    past three workgroups per CU.  (Round 6, tools/r06/sddmm_cap_sweep.py at config 4's mask: 768-byte rows, 61 distinct
     rows per workgroup: 32 slots - the kernel's own default, 24 KB - 0.82 ms, 52: 1.00, 64: 0.59, 72-96: 0.64, 128: 1.07;
     512-byte rows, 41 distinct: 44-72 slots 0.324, 80-96: 0.356; 256-byte rows, 21 distinct: 48-72 slots 0.172, 96 - the
     default - 0.199.)"""
