@@ -417,6 +417,13 @@ int spamd_group_reduce(int op, int val_dtype, int64_t n, const int64_t* keys, in
  * synchronisation plus a copy command, ~20 us - as much as the kernels of a 10^6-element reduction. */
 int spamd_deliver_words(const int64_t* dev_words, int n, int64_t* host_words, int64_t marker, void* stream);
 
+/* out = in^T for a dense row-major matrix (elements of 1 / 2 / 4 / 8 bytes, moved bit-wise; ld_in >= cols, ld_out >= rows):
+ * out[c * ld_out + r] = in[r * ld_in + c].  `dense @ sparse` runs as (sparse^T @ dense^T)^T (the reference's dispatch,
+ * sparse/numba_backend/_common.py:339-503, hands the dense operand to the kernels transposed and contiguous,
+ * `np.ascontiguousarray`, _common.py:744); this is that copy through 64 x 64 LDS tiles. */
+int spamd_transpose_2d(int elem_bytes, int64_t rows, int64_t cols, const void* in, int64_t ld_in, void* out, int64_t ld_out,
+                       void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * A4 / A5  sparse x sparse     replaces `_csr_csr_count_nnz` + `_dot_csr_csr` / `_dot_coo_coo`
  *                              (sparse/numba_backend/_common.py:543-570,639-717,907-976)

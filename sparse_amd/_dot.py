@@ -805,7 +805,8 @@ def _dot(a, b, return_type=None):
 
     if _is_dense(a) and isinstance(b, GCXS):
         # dense @ sparse == (sparse.T @ dense.T).T ; sparse.T is free for 2-D GCXS
-        at = dev.to_device(a, b.device).t()
+        ad = dev.to_device(a, b.device)
+        at = ad.t()
         # the transposed view shares b's buffers; it is kept on b (and dropped with b's other derived layouts) so that
         # what it caches - the CSR twin of a csc operand, the K-tiled block streams of the executor - survives the call
         bt = b.__dict__.get("_t_view")
@@ -814,7 +815,7 @@ def _dot(a, b, return_type=None):
             b.__dict__["_t_view"] = bt
         if rk in (None, "ndarray"):
             # same kernels and the same inspector/executor policy as sparse @ dense (A1): (b^T a^T)^T
-            res = _gcxs_times_dense(bt, at.contiguous(), out_shape[::-1])
+            res = _gcxs_times_dense(bt, K.transposed_copy(ad), out_shape[::-1])
             return io.out(res.t())
         if bt.compressed_axes == (0,):
             data, indices, indptr = K.dot_csr_ndarray_sparse(out_shape[::-1], bt.data, bt.indices,

@@ -146,6 +146,7 @@ SIGNATURES = {
     "spamd_spmm_csr": (_int, [_int, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _u32, _vp]),
     "spamd_spmm_csr_ldsb": (_int, [_int, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _u32, _vp]),
     "spamd_deliver_words": (_int, [_vp, _int, _vp, _i64, _vp]),
+    "spamd_transpose_2d": (_int, [_int, _i64, _i64, _vp, _i64, _vp, _i64, _vp]),
     "spamd_spmm_csr_stream": (_int, [_int, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _u32, _vp]),
     "spamd_spmm_csr_stream_fits": (_int, [_int, _i64, _i64, _i64, _vp, _vp]),
     "spamd_spmm_csr_ldsb_fits": (_int, [_int, _i64, _i64, _i64, _vp, _i64, _vp, _i64]),

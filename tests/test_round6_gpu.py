@@ -356,3 +356,19 @@ def test_group_reduce_is_memory_safe_on_keys_that_are_no_keys():
     del junk
     for name in ("prod", "sum", "max"):
         assert np.array_equal(getattr(x, name)(axis=0).todense(), getattr(d, name)(axis=0))
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (3, 70), (64, 64), (65, 129), (128, 100_003), (1000, 1), (1, 5000), (257, 513)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.int32, torch.int16, torch.uint8, torch.bfloat16])
+def test_transposed_copy(shape, dtype):
+    """csrc/transpose.hip (the dense operand of `dense @ sparse`): the same bits as torch's `x.t().contiguous()`"""
+    from sparse_amd import _kernels as K
+
+    x = (torch.rand(shape, device="cuda", dtype=torch.float64) * 200 - 100).to(dtype)
+    got = K.transposed_copy(x)
+    want = x.t().contiguous()
+    assert got.shape == want.shape and got.dtype == want.dtype and got.is_contiguous()
+    assert torch.equal(got.view(torch.uint8) if dtype == torch.bfloat16 else got, want.view(torch.uint8) if dtype == torch.bfloat16 else want)
+    # a strided operand keeps torch's copy
+    y = x[:, ::2] if shape[1] > 1 else x
+    assert torch.equal(K.transposed_copy(y), y.t().contiguous())
