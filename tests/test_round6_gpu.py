@@ -368,7 +368,7 @@ def test_transposed_copy(shape, dtype):
     got = K.transposed_copy(x)
     want = x.t().contiguous()
     assert got.shape == want.shape and got.dtype == want.dtype and got.is_contiguous()
-    assert torch.equal(got.view(torch.uint8) if dtype == torch.bfloat16 else got, want.view(torch.uint8) if dtype == torch.bfloat16 else want)
+    assert torch.equal(got.float() if dtype == torch.bfloat16 else got, want.float() if dtype == torch.bfloat16 else want)
     # a strided operand keeps torch's copy
     y = x[:, ::2] if shape[1] > 1 else x
     assert torch.equal(K.transposed_copy(y), y.t().contiguous())
