@@ -11,6 +11,8 @@ rng = np.random.default_rng(seed)
 print("seed", seed, flush=True)
 t_end = time.time() + budget
 it = 0
+import os
+BIG = bool(os.environ.get("FUZZ_BIG"))
 TRACE = len(sys.argv) > 3      # any third argument: print every iteration's case and synchronise after every section (to find a device fault)
 
 
@@ -42,7 +44,11 @@ while time.time() < t_end:
     it += 1
     nd = int(rng.integers(1, 5))
     shape = tuple(int(rng.choice([0, 1, 2, 3, 5, 17, 64, 65])) if rng.random() < 0.85 else int(rng.integers(1, 200)) for _ in range(nd))
-    if np.prod(shape) > 2e6:
+    if BIG:       # (FUZZ_BIG=1: larger arrays - several tiles per kernel, runs across tiles, declined fast paths)
+        shape = tuple(int(rng.choice([1, 2, 3, 17, 64, 141, 257, 1000, 2049])) for _ in range(nd))
+        if not 2e5 < np.prod(shape) <= 2e7:
+            continue
+    if np.prod(shape) > (2e7 if BIG else 2e6):
         continue
     dtype = rng.choice([np.float64, np.float32, np.int64, np.int32])
     dens = float(rng.choice([0.0, 0.02, 0.3, 1.0]))
