@@ -57,6 +57,7 @@ def sddmm(s, a, b=None, *, bt=None):
     btt = dev.to_device(bt, sc.device) if bt is not None else dev.to_device(b, sc.device).t().contiguous()
     if at.shape[0] != s.shape[0] or btt.shape[0] != s.shape[1] or at.shape[1] != btt.shape[1]:
         raise ValueError("shape-mismatch for sum")
+    at, btt = K.sddmm_pad_inner(at, btt, sc.nnz)
     _validate_derived(sc)
     # plans depend on the pattern only and are kept on the mask (dropped with its other derived layouts when the
     # coordinates change): the populated 32 x 32 tiles that go to the matrix cores, and - when Bt is larger than an

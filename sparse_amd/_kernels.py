@@ -1163,6 +1163,29 @@ def sddmm_has_panels(dtype, Kd):
     return dtype in (torch.bfloat16, torch.float32, torch.float64) and bool(_ffi.lib().spamd_sddmm_has_panels(code_of(dtype), int(Kd)))
 
 
+SDDMM_PAD_MIN_NNZ = 200_000     # samples from which padding the inner dimension to a row-cached kernel's row length pays the two copies
+_SDDMM_ROW_BYTES = (256, 512, 768, 1024, 1536, 2048, 3072, 4096)      # rows the row-cached / panel kernels are instantiated for
+
+
+def sddmm_pad_inner(a, bt, nnz):
+    """(a, bt) with the inner dimension zero-padded to the next row length the row-cached kernels have, when that is at most
+    1.5x the rows' own length (round 6, tools/r06/sddmm_k_sweep.py: K = 96 or 100 in float32, 192 in bfloat16 - 384-byte rows -
+    ran through the generic gather, 0.61 / 0.85 ms at config 4's mask, without a panel order; as 512-byte rows 0.38 / 0.33 ms
+    plus two copies of ~0.03 ms).  Zeros add nothing to a dot product: the sums are those of the padded kernels' lane order,
+    in the mask's own order and in panel order alike."""
+    if a.dtype not in (torch.bfloat16, torch.float32, torch.float64) or a.dim() != 2 or nnz < SDDMM_PAD_MIN_NNZ:
+        return a, bt
+    esz, k = a.element_size(), int(a.shape[1])
+    if k == 0 or sddmm_has_panels(a.dtype, k):
+        return a, bt
+    rb = -(-k * esz // 16) * 16
+    want = next((w for w in _SDDMM_ROW_BYTES if w >= rb), None)
+    if want is None or want * 2 > rb * 3:
+        return a, bt
+    pad = want // esz - k
+    return torch.nn.functional.pad(a, (0, pad)), torch.nn.functional.pad(bt, (0, pad))
+
+
 def sddmm_panel_width(bt):
     """Bt rows per panel, or 0 when Bt fits the L2 as a whole or its K has no row-cached kernel (no panel order)."""
     row_bytes = int(bt.shape[1]) * bt.element_size()

@@ -301,3 +301,29 @@ def test_sddmm_tile_dispatch_traffic_model():
     coords = torch.from_numpy(np.stack([lin // N, lin % N]).astype(np.int32)).cuda()
     plan = K.sddmm_plan(coords, (M, N))
     assert plan.tiles.numel() == 0 and not K.sddmm_tiles_pay(plan, a, bt, K.sddmm_panel_width(bt))
+
+
+@pytest.mark.parametrize("dt, Kd", [("f32", 100), ("bf16", 200), ("f64", 48), ("f32", 33)])
+def test_sddmm_inner_dimensions_without_a_row_cached_kernel_are_padded(dt, Kd):
+    """From 200 000 samples on, an inner dimension whose rows have no row-cached kernel (384-byte rows: K = 96 or 100 in float32)
+    is zero-padded to the next one that has (round 6: the generic gather, without a panel order, took 2x as long); the sums
+    against the float64 evaluation, the padding switched off for comparison"""
+    import sparse_amd as sp
+    from sparse_amd import _kernels as K
+
+    rng = np.random.default_rng(Kd)
+    M, N, nnz = 3000, 5000, 250_000
+    tdt = {"bf16": torch.bfloat16, "f32": torch.float32, "f64": torch.float64}[dt]
+    s = sp.random((M, N), nnz=nnz, random_state=5, dtype=np.float64 if dt == "f64" else np.float32)
+    at = (torch.rand((M, Kd), device="cuda", dtype=torch.float64) - 0.5).to(tdt)
+    bt = (torch.rand((N, Kd), device="cuda", dtype=torch.float64) - 0.5).to(tdt)
+    pa, pb = K.sddmm_pad_inner(at, bt, nnz)
+    assert (pa.shape[1] > Kd) == (Kd != 33)        # (132-byte rows would become 256-byte ones: more than 1.5x, left alone)
+    r = sp.sddmm(s, at, bt=bt)
+    c = s.coords.cpu().numpy()
+    a64, b64 = at.double().cpu().numpy(), bt.double().cpu().numpy()
+    sv = s.data.double().cpu().numpy()
+    want = sv * np.einsum("ik,ik->i", a64[c[0]], b64[c[1]])
+    absum = np.abs(sv) * np.einsum("ik,ik->i", np.abs(a64[c[0]]), np.abs(b64[c[1]]))
+    got = r.todense()[c[0], c[1]]
+    assert np.all(np.abs(got - want) <= (1e-14 if dt == "f64" else 2e-6) * absum + 1e-300)
