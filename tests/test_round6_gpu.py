@@ -372,3 +372,30 @@ def test_transposed_copy(shape, dtype):
     # a strided operand keeps torch's copy
     y = x[:, ::2] if shape[1] > 1 else x
     assert torch.equal(K.transposed_copy(y), y.t().contiguous())
+
+
+def test_csr_times_dense_with_more_than_2_to_31_result_elements():
+    """17 x 10^6 rows x 128 columns = 2.2 x 10^9 result elements (8.7 GB): the executor (what `a @ b` takes here) and the
+    row-group kernel against a float64 evaluation of rows at the head, around element 2^31 and at the very end"""
+    import sparse_amd as sp
+    from bench import make_csr_device
+    from sparse_amd import _kernels as K
+
+    M, Kd, N = 17_000_000, 1000, 128
+    d, i, p = make_csr_device(M, Kd, 0.003, 9)
+    b = torch.rand((Kd, N), device="cuda") - 0.5
+    a = sp.GCXS((d, i, p), shape=(M, Kd), compressed_axes=(0,))
+    rows = np.concatenate([np.arange(0, 3), np.arange(16_777_214, 16_777_219), np.arange(M - 3, M)])
+    pc = p[torch.from_numpy(np.concatenate([rows, rows + 1])).cuda()].cpu().numpy().reshape(2, -1)
+
+    def check(c):
+        for k, r in enumerate(rows):
+            lo, hi = int(pc[0][k]), int(pc[1][k])
+            want = (d[lo:hi].double()[:, None] * b[i[lo:hi].long()].double()).sum(0)
+            assert torch.allclose(c[int(r)].double(), want, rtol=1e-5, atol=1e-6), int(r)
+
+    c = a @ b
+    assert getattr(a, "_tiled_layouts", None) and c.shape == (M, N)
+    check(c)
+    del c
+    check(K.dot_csr_ndarray((M, N), d, i, p, b, keep_order=True))
