@@ -20,6 +20,12 @@ def _is_scipy_sparse(x):
     return hasattr(x, "tocsr") and hasattr(x, "format") and type(x).__module__.startswith("scipy.sparse")
 
 
+def unified_index_dtype(indices_dtype, stored):
+    """The one index width of a GCXS whose `indices` and `indptr` arrive with different ones: the indices' width, unless
+    pointers of that width could not hold the number of stored elements."""
+    return torch.int64 if indices_dtype == torch.int32 and stored > 2 ** 31 - 1 else indices_dtype
+
+
 class GCXS(SparseArray, NDArrayOperatorsMixin):
     """Generalised compressed row/column storage on the device.
 
@@ -68,7 +74,13 @@ class GCXS(SparseArray, NDArrayOperatorsMixin):
         if self.indices.dtype not in (torch.int32, torch.int64):
             self.indices = self.indices.to(torch.int64)
         if self.indptr.dtype != self.indices.dtype:
-            self.indptr = self.indptr.to(self.indices.dtype)
+            # one index width for both arrays (the kernels take one): the indices' - unless the pointers then no longer hold
+            # the number of stored elements (round 6: int32 indices with int64 pointers of 2.25 x 10^9 elements were narrowed
+            # to int32 pointers here, and the first kernel that followed them faulted)
+            width = unified_index_dtype(self.indices.dtype, int(self.data.numel()))
+            if self.indices.dtype != width:
+                self.indices = self.indices.to(width)
+            self.indptr = self.indptr.to(width)
         if self.data.dim() != 1:
             raise ValueError("data must be a scalar or 1-dimensional.")
 

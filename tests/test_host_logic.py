@@ -407,3 +407,17 @@ def test_slab_merge_plan_of_leading_axis_reductions():
         if p is not None:
             cells, ranges = p
             assert cells & (cells - 1) == 0 and 1 <= cells <= 2048 and (ranges - 1) * cells < P <= ranges * cells
+
+
+def test_gcxs_index_width_follows_the_number_of_stored_elements():
+    """int32 indices with int64 pointers: one width for both - the indices' while int32 pointers can hold the number of stored
+    elements, int64 beyond (round 6: 2.25 x 10^9 elements had their pointers narrowed to int32; tools/r06/big_nnz_check.py runs
+    the products at that size on the GPU)"""
+    import torch
+
+    from sparse_amd._gcxs import unified_index_dtype
+
+    assert unified_index_dtype(torch.int32, 10) == torch.int32
+    assert unified_index_dtype(torch.int32, 2 ** 31 - 1) == torch.int32
+    assert unified_index_dtype(torch.int32, 2 ** 31) == torch.int64
+    assert unified_index_dtype(torch.int64, 5) == torch.int64
