@@ -408,6 +408,14 @@ int64_t spamd_group_reduce_ws_bytes(int val_dtype, int64_t n);
 int spamd_group_reduce(int op, int val_dtype, int64_t n, const int64_t* keys, int64_t divisor, int64_t key_bound,
                        const void* data, int64_t* group_ids, void* values, int64_t* counts, int64_t* n_groups, void* ws,
                        int64_t ws_bytes, void* stream);
+/* The same reduction when EVERY axis is reduced (`x.sum()`, `x.max()`, ... with axis=None; reference _sparse_array.py:372-437
+ * with axis = all axes: one group): the keys are not read.  Outputs in spamd_group_reduce's form, one entry each:
+ * group_ids[0] = 0, values[0], counts[0] = n, n_groups = {1, 0} ({0, ...} for n == 0).  One launch; pieces of the values
+ * are folded in a fixed order (reproducible).  ws: spamd_reduce_all_ws_bytes() bytes, 16-byte aligned, ZEROED once by the
+ * caller and then reusable by successive calls on one stream (the kernel leaves its ticket word zero). */
+int64_t spamd_reduce_all_ws_bytes(void);
+int spamd_reduce_all(int op, int val_dtype, int64_t n, const void* data, int64_t* group_ids, void* values, int64_t* counts,
+                     int64_t* n_groups, void* ws, int64_t ws_bytes, void* stream);
 
 /* n (1..16) device int64 words to the host WITHOUT a blocking copy: queued behind the stream's work, one thread stores
  * dev_words[0 .. n-1] into host_words[0 .. n-1] and then, with release semantics, `marker` into host_words[n].

@@ -68,6 +68,30 @@ def group_reduce(keys, divisor, data, op, key_bound=0, sync=True, ng=None):
     return gids[:count], vals[:count], counts[:count], count
 
 
+REDUCE_ALL_DIRECT = True
+_RA_WS = {}      # (device, stream) -> the zeroed workspace of spamd_reduce_all (its ticket word is left zero by every call)
+
+
+def reduce_all(data, op):
+    """Every element into ONE group without reading keys (C ABI `spamd_reduce_all`; reference _sparse_array.py:372-437 with
+    all axes reduced).  Returns device buffers in `group_reduce(..., sync=False)`'s form."""
+    dev = require_hip(data)
+    if data.dtype == torch.bool:
+        data = data.view(torch.uint8)
+    code = _ffi.U8 if data.dtype == torch.uint8 else code_of(data.dtype)
+    wkey = (dev, stream_ptr(dev))            # concurrent streams must not share the ticket word
+    ws = _RA_WS.get(wkey)
+    if ws is None:
+        ws = _RA_WS[wkey] = torch.zeros(int(_ffi.lib().spamd_reduce_all_ws_bytes()), dtype=torch.uint8, device=dev)
+    buf = torch.empty(5, dtype=torch.int64, device=dev)       # one allocation: id, value, count, [groups, equal-to-fill]
+    gids, counts, ng = buf[0:1], buf[2:3], buf[3:5]
+    vals = buf[1:2].view(data.dtype)[:1]
+    data = data.contiguous()
+    _ffi.call("spamd_reduce_all", _RED_OPS[op], code, int(data.numel()), ptr(data), ptr(gids), ptr(vals), ptr(counts), ptr(ng),
+              ptr(ws), int(ws.numel()), stream_ptr(dev))
+    return gids, vals, counts, ng
+
+
 def _scalar_dev(value, dtype, dev):
     return torch.tensor([value], dtype=dtype, device=dev)
 
@@ -222,7 +246,8 @@ def reduce_impl(x, method, axis=(0,), keepdims=False, _no_merge=False, **kwargs)
         data = data.view(torch.uint8)
 
     # move kept axes first (key permutation + stable sort), group id = key // n_cols
-    keys = x.linear_loc()
+    direct_all = not kept and REDUCE_ALL_DIRECT
+    keys = x.linear_loc() if not direct_all else None
     order = kept + tuple(axis)
     ng = None        # [groups, results equal to the fill value, "the slab merge gave up"]: one read-back below
     if order != tuple(range(x.ndim)) and x.nnz:
@@ -264,9 +289,12 @@ def reduce_impl(x, method, axis=(0,), keepdims=False, _no_merge=False, **kwargs)
         # of the implicit fill entries (reference :405-422) reads it from there and counts the results that equal the
         # result's fill value, and both numbers come back in a single copy (each `.item()` is a stream synchronisation,
         # which at config-1 sizes costs as much as the kernels)
-        n = int(keys.numel())
+        n = 1 if direct_all else int(keys.numel())      # the most groups there can be
         vcode = _ffi.U8 if data.dtype == torch.uint8 else code_of(data.dtype)
-        gids, vals, counts, ng = group_reduce(keys, max(n_cols, 1), data, name, key_bound=max(int(x.size), 1), sync=False, ng=ng)
+        if direct_all:   # one group: the keys say nothing
+            gids, vals, counts, ng = reduce_all(data, name)
+        else:
+            gids, vals, counts, ng = group_reduce(keys, max(n_cols, 1), data, name, key_bound=max(int(x.size), 1), sync=False, ng=ng)
         _ffi.call("spamd_reduce_fill_count", _RED_OPS[name], vcode, n, ptr(ng), ptr(vals), ptr(counts), int(n_cols),
                   fill_f, fill_i, eq_bits, ptr(ng) + 8, stream_ptr(dev))
         head = K.read_words(ng)      # (through pinned host memory: no blocking copy)

@@ -399,3 +399,64 @@ def test_csr_times_dense_with_more_than_2_to_31_result_elements():
     check(c)
     del c
     check(K.dot_csr_ndarray((M, N), d, i, p, b, keep_order=True))
+
+
+@pytest.mark.parametrize("n", [1, 5, 63, 511, 2049, 8192 * 4 + 3, 3_000_017, 40_000_003])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int32, np.int64])
+def test_everything_reduced_without_the_keys(n, dtype):
+    """axis=None: one group, found by `spamd_reduce_all` from the values alone (csrc/group_reduce.hip).  Exact for integers,
+    max / min; sums to re-association; the same results as the grouped path over the keys; the workspace's ticket word is
+    left ready (two calls in a row); a value array that starts off a 16-byte boundary takes the element-wise loads."""
+    import sparse_amd as sp
+    from sparse_amd import _reduce as R
+
+    rng = np.random.default_rng(n % 1000)
+    size = max(4 * n, 8)
+    lin = np.sort(rng.choice(size, size=n, replace=False)) if n < 5_000_000 else np.arange(n, dtype=np.int64) * 4 + 1
+    vals = (rng.integers(-9, 10, size=n) if np.dtype(dtype).kind == "i" else rng.random(n) - 0.3).astype(dtype)
+    vals[vals == 0] = 1
+    shape = (2, size // 2)
+    x = sp.COO(np.stack(np.unravel_index(lin, shape)), vals, shape=shape)
+    dense_sum = vals.sum(dtype=np.float64 if np.dtype(dtype).kind == "f" else np.int64)
+    for rep in range(2):
+        got = x.sum()
+        if np.dtype(dtype).kind == "i":
+            assert int(got) == int(dense_sum)
+        else:
+            assert abs(float(got) - float(dense_sum)) <= (1e-4 if dtype == np.float32 else 1e-10) * max(1.0, np.abs(vals).sum())
+    assert x.max() == max(vals.max(), 0) and x.min() == min(vals.min(), 0)
+    assert bool(x.any()) and not bool(x.all())
+    kd = x.sum(keepdims=True)
+    assert kd.shape == (1, 1)
+    R.REDUCE_ALL_DIRECT = False
+    try:
+        old = (x.max(), x.min(), x.sum())
+    finally:
+        R.REDUCE_ALL_DIRECT = True
+    assert old[0] == x.max() and old[1] == x.min()
+    if np.dtype(dtype).kind == "i":
+        assert old[2] == x.sum()
+    # the C ABI on a pointer 1 element past an aligned one
+    d = torch.from_numpy(vals).cuda()
+    if n > 1:
+        g, v, c, ng = R.reduce_all(d[1:], "add")
+        assert ng.tolist() == [1, 0] and int(c[0]) == n - 1 and int(g[0]) == 0
+        want = vals[1:].sum(dtype=np.float64 if np.dtype(dtype).kind == "f" else np.int64)
+        if np.dtype(dtype).kind == "i":
+            assert int(v[0]) == int(np.asarray(want).astype(dtype))
+        else:
+            assert abs(float(v[0]) - float(want)) <= (1e-4 if dtype == np.float32 else 1e-10) * max(1.0, np.abs(vals).sum())
+
+
+def test_everything_reduced_nan_rules_and_products():
+    """np.maximum propagates a NaN, np.fmax skips it, wherever it sits among the pieces; a product over all elements."""
+    import sparse_amd as sp
+
+    n = 2_100_000
+    vals = np.full(n, 0.5)
+    vals[n - 7] = np.nan
+    x = sp.COO(np.arange(n)[None, :] * 2, vals, shape=(2 * n,))
+    assert np.isnan(x.max()) and np.isnan(x.min())
+    assert sp.nanmax(x) == 0.5 and sp.nanmin(x) == 0.0
+    y = sp.COO(np.arange(40)[None, :], np.full(40, 2.0), shape=(40,), fill_value=1.0)
+    assert y.prod() == 2.0 ** 40
