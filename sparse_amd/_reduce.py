@@ -186,6 +186,11 @@ def reduce_impl(x, method, axis=(0,), keepdims=False, _no_merge=False, **kwargs)
             elif k2 is not None and len(ax) == 1 and not keepdims:   # (more axes / keepdims: the result's axes would need swapping back)
                 stand_in = COO._from_sorted_keys(k2, x.data, (x.shape[1], x.shape[0]), x.fill_value, idt)
                 axis = (1 - ax[0],)
+        if stand_in is None and REDUCE_ALL_DIRECT and x.size and (axis is None or set(
+                a % x.ndim for a in (axis if isinstance(axis, tuple) else (axis,)) if isinstance(a, int) and -x.ndim <= a < x.ndim
+                ) == set(range(x.ndim))) and _device_reducible(x, name, kwargs.get("dtype"), {k: v for k, v in kwargs.items() if k not in ("dtype", "out")}):
+            # every axis reduced: only the stored values matter (no coordinates, no keys: `spamd_reduce_all` below)
+            stand_in, axis = COO._from_sorted_keys(None, x.data, x.shape, x.fill_value, x.indices.dtype), None
         x = stand_in if stand_in is not None else x.tocoo()
     kwargs.pop("out", None)
     axis = normalize_axis(axis, x.ndim)
@@ -250,7 +255,7 @@ def reduce_impl(x, method, axis=(0,), keepdims=False, _no_merge=False, **kwargs)
     keys = x.linear_loc() if not direct_all else None
     order = kept + tuple(axis)
     ng = None        # [groups, results equal to the fill value, "the slab merge gave up"]: one read-back below
-    if order != tuple(range(x.ndim)) and x.nnz:
+    if order != tuple(range(x.ndim)) and x.nnz and not direct_all:       # (one group: in whatever order the axes are named)
         merged = None
         if not _no_merge and tuple(axis) == tuple(range(len(axis))) and n_groups > 0:
             # the reduced axes lead: the elements are n_cols sorted runs (one per index of those axes) - merged, not sorted

@@ -460,3 +460,28 @@ def test_everything_reduced_nan_rules_and_products():
     assert sp.nanmax(x) == 0.5 and sp.nanmin(x) == 0.0
     y = sp.COO(np.arange(40)[None, :], np.full(40, 2.0), shape=(40,), fill_value=1.0)
     assert y.prod() == 2.0 ** 40
+
+
+@pytest.mark.parametrize("ca", [(0,), (1,)])
+def test_gcxs_reduced_over_every_axis_needs_no_coordinates(ca):
+    """A GCXS with every axis reduced goes to `spamd_reduce_all` with its stored values alone (no conversion to COO); axis given
+    as None, as a tuple of all axes (negative too), with keepdims; 3-D; an operand dtype the kernels do not cover still
+    takes the host route."""
+    import sparse_amd as sp
+
+    x = sp.random((300, 200), density=0.05, random_state=5, format="gcxs", compressed_axes=ca)
+    d = x.todense()
+    for ax in (None, (0, 1), (-1, 0)):
+        assert abs(float(x.sum(axis=ax)) - d.sum()) < 1e-9
+        assert float(x.max(axis=ax)) == d.max() and float(x.min(axis=ax)) == d.min()
+    kd = x.sum(axis=None, keepdims=True)
+    assert kd.shape == (1, 1) and abs(float(kd.todense()[0, 0]) - d.sum()) < 1e-9
+    assert abs(float(x.sum(axis=(0,)).todense().sum()) - d.sum()) < 1e-9          # (one axis: the grouped path as before)
+    y = sp.random((20, 30, 40), density=0.05, random_state=6, format="gcxs")
+    assert abs(float(y.sum()) - y.todense().sum()) < 1e-9
+    assert abs(float(y.sum(axis=(0, 1, 2))) - y.todense().sum()) < 1e-9
+    with pytest.raises(Exception):
+        x.sum(axis=(0, 2))
+    c = sp.GCXS.from_numpy((d * (1 + 2j)).astype(np.complex128)) if hasattr(sp.GCXS, "from_numpy") else None
+    if c is not None:
+        assert abs(complex(c.sum()) - (d * (1 + 2j)).sum()) < 1e-9
