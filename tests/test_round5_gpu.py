@@ -459,7 +459,9 @@ def test_reductions_of_a_2d_gcxs_through_its_own_keys(sp, ca, axis):
             want = getattr(c, red)(axis=axis, keepdims=keep)
             assert type(got).__name__ == ("GCXS" if got.ndim else "COO") or got.ndim == 0
             gd, wd = np.asarray(got.todense()), np.asarray(want.todense())
-            assert gd.shape == wd.shape and np.array_equal(gd, wd)
+            # (every axis reduced: a GCXS sums its values in the order it stores them - compressed_axes=(1,): column-major -,
+            # so the sum equals the COO's only up to re-association)
+            assert gd.shape == wd.shape and (np.array_equal(gd, wd) or (axis == (0, 1) and np.allclose(gd, wd, rtol=1e-13, atol=0)))
             assert np.allclose(gd, npf(d, axis=axis, keepdims=keep), rtol=1e-12)
 
 

@@ -485,3 +485,35 @@ def test_gcxs_reduced_over_every_axis_needs_no_coordinates(ca):
     c = sp.GCXS.from_numpy((d * (1 + 2j)).astype(np.complex128)) if hasattr(sp.GCXS, "from_numpy") else None
     if c is not None:
         assert abs(complex(c.sum()) - (d * (1 + 2j)).sum()) < 1e-9
+
+
+@pytest.mark.parametrize("fmt", ["coo", "gcxs"])
+@pytest.mark.parametrize("axis", [None, 0, 1, (0, 1)])
+def test_variance_of_long_groups_and_nan_skipping_sums(fmt, axis):
+    """var / std sum their groups with the grouped reduce (a run of any length; with every axis reduced: spamd_reduce_all) and
+    the NaN-skipping sums replace NaNs on the value array: against NumPy on the dense twin, with and without NaNs, ddof."""
+    import sparse_amd as sp
+
+    rng = np.random.default_rng(3)
+    d = rng.random((3, 200_000)) * (rng.random((3, 200_000)) < 0.3)
+    x = sp.asarray(d, format=fmt) if fmt == "gcxs" else sp.COO.from_numpy(d)
+    for dd in (0, 1):
+        got = x.var(axis=axis, ddof=dd)
+        np.testing.assert_allclose(np.asarray(got.todense() if hasattr(got, "todense") else got), d.var(axis=axis, ddof=dd), rtol=1e-10, atol=1e-14)
+    got = x.std(axis=axis)
+    np.testing.assert_allclose(np.asarray(got.todense() if hasattr(got, "todense") else got), d.std(axis=axis), rtol=1e-10, atol=1e-14)
+    f32 = x.astype(np.float32).var(axis=axis)
+    np.testing.assert_allclose(np.asarray(f32.todense() if hasattr(f32, "todense") else f32), d.astype(np.float32).var(axis=axis), rtol=2e-4)
+    for planted in (False, True):
+        e = d.copy()
+        if planted:
+            e[0, 5] = e[2, 77] = e[1, 199_999] = np.nan
+        y = sp.asarray(e, format=fmt) if fmt == "gcxs" else sp.COO.from_numpy(e)
+        for name in ("nansum", "nanprod", "nanmean", "nanmax", "nanmin"):
+            got = getattr(sp, name)(y, axis=axis)
+            want = getattr(np, name)(e, axis=axis)
+            np.testing.assert_allclose(np.asarray(got.todense() if hasattr(got, "todense") else got), want, rtol=1e-10, atol=1e-14)
+    z = sp.COO.from_numpy(np.where(d > 0.5, d, 2.0), fill_value=2.0)        # a fill value that is not zero
+    got = z.var(axis=axis)
+    np.testing.assert_allclose(np.asarray(got.todense() if hasattr(got, "todense") else got), np.where(d > 0.5, d, 2.0).var(axis=axis),
+                               rtol=1e-10)
