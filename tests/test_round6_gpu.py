@@ -517,3 +517,43 @@ def test_variance_of_long_groups_and_nan_skipping_sums(fmt, axis):
     got = z.var(axis=axis)
     np.testing.assert_allclose(np.asarray(got.todense() if hasattr(got, "todense") else got), np.where(d > 0.5, d, 2.0).var(axis=axis),
                                rtol=1e-10)
+
+
+@pytest.mark.parametrize("ca", [(0,), (1,)])
+@pytest.mark.parametrize("idt", [np.int32, np.int64])
+def test_gcxs_slices_along_its_compressed_axis_without_a_coo(ca, idt):
+    """`x[a:b]`, `x[i]` (CSR) / `x[:, a:b]`, `x[:, j]` (CSC): a pointer range and the elements between its ends; the result keeps
+    the compressed axis (reference _compressed/indexing.py:14-176), equals NumPy's slice of the dense twin and works as an
+    operand (product, sum) - also for empty ranges, empty rows at the ends, negative bounds."""
+    import sparse_amd as sp
+    from sparse_amd import _gcxs as G
+
+    rng = np.random.default_rng(11)
+    d = rng.random((230, 170)) * (rng.random((230, 170)) < 0.1)
+    d[:7] = 0
+    d[100:103] = 0
+    d[:, 160:] = 0
+    x = sp.asarray(d, format="gcxs", compressed_axes=ca, idx_dtype=idt) if False else sp.GCXS(sp.COO.from_numpy(d), compressed_axes=ca, idx_dtype=idt)
+    n = d.shape[ca[0]]
+    pre = (slice(None),) * ca[0]
+    for sl in (slice(0, 5), slice(3, 120), slice(100, 103), slice(-40, None), slice(50, 50), slice(60, 20), slice(None), slice(n - 1, n + 5)):
+        key = pre + (sl,)
+        assert G._compressed_axis_slice(x, key) is not None
+        got = x[key]
+        assert isinstance(got, sp.GCXS) and got.compressed_axes == ca and got.shape == d[key].shape
+        assert got.indices.dtype == x.indices.dtype and got.indptr.dtype == x.indptr.dtype
+        assert np.array_equal(got.todense(), d[key])
+        if got.shape[0] and got.shape[1]:
+            b = rng.random((got.shape[1], 3))
+            np.testing.assert_allclose(got @ b, d[key] @ b, rtol=1e-12, atol=1e-14)
+            np.testing.assert_allclose(got.sum(axis=0).todense(), d[key].sum(axis=0), rtol=1e-12, atol=1e-14)
+    for i in (0, 8, 101, n - 1, -1, -n):
+        key = pre + (i,)
+        got = x[key]
+        assert got.shape == d[key].shape and np.array_equal(got.todense(), d[key])
+    with pytest.raises(IndexError):
+        x[pre + (n,)]
+    # other forms still take the general route
+    for key in ((slice(None, None, 2),), (slice(3, 9), slice(2, 5)), (np.array([1, 5]),), (None,)):
+        assert G._compressed_axis_slice(x, key) is None
+    assert np.array_equal(x[::2].todense(), d[::2]) and np.array_equal(x[3:9, 2:5].todense(), d[3:9, 2:5])
