@@ -225,10 +225,9 @@ def rccl_group():
     if dist.is_initialized():
         yield dist.group.WORLD
         return
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from conftest import init_single_rank_group
+
+    init_single_rank_group("nccl")
     yield dist.group.WORLD
     dist.destroy_process_group()
 

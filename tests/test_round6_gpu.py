@@ -200,14 +200,9 @@ def test_all_gather_csr_rebases_pointers_beyond_2_to_31():
         pytest.skip("needs ~60 GB of free HBM")
     started = False
     if not dist.is_initialized():
-        import os
-        import socket
+        from conftest import init_single_rank_group
 
-        s = socket.socket()
-        s.bind(("127.0.0.1", 0))
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s.getsockname()[1]))
-        s.close()
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        init_single_rank_group("nccl")
         started = True
     try:
         rows, per = 2_200_000, 1000
@@ -557,3 +552,40 @@ def test_gcxs_slices_along_its_compressed_axis_without_a_coo(ca, idt):
     for key in ((slice(None, None, 2),), (slice(3, 9), slice(2, 5)), (np.array([1, 5]),), (None,)):
         assert G._compressed_axis_slice(x, key) is None
     assert np.array_equal(x[::2].todense(), d[::2]) and np.array_equal(x[3:9, 2:5].todense(), d[3:9, 2:5])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32, np.int64, np.int32])
+def test_a_hot_coordinate_among_unique_ones_is_summed_by_the_grouped_reduce(dtype, monkeypatch):
+    """`COO(coords, data)` with 3 x 10^5 duplicates of one coordinate (and of a second one, at the end) among 2 x 10^5 unique
+    ones: the run-per-thread sum would walk the long runs alone (220 ms per 10^6 duplicates); the grouped reduce takes them.
+    Exact for integers, 1e-12 / 1e-5 for floats; without a long run the left-to-right sums are kept bit for bit."""
+    import sparse_amd as sp
+    from sparse_amd import _reduce as R
+
+    rng = np.random.default_rng(5)
+    hot, uniq = 300_000, 200_000
+    keys = np.concatenate([np.full(hot, 7), rng.choice(np.arange(8, 10_000_000), size=uniq, replace=False), np.full(hot, 10_000_001)])
+    vals = (rng.integers(-5, 6, size=keys.size) if np.dtype(dtype).kind == "i" else rng.random(keys.size)).astype(dtype)
+    perm = rng.permutation(keys.size)
+    keys, vals = keys[perm], vals[perm]
+    shape = (5000, 4000)
+    called = []
+    real = R.segment_reduce
+    monkeypatch.setattr(R, "segment_reduce", lambda *a, **k: (called.append(1), real(*a, **k))[1])
+    c = sp.COO(np.stack(np.unravel_index(keys, shape)), vals, shape=shape)
+    assert not called and c.nnz == uniq + 2
+    want = np.zeros(shape, dtype=np.float64 if np.dtype(dtype).kind == "f" else dtype)
+    np.add.at(want.reshape(-1), keys, vals)
+    got = c.todense()
+    if np.dtype(dtype).kind == "i":
+        assert np.array_equal(got, want)
+    else:
+        np.testing.assert_allclose(got, want, rtol=1e-12 if dtype == np.float64 else 1e-4)
+    # short runs only: the run-per-thread kernel, left to right
+    k2 = np.repeat(rng.choice(10_000_000, size=50_000, replace=False), 3)
+    v2 = rng.random(k2.size).astype(dtype) if np.dtype(dtype).kind == "f" else rng.integers(-5, 6, size=k2.size).astype(dtype)
+    c2 = sp.COO(np.stack(np.unravel_index(k2, shape)), v2, shape=shape)
+    assert called
+    order = np.argsort(k2, kind="stable")
+    seq = (v2[order].reshape(-1, 3)[:, 0] + v2[order].reshape(-1, 3)[:, 1]) + v2[order].reshape(-1, 3)[:, 2]
+    assert np.array_equal(c2.data.cpu().numpy(), seq)          # (sums that are zero stay stored: prune=False, as the reference's)
