@@ -432,6 +432,14 @@ int spamd_deliver_words(const int64_t* dev_words, int n, int64_t* host_words, in
 int spamd_transpose_2d(int elem_bytes, int64_t rows, int64_t cols, const void* in, int64_t ld_in, void* out, int64_t ld_out,
                        void* stream);
 
+/* Hub rows (round 6, csrc/hot_rows.hip): `_dot.py` multiplies an operand with a few rows far longer than the rest in two
+ * parts - the matrix without them and the hot rows cut into pieces that are rows of their own - through the CSR x dense kernels
+ * above (reference `_dot_csr_ndarray`, _common.py:720-755: one core walks such a row as one wave does here); this adds the
+ * pieces' results into the hot rows of the result: out[rows[h], :] = sum over v in [vfirst[h], vfirst[h + 1]) of part[v, :],
+ * in piece order.  val_dtype F32 | F64 | I32 | I64; vfirst has n_hot + 1 entries. */
+int spamd_hot_rows_combine(int val_dtype, int64_t n_hot, int64_t n_cols, const void* part, int64_t ld_part,
+                           const int64_t* vfirst, const int64_t* rows, void* out, int64_t ld_out, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * A4 / A5  sparse x sparse     replaces `_csr_csr_count_nnz` + `_dot_csr_csr` / `_dot_coo_coo`
  *                              (sparse/numba_backend/_common.py:543-570,639-717,907-976)

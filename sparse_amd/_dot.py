@@ -525,7 +525,7 @@ def _tiled_min_rows(row_bytes):
     return 45056 if panels == 1 else max(4096, 40960 // panels)
 
 
-DERIVED_CACHES = ("_mm_plans", "_keys2d", "_tdot_views", "_csr_of_t", "_csr_view", "_csr_twin", "_tiled_layouts", "_spmm_uses", "_nan_memo", "_derived_stamp", "_sddmm_plan", "_t_view", "_coo_view")
+DERIVED_CACHES = ("_mm_plans", "_keys2d", "_tdot_views", "_csr_of_t", "_csr_view", "_csr_twin", "_tiled_layouts", "_spmm_uses", "_nan_memo", "_derived_stamp", "_sddmm_plan", "_t_view", "_coo_view", "_hot_split")
 
 
 def drop_derived(a):
@@ -701,6 +701,106 @@ def _coo_first_product_tiled(nnz, row_bytes):
     return row_bytes > 512 and nnz * row_bytes >= COO_TILED_FIRST_BYTES
 
 
+HOT_ROW_SPLIT = True
+HOT_ROW_MIN = 4096            # stored elements from which a row is "hot" (one wave walks a row at ~27-120 ns per element)
+HOT_ROW_MIN_STREAM = 32768    # ... for the widths the stream kernel takes: it deals a row of 10^4 elements to its waves by
+                              # itself (0.05 ms against 0.13-0.18 in two parts), a row of 10^5 costs it 0.37 ms against 0.13
+HOT_ROW_MIN_NNZ = 1 << 16     # operands with fewer stored elements are not probed
+HOT_ROWS_MAX = 1024           # more hot rows than this: the matrix simply has long rows, nothing is split
+HOT_PIECE_GROUPS = 1024       # row groups (of 35 rows) the pieces of the hot rows should fill
+HOT_COMBINE_FAN = 128         # pieces a thread of the combine kernel adds in one loop
+
+
+def _hot_row_split(a, data, indices, indptr):
+    """None, or what `_gcxs_times_dense` needs to multiply an operand with a few hub rows in two parts (csrc/hot_rows.hip):
+    (the matrix without its hot rows, the hot rows cut into pieces that are rows of their own, first piece of every hot row,
+    the hot rows' numbers).  Found once per operand - the longest row from the row pointers, one small read - and kept with
+    it; both parts are GCXS arrays of their own, so their layouts are memoised like anybody's."""
+    from ._gcxs import GCXS
+    from ._reduce import reduce_all
+    from ._umath import binary_arrays
+
+    if "_hot_split" in a.__dict__:
+        return a.__dict__["_hot_split"]
+    res = None
+    M = int(indptr.numel()) - 1
+    nnz = int(data.numel())
+    if nnz >= HOT_ROW_MIN_NNZ and M >= 2 and not a.__dict__.get("_no_hot_split") and indptr.dtype in (torch.int32, torch.int64):
+        lens = binary_arrays("subtract", indptr[1:].clone(), indptr[:-1].contiguous())     # (the clone: an aligned start)
+        longest = int(reduce_all(lens, "maximum")[1])
+        if longest >= HOT_ROW_MIN:
+            devi = data.device
+            lens = lens.to(torch.int64)
+            ge = binary_arrays("greater_equal", lens, torch.tensor([HOT_ROW_MIN], dtype=torch.int64, device=devi), b_scalar=True,
+                               out_bool_as=torch.uint8)
+            flags = K.flag_ne_bits(ge, np.uint8(0))
+            offs = K.exclusive_scan(flags)
+            H = int(offs[-1])
+            if 1 <= H <= HOT_ROWS_MAX:
+                rows = K.compact(torch.arange(M, dtype=torch.int64, device=devi), flags, offs, H)
+                p64 = indptr.to(torch.int64)
+                p0 = K.gather(p64, rows).cpu().numpy()
+                hl = K.gather(lens, rows)
+                p1 = p0 + hl.cpu().numpy()
+                # the matrix without the hot rows: the stretches between them, and the pointers less what went before
+                cuts = np.concatenate(([0], np.stack([p0, p1], axis=1).reshape(-1), [nnz]))
+                keep = [(int(cuts[i]), int(cuts[i + 1])) for i in range(0, len(cuts), 2) if cuts[i + 1] > cuts[i]]
+                cat = lambda t, spans: (torch.cat([t[s:e] for s, e in spans]) if spans else t[:0].clone())
+                d = torch.zeros(M + 1, dtype=torch.int64, device=devi)
+                d[rows] = hl
+                removed = K.exclusive_scan(d)                               # [i] = hot elements in rows before i
+                light = GCXS((cat(data, keep), cat(indices, keep), (p64 - removed).to(indptr.dtype)), shape=(M, int(a.shape[1])),
+                             compressed_axes=(0,), fill_value=a.fill_value)
+                # the hot rows in pieces: enough of them to fill the chip, each a row of a (pieces x K) matrix
+                total = int((p1 - p0).sum())
+                piece = int(min(4096, max(32, total // (HOT_PIECE_GROUPS * 35) // 32 * 32)))
+                hot_spans = [(int(s), int(e)) for s, e in zip(p0, p1)]
+                vptr, vfirst, base = [0], [0], 0
+                for s, e in hot_spans:
+                    n = e - s
+                    vptr.extend(base + np.minimum(np.arange(piece, n + piece, piece), n))
+                    vfirst.append(len(vptr) - 1)
+                    base += n
+                hotv = GCXS((cat(data, hot_spans), cat(indices, hot_spans),
+                             torch.tensor(np.asarray(vptr, dtype=np.int64), device=devi).to(indptr.dtype)),
+                            shape=(len(vptr) - 1, int(a.shape[1])), compressed_axes=(0,), fill_value=a.fill_value)
+                light.__dict__["_no_hot_split"] = hotv.__dict__["_no_hot_split"] = True
+                # a thread of the combine kernel adds the pieces of its row one after the other: rows of more than
+                # HOT_COMBINE_FAN pieces are added in two levels (31 250 pieces in one loop: 6.8 ms)
+                mid = None
+                if max(b - a_ for a_, b in zip(vfirst[:-1], vfirst[1:])) > HOT_COMBINE_FAN:
+                    g1, f2 = [0], [0]
+                    for a_, b in zip(vfirst[:-1], vfirst[1:]):
+                        g1.extend(min(s0 + HOT_COMBINE_FAN, b) for s0 in range(a_, b, HOT_COMBINE_FAN))
+                        f2.append(len(g1) - 1)
+                    mid = (torch.tensor(np.asarray(g1, dtype=np.int64), device=devi),
+                           torch.arange(len(g1) - 1, dtype=torch.int64, device=devi))
+                    vfirst = f2
+                res = (light, hotv, torch.tensor(np.asarray(vfirst, dtype=np.int64), device=devi), rows, mid, longest)
+    a.__dict__["_hot_split"] = res
+    return res
+
+
+_HOT_COMBINE_TYPES = (torch.float32, torch.float64, torch.int32, torch.int64)
+
+
+def _hot_product(split, bt, out_shape):
+    light, hotv, vfirst, rows, mid = split[:5]
+    N = int(out_shape[1])
+    out = _gcxs_times_dense(light, bt, out_shape)
+    part = _gcxs_times_dense(hotv, bt, (int(hotv.shape[0]), N))
+    if part.dtype != out.dtype or out.dtype not in _HOT_COMBINE_TYPES or not (out.is_contiguous() and part.is_contiguous()):
+        raise _ffi.HipBackendError(f"hot-row parts of types {out.dtype} / {part.dtype} cannot be combined")
+    code, st = dev.code_of(out.dtype), dev.stream_ptr(out.device)
+    if mid is not None:
+        g1, ident = mid
+        tmp = torch.empty((int(ident.numel()), N), dtype=out.dtype, device=out.device)
+        _ffi.call("spamd_hot_rows_combine", code, int(ident.numel()), N, dev.ptr(part), N, dev.ptr(g1), dev.ptr(ident), dev.ptr(tmp), N, st)
+        part = tmp
+    _ffi.call("spamd_hot_rows_combine", code, int(rows.numel()), N, dev.ptr(part), N, dev.ptr(vfirst), dev.ptr(rows), dev.ptr(out), N, st)
+    return out
+
+
 def _gcxs_times_dense(a, bt, out_shape):
     """GCXS or canonical 2-D COO times dense."""
     from ._coo import COO
@@ -714,6 +814,13 @@ def _gcxs_times_dense(a, bt, out_shape):
         direct = False
     if not direct:
         data, indices, indptr = _csr_triplet(a)
+        if HOT_ROW_SPLIT and not _settings.EXACT_MULADD and int(out_shape[1]) > 0 and \
+                K.torch_dtype(K.dot_dtype(data.dtype, bt.dtype)) in _HOT_COMBINE_TYPES:
+            split = _hot_row_split(a, data, indices, indptr)
+            if split is not None and (split[5] >= HOT_ROW_MIN_STREAM or not (
+                    int(out_shape[1]) <= K.STREAM_MULTI_MAX_N and K.stream_passes(
+                        int(out_shape[0]), Kd, int(out_shape[1]), K.torch_dtype(K.dot_dtype(data.dtype, bt.dtype)), data, indices))):
+                return _hot_product(split, bt, out_shape)
     use_tiled = eligible = _tiled_eligible(data, bt, out_shape, Kd)
     if use_tiled and not direct and out_shape[1] <= K.STREAM_MULTI_MAX_N and not (
             _settings.EXACT_MULADD and _tiled_dtype(data, bt).is_floating_point):

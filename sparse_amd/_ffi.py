@@ -126,6 +126,7 @@ SIGNATURES = {
     "spamd_reduce_fill_count": (_int, [_int, _int, _i64, _vp, _vp, _vp, _i64, _C.c_double, _i64, _C.c_uint64, _vp, _vp]),
     "spamd_group_reduce_ws_bytes": (_i64, [_int, _i64]),
     "spamd_group_reduce": (_int, [_int, _int, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "spamd_hot_rows_combine": (_int, [_int, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "spamd_reduce_all_ws_bytes": (_i64, []),
     "spamd_reduce_all": (_int, [_int, _int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "spamd_spmm_tiled_params": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -589,3 +589,49 @@ def test_a_hot_coordinate_among_unique_ones_is_summed_by_the_grouped_reduce(dtyp
     order = np.argsort(k2, kind="stable")
     seq = (v2[order].reshape(-1, 3)[:, 0] + v2[order].reshape(-1, 3)[:, 1]) + v2[order].reshape(-1, 3)[:, 2]
     assert np.array_equal(c2.data.cpu().numpy(), seq)          # (sums that are zero stay stored: prune=False, as the reference's)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int64])
+@pytest.mark.parametrize("form", ["csr", "csc", "coo"])
+def test_hub_rows_are_multiplied_in_pieces(dtype, form):
+    """A matrix with two hub rows (15 000 and 5000 stored elements beside 3 per row) is multiplied as (matrix without them) +
+    (their pieces as rows of their own) + `spamd_hot_rows_combine`: results as SciPy's on the host for 1 .. 128 columns,
+    integers exact; the split is found once and kept with the operand; an operand without hub rows is left alone."""
+    import scipy.sparse as ss
+
+    import sparse_amd as sp
+    from sparse_amd import _dot as D
+
+    rng = np.random.default_rng(8)
+    M, Kd = 150_000, 20_000
+    r = np.concatenate([rng.integers(0, M, size=3 * M), np.full(15_000, 4242), np.full(5000, M - 1)])
+    c = np.concatenate([rng.integers(0, Kd, size=3 * M), rng.choice(Kd, size=15_000, replace=False), rng.choice(Kd, size=5000, replace=False)])
+    v = (rng.integers(-4, 5, size=r.size) if np.dtype(dtype).kind == "i" else rng.random(r.size) - 0.5).astype(dtype)
+    host = ss.coo_matrix((v, (r, c)), shape=(M, Kd)).tocsr()
+    host.sum_duplicates()
+    a = sp.GCXS.from_scipy_sparse(host) if form == "csr" else (
+        sp.GCXS.from_scipy_sparse(host.tocsc()) if form == "csc" else sp.COO.from_scipy_sparse(host))
+    for n in (1, 4, 16, 128):
+        b = (rng.integers(-3, 4, size=(Kd, n)) if np.dtype(dtype).kind == "i" else rng.random((Kd, n)) - 0.5).astype(dtype)
+        got = np.asarray(a @ b)
+        want = host @ b
+        if np.dtype(dtype).kind == "i":
+            assert np.array_equal(got, want)
+        else:
+            np.testing.assert_allclose(got, want, rtol=2e-4 if dtype == np.float32 else 1e-11, atol=2e-4 if dtype == np.float32 else 1e-11)
+    split = a.__dict__.get("_hot_split")
+    if form != "csc" or split is not None:       # (a CSC operand may go through its own inspector, which needs no CSR twin)
+        assert split is not None and sorted(split[3].tolist()) == [4242, M - 1]
+        assert split[0].nnz + split[1].nnz == a.nnz and split[0].shape == (M, Kd)
+        assert split[4] is not None          # (15 000 elements in pieces of 32: two levels of the combine)
+    plain = sp.GCXS.from_scipy_sparse(host[:4000])
+    plain @ np.ones((Kd, 4), dtype=dtype)
+    assert plain.__dict__.get("_hot_split", None) is None
+    D.HOT_ROW_SPLIT = False
+    try:
+        a2 = sp.GCXS.from_scipy_sparse(host)
+        b = (rng.integers(-3, 4, size=(Kd, 8)) if np.dtype(dtype).kind == "i" else rng.random((Kd, 8)) - 0.5).astype(dtype)
+        ref = np.asarray(a2 @ b)
+    finally:
+        D.HOT_ROW_SPLIT = True
+    np.testing.assert_allclose(np.asarray(a @ b), ref, rtol=2e-4 if dtype == np.float32 else 1e-11, atol=2e-4 if dtype == np.float32 else 1e-11)
