@@ -35,7 +35,6 @@ def _index_tensor(coords, device, idx_dtype=None):
 
 
 SUM_RUNS_PROBE_MIN = 1 << 12      # fewer elements: even one run of all of them is short work
-SUM_RUNS_LONG = 2048
 
 class COO(SparseArray, NDArrayOperatorsMixin):
     """Coordinate-format sparse array on the HIP device.
@@ -191,7 +190,7 @@ class COO(SparseArray, NDArrayOperatorsMixin):
     def _sum_runs(self, keys):
         """Keep the first coordinate of each run of equal keys and sum the run's data left to
         right in the data dtype (`np.add.reduceat`, reference core.py:1340-1353)."""
-        from ._reduce import group_reduce, reduce_all, segment_reduce
+        from ._reduce import group_reduce, has_long_run, segment_reduce
 
         flags = K.flag_heads(keys)
         offs = K.exclusive_scan(flags)
@@ -200,13 +199,12 @@ class COO(SparseArray, NDArrayOperatorsMixin):
         if self.data.dtype in K._CODE_T and self.data.dtype != torch.bool and keys.numel() >= SUM_RUNS_PROBE_MIN \
                 and self.data.is_contiguous() and self.data.data_ptr() % 16 == 0 and keys.data_ptr() % 16 == 0:
             # a run per thread (or per wave) is what a hot coordinate must not meet: 10^6 duplicates of ONE coordinate among
-            # 10^6 others took 220 ms, 10^7 2.4 s (tools/r06/dup_hot.py).  The grouped reduce sums runs of any length at
-            # streaming speed and tells their lengths; its sums are kept when a run is longer than SUM_RUNS_LONG (there the
-            # reference's reduceat is pairwise, not left-to-right, so no order is "the" order), the run-per-thread sums
-            # - left to right, the reference's bits for runs under 8 - otherwise.
-            _, vals, counts, _ = group_reduce(keys, 1, self.data, "add", key_bound=max(int(self.size), 1), sync=False)
-            if int(reduce_all(counts[:count], "maximum")[1]) > SUM_RUNS_LONG:
-                data = vals[:count]
+            # 10^6 others took 220 ms, 10^7 2.4 s (tools/r06/dup_hot.py).  When the scan of the head flags shows a window of
+            # 1024 elements without a head (`has_long_run`: n / 1024 words read), the grouped reduce sums the runs - any
+            # length, at streaming speed; there the reference's reduceat is pairwise, not left-to-right, so no order is "the"
+            # order.  Otherwise the run-per-thread sums: left to right, the reference's bits for runs under 8.
+            if has_long_run(offs):
+                data = group_reduce(keys, 1, self.data, "add", key_bound=max(int(self.size), 1), sync=False)[1][:count]
         self.data = data if data is not None else segment_reduce(self.data, flags, offs, count, "add")
         self.coords = K.compact(self.coords, flags, offs, count)
         self._keys = K.compact(keys, flags, offs, count)

@@ -808,6 +808,8 @@ def dot_ndarray_coo_sparse(a, coords, data, out_shape, as_keys=False, st=None):
 
 
 SPGEMM_CHUNK_PRODUCTS = 1 << 27  # products expanded/sorted at a time (bounds workspace to ~5 GB)
+SPGEMM_RUN_PROBE_MIN = 1 << 13   # chunks with fewer products: even one output element holding all of them is short work
+SPGEMM_RUN_LONG = True           # False: always the one-thread-per-element sums (tests)
 
 
 def _spgemm_keys(n_row, n_col, a_data, a_indices, a_rows, b_data, b_indices, b_indptr):
@@ -856,7 +858,19 @@ def _spgemm_keys(n_row, n_col, a_data, a_indices, a_rows, b_data, b_indices, b_i
             heads = flag_heads(keys)
             ho = exclusive_scan(heads)
             c = int(ho[-1])
-            out_vals.append(segment_reduce(vals, heads, ho, c, "add", sequential=True))
+            summed = None
+            if P >= SPGEMM_RUN_PROBE_MIN and P - c >= 1023 and dtr in _CODE_T and dtr != torch.bool:
+                # one thread per output element adds its products left to right (the reference's `sums[j] += ...` order, bit for
+                # bit) - and walks alone when an element has 5 x 10^4 of them (the diagonal element of a hub row in a @ a.T:
+                # 10.5 ms of a 15 ms product, tools/r06/spgemm_hub.py).  When the scan of the head flags shows a window of 1024
+                # products without a head (`has_long_run`: P / 1024 words read; P - c products share their element with an
+                # earlier one - fewer than a long run's, and there is none), the grouped reduce adds the runs - any length,
+                # streaming speed, re-associated: 1e-12 / 1e-5 relative.
+                from ._reduce import group_reduce, has_long_run
+
+                if SPGEMM_RUN_LONG and has_long_run(ho):
+                    summed = group_reduce(keys, 1, vals, "add", key_bound=max(n_row * n_col, 1), sync=False)[1][:c]
+            out_vals.append(summed if summed is not None else segment_reduce(vals, heads, ho, c, "add", sequential=True))
             out_keys.append(compact(keys, heads, ho, c))
         p = q
     if not out_keys:

@@ -92,6 +92,28 @@ def reduce_all(data, op):
     return gids, vals, counts, ng
 
 
+LONG_RUN_WINDOW = 1024
+
+
+def has_long_run(offs, window=None):
+    """`offs` = the exclusive scan of head flags (n + 1 entries).  True when some aligned window of `window` consecutive
+    elements holds no head - a run of at least `window` elements exists, and every run of 2 x window - 1 or more is seen -,
+    from every window-th entry of the scan alone (n / 1024 words): what the callers that sum runs with one thread per run
+    (left to right, the reference's order) ask before they do, since such a thread walks a long run alone at ~0.2 us per
+    element."""
+    from ._umath import binary_arrays
+
+    window = window or LONG_RUN_WINDOW
+    n = int(offs.numel()) - 1
+    if n < window:
+        return False
+    s = offs[0:n + 1:window].contiguous()
+    if s.numel() < 2:
+        return False
+    same = binary_arrays("equal", s[1:].clone(), s[:-1].contiguous(), out_bool_as=torch.uint8)
+    return bool(int(reduce_all(same, "logical_or")[1]))
+
+
 def _scalar_dev(value, dtype, dev):
     return torch.tensor([value], dtype=dtype, device=dev)
 

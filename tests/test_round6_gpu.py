@@ -635,3 +635,37 @@ def test_hub_rows_are_multiplied_in_pieces(dtype, form):
     finally:
         D.HOT_ROW_SPLIT = True
     np.testing.assert_allclose(np.asarray(a @ b), ref, rtol=2e-4 if dtype == np.float32 else 1e-11, atol=2e-4 if dtype == np.float32 else 1e-11)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32, np.int64])
+def test_sparse_product_with_an_output_element_of_many_products(dtype):
+    """a @ a.T with a hub row: the diagonal element of that row is the sum of 8000 products - a run the one-thread-per-element
+    sum would walk alone; the grouped reduce takes it (`_kernels._spgemm_keys`).  Against SciPy; integers exact; the same
+    result (to re-association) as with the probe switched off."""
+    import scipy.sparse as ss
+
+    import sparse_amd as sp
+    from sparse_amd import _kernels as K
+
+    rng = np.random.default_rng(4)
+    n = 20_000
+    r = np.concatenate([rng.integers(0, n, size=5 * n), np.full(8000, 321)])
+    c = np.concatenate([rng.integers(0, n, size=5 * n), rng.choice(n, size=8000, replace=False)])
+    v = (rng.integers(-3, 4, size=r.size) if np.dtype(dtype).kind == "i" else rng.random(r.size) - 0.5).astype(dtype)
+    h = ss.coo_matrix((v, (r, c)), shape=(n, n)).tocsr()
+    h.sum_duplicates()
+    a = sp.GCXS.from_scipy_sparse(h)
+    want = (h @ h.T).toarray()
+    got = (a @ a.T).todense()
+    old = K.SPGEMM_RUN_LONG
+    K.SPGEMM_RUN_LONG = False
+    try:
+        ref = (a @ a.T).todense()
+    finally:
+        K.SPGEMM_RUN_LONG = old
+    if np.dtype(dtype).kind == "i":
+        assert np.array_equal(got, want) and np.array_equal(ref, want)
+    else:
+        tol = dict(rtol=1e-11, atol=1e-11) if dtype == np.float64 else dict(rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(got, want, **tol)
+        np.testing.assert_allclose(got, ref, **tol)
