@@ -669,3 +669,37 @@ def test_sparse_product_with_an_output_element_of_many_products(dtype):
         tol = dict(rtol=1e-11, atol=1e-11) if dtype == np.float64 else dict(rtol=2e-4, atol=2e-4)
         np.testing.assert_allclose(got, want, **tol)
         np.testing.assert_allclose(got, ref, **tol)
+
+
+@pytest.mark.parametrize("axis", [0, 1, -1])
+def test_gcxs_matrices_joined_along_their_compressed_axis(axis):
+    """`concatenate` of matrices compressed along the joined axis appends the arrays and shifts the pointers
+    (`_batched._concatenate_compressed`): the dense result of NumPy's concatenate, a GCXS compressed along that axis, the same
+    arrays as the route through COO; mixed value and index types, an operand without rows, one without stored elements."""
+    import sparse_amd as sp
+    from sparse_amd import _batched as B
+
+    rng = np.random.default_rng(2)
+    ax = axis % 2
+    shapes = [(40, 30), (0, 30), (25, 30), (7, 30)] if ax == 0 else [(30, 40), (30, 0), (30, 25), (30, 7)]
+    ds = [rng.random(s) * (rng.random(s) < 0.2) for s in shapes]
+    ds[3][:] = 0
+    ds[2] = ds[2].astype(np.float32)
+    xs = [sp.GCXS(sp.COO.from_numpy(d), compressed_axes=(ax,), idx_dtype=(np.int64 if k == 2 else np.int32)) for k, d in enumerate(ds)]
+    assert B._concatenate_compressed(xs, axis, None) is not None
+    got = sp.concatenate(xs, axis=axis)
+    want = np.concatenate(ds, axis=axis)
+    assert isinstance(got, sp.GCXS) and got.compressed_axes == (ax,) and got.shape == want.shape and got.dtype == want.dtype
+    assert got.indices.dtype == torch.int64 and got.indptr.dtype == torch.int64
+    assert np.array_equal(got.todense(), want)
+    slow = sp.concatenate([x.tocoo() for x in xs], axis=axis).asformat("gcxs", compressed_axes=(ax,))
+    assert np.array_equal(slow.data.cpu().numpy(), got.data.cpu().numpy())
+    assert np.array_equal(slow.indices.cpu().numpy(), got.indices.cpu().numpy())
+    assert np.array_equal(slow.indptr.cpu().numpy(), got.indptr.cpu().numpy())
+    b = rng.random((want.shape[1], 3))
+    np.testing.assert_allclose(got @ b, want @ b, rtol=1e-12, atol=1e-14)
+    # the other axis, a requested layout, a different fill value: the general route
+    assert B._concatenate_compressed(xs[:1] + xs[2:3], 1 - ax, None) is None
+    assert B._concatenate_compressed(xs, axis, (1 - ax,)) is None
+    with pytest.raises(ValueError):
+        sp.concatenate([xs[0], sp.GCXS(sp.COO.from_numpy(ds[2] + 1.0, fill_value=1.0), compressed_axes=(ax,))], axis=axis)
