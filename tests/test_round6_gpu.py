@@ -703,3 +703,35 @@ def test_gcxs_matrices_joined_along_their_compressed_axis(axis):
     assert B._concatenate_compressed(xs, axis, (1 - ax,)) is None
     with pytest.raises(ValueError):
         sp.concatenate([xs[0], sp.GCXS(sp.COO.from_numpy(ds[2] + 1.0, fill_value=1.0), compressed_axes=(ax,))], axis=axis)
+
+
+@pytest.mark.parametrize("ca", [(0,), (1,)])
+@pytest.mark.parametrize("idt", [np.int32, np.int64])
+def test_gcxs_slices_along_its_uncompressed_axis_without_a_coo(ca, idt):
+    """`x[:, a:b]` (CSR) / `x[a:b]` (CSC): the elements inside the range compacted, the pointers read from the scan
+    (`_gcxs._uncompressed_axis_slice`); NumPy's slice of the dense twin, the layout and index widths kept, usable as an operand."""
+    import sparse_amd as sp
+    from sparse_amd import _gcxs as G
+
+    rng = np.random.default_rng(12)
+    d = rng.random((210, 190)) * (rng.random((210, 190)) < 0.1)
+    d[:, :9] = 0
+    d[50:60] = 0
+    x = sp.GCXS(sp.COO.from_numpy(d), compressed_axes=ca, idx_dtype=idt)
+    un = 1 - ca[0]
+    n = d.shape[un]
+    pre = (slice(None),) * un
+    for sl in (slice(0, 9), slice(5, 100), slice(-30, None), slice(70, 70), slice(90, 20), slice(1, n), slice(n - 1, n + 9), slice(None)):
+        key = pre + (sl,)
+        assert G._uncompressed_axis_slice(x, key) is not None or ca == (1,) and G._compressed_axis_slice(x, key) is not None
+        got = x[key]
+        assert isinstance(got, sp.GCXS) and got.compressed_axes == ca and got.shape == d[key].shape
+        assert got.indices.dtype == x.indices.dtype and got.indptr.dtype == x.indptr.dtype
+        assert np.array_equal(got.todense(), d[key])
+        if got.shape[0] and got.shape[1]:
+            b = rng.random((got.shape[1], 3))
+            np.testing.assert_allclose(got @ b, d[key] @ b, rtol=1e-12, atol=1e-14)
+            np.testing.assert_allclose(got.sum(axis=1).todense(), d[key].sum(axis=1), rtol=1e-12, atol=1e-14)
+    assert G._uncompressed_axis_slice(x, pre + (slice(0, 50, 2),)) is None and G._uncompressed_axis_slice(x, pre + (3,)) is None
+    e = sp.GCXS(sp.COO.from_numpy(np.zeros((20, 30))), compressed_axes=ca)
+    assert e[pre + (slice(2, 9),)].nnz == 0
