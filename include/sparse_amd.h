@@ -328,9 +328,13 @@ int spamd_union_positions(int64_t na, const int64_t* ka, const int64_t* posB, in
                           int64_t* slotB, int64_t* out_keys, void* stream);
 int spamd_fill(int elem_bytes, int64_t n, void* out, uint64_t value_bits, void* stream);
 /* out[i] = a[i] (op) b[i]; *_is_scalar broadcasts a 1-element device array.
- * op: 0 add 1 sub 2 mul 3 div 4 maximum 5 minimum 6 power 7 fmax 8 fmin (out dtype = val_dtype);
+ * op: 0 add 1 sub 2 mul 3 div 4 maximum 5 minimum 6 power 7 fmax 8 fmin 9 floor_divide 10 remainder 11 fmod (floats: NumPy's
+ *     npy_divmod / npy_remainder statement for statement; integers: Python's floor rules, x // 0 = x % 0 = 0) 12 copysign
+ *     13 hypot 14 arctan2 (12-14: F32 | F64 only) (out dtype = val_dtype);
  *     32 gt 33 ge 34 lt 35 le 36 eq 37 ne 38 logical_and 39 logical_or 40 logical_xor (out U8);
- *     64 bitwise_and 65 bitwise_or 66 bitwise_xor (integer dtypes).  No FMA contraction. */
+ *     64 bitwise_and 65 bitwise_or 66 bitwise_xor 67 left_shift 68 right_shift (integer dtypes; shift counts outside
+ *     [0, bits) give 0 / the sign, as NumPy's).  No FMA contraction.  (reference: the ufunc itself, applied by
+ *     `_elemwise_n_ary` sparse/numba_backend/_umath.py:420-470 to matched value arrays) */
 int spamd_ewise_binary(int op, int val_dtype, int64_t n, const void* a, int a_is_scalar, const void* b,
                        int b_is_scalar, void* out, void* stream);
 /* out[i] = f(a[i]); op: 0 negative 1 abs 2 sqrt 3 exp 4 expm1 5 log 6 log1p 7 sin 8 cos 9 tan 10 tanh
@@ -348,7 +352,7 @@ int spamd_ewise_select(int elem_bytes, int64_t n, const void* mask_u8, const voi
  *   spamd_merge_union(fill=0, ...) -> counts[nblocks]; host: exclusive scan -> offsets, total;
  *   spamd_merge_union(fill=1, ...) -> out_keys[total] (strictly increasing), out_vals[total].
  *   out = func(a or fill_a, b or fill_b); entries bit-identical to fill_out are dropped.
- *   op codes as spamd_ewise_binary (6 = power is not available here); *_bits = raw bit patterns
+ *   op codes as spamd_ewise_binary (6 = power and 9-14, 67, 68 are not available here); *_bits = raw bit patterns
  *   of the fill values in val_dtype (fill_out in the output dtype: U8 for ops 32..40). */
 int64_t spamd_merge_num_blocks(int64_t na, int64_t nb);
 int spamd_merge_partition(int64_t na, const int64_t* ka, int64_t nb, const int64_t* kb, int64_t* part,

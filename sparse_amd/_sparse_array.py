@@ -287,6 +287,16 @@ class SparseArray:
         return np.conj(self)
 
     def round(self, decimals=0, out=None):
+        if out is None and isinstance(decimals, (int, np.integer)) and not isinstance(decimals, (bool, np.bool_)) \
+                and np.dtype(self.dtype) in (np.dtype("f4"), np.dtype("f8")) and abs(int(decimals)) <= 15:
+            # NumPy's own recipe (PyArray_Round: multiply by 10^d, rint, divide - the other way round for d < 0) as three
+            # device passes over the stored values; `np.round` as ONE function with a keyword has no kernel and was evaluated
+            # on the host: 114 ms at 10^7 stored elements against 0.5 (tools/r06/bcast_sparse_sweep.py)
+            d = int(decimals)
+            if d == 0:
+                return np.rint(self)
+            m = float(10 ** abs(d))
+            return np.rint(self * m) / m if d > 0 else np.rint(self / m) * m
         if out is not None and not isinstance(out, tuple):
             out = (out,)
         return self.__array_ufunc__(np.round, "__call__", self, decimals=decimals, out=out)
@@ -296,6 +306,12 @@ class SparseArray:
     def clip(self, min=None, max=None, out=None):
         if min is None and max is None:
             raise ValueError("One of max or min must be given.")
+        scalar = lambda v: v is None or (isinstance(v, (int, float, np.integer, np.floating)) and not isinstance(v, (bool, np.bool_)))
+        if out is None and scalar(min) and scalar(max) and np.dtype(self.dtype).kind in "fiu":
+            # np.clip(a, lo, hi) is minimum(maximum(a, lo), hi) - NaNs of `a` pass through both -: two device ufuncs instead
+            # of a host evaluation of the three-argument function (93 ms at 10^7 stored elements against 0.4)
+            r = self if min is None else np.maximum(self, min)
+            return r if max is None else np.minimum(r, max)
         if out is not None and not isinstance(out, tuple):
             out = (out,)
         return self.__array_ufunc__(np.clip, "__call__", self, a_min=min, a_max=max, out=out)

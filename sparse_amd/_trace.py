@@ -22,9 +22,10 @@ from . import _ffi
 from . import _kernels as K
 from ._device import ptr, require_hip, stream_ptr, torch_dtype
 
-_ARITH = {"add", "subtract", "multiply", "true_divide", "divide", "maximum", "minimum", "fmax", "fmin"}
+_ARITH = {"add", "subtract", "multiply", "true_divide", "divide", "maximum", "minimum", "fmax", "fmin",
+          "floor_divide", "remainder", "fmod", "copysign"}      # (the last four: NumPy's own rules in the kernel, bit for bit)
 _TO_BOOL = {"greater", "greater_equal", "less", "less_equal", "equal", "not_equal", "logical_and", "logical_or", "logical_xor"}
-_BITWISE = {"bitwise_and", "bitwise_or", "bitwise_xor"}
+_BITWISE = {"bitwise_and", "bitwise_or", "bitwise_xor", "left_shift", "right_shift"}
 _UNARY = {"negative": "negative", "absolute": "absolute", "fabs": "absolute", "positive": "positive",
           "logical_not": "logical_not", "square": None}
 _DTYPES = {np.dtype("float32"), np.dtype("float64"), np.dtype("int32"), np.dtype("int64"), np.dtype("bool")}

@@ -23,7 +23,15 @@ from ._device import ptr, require_hip, stream_ptr, torch_dtype
 _BIN = {"add": 0, "subtract": 1, "multiply": 2, "divide": 3, "true_divide": 3, "maximum": 4, "minimum": 5,
         "power": 6, "fmax": 7, "fmin": 8, "greater": 32, "greater_equal": 33, "less": 34, "less_equal": 35,
         "equal": 36, "not_equal": 37, "logical_and": 38, "logical_or": 39, "logical_xor": 40,
-        "bitwise_and": 64, "bitwise_or": 65, "bitwise_xor": 66}
+        "bitwise_and": 64, "bitwise_or": 65, "bitwise_xor": 66,
+        # late round 6 (tools/r06/ufunc_sweep.py: 70-290 ms per call on the host at 10^7 stored elements): value kernels only,
+        # not in the fused merge (`_UNFUSED`)
+        "float_power": 6, "floor_divide": 9, "remainder": 10, "mod": 10, "fmod": 11, "copysign": 12, "hypot": 13, "arctan2": 14,
+        "left_shift": 67, "right_shift": 68}
+_UNFUSED = {6, 9, 10, 11, 12, 13, 14, 67, 68}       # ops csrc/merge.hip does not evaluate: union first, then the value kernel
+_F = (np.dtype("f4"), np.dtype("f8"))
+_FI = _F + (np.dtype("i4"), np.dtype("i8"))
+_COMP_TYPES = {9: _FI, 10: _FI, 11: _FI, 12: _F, 13: _F, 14: _F, 67: _FI[2:], 68: _FI[2:]}      # compute types of the late ops
 _UN = {"negative": 0, "absolute": 1, "abs": 1, "fabs": 1, "sqrt": 2, "exp": 3, "expm1": 4, "log": 5, "log1p": 6,
        "sin": 7, "cos": 8, "tan": 9, "tanh": 10, "sinh": 11, "cosh": 12, "arcsin": 13, "arctan": 14, "floor": 15,
        "ceil": 16, "rint": 17, "trunc": 18, "sign": 19, "square": 20, "reciprocal": 21, "positive": 22, "log2": 23,
@@ -754,6 +762,18 @@ def elemwise(func, *args, **kwargs):
             kwargs.pop("casting", None)
             fill = np.asarray(x.fill_value).astype(target)[()]
             return finish(x.linear_loc(), K.convert(x.data, torch_dtype(target)), shape, fill, devi)
+        if func is np.invert and not kwargs and dtype_kw is None and x.data.dtype in (torch.int32, torch.int64, torch.bool):
+            # ~x: the integers' bits flipped (x ^ -1), a boolean's negation - no kernel of its own, and as a function without
+            # one it was evaluated on the host (69 ms at 10^7 stored elements)
+            fill = _np_result(func, np.asarray(x.fill_value))[()]
+            if x.data.dtype == torch.bool:
+                res = unary_array("logical_not", x.data)
+            else:
+                res = binary_arrays("bitwise_xor", x.data.contiguous(), torch.tensor([-1], dtype=x.data.dtype, device=devi), b_scalar=True)
+            return finish(x.linear_loc(), res, shape, fill, devi)
+        if func is np.imag and not kwargs and dtype_kw is None and x.data.dtype in _CODE:
+            # the imaginary part of a real array: no stored elements, fill 0 of the array's type
+            return finish(x.linear_loc()[:0], x.data[:0], shape, _np_result(func, np.asarray(x.fill_value))[()], devi)
         if name not in _UN or kwargs or x.data.dtype not in _CODE:   # (complex / narrow value types: host-evaluated func)
             return _elemwise_general(func, proc, kwargs, dtype_kw, finish)
         fill = _np_result(func, np.asarray(x.fill_value))[()]
@@ -817,7 +837,8 @@ def elemwise(func, *args, **kwargs):
         # NumPy's boolean arithmetic is logical (True + True is True): never a raw uint8 add on the 0/1 bytes
         name = _BOOL_ARITH[name]
         code = _BIN[name]
-    if comp_np not in (np.dtype("f4"), np.dtype("f8"), np.dtype("i4"), np.dtype("i8"), np.dtype("bool"), np.dtype("u1")):
+    if comp_np not in (np.dtype("f4"), np.dtype("f8"), np.dtype("i4"), np.dtype("i8"), np.dtype("bool"), np.dtype("u1")) \
+            or comp_np not in _COMP_TYPES.get(code, (comp_np,)) or (code in _COMP_TYPES and code < 32 and out_np != comp_np):
         return _elemwise_general(func, proc, kwargs, dtype_kw, finish)
     comp_t = torch_dtype(comp_np)
 
@@ -924,7 +945,7 @@ def elemwise(func, *args, **kwargs):
         return finish(a.linear_loc(), K.convert(a.data, torch_dtype(out_np)), shape, fill, devi)
     ad, bd = K.convert(a.data, comp_t), K.convert(b.data, comp_t)
     fa, fb = np.asarray(a.fill_value).astype(comp_np), np.asarray(b.fill_value).astype(comp_np)
-    if code != 6 and (torch_dtype(out_np) == comp_t or code in _TO_BOOL_BIN):
+    if code not in _UNFUSED and (torch_dtype(out_np) == comp_t or code in _TO_BOOL_BIN):
         # default: one fused merge-path pass (function + prune inside the kernel)
         fill_in_kernel = fill if code not in _TO_BOOL_BIN else np.uint8(bool(fill))
         if pkey is not None:

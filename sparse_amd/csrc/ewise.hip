@@ -83,9 +83,41 @@ __global__ void __launch_bounds__(256) fill_kernel(U* __restrict__ out, int64_t 
 // ---- arithmetic -------------------------------------------------------------------------------
 enum BinOp {
   B_ADD = 0, B_SUB, B_MUL, B_DIV, B_MAX, B_MIN, B_POW, B_FMAX, B_FMIN,       // T -> T
+  B_FLOORDIV, B_REM, B_FMOD, B_COPYSIGN, B_HYPOT, B_ARCTAN2,                  // T -> T (late round 6; the last three: floats)
   B_GT = 32, B_GE, B_LT, B_LE, B_EQ, B_NE, B_LAND, B_LOR, B_LXOR,            // T -> u8
-  B_BAND = 64, B_BOR, B_BXOR                                                  // int -> int
+  B_BAND = 64, B_BOR, B_BXOR, B_LSHIFT, B_RSHIFT                              // int -> int
 };
+
+// np.floor_divide / np.remainder of floats: NumPy's `npy_divmod` (numpy/_core/src/npymath/npy_math_internal.h.src), statement
+// for statement - fmod is exact, so the results are NumPy's bit for bit
+template <typename T>
+__device__ __forceinline__ void np_divmod(T a, T b, T* floordiv, T* modulus) {
+#pragma clang fp contract(off)
+  T mod = fmod(a, b);
+  if (b == T(0)) {             // (not NaN: b == 0 exactly) - fmod gave NaN, the quotient is a / b
+    *modulus = mod;
+    *floordiv = a / b;
+    return;
+  }
+  T div = (a - mod) / b;
+  if (mod != T(0)) {
+    if ((b < T(0)) != (mod < T(0))) {
+      mod += b;
+      div -= T(1);
+    }
+  } else {
+    mod = copysign(T(0), b);
+  }
+  T fd;
+  if (div != T(0)) {
+    fd = floor(div);
+    if (div - fd > T(0.5)) fd += T(1);
+  } else {
+    fd = copysign(T(0), a / b);
+  }
+  *floordiv = fd;
+  *modulus = mod;
+}
 
 template <typename T>
 __device__ __forceinline__ T np_max(T a, T b) {
@@ -116,6 +148,44 @@ __device__ __forceinline__ T bin_tt(int op, T a, T b) {
     case B_FMIN:
       if constexpr (std::is_floating_point<T>::value) return (a != a) ? b : ((b != b) ? a : (a < b ? a : b));
       else return a < b ? a : b;
+    case B_FLOORDIV:
+      if constexpr (std::is_floating_point<T>::value) {
+        T q, r;
+        np_divmod<T>(a, b, &q, &r);
+        return q;
+      } else {      // Python's floor division; x // 0 = 0 (NumPy warns and stores 0), MIN // -1 wraps
+        if (b == 0) return T(0);
+        if (b == T(-1)) return (T)(T(0) - a);
+        const T q = a / b;
+        return ((a % b != 0) && ((a < 0) != (b < 0))) ? (T)(q - 1) : q;
+      }
+    case B_REM:
+      if constexpr (std::is_floating_point<T>::value) {
+        T mod = fmod(a, b);       // `npy_remainder`
+        if (b == T(0)) return mod;
+        if (mod != T(0)) {
+          if ((b < T(0)) != (mod < T(0))) mod += b;
+        } else {
+          mod = copysign(T(0), b);
+        }
+        return mod;
+      } else {
+        if (b == 0 || b == T(-1)) return T(0);
+        const T r = a % b;
+        return (r != 0 && ((r < 0) != (b < 0))) ? (T)(r + b) : r;
+      }
+    case B_FMOD:
+      if constexpr (std::is_floating_point<T>::value) return fmod(a, b);
+      else return (b == 0 || b == T(-1)) ? T(0) : (T)(a % b);
+    case B_COPYSIGN:
+      if constexpr (std::is_floating_point<T>::value) return copysign(a, b);
+      else return a;
+    case B_HYPOT:
+      if constexpr (std::is_floating_point<T>::value) return hypot(a, b);
+      else return a;
+    case B_ARCTAN2:
+      if constexpr (std::is_floating_point<T>::value) return atan2(a, b);
+      else return a;
     case B_POW:
       if constexpr (std::is_same<T, float>::value) return powf(a, b);
       else if constexpr (std::is_same<T, double>::value) return pow(a, b);
@@ -155,7 +225,16 @@ __global__ void __launch_bounds__(256) binary_tt_kernel(int op, const T* __restr
   GRID_STRIDE(i, n) {
     const T x = a[i * a_stride], y = b[i * b_stride];
     if (op >= B_BAND) {
-      if constexpr (std::is_integral<T>::value) out[i] = op == B_BAND ? (x & y) : (op == B_BOR ? (x | y) : (x ^ y));
+      if constexpr (std::is_integral<T>::value) {
+        using U = typename std::make_unsigned<T>::type;
+        constexpr unsigned long long BITS = sizeof(T) * 8;
+        if (op == B_LSHIFT)        // `npy_lshift`: counts outside [0, bits) give 0
+          out[i] = (unsigned long long)y < BITS ? (T)((U)x << (unsigned)y) : T(0);
+        else if (op == B_RSHIFT)   // `npy_rshift`: ... give the sign
+          out[i] = (unsigned long long)y < BITS ? (T)(x >> (unsigned)y) : (x < 0 ? T(-1) : T(0));
+        else
+          out[i] = op == B_BAND ? (x & y) : (op == B_BOR ? (x | y) : (x ^ y));
+      }
     } else {
       out[i] = bin_tt<T>(op, x, y);
     }
@@ -384,6 +463,8 @@ extern "C" int spamd_ewise_binary(int op, int val_dtype, int64_t n, const void* 
   const int as = a_is_scalar ? 0 : 1, bs = b_is_scalar ? 0 : 1;
   const bool to_bool = op >= B_GT && op < B_BAND;
   if (op >= B_BAND && (val_dtype == SPAMD_F32 || val_dtype == SPAMD_F64)) return SPAMD_ETYPE;
+  if (op >= B_COPYSIGN && op <= B_ARCTAN2 && val_dtype != SPAMD_F32 && val_dtype != SPAMD_F64) return SPAMD_ETYPE;
+  if ((op > B_ARCTAN2 && op < B_GT) || op > B_RSHIFT || op < 0) return SPAMD_EINVAL;
   VAL_SWITCH5(val_dtype, T, {
     if (to_bool)
       hipLaunchKernelGGL(binary_tb_kernel<T>, dim3(grid_for(n)), dim3(256), 0, s, op, (const T*)a, as, (const T*)b, bs,

@@ -735,3 +735,125 @@ def test_gcxs_slices_along_its_uncompressed_axis_without_a_coo(ca, idt):
     assert G._uncompressed_axis_slice(x, pre + (slice(0, 50, 2),)) is None and G._uncompressed_axis_slice(x, pre + (3,)) is None
     e = sp.GCXS(sp.COO.from_numpy(np.zeros((20, 30))), compressed_axes=ca)
     assert e[pre + (slice(2, 9),)].nnz == 0
+
+
+@pytest.mark.parametrize("fmt", ["coo", "gcxs"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32, np.int32])
+def test_round_and_clip_stay_on_the_device(fmt, dtype):
+    """`x.round(d)` = NumPy's own multiply / rint / divide recipe and `x.clip(lo, hi)` = minimum(maximum(x, lo), hi) as device
+    ufuncs: the values, dtypes and fill values NumPy gives on the dense twin (bit for bit), no host evaluation."""
+    import sparse_amd as sp
+
+    rng = np.random.default_rng(6)
+    d = ((rng.random((300, 200)) * 200 - 100) * (rng.random((300, 200)) < 0.2)).astype(dtype)
+    if np.dtype(dtype).kind == "f":
+        d[3, 4] = np.nan
+    x = sp.asarray(d, format=fmt) if fmt == "gcxs" else sp.COO.from_numpy(d)
+    counts = lambda: {k: v for k, v in sp.fallback_stats().items() if k != "recent"}
+    before = counts()
+    if np.dtype(dtype).kind == "f":
+        for dec in (0, 1, 2, 5, -1, -2):
+            got = x.round(dec)
+            want = np.round(d, dec)
+            assert got.dtype == want.dtype and np.array_equal(got.todense(), want, equal_nan=True), dec
+    for lo, hi in ((-10, 20), (0.5, 30.25), (None, 5), (-3.5, None), (2, 1000), (-1000, -2)):
+        got = x.clip(lo, hi)
+        want = np.clip(d, lo, hi)
+        assert got.dtype == want.dtype, (lo, hi, got.dtype, want.dtype)
+        assert np.array_equal(got.todense(), want, equal_nan=True), (lo, hi)
+        assert got.nnz <= d.size
+    assert counts() == before
+    with pytest.raises(ValueError):
+        x.clip()
+
+
+_LATE_OPS = ["floor_divide", "remainder", "fmod", "copysign", "hypot", "arctan2", "left_shift", "right_shift"]
+
+
+@pytest.mark.parametrize("name", _LATE_OPS)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32, np.int64, np.int32])
+def test_late_binary_ufuncs_on_the_device(name, dtype):
+    """floor_divide / remainder / fmod (NumPy's npy_divmod rules for floats, Python's floor rules for integers), copysign, the
+    shifts (bit for bit) and hypot / arctan2 (to 4 ulp) between two sparse arrays, with a scalar on either side, through the
+    operators (`//`, `%`, `<<`, `>>`) and inside a traced lambda: NumPy's values, dtypes and fill values on the dense twins,
+    zeros and negative operands included; no host evaluation."""
+    import warnings
+
+    import sparse_amd as sp
+
+    f = getattr(np, name)
+    kind = np.dtype(dtype).kind
+    if name in ("left_shift", "right_shift") and kind == "f":
+        pytest.skip("integer ufunc")
+    rng = np.random.default_rng(7)
+    shape = (120, 90)
+    def draw():
+        v = rng.integers(-40, 41, size=shape) if kind == "i" else np.round(rng.random(shape) * 80 - 40, 2)
+        return (v * (rng.random(shape) < 0.3)).astype(dtype)
+    da, db = draw(), draw()
+    if name in ("left_shift", "right_shift"):
+        db = np.abs(db) % 70            # (counts beyond the width included)
+        db[0, :4] = [-1, 31, 32, 64]
+    a, b = sp.COO.from_numpy(da), sp.COO.from_numpy(db)
+    exact = name not in ("hypot", "arctan2")
+
+    def same(got, want):
+        gd = got.todense() if hasattr(got, "todense") else np.asarray(got)
+        assert gd.dtype == want.dtype, (gd.dtype, want.dtype)
+        if exact:
+            assert np.array_equal(gd, want, equal_nan=True)
+            if want.dtype.kind == "f":
+                ok = ~np.isnan(want)          # (the sign of a NaN is the platform's: x86 fmod(x, 0) sets it, the device does not)
+                assert np.array_equal(np.signbit(gd)[ok], np.signbit(want)[ok])
+        else:
+            np.testing.assert_allclose(gd, want, rtol=1e-6 if want.dtype == np.float32 else 1e-15, atol=0)
+        fv = np.asarray(got.fill_value)
+        assert fv.dtype == want.dtype
+
+    counts = lambda: {k: v for k, v in sp.fallback_stats().items() if k != "recent"}
+    before = counts()
+    with warnings.catch_warnings(), np.errstate(all="ignore"):
+        warnings.simplefilter("ignore")
+        same(f(a, b), f(da, db))
+        sc = 3 if kind == "i" or name.endswith("shift") else 2.5
+        same(f(a, sc), f(da, sc))
+        same(f(sc, b), f(sc, db))
+        if name == "floor_divide":
+            same(a // b, da // db)
+            same(a // sc, da // sc)
+            same(sp.elemwise(lambda p, q: p // q + p, a, b), da // db + da)
+        if name == "remainder":
+            same(a % b, da % db)
+            same(a % sc, da % sc)
+            same(np.mod(a, -sc), np.mod(da, -sc))
+        if name == "left_shift":
+            same(a << 2, da << 2)
+        if name == "right_shift":
+            same(a >> 2, da >> 2)
+        g = sp.GCXS(a), sp.GCXS(b)
+        same(f(g[0], g[1]), f(da, db))
+    assert counts() == before
+
+
+def test_invert_imag_and_float_power_stay_on_the_device():
+    import sparse_amd as sp
+
+    rng = np.random.default_rng(9)
+    d = (rng.integers(-50, 50, size=(80, 70)) * (rng.random((80, 70)) < 0.3)).astype(np.int32)
+    counts = lambda: {k: v for k, v in sp.fallback_stats().items() if k != "recent"}
+    before = counts()
+    for arr in (d, d.astype(np.int64), d != 0):
+        x = sp.COO.from_numpy(arr)
+        got = ~x
+        want = ~arr
+        assert got.dtype == want.dtype and np.array_equal(got.todense(), want) and got.fill_value == want.dtype.type(~arr.dtype.type(0))
+        assert np.array_equal(np.invert(sp.GCXS(x)).todense(), want)
+    f = sp.COO.from_numpy(d.astype(np.float64) / 7)
+    im = f.imag
+    assert im.nnz == 0 and im.dtype == np.float64 and im.shape == f.shape and not im.todense().any()
+    assert np.array_equal(f.real.todense(), d.astype(np.float64) / 7)
+    fp = np.float_power(sp.COO.from_numpy(np.abs(d).astype(np.float32)), 1.5)
+    want = np.float_power(np.abs(d).astype(np.float32), 1.5)
+    assert fp.dtype == want.dtype
+    np.testing.assert_allclose(fp.todense(), want, rtol=1e-14)
+    assert counts() == before
