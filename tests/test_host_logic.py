@@ -303,7 +303,9 @@ def test_elemwise_tracer_records_numpys_own_dtypes_and_refuses_what_is_not_exact
     assert dt(lambda a: a.astype(np.float32) * 2, A(i64)) == f32
     assert dt(lambda a: np.sin(a) ** 2, A(f64)) is None                          # not bit-identical on the device
     assert dt(lambda a: a ** 3, A(f64)) is None
-    assert dt(lambda a: a // 2, A(i64)) is None
+    assert dt(lambda a: a // 2, A(i64)) == i64 and dt(lambda a, b: a % b, A(f32), A(f64)) == f64      # (late round 6: NumPy's divmod rules in the kernel)
+    assert dt(lambda a: a << 2, A(i32)) == i32 and dt(lambda a, b: np.copysign(a, b), A(i32), A(f32)) == f64
+    assert dt(lambda a, b: np.hypot(a, b), A(f64), A(f64)) is None and dt(lambda a: np.gcd(a, 6), A(i64)) is None
     assert dt(lambda a: np.clip(a, 0, 1), A(f64)) is None
     assert dt(lambda a: a if a > 0 else -a, A(f64)) is None                       # data-dependent control flow
     assert dt(lambda a: a + 1, A(np.dtype("f2"))) is None and dt(lambda a: a + 1j, A(f64)) is None
