@@ -705,7 +705,8 @@ HOT_ROW_SPLIT = True
 HOT_ROW_MIN = 4096            # stored elements from which a row is "hot" (one wave walks a row at ~27-120 ns per element)
 HOT_ROW_MIN_STREAM = 32768    # ... for the widths the stream kernel takes: it deals a row of 10^4 elements to its waves by
                               # itself (0.05 ms against 0.13-0.18 in two parts), a row of 10^5 costs it 0.37 ms against 0.13
-HOT_ROW_MIN_NNZ = 1 << 16     # operands with fewer stored elements are not probed
+HOT_ROW_MIN_NNZ = 1 << 14     # operands with fewer stored elements are not probed (two small kernels and a read, ~40 us once
+                              # per operand; a row of 49 000 elements in a 1 x K operand: 5.6 ms at 16 columns unsplit)
 HOT_ROWS_MAX = 1024           # more hot rows than this: the matrix simply has long rows, nothing is split
 HOT_PIECE_GROUPS = 1024       # row groups (of 35 rows) the pieces of the hot rows should fill
 HOT_COMBINE_FAN = 128         # pieces a thread of the combine kernel adds in one loop
@@ -725,7 +726,7 @@ def _hot_row_split(a, data, indices, indptr):
     res = None
     M = int(indptr.numel()) - 1
     nnz = int(data.numel())
-    if nnz >= HOT_ROW_MIN_NNZ and M >= 2 and not a.__dict__.get("_no_hot_split") and indptr.dtype in (torch.int32, torch.int64):
+    if nnz >= HOT_ROW_MIN_NNZ and M >= 1 and not a.__dict__.get("_no_hot_split") and indptr.dtype in (torch.int32, torch.int64):
         lens = binary_arrays("subtract", indptr[1:].clone(), indptr[:-1].contiguous())     # (the clone: an aligned start)
         longest = int(reduce_all(lens, "maximum")[1])
         if longest >= HOT_ROW_MIN:

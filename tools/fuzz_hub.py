@@ -20,7 +20,7 @@ g = torch.Generator(device="cuda").manual_seed(seed)
 cases = fails = splits = 0
 t_end = time.time() + budget
 while time.time() < t_end:
-    M = int(rng.choice([2, 50, 1000, 40_000, 300_000]))
+    M = int(rng.choice([1, 2, 50, 1000, 40_000, 300_000]))
     Kd = int(rng.choice([4096, 5000, 20_000, 70_000, 300_000]))
     per = float(rng.choice([0.0, 0.5, 3, 20]))
     nb = int(min(M * per, 3_000_000))
