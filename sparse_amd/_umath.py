@@ -80,8 +80,16 @@ def select(mask, a, b):
     """where(mask, a, b) on device arrays, built from flag/compact primitives: scatter-free form
     out = b; out[mask] = a[mask]."""
     devi = require_hip(mask, a, b)
-    out = b.clone()
     m = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
+    if m.dtype == torch.uint8 and a.dtype == b.dtype and a.element_size() in (1, 4, 8) and a.numel() == b.numel() == m.numel():
+        # one pass (`spamd_ewise_select`: 0/1 mask bytes, values moved bit-wise) instead of clone + flags + scan + iota +
+        # compact + gather + scatter with a host read in the middle (late round 6: where(x > 0.5, x, 0) at 10^7 stored
+        # elements 1.51 ms, half of it here)
+        out = torch.empty_like(b.contiguous())
+        _ffi.call("spamd_ewise_select", out.element_size(), int(out.numel()), ptr(m.contiguous()), ptr(a.contiguous()), 0,
+                  ptr(b.contiguous()), 0, ptr(out), stream_ptr(devi))
+        return out
+    out = b.clone()
     flags = K.flag_ne_bits(m, 0)
     offs = K.exclusive_scan(flags)
     cnt = int(offs[-1])
