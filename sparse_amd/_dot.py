@@ -712,6 +712,33 @@ HOT_PIECE_GROUPS = 1024       # row groups (of 35 rows) the pieces of the hot ro
 HOT_COMBINE_FAN = 128         # pieces a thread of the combine kernel adds in one loop
 
 
+def hot_piece_plan(p0, p1, groups=None, fan=None):
+    """Host arithmetic of the hub-row split, from the hot rows' element ranges [p0[h], p1[h]) alone:
+    (vptr, vfirst, g1) - `vptr` = row pointers of the piece matrix over the hot rows' elements laid end to end (pieces of one
+    size, 32 .. 4096 elements and a multiple of 32, chosen so that all pieces fill `groups` row groups of 35 rows; a row's
+    last piece may be shorter), `vfirst[h]` = first combine input of hot row h, `g1` = None or, when a row has more than `fan`
+    pieces (a thread of the combine kernel adds its inputs one after the other: 31 250 pieces in one loop took 6.8 ms), the
+    first piece of every group of at most `fan` pieces of one row - `vfirst` then counts those groups."""
+    groups = groups or HOT_PIECE_GROUPS
+    fan = fan or HOT_COMBINE_FAN
+    lens = np.asarray(p1, dtype=np.int64) - np.asarray(p0, dtype=np.int64)
+    total = int(lens.sum())
+    piece = int(min(4096, max(32, total // (groups * 35) // 32 * 32)))
+    vptr, vfirst, base = [0], [0], 0
+    for n in lens.tolist():
+        vptr.extend((base + np.minimum(np.arange(piece, n + piece, piece), n)).tolist())
+        vfirst.append(len(vptr) - 1)
+        base += n
+    g1 = None
+    if max(b - a_ for a_, b in zip(vfirst[:-1], vfirst[1:])) > fan:
+        g1, f2 = [0], [0]
+        for a_, b in zip(vfirst[:-1], vfirst[1:]):
+            g1.extend(min(s0 + fan, b) for s0 in range(a_, b, fan))
+            f2.append(len(g1) - 1)
+        vfirst, g1 = f2, np.asarray(g1, dtype=np.int64)
+    return np.asarray(vptr, dtype=np.int64), np.asarray(vfirst, dtype=np.int64), g1
+
+
 def _hot_row_split(a, data, indices, indptr):
     """None, or what `_gcxs_times_dense` needs to multiply an operand with a few hub rows in two parts (csrc/hot_rows.hip):
     (the matrix without its hot rows, the hot rows cut into pieces that are rows of their own, first piece of every hot row,
@@ -753,31 +780,16 @@ def _hot_row_split(a, data, indices, indptr):
                 light = GCXS((cat(data, keep), cat(indices, keep), (p64 - removed).to(indptr.dtype)), shape=(M, int(a.shape[1])),
                              compressed_axes=(0,), fill_value=a.fill_value)
                 # the hot rows in pieces: enough of them to fill the chip, each a row of a (pieces x K) matrix
-                total = int((p1 - p0).sum())
-                piece = int(min(4096, max(32, total // (HOT_PIECE_GROUPS * 35) // 32 * 32)))
-                hot_spans = [(int(s), int(e)) for s, e in zip(p0, p1)]
-                vptr, vfirst, base = [0], [0], 0
-                for s, e in hot_spans:
-                    n = e - s
-                    vptr.extend(base + np.minimum(np.arange(piece, n + piece, piece), n))
-                    vfirst.append(len(vptr) - 1)
-                    base += n
+                hot_spans = [(int(s0), int(e0)) for s0, e0 in zip(p0, p1)]
+                vptr, vfirst, g1 = hot_piece_plan(p0, p1)
                 hotv = GCXS((cat(data, hot_spans), cat(indices, hot_spans),
-                             torch.tensor(np.asarray(vptr, dtype=np.int64), device=devi).to(indptr.dtype)),
+                             torch.tensor(vptr, device=devi).to(indptr.dtype)),
                             shape=(len(vptr) - 1, int(a.shape[1])), compressed_axes=(0,), fill_value=a.fill_value)
                 light.__dict__["_no_hot_split"] = hotv.__dict__["_no_hot_split"] = True
-                # a thread of the combine kernel adds the pieces of its row one after the other: rows of more than
-                # HOT_COMBINE_FAN pieces are added in two levels (31 250 pieces in one loop: 6.8 ms)
                 mid = None
-                if max(b - a_ for a_, b in zip(vfirst[:-1], vfirst[1:])) > HOT_COMBINE_FAN:
-                    g1, f2 = [0], [0]
-                    for a_, b in zip(vfirst[:-1], vfirst[1:]):
-                        g1.extend(min(s0 + HOT_COMBINE_FAN, b) for s0 in range(a_, b, HOT_COMBINE_FAN))
-                        f2.append(len(g1) - 1)
-                    mid = (torch.tensor(np.asarray(g1, dtype=np.int64), device=devi),
-                           torch.arange(len(g1) - 1, dtype=torch.int64, device=devi))
-                    vfirst = f2
-                res = (light, hotv, torch.tensor(np.asarray(vfirst, dtype=np.int64), device=devi), rows, mid, longest)
+                if g1 is not None:
+                    mid = (torch.tensor(g1, device=devi), torch.arange(len(g1) - 1, dtype=torch.int64, device=devi))
+                res = (light, hotv, torch.tensor(vfirst, device=devi), rows, mid, longest)
     a.__dict__["_hot_split"] = res
     return res
 

@@ -423,3 +423,38 @@ def test_gcxs_index_width_follows_the_number_of_stored_elements():
     assert unified_index_dtype(torch.int32, 2 ** 31 - 1) == torch.int32
     assert unified_index_dtype(torch.int32, 2 ** 31) == torch.int64
     assert unified_index_dtype(torch.int64, 5) == torch.int64
+
+
+def test_hub_row_piece_plan():
+    """`_dot.hot_piece_plan`: the pieces of the hot rows cover their elements exactly once and in order, no piece is longer
+    than the piece size (32 .. 4096, a multiple of 32) or crosses a row, and no combine loop is longer than the fan-in where
+    two levels are used."""
+    import numpy as np
+
+    from sparse_amd import _dot as D
+
+    rng = np.random.default_rng(0)
+    for case in range(200):
+        H = int(rng.integers(1, 40))
+        lens = rng.integers(4096, int(rng.choice([5000, 40_000, 2_000_000])), size=H)
+        gaps = rng.integers(0, 1000, size=H)
+        p0 = np.cumsum(gaps + np.concatenate(([0], lens[:-1])))
+        p1 = p0 + lens
+        vptr, vfirst, g1 = D.hot_piece_plan(p0, p1)
+        sizes = np.diff(vptr)
+        piece = int(sizes.max())
+        assert vptr[0] == 0 and vptr[-1] == lens.sum() and (sizes > 0).all()
+        assert 32 <= piece <= 4096 and piece % 32 == 0
+        ends = np.cumsum(lens)
+        assert np.isin(ends, vptr).all()                             # no piece crosses a hot row's end
+        pieces_per_row = np.diff(np.searchsorted(vptr, np.concatenate(([0], ends))))
+        assert (pieces_per_row == -(-lens // piece)).all()
+        if g1 is None:
+            assert pieces_per_row.max() <= D.HOT_COMBINE_FAN and (np.diff(vfirst) == pieces_per_row).all()
+        else:
+            assert pieces_per_row.max() > D.HOT_COMBINE_FAN
+            assert g1[0] == 0 and g1[-1] == len(vptr) - 1 and (np.diff(g1) > 0).all() and np.diff(g1).max() <= D.HOT_COMBINE_FAN
+            assert np.isin(np.searchsorted(vptr, ends), g1).all()    # a group never spans two rows
+            assert (np.diff(vfirst) == -(-pieces_per_row // D.HOT_COMBINE_FAN)).all() and vfirst[-1] == len(g1) - 1
+    v, f, g = D.hot_piece_plan([0], [4096])
+    assert v.tolist() == list(range(0, 4097, 32)) and f.tolist() == [0, 128] and g is None
