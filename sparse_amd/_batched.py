@@ -11,6 +11,7 @@ import torch
 from . import _ffi
 from . import _kernels as K
 from ._device import ptr, stream_ptr
+from ._utils import prod
 
 
 def _key_range(keys, lo_key, hi_key):
@@ -60,6 +61,9 @@ def _gcxs_result(out, nd_in, axis, compressed_axes):
     if nd_in == 1:
         return out
     return out.asformat("gcxs", compressed_axes=(axis,) if compressed_axes is None else compressed_axes)
+
+
+CONCAT_MERGE = True
 
 
 def _concatenate_compressed(arrays, axis, compressed_axes):
@@ -137,8 +141,32 @@ def concatenate(arrays, axis=0, compressed_axes=None):
         parts_c.append(cc)
         parts_d.append(K.convert(c.data, dt))
         off += c.shape[axis]
-    out = COO(torch.cat(parts_c, dim=1), torch.cat(parts_d), shape=shape, has_duplicates=False, sorted=(axis == 0),
-              fill_value=fv)
+    out = None
+    if axis != 0 and CONCAT_MERGE and len(coos) <= 8 and all(p.dtype == parts_d[0].dtype for p in parts_d) \
+            and parts_d[0].element_size() in (1, 4, 8) and prod(shape) < 2 ** 62:
+        # joined along an inner axis, every operand's elements keep their order among themselves (canonical operands, one
+        # coordinate shifted): the result is a MERGE of k sorted key arrays, not a sort of their concatenation (1.66 ms for two
+        # operands of 10^7 stored elements, `tools/r06/index_sweep.py`)
+        from ._umath import _as_u8, union_merge
+
+        keys, data = None, None
+        for cc, dd in zip(parts_c, parts_d):
+            if not cc.shape[1]:
+                continue
+            k = K.linearize(cc, shape)
+            if keys is None:
+                keys, data = k, dd
+                continue
+            keys, sa, sb = union_merge(keys, k)
+            nd = torch.empty(int(keys.numel()), dtype=dd.dtype, device=dev)
+            K.scatter_into(_as_u8(nd), sa, _as_u8(data.contiguous()))
+            K.scatter_into(_as_u8(nd), sb, _as_u8(dd.contiguous()))
+            data = nd
+        if keys is not None:
+            out = COO._from_sorted_keys(keys, data, shape, np.asarray(fv).astype(dt)[()], it)
+    if out is None:
+        out = COO(torch.cat(parts_c, dim=1), torch.cat(parts_d), shape=shape, has_duplicates=False, sorted=(axis == 0),
+                  fill_value=fv)
     return _gcxs_result(out, len(ref_shape), axis, compressed_axes) if all_gcxs else out
 
 

@@ -857,3 +857,38 @@ def test_invert_imag_and_float_power_stay_on_the_device():
     assert fp.dtype == want.dtype
     np.testing.assert_allclose(fp.todense(), want, rtol=1e-14)
     assert counts() == before
+
+
+@pytest.mark.parametrize("axis", [1, -1, 2])
+@pytest.mark.parametrize("fmt", ["coo", "gcxs"])
+def test_joining_along_an_inner_axis_merges_sorted_keys(axis, fmt):
+    """`concatenate` along an axis that is not the first: the operands' keys in the result's shape are merged, not sorted
+    (`_batched.CONCAT_MERGE`); NumPy's result on the dense twins, the same stored arrays as the sorting route; three operands of
+    mixed value types, one without stored elements, one of extent 0 along the axis; `stack` along the last axis."""
+    import sparse_amd as sp
+    from sparse_amd import _batched as B
+
+    rng = np.random.default_rng(21)
+    base = (6, 9, 11)
+    def make(ext, dtype, dens=0.3):
+        sh = list(base)
+        sh[axis] = ext
+        return (rng.random(sh) * (rng.random(sh) < dens)).astype(dtype)
+    ds = [make(5, np.float64), make(0, np.float64), make(7, np.float32), make(3, np.float64, 0.0), make(4, np.float64)]
+    xs = [sp.COO.from_numpy(d) if fmt == "coo" else sp.asarray(d, format="gcxs") for d in ds]
+    got = sp.concatenate(xs, axis=axis)
+    want = np.concatenate(ds, axis=axis)
+    assert got.shape == want.shape and got.dtype == want.dtype and np.array_equal(got.todense(), want)
+    B.CONCAT_MERGE = False
+    try:
+        ref = sp.concatenate(xs, axis=axis)
+    finally:
+        B.CONCAT_MERGE = True
+    gc, rc = (got.tocoo(), ref.tocoo()) if fmt == "gcxs" else (got, ref)
+    assert np.array_equal(gc.coords.cpu().numpy(), rc.coords.cpu().numpy()) and np.array_equal(gc.data.cpu().numpy(), rc.data.cpu().numpy())
+    assert gc.fill_value == rc.fill_value and np.asarray(gc.fill_value).dtype == np.asarray(rc.fill_value).dtype
+    b = [sp.COO.from_numpy(d != 0) for d in (ds[0], ds[4][:, :, :] if axis != 0 else ds[4])]
+    bb = sp.concatenate(b, axis=axis)
+    assert bb.dtype == bool and np.array_equal(bb.todense(), np.concatenate([ds[0] != 0, ds[4] != 0], axis=axis))
+    st = sp.stack([xs[0], xs[0] * 2], axis=-1)
+    assert np.array_equal(st.todense(), np.stack([ds[0], ds[0] * 2], axis=-1))
