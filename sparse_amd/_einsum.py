@@ -168,6 +168,11 @@ def _pair_by_tensordot(terms, out, arrays):
     for c in shared:
         if a.shape[ta.index(c)] != b.shape[tb.index(c)]:
             raise ValueError(f"Inconsistent shape for index '{c}'.")
+    if isinstance(a, SparseArray) and isinstance(b, SparseArray) and (len(shared) == len(ta) or len(shared) == len(tb)):
+        # a SPARSE operand that is contracted away entirely ("ij,ij->", "ijk,jk->i"): as a matrix it is one row (or one
+        # column) over the product of the contracted extents - 10^9 row pointers for two 10^5 x 10^4 operands, 929 ms - while
+        # the general route multiplies the aligned operands and sums (0.7 ms): late round 6, tools/r06/einsum_sweep.py
+        return None
     res = tensordot(a, b, axes=([ta.index(c) for c in shared], [tb.index(c) for c in shared]))
     # result format as the reference's broadcast-multiply route gives it: sparse, GCXS only if every sparse
     # operand is GCXS

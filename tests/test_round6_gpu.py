@@ -892,3 +892,24 @@ def test_joining_along_an_inner_axis_merges_sorted_keys(axis, fmt):
     assert bb.dtype == bool and np.array_equal(bb.todense(), np.concatenate([ds[0] != 0, ds[4] != 0], axis=axis))
     st = sp.stack([xs[0], xs[0] * 2], axis=-1)
     assert np.array_equal(st.todense(), np.stack([ds[0], ds[0] * 2], axis=-1))
+
+
+def test_einsum_with_a_sparse_operand_contracted_away():
+    """"ij,ij->" and "ijk,jk->i" between sparse operands: the operand that keeps no axis is not turned into a one-row matrix over
+    the product of the contracted extents (10^9 row pointers at 10^5 x 10^4); NumPy's einsum on the dense twins."""
+    import sparse_amd as sp
+
+    rng = np.random.default_rng(13)
+    a = rng.random((30, 40, 50)) * (rng.random((30, 40, 50)) < 0.1)
+    b = rng.random((40, 50)) * (rng.random((40, 50)) < 0.3)
+    c = rng.random((30, 40, 50)) * (rng.random((30, 40, 50)) < 0.1)
+    A, B, C = sp.COO.from_numpy(a), sp.COO.from_numpy(b), sp.COO.from_numpy(c)
+    for sub, ops, dense in (("ijk,ijk->", (A, C), (a, c)), ("ijk,jk->i", (A, B), (a, b)), ("jk,ijk->i", (B, A), (b, a)),
+                            ("ijk,jk->", (A, B), (a, b)), ("ijk,kj->i", (A, sp.COO.from_numpy(b.T.copy())), (a, b.T))):
+        got = sp.einsum(sub, *ops)
+        want = np.einsum(sub, *dense)
+        np.testing.assert_allclose(np.asarray(got.todense()), want, rtol=1e-12, atol=1e-14)
+    big = sp.random((100_000, 10_000), density=1e-4, random_state=3)
+    other = sp.random((100_000, 10_000), density=1e-4, random_state=4)
+    tot = sp.einsum("ij,ij->", big, other)
+    assert abs(float(tot.todense()) - float((big * other).sum())) < 1e-9
