@@ -913,3 +913,24 @@ def test_einsum_with_a_sparse_operand_contracted_away():
     other = sp.random((100_000, 10_000), density=1e-4, random_state=4)
     tot = sp.einsum("ij,ij->", big, other)
     assert abs(float(tot.todense()) - float((big * other).sum())) < 1e-9
+
+
+def test_tensordot_with_a_sparse_operand_contracted_away_over_a_wide_extent():
+    """`tensordot(x, y, axes=2)` and friends between sparse operands when one keeps no axis and the contracted extents multiply
+    to 2^22 or more: the aligned multiply + sum (einsum's general route), not a one-row matrix with that many row pointers."""
+    import sparse_amd as sp
+
+    x = sp.random((3000, 2000), density=2e-3, random_state=1)
+    y = sp.random((3000, 2000), density=2e-3, random_state=2)
+    want = float((x.todense() * y.todense()).sum())
+    for got in (sp.tensordot(x, y, axes=2), sp.tensordot(x, y, axes=([0, 1], [0, 1])), sp.tensordot(x, y.T, axes=([0, 1], [1, 0])),
+                sp.tensordot(x.asformat("gcxs"), y, axes=2)):
+        assert got.shape == () and abs(float(got.todense()) - want) < 1e-9
+    z = sp.random((4, 3000, 2000), density=1e-3, random_state=3)
+    zw = np.tensordot(z.todense(), y.todense(), axes=([1, 2], [0, 1]))
+    r = sp.tensordot(z, y, axes=([1, 2], [0, 1]))
+    assert r.shape == (4,) and np.allclose(r.todense(), zw, rtol=1e-12)
+    r2 = sp.tensordot(y, z, axes=([0, 1], [1, 2]))
+    assert r2.shape == (4,) and np.allclose(r2.todense(), zw, rtol=1e-12)
+    g = sp.tensordot(z.asformat("gcxs"), y.asformat("gcxs"), axes=([1, 2], [0, 1]))
+    assert isinstance(g, sp.GCXS) and np.allclose(g.todense(), zw, rtol=1e-12)
